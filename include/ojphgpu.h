@@ -1,0 +1,242 @@
+/* include/ojphgpu.h -- C ABI of the MI355X-native HTJ2K hot path (libojphgpu.so).
+ *
+ * This is the drop-in boundary for the hot path of aous72/OpenJPH 0.31.0: 5/3 + 9/7 DWT,
+ * quantise transfer and the HT block coder.  In the reference that path sits behind three
+ * per-line / per-block function-pointer tables
+ *     struct codeblock_fun            src/core/codestream/ojph_codeblock_fun.h:93-119
+ *     rev_/irv_ vert_step, horz_ana.. src/core/transform/ojph_transform.h:61-96
+ *     colour / convert pointers       src/core/transform/ojph_colour.h:53-103
+ * which are called once per image line or per code-block from resolution::push_line/pull_line
+ * (ojph_resolution.cpp:547,713), codeblock::push/encode/decode/pull_line (ojph_codeblock.cpp:
+ * 115-266) and tile::push/pull (ojph_tile.cpp:332-518).  A device round trip per line is not
+ * workable, so the same data contracts are exposed here *batched*: one call transforms every
+ * plane / codes every code-block of a frame, driven by descriptor tables that the host side
+ * (the plan) derives with the reference's geometry rules.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * OJPHGPU_E_* code and never throws.  Pointers named d_* are device (HBM) pointers, h_* are
+ * host pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ * device entry points are asynchronous on `stream`.
+ */
+#ifndef OJPHGPU_H
+#define OJPHGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OJPHGPU_OK              0
+#define OJPHGPU_E_INVALID      -1   /* bad argument / unsupported parameter combination      */
+#define OJPHGPU_E_NOMEM        -2
+#define OJPHGPU_E_HIP          -3   /* a HIP runtime call failed (no device, launch failure)  */
+#define OJPHGPU_E_CODESTREAM   -4   /* malformed codestream (== the reference's OJPH_ERROR)   */
+#define OJPHGPU_E_OVERFLOW     -5   /* output buffer too small; *out_len holds the need       */
+#define OJPHGPU_E_BLOCK        -6   /* a code-block failed to decode (non-resilient mode)     */
+
+/* ------------------------------------------------------------------------------------------ *
+ * 1. Codestream parameters: what ojph::param_siz / param_cod / param_qcd setters carry
+ *    (src/core/openjph/ojph_params.h:68-240).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ojphgpu_params {
+  uint32_t width, height;        /* param_siz::set_image_extent                               */
+  uint32_t num_comps;            /* param_siz::set_num_components  (all comps share the below) */
+  uint32_t bit_depth;            /* param_siz::set_component(.., bit_depth, ..)               */
+  uint32_t is_signed;
+  uint32_t reversible;           /* param_cod::set_reversible                                 */
+  uint32_t num_decomps;          /* param_cod::set_num_decomposition                          */
+  uint32_t block_w, block_h;     /* param_cod::set_block_dims                                 */
+  uint32_t color_transform;      /* param_cod::set_color_transform                            */
+  uint32_t tile_w, tile_h;       /* param_siz::set_tile_size; 0 = one tile                    */
+  uint32_t prog_order;           /* 0 LRCP 1 RLCP 2 RPCL 3 PCRL 4 CPRL (set_progression_order) */
+  float    qstep;                /* param_qcd::set_irrev_quant; <= 0 selects 2^-min(16,B)     */
+  uint32_t precinct_w, precinct_h; /* 0 = 32768 (no explicit precincts)                        */
+  uint32_t tlm;                  /* codestream::request_tlm_marker                            */
+  uint32_t reserved[4];
+} ojphgpu_params;
+
+/* ------------------------------------------------------------------------------------------ *
+ * 2. The plan: host-side geometry (tile -> tile-comp -> resolution -> subband -> code-block,
+ *    precincts, K_max / delta per sub-band) derived with the reference's rules
+ *    (ojph_tile.cpp:191-329, ojph_resolution.cpp:240-470, ojph_subband.cpp:117-276,
+ *    ojph_params.cpp:1495-1760).  Host only; needs no GPU.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ojphgpu_plan ojphgpu_plan;
+
+typedef struct ojphgpu_band_info {   /* one sub-band of one tile-component resolution */
+  uint32_t tile, comp, res, band;    /* band: 0 LL 1 HL 2 LH 3 HH */
+  uint32_t x0, y0, w, h;             /* band rectangle in band coordinates */
+  uint32_t K_max;
+  float    delta, delta_inv;         /* irreversible: step / 2^(31-K_max) and its inverse */
+  uint32_t nbx, nby, first_block;    /* code-block grid and index of its first block */
+  uint64_t plane_off;                /* element (4 B) offset of the band plane in the coefficient arena */
+  uint32_t pitch;                    /* elements */
+  uint32_t reserved;
+} ojphgpu_band_info;
+
+typedef struct ojphgpu_block_info {  /* one code-block */
+  uint32_t band;                     /* index into the band table */
+  uint32_t x0, y0, w, h;             /* rectangle relative to the band origin */
+  uint32_t K_max;
+} ojphgpu_block_info;
+
+typedef struct ojphgpu_level_info {  /* one DWT level of one tile-component: res -> res-1 + 3 bands */
+  uint32_t tile, comp, res;          /* res = resolution being analysed (>= 1) */
+  uint32_t w, h, x_even, y_even;     /* input plane geometry */
+  uint64_t src_off; uint32_t src_pitch;
+  uint64_t ll_off;  uint32_t ll_pitch;
+  uint64_t hl_off;  uint32_t hl_pitch;
+  uint64_t lh_off;  uint32_t lh_pitch;
+  uint64_t hh_off;  uint32_t hh_pitch;
+} ojphgpu_level_info;
+
+typedef struct ojphgpu_coded_block { /* what the packet headers say about one code-block */
+  uint64_t offset;                   /* byte offset of the block's data (encode: in the block-data
+                                        buffer; decode: in the codestream) */
+  uint32_t len1, len2;               /* pass_length[0], pass_length[1] (0,0 = not included) */
+  uint32_t missing_msbs, num_passes;
+} ojphgpu_coded_block;
+
+int  ojphgpu_plan_create(const ojphgpu_params* params, ojphgpu_plan** out);
+void ojphgpu_plan_destroy(ojphgpu_plan* plan);
+int  ojphgpu_plan_params(const ojphgpu_plan* plan, ojphgpu_params* out);
+/* counts: out[0]=tiles [1]=bands [2]=blocks [3]=dwt levels [4]=coefficient arena elements
+ *         [5]=max coded bytes of one block [6]=precincts [7]=tile-comps */
+int  ojphgpu_plan_counts(const ojphgpu_plan* plan, uint64_t out[8]);
+int  ojphgpu_plan_bands(const ojphgpu_plan* plan, ojphgpu_band_info* out, size_t n);
+int  ojphgpu_plan_blocks(const ojphgpu_plan* plan, ojphgpu_block_info* out, size_t n);
+int  ojphgpu_plan_levels(const ojphgpu_plan* plan, ojphgpu_level_info* out, size_t n);
+/* element offset + pitch of tile-component (tile, comp)'s full-resolution plane in the arena */
+int  ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t comp,
+                             uint64_t* off, uint32_t* pitch, uint32_t rect[4]);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 3. Tier-2 on the host: marker segments + packet headers (tag trees, pass lengths) around the
+ *    code-block bytes.  Replaces local::codestream::write_headers/flush
+ *    (ojph_codestream_local.cpp:556-712,1148), tile::flush (ojph_tile.cpp:584-774),
+ *    precinct::prepare_precinct/write/parse (ojph_precinct.cpp:94-573) and
+ *    read_headers/read (ojph_codestream_local.cpp:769-1146).
+ * ------------------------------------------------------------------------------------------ */
+/* blocks[i] describes code-block i of the plan (plan order); len1 == 0 -> block not coded.
+ * Writes a complete codestream (SOC .. EOC). */
+int  ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* h_block_data,
+                      const ojphgpu_coded_block* blocks, uint8_t* h_out, size_t cap,
+                      size_t* out_len);
+/* Parses main header + all tile-parts; creates the plan the codestream implies. */
+int  ojphgpu_t2_parse(const uint8_t* h_codestream, size_t len, int resilient, ojphgpu_plan** out);
+/* after ojphgpu_t2_parse: per-block coded info (offsets are into the parsed codestream) */
+int  ojphgpu_plan_coded_blocks(const ojphgpu_plan* plan, ojphgpu_coded_block* out, size_t n);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 4. Batched device stages.  Descriptor arrays live in device memory.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ojphgpu_dwt_desc {    /* one plane, one DWT level (32-bit elements everywhere) */
+  uint64_t src_off, ll_off, hl_off, lh_off, hh_off;   /* element offsets from `base` */
+  uint32_t src_pitch, ll_pitch, hl_pitch, lh_pitch, hh_pitch;
+  uint32_t w, h;                                       /* size of the un-decomposed plane */
+  uint32_t x_even, y_even;                             /* origin parity: 1 = even coordinate */
+  uint32_t reserved;
+} ojphgpu_dwt_desc;
+
+/* K1-K4 (ojph_transform.cpp:209-852 driven by ojph_resolution.cpp:547-949).  `reversible`
+ * selects the 5/3 integer or the 9/7 float lifting; `base` is int32 or float accordingly.
+ * max_w / max_h = largest plane in the batch (sizes the launch grid). */
+int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                        uint32_t max_w, uint32_t max_h, void* d_base);
+int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                        uint32_t max_w, uint32_t max_h, void* d_base);
+
+typedef struct ojphgpu_cb_desc {     /* one code-block */
+  uint64_t coef_off;                 /* element offset of the block's first sample in `d_coef` */
+  uint32_t pitch;                    /* elements */
+  uint16_t w, h;
+  uint8_t  K_max, reversible, missing_msbs, num_passes;   /* last two: decode only */
+  float    delta;                    /* irreversible: encode uses 1/delta, decode uses delta */
+  uint32_t len1, len2;               /* decode: pass lengths */
+  uint64_t data_off;                 /* decode: byte offset of the coded bytes in `d_data`;
+                                        encode: byte offset of this block's scratch slot */
+  uint32_t scratch_cap;              /* encode: bytes available at data_off */
+  uint32_t reserved;
+} ojphgpu_cb_desc;
+
+typedef struct ojphgpu_cb_result {   /* encode result per block */
+  uint32_t offset;                   /* byte offset of the block in the compacted output */
+  uint32_t length;                   /* pass_length[0]; 0 = block has no significant sample */
+} ojphgpu_cb_result;
+
+/* K5/K6 + K8: quantise transfer (ojph_codestream_gen.cpp:59-121) fused into the HT cleanup
+ * encoder (ojph_block_encoder.cpp:542-1017).  One wavefront per code-block.  d_cursor is a
+ * device uint32 (zeroed by the caller) that ends up holding the number of bytes written to
+ * d_out; d_status (device uint32, zeroed) receives a non-zero value on scratch/out overflow. */
+int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                      const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
+                      ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status);
+
+/* K9 + K7: HT decoder (ojph_block_decoder32.cpp:742-1613) with the dequantise transfer
+ * (ojph_codestream_gen.cpp:124-168) fused.  One wavefront per code-block.  d_block_status[i]
+ * = 0 ok / 1 failed (block zeroed), mirroring the bool of decode_cb32.  lds_bytes_hint = max
+ * over blocks of len1 (sizes the per-wave LDS). */
+int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                      const uint8_t* d_data, void* d_coef, uint8_t* d_block_status,
+                      uint32_t max_len1);
+
+typedef struct ojphgpu_convert_desc { /* one tile-component */
+  uint64_t plane_off;                /* element offset in the arena */
+  uint32_t pitch, w, h;
+  uint32_t src_x0, src_y0;           /* position inside the image-sized input plane */
+  uint32_t reserved;
+} ojphgpu_convert_desc;
+
+/* K10/K11: level shift / int<->float conversion and RCT / ICT (ojph_colour.cpp:238-571 as
+ * driven by tile::push/pull, ojph_tile.cpp:332-518).  Image samples are int32 planes of
+ * img_w x img_h (component-major), like the i32 line_bufs the reference exchanges. */
+int ojphgpu_convert_forward(void* stream, const ojphgpu_params* params,
+                            const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                            uint32_t max_w, uint32_t max_h, const int32_t* d_image, void* d_arena);
+int ojphgpu_convert_inverse(void* stream, const ojphgpu_params* params,
+                            const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                            uint32_t max_w, uint32_t max_h, int32_t* d_image, const void* d_arena);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 5. Whole-frame codec objects: what an ojph::codestream-compatible facade calls from
+ *    flush() (encode) and create()/pull() (decode).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ojphgpu_encoder ojphgpu_encoder;
+typedef struct ojphgpu_decoder ojphgpu_decoder;
+
+int  ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_encoder** out);
+void ojphgpu_encoder_destroy(ojphgpu_encoder* enc);
+/* device part only: d_image (int32 planes, resident in HBM) -> coded block bytes in HBM */
+int  ojphgpu_encoder_run_device(ojphgpu_encoder* enc, const int32_t* d_image);
+/* D2H of block bytes + lengths, then host Tier-2 -> complete codestream */
+int  ojphgpu_encoder_finish(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len);
+/* convenience: H2D + run_device + finish */
+int  ojphgpu_encode(ojphgpu_encoder* enc, const int32_t* h_image, uint8_t* h_out, size_t cap,
+                    size_t* out_len);
+/* total coded bytes produced by the last run_device (synchronises the stream) */
+int  ojphgpu_encoder_coded_bytes(ojphgpu_encoder* enc, uint64_t* bytes);
+
+/* plan must come from ojphgpu_t2_parse over (h_codestream, len) */
+int  ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_decoder** out);
+void ojphgpu_decoder_destroy(ojphgpu_decoder* dec);
+/* H2D of the codestream bytes */
+int  ojphgpu_decoder_upload(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len);
+/* device part only: coded bytes in HBM -> d_image (int32 planes) */
+int  ojphgpu_decoder_run_device(ojphgpu_decoder* dec, int32_t* d_image);
+/* number of code-blocks that failed to decode in the last run (synchronises) */
+int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
+int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len,
+                    int32_t* h_image);
+
+/* timing of the last run_device, in milliseconds, measured with HIP events on the codec's own
+ * stream: out[0]=convert+colour [1]=DWT [2]=HT block coder [3]=total */
+int  ojphgpu_encoder_timing(ojphgpu_encoder* enc, float out[4]);
+int  ojphgpu_decoder_timing(ojphgpu_decoder* dec, float out[4]);
+
+const char* ojphgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OJPHGPU_H */

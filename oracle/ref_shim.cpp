@@ -1,0 +1,229 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// extern "C" facade over the *real* reference (aous72/OpenJPH 0.31.0), linked against objects
+// compiled from /root/reference by oracle/Makefile.  It lets the Python tests / bench drive the
+// reference through ctypes:
+//   * whole-codestream encode/decode through the public ojph::codestream API
+//     (reference: src/core/openjph/ojph_codestream.h:88-383), and
+//   * single code-block HT encode / decode through the internal kernels
+//     (reference: src/core/coding/ojph_block_encoder.h:52, ojph_block_decoder.h:53).
+// Nothing in the product (openjph_amd/) may link or load this file.
+
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <stdexcept>
+#include <vector>
+
+#include "ojph_arch.h"
+#include "ojph_mem.h"
+#include "ojph_file.h"
+#include "ojph_params.h"
+#include "ojph_codestream.h"
+#include "ojph_message.h"
+#include "ojph_block_encoder.h"
+#include "ojph_block_decoder.h"
+
+namespace ojph { namespace local {
+  // reference: src/core/coding/ojph_block_encoder.cpp:258 (+ _avx2 / _avx512 variants)
+  bool initialize_block_encoder_tables();
+#ifndef OJPH_DISABLE_SIMD
+  bool initialize_block_encoder_tables_avx2();
+  bool initialize_block_encoder_tables_avx512();
+#endif
+}}
+
+extern "C" {
+
+struct ref_params {
+  uint32_t width, height, num_comps;
+  uint32_t bit_depth, is_signed;
+  uint32_t reversible, num_decomps, block_w, block_h;
+  uint32_t color_transform;      // 0/1
+  uint32_t tile_w, tile_h;       // 0 => single tile
+  uint32_t prog_order;           // 0 LRCP 1 RLCP 2 RPCL 3 PCRL 4 CPRL
+  uint32_t planar;               // 0 interleaved lines, 1 planar
+  float    qstep;                // irreversible base step; <=0 => library default
+  uint32_t precinct_w, precinct_h; // 0 => default (32768); applied to all resolutions
+  uint32_t tlm;                  // request TLM marker
+};
+
+static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
+
+int ref_simd_level(void)
+{
+#ifdef OJPH_DISABLE_SIMD
+  return -1;
+#else
+  return ojph::get_cpu_ext_level();
+#endif
+}
+
+// planes: num_comps pointers to int32 rows (width*height each).  Returns codestream length or
+// a negative number on error / insufficient capacity (-needed).
+long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out, long out_cap)
+{
+  try {
+    ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
+    ojph::codestream cs;
+    ojph::param_siz siz = cs.access_siz();
+    siz.set_image_extent(ojph::point(p->width, p->height));
+    siz.set_num_components(p->num_comps);
+    for (uint32_t c = 0; c < p->num_comps; ++c)
+      siz.set_component(c, ojph::point(1, 1), p->bit_depth, p->is_signed != 0);
+    if (p->tile_w && p->tile_h)
+      siz.set_tile_size(ojph::size(p->tile_w, p->tile_h));
+    ojph::param_cod cod = cs.access_cod();
+    cod.set_num_decomposition(p->num_decomps);
+    cod.set_block_dims(p->block_w, p->block_h);
+    cod.set_progression_order(po_names[p->prog_order % 5]);
+    cod.set_color_transform(p->color_transform != 0);
+    cod.set_reversible(p->reversible != 0);
+    if (p->precinct_w && p->precinct_h) {
+      std::vector<ojph::size> ps(p->num_decomps + 1, ojph::size(p->precinct_w, p->precinct_h));
+      cod.set_precinct_size((int)ps.size(), ps.data());
+    }
+    if (!p->reversible && p->qstep > 0.0f)
+      cs.access_qcd().set_irrev_quant(p->qstep);
+    cs.set_planar(p->planar != 0);
+    if (p->tlm) cs.request_tlm_marker(true);
+
+    ojph::mem_outfile mf;
+    mf.open();
+    cs.write_headers(&mf);
+
+    ojph::ui32 next_comp = 0;
+    ojph::line_buf* line = cs.exchange(NULL, next_comp);
+    if (p->planar) {
+      for (uint32_t c = 0; c < p->num_comps; ++c)
+        for (uint32_t y = 0; y < p->height; ++y) {
+          memcpy(line->i32, planes[next_comp] + (size_t)y * p->width, sizeof(int32_t) * p->width);
+          line = cs.exchange(line, next_comp);
+        }
+    } else {
+      for (uint32_t y = 0; y < p->height; ++y)
+        for (uint32_t c = 0; c < p->num_comps; ++c) {
+          memcpy(line->i32, planes[next_comp] + (size_t)y * p->width, sizeof(int32_t) * p->width);
+          line = cs.exchange(line, next_comp);
+        }
+    }
+    cs.flush();
+    long len = (long)mf.tell();
+    if (len > out_cap) { cs.close(); return -len; }
+    memcpy(out, mf.get_data(), (size_t)len);
+    cs.close();
+    return len;
+  } catch (const std::exception&) {
+    return 0;
+  }
+}
+
+// Decodes to int32 planes (caller allocates num_comps * width * height).  Fills info[0..5] =
+// width,height,num_comps,bit_depth,is_signed,reversible.  Returns 0 on success.
+int ref_decode(const uint8_t* data, long len, int32_t* const* planes, uint32_t* info, int resilient)
+{
+  try {
+    ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
+    ojph::mem_infile in;
+    in.open(data, (size_t)len);
+    ojph::codestream cs;
+    if (resilient) cs.enable_resilience();
+    cs.read_headers(&in);
+    ojph::param_siz siz = cs.access_siz();
+    uint32_t nc = siz.get_num_components();
+    uint32_t w = siz.get_recon_width(0), h = siz.get_recon_height(0);
+    if (info) {
+      info[0] = w; info[1] = h; info[2] = nc; info[3] = siz.get_bit_depth(0);
+      info[4] = siz.is_signed(0) ? 1 : 0; info[5] = cs.access_cod().is_reversible() ? 1 : 0;
+    }
+    if (planes == NULL) { cs.close(); return 0; }
+    cs.create();
+    if (cs.is_planar()) {
+      for (uint32_t c = 0; c < nc; ++c)
+        for (uint32_t y = 0; y < h; ++y) {
+          ojph::ui32 cn;
+          ojph::line_buf* l = cs.pull(cn);
+          memcpy(planes[cn] + (size_t)y * w, l->i32, sizeof(int32_t) * w);
+        }
+    } else {
+      for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t c = 0; c < nc; ++c) {
+          ojph::ui32 cn;
+          ojph::line_buf* l = cs.pull(cn);
+          memcpy(planes[cn] + (size_t)y * w, l->i32, sizeof(int32_t) * w);
+        }
+    }
+    cs.close();
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  } catch (const char*) {
+    return -2;
+  }
+}
+
+// variant: 0 = generic C++, 1 = avx2, 2 = avx512 (SIMD build only)
+long ref_encode_block32(int variant, uint32_t* buf, uint32_t missing_msbs, uint32_t width,
+                        uint32_t height, uint32_t stride, uint8_t* out, long out_cap)
+{
+  try {
+    static bool init = false;
+    if (!init) {
+      ojph::local::initialize_block_encoder_tables();
+#ifndef OJPH_DISABLE_SIMD
+      ojph::local::initialize_block_encoder_tables_avx2();
+      ojph::local::initialize_block_encoder_tables_avx512();
+#endif
+      init = true;
+    }
+    ojph::mem_elastic_allocator elastic(1048576);
+    ojph::coded_lists* coded = NULL;
+    ojph::ui32 lengths[2] = { 0, 0 };
+    switch (variant) {
+#ifndef OJPH_DISABLE_SIMD
+      case 1:
+        ojph::local::ojph_encode_codeblock_avx2(buf, missing_msbs, 1, width, height, stride,
+                                                lengths, &elastic, coded);
+        break;
+      case 2:
+        ojph::local::ojph_encode_codeblock_avx512(buf, missing_msbs, 1, width, height, stride,
+                                                  lengths, &elastic, coded);
+        break;
+#endif
+      default:
+        ojph::local::ojph_encode_codeblock32(buf, missing_msbs, 1, width, height, stride,
+                                             lengths, &elastic, coded);
+    }
+    if ((long)lengths[0] > out_cap) return -(long)lengths[0];
+    memcpy(out, coded->buf, lengths[0]);
+    return (long)lengths[0];
+  } catch (const std::exception&) {
+    return 0;
+  }
+}
+
+// coded must have 8 readable bytes before and 16 after (ojph_codeblock.h:123-124).
+int ref_decode_block32(int variant, const uint8_t* coded, uint32_t len1, uint32_t len2,
+                       uint32_t missing_msbs, uint32_t num_passes, uint32_t width,
+                       uint32_t height, uint32_t stride, uint32_t* out, int stripe_causal)
+{
+  std::vector<uint8_t> padded((size_t)len1 + len2 + 64, 0);
+  memcpy(padded.data() + 16, coded, (size_t)len1 + len2);
+  bool ok;
+  try {
+#ifndef OJPH_DISABLE_SIMD
+    if (variant == 1)
+      ok = ojph::local::ojph_decode_codeblock_avx2(padded.data() + 16, out, missing_msbs, num_passes,
+                                                   len1, len2, width, height, stride,
+                                                   stripe_causal != 0);
+    else
+#endif
+      ok = ojph::local::ojph_decode_codeblock32(padded.data() + 16, out, missing_msbs, num_passes,
+                                                len1, len2, width, height, stride,
+                                                stripe_causal != 0);
+  } catch (const std::exception&) { return -1; }
+  (void)variant;
+  return ok ? 0 : 1;
+}
+
+} // extern "C"

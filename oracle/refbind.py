@@ -1,0 +1,117 @@
+"""ctypes binding to oracle/_ref/libojph_ref*.so (the real reference, built by oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() -- never from the product package (openjph_amd/).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
+
+
+class RefParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("num_comps", C.c_uint32),
+        ("bit_depth", C.c_uint32), ("is_signed", C.c_uint32),
+        ("reversible", C.c_uint32), ("num_decomps", C.c_uint32),
+        ("block_w", C.c_uint32), ("block_h", C.c_uint32),
+        ("color_transform", C.c_uint32),
+        ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+        ("prog_order", C.c_uint32), ("planar", C.c_uint32),
+        ("qstep", C.c_float),
+        ("precinct_w", C.c_uint32), ("precinct_h", C.c_uint32),
+        ("tlm", C.c_uint32),
+    ]
+
+
+def fnv1a64(data: bytes) -> str:
+    h = 0xcbf29ce484222325
+    for b in bytes(data):
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def available(generic=False):
+    return os.path.exists(os.path.join(_HERE, "_ref",
+                                       "libojph_refgen.so" if generic else "libojph_ref.so"))
+
+
+class Ref:
+    """The reference library. generic=True -> the -DOJPH_DISABLE_SIMD build."""
+
+    def __init__(self, generic=False):
+        name = "libojph_refgen.so" if generic else "libojph_ref.so"
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", name))
+        L = self.lib
+        L.ref_encode.restype = C.c_long
+        L.ref_encode.argtypes = [C.POINTER(RefParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_long]
+        L.ref_decode.restype = C.c_int
+        L.ref_decode.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.ref_encode_block32.restype = C.c_long
+        L.ref_encode_block32.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_void_p, C.c_long]
+        L.ref_decode_block32.restype = C.c_int
+        L.ref_decode_block32.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_int]
+        L.ref_simd_level.restype = C.c_int
+
+    def simd_level(self):
+        return self.lib.ref_simd_level()
+
+    def encode(self, planes, bit_depth, is_signed=False, reversible=True, num_decomps=5,
+               block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
+               planar=None, qstep=-1.0, precinct=(0, 0), tlm=False):
+        """planes: int32 array [num_comps, H, W]. Returns codestream bytes."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        nc, h, w = planes.shape
+        if planar is None:
+            planar = not color_transform
+        p = RefParams(w, h, nc, bit_depth, int(is_signed), int(reversible), num_decomps,
+                      block[0], block[1], int(color_transform), tile[0], tile[1],
+                      PROG_ORDERS[prog_order], int(planar), float(qstep),
+                      precinct[0], precinct[1], int(tlm))
+        ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
+        cap = planes.size * 5 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.lib.ref_encode(C.byref(p), ptrs, out.ctypes.data, cap)
+        if n <= 0:
+            raise RuntimeError("reference encode failed (%d)" % n)
+        return out[:n].tobytes()
+
+    def decode(self, data: bytes, resilient=False):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        info = np.zeros(8, dtype=np.uint32)
+        r = self.lib.ref_decode(buf.ctypes.data, len(data), None, info.ctypes.data, int(resilient))
+        if r != 0:
+            raise RuntimeError("reference read_headers failed (%d)" % r)
+        w, h, nc = int(info[0]), int(info[1]), int(info[2])
+        planes = np.zeros((nc, h, w), dtype=np.int32)
+        ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
+        r = self.lib.ref_decode(buf.ctypes.data, len(data), ptrs, info.ctypes.data, int(resilient))
+        if r != 0:
+            raise RuntimeError("reference decode failed (%d)" % r)
+        return planes, dict(bit_depth=int(info[3]), is_signed=bool(info[4]),
+                            reversible=bool(info[5]))
+
+    def encode_block(self, buf, missing_msbs, width, height, stride, variant=0):
+        buf = np.ascontiguousarray(buf, dtype=np.uint32)
+        out = np.empty(65536 * 4, dtype=np.uint8)
+        n = self.lib.ref_encode_block32(variant, buf.ctypes.data, missing_msbs, width, height,
+                                        stride, out.ctypes.data, out.size)
+        if n <= 0:
+            raise RuntimeError("reference block encode failed (%d)" % n)
+        return out[:n].tobytes()
+
+    def decode_block(self, coded: bytes, missing_msbs, width, height, stride, len2=0,
+                     num_passes=1, variant=0, stripe_causal=False):
+        data = np.frombuffer(coded, dtype=np.uint8)
+        out = np.zeros((height + 2) * stride, dtype=np.uint32)
+        len1 = len(coded) - len2
+        r = self.lib.ref_decode_block32(variant, data.ctypes.data, len1, len2, missing_msbs,
+                                        num_passes, width, height, stride, out.ctypes.data,
+                                        int(stripe_causal))
+        return r == 0, out[:height * stride].reshape(height, stride)
