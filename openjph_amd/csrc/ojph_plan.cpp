@@ -1,0 +1,476 @@
+// openjph_amd/csrc/ojph_plan.cpp -- see ojph_plan.h
+#include "ojph_plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ojphgpu {
+
+// BIBO gains of the 5/3 kernel and sqrt energy gains of the 9/7 kernel, index = number of
+// decompositions.  These are properties of the wavelet filters; the values (5 significant
+// digits) are the ones the reference quantiser is built on (ojph_params.cpp:513-596), and
+// the step sizes written into QCD -- hence the codestream bytes -- depend on them.
+static const float bibo53_l[34] = { 1.0000e+00f, 1.5000e+00f, 1.6250e+00f, 1.6875e+00f,
+  1.6963e+00f, 1.7067e+00f, 1.7116e+00f, 1.7129e+00f, 1.7141e+00f, 1.7145e+00f, 1.7151e+00f,
+  1.7152e+00f, 1.7155e+00f, 1.7155e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+  1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+  1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+  1.7156e+00f, 1.7156e+00f };
+static const float bibo53_h[34] = { 2.0000e+00f, 2.5000e+00f, 2.7500e+00f, 2.8047e+00f,
+  2.8198e+00f, 2.8410e+00f, 2.8558e+00f, 2.8601e+00f, 2.8628e+00f, 2.8656e+00f, 2.8662e+00f,
+  2.8667e+00f, 2.8669e+00f, 2.8670e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+  2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+  2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+  2.8671e+00f, 2.8671e+00f };
+static const float energy97_l[34] = { 1.0000e+00f, 1.4021e+00f, 2.0304e+00f, 2.9012e+00f,
+  4.1153e+00f, 5.8245e+00f, 8.2388e+00f, 1.1652e+01f, 1.6479e+01f, 2.3304e+01f, 3.2957e+01f,
+  4.6609e+01f, 6.5915e+01f, 9.3217e+01f, 1.3183e+02f, 1.8643e+02f, 2.6366e+02f, 3.7287e+02f,
+  5.2732e+02f, 7.4574e+02f, 1.0546e+03f, 1.4915e+03f, 2.1093e+03f, 2.9830e+03f, 4.2185e+03f,
+  5.9659e+03f, 8.4371e+03f, 1.1932e+04f, 1.6874e+04f, 2.3864e+04f, 3.3748e+04f, 4.7727e+04f,
+  6.7496e+04f, 9.5454e+04f };
+static const float energy97_h[34] = { 1.4425e+00f, 1.9669e+00f, 2.8839e+00f, 4.1475e+00f,
+  5.8946e+00f, 8.3472e+00f, 1.1809e+01f, 1.6701e+01f, 2.3620e+01f, 3.3403e+01f, 4.7240e+01f,
+  6.6807e+01f, 9.4479e+01f, 1.3361e+02f, 1.8896e+02f, 2.6723e+02f, 3.7792e+02f, 5.3446e+02f,
+  7.5583e+02f, 1.0689e+03f, 1.5117e+03f, 2.1378e+03f, 3.0233e+03f, 4.2756e+03f, 6.0467e+03f,
+  8.5513e+03f, 1.2093e+04f, 1.7103e+04f, 2.4187e+04f, 3.4205e+04f, 4.8373e+04f, 6.8410e+04f,
+  9.6747e+04f, 1.3682e+05f };
+
+static inline uint32_t div_ceil(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static inline uint32_t ilog2(uint32_t v) { uint32_t r = 0; while ((1u << (r + 1)) <= v && r < 31) ++r; return r; }
+
+// ojph_params.cpp:1495-1540 (reversible) and :1542-1613 (irreversible)
+void derive_quant(Plan& plan)
+{
+  const ojphgpu_params& p = plan.p;
+  uint32_t D = p.num_decomps;
+  plan.spqcd8.clear(); plan.spqcd16.clear();
+  if (p.reversible) {
+    uint32_t B = p.bit_depth + (p.color_transform ? 1 : 0);
+    std::vector<uint32_t> e;
+    double bl = bibo53_l[D];
+    uint32_t X = (uint32_t)std::ceil(std::log(bl * bl) / M_LN2);
+    e.push_back(B + X);
+    uint32_t mx = B + X;
+    for (uint32_t d = D; d > 0; --d) {
+      double l = bibo53_l[d], h = bibo53_h[d - 1];
+      X = (uint32_t)std::ceil(std::log(h * l) / M_LN2);
+      e.push_back(B + X); e.push_back(B + X); mx = std::max(mx, B + X);
+      X = (uint32_t)std::ceil(std::log(h * h) / M_LN2);
+      e.push_back(B + X); mx = std::max(mx, B + X);
+    }
+    int guard = std::max(1, (int)mx - 31);
+    plan.guard_bits = (uint32_t)guard;
+    plan.sqcd = (uint8_t)(guard << 5);
+    for (uint32_t v : e) plan.spqcd8.push_back((uint8_t)((v - guard) << 3));
+  } else {
+    plan.guard_bits = 1;
+    plan.sqcd = (uint8_t)((1 << 5) | 0x2);
+    float base = p.qstep;
+    if (!(base > 0.0f)) {                                  // ojph_params.cpp:1456-1460
+      uint32_t t = std::min<uint32_t>(16, p.bit_depth);
+      base = 1.0f / (float)(1 << t);
+    }
+    auto enc = [&](float delta) {                          // encode_SPqcd :1602-1613
+      int exp = 0;
+      while (delta < 1.0f) { exp++; delta *= 2.0f; }
+      int mant = (int)std::round(delta * (float)(1 << 11)) - (1 << 11);
+      mant = mant < (1 << 11) ? mant : 0x7FF;
+      plan.spqcd16.push_back((uint16_t)((exp << 11) | mant));
+    };
+    // no qfactor: g_c = 1, w_b = pow(1, 1) = 1
+    float gl = energy97_l[D];
+    enc(base / (gl * gl * 1.0f * 1.0f));
+    for (uint32_t d = D; d > 0; --d) {
+      float l = energy97_l[d], h = energy97_h[d - 1];
+      enc(base / (h * l * 1.0f * 1.0f));
+      enc(base / (l * h * 1.0f * 1.0f));
+      enc(base / (h * h * 1.0f * 1.0f));
+    }
+  }
+}
+
+static inline uint32_t band_index(uint32_t res, uint32_t band) { return res ? (res - 1) * 3 + band : 0; }
+
+uint32_t band_Kmax(const Plan& plan, uint32_t res, uint32_t band)   // ojph_params.cpp:1715-1749
+{
+  uint32_t idx = band_index(res, band);
+  if (plan.p.reversible) {
+    idx = std::min<uint32_t>(idx, (uint32_t)plan.spqcd8.size() - 1);
+    uint32_t nb = plan.spqcd8[idx] >> 3;
+    nb = nb == 0 ? 0 : nb - 1;
+    return nb + plan.guard_bits;
+  }
+  idx = std::min<uint32_t>(idx, (uint32_t)plan.spqcd16.size() - 1);
+  return (uint32_t)(plan.spqcd16[idx] >> 11) - 1 + plan.guard_bits;
+}
+
+float band_delta(const Plan& plan, uint32_t res, uint32_t band)    // ojph_params.cpp:1650-1681
+{
+  static const float arr[4] = { 1.0f, 2.0f, 2.0f, 4.0f };
+  uint32_t idx = std::min<uint32_t>(band_index(res, band), (uint32_t)plan.spqcd16.size() - 1);
+  int eps = plan.spqcd16[idx] >> 11;
+  float mantissa = (float)((plan.spqcd16[idx] & 0x7FF) | 0x800) * arr[band];
+  mantissa /= (float)(1 << 11);
+  mantissa /= (float)(1u << eps);
+  return mantissa;
+}
+
+uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max)
+{
+  // MagSgn: every sample <= K_max+1 bits, stuffing adds at most 1 bit per 7;
+  // MEL + VLC: the reference's fixed 3072-byte budget (ojph_block_encoder.cpp:552-557)
+  uint64_t bits = (uint64_t)w * h * (K_max + 2);
+  uint64_t ms = (bits + 6) / 7 + 16;
+  uint64_t total = ms + 3072 + 64;
+  return (uint32_t)((total + 63) & ~63ull);
+}
+
+int build_plan(const ojphgpu_params& pin, Plan& plan)
+{
+  plan = Plan();
+  ojphgpu_params p = pin;
+  auto fail = [&](const char* m) { plan.error = m; return OJPHGPU_E_INVALID; };
+  if (p.width == 0 || p.height == 0 || p.num_comps == 0) return fail("empty image");
+  if (p.num_comps > 16384) return fail("too many components");
+  if (p.bit_depth < 1 || p.bit_depth > 26) return fail("bit depth unsupported (32-bit sample path only)");
+  if (p.num_decomps > 32) return fail("too many decompositions");
+  if (p.block_w == 0) p.block_w = 64;
+  if (p.block_h == 0) p.block_h = 64;
+  uint32_t lbw = ilog2(p.block_w), lbh = ilog2(p.block_h);
+  if ((1u << lbw) != p.block_w || (1u << lbh) != p.block_h || lbw < 2 || lbh < 2 ||
+      lbw > 10 || lbh > 10 || lbw + lbh > 12)
+    return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
+  if (p.color_transform && p.num_comps != 3) return fail("colour transform needs exactly 3 components here");
+  if (p.prog_order > 4) return fail("unknown progression order");
+  if (p.tile_w == 0 || p.tile_h == 0) { p.tile_w = p.width; p.tile_h = p.height; }
+  uint32_t lpw = 15, lph = 15;
+  if (p.precinct_w && p.precinct_h) {
+    lpw = ilog2(p.precinct_w); lph = ilog2(p.precinct_h);
+    if ((1u << lpw) != p.precinct_w || (1u << lph) != p.precinct_h || lpw > 15 || lph > 15)
+      return fail("precinct size must be a power of two <= 32768");
+    if (p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");
+  }
+  plan.p = p;
+  derive_quant(plan);
+
+  plan.ntx = div_ceil(p.width, p.tile_w);
+  plan.nty = div_ceil(p.height, p.tile_h);
+  if ((uint64_t)plan.ntx * plan.nty > 65535) return fail("the number of tiles cannot exceed 65535");
+  const uint32_t L = p.num_decomps;
+  uint64_t arena = 0;
+  auto alloc = [&](uint32_t w, uint32_t h, uint32_t& pitch) {
+    pitch = (std::max<uint32_t>(w, 1) + 63u) & ~63u;
+    uint64_t off = arena;
+    arena += (uint64_t)pitch * std::max<uint32_t>(h, 1) + 64;   // +64: kernels may over-read a row tail
+    arena = (arena + 63) & ~63ull;
+    return off;
+  };
+
+  for (uint32_t ty = 0; ty < plan.nty; ++ty)
+    for (uint32_t tx = 0; tx < plan.ntx; ++tx) {
+      Tile t; t.idx = ty * plan.ntx + tx;
+      t.r.x0 = tx * p.tile_w; t.r.y0 = ty * p.tile_h;
+      t.r.w = std::min(t.r.x0 + p.tile_w, p.width) - t.r.x0;
+      t.r.h = std::min(t.r.y0 + p.tile_h, p.height) - t.r.y0;
+      for (uint32_t c = 0; c < p.num_comps; ++c) {
+        TileComp tc; tc.tile = t.idx; tc.comp = c; tc.r = t.r;     // no sub-sampling
+        tc.res.assign(L + 1, 0);
+        // resolution rectangles, top down (ojph_resolution.cpp:302-330 with band 0)
+        std::vector<Rect> rr(L + 1);
+        rr[L] = tc.r;
+        for (uint32_t r = L; r > 0; --r) {
+          Rect a = rr[r], b;
+          b.x0 = (a.x0 + 1) >> 1; b.y0 = (a.y0 + 1) >> 1;
+          b.w = ((a.x0 + a.w + 1) >> 1) - b.x0; b.h = ((a.y0 + a.h + 1) >> 1) - b.y0;
+          rr[r - 1] = b;
+        }
+        for (uint32_t r = 0; r <= L; ++r) {
+          Resolution R; R.tile = t.idx; R.comp = c; R.res = r; R.r = rr[r];
+          R.log_ppw = lpw; R.log_pph = lph;
+          for (int i = 0; i < 4; ++i) R.band[i] = -1;
+          R.plane_off = 0; R.pitch = 0;
+          if (r > 0) R.plane_off = alloc(R.r.w, R.r.h, R.pitch);   // raw plane; res 0 lives in its LL band
+          uint32_t trx0 = R.r.x0, try0 = R.r.y0, trx1 = R.r.x0 + R.r.w, try1 = R.r.y0 + R.r.h;
+          uint32_t off = r > 0 ? 1 : 0;
+          for (uint32_t b = (r ? 1 : 0); b < (r ? 4u : 1u); ++b) {
+            Band B; B.tile = t.idx; B.comp = c; B.res = r; B.band = b;
+            if (r > 0) {
+              B.r.x0 = (trx0 - (b & 1) + 1) >> 1; B.r.y0 = (try0 - (b >> 1) + 1) >> 1;
+              B.r.w = ((trx1 - (b & 1) + 1) >> 1) - B.r.x0;
+              B.r.h = ((try1 - (b >> 1) + 1) >> 1) - B.r.y0;
+            } else B.r = R.r;
+            B.K_max = band_Kmax(plan, r, b);
+            B.delta = 0.0f; B.delta_inv = 0.0f;
+            if (!p.reversible) {                                   // ojph_subband.cpp:156-164
+              float d = band_delta(plan, r, b);
+              d /= (float)(1u << (31 - B.K_max));
+              B.delta = d; B.delta_inv = 1.0f / d;
+            }
+            B.xcb = std::min(lbw, lpw - off); B.ycb = std::min(lbh, lph - off);
+            B.empty = (B.r.w == 0 || B.r.h == 0);
+            B.nbx = B.nby = 0; B.first_block = (uint32_t)plan.blocks.size();
+            B.plane_off = alloc(B.r.w, B.r.h, B.pitch);
+            if (!B.empty) {
+              uint32_t x1 = B.r.x0 + B.r.w, y1 = B.r.y0 + B.r.h;
+              B.nbx = ((x1 + (1u << B.xcb) - 1) >> B.xcb) - (B.r.x0 >> B.xcb);
+              B.nby = ((y1 + (1u << B.ycb) - 1) >> B.ycb) - (B.r.y0 >> B.ycb);
+              uint32_t xl = (B.r.x0 >> B.xcb) << B.xcb, yl = (B.r.y0 >> B.ycb) << B.ycb;
+              for (uint32_t by = 0; by < B.nby; ++by)
+                for (uint32_t bx = 0; bx < B.nbx; ++bx) {
+                  Block k; k.band = (uint32_t)plan.bands.size(); k.bx = bx; k.by = by;
+                  uint32_t cx0 = std::max(B.r.x0, xl + (bx << B.xcb));
+                  uint32_t cx1 = std::min(x1, xl + ((bx + 1) << B.xcb));
+                  uint32_t cy0 = std::max(B.r.y0, yl + (by << B.ycb));
+                  uint32_t cy1 = std::min(y1, yl + ((by + 1) << B.ycb));
+                  k.r.x0 = cx0 - B.r.x0; k.r.y0 = cy0 - B.r.y0; k.r.w = cx1 - cx0; k.r.h = cy1 - cy0;
+                  plan.blocks.push_back(k);
+                  plan.max_block_bytes = std::max(plan.max_block_bytes,
+                                                  block_scratch_bytes(k.r.w, k.r.h, B.K_max));
+                }
+            }
+            R.band[b] = (int)plan.bands.size();
+            plan.bands.push_back(B);
+          }
+          // precincts (ojph_resolution.cpp:401-441)
+          R.npw = R.nph = 0; R.first_precinct = (uint32_t)plan.precincts.size();
+          if (trx0 != trx1 && try0 != try1) {
+            R.npw = ((trx1 + (1u << lpw) - 1) >> lpw) - (trx0 >> lpw);
+            R.nph = ((try1 + (1u << lph) - 1) >> lph) - (try0 >> lph);
+            uint32_t xlb = (trx0 >> lpw) << lpw, ylb = (try0 >> lph) << lph;
+            uint32_t ds = 1u << (L - r);
+            for (uint32_t y = 0; y < R.nph; ++y)
+              for (uint32_t x = 0; x < R.npw; ++x) {
+                Precinct P; P.tile = t.idx; P.comp = c; P.res = r;
+                uint64_t ix = (uint64_t)ds * (xlb + (x << lpw)), iy = (uint64_t)ds * (ylb + (y << lph));
+                P.img_x = (uint32_t)std::max<uint64_t>(ix, t.r.x0);
+                P.img_y = (uint32_t)std::max<uint64_t>(iy, t.r.y0);
+                for (int i = 0; i < 4; ++i) P.cb[i] = Rect{0, 0, 0, 0};
+                plan.precincts.push_back(P);
+              }
+            // code-block index rectangles per band (ojph_subband.cpp:224-276)
+            for (uint32_t b = 0; b < 4; ++b) {
+              if (R.band[b] < 0) continue;
+              const Band& B = plan.bands[(size_t)R.band[b]];
+              if (B.empty) continue;
+              uint32_t pc_l = (trx0 >> lpw) << lpw, pc_t = (try0 >> lph) << lph;
+              uint32_t xs = off, ys = off, coly = 0;
+              for (uint32_t y = 0; y < R.nph; ++y) {
+                uint32_t pcy0 = std::max(try0, pc_t + (y << lph));
+                uint32_t pcy1 = std::min(try1, pc_t + ((y + 1) << lph));
+                pcy0 = (pcy0 - (b >> 1) + (1u << ys) - 1) >> ys;
+                pcy1 = (pcy1 - (b >> 1) + (1u << ys) - 1) >> ys;
+                uint32_t yb = ((pcy1 + (1u << B.ycb) - 1) >> B.ycb) - (pcy0 >> B.ycb);
+                uint32_t colx = 0;
+                for (uint32_t x = 0; x < R.npw; ++x) {
+                  uint32_t pcx0 = std::max(trx0, pc_l + (x << lpw));
+                  uint32_t pcx1 = std::min(trx1, pc_l + ((x + 1) << lpw));
+                  pcx0 = (pcx0 - (b & 1) + (1u << xs) - 1) >> xs;
+                  pcx1 = (pcx1 - (b & 1) + (1u << xs) - 1) >> xs;
+                  uint32_t xb = ((pcx1 + (1u << B.xcb) - 1) >> B.xcb) - (pcx0 >> B.xcb);
+                  Precinct& P = plan.precincts[R.first_precinct + y * R.npw + x];
+                  P.cb[b] = Rect{colx, coly, xb, yb};
+                  colx += xb;
+                }
+                coly += yb;
+              }
+            }
+          }
+          tc.res[r] = (uint32_t)plan.ress.size();
+          plan.ress.push_back(R);
+        }
+        // DWT levels: res r -> res r-1 (or the LL band when r-1 == 0) + bands of res r
+        for (uint32_t r = L; r > 0; --r) {
+          const Resolution& R = plan.ress[tc.res[r]];
+          const Resolution& C = plan.ress[tc.res[r - 1]];
+          ojphgpu_level_info lv; memset(&lv, 0, sizeof(lv));
+          lv.tile = t.idx; lv.comp = c; lv.res = r;
+          lv.w = R.r.w; lv.h = R.r.h; lv.x_even = (R.r.x0 & 1) == 0; lv.y_even = (R.r.y0 & 1) == 0;
+          lv.src_off = R.plane_off; lv.src_pitch = R.pitch;
+          if (r - 1 == 0) { const Band& B = plan.bands[(size_t)C.band[0]]; lv.ll_off = B.plane_off; lv.ll_pitch = B.pitch; }
+          else { lv.ll_off = C.plane_off; lv.ll_pitch = C.pitch; }
+          const Band& HL = plan.bands[(size_t)R.band[1]];
+          const Band& LH = plan.bands[(size_t)R.band[2]];
+          const Band& HH = plan.bands[(size_t)R.band[3]];
+          lv.hl_off = HL.plane_off; lv.hl_pitch = HL.pitch;
+          lv.lh_off = LH.plane_off; lv.lh_pitch = LH.pitch;
+          lv.hh_off = HH.plane_off; lv.hh_pitch = HH.pitch;
+          plan.levels.push_back(lv);
+        }
+        t.comps.push_back((uint32_t)plan.tcomps.size());
+        plan.tcomps.push_back(tc);
+      }
+      plan.tiles.push_back(t);
+    }
+  plan.arena_elems = arena;
+
+  // packet (precinct) order per tile (ojph_tile.cpp:604-772)
+  for (Tile& t : plan.tiles) {
+    auto res_of = [&](uint32_t c, uint32_t r) -> const Resolution& {
+      return plan.ress[plan.tcomps[t.comps[c]].res[r]];
+    };
+    uint32_t nc = p.num_comps;
+    std::vector<std::vector<uint32_t>> cur(nc, std::vector<uint32_t>(L + 1, 0));
+    auto top = [&](uint32_t c, uint32_t r, uint32_t& x, uint32_t& y) {
+      const Resolution& R = res_of(c, r);
+      if (cur[c][r] >= R.npw * R.nph) return false;
+      const Precinct& P = plan.precincts[R.first_precinct + cur[c][r]];
+      x = P.img_x; y = P.img_y; return true;
+    };
+    auto emit = [&](uint32_t c, uint32_t r) {
+      const Resolution& R = res_of(c, r);
+      t.packets.push_back(R.first_precinct + cur[c][r]); cur[c][r]++;
+    };
+    if (p.prog_order == 0 || p.prog_order == 1) {
+      for (uint32_t r = 0; r <= L; ++r)
+        for (uint32_t c = 0; c < nc; ++c) {
+          const Resolution& R = res_of(c, r);
+          for (uint32_t i = 0; i < R.npw * R.nph; ++i) emit(c, r);
+        }
+    } else if (p.prog_order == 2) {
+      for (uint32_t r = 0; r <= L; ++r)
+        for (;;) {
+          bool found = false; uint32_t bc = 0, sx = 0x7FFFFFFF, sy = 0x7FFFFFFF, x, y;
+          for (uint32_t c = 0; c < nc; ++c) {
+            if (!top(c, r, x, y)) continue;
+            found = true;
+            if (y < sy || (y == sy && x < sx)) { sx = x; sy = y; bc = c; }
+          }
+          if (!found) break;
+          emit(bc, r);
+        }
+    } else if (p.prog_order == 3) {
+      for (;;) {
+        bool found = false; uint32_t bc = 0, br = 0, sx = 0x7FFFFFFF, sy = 0x7FFFFFFF, x, y;
+        for (uint32_t c = 0; c < nc; ++c)
+          for (uint32_t r = 0; r <= L; ++r) {
+            if (!top(c, r, x, y)) continue;
+            found = true;
+            if (y < sy || (y == sy && x < sx) || (y == sy && x == sx && c < bc) ||
+                (y == sy && x == sx && c == bc && r < br)) { sx = x; sy = y; bc = c; br = r; }
+          }
+        if (!found) break;
+        emit(bc, br);
+      }
+    } else {
+      for (uint32_t c = 0; c < nc; ++c)
+        for (;;) {
+          bool found = false; uint32_t br = 0, sx = 0x7FFFFFFF, sy = 0x7FFFFFFF, x, y;
+          for (uint32_t r = 0; r <= L; ++r) {
+            if (!top(c, r, x, y)) continue;
+            found = true;
+            if (y < sy || (y == sy && x < sx)) { sx = x; sy = y; br = r; }
+          }
+          if (!found) break;
+          emit(c, br);
+        }
+    }
+  }
+  return OJPHGPU_OK;
+}
+
+}  // namespace ojphgpu
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: plan
+// ---------------------------------------------------------------------------------------------
+using namespace ojphgpu;
+
+extern "C" int ojphgpu_plan_create(const ojphgpu_params* params, ojphgpu_plan** out)
+{
+  if (!params || !out) return OJPHGPU_E_INVALID;
+  ojphgpu_plan* h = new (std::nothrow) ojphgpu_plan();
+  if (!h) return OJPHGPU_E_NOMEM;
+  int rc = build_plan(*params, h->plan);
+  if (rc != OJPHGPU_OK) { delete h; *out = nullptr; return rc; }
+  *out = h;
+  return OJPHGPU_OK;
+}
+
+extern "C" void ojphgpu_plan_destroy(ojphgpu_plan* plan) { delete plan; }
+
+extern "C" int ojphgpu_plan_params(const ojphgpu_plan* plan, ojphgpu_params* out)
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  *out = plan->plan.p;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_counts(const ojphgpu_plan* plan, uint64_t out[8])
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  out[0] = P.tiles.size(); out[1] = P.bands.size(); out[2] = P.blocks.size();
+  out[3] = P.levels.size(); out[4] = P.arena_elems; out[5] = P.max_block_bytes;
+  out[6] = P.precincts.size(); out[7] = P.tcomps.size();
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_bands(const ojphgpu_plan* plan, ojphgpu_band_info* out, size_t n)
+{
+  if (!plan || !out || n < plan->plan.bands.size()) return OJPHGPU_E_INVALID;
+  size_t i = 0;
+  for (const Band& B : plan->plan.bands) {
+    ojphgpu_band_info& o = out[i++];
+    o.tile = B.tile; o.comp = B.comp; o.res = B.res; o.band = B.band;
+    o.x0 = B.r.x0; o.y0 = B.r.y0; o.w = B.r.w; o.h = B.r.h; o.K_max = B.K_max;
+    o.delta = B.delta; o.delta_inv = B.delta_inv; o.nbx = B.nbx; o.nby = B.nby;
+    o.first_block = B.first_block; o.plane_off = B.plane_off; o.pitch = B.pitch; o.reserved = 0;
+  }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_blocks(const ojphgpu_plan* plan, ojphgpu_block_info* out, size_t n)
+{
+  if (!plan || !out || n < plan->plan.blocks.size()) return OJPHGPU_E_INVALID;
+  size_t i = 0;
+  for (const Block& k : plan->plan.blocks) {
+    ojphgpu_block_info& o = out[i++];
+    o.band = k.band; o.x0 = k.r.x0; o.y0 = k.r.y0; o.w = k.r.w; o.h = k.r.h;
+    o.K_max = plan->plan.bands[k.band].K_max;
+  }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_levels(const ojphgpu_plan* plan, ojphgpu_level_info* out, size_t n)
+{
+  if (!plan || !out || n < plan->plan.levels.size()) return OJPHGPU_E_INVALID;
+  if (!plan->plan.levels.empty())
+    memcpy(out, plan->plan.levels.data(), sizeof(ojphgpu_level_info) * plan->plan.levels.size());
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t comp,
+                                        uint64_t* off, uint32_t* pitch, uint32_t rect[4])
+{
+  if (!plan) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  if (tile >= P.tiles.size() || comp >= P.p.num_comps) return OJPHGPU_E_INVALID;
+  const TileComp& tc = P.tcomps[P.tiles[tile].comps[comp]];
+  uint32_t L = P.p.num_decomps;
+  const Resolution& R = P.ress[tc.res[L]];
+  if (L == 0) {
+    const Band& B = P.bands[(size_t)R.band[0]];
+    if (off) *off = B.plane_off;
+    if (pitch) *pitch = B.pitch;
+  } else {
+    if (off) *off = R.plane_off;
+    if (pitch) *pitch = R.pitch;
+  }
+  if (rect) { rect[0] = tc.r.x0; rect[1] = tc.r.y0; rect[2] = tc.r.w; rect[3] = tc.r.h; }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_coded_blocks(const ojphgpu_plan* plan, ojphgpu_coded_block* out, size_t n)
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  if (P.coded.size() != P.blocks.size() || n < P.coded.size()) return OJPHGPU_E_INVALID;
+  for (size_t i = 0; i < P.coded.size(); ++i) {
+    out[i].offset = P.coded[i].offset; out[i].len1 = P.coded[i].len1; out[i].len2 = P.coded[i].len2;
+    out[i].missing_msbs = P.coded[i].missing_msbs; out[i].num_passes = P.coded[i].num_passes;
+  }
+  return OJPHGPU_OK;
+}
+
+extern "C" const char* ojphgpu_version(void) { return "openjph_amd 0.1 (HTJ2K hot path for gfx950; compatible with OpenJPH 0.31.0)"; }

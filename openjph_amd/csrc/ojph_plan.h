@@ -1,0 +1,110 @@
+// openjph_amd/csrc/ojph_plan.h -- host-side codestream geometry ("plan") for the GPU hot path.
+//
+// The reference builds a tree of objects tile -> tile_comp -> resolution -> subband -> codeblock
+// (+ precinct) and streams image lines through it.  Here the same geometry is flattened once
+// per frame shape into tables (bands, code-blocks, DWT levels, precincts, packet order) that are
+// uploaded to HBM and drive a handful of large kernels.  Rules restated from:
+//   tile / tile-comp rectangles      src/core/codestream/ojph_codestream_local.cpp:113-220,
+//                                    ojph_tile.cpp:253-289
+//   resolution / sub-band rectangles ojph_resolution.cpp:302-330
+//   code-block grid                  ojph_subband.cpp:133-206
+//   precincts + block index map      ojph_resolution.cpp:401-441, ojph_subband.cpp:224-276
+//   quantisation (K_max, delta)      ojph_params.cpp:1495-1760, ojph_subband.cpp:153-164
+#ifndef OJPH_PLAN_H
+#define OJPH_PLAN_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/ojphgpu.h"
+
+namespace ojphgpu {
+
+struct Rect { uint32_t x0, y0, w, h; };
+
+struct Band {
+  uint32_t tile, comp, res, band;
+  Rect r;                       // band coordinates
+  uint32_t K_max;
+  float delta, delta_inv;
+  uint32_t xcb, ycb;            // log2 of the code-block size in this band (xcb', ycb')
+  uint32_t nbx, nby, first_block;
+  uint64_t plane_off;           // elements
+  uint32_t pitch;
+  bool empty;
+};
+
+struct Block {
+  uint32_t band;
+  uint32_t bx, by;              // position in the band's block grid
+  Rect r;                       // relative to the band origin
+};
+
+struct Precinct {
+  uint32_t tile, comp, res;
+  uint32_t img_x, img_y;        // precinct::img_point (ojph_resolution.cpp:428-433)
+  Rect cb[4];                   // per band: rectangle in the band's block grid
+};
+
+struct Resolution {
+  uint32_t tile, comp, res;
+  Rect r;
+  uint32_t log_ppw, log_pph;
+  uint32_t npw, nph;            // precinct grid
+  uint32_t first_precinct;
+  int band[4];                  // band table indices (-1 = absent)
+  uint64_t plane_off;           // raw (un-coded) plane of this resolution, elements
+  uint32_t pitch;
+};
+
+struct TileComp {
+  uint32_t tile, comp;
+  Rect r;
+  std::vector<uint32_t> res;    // resolution table indices, res[0] = lowest
+};
+
+struct Tile {
+  uint32_t idx;
+  Rect r;
+  std::vector<uint32_t> comps;  // tile-comp indices
+  std::vector<uint32_t> packets; // precinct indices in progression order
+};
+
+struct CodedBlock {             // filled by the codestream parser
+  uint64_t offset; uint32_t len1, len2, missing_msbs, num_passes;
+};
+
+struct Plan {
+  ojphgpu_params p;
+  uint32_t ntx, nty;
+  uint32_t guard_bits;
+  std::vector<uint8_t> spqcd8;   // reversible: exponent bytes as written in QCD
+  std::vector<uint16_t> spqcd16; // irreversible
+  uint8_t sqcd;
+  std::vector<Tile> tiles;
+  std::vector<TileComp> tcomps;
+  std::vector<Resolution> ress;
+  std::vector<Band> bands;
+  std::vector<Block> blocks;
+  std::vector<Precinct> precincts;
+  std::vector<ojphgpu_level_info> levels;   // DWT levels, highest resolution first per tile-comp
+  std::vector<CodedBlock> coded;            // only after parse
+  uint64_t arena_elems;
+  uint32_t max_block_bytes;
+  std::string error;
+};
+
+// builds everything from p (p.tile_w/h == 0 -> single tile). Returns 0 or OJPHGPU_E_INVALID.
+int build_plan(const ojphgpu_params& p, Plan& plan);
+// derives QCD contents (ojph_params.cpp:1495-1613)
+void derive_quant(Plan& plan);
+uint32_t band_Kmax(const Plan& plan, uint32_t res, uint32_t band);
+float band_delta(const Plan& plan, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
+// worst-case coded size of a block of w*h samples with K_max magnitude bits
+uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max);
+
+}  // namespace ojphgpu
+
+struct ojphgpu_plan { ojphgpu::Plan plan; };
+
+#endif

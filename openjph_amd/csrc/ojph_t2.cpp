@@ -1,0 +1,542 @@
+// openjph_amd/csrc/ojph_t2.cpp -- host Tier-2: marker segments and packet headers around the
+// code-block bytes the GPU produced / is about to consume.
+//
+// Behaviour restated from the reference (aous72/OpenJPH 0.31.0):
+//   main header            local::codestream::write_headers   ojph_codestream_local.cpp:556-712
+//   SIZ / CAP / COD / QCD  param_*::write                     ojph_params.cpp:805,968,1035,1778
+//   SOT / TLM              param_sot::write, param_tlm::write ojph_params.cpp:2343,2497
+//   tile-part sequencing   tile::flush                        ojph_tile.cpp:584-774
+//   packet header coder    precinct::prepare_precinct/write   ojph_precinct.cpp:94-324
+//   header bit stuffing    bb_put_bit / bb_terminate          ojph_bitbuffer_write.h:83-147
+//   parsing                codestream::read_headers / read    ojph_codestream_local.cpp:769-1146
+//                          precinct::parse                    ojph_precinct.cpp:328-573
+//                          bit reader                         ojph_bitbuffer_read.h:66-176
+#include "ojph_plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace ojphgpu {
+
+namespace {
+
+enum : uint16_t { SOC = 0xFF4F, CAP = 0xFF50, SIZ = 0xFF51, COD = 0xFF52, COC = 0xFF53, TLM = 0xFF55,
+                  PLM = 0xFF57, PLT = 0xFF58, QCD = 0xFF5C, QCC = 0xFF5D, RGN = 0xFF5E, POC = 0xFF5F,
+                  PPM = 0xFF60, PPT = 0xFF61, CRG = 0xFF63, COM = 0xFF64, SOT = 0xFF90, SOP = 0xFF91,
+                  EPH = 0xFF92, SOD = 0xFF93, EOC = 0xFFD9, NLT = 0xFF76, DFS = 0xFF72, ATK = 0xFF79 };
+
+struct ByteSink {
+  std::vector<uint8_t> v;
+  void u8(uint32_t x) { v.push_back((uint8_t)x); }
+  void u16(uint32_t x) { u8(x >> 8); u8(x); }
+  void u32(uint32_t x) { u16(x >> 16); u16(x); }
+  void bytes(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; v.insert(v.end(), b, b + n); }
+};
+
+// MSB-first bit writer with the 0xFF -> 7-bit rule of packet headers
+struct HeaderBits {
+  std::vector<uint8_t>& out;
+  int avail = 8; uint32_t tmp = 0;
+  explicit HeaderBits(std::vector<uint8_t>& o) : out(o) {}
+  void bit(uint32_t b) {
+    --avail; tmp |= (b & 1u) << avail;
+    if (avail <= 0) { out.push_back((uint8_t)tmp); avail = (tmp != 0xFF) ? 8 : 7; tmp = 0; }
+  }
+  void bits(uint32_t data, int n) { for (int i = n - 1; i >= 0; --i) bit(data >> i); }
+  void zeros(int n) { for (int i = 0; i < n; ++i) bit(0); }
+  void terminate() { if (avail < 8) out.push_back((uint8_t)tmp); }
+};
+
+inline uint32_t log2ceil(uint32_t x) { uint32_t t = 31 - (uint32_t)__builtin_clz(x); return t + ((x & (x - 1)) ? 1 : 0); }
+inline int bitlen(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
+
+// Tag tree storage laid out like the reference's (ojph_precinct.cpp:58-84): level l is a flat
+// array of 4^(levels-1-l) entries pre-filled with `fill`, addressed x + y * ceil(w / 2^l) with no
+// bounds check.  The encoder's min-reduction reads (2x+1, 2y) even when 2x+1 == row width, which
+// wraps into the next row (or into the fill value); byte-identical headers need the same reads.
+struct TagTree {
+  uint32_t w, h, levels;
+  std::vector<std::vector<uint8_t>> lv;   // lv[levels] is the virtual parent of the root (value 0)
+  void init(uint32_t w_, uint32_t h_, uint32_t levels_, uint8_t fill) {
+    w = w_; h = h_; levels = levels_; lv.assign(levels + 1, std::vector<uint8_t>());
+    for (uint32_t l = 0; l < levels; ++l)
+      lv[l].assign((size_t)1 << ((levels - 1 - l) << 1), fill);
+    lv[levels].assign(1, 0);
+  }
+  uint8_t& at(uint32_t x, uint32_t y, uint32_t l) {
+    if (l >= levels) return lv[levels][0];
+    size_t i = x + (size_t)y * ((w + (1u << l) - 1) >> l);
+    if (i >= lv[l].size()) { static uint8_t pad; pad = 255; return pad; }
+    return lv[l][i];
+  }
+};
+
+void write_main_header(const Plan& P, ByteSink& s)
+{
+  const ojphgpu_params& p = P.p;
+  s.u16(SOC);
+  // SIZ (ojph_params.cpp:805-851); Rsiz = 0x4000: HTJ2K codestream
+  s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000);
+  s.u32(p.width); s.u32(p.height); s.u32(0); s.u32(0);
+  s.u32(p.tile_w); s.u32(p.tile_h); s.u32(0); s.u32(0);
+  s.u16(p.num_comps);
+  for (uint32_t c = 0; c < p.num_comps; ++c) { s.u8((p.bit_depth - 1) | (p.is_signed ? 0x80 : 0)); s.u8(1); s.u8(1); }
+  // CAP (ojph_params.cpp:968-989, Ccap from ojph_params_local.h:929-945 + get_MAGB :1615-1647)
+  uint32_t B = 0;
+  if (p.reversible) {
+    for (uint8_t e : P.spqcd8) B = std::max<uint32_t>(B, (uint32_t)(e >> 3) + P.guard_bits - 1);
+  } else {
+    uint32_t D = p.num_decomps;
+    for (size_t i = 0; i < P.spqcd16.size(); ++i) {
+      uint32_t nb = D - (i ? (uint32_t)(i - 1) / 3 : 0);
+      B = std::max<uint32_t>(B, (uint32_t)(P.spqcd16[i] >> 11) + P.guard_bits - nb);
+    }
+  }
+  uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : 13 + (B >> 2));
+  uint32_t Ccap = (p.reversible ? 0u : 0x0020u) | Bp;
+  s.u16(CAP); s.u16(8); s.u32(0x00020000); s.u16(Ccap);
+  // COD (ojph_params.cpp:1035-1078)
+  bool prec = p.precinct_w && p.precinct_h;
+  s.u16(COD); s.u16(12 + (prec ? 1 + p.num_decomps : 0));
+  s.u8(prec ? 1 : 0); s.u8(p.prog_order); s.u16(1); s.u8(p.color_transform ? 1 : 0);
+  s.u8(p.num_decomps);
+  uint32_t lbw = 0, lbh = 0; while ((1u << lbw) < p.block_w) ++lbw; while ((1u << lbh) < p.block_h) ++lbh;
+  s.u8(lbw - 2); s.u8(lbh - 2); s.u8(0x40); s.u8(p.reversible ? 1 : 0);
+  if (prec) {
+    uint32_t a = 0, b = 0; while ((1u << a) < p.precinct_w) ++a; while ((1u << b) < p.precinct_h) ++b;
+    for (uint32_t i = 0; i <= p.num_decomps; ++i) s.u8(a | (b << 4));
+  }
+  // QCD (ojph_params.cpp:1778-1819)
+  uint32_t nb = 1 + 3 * p.num_decomps;
+  s.u16(QCD);
+  if (p.reversible) { s.u16(3 + nb); s.u8(P.sqcd); for (uint8_t e : P.spqcd8) s.u8(e); }
+  else { s.u16(3 + 2 * nb); s.u8(P.sqcd); for (uint16_t e : P.spqcd16) s.u16(e); }
+  // COM: the reference identifies itself; byte-identical output needs the same string
+  // (ojph_codestream_local.cpp:678-696)
+  static const char ver[] = "OpenJPH Ver 0.31.0.";
+  s.u16(COM); s.u16((uint32_t)strlen(ver) + 4); s.u16(1); s.bytes(ver, strlen(ver));
+}
+
+// Encodes the header of one packet (one precinct).  Returns false for an empty packet.
+bool write_packet_header(const Plan& P, const Precinct& pc, const ojphgpu_coded_block* cb,
+                         std::vector<uint8_t>& hdr, uint64_t& body_bytes)
+{
+  const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
+  HeaderBits bb(hdr);
+  bool started = false; int skipped = 0;
+  body_bytes = 0;
+  for (int s = 0; s < 4; ++s) {
+    if (R.band[s] < 0) continue;
+    const Band& B = P.bands[(size_t)R.band[s]];
+    if (B.empty) continue;
+    const Rect& q = pc.cb[s];
+    if (q.w == 0 || q.h == 0) continue;
+    uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
+    TagTree inc, incf, mm, mmf;
+    inc.init(q.w, q.h, levels, 255); incf.init(q.w, q.h, levels, 0);
+    mm.init(q.w, q.h, levels, 255); mmf.init(q.w, q.h, levels, 0);
+    auto blk = [&](uint32_t x, uint32_t y) -> const ojphgpu_coded_block& {
+      return cb[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
+    };
+    for (uint32_t y = 0; y < q.h; ++y)
+      for (uint32_t x = 0; x < q.w; ++x) {
+        const ojphgpu_coded_block& k = blk(x, y);
+        inc.at(x, y, 0) = (k.len1 == 0) ? 1 : 0;
+        mm.at(x, y, 0) = (uint8_t)(k.len1 ? k.missing_msbs : 0);
+      }
+    for (uint32_t l = 1; l < levels; ++l) {
+      uint32_t hh = (q.h + (1u << l) - 1) >> l, ww = (q.w + (1u << l) - 1) >> l;
+      for (uint32_t y = 0; y < hh; ++y)
+        for (uint32_t x = 0; x < ww; ++x) {
+          uint8_t a = std::min(std::min(inc.at(2 * x, 2 * y, l - 1), inc.at(2 * x + 1, 2 * y, l - 1)),
+                               std::min(inc.at(2 * x, 2 * y + 1, l - 1), inc.at(2 * x + 1, 2 * y + 1, l - 1)));
+          uint8_t b = std::min(std::min(mm.at(2 * x, 2 * y, l - 1), mm.at(2 * x + 1, 2 * y, l - 1)),
+                               std::min(mm.at(2 * x, 2 * y + 1, l - 1), mm.at(2 * x + 1, 2 * y + 1, l - 1)));
+          inc.at(x, y, l) = a; mm.at(x, y, l) = b;
+        }
+    }
+    if (inc.at(0, 0, levels - 1) != 0) {           // no block of this band is coded
+      if (started) bb.bit(0); else ++skipped;
+      continue;
+    }
+    if (!started) { started = true; bb.bit(1); bb.zeros(skipped); skipped = 0; }
+    for (uint32_t y = 0; y < q.h; ++y)
+      for (uint32_t x = 0; x < q.w; ++x) {
+        const ojphgpu_coded_block& k = blk(x, y);
+        for (uint32_t cl = levels; cl > 0; --cl) {   // inclusion
+          uint32_t l = cl - 1;
+          if (incf.at(x >> l, y >> l, l) == 0) {
+            uint32_t sk = (uint32_t)inc.at(x >> l, y >> l, l) - (uint32_t)inc.at(x >> cl, y >> cl, cl);
+            bb.bit(1 - sk);
+            incf.at(x >> l, y >> l, l) = 1;
+          }
+          if (inc.at(x >> l, y >> l, l) > 0) break;
+        }
+        if (k.len1 == 0) continue;
+        for (uint32_t cl = levels; cl > 0; --cl) {   // missing MSBs
+          uint32_t l = cl - 1;
+          if (mmf.at(x >> l, y >> l, l) == 0) {
+            int nz = (int)mm.at(x >> l, y >> l, l) - (int)mm.at(x >> cl, y >> cl, cl);
+            bb.zeros(nz); bb.bit(1);
+            mmf.at(x >> l, y >> l, l) = 1;
+          }
+        }
+        uint32_t np = k.num_passes ? k.num_passes : 1;
+        if (np == 3) bb.bits(12, 4); else if (np == 2) bb.bits(2, 2); else bb.bits(0, 1);
+        int bits1 = bitlen(k.len1), extra = np > 2 ? 1 : 0, bits2 = np > 1 ? bitlen(k.len2) : 0;
+        int nb = std::max(std::max(bits1, bits2 - extra) - 3, 0);
+        bb.bits(0xFFFFFFFEu, nb + 1);
+        bb.bits(k.len1, nb + 3);
+        if (np > 1) bb.bits(k.len2, nb + 3 + extra);
+        body_bytes += (uint64_t)k.len1 + k.len2;
+      }
+  }
+  if (started) bb.terminate();
+  return started;
+}
+
+}  // namespace
+
+}  // namespace ojphgpu
+
+using namespace ojphgpu;
+
+extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
+                                 const ojphgpu_coded_block* cb, uint8_t* out, size_t cap,
+                                 size_t* out_len)
+{
+  if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  ByteSink hdr;
+  write_main_header(P, hdr);
+
+  // per tile: packet headers first (sizes are needed for Psot / TLM)
+  struct Pkt { std::vector<uint8_t> hdr; bool coded; };
+  std::vector<std::vector<Pkt>> tile_pkts(P.tiles.size());
+  std::vector<uint64_t> tile_bytes(P.tiles.size(), 0);
+  for (size_t t = 0; t < P.tiles.size(); ++t) {
+    const Tile& T = P.tiles[t];
+    tile_pkts[t].resize(T.packets.size());
+    for (size_t i = 0; i < T.packets.size(); ++i) {
+      Pkt& k = tile_pkts[t][i]; uint64_t body = 0;
+      k.coded = write_packet_header(P, P.precincts[T.packets[i]], cb, k.hdr, body);
+      tile_bytes[t] += k.coded ? k.hdr.size() + body : 1;
+    }
+  }
+  size_t total = hdr.v.size() + 2;
+  if (P.p.tlm) total += 6 + 6 * P.tiles.size();
+  for (size_t t = 0; t < P.tiles.size(); ++t) total += 14 + tile_bytes[t];
+  *out_len = total;
+  if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
+
+  uint8_t* w = out;
+  memcpy(w, hdr.v.data(), hdr.v.size()); w += hdr.v.size();
+  auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
+  auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
+  if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
+    u16(TLM); u16(4 + 6 * (uint32_t)P.tiles.size()); *w++ = 0; *w++ = 0x60;
+    for (size_t t = 0; t < P.tiles.size(); ++t) { u16((uint32_t)t); u32((uint32_t)tile_bytes[t] + 14); }
+  }
+  for (size_t t = 0; t < P.tiles.size(); ++t) {
+    const Tile& T = P.tiles[t];
+    u16(SOT); u16(10); u16(T.idx); u32((uint32_t)tile_bytes[t] + 14); *w++ = 0; *w++ = 1;
+    u16(SOD);
+    for (size_t i = 0; i < T.packets.size(); ++i) {
+      const Pkt& k = tile_pkts[t][i];
+      if (!k.coded) { *w++ = 0; continue; }
+      memcpy(w, k.hdr.data(), k.hdr.size()); w += k.hdr.size();
+      const Precinct& pc = P.precincts[T.packets[i]];
+      const Resolution& R = P.ress[P.tcomps[T.comps[pc.comp]].res[pc.res]];
+      for (int s = 0; s < 4; ++s) {
+        if (R.band[s] < 0) continue;
+        const Band& B = P.bands[(size_t)R.band[s]];
+        if (B.empty) continue;
+        const Rect& q = pc.cb[s];
+        for (uint32_t y = 0; y < q.h; ++y)
+          for (uint32_t x = 0; x < q.w; ++x) {
+            const ojphgpu_coded_block& b = cb[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
+            size_t n = (size_t)b.len1 + b.len2;
+            if (n) { memcpy(w, data + b.offset, n); w += n; }
+          }
+      }
+    }
+  }
+  u16(EOC);
+  return (size_t)(w - out) == total ? OJPHGPU_OK : OJPHGPU_E_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parsing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Reader {
+  const uint8_t* d; size_t n, pos;
+  bool ok(size_t k) const { return pos + k <= n; }
+  uint32_t u8() { return d[pos++]; }
+  uint32_t u16() { uint32_t v = ((uint32_t)d[pos] << 8) | d[pos + 1]; pos += 2; return v; }
+  uint32_t u32() { uint32_t v = u16(); return (v << 16) | u16(); }
+};
+
+struct HeaderReader {      // ojph_bitbuffer_read.h:66-176
+  const uint8_t* d; size_t pos, end;
+  uint32_t tmp = 0; int avail = 0; bool unstuff = false; bool exhausted = false;
+  bool fill() {
+    if (pos < end) { uint8_t t = d[pos++]; tmp = t; avail = 8 - (unstuff ? 1 : 0); unstuff = (t == 0xFF); return true; }
+    tmp = 0; avail = 8 - (unstuff ? 1 : 0); unstuff = false; exhausted = true; return false;
+  }
+  bool bit(uint32_t& b) { bool r = true; if (avail == 0) r = fill(); b = (tmp >> --avail) & 1; return r; }
+  bool bits(int n, uint32_t& v) {
+    v = 0; bool r = true;
+    while (n) {
+      if (avail == 0) r = fill();
+      int t = std::min(avail, n);
+      v <<= t; avail -= t; n -= t; v |= (tmp >> avail) & ((1u << t) - 1);
+    }
+    return r;
+  }
+  void terminate() { if (unstuff) fill(); tmp = 0; avail = 0; }
+};
+
+}  // namespace
+
+// Parses one packet starting at d[pos]; fills coded[] for the blocks of the precinct.
+// Returns 0, or OJPHGPU_E_CODESTREAM.
+static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end,
+                        bool use_sop, bool use_eph)
+{
+  const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
+  if (use_sop && pos + 6 <= end && d[pos] == 0xFF && d[pos + 1] == 0x91) pos += 6;
+  HeaderReader bb{ d, pos, end };
+  bool empty_packet = true;
+  for (int s = 0; s < 4; ++s) {
+    if (R.band[s] < 0) continue;
+    const Band& B = P.bands[(size_t)R.band[s]];
+    if (B.empty) continue;
+    const Rect& q = pc.cb[s];
+    if (q.w == 0 || q.h == 0) continue;
+    if (empty_packet) {
+      uint32_t b; bb.bit(b);
+      if (b == 0) { bb.terminate(); pos = bb.pos; if (use_eph && pos + 2 <= end) pos += 2; return 0; }
+      empty_packet = false;
+    }
+    uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
+    TagTree inc, incf, mm, mmf;
+    inc.init(q.w, q.h, levels, 0); incf.init(q.w, q.h, levels, 0);
+    mm.init(q.w, q.h, levels, 0); mmf.init(q.w, q.h, levels, 0);
+    for (uint32_t y = 0; y < q.h; ++y)
+      for (uint32_t x = 0; x < q.w; ++x) {
+        CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
+        bool empty_cb = false;
+        for (uint32_t cl = levels; cl > 0; --cl) {
+          uint32_t l = cl - 1;
+          empty_cb = inc.at(x >> l, y >> l, l) == 1;
+          if (empty_cb) break;
+          if (incf.at(x >> l, y >> l, l) == 0) {
+            uint32_t b; if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+            empty_cb = (b == 0);
+            inc.at(x >> l, y >> l, l) = (uint8_t)(1 - b);
+            incf.at(x >> l, y >> l, l) = 1;
+          }
+          if (empty_cb) break;
+        }
+        if (empty_cb) continue;
+        uint32_t mmsbs = 0;
+        for (uint32_t cl = levels; cl > 0; --cl) {
+          uint32_t l = cl - 1;
+          mmsbs = mm.at(x >> cl, y >> cl, cl);
+          if (mmf.at(x >> l, y >> l, l) == 0) {
+            uint32_t b = 0;
+            while (b == 0) { if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM; mmsbs += 1 - b; }
+            mm.at(x >> l, y >> l, l) = (uint8_t)mmsbs;
+            mmf.at(x >> l, y >> l, l) = 1;
+          } else mmsbs = mm.at(x >> l, y >> l, l);
+        }
+        if (mmsbs > B.K_max) return OJPHGPU_E_CODESTREAM;
+        uint32_t b, np = 1;
+        if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+        if (b) {
+          np = 2; if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+          if (b) {
+            if (!bb.bits(2, b)) return OJPHGPU_E_CODESTREAM;
+            np = 3 + b;
+            if (b == 3) {
+              if (!bb.bits(5, b)) return OJPHGPU_E_CODESTREAM;
+              np = 6 + b;
+              if (b == 31) { if (!bb.bits(7, b)) return OJPHGPU_E_CODESTREAM; np = 37 + b; }
+            }
+          }
+        }
+        uint32_t phld = (np - 1) / 3;
+        k.missing_msbs = mmsbs + phld;
+        phld *= 3;
+        k.num_passes = np - phld;
+        int Lblock = 3; b = 1;
+        while (b) { if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM; Lblock += (int)b; }
+        int nbits = Lblock + 31 - __builtin_clz(phld + 1);
+        if (!bb.bits(nbits, b)) return OJPHGPU_E_CODESTREAM;
+        if (b < 2 || b >= 65535) return OJPHGPU_E_CODESTREAM;
+        k.len1 = b; k.len2 = 0;
+        if (k.num_passes > 1) {
+          nbits = Lblock + (k.num_passes > 2 ? 1 : 0);
+          if (!bb.bits(nbits, b)) return OJPHGPU_E_CODESTREAM;
+          if (b >= 2047) return OJPHGPU_E_CODESTREAM;
+          k.len2 = b;
+        }
+      }
+  }
+  if (empty_packet) { uint32_t b; bb.bit(b); }
+  bb.terminate();
+  pos = bb.pos;
+  if (use_eph && pos + 2 <= end && d[pos] == 0xFF && d[pos + 1] == 0x92) pos += 2;
+  // body
+  for (int s = 0; s < 4; ++s) {
+    if (R.band[s] < 0) continue;
+    const Band& B = P.bands[(size_t)R.band[s]];
+    if (B.empty) continue;
+    const Rect& q = pc.cb[s];
+    for (uint32_t y = 0; y < q.h; ++y)
+      for (uint32_t x = 0; x < q.w; ++x) {
+        CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
+        size_t nbytes = (size_t)k.len1 + k.len2;
+        if (!nbytes) continue;
+        if (pos + nbytes > end) { k.len1 = k.len2 = 0; k.num_passes = 0; pos = end; return OJPHGPU_E_CODESTREAM; }
+        k.offset = pos; pos += nbytes;
+      }
+  }
+  return 0;
+}
+
+extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
+{
+  if (!d || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  Reader r{ d, len, 0 };
+  if (!r.ok(2) || r.u16() != SOC) return OJPHGPU_E_CODESTREAM;
+  ojphgpu_params p; memset(&p, 0, sizeof(p));
+  bool have_siz = false, have_cod = false, have_qcd = false;
+  uint8_t scod = 0, sqcd = 0; std::vector<uint8_t> q8; std::vector<uint16_t> q16;
+  bool use_sop = false, use_eph = false;
+  for (;;) {
+    if (!r.ok(4)) return OJPHGPU_E_CODESTREAM;
+    uint32_t m = r.u16();
+    if (m == SOT) { r.pos -= 2; break; }
+    uint32_t L = r.u16();
+    if (L < 2 || !r.ok(L - 2)) return OJPHGPU_E_CODESTREAM;
+    size_t next = r.pos + L - 2;
+    if (m == SIZ) {
+      uint32_t rsiz = r.u16();
+      if ((rsiz & 0x4000) == 0) return OJPHGPU_E_CODESTREAM;      // not an HTJ2K codestream
+      p.width = r.u32(); p.height = r.u32();
+      uint32_t xo = r.u32(), yo = r.u32();
+      p.tile_w = r.u32(); p.tile_h = r.u32();
+      uint32_t txo = r.u32(), tyo = r.u32();
+      if (xo || yo || txo || tyo) return OJPHGPU_E_INVALID;        // image / tile offsets: not supported yet
+      p.num_comps = r.u16();
+      if (L != 38 + 3 * p.num_comps || p.num_comps == 0) return OJPHGPU_E_CODESTREAM;
+      for (uint32_t c = 0; c < p.num_comps; ++c) {
+        uint32_t ss = r.u8(), xr = r.u8(), yr = r.u8();
+        uint32_t bd = (ss & 0x7F) + 1, sg = ss >> 7;
+        if (xr != 1 || yr != 1) return OJPHGPU_E_INVALID;         // sub-sampled components: not supported yet
+        if (c == 0) { p.bit_depth = bd; p.is_signed = sg; }
+        else if (bd != p.bit_depth || sg != p.is_signed) return OJPHGPU_E_INVALID;
+      }
+      have_siz = true;
+    } else if (m == COD) {
+      scod = (uint8_t)r.u8(); p.prog_order = r.u8();
+      uint32_t layers = r.u16(); p.color_transform = r.u8();
+      p.num_decomps = r.u8(); uint32_t xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
+      if (layers != 1) return OJPHGPU_E_INVALID;
+      if ((style & 0x40) == 0) return OJPHGPU_E_CODESTREAM;       // not HT code-blocks
+      if (style & ~0x48u) return OJPHGPU_E_INVALID;               // only HT (+ vertically causal) styles
+      if (wt > 1) return OJPHGPU_E_INVALID;                       // ATK wavelets: not supported
+      p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
+      use_sop = scod & 2; use_eph = scod & 4;
+      if (scod & 1) {
+        uint32_t pw = 0, ph = 0;
+        for (uint32_t i = 0; i <= p.num_decomps; ++i) {
+          uint32_t v = r.u8();
+          if (i == 0) { pw = v & 0xF; ph = v >> 4; }
+          else if ((v & 0xF) != pw || (v >> 4) != ph) return OJPHGPU_E_INVALID;   // per-resolution precincts: later
+        }
+        p.precinct_w = 1u << pw; p.precinct_h = 1u << ph;
+      }
+      have_cod = true;
+    } else if (m == QCD) {
+      sqcd = (uint8_t)r.u8();
+      uint32_t n = L - 3;
+      if ((sqcd & 0x1F) == 0) for (uint32_t i = 0; i < n; ++i) q8.push_back((uint8_t)r.u8());
+      else if ((sqcd & 0x1F) == 2) for (uint32_t i = 0; i < n / 2; ++i) q16.push_back((uint16_t)r.u16());
+      else return OJPHGPU_E_INVALID;                              // scalar derived: not supported
+      have_qcd = true;
+    } else if (m == TLM) {
+      p.tlm = 1;
+    } else if (m == COC || m == QCC || m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
+      return OJPHGPU_E_INVALID;                                    // per-component / Part-2 markers: later
+    }
+    r.pos = next;
+  }
+  if (!have_siz || !have_cod || !have_qcd) return OJPHGPU_E_CODESTREAM;
+  if (p.tile_w >= p.width && p.tile_h >= p.height) { /* single tile */ }
+  ojphgpu_plan* h = new (std::nothrow) ojphgpu_plan();
+  if (!h) return OJPHGPU_E_NOMEM;
+  ojphgpu_params pp = p;
+  if (pp.tile_w > pp.width) pp.tile_w = pp.width;     // geometry is identical; markers keep the original
+  if (pp.tile_h > pp.height) pp.tile_h = pp.height;
+  int rc = build_plan(pp, h->plan);
+  if (rc != OJPHGPU_OK) { delete h; return rc; }
+  Plan& P = h->plan;
+  P.p.tile_w = p.tile_w; P.p.tile_h = p.tile_h;
+  // the codestream's own quantisation parameters override the derived ones
+  P.sqcd = sqcd; P.guard_bits = sqcd >> 5;
+  if (p.reversible) { if ((sqcd & 0x1F) != 0 || q8.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.spqcd8 = q8; }
+  else { if ((sqcd & 0x1F) != 2 || q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.spqcd16 = q16; }
+  for (Band& B : P.bands) {
+    B.K_max = band_Kmax(P, B.res, B.band);
+    if (!p.reversible) {
+      float dlt = band_delta(P, B.res, B.band);
+      dlt /= (float)(1u << (31 - B.K_max));
+      B.delta = dlt; B.delta_inv = 1.0f / dlt;
+    }
+  }
+  P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
+  std::vector<size_t> next_pkt(P.tiles.size(), 0);
+  int status = OJPHGPU_OK;
+  // tile-parts
+  for (;;) {
+    if (!r.ok(2)) { status = OJPHGPU_E_CODESTREAM; break; }
+    size_t sot_pos = r.pos;
+    uint32_t m = r.u16();
+    if (m == EOC) break;
+    if (m != SOT || !r.ok(10)) { status = OJPHGPU_E_CODESTREAM; break; }
+    uint32_t lsot = r.u16(), isot = r.u16(), psot = r.u32(); r.u8(); r.u8();
+    if (lsot != 10 || isot >= P.tiles.size()) { status = OJPHGPU_E_CODESTREAM; break; }
+    size_t tp_end = psot ? sot_pos + psot : (len >= 2 ? len - 2 : len);
+    if (tp_end > len) { tp_end = len; status = OJPHGPU_E_CODESTREAM; }
+    bool bad = false;
+    for (;;) {                                   // tile-part header markers up to SOD
+      if (!r.ok(2)) { bad = true; break; }
+      uint32_t mk = r.u16();
+      if (mk == SOD) break;
+      if (!r.ok(2)) { bad = true; break; }
+      uint32_t L = r.u16();
+      if (L < 2 || !r.ok(L - 2)) { bad = true; break; }
+      if (mk != PLT && mk != COM) { delete h; return OJPHGPU_E_INVALID; }
+      r.pos += L - 2;
+    }
+    if (bad) { status = OJPHGPU_E_CODESTREAM; break; }
+    const Tile& T = P.tiles[isot];
+    size_t pos = r.pos;
+    while (pos < tp_end && next_pkt[isot] < T.packets.size()) {
+      int prc = parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], d, pos, tp_end, use_sop, use_eph);
+      next_pkt[isot]++;
+      if (prc != 0) { status = prc; break; }
+    }
+    r.pos = tp_end;
+    if (status != OJPHGPU_OK) break;
+  }
+  if (status != OJPHGPU_OK && !resilient) { delete h; return status; }
+  *out = h;
+  return OJPHGPU_OK;
+}

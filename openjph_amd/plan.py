@@ -1,0 +1,97 @@
+"""Host-side plan + Tier-2 wrappers over the C ABI (numpy views of the plan tables)."""
+import ctypes as C
+import numpy as np
+
+from . import capi
+from .capi import Params, BandInfo, BlockInfo, LevelInfo, CodedBlock, check, PROG_ORDERS
+
+band_dtype = np.dtype(BandInfo)
+block_dtype = np.dtype(BlockInfo)
+level_dtype = np.dtype(LevelInfo)
+coded_dtype = np.dtype(CodedBlock)
+
+
+def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
+                num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
+                prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False):
+    p = Params()
+    p.width, p.height, p.num_comps = width, height, num_comps
+    p.bit_depth, p.is_signed = bit_depth, int(is_signed)
+    p.reversible, p.num_decomps = int(reversible), num_decomps
+    p.block_w, p.block_h = block
+    p.color_transform = int(color_transform)
+    p.tile_w, p.tile_h = tile
+    p.prog_order = PROG_ORDERS[prog_order] if isinstance(prog_order, str) else int(prog_order)
+    p.qstep = float(qstep)
+    p.precinct_w, p.precinct_h = precinct
+    p.tlm = int(tlm)
+    return p
+
+
+class Plan:
+    """Owns an ojphgpu_plan*. Tables are exposed as numpy structured arrays."""
+
+    def __init__(self, params=None, handle=None):
+        self._lib = capi.lib()
+        if handle is None:
+            h = C.c_void_p()
+            check(self._lib.ojphgpu_plan_create(C.byref(params), C.byref(h)), "plan_create")
+            handle = h
+        self.handle = handle
+        cnt = (C.c_uint64 * 8)()
+        check(self._lib.ojphgpu_plan_counts(self.handle, cnt))
+        (self.num_tiles, self.num_bands, self.num_blocks, self.num_levels, self.arena_elems,
+         self.max_block_bytes, self.num_precincts, self.num_tcomps) = [int(v) for v in cnt]
+        self.params = Params()
+        check(self._lib.ojphgpu_plan_params(self.handle, C.byref(self.params)))
+        self.bands = np.zeros(self.num_bands, band_dtype)
+        self.blocks = np.zeros(self.num_blocks, block_dtype)
+        self.levels = np.zeros(self.num_levels, level_dtype)
+        if self.num_bands:
+            check(self._lib.ojphgpu_plan_bands(self.handle, self.bands.ctypes.data, self.num_bands))
+        if self.num_blocks:
+            check(self._lib.ojphgpu_plan_blocks(self.handle, self.blocks.ctypes.data, self.num_blocks))
+        if self.num_levels:
+            check(self._lib.ojphgpu_plan_levels(self.handle, self.levels.ctypes.data, self.num_levels))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.ojphgpu_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def comp_plane(self, tile, comp):
+        off, pitch, rect = C.c_uint64(), C.c_uint32(), (C.c_uint32 * 4)()
+        check(self._lib.ojphgpu_plan_comp_plane(self.handle, tile, comp, C.byref(off), C.byref(pitch), rect))
+        return int(off.value), int(pitch.value), tuple(int(v) for v in rect)
+
+    def coded_blocks(self):
+        out = np.zeros(self.num_blocks, coded_dtype)
+        check(self._lib.ojphgpu_plan_coded_blocks(self.handle, out.ctypes.data, self.num_blocks))
+        return out
+
+    def t2_write(self, block_data: np.ndarray, coded: np.ndarray) -> bytes:
+        """block_data: uint8 array; coded: coded_dtype array (offset/len1/...) in plan order."""
+        block_data = np.ascontiguousarray(block_data, dtype=np.uint8)
+        coded = np.ascontiguousarray(coded, dtype=coded_dtype)
+        need = C.c_size_t()
+        cap = int(block_data.size + 64 * self.num_blocks + 4096 * (self.num_tiles + 1) + (1 << 16))
+        out = np.empty(cap, np.uint8)
+        rc = self._lib.ojphgpu_t2_write(self.handle, block_data.ctypes.data, coded.ctypes.data,
+                                        out.ctypes.data, cap, C.byref(need))
+        if rc == capi.E_OVERFLOW:
+            cap = int(need.value)
+            out = np.empty(cap, np.uint8)
+            rc = self._lib.ojphgpu_t2_write(self.handle, block_data.ctypes.data, coded.ctypes.data,
+                                            out.ctypes.data, cap, C.byref(need))
+        check(rc, "t2_write")
+        return out[:need.value].tobytes()
+
+
+def parse_codestream(data: bytes, resilient=False) -> Plan:
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h = C.c_void_p()
+    check(capi.lib().ojphgpu_t2_parse(buf.ctypes.data, len(data), int(resilient), C.byref(h)), "t2_parse")
+    return Plan(handle=h)

@@ -1,0 +1,172 @@
+"""CPU model of the whole encode / decode path, glued from the ORACLE stages (oracle/) and the
+product's host-side plan + Tier-2 (through the C ABI).  Test infrastructure only: it exists so
+that (a) the oracle, the plan geometry and the Tier-2 writer/parser can be pinned against the
+real reference codestream byte for byte without a GPU, and (b) the GPU stages have an exact
+stage-by-stage expectation on the GPU box.
+"""
+import numpy as np
+
+from openjph_amd.plan import Plan, make_params, parse_codestream, coded_dtype
+from oracle import oraclebind as ob
+
+
+def _view(arena, off, pitch, w, h, dtype):
+    a = arena.view(dtype)
+    return np.lib.stride_tricks.as_strided(a[off:], shape=(h, w), strides=(pitch * 4, 4))
+
+
+def forward_stages(plan: Plan, image: np.ndarray):
+    """image: int32 [C,H,W]. Returns the arena (uint32) after convert + all DWT levels."""
+    p = plan.params
+    rev = bool(p.reversible)
+    dt = np.int32 if rev else np.float32
+    arena = np.zeros(plan.arena_elems, np.uint32)
+    lib = ob.lib()
+    for t in range(plan.num_tiles):
+        planes = []
+        for c in range(p.num_comps):
+            off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
+            src = np.ascontiguousarray(image[c, y0:y0 + h, x0:x0 + w], dtype=np.int32)
+            if rev:
+                shift = 0 if p.is_signed else -(1 << (p.bit_depth - 1))
+                dst = src + shift
+            else:
+                dst = np.empty(src.shape, np.float32)
+                lib.ojo_irv_to_float(src.ctypes.data, dst.ctypes.data, src.size, p.bit_depth, int(p.is_signed))
+            planes.append((off, pitch, w, h, dst))
+        if p.color_transform:
+            r, g, b = [np.ascontiguousarray(pl[4]) for pl in planes[:3]]
+            y = np.empty_like(r); cb = np.empty_like(r); cr = np.empty_like(r)
+            f = lib.ojo_rct_fwd if rev else lib.ojo_ict_fwd
+            f(r.ctypes.data, g.ctypes.data, b.ctypes.data, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.size)
+            for i, v in enumerate((y, cb, cr)):
+                planes[i] = planes[i][:4] + (v,)
+        for off, pitch, w, h, v in planes:
+            _view(arena, off, pitch, w, h, dt)[:] = v
+    for lv in plan.levels:
+        w, h = int(lv["w"]), int(lv["h"])
+        if w == 0 or h == 0:
+            continue
+        src = np.ascontiguousarray(_view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt))
+        xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
+        ll, hl, lh, hh = (ob.dwt53_fwd if rev else ob.dwt97_fwd)(src, xe, ye)
+        for name, b in (("ll", ll), ("hl", hl), ("lh", lh), ("hh", hh)):
+            if b.size:
+                _view(arena, int(lv[name + "_off"]), int(lv[name + "_pitch"]), b.shape[1], b.shape[0], dt)[:] = b
+    return arena
+
+
+def quantise_block(plan, arena, k):
+    """Returns (sign-magnitude uint32 block [h, stride], stride) for block index k."""
+    blk = plan.blocks[k]
+    band = plan.bands[int(blk["band"])]
+    w, h = int(blk["w"]), int(blk["h"])
+    off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
+    rev = bool(plan.params.reversible)
+    raw = np.ascontiguousarray(_view(arena, off, int(band["pitch"]), w, h, np.int32 if rev else np.float32))
+    if rev:
+        q, mx = ob.quant_rev(raw, int(band["K_max"]))
+    else:
+        q, mx = ob.quant_irv(raw, float(band["delta_inv"]))
+    return q, mx
+
+
+def encode_blocks(plan: Plan, arena):
+    """HT-encodes every block with the oracle. Returns (data bytes, coded table)."""
+    coded = np.zeros(plan.num_blocks, coded_dtype)
+    chunks = []
+    pos = 0
+    for k in range(plan.num_blocks):
+        blk = plan.blocks[k]
+        K = int(blk["K_max"])
+        q, mx = quantise_block(plan, arena, k)
+        if mx >= (1 << (31 - K)):                       # ojph_codeblock.cpp:146-158
+            w, h = int(blk["w"]), int(blk["h"])
+            b = ob.ht_encode(q, w, h, w, K - 1)
+            assert len(b) > 0
+            coded[k] = (pos, len(b), 0, K - 1, 1)
+            chunks.append(b); pos += len(b)
+    data = np.frombuffer(b"".join(chunks) if chunks else b"", dtype=np.uint8)
+    return data, coded
+
+
+def encode(image, **kw):
+    image = np.ascontiguousarray(image, dtype=np.int32)
+    nc, h, w = image.shape
+    plan = Plan(make_params(w, h, nc, **kw))
+    arena = forward_stages(plan, image)
+    data, coded = encode_blocks(plan, arena)
+    return plan.t2_write(data, coded), plan, arena, data, coded
+
+
+def decode_blocks(plan: Plan, cs: bytes):
+    """Oracle HT decode + dequantise of every block into a fresh arena."""
+    coded = plan.coded_blocks()
+    rev = bool(plan.params.reversible)
+    arena = np.zeros(plan.arena_elems, np.uint32)
+    buf = np.frombuffer(cs, dtype=np.uint8)
+    for k in range(plan.num_blocks):
+        cbk = coded[k]
+        if cbk["len1"] == 0:
+            continue
+        blk = plan.blocks[k]
+        band = plan.bands[int(blk["band"])]
+        w, h = int(blk["w"]), int(blk["h"])
+        o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
+        ok, sm = ob.ht_decode(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
+                              len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]))
+        if not ok:
+            raise RuntimeError("oracle failed to decode block %d" % k)
+        off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
+        if rev:
+            _view(arena, off, int(band["pitch"]), w, h, np.int32)[:] = ob.dequant_rev(sm, int(band["K_max"]))
+        else:
+            _view(arena, off, int(band["pitch"]), w, h, np.float32)[:] = ob.dequant_irv(sm, float(band["delta"]))
+    return arena
+
+
+def inverse_stages(plan: Plan, arena):
+    p = plan.params
+    rev = bool(p.reversible)
+    dt = np.int32 if rev else np.float32
+    lib = ob.lib()
+    for lv in plan.levels[::-1]:
+        w, h = int(lv["w"]), int(lv["h"])
+        if w == 0 or h == 0:
+            continue
+        xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
+        lw, hw, lh_, hh_ = ob.band_dims(w, h, xe, ye)
+        ll = _view(arena, int(lv["ll_off"]), int(lv["ll_pitch"]), lw, lh_, dt)
+        hl = _view(arena, int(lv["hl_off"]), int(lv["hl_pitch"]), hw, lh_, dt)
+        lh = _view(arena, int(lv["lh_off"]), int(lv["lh_pitch"]), lw, hh_, dt)
+        hh = _view(arena, int(lv["hh_off"]), int(lv["hh_pitch"]), hw, hh_, dt)
+        dst = (ob.dwt53_inv if rev else ob.dwt97_inv)(ll, hl, lh, hh, w, h, xe, ye)
+        _view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt)[:] = dst
+    image = np.zeros((p.num_comps, p.height, p.width), np.int32)
+    for t in range(plan.num_tiles):
+        planes = []
+        for c in range(p.num_comps):
+            off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
+            planes.append(np.ascontiguousarray(_view(arena, off, pitch, w, h, dt)))
+        if p.color_transform:
+            y, cb, cr = planes[:3]
+            r = np.empty_like(y); g = np.empty_like(y); b = np.empty_like(y)
+            f = lib.ojo_rct_inv if rev else lib.ojo_ict_inv
+            f(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.ctypes.data, g.ctypes.data, b.ctypes.data, y.size)
+            planes[:3] = [r, g, b]
+        for c in range(p.num_comps):
+            off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
+            v = planes[c]
+            if rev:
+                out = v + (0 if p.is_signed else (1 << (p.bit_depth - 1)))
+            else:
+                out = np.empty(v.shape, np.int32)
+                lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, p.bit_depth, int(p.is_signed))
+            image[c, y0:y0 + h, x0:x0 + w] = out
+    return image
+
+
+def decode(cs: bytes):
+    plan = parse_codestream(cs)
+    arena = decode_blocks(plan, cs)
+    return inverse_stages(plan, arena), plan
