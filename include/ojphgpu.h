@@ -175,11 +175,12 @@ int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
 
 /* K9 + K7: HT decoder (ojph_block_decoder32.cpp:742-1613) with the dequantise transfer
  * (ojph_codestream_gen.cpp:124-168) fused.  One wavefront per code-block.  d_block_status[i]
- * = 0 ok / 1 failed (block zeroed), mirroring the bool of decode_cb32.  lds_bytes_hint = max
- * over blocks of len1 (sizes the per-wave LDS). */
+ * = 0 ok / non-zero failed (block zeroed), mirroring the bool of decode_cb32.  max_len1 = max
+ * over blocks of len1 and nominal_w x nominal_h = the nominal code-block size (they size the
+ * per-wave LDS: flat MagSgn buffer and per-quad records). */
 int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                       const uint8_t* d_data, void* d_coef, uint8_t* d_block_status,
-                      uint32_t max_len1);
+                      uint32_t max_len1, uint32_t nominal_w, uint32_t nominal_h);
 
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */

@@ -1,0 +1,212 @@
+"""Python host-side wrapper of the GPU codec objects (C ABI sections 4 and 5).
+
+PyTorch is used only as plumbing: device memory (torch tensors on ``cuda:N``) and streams.  All
+arithmetic happens in the HIP kernels behind libojphgpu.so; there is no CPU fallback -- without the
+library or without a GPU these calls raise.
+"""
+import ctypes as C
+import numpy as np
+
+from . import capi
+from .capi import check, Params, DwtDesc, CbDesc, CbResult, ConvertDesc
+from .plan import Plan, make_params, parse_codestream
+
+dwt_desc_dtype = np.dtype(DwtDesc)
+cb_desc_dtype = np.dtype(CbDesc)
+cb_result_dtype = np.dtype(CbResult)
+convert_desc_dtype = np.dtype(ConvertDesc)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("openjph_amd: no GPU visible (torch.cuda.is_available() is False); "
+                           "the HTJ2K hot path has no CPU fallback")
+    return torch
+
+
+def _stream_ptr(torch, device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to_device(arr: np.ndarray, device=0):
+    """numpy (any dtype / structured) -> uint8 torch tensor on the device holding the same bytes."""
+    torch = _torch()
+    raw = np.frombuffer(np.ascontiguousarray(arr).tobytes(), dtype=np.uint8)
+    if raw.size == 0:
+        return torch.zeros(16, dtype=torch.uint8, device="cuda:%d" % device)
+    return torch.from_numpy(raw.copy()).to("cuda:%d" % device)
+
+
+class Encoder:
+    """Whole-frame encoder for one frame shape / parameter set (ojphgpu_encoder)."""
+
+    def __init__(self, params: Params = None, device=0, plan: Plan = None, **kw):
+        torch = _torch()
+        self.device = device
+        self.plan = plan if plan is not None else Plan(params if params is not None else make_params(**kw))
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(self._lib.ojphgpu_encoder_create(self.plan.handle, device, _stream_ptr(torch, device),
+                                                   C.byref(self._h)), "encoder_create")
+        p = self.plan.params
+        self.shape = (p.num_comps, p.height, p.width)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ojphgpu_encoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def run_device(self, d_image):
+        """d_image: int32 torch tensor [C,H,W] resident on the device. Asynchronous."""
+        assert d_image.is_cuda and d_image.dtype == _torch().int32 and tuple(d_image.shape) == self.shape
+        assert d_image.is_contiguous()
+        check(self._lib.ojphgpu_encoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device")
+
+    def coded_bytes(self):
+        n = C.c_uint64()
+        check(self._lib.ojphgpu_encoder_coded_bytes(self._h, C.byref(n)), "encoder_coded_bytes")
+        return int(n.value)
+
+    def finish(self) -> bytes:
+        p = self.plan.params
+        cap = int(p.width) * int(p.height) * int(p.num_comps) * 3 + (1 << 20)
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        rc = self._lib.ojphgpu_encoder_finish(self._h, out.ctypes.data, cap, C.byref(n))
+        if rc == capi.E_OVERFLOW and n.value > cap:
+            cap = int(n.value)
+            out = np.empty(cap, np.uint8)
+            rc = self._lib.ojphgpu_encoder_finish(self._h, out.ctypes.data, cap, C.byref(n))
+        check(rc, "encoder_finish")
+        return out[:n.value].tobytes()
+
+    def encode(self, image) -> bytes:
+        """image: numpy int32 [C,H,W] (host) or torch int32 tensor on the device."""
+        torch = _torch()
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
+        self.run_device(image)
+        return self.finish()
+
+    def timing(self):
+        t = (C.c_float * 4)()
+        check(self._lib.ojphgpu_encoder_timing(self._h, t), "encoder_timing")
+        return dict(convert_ms=t[0], dwt_ms=t[1], ht_ms=t[2], total_ms=t[3])
+
+
+class Decoder:
+    """Whole-frame decoder bound to one parsed codestream layout (ojphgpu_decoder)."""
+
+    def __init__(self, codestream: bytes, device=0, resilient=False):
+        torch = _torch()
+        self.device = device
+        self.resilient = resilient
+        self.plan = parse_codestream(codestream, resilient)
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(self._lib.ojphgpu_decoder_create(self.plan.handle, device, _stream_ptr(torch, device),
+                                                   C.byref(self._h)), "decoder_create")
+        p = self.plan.params
+        self.shape = (p.num_comps, p.height, p.width)
+        self.upload(codestream)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ojphgpu_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def upload(self, codestream: bytes):
+        buf = np.frombuffer(codestream, dtype=np.uint8)
+        check(self._lib.ojphgpu_decoder_upload(self._h, buf.ctypes.data, len(codestream)), "decoder_upload")
+        _torch().cuda.synchronize(self.device)   # the host buffer may go away after this call
+
+    def run_device(self, d_image=None):
+        torch = _torch()
+        if d_image is None:
+            d_image = torch.empty(self.shape, dtype=torch.int32, device="cuda:%d" % self.device)
+        check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
+        return d_image
+
+    def failed_blocks(self):
+        n = C.c_uint32()
+        check(self._lib.ojphgpu_decoder_failed_blocks(self._h, C.byref(n)), "decoder_failed_blocks")
+        return int(n.value)
+
+    def decode(self) -> np.ndarray:
+        img = self.run_device()
+        failed = self.failed_blocks()
+        if failed and not self.resilient:
+            raise capi.OjphError(capi.E_BLOCK, "%d code-blocks" % failed)   # ojph_codeblock.cpp:214-224
+        return img.cpu().numpy()
+
+    def timing(self):
+        t = (C.c_float * 4)()
+        check(self._lib.ojphgpu_decoder_timing(self._h, t), "decoder_timing")
+        return dict(ht_ms=t[0], dwt_ms=t[1], convert_ms=t[2], total_ms=t[3])
+
+
+def encode(image: np.ndarray, device=0, **kw) -> bytes:
+    """One-shot helper: image int32 [C,H,W]; keyword args as in plan.make_params (minus sizes)."""
+    nc, h, w = image.shape
+    return Encoder(make_params(w, h, nc, **kw), device=device).encode(image)
+
+
+def decode(codestream: bytes, device=0, resilient=False) -> np.ndarray:
+    return Decoder(codestream, device=device, resilient=resilient).decode()
+
+
+# -------------------------------------------------------------------------------------------------
+# stage-level entry points (used by the parity tests; same C ABI the codec objects call)
+# -------------------------------------------------------------------------------------------------
+def dwt(direction, reversible, descs: np.ndarray, arena, max_w, max_h):
+    """descs: dwt_desc_dtype array (host); arena: torch int32/float32/uint32 tensor on the device."""
+    torch = _torch()
+    dev = arena.device.index
+    d = to_device(descs, dev)
+    f = capi.lib().ojphgpu_dwt_forward if direction == "forward" else capi.lib().ojphgpu_dwt_inverse
+    check(f(_stream_ptr(torch, dev), int(reversible), C.c_void_p(d.data_ptr()), len(descs), max_w, max_h,
+            C.c_void_p(arena.data_ptr())), "dwt_" + direction)
+    torch.cuda.synchronize(dev)
+
+
+def ht_encode(descs: np.ndarray, coef, scratch_bytes, out_cap):
+    """Returns (results array, out bytes tensor (host numpy), status)."""
+    torch = _torch()
+    dev = coef.device.index
+    d = to_device(descs, dev)
+    scratch = torch.zeros(max(int(scratch_bytes), 16), dtype=torch.uint8, device=coef.device)
+    out = torch.zeros(max(int(out_cap), 16), dtype=torch.uint8, device=coef.device)
+    results = torch.zeros(len(descs) * 2 + 2, dtype=torch.int32, device=coef.device)
+    counters = torch.zeros(4, dtype=torch.int32, device=coef.device)
+    check(capi.lib().ojphgpu_ht_encode(_stream_ptr(torch, dev), C.c_void_p(d.data_ptr()), len(descs),
+                                       C.c_void_p(coef.data_ptr()), C.c_void_p(scratch.data_ptr()),
+                                       C.c_void_p(out.data_ptr()), int(out_cap), C.c_void_p(results.data_ptr()),
+                                       C.c_void_p(counters.data_ptr()), C.c_void_p(counters.data_ptr() + 4)),
+          "ht_encode")
+    torch.cuda.synchronize(dev)
+    res = results.cpu().numpy()[:len(descs) * 2].view(np.uint32).reshape(-1, 2)
+    cnt = counters.cpu().numpy().view(np.uint32)
+    return res, out.cpu().numpy()[:int(cnt[0])], int(cnt[1])
+
+
+def ht_decode(descs: np.ndarray, data: np.ndarray, coef, max_len1, nominal=(64, 64)):
+    torch = _torch()
+    dev = coef.device.index
+    d = to_device(descs, dev)
+    dd = to_device(np.concatenate([np.asarray(data, np.uint8), np.zeros(64, np.uint8)]), dev)
+    status = torch.zeros(len(descs) + 16, dtype=torch.uint8, device=coef.device)
+    check(capi.lib().ojphgpu_ht_decode(_stream_ptr(torch, dev), C.c_void_p(d.data_ptr()), len(descs),
+                                       C.c_void_p(dd.data_ptr()), C.c_void_p(coef.data_ptr()),
+                                       C.c_void_p(status.data_ptr()), int(max_len1), nominal[0], nominal[1]),
+          "ht_decode")
+    torch.cuda.synchronize(dev)
+    return status.cpu().numpy()[:len(descs)]

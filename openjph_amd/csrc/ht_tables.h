@@ -1,0 +1,27 @@
+// openjph_amd/csrc/ht_tables.h -- HT block coder look-up tables, built on the host from the
+// CxtVLC rows of ITU-T T.814 Annex C (ht_vlc_tables.inc) and uploaded once per device.
+//
+// Same table *contents* as the reference builds at start-up (encoder: vlc_init_tables,
+// ojph_block_encoder.cpp:76-193; decoder: vlc_init_tables / uvlc_init_tables,
+// ojph_block_common.cpp:124-336) -- the kernels index them the same way.
+#ifndef OJPH_HT_TABLES_H
+#define OJPH_HT_TABLES_H
+#include <stdint.h>
+
+namespace ojphgpu {
+
+struct HtTables {
+  uint16_t enc_vlc[2][2048];   // [(c_q << 8) | (rho << 4) | eps] -> (cwd << 8) | (len << 4) | e_k
+  uint16_t dec_vlc[2][1024];   // [(c_q << 7) | 7 bits] -> e_k<<12 | e_1<<8 | rho<<4 | u_off<<3 | len
+  uint16_t dec_uvlc0[320];     // initial quad row
+  uint16_t dec_uvlc1[256];     // other rows
+};
+
+void build_ht_tables(HtTables& t);
+// uploads the tables to the current HIP device (once per device); 0 on success
+int ensure_tables();
+int upload_enc_tables(const HtTables& t);
+int upload_dec_tables(const HtTables& t);
+
+}  // namespace ojphgpu
+#endif

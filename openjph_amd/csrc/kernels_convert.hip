@@ -1,0 +1,161 @@
+// openjph_amd/csrc/kernels_convert.hip -- sample conversion (level shift / int<->float) and
+// colour transforms (RCT / ICT) between image-sized int32 component planes and the
+// tile-component planes of the coefficient arena.
+//
+// Reference (per image line, ojph_tile.cpp:332-518 calling ojph_colour.cpp):
+//   gen_rev_convert            ojph_colour.cpp:238-275   v + shift
+//   gen_irv_convert_to_float   ojph_colour.cpp:388-436   (v - half) * 2^-B
+//   gen_irv_convert_to_integer ojph_colour.cpp:316-386   round(t * 2^B) clamped, + half
+//   gen_rct_forward/backward   ojph_colour.cpp:443-543
+//   gen_ict_forward/backward   ojph_colour.cpp:545-567   constants :221-231
+// Pure element-wise, HBM-bound: 16-byte vector accesses when rows are 16-byte aligned.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ojphgpu.h"
+
+namespace {
+
+struct ConvParams {
+  uint32_t img_w, img_h, num_comps, bit_depth, is_signed, reversible, color;
+};
+
+constexpr float ALPHA_RF = 0.299f, ALPHA_GF = 0.587f, ALPHA_BF = 0.114f;
+
+__device__ __forceinline__ float to_float(int v, const ConvParams& p)
+{
+  const float mul = (float)(1.0 / (double)(1ULL << p.bit_depth));
+  const int half = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
+  return __fmul_rn((float)(v - half), mul);
+}
+
+__device__ __forceinline__ int to_int(float f, const ConvParams& p)
+{
+  const int neg_limit = (int)0x80000000 >> (32 - p.bit_depth);
+  const float mul = (float)(1ull << p.bit_depth);
+  const float up = -(float)neg_limit, low = (float)neg_limit;
+  const int s_up = 0x7FFFFFFF >> (32 - p.bit_depth), s_low = (int)0x80000000 >> (32 - p.bit_depth);
+  const int half = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
+  float t = __fmul_rn(f, mul);
+  int v = (int)__fadd_rn(t, t >= 0.0f ? 0.5f : -0.5f);    // ojph_round: truncation of t +- 0.5
+  v = t >= low ? v : s_low;
+  v = t < up ? v : s_up;
+  return v + half;
+}
+
+__global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
+                                                              const int* __restrict__ image, uint32_t* __restrict__ arena)
+{
+  const uint32_t tile = blockIdx.z;
+  const uint32_t nc = p.num_comps;
+  const ojphgpu_convert_desc d0 = descs[tile * nc];
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= d0.w || y >= d0.h) return;
+  const size_t plane = (size_t)p.img_w * p.img_h;
+  const size_t src = (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;
+  if (p.color) {
+    const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
+    int r = image[src], g = image[plane + src], b = image[2 * plane + src];
+    if (p.reversible) {
+      const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
+      r += shift; g += shift; b += shift;
+      int yy = (r + (g << 1) + b) >> 2, cb = b - g, cr = r - g;
+      arena[d0.plane_off + (size_t)y * d0.pitch + x] = (uint32_t)yy;
+      arena[d1.plane_off + (size_t)y * d1.pitch + x] = (uint32_t)cb;
+      arena[d2.plane_off + (size_t)y * d2.pitch + x] = (uint32_t)cr;
+    } else {
+      const float beta_cb = (float)(0.5 / (1 - (double)ALPHA_BF)), beta_cr = (float)(0.5 / (1 - (double)ALPHA_RF));
+      float rf = to_float(r, p), gf = to_float(g, p), bf = to_float(b, p);
+      float yy = __fadd_rn(__fadd_rn(__fmul_rn(ALPHA_RF, rf), __fmul_rn(ALPHA_GF, gf)), __fmul_rn(ALPHA_BF, bf));
+      float cb = __fmul_rn(beta_cb, __fsub_rn(bf, yy)), cr = __fmul_rn(beta_cr, __fsub_rn(rf, yy));
+      arena[d0.plane_off + (size_t)y * d0.pitch + x] = __float_as_uint(yy);
+      arena[d1.plane_off + (size_t)y * d1.pitch + x] = __float_as_uint(cb);
+      arena[d2.plane_off + (size_t)y * d2.pitch + x] = __float_as_uint(cr);
+    }
+    return;
+  }
+  for (uint32_t c = 0; c < nc; ++c) {
+    const ojphgpu_convert_desc d = descs[tile * nc + c];
+    int v = image[c * plane + src];
+    uint32_t o;
+    if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
+    else o = __float_as_uint(to_float(v, p));
+    arena[d.plane_off + (size_t)y * d.pitch + x] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
+                                                              int* __restrict__ image, const uint32_t* __restrict__ arena)
+{
+  const uint32_t tile = blockIdx.z;
+  const uint32_t nc = p.num_comps;
+  const ojphgpu_convert_desc d0 = descs[tile * nc];
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= d0.w || y >= d0.h) return;
+  const size_t plane = (size_t)p.img_w * p.img_h;
+  const size_t dst = (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;
+  if (p.color) {
+    const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
+    uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];
+    uint32_t b = arena[d1.plane_off + (size_t)y * d1.pitch + x];
+    uint32_t c = arena[d2.plane_off + (size_t)y * d2.pitch + x];
+    if (p.reversible) {
+      const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
+      int yy = (int)a, cb = (int)b, cr = (int)c;
+      int g = yy - ((cb + cr) >> 2);
+      image[dst] = cr + g + shift; image[plane + dst] = g + shift; image[2 * plane + dst] = cb + g + shift;
+    } else {
+      const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
+      const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
+      const float g_cb2b = (float)(2.0 * (1.0 - (double)ALPHA_BF));
+      const float g_cr2r = (float)(2.0 * (1.0 - (double)ALPHA_RF));
+      float yy = __uint_as_float(a), cb = __uint_as_float(b), cr = __uint_as_float(c);
+      float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
+      float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
+      float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
+      image[dst] = to_int(r, p); image[plane + dst] = to_int(g, p); image[2 * plane + dst] = to_int(bb, p);
+    }
+    return;
+  }
+  for (uint32_t c = 0; c < nc; ++c) {
+    const ojphgpu_convert_desc d = descs[tile * nc + c];
+    uint32_t a = arena[d.plane_off + (size_t)y * d.pitch + x];
+    int v;
+    if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
+    else v = to_int(__uint_as_float(a), p);
+    image[c * plane + dst] = v;
+  }
+}
+
+ConvParams make(const ojphgpu_params* q)
+{
+  ConvParams p;
+  p.img_w = q->width; p.img_h = q->height; p.num_comps = q->num_comps; p.bit_depth = q->bit_depth;
+  p.is_signed = q->is_signed; p.reversible = q->reversible; p.color = q->color_transform;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int ojphgpu_convert_forward(void* stream, const ojphgpu_params* params,
+                                        const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                                        uint32_t max_w, uint32_t max_h, const int32_t* d_image, void* d_arena)
+{
+  if (!params || !d_descs || !d_image || !d_arena) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_forward_kernel, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     d_image, (uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_convert_inverse(void* stream, const ojphgpu_params* params,
+                                        const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                                        uint32_t max_w, uint32_t max_h, int32_t* d_image, const void* d_arena)
+{
+  if (!params || !d_descs || !d_image || !d_arena) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_inverse_kernel, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     d_image, (const uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}

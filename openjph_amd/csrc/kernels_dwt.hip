@@ -1,0 +1,364 @@
+// openjph_amd/csrc/kernels_dwt.hip -- 5/3 (reversible, int32) and 9/7 (irreversible, fp32) DWT
+// for gfx950, one launch per decomposition level over every tile-component of a frame.
+//
+// What the reference does (one image line per call, rolling line buffers):
+//   vertical lifting state machine   resolution::push_line / pull_line  ojph_resolution.cpp:547-949
+//   per-line horizontal lifting      gen_rev_horz_ana/syn, gen_irv_horz_ana/syn
+//                                                                        ojph_transform.cpp:336-852
+//   lifting steps / K               param_atk::init_rev53 / init_irv97   ojph_params.cpp:2870-2896
+//
+// MI355X design (bandwidth-bound, no LDS, no MFMA):
+//   * a wavefront owns a strip of 64 column PAIRS (even/odd sample of the same lifting site) and
+//     walks down the rows.  Every row is fetched as one coalesced 512-byte segment (8 B / lane).
+//   * vertical lifting is a software pipeline in registers: the lane keeps the 4-step lifting
+//     state of its two columns (x, a, b, c) and emits one low and one high row per iteration.
+//   * horizontal lifting of the emitted rows happens in the same registers: the neighbour
+//     column pair is the neighbour lane, fetched with a wave shuffle.  Strips overlap by 2 pairs
+//     on each side (halo recomputation) so no inter-wave exchange is needed.
+//   * the four sub-band rows are written as coalesced 256-byte segments (4 B / lane).
+//   Analysis is vertical-then-horizontal, synthesis horizontal-then-vertical, exactly the
+//   reference's order -- for 5/3 the rounding makes the order observable.
+//   Boundary rule = the reference's: a missing neighbour is replaced by the other neighbour
+//   (whole-sample symmetric extension); a 1-sample-long dimension is passed through (even
+//   origin) or doubled / halved (odd origin) without the K scaling.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ojphgpu.h"
+
+namespace {
+
+constexpr int HALO = 2;             // column pairs recomputed on each side of a strip
+constexpr int VALID = 64 - 2 * HALO; // 60 pairs = 120 columns produced per wavefront
+constexpr int ROW_PAIRS = 64;       // row pairs produced per strip (128 image rows)
+
+template <bool REV> struct Wv;
+
+template <> struct Wv<true> {       // reversible 5/3 (ojph_params.cpp:2883-2896)
+  typedef int T;
+  static __device__ __forceinline__ T a0(T h, T p, T q) { return h - ((p + q) >> 1); }     // predict
+  static __device__ __forceinline__ T a1(T l, T p, T q) { return l + ((p + q + 2) >> 2); } // update
+  static __device__ __forceinline__ T a2(T h, T, T) { return h; }
+  static __device__ __forceinline__ T a3(T l, T, T) { return l; }
+  static __device__ __forceinline__ T s0(T l, T p, T q) { return l - ((p + q + 2) >> 2); }
+  static __device__ __forceinline__ T s1(T h, T p, T q) { return h + ((p + q) >> 1); }
+  static __device__ __forceinline__ T s2(T l, T, T) { return l; }
+  static __device__ __forceinline__ T s3(T h, T, T) { return h; }
+  static __device__ __forceinline__ T mulK(T v) { return v; }
+  static __device__ __forceinline__ T mulKinv(T v) { return v; }
+  static __device__ __forceinline__ T dbl(T v) { return v << 1; }
+  static __device__ __forceinline__ T halve(T v) { return v >> 1; }
+};
+
+template <> struct Wv<false> {      // irreversible 9/7 (ojph_params.cpp:2870-2881)
+  typedef float T;
+  // fp32 "add, mul, add" with no contraction: the generic reference build is the bit-exact pin
+  static __device__ __forceinline__ T lift(T v, float c, T p, T q) { return __fadd_rn(v, __fmul_rn(c, __fadd_rn(p, q))); }
+  static __device__ __forceinline__ T unlift(T v, float c, T p, T q) { return __fsub_rn(v, __fmul_rn(c, __fadd_rn(p, q))); }
+  static __device__ __forceinline__ T a0(T h, T p, T q) { return lift(h, (float)-1.586134342059924, p, q); }
+  static __device__ __forceinline__ T a1(T l, T p, T q) { return lift(l, (float)-0.052980118572961, p, q); }
+  static __device__ __forceinline__ T a2(T h, T p, T q) { return lift(h, (float)0.882911075530934, p, q); }
+  static __device__ __forceinline__ T a3(T l, T p, T q) { return lift(l, (float)0.443506852043971, p, q); }
+  static __device__ __forceinline__ T s0(T l, T p, T q) { return unlift(l, (float)0.443506852043971, p, q); }
+  static __device__ __forceinline__ T s1(T h, T p, T q) { return unlift(h, (float)0.882911075530934, p, q); }
+  static __device__ __forceinline__ T s2(T l, T p, T q) { return unlift(l, (float)-0.052980118572961, p, q); }
+  static __device__ __forceinline__ T s3(T h, T p, T q) { return unlift(h, (float)-1.586134342059924, p, q); }
+  static __device__ __forceinline__ T mulK(T v) { return __fmul_rn(v, (float)1.230174104914001); }
+  static __device__ __forceinline__ T mulKinv(T v) { return __fmul_rn(v, __fdiv_rn(1.0f, (float)1.230174104914001)); }
+  static __device__ __forceinline__ T dbl(T v) { return __fmul_rn(v, 2.0f); }
+  static __device__ __forceinline__ T halve(T v) { return __fmul_rn(v, 0.5f); }
+};
+
+// neighbour selection with the "missing -> use the other one" rule
+template <typename T>
+__device__ __forceinline__ T pick(bool e, T v, T other) { return e ? v : other; }
+
+template <typename T> struct Pair { T l, h; };
+
+// geometry of one plane as seen by one lane
+struct Geo {
+  int w, h, ox, oy;      // ox/oy = 1 when the plane origin is at an odd coordinate
+  int j;                 // column-pair index of this lane in "u = x + ox" space
+  bool eL, eH, eLn, eHp; // existence of own low/high column and of the neighbours' (j+1 low, j-1 high)
+  bool store;            // lane is in the valid (non-halo) zone of its strip
+};
+
+__device__ __forceinline__ bool col_exists(int x, int w) { return x >= 0 && x < w; }
+
+template <bool REV>
+__device__ __forceinline__ void horz_analysis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
+{
+  typedef typename Wv<REV>::T T;
+  if (g.w == 1) { if (g.ox) vh = Wv<REV>::dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
+  T nl = __shfl_down(vl, 1);
+  vh = Wv<REV>::a0(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+  T ph = __shfl_up(vh, 1);
+  vl = Wv<REV>::a1(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+  if (!REV) {
+    nl = __shfl_down(vl, 1);
+    vh = Wv<REV>::a2(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+    ph = __shfl_up(vh, 1);
+    vl = Wv<REV>::a3(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+    vl = Wv<REV>::mulKinv(vl); vh = Wv<REV>::mulK(vh);          // ojph_transform.cpp:763-775
+  }
+}
+
+template <bool REV>
+__device__ __forceinline__ void horz_synthesis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
+{
+  typedef typename Wv<REV>::T T;
+  if (g.w == 1) { if (g.ox) vh = Wv<REV>::halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
+  if (!REV) { vl = Wv<REV>::mulK(vl); vh = Wv<REV>::mulKinv(vh); }   // :797-809
+  T ph = __shfl_up(vh, 1);
+  vl = Wv<REV>::s0(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+  T nl = __shfl_down(vl, 1);
+  vh = Wv<REV>::s1(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+  if (!REV) {
+    ph = __shfl_up(vh, 1);
+    vl = Wv<REV>::s2(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+    nl = __shfl_down(vl, 1);
+    vh = Wv<REV>::s3(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+  }
+}
+
+__device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, int lane)
+{
+  Geo g;
+  g.w = (int)d.w; g.h = (int)d.h; g.ox = d.x_even ? 0 : 1; g.oy = d.y_even ? 0 : 1;
+  g.j = strip_x * VALID - HALO + lane;
+  int xl = 2 * g.j - g.ox, xh = xl + 1;
+  g.eL = col_exists(xl, g.w); g.eH = col_exists(xh, g.w);
+  g.eLn = col_exists(xl + 2, g.w); g.eHp = col_exists(xh - 2, g.w);
+  g.store = lane >= HALO && lane < 64 - HALO;
+  return g;
+}
+
+// loads the lane's two columns of image row y (plane-relative); missing samples read as 0
+template <typename T>
+__device__ __forceinline__ Pair<T> load_pair(const T* __restrict__ row, const Geo& g)
+{
+  Pair<T> p; p.l = 0; p.h = 0;
+  int xl = 2 * g.j - g.ox;
+  if (g.ox == 0) {
+    if (g.eL && g.eH) {
+      typedef T V2 __attribute__((ext_vector_type(2)));
+      V2 v = *reinterpret_cast<const V2*>(row + xl);
+      p.l = v.x; p.h = v.y;
+    } else if (g.eL) p.l = row[xl];
+  } else {
+    if (g.eL) p.l = row[xl];
+    if (g.eH) p.h = row[xl + 1];
+  }
+  return p;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_pair(T* __restrict__ row, const Geo& g, T l, T h)
+{
+  if (!g.store) return;
+  int xl = 2 * g.j - g.ox;
+  if (g.ox == 0 && g.eL && g.eH) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 v; v.x = l; v.y = h;
+    *reinterpret_cast<V2*>(row + xl) = v;
+  } else {
+    if (g.eL) row[xl] = l;
+    if (g.eH) row[xl + 1] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: plane -> LL, HL, LH, HH
+// ---------------------------------------------------------------------------------------------
+template <bool REV>
+__global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
+                                                          typename Wv<REV>::T* __restrict__ base)
+{
+  typedef typename Wv<REV>::T T;
+  typedef Wv<REV> W;
+  const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip_x = blockIdx.x * 4 + wave;
+  if (d.w == 0 || d.h == 0) return;
+  const Geo g = make_geo(d, strip_x, lane);
+  const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
+  if (strip_x * VALID >= npx) return;
+  const int i0 = blockIdx.y * ROW_PAIRS;
+  if (i0 >= npy) return;
+  const int i1 = min(i0 + ROW_PAIRS, npy);
+
+  const T* src = base + d.src_off;
+  T* ll = base + d.ll_off; T* hl = base + d.hl_off; T* lh = base + d.lh_off; T* hh = base + d.hh_off;
+  const int h = g.h, oy = g.oy;
+  auto rowL = [&](int t) { return 2 * t - oy; };          // image row of the low row of pair t
+  auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
+  auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
+  auto emit = [&](int t, bool low_row, T vl, T vh) {       // horizontal pass + store of one row
+    horz_analysis<REV>(vl, vh, g);
+    if (!g.store) return;
+    T* lo = low_row ? ll : lh; T* hi = low_row ? hl : hh;
+    const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+    const int r = low_row ? t - oy : t;                    // row index inside the sub-band
+    if (g.eL) lo[(size_t)r * lop + (g.j - g.ox)] = vl;
+    if (g.eH) hi[(size_t)r * hip + g.j] = vh;
+  };
+
+  if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
+    if (i0 > 0) return;
+    Pair<T> x = load_pair(src, g);
+    if (oy == 0) emit(0, true, x.l, x.h);
+    else emit(0, false, W::dbl(x.l), W::dbl(x.h));
+    return;
+  }
+
+  // vertical software pipeline over row pairs t; see file header
+  const int t0 = max(i0 - 2, 0);
+  Pair<T> xl, xn, a, ap, b, bp, c, cp;   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
+  xl.l = xl.h = 0; a = ap = b = bp = c = cp = xl;
+  if (exL(t0)) xl = load_pair(src + (size_t)rowL(t0) * d.src_pitch, g);
+  for (int t = t0; t <= i1; ++t) {
+    Pair<T> xh; xh.l = xh.h = 0; xn = xh;
+    const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
+    if (eHt) xh = load_pair(src + (size_t)(rowL(t) + 1) * d.src_pitch, g);
+    if (eLn) xn = load_pair(src + (size_t)(rowL(t) + 2) * d.src_pitch, g);
+    // a[t]
+    ap = a;
+    a.l = W::a0(xh.l, pick(eLt, xl.l, xn.l), pick(eLn, xn.l, xl.l));
+    a.h = W::a0(xh.h, pick(eLt, xl.h, xn.h), pick(eLn, xn.h, xl.h));
+    // b[t]
+    const bool eHp = exH(t - 1);
+    Pair<T> bo = b;                       // b[t-1]
+    b.l = W::a1(xl.l, pick(eHp, ap.l, a.l), pick(eHt, a.l, ap.l));
+    b.h = W::a1(xl.h, pick(eHp, ap.h, a.h), pick(eHt, a.h, ap.h));
+    bp = bo;
+    // c[t-1]
+    const bool eLp = exL(t - 1);
+    cp = c;
+    c.l = W::a2(ap.l, pick(eLp, bp.l, b.l), pick(eLt, b.l, bp.l));
+    c.h = W::a2(ap.h, pick(eLp, bp.h, b.h), pick(eLt, b.h, bp.h));
+    // d[t-1]
+    const bool eHpp = exH(t - 2);
+    T dl = W::a3(bp.l, pick(eHpp, cp.l, c.l), pick(eHp, c.l, cp.l));
+    T dh = W::a3(bp.h, pick(eHpp, cp.h, c.h), pick(eHp, c.h, cp.h));
+    if (t - 1 >= i0 && t - 1 < i1) {
+      if (eLp) emit(t - 1, true, W::mulKinv(dl), W::mulKinv(dh));   // ojph_resolution.cpp:674-675
+      if (eHp) emit(t - 1, false, W::mulK(c.l), W::mulK(c.h));      // :663-664
+    }
+    xl = xn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse: LL, HL, LH, HH -> plane
+// ---------------------------------------------------------------------------------------------
+template <bool REV>
+__global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
+                                                          typename Wv<REV>::T* __restrict__ base)
+{
+  typedef typename Wv<REV>::T T;
+  typedef Wv<REV> W;
+  const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip_x = blockIdx.x * 4 + wave;
+  if (d.w == 0 || d.h == 0) return;
+  const Geo g = make_geo(d, strip_x, lane);
+  const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
+  if (strip_x * VALID >= npx) return;
+  const int i0 = blockIdx.y * ROW_PAIRS;
+  if (i0 >= npy) return;
+  const int i1 = min(i0 + ROW_PAIRS, npy);
+
+  T* dst = base + d.src_off;
+  const T* ll = base + d.ll_off; const T* hl = base + d.hl_off;
+  const T* lh = base + d.lh_off; const T* hh = base + d.hh_off;
+  const int h = g.h, oy = g.oy;
+  auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
+  auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
+  // fetches a sub-band row pair and runs the horizontal synthesis: returns the lane's two
+  // columns of the (vertically still transformed) row
+  auto fetch = [&](int t, bool low_row) {
+    const T* lo = low_row ? ll : lh; const T* hi = low_row ? hl : hh;
+    const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+    const int r = low_row ? t - oy : t;
+    T vl = 0, vh = 0;
+    if (g.eL) vl = lo[(size_t)r * lop + (g.j - g.ox)];
+    if (g.eH) vh = hi[(size_t)r * hip + g.j];
+    horz_synthesis<REV>(vl, vh, g);
+    Pair<T> p; p.l = vl; p.h = vh;
+    return p;
+  };
+
+  if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
+    if (i0 > 0) return;
+    Pair<T> x = fetch(0, oy == 0);
+    if (oy != 0) { x.l = W::halve(x.l); x.h = W::halve(x.h); }
+    store_pair(dst, g, x.l, x.h);
+    return;
+  }
+
+  const int t0 = max(i0 - 2, 0);
+  Pair<T> z; z.l = z.h = 0;
+  Pair<T> c = z, cp = z, b = z, bp = z, a = z, ap = z, xL = z, xLp = z;
+  // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
+  for (int t = t0; t <= i1 + 1; ++t) {
+    const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
+    const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
+    Pair<T> dd = z;
+    cp = c; c = z;
+    if (eLt) { dd = fetch(t, true); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); }            // :855-856
+    if (eHt) { c = fetch(t, false); c.l = W::mulKinv(c.l); c.h = W::mulKinv(c.h); }          // :871-872
+    // b[t]
+    bp = b;
+    b.l = W::s0(dd.l, pick(eHp, cp.l, c.l), pick(eHt, c.l, cp.l));
+    b.h = W::s0(dd.h, pick(eHp, cp.h, c.h), pick(eHt, c.h, cp.h));
+    // a[t-1]
+    ap = a;
+    a.l = W::s1(cp.l, pick(eLp, bp.l, b.l), pick(eLt, b.l, bp.l));
+    a.h = W::s1(cp.h, pick(eLp, bp.h, b.h), pick(eLt, b.h, bp.h));
+    // xL[t-1]
+    xLp = xL;
+    xL.l = W::s2(bp.l, pick(eHpp, ap.l, a.l), pick(eHp, a.l, ap.l));
+    xL.h = W::s2(bp.h, pick(eHpp, ap.h, a.h), pick(eHp, a.h, ap.h));
+    // xH[t-2]
+    T xhl = W::s3(ap.l, pick(eLpp, xLp.l, xL.l), pick(eLp, xL.l, xLp.l));
+    T xhh = W::s3(ap.h, pick(eLpp, xLp.h, xL.h), pick(eLp, xL.h, xLp.h));
+    if (t - 2 >= i0 && t - 2 < i1 && eHpp)
+      store_pair(dst + (size_t)(2 * (t - 2) + 1 - oy) * d.src_pitch, g, xhl, xhh);
+    if (t - 1 >= i0 && t - 1 < i1 && eLp)
+      store_pair(dst + (size_t)(2 * (t - 1) - oy) * d.src_pitch, g, xL.l, xL.h);
+  }
+}
+
+dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h)
+{
+  uint32_t npx = (max_w + 2) >> 1, npy = (max_h + 2) >> 1;
+  uint32_t sx = (npx + VALID - 1) / VALID;
+  return dim3((sx + 3) / 4, (npy + ROW_PAIRS - 1) / ROW_PAIRS, n);
+}
+
+}  // namespace
+
+extern "C" int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
+                                    uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)
+{
+  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
+  dim3 grid = dwt_grid(n, max_w, max_h);
+  if (reversible)
+    hipLaunchKernelGGL(dwt_forward_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (int*)d_base);
+  else
+    hipLaunchKernelGGL(dwt_forward_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (float*)d_base);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
+                                    uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)
+{
+  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
+  dim3 grid = dwt_grid(n, max_w, max_h);
+  if (reversible)
+    hipLaunchKernelGGL(dwt_inverse_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (int*)d_base);
+  else
+    hipLaunchKernelGGL(dwt_inverse_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (float*)d_base);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}

@@ -1,0 +1,493 @@
+// openjph_amd/csrc/kernels_ht_enc.hip -- HT cleanup-pass block encoder for gfx950, with the
+// quantise transfer fused into its sample loads.  ONE WAVEFRONT PER CODE-BLOCK.
+//
+// Reference: ojph_encode_codeblock32 (src/core/coding/ojph_block_encoder.cpp:542-1017) and its
+// writers (mel :273-347, vlc :352-407, ms :446-534, terminate_mel_vlc :412-441);
+// quantise transfer gen_rev/irv_tx_to_cb32 (src/core/codestream/ojph_codestream_gen.cpp:59-121);
+// "is there anything to code" test codeblock::encode (ojph_codeblock.cpp:142-175).
+//
+// The reference walks the block quad pair by quad pair with three serial bit writers.  Here
+//   * a lane owns one quad PAIR (8 samples) per step, the wave covers 64 consecutive pairs in
+//     raster order; everything a quad contributes (rho, exponents, context, kappa, u, VLC
+//     codeword, MagSgn bits) depends only on sample values, so it is computed in parallel --
+//     neighbour quads are read straight from the block (L1/L2 hits), not from line state;
+//   * MagSgn and VLC bits are OR-ed by all lanes into flat, un-stuffed LDS bit buffers at
+//     offsets given by a wavefront prefix sum;
+//   * byte stuffing (0xFF -> 7 bits forward; >0x8F,0x7F backward) is resolved by a speculative
+//     pass: every lane proposes one output byte assuming no stuffing event inside the 64-byte
+//     window, a ballot finds the first event, lanes up to it commit, and the window restarts;
+//   * MEL is an adaptive run-length coder and stays serial, but it runs on ballot-compacted
+//     event bits, whole zero-runs at a time, in wave-uniform (scalar) code;
+//   * stuffed bytes stream to a per-block scratch slot in HBM; when the three lengths are
+//     known the block takes its place in the compacted output with one atomicAdd.
+// The produced bytes are identical to the reference's (oracle/ht_oracle.c variant 1 is the CPU
+// model of exactly this formulation and is pinned against the reference).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ojphgpu.h"
+#include "ht_tables.h"
+
+namespace ojphgpu {
+__device__ uint16_t g_enc_vlc[2][2048];   // filled by ojphgpu_upload_tables()
+}
+
+namespace {
+
+constexpr int MS_WORDS = 512;     // 64 lanes * 8 samples * 31 bits + carry  < 2048 bytes
+constexpr int VLC_WORDS = 64;     // 64 lanes * 30 bits + carry < 256 bytes
+constexpr int MEL_CAP = 192;      // ojph_block_encoder.cpp:554
+constexpr int VLC_CAP = 3072 - MEL_CAP;   // :556
+constexpr int WAVES = 4;
+
+struct WaveLds {
+  uint32_t ms[MS_WORDS];
+  uint32_t vlc[VLC_WORDS];
+  uint32_t ev[8];                 // compacted MEL event bits of one step (<= 192)
+  uint8_t  mel[MEL_CAP];
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t get_bits(const uint32_t* buf, uint32_t pos, uint32_t n)
+{
+  const uint32_t w = pos >> 5, sh = pos & 31;
+  const uint32_t lo = buf[w], hi = buf[w + 1];
+  const uint32_t v = __funnelshift_r(lo, hi, sh);
+  return v & ((1u << n) - 1u);
+}
+
+__device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v, uint32_t n)
+{
+  if (n == 0) return;
+  const uint32_t w = pos >> 5, sh = pos & 31;
+  atomicOr(&buf[w], v << sh);
+  if (sh + n > 32) atomicOr(&buf[w + 1], v >> (32 - sh));
+}
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// quantise transfer of one raw coefficient: sign | magnitude, MSB aligned
+__device__ __forceinline__ uint32_t to_sign_mag(uint32_t raw, bool reversible, uint32_t shift, float delta_inv)
+{
+  int t;
+  if (reversible) {
+    int v = (int)raw;
+    uint32_t m = (uint32_t)(v >= 0 ? v : -v) << shift;                   // ojph_codestream_gen.cpp:70-76
+    return (v >= 0 ? 0u : 0x80000000u) | m;
+  }
+  t = (int)__fmul_rn(__uint_as_float(raw), delta_inv);                    // :113-118, C truncation
+  return (t >= 0 ? 0u : 0x80000000u) | (uint32_t)(t >= 0 ? t : -t);
+}
+
+__device__ __forceinline__ uint32_t expo(uint32_t val) { return val ? 32u - (uint32_t)__clz((int)(val - 1)) : 0u; }
+
+// MEL exponents {0,0,0,1,1,1,2,2,2,3,3,4,5} packed 3 bits each (ojph_block_encoder.cpp:324)
+__device__ __forceinline__ uint32_t mel_exp(uint32_t k)
+{
+  const uint64_t tbl = 0ull | (1ull << 9) | (1ull << 12) | (1ull << 15) | (2ull << 18) | (2ull << 21) | (2ull << 24) |
+                       (3ull << 27) | (3ull << 30) | (4ull << 33) | (5ull << 36);
+  return (uint32_t)(tbl >> (3 * k)) & 7u;
+}
+
+struct MelState {          // all wave-uniform
+  uint32_t k, run, acc, nb, pos, lastff, err;
+};
+
+__device__ __forceinline__ void mel_put(MelState& m, uint8_t* buf, uint32_t code, uint32_t n, int lane)
+{
+  m.acc = (m.acc << n) | code; m.nb += n;
+  for (;;) {
+    const uint32_t need = m.lastff ? 7u : 8u;
+    if (m.nb < need) break;
+    const uint32_t byte = (m.acc >> (m.nb - need)) & ((1u << need) - 1u);
+    m.nb -= need; m.acc &= (1u << m.nb) - 1u;
+    if (m.pos >= (uint32_t)MEL_CAP) { m.err = 1; break; }
+    if (lane == 0) buf[m.pos] = (uint8_t)byte;
+    m.pos++; m.lastff = (byte == 0xFF);
+  }
+}
+
+__device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t n, int lane)
+{
+  while (n > 0) {
+    const uint32_t thr = 1u << mel_exp(m.k);
+    const uint32_t need = thr - m.run;
+    if (n >= need) { mel_put(m, buf, 1, 1, lane); n -= need; m.run = 0; m.k = m.k < 12 ? m.k + 1 : 12; }
+    else { m.run += n; n = 0; }
+  }
+}
+
+__device__ __forceinline__ void mel_one(MelState& m, uint8_t* buf, int lane)
+{
+  const uint32_t e = mel_exp(m.k);
+  mel_put(m, buf, m.run, e + 1, lane);          // a 0 followed by e bits of the run count
+  m.run = 0; m.k = m.k > 0 ? m.k - 1 : 0;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
+    uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
+    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
+{
+  __shared__ uint16_t s_vlc[2][2048];
+  __shared__ WaveLds s_wave[WAVES];
+  for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t bi = blockIdx.x * WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  WaveLds& L = s_wave[wave];
+  const uint32_t W = d.w, H = d.h;
+  if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
+  const uint32_t K = d.K_max, p = 31u - K;      // missing_msbs = K_max - 1, p = 30 - missing_msbs
+  const bool rev = d.reversible != 0;
+  const float delta_inv = rev ? 0.0f : __fdiv_rn(1.0f, d.delta);         // ojph_codeblock.cpp:98
+  const uint32_t* src = coef + d.coef_off;
+  const uint32_t pitch = d.pitch;
+  uint8_t* ms_out = scratch + d.data_off;
+  const uint32_t ms_cap = d.scratch_cap > (uint32_t)VLC_CAP ? d.scratch_cap - VLC_CAP : 0;
+  uint8_t* vlc_last = scratch + d.data_off + d.scratch_cap - 1;          // VLC grows downwards from here
+
+  const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1, PW = (QW + 1) >> 1, NP = PW * QH;
+
+  for (int i = lane; i < MS_WORDS; i += 64) L.ms[i] = 0;
+  if (lane < VLC_WORDS) L.vlc[lane] = 0;
+  if (lane < 8) L.ev[lane] = 0;
+  wave_sync();
+  if (lane == 0) L.vlc[0] = 0xF;                                          // vlc_init: 4 bits already used (:365-375)
+  wave_sync();
+
+  // wave-uniform stream state
+  uint32_t ms_carry = 0, ms_k = 0, ms_ff = 0;           // carried bits, bytes written, last byte was 0xFF
+  uint32_t v_carry = 4, v_pos = 1, v_prev = 0xFF;       // carried bits, bytes "written" (incl. the 0xFF head), last byte
+  MelState mel = { 0, 0, 0, 0, 0, 0, 0 };
+  uint32_t err = 0, any_sig = 0;
+  uint32_t carry_rho = 0;                               // rho of the last quad of the previous step
+
+  auto sample = [&](int x, int y) -> uint32_t {         // quantised sign-magnitude, 0 outside the block
+    if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return 0u;
+    return to_sign_mag(src[(size_t)y * pitch + x], rev, p, delta_inv);
+  };
+
+  for (uint32_t base = 0; base < NP; base += 64) {
+    const uint32_t P = base + lane;
+    const bool active = P < NP;
+    const uint32_t qy = active ? P / PW : 0, px = active ? P - qy * PW : 0;
+    const int x0 = (int)(4 * px), y0 = (int)(2 * qy);
+    const bool has_q1 = active && (x0 + 2 < (int)W);
+    const bool first_row = qy == 0;
+
+    // ---- samples of the pair: t[q*4+n], n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1) ----
+    uint32_t val[8], sgn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = i >> 2, nn = i & 3;
+      uint32_t t = active ? sample(x0 + 2 * q + (nn >> 1), y0 + (nn & 1)) : 0u;
+      val[i] = ((t + t) >> p) & ~1u;                    // 2*mu_p        (:592-595)
+      sgn[i] = t >> 31;
+    }
+    // ---- bottom sample row of the quad row above: columns x0-1 .. x0+4 ----
+    uint32_t Eab[6], Sab[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      uint32_t t = (active && !first_row) ? sample(x0 - 1 + i, y0 - 1) : 0u;
+      uint32_t v = ((t + t) >> p) & ~1u;
+      Eab[i] = expo(v); Sab[i] = v != 0;
+    }
+
+    // ---- per quad symbols ----
+    uint32_t rho[2], cq[2], uq[2], Uq[2], tup[2];
+    uint32_t msv[8], msl[8];
+    uint32_t rho_q[2] = { 0, 0 }, emax[2] = { 0, 0 }, e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      e[i] = expo(val[i]);
+      if (val[i]) rho_q[i >> 2] |= 1u << (i & 3);
+      emax[i >> 2] = max(emax[i >> 2], e[i]);
+    }
+    if (!has_q1) { rho_q[1] = 0; emax[1] = 0; }
+    // rho of the quad to the left of q0: q1 of the previous pair (previous lane / previous step)
+    uint32_t rho_prev = __shfl_up(rho_q[1], 1);
+    if (lane == 0) rho_prev = carry_rho;
+    if (px == 0) rho_prev = 0;
+    carry_rho = rdlane(rho_q[1], 63);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t rl = q == 0 ? rho_prev : rho_q[0];
+      uint32_t kappa = 1, c;
+      if (first_row) c = (rl >> 1) | (rl & 1);                                      // :731,:788
+      else {
+        const uint32_t* E = Eab + 2 * q; const uint32_t* S = Sab + 2 * q;
+        uint32_t me = max(max(E[0], E[1]), max(E[2], E[3]));
+        int max_e = (int)me - 1;
+        if (rho_q[q] & (rho_q[q] - 1)) kappa = (uint32_t)max(1, max_e);             // :862,:950
+        c = (S[0] | S[1]) | ((S[2] | S[3]) << 2) | ((rl & 4) >> 1) | ((rl & 8) >> 2); // :802,:878,:951,:967,:991
+      }
+      const uint32_t U = max(emax[q], kappa), u = U - kappa;
+      uint32_t eps = 0;
+      if (u > 0) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) eps |= (uint32_t)(e[q * 4 + nn] == emax[q]) << nn;
+      }
+      const uint32_t tuple = s_vlc[first_row ? 0 : 1][(c << 8) + (rho_q[q] << 4) + eps];
+      rho[q] = rho_q[q]; cq[q] = c; uq[q] = u; Uq[q] = U; tup[q] = tuple;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        const int i = q * 4 + nn;
+        const uint32_t m = ((rho_q[q] >> nn) & 1u) ? U - ((tuple >> nn) & 1u) : 0u;   // :667-674
+        const uint32_t s = val[i] ? val[i] - 2u + sgn[i] : 0u;                      // v_n = 2(mu-1)+sign (:601)
+        msl[i] = m;
+        msv[i] = m ? (s & ((m >= 32 ? 0u : (1u << m)) - 1u)) : 0u;
+      }
+    }
+    const bool q0on = active, q1on = has_q1;
+    if (!q1on) { uq[1] = 0; for (int nn = 4; nn < 8; ++nn) { msl[nn] = 0; msv[nn] = 0; } }
+    if (!q0on) { uq[0] = 0; for (int nn = 0; nn < 4; ++nn) { msl[nn] = 0; msv[nn] = 0; } }
+    any_sig |= (__ballot((rho[0] | rho[1]) != 0 && active) != 0ull) ? 1u : 0u;
+
+    // ---- VLC bits of the pair: cwd(q0) cwd(q1) then the interleaved U-VLC ----
+    uint32_t vb = 0, vl = 0;
+    auto vadd = [&](uint32_t c, uint32_t len) { vb |= c << vl; vl += len; };
+    auto uvlc = [](uint32_t u, uint32_t& pre, uint32_t& pl, uint32_t& suf, uint32_t& sl) {   // :196-255
+      if (u == 0) { pre = 0; pl = 0; suf = 0; sl = 0; }
+      else if (u == 1) { pre = 1; pl = 1; suf = 0; sl = 0; }
+      else if (u == 2) { pre = 2; pl = 2; suf = 0; sl = 0; }
+      else if (u <= 4) { pre = 4; pl = 3; suf = u - 3; sl = 1; }
+      else { pre = 0; pl = 3; suf = u - 5; sl = 5; }
+    };
+    bool ev2_valid = false; uint32_t ev2_bit = 0;
+    if (q0on) {
+      vadd(tup[0] >> 8, (tup[0] >> 4) & 7);
+      if (q1on) vadd(tup[1] >> 8, (tup[1] >> 4) & 7);
+      const uint32_t u0 = uq[0], u1 = uq[1];
+      uint32_t p0, l0, s0, sl0, p1, l1, s1, sl1;
+      if (first_row && u0 > 0 && u1 > 0) { ev2_valid = true; ev2_bit = min(u0, u1) > 2; }    // :763-764
+      if (first_row && u0 > 2 && u1 > 2) {                                                    // :766-772
+        uvlc(u0 - 2, p0, l0, s0, sl0); uvlc(u1 - 2, p1, l1, s1, sl1);
+        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1);
+      } else if (first_row && u0 > 2 && u1 > 0) {                                             // :773-778
+        uvlc(u0, p0, l0, s0, sl0);
+        vadd(p0, l0); vadd(u1 - 1, 1); vadd(s0, sl0);
+      } else {                                                                                // :779-785, :985-988
+        uvlc(u0, p0, l0, s0, sl0); uvlc(u1, p1, l1, s1, sl1);
+        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1);
+      }
+    }
+
+    // ---- MEL events of the pair, compacted in pair order ----
+    const bool ev0_valid = q0on && cq[0] == 0, ev1_valid = q1on && cq[1] == 0;
+    const uint32_t ev0_bit = rho[0] != 0, ev1_bit = rho[1] != 0;
+    {
+      const uint32_t cnt = (uint32_t)ev0_valid + (uint32_t)ev1_valid + (uint32_t)ev2_valid;
+      const uint32_t incl = wave_incl_scan(cnt, lane);
+      const uint32_t nev = rdlane(incl, 63);
+      uint32_t at = incl - cnt;
+      if (ev0_valid) { if (ev0_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+      if (ev1_valid) { if (ev1_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+      if (ev2_valid) { if (ev2_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+      wave_sync();
+      uint32_t done = 0;
+      while (done < nev) {                       // wave-uniform: whole zero runs at a time
+        const uint32_t w = done >> 5, sh = done & 31;
+        uint32_t word = rdfirst(L.ev[w]) >> sh;
+        const uint32_t avail = min(32u - sh, nev - done);
+        if (word == 0) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
+        const uint32_t z = (uint32_t)__builtin_ctz(word);
+        if (z >= avail) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
+        mel_zero_run(mel, L.mel, z, lane);
+        mel_one(mel, L.mel, lane);
+        done += z + 1;
+      }
+      wave_sync();
+      if (lane < 8) L.ev[lane] = 0;
+    }
+
+    // ---- MagSgn: OR the pair's bits into the flat buffer, then stuff a window at a time ----
+    {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tot += msl[i];
+      const uint32_t incl = wave_incl_scan(tot, lane);
+      const uint32_t T = ms_carry + rdlane(incl, 63);
+      uint32_t at = ms_carry + incl - tot;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { or_bits(L.ms, at, msv[i], msl[i]); at += msl[i]; }
+      wave_sync();
+      uint32_t pos = 0;
+      for (;;) {
+        const uint32_t first_n = ms_ff ? 7u : 8u;
+        const uint32_t start = pos + (lane == 0 ? 0u : first_n + 8u * (uint32_t)(lane - 1));
+        const uint32_t nb = lane == 0 ? first_n : 8u;
+        const bool ok = start + nb <= T;
+        const uint32_t v = ok ? get_bits(L.ms, start, nb) : 0u;
+        const uint64_t m_ok = __ballot(ok), m_ff = __ballot(ok && v == 0xFF);
+        const uint32_t n_ok = m_ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_ok);
+        const uint32_t f_ff = m_ff ? (uint32_t)__builtin_ctzll(m_ff) : 64u;
+        const uint32_t nc = min(n_ok, f_ff + 1u);
+        if (nc == 0) break;
+        if (ms_k + nc > ms_cap) { err = 1; break; }
+        if ((uint32_t)lane < nc) ms_out[ms_k + lane] = (uint8_t)v;
+        ms_k += nc;
+        pos += first_n + 8u * (nc - 1u);
+        ms_ff = f_ff < n_ok ? 1u : 0u;
+      }
+      const uint32_t rem = T - pos;                       // < 8 bits stay for the next step
+      const uint32_t cv = rem ? get_bits(L.ms, pos, rem) : 0u;
+      wave_sync();
+      const uint32_t used = (T >> 5) + 2;
+      for (uint32_t i = lane; i < used && i < (uint32_t)MS_WORDS; i += 64) L.ms[i] = 0;
+      wave_sync();
+      if (lane == 0) L.ms[0] = cv;
+      ms_carry = rem;
+      wave_sync();
+    }
+
+    // ---- VLC: same idea, bytes grow downwards and the stuffing rule looks at the byte above ----
+    {
+      const uint32_t incl = wave_incl_scan(vl, lane);
+      const uint32_t T = v_carry + rdlane(incl, 63);
+      or_bits(L.vlc, v_carry + incl - vl, vb, vl);
+      wave_sync();
+      uint32_t pos = 0;
+      for (;;) {
+        const uint32_t start = pos + 8u * (uint32_t)lane;
+        const bool have7 = start + 7 <= T, have8 = start + 8 <= T;
+        const uint32_t v8 = have7 ? get_bits(L.vlc, start, 8) : 0u;     // bits past T are zero
+        uint32_t pv = __shfl_up(v8, 1);
+        if (lane == 0) pv = v_prev;
+        const bool special = have7 && pv > 0x8F && (v8 & 0x7F) == 0x7F;    // :386-405
+        const bool stop = !have8 && !special;
+        const uint64_t m_sp = __ballot(special), m_st = __ballot(stop);
+        const uint32_t fs = m_sp ? (uint32_t)__builtin_ctzll(m_sp) : 64u;
+        const uint32_t ft = m_st ? (uint32_t)__builtin_ctzll(m_st) : 64u;
+        const uint32_t n8 = min(fs, ft);
+        const bool sp = fs < ft;
+        if (n8 == 0 && !sp) break;
+        if (v_pos + n8 + 1 >= (uint32_t)VLC_CAP) { err = 1; break; }
+        if ((uint32_t)lane < n8) *(vlc_last - (v_pos + lane)) = (uint8_t)v8;
+        if (sp && (uint32_t)lane == fs) *(vlc_last - (v_pos + lane)) = 0x7F;
+        const uint32_t last8 = n8 ? rdlane(v8, (int)(n8 - 1)) : v_prev;
+        v_pos += n8 + (sp ? 1u : 0u);
+        pos += 8u * n8 + (sp ? 7u : 0u);
+        v_prev = sp ? 0x7Fu : last8;
+      }
+      const uint32_t rem = T - pos;
+      const uint32_t cv = rem ? get_bits(L.vlc, pos, rem) : 0u;
+      wave_sync();
+      if (lane < VLC_WORDS) L.vlc[lane] = 0;
+      wave_sync();
+      if (lane == 0) L.vlc[0] = cv;
+      v_carry = rem;
+      wave_sync();
+    }
+    if (err) break;
+  }
+
+  err |= mel.err;
+  uint32_t total = 0, ms_len = ms_k;
+  if (!err && any_sig) {
+    // ---- ms_terminate (:517-534) ----
+    const uint32_t ms_tmp0 = rdfirst(L.ms[0]);
+    if (ms_carry) {
+      const uint32_t maxb = ms_ff ? 7u : 8u, t = maxb - ms_carry;
+      const uint32_t tmp = ms_tmp0 | ((0xFFu & ((1u << t) - 1u)) << ms_carry);
+      if (tmp != 0xFF) {
+        if (ms_len >= ms_cap) err = 1;
+        else { if (lane == 0) ms_out[ms_len] = (uint8_t)tmp; ms_len++; }
+      }
+    } else if (ms_ff) ms_len--;
+    // ---- terminate_mel_vlc (:412-441) ----
+    if (mel.run > 0) mel_put(mel, L.mel, 1, 1, lane);
+    const uint32_t need = mel.lastff ? 7u : 8u, remaining = need - mel.nb;
+    const uint32_t mel_tmp = (mel.acc << remaining) & 0xFFu;
+    const uint32_t mel_mask = (0xFFu << remaining) & 0xFFu;
+    const uint32_t vlc_tmp = rdfirst(L.vlc[0]) & 0xFFu;
+    const uint32_t vlc_mask = v_carry ? (0xFFu >> (8 - v_carry)) : 0u;
+    if ((mel_mask | vlc_mask) != 0) {
+      if (mel.pos >= (uint32_t)MEL_CAP) err = 1;
+      else {
+        const uint32_t fuse = mel_tmp | vlc_tmp;
+        if (((((fuse ^ mel_tmp) & mel_mask) | ((fuse ^ vlc_tmp) & vlc_mask)) == 0) && fuse != 0xFF && v_pos > 1) {
+          if (lane == 0) L.mel[mel.pos] = (uint8_t)fuse;
+          mel.pos++;
+        } else {
+          if (v_pos >= (uint32_t)VLC_CAP) err = 1;
+          else {
+            if (lane == 0) { L.mel[mel.pos] = (uint8_t)mel_tmp; *(vlc_last - v_pos) = (uint8_t)vlc_tmp; }
+            mel.pos++; v_pos++;
+          }
+        }
+      }
+    }
+    err |= mel.err;
+    total = ms_len + mel.pos + v_pos;
+  }
+  wave_sync();
+  __threadfence_block();
+
+  // ---- claim a slot in the compacted output and copy MagSgn | MEL | VLC (:1003-1014) ----
+  uint32_t off = 0;
+  if (err) total = 0;
+  if (total) {
+    if (lane == 0) off = atomicAdd(cursor, total);
+    off = rdfirst(off);
+    if (off + total > out_cap) { err = 1; total = 0; }
+  }
+  if (total) {
+    const uint32_t scup = mel.pos + v_pos;
+    uint8_t* dst = out + off;
+    const uint8_t* vsrc = vlc_last - v_pos + 1;
+    for (uint32_t i = lane; i < total; i += 64) {
+      uint32_t b;
+      if (i < ms_len) b = ms_out[i];
+      else if (i < ms_len + mel.pos) b = L.mel[i - ms_len];
+      else b = vsrc[i - ms_len - mel.pos];
+      if (i == total - 1) b = scup >> 4;
+      else if (i == total - 2) b = (b & 0xF0u) | (scup & 0xFu);
+      dst[i] = (uint8_t)b;
+    }
+  }
+  if (lane == 0) {
+    results[bi].offset = off; results[bi].length = total;
+    if (err) atomicOr(status, 1u);
+  }
+}
+
+}  // namespace
+
+extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                  const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
+                                  ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (ojphgpu::ensure_tables() != 0) return OJPHGPU_E_HIP;
+  if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
+  dim3 grid((n + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL(ht_encode_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                     (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+namespace ojphgpu {
+int upload_enc_tables(const HtTables& t)
+{
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_enc_vlc), t.enc_vlc, sizeof(t.enc_vlc)) == hipSuccess ? 0 : -1;
+}
+}

@@ -1,0 +1,388 @@
+// openjph_amd/csrc/ojphgpu_codec.cpp -- whole-frame encoder / decoder objects of the C ABI.
+//
+// These are what an ojph::codestream-compatible facade calls where the reference runs its
+// per-line object tree: ojphgpu_encoder_* replaces tile::push -> resolution::push_line ->
+// subband::push_line -> codeblock::push/encode (ojph_tile.cpp:332, ojph_resolution.cpp:547,
+// ojph_subband.cpp:292, ojph_codeblock.cpp:115-175) followed by codestream::flush
+// (ojph_codestream_local.cpp:1148); ojphgpu_decoder_* replaces codestream::read
+// (ojph_codestream_local.cpp:912) and the pull chain tile::pull -> resolution::pull_line ->
+// subband::pull_line -> codeblock::decode/pull_line (ojph_tile.cpp:425, ojph_resolution.cpp:713,
+// ojph_subband.cpp:336, ojph_codeblock.cpp:190-266).
+//
+// Layout in HBM (one arena of 32-bit elements per codec object, planned once per frame shape):
+//   [ tile-component planes per resolution | sub-band planes ]   see ojph_plan.cpp (alloc)
+// plus descriptor tables, the per-block scratch slots and the compacted code-block bytes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "ht_tables.h"
+#include "ojph_plan.h"
+
+using namespace ojphgpu;
+
+namespace ojphgpu {
+
+int ensure_tables()
+{
+  static std::mutex mu;
+  static bool done[64] = { false };
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done[dev]) return 0;
+  static HtTables tables;
+  static bool built = false;
+  if (!built) { build_ht_tables(tables); built = true; }
+  if (upload_enc_tables(tables) != 0 || upload_dec_tables(tables) != 0) return -1;
+  done[dev] = true;
+  return 0;
+}
+
+}  // namespace ojphgpu
+
+namespace {
+
+#define HIPCHK(x) do { if ((x) != hipSuccess) return OJPHGPU_E_HIP; } while (0)
+
+struct DeviceBuf {
+  void* p = nullptr; size_t n = 0;
+  int alloc(size_t bytes) { n = bytes; return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+struct LevelBatch { uint32_t first, count, max_w, max_h; };
+
+// DWT descriptors grouped by resolution so that one launch handles every tile-component
+void build_level_batches(const Plan& P, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
+{
+  const uint32_t L = P.p.num_decomps;
+  descs.clear(); batches.clear();
+  for (uint32_t r = L; r >= 1; --r) {
+    LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0 };
+    for (const ojphgpu_level_info& lv : P.levels) {
+      if (lv.res != r) continue;
+      ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
+      d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
+      d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
+      d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
+      descs.push_back(d);
+      b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
+    }
+    batches.push_back(b);
+  }
+}
+
+void build_convert_descs(const Plan& P, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
+{
+  descs.clear(); max_w = max_h = 0;
+  const uint32_t L = P.p.num_decomps;
+  for (const Tile& t : P.tiles)
+    for (uint32_t c = 0; c < P.p.num_comps; ++c) {
+      const TileComp& tc = P.tcomps[t.comps[c]];
+      const Resolution& R = P.ress[tc.res[L]];
+      ojphgpu_convert_desc d; memset(&d, 0, sizeof(d));
+      if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
+      else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
+      d.w = tc.r.w; d.h = tc.r.h; d.src_x0 = tc.r.x0; d.src_y0 = tc.r.y0;
+      descs.push_back(d);
+      max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
+    }
+}
+
+struct Timer {
+  hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  bool ok = false;
+  int init() { for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1; ok = true; return 0; }
+  void destroy() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+  void mark(int i, hipStream_t s) { if (ok) (void)hipEventRecord(ev[i], s); }
+  int read(float out[4]) {
+    if (!ok) return -1;
+    if (hipEventSynchronize(ev[3]) != hipSuccess) return -1;
+    for (int i = 0; i < 3; ++i) if (hipEventElapsedTime(&out[i], ev[i], ev[i + 1]) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&out[3], ev[0], ev[3]) != hipSuccess) return -1;
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+struct ojphgpu_encoder {
+  const ojphgpu_plan* handle = nullptr;
+  const Plan* P = nullptr;
+  int device = 0; hipStream_t stream = nullptr;
+  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, scratch, out, results, counters;
+  std::vector<LevelBatch> batches;
+  uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
+  std::vector<ojphgpu_cb_result> h_results;
+  std::vector<uint8_t> h_out;
+  Timer timer;
+  bool ran = false;
+};
+
+extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
+{
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
+                        &e->results, &e->counters }) b->release();
+  e->timer.destroy();
+  delete e;
+}
+
+extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_encoder** out)
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device));
+  if (ensure_tables() != 0) return OJPHGPU_E_HIP;
+  ojphgpu_encoder* e = new (std::nothrow) ojphgpu_encoder();
+  if (!e) return OJPHGPU_E_NOMEM;
+  const Plan& P = plan->plan;
+  e->handle = plan; e->P = &P; e->device = device; e->stream = (hipStream_t)stream;
+  auto bail = [&](int rc) { ojphgpu_encoder_destroy(e); return rc; };
+
+  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, e->batches);
+  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, e->conv_max_w, e->conv_max_h);
+  std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
+  uint64_t scratch_bytes = 0;
+  for (size_t i = 0; i < P.blocks.size(); ++i) {
+    const Block& k = P.blocks[i]; const Band& B = P.bands[k.band];
+    ojphgpu_cb_desc& d = bd[i]; memset(&d, 0, sizeof(d));
+    d.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; d.pitch = B.pitch;
+    d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)P.p.reversible;
+    d.missing_msbs = (uint8_t)(B.K_max - 1); d.num_passes = 1; d.delta = B.delta;
+    d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
+    scratch_bytes += d.scratch_cap;
+  }
+  const uint64_t samples = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
+  uint64_t cap = std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
+  cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
+  e->out_cap = (uint32_t)cap;
+
+  if (e->arena.alloc(P.arena_elems * 4) || e->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
+      e->cb_descs.alloc(bd.size() * sizeof(bd[0])) || e->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
+      e->scratch.alloc(scratch_bytes) || e->out.alloc(cap) ||
+      e->results.alloc(bd.size() * sizeof(ojphgpu_cb_result)) || e->counters.alloc(16))
+    return bail(OJPHGPU_E_NOMEM);
+  if (hipMemset(e->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!dd.empty() && hipMemcpy(e->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!bd.empty() && hipMemcpy(e->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!cd.empty() && hipMemcpy(e->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  e->h_results.resize(bd.size());
+  if (e->timer.init() != 0) return bail(OJPHGPU_E_HIP);
+  *out = e;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image)
+{
+  if (!e || !d_image) return OJPHGPU_E_INVALID;
+  const Plan& P = *e->P;
+  hipStream_t s = e->stream;
+  HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
+  e->timer.mark(0, s);
+  int rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, (uint32_t)P.tiles.size(),
+                                   e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
+  if (rc) return rc;
+  e->timer.mark(1, s);
+  for (const LevelBatch& b : e->batches) {
+    rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
+                             b.max_w, b.max_h, e->arena.p);
+    if (rc) return rc;
+  }
+  e->timer.mark(2, s);
+  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)P.blocks.size(), e->arena.p,
+                         (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap, (ojphgpu_cb_result*)e->results.p,
+                         (uint32_t*)e->counters.p, (uint32_t*)e->counters.p + 1);
+  if (rc) return rc;
+  e->timer.mark(3, s);
+  e->ran = true;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_coded_bytes(ojphgpu_encoder* e, uint64_t* bytes)
+{
+  if (!e || !bytes || !e->ran) return OJPHGPU_E_INVALID;
+  uint32_t c[2] = { 0, 0 };
+  HIPCHK(hipMemcpyAsync(c, e->counters.p, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *bytes = c[0];
+  return c[1] ? OJPHGPU_E_OVERFLOW : OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_finish(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
+  const Plan& P = *e->P;
+  uint64_t nbytes = 0;
+  int rc = ojphgpu_encoder_coded_bytes(e, &nbytes);
+  if (rc) return rc;
+  e->h_out.resize((size_t)nbytes + 16);
+  if (!e->h_results.empty())
+    HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, e->h_results.size() * sizeof(ojphgpu_cb_result),
+                          hipMemcpyDeviceToHost, e->stream));
+  if (nbytes) HIPCHK(hipMemcpyAsync(e->h_out.data(), e->out.p, (size_t)nbytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<ojphgpu_coded_block> cb(P.blocks.size());
+  for (size_t i = 0; i < cb.size(); ++i) {
+    const ojphgpu_cb_result& r = e->h_results[i];
+    cb[i].offset = r.offset; cb[i].len1 = r.length; cb[i].len2 = 0;
+    cb[i].missing_msbs = r.length ? P.bands[P.blocks[i].band].K_max - 1 : 0;      // ojph_codeblock.cpp:148
+    cb[i].num_passes = r.length ? 1 : 0;
+  }
+  return ojphgpu_t2_write(e->handle, e->h_out.data(), cb.data(), h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  if (!e || !h_image) return OJPHGPU_E_INVALID;
+  const Plan& P = *e->P;
+  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4;
+  if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
+  HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes, hipMemcpyHostToDevice, e->stream));
+  int rc = ojphgpu_encoder_run_device(e, (const int32_t*)e->image.p);
+  if (rc) return rc;
+  return ojphgpu_encoder_finish(e, h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encoder_timing(ojphgpu_encoder* e, float out[4])
+{
+  if (!e || !out || !e->ran) return OJPHGPU_E_INVALID;
+  return e->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct ojphgpu_decoder {
+  const Plan* P = nullptr;
+  int device = 0; hipStream_t stream = nullptr;
+  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, data, status;
+  std::vector<LevelBatch> batches;
+  uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
+  size_t data_len = 0;
+  Timer timer;
+  bool ran = false;
+};
+
+extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
+{
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status })
+    b->release();
+  d->timer.destroy();
+  delete d;
+}
+
+extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_decoder** out)
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  const Plan& P = plan->plan;
+  if (P.coded.size() != P.blocks.size()) return OJPHGPU_E_INVALID;    // plan must come from ojphgpu_t2_parse
+  HIPCHK(hipSetDevice(device));
+  if (ensure_tables() != 0) return OJPHGPU_E_HIP;
+  ojphgpu_decoder* d = new (std::nothrow) ojphgpu_decoder();
+  if (!d) return OJPHGPU_E_NOMEM;
+  d->P = &P; d->device = device; d->stream = (hipStream_t)stream;
+  auto bail = [&](int rc) { ojphgpu_decoder_destroy(d); return rc; };
+
+  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, d->batches);
+  std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
+  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, d->conv_max_w, d->conv_max_h);
+  std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
+  uint64_t max_off = 0;
+  for (size_t i = 0; i < P.blocks.size(); ++i) {
+    const Block& k = P.blocks[i]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[i];
+    ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
+    o.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
+    o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max; o.reversible = (uint8_t)P.p.reversible;
+    o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
+    o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
+    d->max_len1 = std::max(d->max_len1, c.len1);
+    max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
+  }
+  d->data_len = (size_t)max_off;
+  if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
+      d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
+      d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
+    return bail(OJPHGPU_E_NOMEM);
+  if (hipMemset(d->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!dd.empty() && hipMemcpy(d->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!bd.empty() && hipMemcpy(d->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!cd.empty() && hipMemcpy(d->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (d->timer.init() != 0) return bail(OJPHGPU_E_HIP);
+  *out = d;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_upload(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len)
+{
+  if (!d || !h_codestream || len < d->data_len) return OJPHGPU_E_INVALID;
+  if (d->data_len) HIPCHK(hipMemcpyAsync(d->data.p, h_codestream, d->data_len, hipMemcpyHostToDevice, d->stream));
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
+{
+  if (!d || !d_image) return OJPHGPU_E_INVALID;
+  const Plan& P = *d->P;
+  hipStream_t s = d->stream;
+  d->timer.mark(0, s);
+  int rc = ojphgpu_ht_decode(s, (const ojphgpu_cb_desc*)d->cb_descs.p, (uint32_t)P.blocks.size(), (const uint8_t*)d->data.p,
+                             d->arena.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w, P.p.block_h);
+  if (rc) return rc;
+  d->timer.mark(1, s);
+  for (const LevelBatch& b : d->batches) {
+    rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
+                             b.max_w, b.max_h, d->arena.p);
+    if (rc) return rc;
+  }
+  d->timer.mark(2, s);
+  rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, (uint32_t)P.tiles.size(),
+                               d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
+  if (rc) return rc;
+  d->timer.mark(3, s);
+  d->ran = true;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count)
+{
+  if (!d || !count || !d->ran) return OJPHGPU_E_INVALID;
+  std::vector<uint8_t> st(d->P->blocks.size());
+  if (!st.empty()) HIPCHK(hipMemcpyAsync(st.data(), d->status.p, st.size(), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  uint32_t n = 0;
+  for (uint8_t v : st) n += v != 0;
+  *count = n;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, int32_t* h_image)
+{
+  if (!d || !h_image) return OJPHGPU_E_INVALID;
+  const Plan& P = *d->P;
+  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4;
+  if (!d->image.p && d->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
+  int rc = ojphgpu_decoder_upload(d, h_codestream, len);
+  if (rc) return rc;
+  rc = ojphgpu_decoder_run_device(d, (int32_t*)d->image.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes, hipMemcpyDeviceToHost, d->stream));
+  uint32_t failed = 0;
+  rc = ojphgpu_decoder_failed_blocks(d, &failed);
+  if (rc) return rc;
+  return failed ? OJPHGPU_E_BLOCK : OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_timing(ojphgpu_decoder* d, float out[4])
+{
+  if (!d || !out || !d->ran) return OJPHGPU_E_INVALID;
+  return d->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
