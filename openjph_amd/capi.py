@@ -145,6 +145,13 @@ def lib():
                 "openjph_amd: %s is missing -- the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU "
                 "fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import it first so
+        # that libojphgpu.so binds to the SAME HIP runtime instance torch uses -- streams and
+        # device pointers are exchanged between the two.  (Pure C/C++ users simply get /opt/rocm's.)
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing only
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)
