@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- HTJ2K hot path on MI355X: Msamples/s for encode+decode of BASELINE.json's headline
+configuration (8K 7680x4320, 12-bit, 4:4:4, irreversible 9/7, Qstep 0.001, 64x64 blocks, 5 levels).
+
+A "step" is one pass of the hot path over one synthetic frame whose samples are already resident
+in HBM: encode (sample convert -> 5 DWT levels -> HT block encode) followed by decode (HT block
+decode -> 5 inverse DWT levels -> convert) of that frame's code-block bytes, also resident in HBM.
+Host Tier-2 (packet headers) and PCIe are outside the timed region; DESIGN.md quotes them.
+
+One process per GPU.  With N > 1 every rank codes its own independent frame (the path shards by
+frame / tile with no data-path collective): weak scaling, value = samples of all ranks / time.
+
+Prints ONE JSON line (rank 0).  Extra objects on that line:
+  roofline     -- the dominant kernel of the step against the HBM roofline, from live HIP-event
+                  timings on the codec's own stream (algorithmic bytes: SURVEY.md section 8(d))
+  cpu_baseline -- the reference library itself (oracle/_ref, built from /root/reference) timed
+                  on this box's host CPU, single thread (the library is single-threaded)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+
+WORKLOADS = {
+    # name: (width, height, comps, bit_depth, reversible, color_transform, qstep, tile)
+    "c3_8k_444_12b_irv97": (7680, 4320, 3, 12, False, False, 0.001, (0, 0)),
+    "c2_4k_rgb_8b_rev53": (3840, 2160, 3, 8, True, True, -1.0, (0, 0)),
+    "c4_16k_gray_16b_rev53_tiled": (16384, 16384, 1, 16, True, False, -1.0, (1024, 1024)),
+    "c1_256_gray_8b_rev53": (256, 256, 1, 8, True, False, -1.0, (0, 0)),
+}
+
+
+def dwt_alg_bytes(nsamples, levels):
+    """each level reads its input once and writes its four sub-bands once, 4-byte elements"""
+    return 8.0 * nsamples * sum(4.0 ** -l for l in range(levels))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3_8k_444_12b_irv97", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    from tests.synth import synth_image
+
+    w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[args.workload]
+    nsamples = w * h * nc
+    img = synth_image(nc, h, w, bd, seed=1234 + rank)
+    d_img = torch.from_numpy(img).to(dev)
+    params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
+    enc = codec.Encoder(params, device=local_rank)
+    t0 = time.perf_counter()
+    cs = enc.encode(d_img)                       # also serves as the first warm-up + produces the decoder's input
+    t_e2e_enc = time.perf_counter() - t0
+    dec = codec.Decoder(cs, device=local_rank)
+    d_out = torch.empty_like(d_img)
+    t0 = time.perf_counter()
+    dec.run_device(d_out)
+    torch.cuda.synchronize(dev)
+    failed = dec.failed_blocks()
+    assert failed == 0, "decode failed for %d code-blocks" % failed
+    err = (d_out - d_img).abs().max().item()
+    if rev:
+        assert err == 0, "reversible round trip is not lossless"
+    coded_bytes = enc.coded_bytes()
+    c_rate = coded_bytes / nsamples
+    levels = int(params.num_decomps)
+
+    def step():
+        enc.run_device(d_img)
+        dec.run_device(d_out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # per-kernel timings of the last step (HIP events on the codec's stream)
+    te, td = enc.timing(), dec.timing()
+    kernels = {
+        "dwt_forward(all levels)": (dwt_alg_bytes(nsamples, levels), te["dwt_ms"]),
+        "dwt_forward(level 1)": (8.0 * nsamples, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
+        "dwt_inverse(all levels)": (dwt_alg_bytes(nsamples, levels), td["dwt_ms"]),
+        "dwt_inverse(level 1)": (8.0 * nsamples, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
+        "ht_encode": ((4.0 + c_rate) * nsamples, te["ht_ms"]),
+        "ht_decode": ((4.0 + c_rate) * nsamples, td["ht_ms"]),
+        "convert_forward": (8.0 * nsamples, te["convert_ms"]),
+        "convert_inverse": (8.0 * nsamples, td["convert_ms"]),
+    }
+    kinfo = {}
+    for k, (b, ms) in kernels.items():
+        kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}
+    dom = max(("ht_encode", "ht_decode", "dwt_forward(all levels)", "dwt_inverse(all levels)",
+               "convert_forward", "convert_inverse"), key=lambda k: kernels[k][1])
+    dom_b, dom_ms = kernels[dom]
+    achieved = dom_b / 1e6 / dom_ms if dom_ms > 0 else 0.0
+
+    result = {
+        "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
+        "value": round(nsamples * world / (ms_per_step * 1e-3) / 1e6, 2),
+        "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32" if rev else "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "width": w, "height": h, "components": nc, "bit_depth": bd,
+                   "wavelet": "5/3 reversible" if rev else "9/7 irreversible", "qstep": qstep if not rev else None,
+                   "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
+                   "tile": list(tile), "frames_per_step": world, "sharding": "one frame per GPU",
+                   "coded_bytes_per_sample": round(c_rate, 4),
+                   "encode_ms": round(te["total_ms"], 4), "decode_ms": round(td["total_ms"], 4),
+                   "encode_Msamples_s": round(nsamples / te["total_ms"] / 1e3, 1),
+                   "decode_Msamples_s": round(nsamples / td["total_ms"] / 1e3, 1),
+                   "e2e_first_encode_s_incl_pcie_tier2": round(t_e2e_enc, 3),
+                   "roundtrip_max_abs_err": int(err)},
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+        "kernels": kinfo,
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(img, bd, rev, ct, qstep, tile, args.cpu_reps)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(img, bd, rev, ct, qstep, tile, reps):
+    """The reference library (its own SIMD dispatch) on this host, one thread, same frame."""
+    from oracle import refbind
+    if not refbind.available():
+        return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/libojph_ref.so missing"}
+    r = refbind.Ref()
+    best_e = best_d = 1e30
+    cs = None
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        cs = r.encode(img, bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
+        t1 = time.perf_counter()
+        r.decode(cs)
+        t2 = time.perf_counter()
+        best_e = min(best_e, t1 - t0); best_d = min(best_d, t2 - t1)
+    n = img.size
+    return {"value": round(n / (best_e + best_d) / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "sample": "the full %dx%dx%d frame, best of %d (encode %.3f s, decode %.3f s; simd level %d; host has %d cpus)"
+                      % (img.shape[2], img.shape[1], img.shape[0], reps, best_e, best_d, r.simd_level(), os.cpu_count()),
+            "encode_Msamples_s": round(n / best_e / 1e6, 2), "decode_Msamples_s": round(n / best_d / 1e6, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -234,6 +234,10 @@ int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t le
  * stream: out[0]=convert+colour [1]=DWT [2]=HT block coder [3]=total */
 int  ojphgpu_encoder_timing(ojphgpu_encoder* enc, float out[4]);
 int  ojphgpu_decoder_timing(ojphgpu_decoder* dec, float out[4]);
+/* duration (ms) of every DWT level launch of the last run_device, in launch order (encode:
+ * highest resolution first; decode: lowest first); *n = number of levels written */
+int  ojphgpu_encoder_level_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, uint32_t* n);
+int  ojphgpu_decoder_level_timing(ojphgpu_decoder* dec, float* out, uint32_t cap, uint32_t* n);
 
 const char* ojphgpu_version(void);
 

@@ -132,6 +132,8 @@ SIGNATURES = {
     "ojphgpu_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_encoder_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_decoder_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "ojphgpu_encoder_level_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ojphgpu_decoder_level_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_version": (C.c_char_p, []),
 }
 

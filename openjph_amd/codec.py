@@ -96,7 +96,9 @@ class Encoder:
     def timing(self):
         t = (C.c_float * 4)()
         check(self._lib.ojphgpu_encoder_timing(self._h, t), "encoder_timing")
-        return dict(convert_ms=t[0], dwt_ms=t[1], ht_ms=t[2], total_ms=t[3])
+        lv = (C.c_float * 40)(); n = C.c_uint32()
+        check(self._lib.ojphgpu_encoder_level_timing(self._h, lv, 40, C.byref(n)), "encoder_level_timing")
+        return dict(convert_ms=t[0], dwt_ms=t[1], ht_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)])
 
 
 class Decoder:
@@ -151,7 +153,9 @@ class Decoder:
     def timing(self):
         t = (C.c_float * 4)()
         check(self._lib.ojphgpu_decoder_timing(self._h, t), "decoder_timing")
-        return dict(ht_ms=t[0], dwt_ms=t[1], convert_ms=t[2], total_ms=t[3])
+        lv = (C.c_float * 40)(); n = C.c_uint32()
+        check(self._lib.ojphgpu_decoder_level_timing(self._h, lv, 40, C.byref(n)), "decoder_level_timing")
+        return dict(ht_ms=t[0], dwt_ms=t[1], convert_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)])
 
 
 def encode(image: np.ndarray, device=0, **kw) -> bytes:

@@ -94,18 +94,36 @@ void build_convert_descs(const Plan& P, std::vector<ojphgpu_convert_desc>& descs
     }
 }
 
+// HIP events on the codec's own stream: 4 stage marks + one mark after every DWT level launch
 struct Timer {
-  hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  static constexpr int MAXLV = 34;
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  hipEvent_t lv[MAXLV] = { nullptr };
+  int nlv = 0;
   bool ok = false;
-  int init() { for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1; ok = true; return 0; }
-  void destroy() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+  int init() {
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1;
+    for (auto& e : lv) if (hipEventCreate(&e) != hipSuccess) return -1;
+    ok = true; return 0;
+  }
+  void destroy() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& e : lv) if (e) (void)hipEventDestroy(e); }
   void mark(int i, hipStream_t s) { if (ok) (void)hipEventRecord(ev[i], s); }
+  void begin_levels() { nlv = 0; }
+  void mark_level(hipStream_t s) { if (ok && nlv < MAXLV) (void)hipEventRecord(lv[nlv++], s); }
   int read(float out[4]) {
     if (!ok) return -1;
     if (hipEventSynchronize(ev[3]) != hipSuccess) return -1;
     for (int i = 0; i < 3; ++i) if (hipEventElapsedTime(&out[i], ev[i], ev[i + 1]) != hipSuccess) return -1;
     if (hipEventElapsedTime(&out[3], ev[0], ev[3]) != hipSuccess) return -1;
     return 0;
+  }
+  // per-level DWT launch durations; `before` = the stage mark preceding the first level
+  int read_levels(int before, float* out, uint32_t cap) {
+    if (!ok) return -1;
+    if (hipEventSynchronize(ev[3]) != hipSuccess) return -1;
+    for (int i = 0; i < nlv && (uint32_t)i < cap; ++i)
+      if (hipEventElapsedTime(&out[i], i == 0 ? ev[before] : lv[i - 1], lv[i]) != hipSuccess) return -1;
+    return nlv;
   }
 };
 
@@ -191,10 +209,12 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
                                    e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
   if (rc) return rc;
   e->timer.mark(1, s);
+  e->timer.begin_levels();
   for (const LevelBatch& b : e->batches) {
     rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                              b.max_w, b.max_h, e->arena.p);
     if (rc) return rc;
+    e->timer.mark_level(s);
   }
   e->timer.mark(2, s);
   rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)P.blocks.size(), e->arena.p,
@@ -255,6 +275,15 @@ extern "C" int ojphgpu_encoder_timing(ojphgpu_encoder* e, float out[4])
 {
   if (!e || !out || !e->ran) return OJPHGPU_E_INVALID;
   return e->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint32_t cap, uint32_t* n)
+{
+  if (!e || !out || !n || !e->ran) return OJPHGPU_E_INVALID;
+  int k = e->timer.read_levels(1, out, cap);
+  if (k < 0) return OJPHGPU_E_HIP;
+  *n = (uint32_t)k;
+  return OJPHGPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,10 +367,12 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
                              d->arena.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w, P.p.block_h);
   if (rc) return rc;
   d->timer.mark(1, s);
+  d->timer.begin_levels();
   for (const LevelBatch& b : d->batches) {
     rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                              b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;
+    d->timer.mark_level(s);
   }
   d->timer.mark(2, s);
   rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, (uint32_t)P.tiles.size(),
@@ -385,4 +416,13 @@ extern "C" int ojphgpu_decoder_timing(ojphgpu_decoder* d, float out[4])
 {
   if (!d || !out || !d->ran) return OJPHGPU_E_INVALID;
   return d->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_decoder_level_timing(ojphgpu_decoder* d, float* out, uint32_t cap, uint32_t* n)
+{
+  if (!d || !out || !n || !d->ran) return OJPHGPU_E_INVALID;
+  int k = d->timer.read_levels(1, out, cap);
+  if (k < 0) return OJPHGPU_E_HIP;
+  *n = (uint32_t)k;
+  return OJPHGPU_OK;
 }
