@@ -156,7 +156,8 @@ typedef struct ojphgpu_cb_desc {     /* one code-block */
   uint32_t len1, len2;               /* decode: pass lengths */
   uint64_t data_off;                 /* decode: byte offset of the coded bytes in `d_data`;
                                         encode: byte offset of this block's scratch slot */
-  uint32_t scratch_cap;              /* encode: bytes available at data_off */
+  uint32_t scratch_cap;              /* encode: bytes available at data_off; decode: offset of the
+                                        block's per-quad records in d_quad_scratch (elements) */
   uint32_t reserved;
 } ojphgpu_cb_desc;
 
@@ -174,13 +175,16 @@ int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                       ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status);
 
 /* K9 + K7: HT decoder (ojph_block_decoder32.cpp:742-1613) with the dequantise transfer
- * (ojph_codestream_gen.cpp:124-168) fused.  One wavefront per code-block.  d_block_status[i]
- * = 0 ok / non-zero failed (block zeroed), mirroring the bool of decode_cb32.  max_len1 = max
- * over blocks of len1 and nominal_w x nominal_h = the nominal code-block size (they size the
- * per-wave LDS: flat MagSgn buffer and per-quad records). */
+ * (ojph_codestream_gen.cpp:124-168) fused.  Two launches: the serial MEL/VLC state machines run
+ * one lane per code-block, the MagSgn stage one wavefront per code-block.  For decoding,
+ * blocks[i].scratch_cap is the offset (in uint32 elements) of block i's per-quad records inside
+ * d_quad_scratch (ceil(w/2) * ceil(h/2) records per block).  d_block_status[i] = 0 ok / non-zero
+ * failed (block zeroed), mirroring the bool of decode_cb32.  max_len1 = max over blocks of len1
+ * and nominal_w x nominal_h = the nominal code-block size (they size the per-wave LDS). */
 int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
-                      const uint8_t* d_data, void* d_coef, uint8_t* d_block_status,
-                      uint32_t max_len1, uint32_t nominal_w, uint32_t nominal_h);
+                      const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
+                      uint8_t* d_block_status, uint32_t max_len1, uint32_t nominal_w,
+                      uint32_t nominal_h);
 
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */

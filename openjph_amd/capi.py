@@ -113,7 +113,7 @@ SIGNATURES = {
     "ojphgpu_ht_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ojphgpu_ht_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ojphgpu_convert_forward": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ojphgpu_convert_inverse": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,

@@ -205,12 +205,20 @@ def ht_encode(descs: np.ndarray, coef, scratch_bytes, out_cap):
 def ht_decode(descs: np.ndarray, data: np.ndarray, coef, max_len1, nominal=(64, 64)):
     torch = _torch()
     dev = coef.device.index
+    descs = descs.copy()
+    qoff = 0
+    for x in descs:                               # per-quad record offsets (see include/ojphgpu.h)
+        x["scratch_cap"] = qoff
+        qoff += ((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2)
     d = to_device(descs, dev)
     dd = to_device(np.concatenate([np.asarray(data, np.uint8), np.zeros(64, np.uint8)]), dev)
     status = torch.zeros(len(descs) + 16, dtype=torch.uint8, device=coef.device)
+    nq = int(sum(((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2) for x in descs))
+    quads = torch.zeros(nq + 16, dtype=torch.int32, device=coef.device)
     check(capi.lib().ojphgpu_ht_decode(_stream_ptr(torch, dev), C.c_void_p(d.data_ptr()), len(descs),
                                        C.c_void_p(dd.data_ptr()), C.c_void_p(coef.data_ptr()),
-                                       C.c_void_p(status.data_ptr()), int(max_len1), nominal[0], nominal[1]),
+                                       C.c_void_p(quads.data_ptr()), C.c_void_p(status.data_ptr()),
+                                       int(max_len1), nominal[0], nominal[1]),
           "ht_decode")
     torch.cuda.synchronize(dev)
     return status.cpu().numpy()[:len(descs)]

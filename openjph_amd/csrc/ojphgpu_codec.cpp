@@ -290,7 +290,7 @@ extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint
 struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, data, status;
+  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, data, status, quads;
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
   size_t data_len = 0;
@@ -302,7 +302,7 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status })
+  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads })
     b->release();
   d->timer.destroy();
   delete d;
@@ -325,7 +325,7 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, d->conv_max_w, d->conv_max_h);
   std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
-  uint64_t max_off = 0;
+  uint64_t max_off = 0, nquads = 0;
   for (size_t i = 0; i < P.blocks.size(); ++i) {
     const Block& k = P.blocks[i]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[i];
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
@@ -333,10 +333,14 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max; o.reversible = (uint8_t)P.p.reversible;
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
+    o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
+    nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2);
     d->max_len1 = std::max(d->max_len1, c.len1);
     max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
   }
   d->data_len = (size_t)max_off;
+  if (nquads >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
+  if (d->quads.alloc((size_t)nquads * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
@@ -364,7 +368,8 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   hipStream_t s = d->stream;
   d->timer.mark(0, s);
   int rc = ojphgpu_ht_decode(s, (const ojphgpu_cb_desc*)d->cb_descs.p, (uint32_t)P.blocks.size(), (const uint8_t*)d->data.p,
-                             d->arena.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w, P.p.block_h);
+                             d->arena.p, (uint32_t*)d->quads.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w,
+                             P.p.block_h);
   if (rc) return rc;
   d->timer.mark(1, s);
   d->timer.begin_levels();
