@@ -49,14 +49,17 @@ __device__ __forceinline__ void wave_sync()
 }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+// wave64 inclusive prefix sum with DPP adds (row shifts inside 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
 {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+  return (uint32_t)x;
 }
 
 __device__ __forceinline__ uint32_t mel_exp(uint32_t k)      // {0,0,0,1,1,1,2,2,2,3,3,4,5}
@@ -80,50 +83,81 @@ __device__ __forceinline__ uint32_t check_block(const ojphgpu_cb_desc& d, const 
 // -------------------------------------------------------------------------------------------------
 // step 1: one lane = one code-block
 // -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
+{
+  uint32_t v; __builtin_memcpy(&v, p, 4); return v;
+}
+
+// Both readers keep the NEXT four raw bytes in a register, loaded one refill ahead, so the HBM/L2
+// latency of the byte stream never sits on the serial decode chain.
 struct VlcReader {          // backward reader with un-stuffing (block_decoder32.cpp:308-439)
-  const uint8_t* p; int left; uint64_t tmp; uint32_t bits; uint32_t unstuff;
+  const uint8_t* p; int left; uint64_t tmp; uint32_t bits, unstuff, nxt;
+  __device__ __forceinline__ void fetch() {           // raw bytes p, p-1, p-2, p-3 -> nxt (first byte on top)
+    if (left >= 4) nxt = load_u32_unaligned(p - 3);
+    else {
+      nxt = 0;
+      if (left > 0) nxt |= (uint32_t)p[0] << 24;
+      if (left > 1) nxt |= (uint32_t)p[-1] << 16;
+      if (left > 2) nxt |= (uint32_t)p[-2] << 8;
+    }
+  }
   __device__ __forceinline__ void init(const uint8_t* cb, uint32_t lcup, uint32_t scup) {
     const uint32_t d = cb[lcup - 2];
     tmp = d >> 4;
     bits = 4u - (((uint32_t)tmp & 7u) == 7u ? 1u : 0u);
     unstuff = (d | 0xFu) > 0x8Fu;
     p = cb + lcup - 3; left = (int)scup - 2;
-    refill(); refill();
+    fetch(); refill(); refill();
   }
   __device__ __forceinline__ void refill() {
     if (bits > 32) return;
+    const uint32_t v = nxt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t b = 0;
-      if (left > 0) { b = *p; --p; --left; }
+    for (int k = 0; k < 4; ++k) {                     // bytes past the segment read as 0 (:313-331)
+      const uint32_t b = (v >> (24 - 8 * k)) & 0xFFu;
       const uint32_t nb = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
       tmp |= (uint64_t)(b & ((1u << nb) - 1u)) << bits;
       bits += nb;
       unstuff = b > 0x8Fu;
     }
+    p -= 4; left = left > 4 ? left - 4 : 0;
+    fetch();
   }
   __device__ __forceinline__ uint32_t peek() const { return (uint32_t)tmp; }
   __device__ __forceinline__ void skip(uint32_t n) { tmp >>= n; bits -= n; }
 };
 
 struct MelReader {          // forward, MSB first, 0xFF -> 7 bits (block_decoder32.cpp:93-269)
-  const uint8_t* p; int left; uint64_t tmp; int bits; uint32_t unstuff; uint32_t k, run, one;
+  const uint8_t* p; int left; uint64_t tmp; int bits; uint32_t unstuff, nxt; uint32_t k, run, one;
+  __device__ __forceinline__ void fetch() {           // raw bytes p .. p+3 -> nxt (first byte in the LSB)
+    if (left >= 4) { nxt = load_u32_unaligned(p); if (left == 4) nxt |= 0x0F000000u; }   // last byte |= 0xF (:116)
+    else {
+      nxt = 0xFFFFFFFFu;                              // past the end the segment continues with 0xFF (:98)
+      if (left > 0) nxt = (nxt & ~0xFFu) | (uint32_t)p[0] | (left == 1 ? 0xFu : 0u);
+      if (left > 1) nxt = (nxt & ~0xFF00u) | (((uint32_t)p[1] | (left == 2 ? 0xFu : 0u)) << 8);
+      if (left > 2) nxt = (nxt & ~0xFF0000u) | (((uint32_t)p[2] | (left == 3 ? 0xFu : 0u)) << 16);
+    }
+  }
   __device__ __forceinline__ void init(const uint8_t* cb, uint32_t lcup, uint32_t scup) {
     p = cb + lcup - scup; left = (int)scup - 1; tmp = 0; bits = 0; unstuff = 0; k = 0; run = 0; one = 0;
+    fetch(); refill();
   }
   __device__ __forceinline__ void refill() {
-    while (bits <= 32) {
-      uint32_t b = 0xFF;                           // past the end the segment continues with 0xFF (:98)
-      if (left > 0) { b = *p; ++p; if (left == 1) b |= 0xFu; --left; }   // last byte overlaps VLC (:116)
+    if (bits > 32) return;
+    const uint32_t v = nxt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t b = (v >> (8 * i)) & 0xFFu;
       const int nb = 8 - (int)unstuff;
       tmp |= (uint64_t)(b & ((1u << nb) - 1u)) << (64 - bits - nb);
       bits += nb;
       unstuff = (b == 0xFF);
     }
+    p += 4; left = left > 4 ? left - 4 : 0;
+    fetch();
   }
   __device__ __forceinline__ uint32_t sym() {     // T.814 decodeMELSym; same runs as :170-269
     if (run == 0 && one == 0) {
-      if (bits < 6) refill();
       const uint32_t e = mel_exp(k);
       if (tmp >> 63) { run = 1u << e; k = k < 12 ? k + 1 : 12; tmp <<= 1; bits -= 1; }
       else {
@@ -174,6 +208,8 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
     a_cur = 0; b_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       uint32_t t[2] = { 0, 0 };
+      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
+      mel.refill();                       // > 32 bits: a pair consumes at most 3 symbols of <= 6 bits
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const uint32_t x = qx + j;
@@ -196,7 +232,6 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
             c_q |= (nw | nn_l) << 7;                                                        // :990,:1024,:1026
             c_q |= (nn_r | ne) << 9;                                                        // :991,:1027
           }
-          vlc.refill();
           uint32_t tv = tbl[c_q + (vlc.peek() & 0x7Fu)];
           if (c_q == 0) { if (mel.sym() == 0) tv = 0; }                                     // :882-894
           vlc.skip(tv & 7u);
@@ -205,7 +240,6 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
         }
       }
       uint32_t mode = ((t[0] & 0x8u) << 3) | ((t[1] & 0x8u) << 4);
-      vlc.refill();
       uint32_t entry;
       if (qy == 0) {
         if (mode == 0xC0u) { if (mel.sym()) mode += 0x40u; }                                // :943-952
@@ -318,13 +352,20 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const float delta = d.delta;
   uint32_t mpos = 0;                              // wave-uniform bit position in the flat MagSgn stream
   bool bad = false;
+  uint32_t ent_next = (uint32_t)lane < QW ? rec[lane] : 0u;      // records are fetched one step ahead
   for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
     const uint8_t* vexp = (qy & 1) ? vexp_b : vexp_a;     // exponents of the sample row above
     uint8_t* vnew = (qy & 1) ? vexp_a : vexp_b;           // ... and of this quad row's bottom samples
     for (uint32_t qb = 0; qb < QW; qb += 64) {
       const uint32_t qx = qb + (uint32_t)lane;
       const bool act = qx < QW;
-      const uint32_t ent = act ? rec[qy * QW + qx] : 0u;
+      const uint32_t ent = ent_next;
+      {
+        uint32_t nqb = qb + 64, nqy = qy;
+        if (nqb >= QW) { nqb = 0; nqy = qy + 1; }
+        const uint32_t nqx = nqb + (uint32_t)lane;
+        ent_next = (nqy < QH && nqx < QW) ? rec[nqy * QW + nqx] : 0u;
+      }
       const uint32_t inf = ent & 0xFFFFu;
       uint32_t U_q = ent >> 16;
       if (qy > 0 && act) {

@@ -52,14 +52,17 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+// wave64 inclusive prefix sum with DPP adds (row shifts inside 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
 {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+  return (uint32_t)x;
 }
 
 __device__ __forceinline__ uint32_t get_bits(const uint32_t* buf, uint32_t pos, uint32_t n)
