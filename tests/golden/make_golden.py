@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz|json from the REAL reference (oracle/_ref/libojph_ref*.so built from
+/root/reference by oracle/Makefile).  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The fixtures pin (a) single code-block HT cleanup encodes (input seed -> coded bytes), (b) whole
+codestream digests for small images over a spread of parameters, (c) 5/3 and 9/7 one-level DWT
+outputs, so that `-m "not gpu"` tests can check the oracle on machines where the reference is
+absent (the GPU box).  Inputs are regenerated from seeds by tests/synth.py; only outputs are stored.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import refbind                      # noqa: E402
+from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
+from tests.golden_cases import BLOCK_CASES, STREAM_CASES, stream_kwargs  # noqa: E402
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def main():
+    ref = refbind.Ref()
+    refgen = refbind.Ref(generic=True)
+    out = {"reference": "aous72/OpenJPH 0.31.0 (oracle/_ref, simd level %d)" % ref.simd_level(),
+           "blocks": [], "streams": []}
+    blobs = {}
+    # (a) code-blocks
+    buf = ka2_block()
+    b = ref.encode_block(buf, 9, 64, 64, 64)
+    assert b == refgen.encode_block(buf, 9, 64, 64, 64)
+    out["ka2"] = {"len": len(b), "sha256": sha(b), "fnv1a64": refbind.fnv1a64(b)}
+    blobs["ka2"] = np.frombuffer(b, np.uint8)
+    for i, (w, h, kmax, density, amp, seed) in enumerate(BLOCK_CASES):
+        rng = np.random.default_rng(seed)
+        stride = (w + 15) // 16 * 16
+        q, _ = random_block(rng, w, h, stride, kmax, density, amp)
+        q[:, w:] = 0
+        b = ref.encode_block(q, kmax - 1, w, h, stride)
+        ok, dec = ref.decode_block(b, kmax - 1, w, h, stride)
+        assert ok
+        out["blocks"].append({"case": i, "len": len(b), "sha256": sha(b),
+                              "dec_sha256": sha(np.ascontiguousarray(dec[:, :w]).tobytes())})
+        if w * h <= 1024:
+            blobs["block%d" % i] = np.frombuffer(b, np.uint8)
+    # (b) codestreams
+    for i, case in enumerate(STREAM_CASES):
+        img, kw = stream_kwargs(case)
+        r = ref if kw.get("reversible", True) else refgen        # 9/7: the generic build is the pin
+        cs = r.encode(img, **kw)
+        dec, _ = r.decode(cs)
+        out["streams"].append({"case": i, "len": len(cs), "sha256": sha(cs),
+                               "dec_sha256": sha(dec.astype(np.int32).tobytes())})
+    cs = ref.encode(c1_image(), 8)
+    out["ka1"] = {"len": len(cs), "sha256": sha(cs), "fnv1a64": refbind.fnv1a64(cs)}
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "golden_blocks.npz"), **blobs)
+    print("wrote golden.json (%d blocks, %d streams) and golden_blocks.npz" % (len(out["blocks"]), len(out["streams"])))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Case lists shared by tests/golden/make_golden.py (which runs the real reference once, in the
+build container) and tests/test_cpu_parity.py (which checks the oracle + host pipeline against the
+stored reference outputs anywhere)."""
+from tests.synth import synth_image
+
+# (w, h, K_max, density, amplitude, seed) -- single HT code-blocks (ojph_encode_codeblock32 inputs)
+BLOCK_CASES = [
+    (64, 64, 10, 0.5, 300, 1), (64, 64, 8, 0.05, 100, 2), (64, 64, 16, 1.0, 30000, 3),
+    (64, 64, 12, 0.9, 3, 4), (32, 32, 9, 0.3, 200, 5), (128, 32, 11, 0.5, 900, 6),
+    (32, 128, 11, 0.5, 900, 7), (4, 1024, 10, 0.4, 400, 8), (1024, 4, 10, 0.4, 400, 9),
+    (1, 1, 6, 1.0, 20, 10), (1, 17, 7, 1.0, 60, 11), (17, 1, 7, 1.0, 60, 12), (2, 2, 5, 1.0, 15, 13),
+    (3, 5, 8, 0.7, 120, 14), (63, 61, 10, 0.6, 500, 15), (64, 3, 9, 0.2, 250, 16),
+    (5, 64, 9, 0.8, 250, 17), (64, 64, 20, 0.7, 500000, 18), (64, 64, 30, 0.6, 500000000, 19),
+    (64, 64, 6, 0.02, 30, 20), (16, 16, 7, 1.0, 1, 21), (47, 33, 13, 0.95, 4000, 22),
+]
+
+# whole codestreams: small images over a spread of parameters
+STREAM_CASES = [
+    dict(nc=1, h=256, w=256, bd=8),
+    dict(nc=3, h=200, w=300, bd=8, color_transform=True),
+    dict(nc=3, h=131, w=257, bd=10),
+    dict(nc=1, h=517, w=389, bd=12, num_decomps=3),
+    dict(nc=1, h=300, w=500, bd=16, tile=(128, 128)),
+    dict(nc=3, h=260, w=260, bd=8, prog_order="CPRL", precinct=(128, 128)),
+    dict(nc=1, h=200, w=333, bd=8, prog_order="LRCP"),
+    dict(nc=1, h=200, w=333, bd=8, prog_order="RLCP", tile=(100, 200)),
+    dict(nc=3, h=150, w=150, bd=8, prog_order="PCRL", precinct=(64, 64)),
+    dict(nc=1, h=64, w=1, bd=8),
+    dict(nc=1, h=1, w=64, bd=8),
+    dict(nc=1, h=1, w=1, bd=8),
+    dict(nc=1, h=5, w=7, bd=8),
+    dict(nc=1, h=200, w=200, bd=8, block=(128, 32)),
+    dict(nc=1, h=200, w=200, bd=8, block=(4, 1024)),
+    dict(nc=1, h=256, w=256, bd=8, signed=True),
+    dict(nc=1, h=256, w=256, bd=8, num_decomps=0),
+    dict(nc=1, h=256, w=256, bd=8, tlm=True, tile=(64, 64)),
+    dict(nc=1, h=256, w=256, bd=12, reversible=False),
+    dict(nc=3, h=200, w=300, bd=8, reversible=False, color_transform=True),
+    dict(nc=3, h=240, w=320, bd=12, reversible=False, qstep=0.001),
+    dict(nc=1, h=300, w=500, bd=10, reversible=False, tile=(128, 128), qstep=0.01),
+    dict(nc=1, h=97, w=113, bd=8, reversible=False, num_decomps=2, qstep=0.05),
+]
+
+
+def stream_kwargs(case, seed=3):
+    """-> (image int32 [C,H,W], kwargs understood by plan.make_params / refbind.Ref.encode)"""
+    c = dict(case)
+    nc, h, w, bd = c.pop("nc"), c.pop("h"), c.pop("w"), c.pop("bd")
+    signed = c.pop("signed", False)
+    img = synth_image(nc, h, w, bd, seed=seed, signed=signed)
+    return img, dict(c, bit_depth=bd, is_signed=signed)

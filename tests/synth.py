@@ -29,3 +29,16 @@ def random_block(rng, w, h, stride, kmax, density, amp):
     v = (rng.integers(-amp, amp + 1, size=(h, stride)) * (rng.random((h, stride)) < density)).astype(np.int64)
     buf = ((v < 0).astype(np.uint32) << np.uint32(31)) | (np.abs(v).astype(np.uint32) << np.uint32(31 - kmax))
     return buf.astype(np.uint32), v
+
+
+def ka2_block():
+    """64x64 block, K_max 10, LCG-driven sparse large + dense small values."""
+    s = 12345
+    K = 10
+    buf = np.zeros((64, 64), np.uint32)
+    for y in range(64):
+        for x in range(64):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            v = (((s >> 16) & 0x3FF) - 512) * (1 if (x + y) % 7 == 0 else 0) + (((s >> 8) & 7) - 3)
+            buf[y, x] = ((1 << 31) if v < 0 else 0) | (abs(v) << (31 - K))
+    return buf
