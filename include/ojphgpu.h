@@ -147,6 +147,19 @@ int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_
 int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n,
                         uint32_t max_w, uint32_t max_h, void* d_base);
 
+/* The same transforms with the sample conversion of the adjacent stage fused in (no colour
+ * transform): the first analysis level reads the int32 image planes directly -- level shift
+ * (gen_rev_convert, ojph_colour.cpp:238) or int -> float (gen_irv_convert_to_float, :388) applied
+ * in the load -- and the last synthesis level writes them (gen_irv_convert_to_integer, :316).
+ * For these two calls desc.src_off / src_pitch address the plane inside d_image (elements),
+ * everything else inside d_base.  Saves one read + one write of the whole frame per direction. */
+int ojphgpu_dwt_forward_image(void* stream, const ojphgpu_params* params,
+                              const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w,
+                              uint32_t max_h, const int32_t* d_image, void* d_base);
+int ojphgpu_dwt_inverse_image(void* stream, const ojphgpu_params* params,
+                              const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w,
+                              uint32_t max_h, int32_t* d_image, void* d_base);
+
 typedef struct ojphgpu_cb_desc {     /* one code-block */
   uint64_t coef_off;                 /* element offset of the block's first sample in `d_coef` */
   uint32_t pitch;                    /* elements */

@@ -110,6 +110,10 @@ SIGNATURES = {
                                       C.c_uint32, C.c_void_p]),
     "ojphgpu_dwt_inverse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_void_p]),
+    "ojphgpu_dwt_forward_image": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_void_p, C.c_void_p]),
+    "ojphgpu_dwt_inverse_image": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_void_p, C.c_void_p]),
     "ojphgpu_ht_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ojphgpu_ht_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,

@@ -13,8 +13,18 @@
 //   * vertical lifting is a software pipeline in registers: the lane keeps the 4-step lifting
 //     state of its two columns (x, a, b, c) and emits one low and one high row per iteration.
 //   * horizontal lifting of the emitted rows happens in the same registers: the neighbour
-//     column pair is the neighbour lane, fetched with a wave shuffle.  Strips overlap by 2 pairs
-//     on each side (halo recomputation) so no inter-wave exchange is needed.
+//     column pair is the neighbour lane, fetched with a DPP wave shift (wave_shl:1 / wave_shr:1,
+//     a plain VALU move -- no LDS crossbar).  Strips overlap by 2 pairs on each side (halo
+//     recomputation) so no inter-wave exchange is needed.
+//   * the rows of iteration t+1 are requested before iteration t computes and stores, so the
+//     HBM latency of the row stream overlaps the lifting arithmetic of the previous row pair.
+//   * the number of row pairs a wavefront walks (its vertical chunk) is chosen per launch so
+//     that every level of the pyramid fills the 256 CUs: 64 at full resolution, down to 8 at
+//     the small levels, where the kernel is otherwise bound by the length of the serial walk.
+//   * the first analysis level can read the int32 image planes directly (level shift / int ->
+//     float conversion of ojph_colour.cpp:238-436 applied in the load), and the last synthesis
+//     level can write them (float -> int with rounding + clamp), which removes one full
+//     read+write pass over the frame in each direction when no colour transform is used.
 //   * the four sub-band rows are written as coalesced 256-byte segments (4 B / lane).
 //   Analysis is vertical-then-horizontal, synthesis horizontal-then-vertical, exactly the
 //   reference's order -- for 5/3 the rounding makes the order observable.
@@ -29,7 +39,8 @@ namespace {
 
 constexpr int HALO = 2;             // column pairs recomputed on each side of a strip
 constexpr int VALID = 64 - 2 * HALO; // 60 pairs = 120 columns produced per wavefront
-constexpr int ROW_PAIRS = 64;       // row pairs produced per strip (128 image rows)
+constexpr int MAX_ROW_PAIRS = 64;   // row pairs produced per strip at full resolution (128 image rows)
+constexpr int MIN_ROW_PAIRS = 8;
 
 template <bool REV> struct Wv;
 
@@ -68,6 +79,13 @@ template <> struct Wv<false> {      // irreversible 9/7 (ojph_params.cpp:2870-28
   static __device__ __forceinline__ T halve(T v) { return __fmul_rn(v, 0.5f); }
 };
 
+// value of the same register in lane+1 / lane-1 (DPP wave shifts; the end lanes keep their own
+// value, they are halo lanes whose results are never stored)
+__device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
+__device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
+__device__ __forceinline__ float lane_next(float v) { return __int_as_float(lane_next(__float_as_int(v))); }
+__device__ __forceinline__ float lane_prev(float v) { return __int_as_float(lane_prev(__float_as_int(v))); }
+
 // neighbour selection with the "missing -> use the other one" rule
 template <typename T>
 __device__ __forceinline__ T pick(bool e, T v, T other) { return e ? v : other; }
@@ -89,14 +107,14 @@ __device__ __forceinline__ void horz_analysis(typename Wv<REV>::T& vl, typename 
 {
   typedef typename Wv<REV>::T T;
   if (g.w == 1) { if (g.ox) vh = Wv<REV>::dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
-  T nl = __shfl_down(vl, 1);
+  T nl = lane_next(vl);
   vh = Wv<REV>::a0(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
-  T ph = __shfl_up(vh, 1);
+  T ph = lane_prev(vh);
   vl = Wv<REV>::a1(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
   if (!REV) {
-    nl = __shfl_down(vl, 1);
+    nl = lane_next(vl);
     vh = Wv<REV>::a2(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
-    ph = __shfl_up(vh, 1);
+    ph = lane_prev(vh);
     vl = Wv<REV>::a3(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
     vl = Wv<REV>::mulKinv(vl); vh = Wv<REV>::mulK(vh);          // ojph_transform.cpp:763-775
   }
@@ -108,14 +126,14 @@ __device__ __forceinline__ void horz_synthesis(typename Wv<REV>::T& vl, typename
   typedef typename Wv<REV>::T T;
   if (g.w == 1) { if (g.ox) vh = Wv<REV>::halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
   if (!REV) { vl = Wv<REV>::mulK(vl); vh = Wv<REV>::mulKinv(vh); }   // :797-809
-  T ph = __shfl_up(vh, 1);
+  T ph = lane_prev(vh);
   vl = Wv<REV>::s0(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
-  T nl = __shfl_down(vl, 1);
+  T nl = lane_next(vl);
   vh = Wv<REV>::s1(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
   if (!REV) {
-    ph = __shfl_up(vh, 1);
+    ph = lane_prev(vh);
     vl = Wv<REV>::s2(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
-    nl = __shfl_down(vl, 1);
+    nl = lane_next(vl);
     vh = Wv<REV>::s3(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
   }
 }
@@ -132,46 +150,102 @@ __device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, 
   return g;
 }
 
-// loads the lane's two columns of image row y (plane-relative); missing samples read as 0
-template <typename T>
-__device__ __forceinline__ Pair<T> load_pair(const T* __restrict__ row, const Geo& g)
+// sample conversion between the int32 image planes and the working type, fused into the first
+// analysis / last synthesis level (ojph_colour.cpp:238-275 rev, :388-436 to float, :316-386 to int)
+struct Conv { int bit_depth, is_signed; };
+
+template <bool REV> struct Cv;
+template <> struct Cv<true> {
+  static __device__ __forceinline__ int from_image(int v, const Conv& c) { return v - (c.is_signed ? 0 : (1 << (c.bit_depth - 1))); }
+  static __device__ __forceinline__ int to_image(int v, const Conv& c) { return v + (c.is_signed ? 0 : (1 << (c.bit_depth - 1))); }
+};
+template <> struct Cv<false> {
+  static __device__ __forceinline__ float from_image(int v, const Conv& c) {
+    const float mul = __uint_as_float((uint32_t)(127 - c.bit_depth) << 23);            // 2^-B
+    const int half = c.is_signed ? 0 : (1 << (c.bit_depth - 1));
+    return __fmul_rn((float)(v - half), mul);
+  }
+  static __device__ __forceinline__ int to_image(float f, const Conv& c) {
+    const int neg_limit = (int)0x80000000 >> (32 - c.bit_depth);
+    const float mul = __uint_as_float((uint32_t)(127 + c.bit_depth) << 23);            // 2^B
+    const float up = -(float)neg_limit, low = (float)neg_limit;
+    const int s_up = 0x7FFFFFFF >> (32 - c.bit_depth), s_low = neg_limit;
+    const int half = c.is_signed ? 0 : (1 << (c.bit_depth - 1));
+    const float t = __fmul_rn(f, mul);
+    int v = (int)__fadd_rn(t, t >= 0.0f ? 0.5f : -0.5f);    // ojph_round: truncation of t +- 0.5
+    v = t >= low ? v : s_low;
+    v = t < up ? v : s_up;
+    return v + half;
+  }
+};
+
+struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
+
+// loads the lane's two columns of row `row` (plane-relative); missing samples read as 0.
+// IMG: `row` points into an int32 image plane and the samples are converted on the fly.
+template <bool REV, bool IMG>
+__device__ __forceinline__ Pair<typename Wv<REV>::T> load_pair(const void* __restrict__ rowp, const Geo& g, const Conv& cv)
 {
+  typedef typename Wv<REV>::T T;
   Pair<T> p; p.l = 0; p.h = 0;
-  int xl = 2 * g.j - g.ox;
-  if (g.ox == 0) {
-    if (g.eL && g.eH) {
-      typedef T V2 __attribute__((ext_vector_type(2)));
-      V2 v = *reinterpret_cast<const V2*>(row + xl);
-      p.l = v.x; p.h = v.y;
-    } else if (g.eL) p.l = row[xl];
+  const int xl = 2 * g.j - g.ox;
+  if (IMG) {
+    const int* row = (const int*)rowp;
+    int a = 0, b = 0;
+    if (g.eL && g.eH) { const I2 v = *reinterpret_cast<const I2*>(row + xl); a = v.x; b = v.y; }
+    else if (g.eL) a = row[xl];
+    else if (g.eH) b = row[xl + 1];
+    if (g.eL) p.l = Cv<REV>::from_image(a, cv);
+    if (g.eH) p.h = Cv<REV>::from_image(b, cv);
   } else {
-    if (g.eL) p.l = row[xl];
-    if (g.eH) p.h = row[xl + 1];
+    const T* row = (const T*)rowp;
+    if (g.ox == 0) {
+      if (g.eL && g.eH) {
+        typedef T V2 __attribute__((ext_vector_type(2)));
+        V2 v = *reinterpret_cast<const V2*>(row + xl);
+        p.l = v.x; p.h = v.y;
+      } else if (g.eL) p.l = row[xl];
+    } else {
+      if (g.eL) p.l = row[xl];
+      if (g.eH) p.h = row[xl + 1];
+    }
   }
   return p;
 }
 
-template <typename T>
-__device__ __forceinline__ void store_pair(T* __restrict__ row, const Geo& g, T l, T h)
+template <bool REV, bool IMG>
+__device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
+                                           const Conv& cv)
 {
+  typedef typename Wv<REV>::T T;
   if (!g.store) return;
-  int xl = 2 * g.j - g.ox;
-  if (g.ox == 0 && g.eL && g.eH) {
-    typedef T V2 __attribute__((ext_vector_type(2)));
-    V2 v; v.x = l; v.y = h;
-    *reinterpret_cast<V2*>(row + xl) = v;
+  const int xl = 2 * g.j - g.ox;
+  if (IMG) {
+    int* row = (int*)rowp;
+    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
+    if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
+    else if (g.eL) row[xl] = a;
+    else if (g.eH) row[xl + 1] = b;
   } else {
-    if (g.eL) row[xl] = l;
-    if (g.eH) row[xl + 1] = h;
+    T* row = (T*)rowp;
+    if (g.ox == 0 && g.eL && g.eH) {
+      typedef T V2 __attribute__((ext_vector_type(2)));
+      V2 v; v.x = l; v.y = h;
+      *reinterpret_cast<V2*>(row + xl) = v;
+    } else {
+      if (g.eL) row[xl] = l;
+      if (g.eH) row[xl + 1] = h;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: plane -> LL, HL, LH, HH
+// forward: plane (or image plane, IMG) -> LL, HL, LH, HH
 // ---------------------------------------------------------------------------------------------
-template <bool REV>
+template <bool REV, bool IMG>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
-                                                          typename Wv<REV>::T* __restrict__ base)
+                                                          typename Wv<REV>::T* __restrict__ base,
+                                                          const int* __restrict__ image, Conv cv, int row_pairs)
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
@@ -182,16 +256,20 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const Geo g = make_geo(d, strip_x, lane);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
-  const int i0 = blockIdx.y * ROW_PAIRS;
+  const int i0 = blockIdx.y * row_pairs;
   if (i0 >= npy) return;
-  const int i1 = min(i0 + ROW_PAIRS, npy);
+  const int i1 = min(i0 + row_pairs, npy);
 
-  const T* src = base + d.src_off;
+  const char* src = IMG ? (const char*)(image + d.src_off) : (const char*)(base + d.src_off);
+  const size_t sp = (size_t)d.src_pitch * 4;
   T* ll = base + d.ll_off; T* hl = base + d.hl_off; T* lh = base + d.lh_off; T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
-  auto rowL = [&](int t) { return 2 * t - oy; };          // image row of the low row of pair t
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
+  auto ldrow = [&](int y, bool ex) {                       // image row y of the plane (0 when it does not exist)
+    Pair<T> z; z.l = z.h = 0;
+    return ex ? load_pair<REV, IMG>(src + (size_t)y * sp, g, cv) : z;
+  };
   auto emit = [&](int t, bool low_row, T vl, T vh) {       // horizontal pass + store of one row
     horz_analysis<REV>(vl, vh, g);
     if (!g.store) return;
@@ -204,22 +282,25 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 
   if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
     if (i0 > 0) return;
-    Pair<T> x = load_pair(src, g);
+    Pair<T> x = ldrow(0, true);
     if (oy == 0) emit(0, true, x.l, x.h);
     else emit(0, false, W::dbl(x.l), W::dbl(x.h));
     return;
   }
 
   // vertical software pipeline over row pairs t; see file header
-  const int t0 = max(i0 - 2, 0);
+  const int t0 = max(i0 - (REV ? 1 : 2), 0);
   Pair<T> xl, xn, a, ap, b, bp, c, cp;   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
   xl.l = xl.h = 0; a = ap = b = bp = c = cp = xl;
-  if (exL(t0)) xl = load_pair(src + (size_t)rowL(t0) * d.src_pitch, g);
+  xl = ldrow(2 * t0 - oy, exL(t0));
+  Pair<T> nh = ldrow(2 * t0 + 1 - oy, exH(t0)), nn = ldrow(2 * t0 + 2 - oy, exL(t0 + 1));   // rows of iteration t0
   for (int t = t0; t <= i1; ++t) {
-    Pair<T> xh; xh.l = xh.h = 0; xn = xh;
+    const Pair<T> xh = nh; xn = nn;
     const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
-    if (eHt) xh = load_pair(src + (size_t)(rowL(t) + 1) * d.src_pitch, g);
-    if (eLn) xn = load_pair(src + (size_t)(rowL(t) + 2) * d.src_pitch, g);
+    if (t < i1) {                                          // request the rows of iteration t+1 now
+      nh = ldrow(2 * t + 3 - oy, exH(t + 1));
+      nn = ldrow(2 * t + 4 - oy, exL(t + 2));
+    }
     // a[t]
     ap = a;
     a.l = W::a0(xh.l, pick(eLt, xl.l, xn.l), pick(eLn, xn.l, xl.l));
@@ -248,11 +329,12 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 }
 
 // ---------------------------------------------------------------------------------------------
-// inverse: LL, HL, LH, HH -> plane
+// inverse: LL, HL, LH, HH -> plane (or image plane, IMG)
 // ---------------------------------------------------------------------------------------------
-template <bool REV>
+template <bool REV, bool IMG>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
-                                                          typename Wv<REV>::T* __restrict__ base)
+                                                          typename Wv<REV>::T* __restrict__ base,
+                                                          int* __restrict__ image, Conv cv, int row_pairs)
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
@@ -263,49 +345,51 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const Geo g = make_geo(d, strip_x, lane);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
-  const int i0 = blockIdx.y * ROW_PAIRS;
+  const int i0 = blockIdx.y * row_pairs;
   if (i0 >= npy) return;
-  const int i1 = min(i0 + ROW_PAIRS, npy);
+  const int i1 = min(i0 + row_pairs, npy);
 
-  T* dst = base + d.src_off;
+  char* dst = IMG ? (char*)(image + d.src_off) : (char*)(base + d.src_off);
+  const size_t dp = (size_t)d.src_pitch * 4;
   const T* ll = base + d.ll_off; const T* hl = base + d.hl_off;
   const T* lh = base + d.lh_off; const T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  // fetches a sub-band row pair and runs the horizontal synthesis: returns the lane's two
-  // columns of the (vertically still transformed) row
-  auto fetch = [&](int t, bool low_row) {
+  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t
+  auto fetch = [&](int t, bool low_row, bool ex) {
+    Pair<T> p; p.l = p.h = 0;
+    if (!ex) return p;
     const T* lo = low_row ? ll : lh; const T* hi = low_row ? hl : hh;
     const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
     const int r = low_row ? t - oy : t;
-    T vl = 0, vh = 0;
-    if (g.eL) vl = lo[(size_t)r * lop + (g.j - g.ox)];
-    if (g.eH) vh = hi[(size_t)r * hip + g.j];
-    horz_synthesis<REV>(vl, vh, g);
-    Pair<T> p; p.l = vl; p.h = vh;
+    if (g.eL) p.l = lo[(size_t)r * lop + (g.j - g.ox)];
+    if (g.eH) p.h = hi[(size_t)r * hip + g.j];
     return p;
   };
+  auto horz = [&](Pair<T> p) { horz_synthesis<REV>(p.l, p.h, g); return p; };
 
   if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
     if (i0 > 0) return;
-    Pair<T> x = fetch(0, oy == 0);
+    Pair<T> x = horz(fetch(0, oy == 0, true));
     if (oy != 0) { x.l = W::halve(x.l); x.h = W::halve(x.h); }
-    store_pair(dst, g, x.l, x.h);
+    store_pair<REV, IMG>(dst, g, x.l, x.h, cv);
     return;
   }
 
-  const int t0 = max(i0 - 2, 0);
+  const int t0 = max(i0 - (REV ? 1 : 2), 0);
   Pair<T> z; z.l = z.h = 0;
   Pair<T> c = z, cp = z, b = z, bp = z, a = z, ap = z, xL = z, xLp = z;
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
+  Pair<T> nlo = fetch(t0, true, exL(t0)), nhi = fetch(t0, false, exH(t0));       // sub-band rows of iteration t0
   for (int t = t0; t <= i1 + 1; ++t) {
     const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
     const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
-    Pair<T> dd = z;
+    Pair<T> dd = nlo, cc = nhi;
+    if (t <= i1) { nlo = fetch(t + 1, true, exL(t + 1)); nhi = fetch(t + 1, false, exH(t + 1)); }   // request t+1 now
     cp = c; c = z;
-    if (eLt) { dd = fetch(t, true); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); }            // :855-856
-    if (eHt) { c = fetch(t, false); c.l = W::mulKinv(c.l); c.h = W::mulKinv(c.h); }          // :871-872
+    if (eLt) { dd = horz(dd); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;     // :855-856
+    if (eHt) { c = horz(cc); c.l = W::mulKinv(c.l); c.h = W::mulKinv(c.h); }                // :871-872
     // b[t]
     bp = b;
     b.l = W::s0(dd.l, pick(eHp, cp.l, c.l), pick(eHt, c.l, cp.l));
@@ -322,17 +406,54 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     T xhl = W::s3(ap.l, pick(eLpp, xLp.l, xL.l), pick(eLp, xL.l, xLp.l));
     T xhh = W::s3(ap.h, pick(eLpp, xLp.h, xL.h), pick(eLp, xL.h, xLp.h));
     if (t - 2 >= i0 && t - 2 < i1 && eHpp)
-      store_pair(dst + (size_t)(2 * (t - 2) + 1 - oy) * d.src_pitch, g, xhl, xhh);
+      store_pair<REV, IMG>(dst + (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xhl, xhh, cv);
     if (t - 1 >= i0 && t - 1 < i1 && eLp)
-      store_pair(dst + (size_t)(2 * (t - 1) - oy) * d.src_pitch, g, xL.l, xL.h);
+      store_pair<REV, IMG>(dst + (size_t)(2 * (t - 1) - oy) * dp, g, xL.l, xL.h, cv);
   }
 }
 
-dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h)
+// vertical chunk: as tall as possible (less halo recomputation) while the launch still offers
+// ~16 waves per CU; the result is wave-uniform per launch
+int pick_row_pairs(uint32_t n, uint32_t max_w, uint32_t max_h)
+{
+  const uint32_t npx = (max_w + 2) >> 1, npy = (max_h + 2) >> 1;
+  const uint64_t strips = (uint64_t)((npx + VALID - 1) / VALID) * n;
+  const uint64_t want_waves = 4096;
+  uint64_t chunks = (want_waves + strips - 1) / strips;
+  if (chunks < 1) chunks = 1;
+  uint64_t rp = (npy + chunks - 1) / chunks;
+  rp = (rp + 7) & ~7ull;
+  if (rp < (uint64_t)MIN_ROW_PAIRS) rp = MIN_ROW_PAIRS;
+  if (rp > (uint64_t)MAX_ROW_PAIRS) rp = MAX_ROW_PAIRS;
+  return (int)rp;
+}
+
+dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h, int rp)
 {
   uint32_t npx = (max_w + 2) >> 1, npy = (max_h + 2) >> 1;
   uint32_t sx = (npx + VALID - 1) / VALID;
-  return dim3((sx + 3) / 4, (npy + ROW_PAIRS - 1) / ROW_PAIRS, n);
+  return dim3((sx + 3) / 4, (npy + rp - 1) / rp, n);
+}
+
+template <bool FWD>
+int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+           void* d_base, int32_t* d_image, Conv cv)
+{
+  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
+  const int rp = pick_row_pairs(n, max_w, max_h);
+  const dim3 grid = dwt_grid(n, max_w, max_h, rp);
+  hipStream_t s = (hipStream_t)stream;
+#define OJPH_LAUNCH(K, REV, IMG, TP) hipLaunchKernelGGL((K<REV, IMG>), grid, dim3(256), 0, s, d_descs, (TP*)d_base, d_image, cv, rp)
+  if (FWD) {
+    if (reversible) { if (d_image) OJPH_LAUNCH(dwt_forward_kernel, true, true, int); else OJPH_LAUNCH(dwt_forward_kernel, true, false, int); }
+    else { if (d_image) OJPH_LAUNCH(dwt_forward_kernel, false, true, float); else OJPH_LAUNCH(dwt_forward_kernel, false, false, float); }
+  } else {
+    if (reversible) { if (d_image) OJPH_LAUNCH(dwt_inverse_kernel, true, true, int); else OJPH_LAUNCH(dwt_inverse_kernel, true, false, int); }
+    else { if (d_image) OJPH_LAUNCH(dwt_inverse_kernel, false, true, float); else OJPH_LAUNCH(dwt_inverse_kernel, false, false, float); }
+  }
+#undef OJPH_LAUNCH
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
 }  // namespace
@@ -340,25 +461,27 @@ dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h)
 extern "C" int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
                                     uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)
 {
-  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
-  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
-  dim3 grid = dwt_grid(n, max_w, max_h);
-  if (reversible)
-    hipLaunchKernelGGL(dwt_forward_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (int*)d_base);
-  else
-    hipLaunchKernelGGL(dwt_forward_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (float*)d_base);
-  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  return launch<true>(stream, reversible, d_descs, n, max_w, max_h, d_base, nullptr, Conv{ 0, 0 });
 }
 
 extern "C" int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
                                     uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)
 {
-  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
-  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
-  dim3 grid = dwt_grid(n, max_w, max_h);
-  if (reversible)
-    hipLaunchKernelGGL(dwt_inverse_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (int*)d_base);
-  else
-    hipLaunchKernelGGL(dwt_inverse_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_descs, (float*)d_base);
-  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  return launch<false>(stream, reversible, d_descs, n, max_w, max_h, d_base, nullptr, Conv{ 0, 0 });
+}
+
+extern "C" int ojphgpu_dwt_forward_image(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                          uint32_t n, uint32_t max_w, uint32_t max_h, const int32_t* d_image, void* d_base)
+{
+  if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 31) return OJPHGPU_E_INVALID;
+  return launch<true>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, const_cast<int32_t*>(d_image),
+                      Conv{ (int)params->bit_depth, (int)params->is_signed });
+}
+
+extern "C" int ojphgpu_dwt_inverse_image(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                          uint32_t n, uint32_t max_w, uint32_t max_h, int32_t* d_image, void* d_base)
+{
+  if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 31) return OJPHGPU_E_INVALID;
+  return launch<false>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, d_image,
+                       Conv{ (int)params->bit_depth, (int)params->is_signed });
 }

@@ -77,6 +77,26 @@ void build_level_batches(const Plan& P, std::vector<ojphgpu_dwt_desc>& descs, st
   }
 }
 
+// Descriptors of the top DWT level with the un-decomposed plane addressed inside the image-sized
+// int32 component planes (for ojphgpu_dwt_forward_image / _inverse_image).  Empty when the fused
+// path does not apply (colour transform, or no decomposition).
+void build_image_level_descs(const Plan& P, const std::vector<ojphgpu_dwt_desc>& descs, const LevelBatch& top,
+                             std::vector<ojphgpu_dwt_desc>& out)
+{
+  out.clear();
+  if (P.p.color_transform || P.p.num_decomps == 0) return;
+  const uint64_t plane = (uint64_t)P.p.width * P.p.height;
+  size_t k = 0;
+  for (const ojphgpu_level_info& lv : P.levels) {
+    if (lv.res != P.p.num_decomps) continue;
+    ojphgpu_dwt_desc d = descs[top.first + k++];
+    const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
+    d.src_off = (uint64_t)lv.comp * plane + (uint64_t)tc.r.y0 * P.p.width + tc.r.x0;
+    d.src_pitch = P.p.width;
+    out.push_back(d);
+  }
+}
+
 void build_convert_descs(const Plan& P, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
 {
   descs.clear(); max_w = max_h = 0;
@@ -134,7 +154,8 @@ struct ojphgpu_encoder {
   const ojphgpu_plan* handle = nullptr;
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, scratch, out, results, counters;
+  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, scratch, out, results, counters;
+  bool fused_convert = false;
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
   std::vector<ojphgpu_cb_result> h_results;
@@ -147,7 +168,7 @@ extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
+  for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->img_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
                         &e->results, &e->counters }) b->release();
   e->timer.destroy();
   delete e;
@@ -166,6 +187,9 @@ extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void
   auto bail = [&](int rc) { ojphgpu_encoder_destroy(e); return rc; };
 
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, e->batches);
+  std::vector<ojphgpu_dwt_desc> idd;
+  if (!e->batches.empty()) build_image_level_descs(P, dd, e->batches.front(), idd);
+  e->fused_convert = !idd.empty();
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, e->conv_max_w, e->conv_max_h);
   std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
   uint64_t scratch_bytes = 0;
@@ -184,12 +208,13 @@ extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void
   e->out_cap = (uint32_t)cap;
 
   if (e->arena.alloc(P.arena_elems * 4) || e->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
-      e->cb_descs.alloc(bd.size() * sizeof(bd[0])) || e->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
+      e->img_descs.alloc(idd.size() * sizeof(dd[0])) || e->cb_descs.alloc(bd.size() * sizeof(bd[0])) || e->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       e->scratch.alloc(scratch_bytes) || e->out.alloc(cap) ||
       e->results.alloc(bd.size() * sizeof(ojphgpu_cb_result)) || e->counters.alloc(16))
     return bail(OJPHGPU_E_NOMEM);
   if (hipMemset(e->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(e->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!idd.empty() && hipMemcpy(e->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!bd.empty() && hipMemcpy(e->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!cd.empty() && hipMemcpy(e->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   e->h_results.resize(bd.size());
@@ -205,14 +230,20 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   hipStream_t s = e->stream;
   HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
   e->timer.mark(0, s);
-  int rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, (uint32_t)P.tiles.size(),
-                                   e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
+  int rc = OJPHGPU_OK;
+  if (!e->fused_convert)
+    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, (uint32_t)P.tiles.size(),
+                                 e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
   if (rc) return rc;
   e->timer.mark(1, s);
   e->timer.begin_levels();
   for (const LevelBatch& b : e->batches) {
-    rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
-                             b.max_w, b.max_h, e->arena.p);
+    if (e->fused_convert && &b == &e->batches.front())      // level shift / int->float applied in the loads
+      rc = ojphgpu_dwt_forward_image(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
+                                     d_image, e->arena.p);
+    else
+      rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
+                               b.max_w, b.max_h, e->arena.p);
     if (rc) return rc;
     e->timer.mark_level(s);
   }
@@ -290,7 +321,8 @@ extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint
 struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, cb_descs, conv_descs, data, status, quads;
+  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads;
+  bool fused_convert = false;
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
   size_t data_len = 0;
@@ -302,7 +334,7 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads })
+  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads })
     b->release();
   d->timer.destroy();
   delete d;
@@ -322,6 +354,9 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
   auto bail = [&](int rc) { ojphgpu_decoder_destroy(d); return rc; };
 
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, d->batches);
+  std::vector<ojphgpu_dwt_desc> idd;
+  if (!d->batches.empty()) build_image_level_descs(P, dd, d->batches.front(), idd);
+  d->fused_convert = !idd.empty();
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, d->conv_max_w, d->conv_max_h);
   std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
@@ -342,11 +377,12 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
   if (nquads >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
-      d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
+      d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
     return bail(OJPHGPU_E_NOMEM);
   if (hipMemset(d->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(d->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (!idd.empty() && hipMemcpy(d->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!bd.empty() && hipMemcpy(d->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!cd.empty() && hipMemcpy(d->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (d->timer.init() != 0) return bail(OJPHGPU_E_HIP);
@@ -374,14 +410,19 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   d->timer.mark(1, s);
   d->timer.begin_levels();
   for (const LevelBatch& b : d->batches) {
-    rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
-                             b.max_w, b.max_h, d->arena.p);
+    if (d->fused_convert && &b == &d->batches.back())       // float->int / level shift applied in the stores
+      rc = ojphgpu_dwt_inverse_image(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
+                                     d_image, d->arena.p);
+    else
+      rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
+                               b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;
     d->timer.mark_level(s);
   }
   d->timer.mark(2, s);
-  rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, (uint32_t)P.tiles.size(),
-                               d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
+  if (!d->fused_convert)
+    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, (uint32_t)P.tiles.size(),
+                                 d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
   if (rc) return rc;
   d->timer.mark(3, s);
   d->ran = true;
