@@ -123,6 +123,17 @@ int  ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t c
 int  ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* h_block_data,
                       const ojphgpu_coded_block* blocks, uint8_t* h_out, size_t cap,
                       size_t* out_len);
+/* The same in pieces, for tile-sharded encoding (tiles are independent: own DWT, blocks, packets
+ * and tile-part, ojph_tile.cpp:584-774): the tile-parts (SOT .. last packet) of tiles
+ * [tile_first, tile_first + tile_count) -- tile_part_len[i] receives Psot of tile tile_first + i --
+ * and the main header (SOC .. last main-header marker; needs every tile's Psot only when a TLM
+ * marker was requested).  codestream = main header | tile-parts in tile order | EOC (0xFFD9). */
+int  ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* h_block_data,
+                            const ojphgpu_coded_block* blocks, uint32_t tile_first,
+                            uint32_t tile_count, uint8_t* h_out, size_t cap, size_t* out_len,
+                            uint32_t* tile_part_len);
+int  ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile_part_len,
+                                  uint8_t* h_out, size_t cap, size_t* out_len);
 /* Parses main header + all tile-parts; creates the plan the codestream implies. */
 int  ojphgpu_t2_parse(const uint8_t* h_codestream, size_t len, int resilient, ojphgpu_plan** out);
 /* after ojphgpu_t2_parse: per-block coded info (offsets are into the parsed codestream) */
@@ -225,6 +236,14 @@ typedef struct ojphgpu_decoder ojphgpu_decoder;
 
 int  ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_encoder** out);
 void ojphgpu_encoder_destroy(ojphgpu_encoder* enc);
+/* An encoder that codes only tiles [tile_first, tile_first + tile_count) of the plan's frame: the
+ * unit of multi-GPU sharding (one rank = one contiguous run of tiles).  d_image still addresses
+ * the whole frame; only the rows/columns of the range's tiles are read. */
+int  ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream,
+                                  uint32_t tile_first, uint32_t tile_count, ojphgpu_encoder** out);
+/* D2H + host Tier-2 of the range: its tile-parts only (see ojphgpu_t2_write_tiles) */
+int  ojphgpu_encoder_finish_tiles(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len,
+                                  uint32_t* tile_part_len);
 /* device part only: d_image (int32 planes, resident in HBM) -> coded block bytes in HBM */
 int  ojphgpu_encoder_run_device(ojphgpu_encoder* enc, const int32_t* d_image);
 /* D2H of block bytes + lengths, then host Tier-2 -> complete codestream */
@@ -237,6 +256,9 @@ int  ojphgpu_encoder_coded_bytes(ojphgpu_encoder* enc, uint64_t* bytes);
 
 /* plan must come from ojphgpu_t2_parse over (h_codestream, len) */
 int  ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_decoder** out);
+/* decodes only tiles [tile_first, tile_first + tile_count): writes their region of d_image */
+int  ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream,
+                                  uint32_t tile_first, uint32_t tile_count, ojphgpu_decoder** out);
 void ojphgpu_decoder_destroy(ojphgpu_decoder* dec);
 /* H2D of the codestream bytes */
 int  ojphgpu_decoder_upload(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len);

@@ -105,6 +105,9 @@ SIGNATURES = {
     "ojphgpu_plan_coded_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ojphgpu_t2_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_size_t)]),
+    "ojphgpu_t2_write_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                         C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
+    "ojphgpu_t2_write_main_header": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ojphgpu_t2_parse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "ojphgpu_dwt_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_void_p]),
@@ -123,6 +126,11 @@ SIGNATURES = {
     "ojphgpu_convert_inverse": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ojphgpu_encoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ojphgpu_encoder_create_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.POINTER(C.c_void_p)]),
+    "ojphgpu_encoder_finish_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
+    "ojphgpu_decoder_create_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.POINTER(C.c_void_p)]),
     "ojphgpu_encoder_destroy": (None, [C.c_void_p]),
     "ojphgpu_encoder_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_encoder_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

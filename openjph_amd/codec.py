@@ -41,15 +41,18 @@ def to_device(arr: np.ndarray, device=0):
 class Encoder:
     """Whole-frame encoder for one frame shape / parameter set (ojphgpu_encoder)."""
 
-    def __init__(self, params: Params = None, device=0, plan: Plan = None, **kw):
+    def __init__(self, params: Params = None, device=0, plan: Plan = None, tiles=None, **kw):
+        """tiles=(first, count) restricts the encoder to a run of tiles (multi-GPU sharding)."""
         torch = _torch()
         self.device = device
         self.plan = plan if plan is not None else Plan(params if params is not None else make_params(**kw))
+        self.tiles = (0, self.plan.num_tiles) if tiles is None else (int(tiles[0]), int(tiles[1]))
         self._lib = capi.lib()
         self._h = C.c_void_p()
         with torch.cuda.device(device):
-            check(self._lib.ojphgpu_encoder_create(self.plan.handle, device, _stream_ptr(torch, device),
-                                                   C.byref(self._h)), "encoder_create")
+            check(self._lib.ojphgpu_encoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
+                                                         self.tiles[0], self.tiles[1], C.byref(self._h)),
+                  "encoder_create")
         p = self.plan.params
         self.shape = (p.num_comps, p.height, p.width)
 
@@ -85,6 +88,21 @@ class Encoder:
         check(rc, "encoder_finish")
         return out[:n.value].tobytes()
 
+    def finish_tiles(self):
+        """-> (tile-part bytes of this encoder's tile range, Psot per tile)"""
+        p = self.plan.params
+        cap = int(p.width) * int(p.height) * int(p.num_comps) * 3 + (1 << 20)
+        lens = np.zeros(max(self.tiles[1], 1), np.uint32)
+        n = C.c_size_t()
+        out = np.empty(cap, np.uint8)
+        rc = self._lib.ojphgpu_encoder_finish_tiles(self._h, out.ctypes.data, cap, C.byref(n), lens.ctypes.data)
+        if rc == capi.E_OVERFLOW and n.value > cap:
+            cap = int(n.value)
+            out = np.empty(cap, np.uint8)
+            rc = self._lib.ojphgpu_encoder_finish_tiles(self._h, out.ctypes.data, cap, C.byref(n), lens.ctypes.data)
+        check(rc, "encoder_finish_tiles")
+        return out[:n.value].tobytes(), lens[:self.tiles[1]].copy()
+
     def encode(self, image) -> bytes:
         """image: numpy int32 [C,H,W] (host) or torch int32 tensor on the device."""
         torch = _torch()
@@ -104,16 +122,19 @@ class Encoder:
 class Decoder:
     """Whole-frame decoder bound to one parsed codestream layout (ojphgpu_decoder)."""
 
-    def __init__(self, codestream: bytes, device=0, resilient=False):
+    def __init__(self, codestream: bytes, device=0, resilient=False, tiles=None):
+        """tiles=(first, count) restricts the decoder to a run of tiles (multi-GPU sharding)."""
         torch = _torch()
         self.device = device
         self.resilient = resilient
         self.plan = parse_codestream(codestream, resilient)
+        self.tiles = (0, self.plan.num_tiles) if tiles is None else (int(tiles[0]), int(tiles[1]))
         self._lib = capi.lib()
         self._h = C.c_void_p()
         with torch.cuda.device(device):
-            check(self._lib.ojphgpu_decoder_create(self.plan.handle, device, _stream_ptr(torch, device),
-                                                   C.byref(self._h)), "decoder_create")
+            check(self._lib.ojphgpu_decoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
+                                                         self.tiles[0], self.tiles[1], C.byref(self._h)),
+                  "decoder_create")
         p = self.plan.params
         self.shape = (p.num_comps, p.height, p.width)
         self.upload(codestream)
@@ -134,7 +155,8 @@ class Decoder:
     def run_device(self, d_image=None):
         torch = _torch()
         if d_image is None:
-            d_image = torch.empty(self.shape, dtype=torch.int32, device="cuda:%d" % self.device)
+            alloc = torch.empty if self.tiles == (0, self.plan.num_tiles) else torch.zeros
+            d_image = alloc(self.shape, dtype=torch.int32, device="cuda:%d" % self.device)
         check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
         return d_image
 

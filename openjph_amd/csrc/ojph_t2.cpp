@@ -202,48 +202,43 @@ bool write_packet_header(const Plan& P, const Precinct& pc, const ojphgpu_coded_
 
 using namespace ojphgpu;
 
-extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
-                                 const ojphgpu_coded_block* cb, uint8_t* out, size_t cap,
-                                 size_t* out_len)
-{
-  if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
-  const Plan& P = plan->plan;
-  ByteSink hdr;
-  write_main_header(P, hdr);
+namespace {
 
-  // per tile: packet headers first (sizes are needed for Psot / TLM)
+// Tile-parts of tiles [t0, t1): SOT + SOD + packets (tile::flush, ojph_tile.cpp:584-774).  Tiles
+// are independent of each other, which is what lets ranks shard them.  len_out[t - t0] receives
+// Psot of tile t.  Returns 0 / OJPHGPU_E_OVERFLOW with *out_len = bytes needed.
+int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_block* cb, size_t t0, size_t t1,
+                     uint8_t* out, size_t cap, size_t* out_len, uint32_t* len_out)
+{
+  // packet headers first (sizes are needed for Psot / TLM)
   struct Pkt { std::vector<uint8_t> hdr; bool coded; };
-  std::vector<std::vector<Pkt>> tile_pkts(P.tiles.size());
-  std::vector<uint64_t> tile_bytes(P.tiles.size(), 0);
-  for (size_t t = 0; t < P.tiles.size(); ++t) {
+  std::vector<std::vector<Pkt>> tile_pkts(t1 - t0);
+  std::vector<uint64_t> tile_bytes(t1 - t0, 0);
+  size_t total = 0;
+  for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
-    tile_pkts[t].resize(T.packets.size());
+    tile_pkts[t - t0].resize(T.packets.size());
     for (size_t i = 0; i < T.packets.size(); ++i) {
-      Pkt& k = tile_pkts[t][i]; uint64_t body = 0;
+      Pkt& k = tile_pkts[t - t0][i]; uint64_t body = 0;
       k.coded = write_packet_header(P, P.precincts[T.packets[i]], cb, k.hdr, body);
-      tile_bytes[t] += k.coded ? k.hdr.size() + body : 1;
+      tile_bytes[t - t0] += k.coded ? k.hdr.size() + body : 1;
     }
+    if (tile_bytes[t - t0] + 14 > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
+    if (len_out) len_out[t - t0] = (uint32_t)tile_bytes[t - t0] + 14;
+    total += 14 + tile_bytes[t - t0];
   }
-  size_t total = hdr.v.size() + 2;
-  if (P.p.tlm) total += 6 + 6 * P.tiles.size();
-  for (size_t t = 0; t < P.tiles.size(); ++t) total += 14 + tile_bytes[t];
   *out_len = total;
   if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
 
   uint8_t* w = out;
-  memcpy(w, hdr.v.data(), hdr.v.size()); w += hdr.v.size();
   auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
   auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
-  if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
-    u16(TLM); u16(4 + 6 * (uint32_t)P.tiles.size()); *w++ = 0; *w++ = 0x60;
-    for (size_t t = 0; t < P.tiles.size(); ++t) { u16((uint32_t)t); u32((uint32_t)tile_bytes[t] + 14); }
-  }
-  for (size_t t = 0; t < P.tiles.size(); ++t) {
+  for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
-    u16(SOT); u16(10); u16(T.idx); u32((uint32_t)tile_bytes[t] + 14); *w++ = 0; *w++ = 1;
+    u16(SOT); u16(10); u16(T.idx); u32((uint32_t)tile_bytes[t - t0] + 14); *w++ = 0; *w++ = 1;
     u16(SOD);
     for (size_t i = 0; i < T.packets.size(); ++i) {
-      const Pkt& k = tile_pkts[t][i];
+      const Pkt& k = tile_pkts[t - t0][i];
       if (!k.coded) { *w++ = 0; continue; }
       memcpy(w, k.hdr.data(), k.hdr.size()); w += k.hdr.size();
       const Precinct& pc = P.precincts[T.packets[i]];
@@ -262,8 +257,63 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
       }
     }
   }
-  u16(EOC);
   return (size_t)(w - out) == total ? OJPHGPU_OK : OJPHGPU_E_INVALID;
+}
+
+}  // namespace
+
+extern "C" int ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* data, const ojphgpu_coded_block* cb,
+                                       uint32_t tile_first, uint32_t tile_count, uint8_t* out, size_t cap,
+                                       size_t* out_len, uint32_t* tile_part_len)
+{
+  if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
+  return write_tile_parts(P, data, cb, tile_first, (size_t)tile_first + tile_count, out, cap, out_len, tile_part_len);
+}
+
+extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile_part_len, uint8_t* out,
+                                             size_t cap, size_t* out_len)
+{
+  if (!plan || !out_len) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  if (P.p.tlm && !tile_part_len) return OJPHGPU_E_INVALID;
+  ByteSink hdr;
+  write_main_header(P, hdr);
+  size_t total = hdr.v.size();
+  if (P.p.tlm) total += 6 + 6 * P.tiles.size();
+  *out_len = total;
+  if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
+  uint8_t* w = out;
+  memcpy(w, hdr.v.data(), hdr.v.size()); w += hdr.v.size();
+  auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
+  auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
+  if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
+    u16(TLM); u16(4 + 6 * (uint32_t)P.tiles.size()); *w++ = 0; *w++ = 0x60;
+    for (size_t t = 0; t < P.tiles.size(); ++t) { u16((uint32_t)t); u32(tile_part_len[t]); }
+  }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
+                                 const ojphgpu_coded_block* cb, uint8_t* out, size_t cap,
+                                 size_t* out_len)
+{
+  if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  const size_t nt = P.tiles.size();
+  std::vector<uint32_t> lens(nt, 0);
+  size_t hlen = 0, tlen = 0;
+  int rc = ojphgpu_t2_write_main_header(plan, lens.data(), nullptr, 0, &hlen);       // size only (independent of lens)
+  if (rc != OJPHGPU_E_OVERFLOW && rc != OJPHGPU_OK) return rc;
+  const bool room = out && cap > hlen + 2;
+  rc = write_tile_parts(P, data, cb, 0, nt, room ? out + hlen : nullptr, room ? cap - hlen - 2 : 0, &tlen, lens.data());
+  *out_len = hlen + tlen + 2;
+  if (rc) return rc;
+  rc = ojphgpu_t2_write_main_header(plan, lens.data(), out, hlen, &hlen);
+  if (rc) return rc;
+  out[hlen + tlen] = (uint8_t)(EOC >> 8); out[hlen + tlen + 1] = (uint8_t)EOC;
+  return OJPHGPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

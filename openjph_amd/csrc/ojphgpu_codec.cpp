@@ -58,14 +58,16 @@ struct DeviceBuf {
 struct LevelBatch { uint32_t first, count, max_w, max_h; };
 
 // DWT descriptors grouped by resolution so that one launch handles every tile-component
-void build_level_batches(const Plan& P, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
+struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
+
+void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
 {
   const uint32_t L = P.p.num_decomps;
   descs.clear(); batches.clear();
   for (uint32_t r = L; r >= 1; --r) {
     LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0 };
     for (const ojphgpu_level_info& lv : P.levels) {
-      if (lv.res != r) continue;
+      if (lv.res != r || !tr.has(lv.tile)) continue;
       ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
       d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
       d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
@@ -80,7 +82,7 @@ void build_level_batches(const Plan& P, std::vector<ojphgpu_dwt_desc>& descs, st
 // Descriptors of the top DWT level with the un-decomposed plane addressed inside the image-sized
 // int32 component planes (for ojphgpu_dwt_forward_image / _inverse_image).  Empty when the fused
 // path does not apply (colour transform, or no decomposition).
-void build_image_level_descs(const Plan& P, const std::vector<ojphgpu_dwt_desc>& descs, const LevelBatch& top,
+void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojphgpu_dwt_desc>& descs, const LevelBatch& top,
                              std::vector<ojphgpu_dwt_desc>& out)
 {
   out.clear();
@@ -88,7 +90,7 @@ void build_image_level_descs(const Plan& P, const std::vector<ojphgpu_dwt_desc>&
   const uint64_t plane = (uint64_t)P.p.width * P.p.height;
   size_t k = 0;
   for (const ojphgpu_level_info& lv : P.levels) {
-    if (lv.res != P.p.num_decomps) continue;
+    if (lv.res != P.p.num_decomps || !tr.has(lv.tile)) continue;
     ojphgpu_dwt_desc d = descs[top.first + k++];
     const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
     d.src_off = (uint64_t)lv.comp * plane + (uint64_t)tc.r.y0 * P.p.width + tc.r.x0;
@@ -97,11 +99,12 @@ void build_image_level_descs(const Plan& P, const std::vector<ojphgpu_dwt_desc>&
   }
 }
 
-void build_convert_descs(const Plan& P, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
+void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
 {
   descs.clear(); max_w = max_h = 0;
   const uint32_t L = P.p.num_decomps;
-  for (const Tile& t : P.tiles)
+  for (const Tile& t : P.tiles) {
+    if (!tr.has(t.idx)) continue;
     for (uint32_t c = 0; c < P.p.num_comps; ++c) {
       const TileComp& tc = P.tcomps[t.comps[c]];
       const Resolution& R = P.ress[tc.res[L]];
@@ -112,6 +115,16 @@ void build_convert_descs(const Plan& P, std::vector<ojphgpu_convert_desc>& descs
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
+  }
+}
+
+// plan-order indices of the code-blocks that belong to the tile range
+std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
+{
+  std::vector<uint32_t> ids;
+  for (size_t i = 0; i < P.blocks.size(); ++i)
+    if (tr.has(P.bands[P.blocks[i].band].tile)) ids.push_back((uint32_t)i);
+  return ids;
 }
 
 // HIP events on the codec's own stream: 4 stage marks + one mark after every DWT level launch
@@ -158,6 +171,8 @@ struct ojphgpu_encoder {
   bool fused_convert = false;
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
+  TileRange tiles{ 0, 0 };
+  std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes
   std::vector<ojphgpu_cb_result> h_results;
   std::vector<uint8_t> h_out;
   Timer timer;
@@ -176,8 +191,16 @@ extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
 
 extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_encoder** out)
 {
+  if (!plan) return OJPHGPU_E_INVALID;
+  return ojphgpu_encoder_create_tiles(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), out);
+}
+
+extern "C" int ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
+                                             uint32_t tile_count, ojphgpu_encoder** out)
+{
   if (!plan || !out) return OJPHGPU_E_INVALID;
   *out = nullptr;
+  if ((uint64_t)tile_first + tile_count > plan->plan.tiles.size()) return OJPHGPU_E_INVALID;
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   ojphgpu_encoder* e = new (std::nothrow) ojphgpu_encoder();
@@ -186,15 +209,19 @@ extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void
   e->handle = plan; e->P = &P; e->device = device; e->stream = (hipStream_t)stream;
   auto bail = [&](int rc) { ojphgpu_encoder_destroy(e); return rc; };
 
-  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, e->batches);
+  e->tiles = TileRange{ tile_first, tile_count };
+  const TileRange tr = e->tiles;
+  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, e->batches);
   std::vector<ojphgpu_dwt_desc> idd;
-  if (!e->batches.empty()) build_image_level_descs(P, dd, e->batches.front(), idd);
+  if (!e->batches.empty()) build_image_level_descs(P, tr, dd, e->batches.front(), idd);
   e->fused_convert = !idd.empty();
-  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, e->conv_max_w, e->conv_max_h);
-  std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
-  uint64_t scratch_bytes = 0;
-  for (size_t i = 0; i < P.blocks.size(); ++i) {
-    const Block& k = P.blocks[i]; const Band& B = P.bands[k.band];
+  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
+  e->block_ids = blocks_of_tiles(P, tr);
+  std::vector<ojphgpu_cb_desc> bd(e->block_ids.size());
+  uint64_t scratch_bytes = 0, samples = 0;
+  for (size_t i = 0; i < bd.size(); ++i) {
+    const Block& k = P.blocks[e->block_ids[i]]; const Band& B = P.bands[k.band];
+    samples += (uint64_t)k.r.w * k.r.h;
     ojphgpu_cb_desc& d = bd[i]; memset(&d, 0, sizeof(d));
     d.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; d.pitch = B.pitch;
     d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)P.p.reversible;
@@ -202,7 +229,6 @@ extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
   }
-  const uint64_t samples = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
   uint64_t cap = std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
   cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
   e->out_cap = (uint32_t)cap;
@@ -232,7 +258,7 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   e->timer.mark(0, s);
   int rc = OJPHGPU_OK;
   if (!e->fused_convert)
-    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, (uint32_t)P.tiles.size(),
+    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count,
                                  e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
   if (rc) return rc;
   e->timer.mark(1, s);
@@ -248,7 +274,7 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
     e->timer.mark_level(s);
   }
   e->timer.mark(2, s);
-  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)P.blocks.size(), e->arena.p,
+  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)e->block_ids.size(), e->arena.p,
                          (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap, (ojphgpu_cb_result*)e->results.p,
                          (uint32_t*)e->counters.p, (uint32_t*)e->counters.p + 1);
   if (rc) return rc;
@@ -267,9 +293,9 @@ extern "C" int ojphgpu_encoder_coded_bytes(ojphgpu_encoder* e, uint64_t* bytes)
   return c[1] ? OJPHGPU_E_OVERFLOW : OJPHGPU_OK;
 }
 
-extern "C" int ojphgpu_encoder_finish(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len)
+// D2H of the block bytes + lengths of the last run; fills the plan-order coded-block table
+static int encoder_fetch(ojphgpu_encoder* e, std::vector<ojphgpu_coded_block>& cb)
 {
-  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
   uint64_t nbytes = 0;
   int rc = ojphgpu_encoder_coded_bytes(e, &nbytes);
@@ -280,14 +306,36 @@ extern "C" int ojphgpu_encoder_finish(ojphgpu_encoder* e, uint8_t* h_out, size_t
                           hipMemcpyDeviceToHost, e->stream));
   if (nbytes) HIPCHK(hipMemcpyAsync(e->h_out.data(), e->out.p, (size_t)nbytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  std::vector<ojphgpu_coded_block> cb(P.blocks.size());
-  for (size_t i = 0; i < cb.size(); ++i) {
+  cb.assign(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
+  for (size_t i = 0; i < e->block_ids.size(); ++i) {
     const ojphgpu_cb_result& r = e->h_results[i];
-    cb[i].offset = r.offset; cb[i].len1 = r.length; cb[i].len2 = 0;
-    cb[i].missing_msbs = r.length ? P.bands[P.blocks[i].band].K_max - 1 : 0;      // ojph_codeblock.cpp:148
-    cb[i].num_passes = r.length ? 1 : 0;
+    ojphgpu_coded_block& c = cb[e->block_ids[i]];
+    c.offset = r.offset; c.len1 = r.length; c.len2 = 0;
+    c.missing_msbs = r.length ? P.bands[P.blocks[e->block_ids[i]].band].K_max - 1 : 0;      // ojph_codeblock.cpp:148
+    c.num_passes = r.length ? 1 : 0;
   }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_finish(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
+  if (e->tiles.first != 0 || e->tiles.count != e->P->tiles.size()) return OJPHGPU_E_INVALID;   // use _finish_tiles
+  std::vector<ojphgpu_coded_block> cb;
+  int rc = encoder_fetch(e, cb);
+  if (rc) return rc;
   return ojphgpu_t2_write(e->handle, e->h_out.data(), cb.data(), h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len,
+                                             uint32_t* tile_part_len)
+{
+  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
+  std::vector<ojphgpu_coded_block> cb;
+  int rc = encoder_fetch(e, cb);
+  if (rc) return rc;
+  return ojphgpu_t2_write_tiles(e->handle, e->h_out.data(), cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
+                                out_len, tile_part_len);
 }
 
 extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
@@ -323,9 +371,11 @@ struct ojphgpu_decoder {
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads;
   bool fused_convert = false;
+  TileRange tiles{ 0, 0 };
+  uint32_t nblocks = 0;                            // code-blocks of the tile range
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
-  size_t data_len = 0;
+  size_t data_first = 0, data_len = 0;              // byte range of the codestream holding this range's block data
   Timer timer;
   bool ran = false;
 };
@@ -342,9 +392,17 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 
 extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void* stream, ojphgpu_decoder** out)
 {
+  if (!plan) return OJPHGPU_E_INVALID;
+  return ojphgpu_decoder_create_tiles(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), out);
+}
+
+extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
+                                             uint32_t tile_count, ojphgpu_decoder** out)
+{
   if (!plan || !out) return OJPHGPU_E_INVALID;
   *out = nullptr;
   const Plan& P = plan->plan;
+  if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
   if (P.coded.size() != P.blocks.size()) return OJPHGPU_E_INVALID;    // plan must come from ojphgpu_t2_parse
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -353,16 +411,20 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
   d->P = &P; d->device = device; d->stream = (hipStream_t)stream;
   auto bail = [&](int rc) { ojphgpu_decoder_destroy(d); return rc; };
 
-  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, dd, d->batches);
+  d->tiles = TileRange{ tile_first, tile_count };
+  const TileRange tr = d->tiles;
+  std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, d->batches);
   std::vector<ojphgpu_dwt_desc> idd;
-  if (!d->batches.empty()) build_image_level_descs(P, dd, d->batches.front(), idd);
+  if (!d->batches.empty()) build_image_level_descs(P, tr, dd, d->batches.front(), idd);
   d->fused_convert = !idd.empty();
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
-  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, cd, d->conv_max_w, d->conv_max_h);
-  std::vector<ojphgpu_cb_desc> bd(P.blocks.size());
-  uint64_t max_off = 0, nquads = 0;
-  for (size_t i = 0; i < P.blocks.size(); ++i) {
-    const Block& k = P.blocks[i]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[i];
+  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
+  const std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
+  d->nblocks = (uint32_t)ids.size();
+  std::vector<ojphgpu_cb_desc> bd(ids.size());
+  uint64_t max_off = 0, min_off = ~0ull, nquads = 0;
+  for (size_t i = 0; i < ids.size(); ++i) {
+    const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[ids[i]];
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
     o.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max; o.reversible = (uint8_t)P.p.reversible;
@@ -371,9 +433,16 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
     o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
     nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2);
     d->max_len1 = std::max(d->max_len1, c.len1);
-    max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
+    if (c.len1 + c.len2) {
+      max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
+      min_off = std::min<uint64_t>(min_off, c.offset);
+    }
   }
-  d->data_len = (size_t)max_off;
+  if (min_off > max_off) min_off = max_off = 0;
+  min_off &= ~(uint64_t)15;                                             // only this byte range of the codestream is uploaded
+  for (ojphgpu_cb_desc& o : bd) if (o.len1 + o.len2) o.data_off -= min_off; else o.data_off = 0;
+  d->data_first = (size_t)min_off;
+  d->data_len = (size_t)(max_off - min_off);
   if (nquads >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
@@ -392,8 +461,8 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
 
 extern "C" int ojphgpu_decoder_upload(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len)
 {
-  if (!d || !h_codestream || len < d->data_len) return OJPHGPU_E_INVALID;
-  if (d->data_len) HIPCHK(hipMemcpyAsync(d->data.p, h_codestream, d->data_len, hipMemcpyHostToDevice, d->stream));
+  if (!d || !h_codestream || len < d->data_first + d->data_len) return OJPHGPU_E_INVALID;
+  if (d->data_len) HIPCHK(hipMemcpyAsync(d->data.p, h_codestream + d->data_first, d->data_len, hipMemcpyHostToDevice, d->stream));
   return OJPHGPU_OK;
 }
 
@@ -403,7 +472,7 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   const Plan& P = *d->P;
   hipStream_t s = d->stream;
   d->timer.mark(0, s);
-  int rc = ojphgpu_ht_decode(s, (const ojphgpu_cb_desc*)d->cb_descs.p, (uint32_t)P.blocks.size(), (const uint8_t*)d->data.p,
+  int rc = ojphgpu_ht_decode(s, (const ojphgpu_cb_desc*)d->cb_descs.p, d->nblocks, (const uint8_t*)d->data.p,
                              d->arena.p, (uint32_t*)d->quads.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w,
                              P.p.block_h);
   if (rc) return rc;
@@ -421,7 +490,7 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   }
   d->timer.mark(2, s);
   if (!d->fused_convert)
-    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, (uint32_t)P.tiles.size(),
+    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count,
                                  d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
   if (rc) return rc;
   d->timer.mark(3, s);
@@ -432,7 +501,7 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
 extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count)
 {
   if (!d || !count || !d->ran) return OJPHGPU_E_INVALID;
-  std::vector<uint8_t> st(d->P->blocks.size());
+  std::vector<uint8_t> st(d->nblocks);
   if (!st.empty()) HIPCHK(hipMemcpyAsync(st.data(), d->status.p, st.size(), hipMemcpyDeviceToHost, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   uint32_t n = 0;

@@ -90,6 +90,38 @@ class Plan:
         return out[:need.value].tobytes()
 
 
+    def t2_write_tiles(self, block_data: np.ndarray, coded: np.ndarray, tile_first: int, tile_count: int):
+        """Tile-parts of tiles [tile_first, tile_first+tile_count) -> (bytes, Psot per tile)."""
+        block_data = np.ascontiguousarray(block_data, dtype=np.uint8)
+        coded = np.ascontiguousarray(coded, dtype=coded_dtype)
+        lens = np.zeros(max(tile_count, 1), np.uint32)
+        need = C.c_size_t()
+        rc = self._lib.ojphgpu_t2_write_tiles(self.handle, block_data.ctypes.data, coded.ctypes.data, tile_first,
+                                              tile_count, None, 0, C.byref(need), lens.ctypes.data)
+        if rc not in (capi.OK, capi.E_OVERFLOW):
+            check(rc, "t2_write_tiles")
+        out = np.empty(max(int(need.value), 1), np.uint8)
+        check(self._lib.ojphgpu_t2_write_tiles(self.handle, block_data.ctypes.data, coded.ctypes.data, tile_first,
+                                               tile_count, out.ctypes.data, out.size, C.byref(need), lens.ctypes.data),
+              "t2_write_tiles")
+        return out[:need.value].tobytes(), lens[:tile_count].copy()
+
+    def t2_main_header(self, tile_part_len=None) -> bytes:
+        """SOC .. end of the main header; tile_part_len (Psot of every tile) feeds the TLM marker."""
+        lens = None if tile_part_len is None else np.ascontiguousarray(tile_part_len, dtype=np.uint32)
+        if lens is not None and lens.size != self.num_tiles:
+            raise ValueError("tile_part_len must have one entry per tile")
+        need = C.c_size_t()
+        ptr = None if lens is None else lens.ctypes.data
+        rc = self._lib.ojphgpu_t2_write_main_header(self.handle, ptr, None, 0, C.byref(need))
+        if rc not in (capi.OK, capi.E_OVERFLOW):
+            check(rc, "t2_write_main_header")
+        out = np.empty(int(need.value), np.uint8)
+        check(self._lib.ojphgpu_t2_write_main_header(self.handle, ptr, out.ctypes.data, out.size, C.byref(need)),
+              "t2_write_main_header")
+        return out[:need.value].tobytes()
+
+
 def parse_codestream(data: bytes, resilient=False) -> Plan:
     buf = np.frombuffer(data, dtype=np.uint8)
     h = C.c_void_p()

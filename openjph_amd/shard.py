@@ -1,0 +1,90 @@
+"""Tile sharding across the GPUs of one node.
+
+Tiles are fully independent in JPEG 2000 -- own DWT, quantisation, code-blocks, packets and
+tile-part (reference: ojph_codestream_local.cpp:113-180, ojph_tile.cpp:584-774) -- so the path
+shards by contiguous runs of tiles with NO data-path collective: every rank (one process per GPU)
+runs convert -> DWT -> HT block coder over its own tiles.  The only exchange is the final
+codestream gather: the per-tile Psot lengths (tiny) and the variable-length tile-part byte ranges
+travel to rank 0, which prepends the main header (with the TLM marker when requested) and appends
+EOC.  Decoding mirrors it: every rank parses the (small) headers, decodes its tiles into its rows
+of the frame; a gather of the image is only needed if one process wants the whole frame.
+
+torch.distributed is plumbing (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests); the codec work is behind the C ABI.
+"""
+import numpy as np
+
+
+def tile_range(num_tiles: int, rank: int, world: int):
+    """Contiguous, balanced run of tiles for `rank`: (first, count).  The first num_tiles % world
+    ranks take one extra tile, so that a rank's output is a contiguous run of tile-parts."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(num_tiles, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def assemble(main_header: bytes, tile_parts) -> bytes:
+    """main header | tile-parts in tile order | EOC"""
+    return b"".join([main_header] + list(tile_parts) + [b"\xff\xd9"])
+
+
+def gather_bytes(payload: bytes, group=None, dst=0, device=None):
+    """Variable-length gather of one byte string per rank to `dst` (None elsewhere).
+
+    Two steps, as the path needs: an all-gather of the lengths (so that every rank knows the
+    prefix-sum offsets), then one gather of fixed-size padded buffers.  Works on gloo (CPU tensors)
+    and on nccl/RCCL (device tensors; pass device)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else "cpu"
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    if dist.get_backend(group) == "nccl":
+        out = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(out, buf, group=group)          # RCCL: all-gather is the robust primitive
+        if rank != dst:
+            return None, sizes
+    else:
+        out = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, out, dst=dst, group=group)
+        if rank != dst:
+            return None, sizes
+    return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)], sizes
+
+
+def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None):
+    """All ranks learn Psot of every tile (needed by the TLM marker and for file offsets)."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else "cpu"
+    full = torch.zeros(num_tiles, dtype=torch.int64, device=dev)
+    if len(lens):
+        full[first:first + len(lens)] = torch.from_numpy(np.asarray(lens, dtype=np.int64)).to(dev)
+    dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    return full.cpu().numpy().astype(np.uint32)
+
+
+def encode_sharded(encode_tiles, plan, group=None, device=None):
+    """encode_tiles(first, count) -> (tile-part bytes, Psot array) for this rank's tile run (the GPU
+    encoder's finish_tiles, or the oracle pipeline in the CPU tests).  Returns the whole
+    codestream on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    first, count = tile_range(plan.num_tiles, rank, world)
+    part, lens = encode_tiles(first, count) if count else (b"", np.zeros(0, np.uint32))
+    all_lens = gather_tile_lengths(lens, plan.num_tiles, first, group, device)
+    parts, _ = gather_bytes(part, group, 0, device)
+    if rank != 0:
+        return None
+    return assemble(plan.t2_main_header(all_lens), parts)

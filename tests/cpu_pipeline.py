@@ -15,14 +15,16 @@ def _view(arena, off, pitch, w, h, dtype):
     return np.lib.stride_tricks.as_strided(a[off:], shape=(h, w), strides=(pitch * 4, 4))
 
 
-def forward_stages(plan: Plan, image: np.ndarray):
-    """image: int32 [C,H,W]. Returns the arena (uint32) after convert + all DWT levels."""
+def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
+    """image: int32 [C,H,W]. Returns the arena (uint32) after convert + all DWT levels.
+    tiles=(first, count) restricts the work to a run of tiles (sharding tests)."""
     p = plan.params
     rev = bool(p.reversible)
     dt = np.int32 if rev else np.float32
     arena = np.zeros(plan.arena_elems, np.uint32)
     lib = ob.lib()
-    for t in range(plan.num_tiles):
+    t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
+    for t in range(t_first, t_first + t_count):
         planes = []
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
@@ -45,7 +47,7 @@ def forward_stages(plan: Plan, image: np.ndarray):
             _view(arena, off, pitch, w, h, dt)[:] = v
     for lv in plan.levels:
         w, h = int(lv["w"]), int(lv["h"])
-        if w == 0 or h == 0:
+        if w == 0 or h == 0 or not (t_first <= int(lv["tile"]) < t_first + t_count):
             continue
         src = np.ascontiguousarray(_view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt))
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
@@ -71,13 +73,16 @@ def quantise_block(plan, arena, k):
     return q, mx
 
 
-def encode_blocks(plan: Plan, arena):
-    """HT-encodes every block with the oracle. Returns (data bytes, coded table)."""
+def encode_blocks(plan: Plan, arena, tiles=None):
+    """HT-encodes every block (of the tile run) with the oracle. Returns (data bytes, coded table)."""
     coded = np.zeros(plan.num_blocks, coded_dtype)
     chunks = []
     pos = 0
+    t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
     for k in range(plan.num_blocks):
         blk = plan.blocks[k]
+        if not (t_first <= int(plan.bands[int(blk["band"])]["tile"]) < t_first + t_count):
+            continue
         K = int(blk["K_max"])
         q, mx = quantise_block(plan, arena, k)
         if mx >= (1 << (31 - K)):                       # ojph_codeblock.cpp:146-158
@@ -97,6 +102,13 @@ def encode(image, **kw):
     arena = forward_stages(plan, image)
     data, coded = encode_blocks(plan, arena)
     return plan.t2_write(data, coded), plan, arena, data, coded
+
+
+def encode_tiles(plan: Plan, image, first, count):
+    """Oracle pipeline over a run of tiles -> (tile-part bytes, Psot per tile)."""
+    arena = forward_stages(plan, np.ascontiguousarray(image, dtype=np.int32), (first, count))
+    data, coded = encode_blocks(plan, arena, (first, count))
+    return plan.t2_write_tiles(data, coded, first, count)
 
 
 def decode_blocks(plan: Plan, cs: bytes):

@@ -1,0 +1,118 @@
+"""Multi-GPU path: tiles shard across ranks with no data-path collective;
+one gather of variable-length tile-parts at the end.  The N>1 logic is covered here with
+world_size-2/3 `gloo` process groups on CPU (device stages replaced by the oracle pipeline), and on
+the GPU box with several tile-range encoders/decoders sharing the one GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests.synth import synth_image
+
+
+def test_tile_range_is_a_partition():
+    from openjph_amd.shard import tile_range
+    for nt in (1, 2, 7, 12, 256):
+        for world in (1, 2, 3, 8):
+            runs = [tile_range(nt, r, world) for r in range(world)]
+            pos = 0
+            for first, count in runs:
+                assert first == pos and count >= 0
+                pos += count
+            assert pos == nt
+            counts = [c for _, c in runs]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        tile_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openjph_amd import shard
+        from openjph_amd.plan import Plan, make_params
+        from tests import cpu_pipeline as cp
+        img = synth_image(case["nc"], case["h"], case["w"], case["bd"], seed=3)
+        kw = dict(case["kw"], bit_depth=case["bd"])
+        plan = Plan(make_params(case["w"], case["h"], case["nc"], **kw))
+        cs = shard.encode_sharded(lambda first, count: cp.encode_tiles(plan, img, first, count), plan)
+        if rank == 0:
+            q.put(cs)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+SHARD_CASES = [
+    dict(nc=1, h=300, w=500, bd=16, kw=dict(tile=(128, 128))),                       # 12 tiles, C4-like
+    dict(nc=1, h=256, w=256, bd=8, kw=dict(tile=(64, 64), tlm=True)),                # TLM needs every Psot
+    dict(nc=3, h=100, w=260, bd=8, kw=dict(tile=(128, 128), color_transform=True)),  # 3 tiles on 2 ranks
+    dict(nc=1, h=64, w=64, bd=8, kw=dict()),                                         # 1 tile: rank 1 idle
+]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("ci", range(len(SHARD_CASES)))
+def test_sharded_encode_gloo_matches_single_process(ci, world):
+    import torch.multiprocessing as mp
+    from tests import cpu_pipeline as cp
+    case = SHARD_CASES[ci]
+    if world == 3 and ci not in (0, 1):
+        pytest.skip("covered at world_size 2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    img = synth_image(case["nc"], case["h"], case["w"], case["bd"], seed=3)
+    want, *_ = cp.encode(img, bit_depth=case["bd"], **case["kw"])
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(len(SHARD_CASES)))
+def test_tile_range_encoders_and_decoders_on_gpu(ci):
+    """Several tile-range encoders (what the ranks of a node run) == the whole-frame encoder; several
+    tile-range decoders writing one frame buffer == the whole-frame decoder."""
+    import torch
+    from openjph_amd import codec, shard
+    from openjph_amd.plan import Plan, make_params
+    case = SHARD_CASES[ci]
+    img = synth_image(case["nc"], case["h"], case["w"], case["bd"], seed=3)
+    kw = dict(case["kw"], bit_depth=case["bd"])
+    plan = Plan(make_params(case["w"], case["h"], case["nc"], **kw))
+    whole = codec.Encoder(plan=plan).encode(img)
+    d_img = torch.from_numpy(img).cuda()
+    for world in (2, 3):
+        parts, lens = [], []
+        for r in range(world):
+            first, count = shard.tile_range(plan.num_tiles, r, world)
+            if count == 0:
+                parts.append(b""); continue
+            enc = codec.Encoder(plan=plan, tiles=(first, count))
+            enc.run_device(d_img)
+            b, l = enc.finish_tiles()
+            parts.append(b); lens.append(l)
+        got = shard.assemble(plan.t2_main_header(np.concatenate(lens)), parts)
+        assert got == whole
+        out = torch.zeros_like(d_img)
+        for r in range(world):
+            first, count = shard.tile_range(plan.num_tiles, r, world)
+            if count:
+                dec = codec.Decoder(whole, tiles=(first, count))
+                dec.run_device(out)
+                assert dec.failed_blocks() == 0
+        assert np.array_equal(out.cpu().numpy(), codec.decode(whole))
