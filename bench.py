@@ -7,8 +7,11 @@ in HBM: encode (sample convert -> 5 DWT levels -> HT block encode) followed by d
 decode -> 5 inverse DWT levels -> convert) of that frame's code-block bytes, also resident in HBM.
 Host Tier-2 (packet headers) and PCIe are outside the timed region; DESIGN.md quotes them.
 
-One process per GPU.  With N > 1 every rank codes its own independent frame (the path shards by
-frame / tile with no data-path collective): weak scaling, value = samples of all ranks / time.
+One process per GPU.  The path shards with no data-path collective: single-tile frames (the default
+C3 workload) are replicas -- with N > 1 every rank codes its own independent frame, weak scaling,
+value = samples of all ranks / time; tiled frames (--workload c4_...) shard by contiguous runs of
+tiles of ONE frame, strong scaling, with the final tile-part gather over RCCL outside the timed
+region (it is host Tier-2 + PCIe work, like the single-GPU finish()).
 
 Prints ONE JSON line (rank 0).  Extra objects on that line:
   roofline     -- the dominant kernel of the step against the HBM roofline, from live HIP-event
@@ -51,6 +54,8 @@ def main():
     ap.add_argument("--workload", default="c3_8k_444_12b_irv97", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch one elementwise kernel of known traffic (PMC unit calibration)")
     args = ap.parse_args()
 
     import torch
@@ -75,22 +80,54 @@ def main():
     img = synth_image(nc, h, w, bd, seed=1234 + rank)
     d_img = torch.from_numpy(img).to(dev)
     params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
-    enc = codec.Encoder(params, device=local_rank)
+    from openjph_amd.plan import Plan
+    from openjph_amd import shard
+    plan = Plan(params)
+    # single-tile frames do not shard (replicas only): every rank codes its own frame (weak scaling).
+    # tiled frames shard by contiguous runs of tiles: all ranks share one frame (strong scaling).
+    tiled = plan.num_tiles > 1 and world > 1
+    if tiled:
+        img = synth_image(nc, h, w, bd, seed=1234)
+        d_img = torch.from_numpy(img).to(dev)
+        my_tiles = shard.tile_range(plan.num_tiles, rank, world)
+        assert my_tiles[1] > 0, "more ranks than tiles"
+    else:
+        my_tiles = (0, plan.num_tiles)
+    my_share = my_tiles[1] / plan.num_tiles
+    enc = codec.Encoder(plan=plan, device=local_rank, tiles=my_tiles)
     t0 = time.perf_counter()
-    cs = enc.encode(d_img)                       # also serves as the first warm-up + produces the decoder's input
+    if tiled:
+        enc.run_device(d_img)
+        part, lens = enc.finish_tiles()
+        all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=dev)
+        parts, _ = shard.gather_bytes(part, device=dev)          # RCCL: the final codestream gather
+        cs = shard.assemble(plan.t2_main_header(all_lens), parts) if rank == 0 else None
+        box = [cs]
+        dist.broadcast_object_list(box, src=0)                   # every rank decodes from the same stream
+        cs = box[0]
+    else:
+        cs = enc.encode(d_img)                   # also serves as the first warm-up + produces the decoder's input
     t_e2e_enc = time.perf_counter() - t0
-    dec = codec.Decoder(cs, device=local_rank)
-    d_out = torch.empty_like(d_img)
+    dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles)
+    d_out = torch.zeros_like(d_img) if tiled else torch.empty_like(d_img)
     t0 = time.perf_counter()
     dec.run_device(d_out)
     torch.cuda.synchronize(dev)
     failed = dec.failed_blocks()
     assert failed == 0, "decode failed for %d code-blocks" % failed
-    err = (d_out - d_img).abs().max().item()
+    if tiled:                                    # compare only this rank's tile rows / columns
+        mask = torch.zeros_like(d_img, dtype=torch.bool)
+        for t in range(my_tiles[0], my_tiles[0] + my_tiles[1]):
+            _, _, (x0, y0, tw, th) = plan.comp_plane(t, 0)
+            mask[:, y0:y0 + th, x0:x0 + tw] = True
+        err = ((d_out - d_img).abs() * mask).max().item()
+    else:
+        err = (d_out - d_img).abs().max().item()
     if rev:
         assert err == 0, "reversible round trip is not lossless"
     coded_bytes = enc.coded_bytes()
-    c_rate = coded_bytes / nsamples
+    nsamples_rank = nsamples * my_share          # samples this rank codes per step
+    c_rate = coded_bytes / nsamples_rank
     levels = int(params.num_decomps)
 
     def step():
@@ -116,47 +153,76 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
+    if args.calibrate:                           # known traffic: reads 4 B/elem, writes 4 B/elem, 16 B per lane
+        a = torch.zeros(64 * 1024 * 1024, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            torch.add(a, 1.0, out=b)
+        torch.cuda.synchronize(dev)
+        del a, b
 
-    # per-kernel timings of the last step (HIP events on the codec's stream)
-    te, td = enc.timing(), dec.timing()
+    # per-kernel timings: HIP events on the codec's own stream, averaged over a second run of the
+    # same steps (reading the events synchronises, so it is kept out of the timed region above)
+    reps = max(1, min(args.steps, 10))
+    te, td = None, None
+    for _ in range(reps):
+        step()
+        a, b = enc.timing(), dec.timing()
+        if te is None:
+            te, td = a, b
+        else:
+            for acc, cur in ((te, a), (td, b)):
+                for k, v in cur.items():
+                    acc[k] = [x + y for x, y in zip(acc[k], v)] if isinstance(v, list) else acc[k] + v
+    for acc in (te, td):
+        for k, v in acc.items():
+            acc[k] = [x / reps for x in v] if isinstance(v, list) else v / reps
+    ns = nsamples_rank
     kernels = {
-        "dwt_forward(all levels)": (dwt_alg_bytes(nsamples, levels), te["dwt_ms"]),
-        "dwt_forward(level 1)": (8.0 * nsamples, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
-        "dwt_inverse(all levels)": (dwt_alg_bytes(nsamples, levels), td["dwt_ms"]),
-        "dwt_inverse(level 1)": (8.0 * nsamples, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
-        "ht_encode": ((4.0 + c_rate) * nsamples, te["ht_ms"]),
-        "ht_decode": ((4.0 + c_rate) * nsamples, td["ht_ms"]),
-        "convert_forward": (8.0 * nsamples, te["convert_ms"]),
-        "convert_inverse": (8.0 * nsamples, td["convert_ms"]),
+        "dwt_forward(all levels)": (dwt_alg_bytes(ns, levels), te["dwt_ms"]),
+        "dwt_forward(level 1)": (8.0 * ns, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
+        "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels), td["dwt_ms"]),
+        "dwt_inverse(level 1)": (8.0 * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
+        "ht_encode": ((4.0 + c_rate) * ns, te["ht_ms"]),
+        "ht_decode": ((4.0 + c_rate) * ns, td["ht_ms"]),
     }
+    if ct or levels == 0:                        # otherwise the conversion is fused into the top DWT level
+        kernels["convert_forward"] = (8.0 * ns, te["convert_ms"])
+        kernels["convert_inverse"] = (8.0 * ns, td["convert_ms"])
     kinfo = {}
     for k, (b, ms) in kernels.items():
         kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}
-    dom = max(("ht_encode", "ht_decode", "dwt_forward(all levels)", "dwt_inverse(all levels)",
-               "convert_forward", "convert_inverse"), key=lambda k: kernels[k][1])
+    dom = max((k for k in kernels if "level 1" not in k), key=lambda k: kernels[k][1])
     dom_b, dom_ms = kernels[dom]
     achieved = dom_b / 1e6 / dom_ms if dom_ms > 0 else 0.0
+    traffic = None
+    try:                                         # HBM bytes per launch from the last committed PMC pass
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = pmc.get(args.workload, {}).get(dom)
+    except Exception:
+        pass
 
     result = {
         "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
-        "value": round(nsamples * world / (ms_per_step * 1e-3) / 1e6, 2),
+        "value": round(nsamples * (1 if tiled else world) / (ms_per_step * 1e-3) / 1e6, 2),
         "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
         "dtype": "i32" if rev else "f32", "data": "synthetic",
         "config": {"workload": args.workload, "width": w, "height": h, "components": nc, "bit_depth": bd,
                    "wavelet": "5/3 reversible" if rev else "9/7 irreversible", "qstep": qstep if not rev else None,
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
-                   "tile": list(tile), "frames_per_step": world, "sharding": "one frame per GPU",
+                   "tile": list(tile), "frames_per_step": 1 if tiled else world,
+                   "sharding": ("%d tiles per GPU of one frame" % my_tiles[1]) if tiled else "one frame per GPU (replicas)",
                    "coded_bytes_per_sample": round(c_rate, 4),
                    "encode_ms": round(te["total_ms"], 4), "decode_ms": round(td["total_ms"], 4),
-                   "encode_Msamples_s": round(nsamples / te["total_ms"] / 1e3, 1),
-                   "decode_Msamples_s": round(nsamples / td["total_ms"] / 1e3, 1),
+                   "encode_Msamples_s": round(ns / te["total_ms"] / 1e3, 1),
+                   "decode_Msamples_s": round(ns / td["total_ms"] / 1e3, 1),
                    "e2e_first_encode_s_incl_pcie_tier2": round(t_e2e_enc, 3),
                    "roundtrip_max_abs_err": int(err)},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic},
         "kernels": kinfo,
     }
 
