@@ -182,7 +182,7 @@ typedef struct ojphgpu_cb_desc {     /* one code-block */
                                         encode: byte offset of this block's scratch slot */
   uint32_t scratch_cap;              /* encode: bytes available at data_off; decode: offset of the
                                         block's per-quad records in d_quad_scratch (elements) */
-  uint32_t reserved;
+  uint32_t reserved;                 /* decode: offset of the block's area in d_aux (elements) */
 } ojphgpu_cb_desc;
 
 typedef struct ojphgpu_cb_result {   /* encode result per block */
@@ -199,16 +199,27 @@ int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                       ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status);
 
 /* K9 + K7: HT decoder (ojph_block_decoder32.cpp:742-1613) with the dequantise transfer
- * (ojph_codestream_gen.cpp:124-168) fused.  Two launches: the serial MEL/VLC state machines run
- * one lane per code-block, the MagSgn stage one wavefront per code-block.  For decoding,
- * blocks[i].scratch_cap is the offset (in uint32 elements) of block i's per-quad records inside
- * d_quad_scratch (ceil(w/2) * ceil(h/2) records per block).  d_block_status[i] = 0 ok / non-zero
- * failed (block zeroed), mirroring the bool of decode_cb32.  max_len1 = max over blocks of len1
- * and nominal_w x nominal_h = the nominal code-block size (they size the per-wave LDS). */
+ * (ojph_codestream_gen.cpp:124-168) fused.  Three launches: prep (one wavefront per block:
+ * un-stuffs the VLC and MEL segments into flat bit strings in d_aux), step 1 (the serial MEL /
+ * VLC / U-VLC chains, one lane per block -> one 32-bit record per quad in d_quad_scratch), step 2
+ * (MagSgn -> de-quantised samples, one wavefront per block, one lane per sample column).
+ * For decoding, blocks[i].scratch_cap is the offset (uint32 elements) of block i's per-quad
+ * records inside d_quad_scratch (ceil(w/2) * ceil(h/2) records) and blocks[i].reserved the offset
+ * (uint32 elements) of its area inside d_aux, ojphgpu_ht_decode_aux_words(len1) elements long.
+ * d_block_status[i] = 0 ok / non-zero failed (block zeroed), mirroring the bool of decode_cb32. */
+uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1);
 int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                       const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
-                      uint8_t* d_block_status, uint32_t max_len1, uint32_t nominal_w,
-                      uint32_t nominal_h);
+                      uint32_t* d_aux, uint8_t* d_block_status);
+/* the three launches one by one (ojphgpu_ht_decode == prep, step1, step2 in this order) */
+int ojphgpu_ht_decode_prep(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                           const uint8_t* d_data, uint32_t* d_aux);
+int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                            const uint8_t* d_data, const uint32_t* d_aux, uint32_t* d_quad_scratch,
+                            uint8_t* d_block_status);
+int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                            const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
+                            uint8_t* d_block_status);
 
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */
@@ -273,6 +284,8 @@ int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t le
  * stream: out[0]=convert+colour [1]=DWT [2]=HT block coder [3]=total */
 int  ojphgpu_encoder_timing(ojphgpu_encoder* enc, float out[4]);
 int  ojphgpu_decoder_timing(ojphgpu_decoder* dec, float out[4]);
+/* the block decoder's three launches of the last run_device: out[0]=prep [1]=step 1 [2]=step 2 (ms) */
+int  ojphgpu_decoder_ht_timing(ojphgpu_decoder* dec, float out[3]);
 /* duration (ms) of every DWT level launch of the last run_device, in launch order (encode:
  * highest resolution first; decode: lowest first); *n = number of levels written */
 int  ojphgpu_encoder_level_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, uint32_t* n);

@@ -120,7 +120,14 @@ SIGNATURES = {
     "ojphgpu_ht_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ojphgpu_ht_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ojphgpu_ht_decode_aux_words": (C.c_uint32, [C.c_uint32]),
+    "ojphgpu_ht_decode_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "ojphgpu_ht_decode_step1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "ojphgpu_ht_decode_step2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "ojphgpu_decoder_ht_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_convert_forward": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ojphgpu_convert_inverse": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,

@@ -177,7 +177,10 @@ class Decoder:
         check(self._lib.ojphgpu_decoder_timing(self._h, t), "decoder_timing")
         lv = (C.c_float * 40)(); n = C.c_uint32()
         check(self._lib.ojphgpu_decoder_level_timing(self._h, lv, 40, C.byref(n)), "decoder_level_timing")
-        return dict(ht_ms=t[0], dwt_ms=t[1], convert_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)])
+        ht = (C.c_float * 3)()
+        check(self._lib.ojphgpu_decoder_ht_timing(self._h, ht), "decoder_ht_timing")
+        return dict(ht_ms=t[0], dwt_ms=t[1], convert_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)],
+                    ht_prep_ms=ht[0], ht_step1_ms=ht[1], ht_step2_ms=ht[2])
 
 
 def encode(image: np.ndarray, device=0, **kw) -> bytes:
@@ -224,23 +227,26 @@ def ht_encode(descs: np.ndarray, coef, scratch_bytes, out_cap):
     return res, out.cpu().numpy()[:int(cnt[0])], int(cnt[1])
 
 
-def ht_decode(descs: np.ndarray, data: np.ndarray, coef, max_len1, nominal=(64, 64)):
+def ht_decode(descs: np.ndarray, data: np.ndarray, coef):
     torch = _torch()
     dev = coef.device.index
+    L = capi.lib()
     descs = descs.copy()
-    qoff = 0
-    for x in descs:                               # per-quad record offsets (see include/ojphgpu.h)
+    qoff = aoff = 0
+    for x in descs:                               # per-quad record / aux offsets (see include/ojphgpu.h)
         x["scratch_cap"] = qoff
         qoff += ((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2)
+        x["reserved"] = aoff
+        aoff += int(L.ojphgpu_ht_decode_aux_words(int(x["len1"])))
     d = to_device(descs, dev)
     dd = to_device(np.concatenate([np.asarray(data, np.uint8), np.zeros(64, np.uint8)]), dev)
     status = torch.zeros(len(descs) + 16, dtype=torch.uint8, device=coef.device)
-    nq = int(sum(((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2) for x in descs))
-    quads = torch.zeros(nq + 16, dtype=torch.int32, device=coef.device)
-    check(capi.lib().ojphgpu_ht_decode(_stream_ptr(torch, dev), C.c_void_p(d.data_ptr()), len(descs),
-                                       C.c_void_p(dd.data_ptr()), C.c_void_p(coef.data_ptr()),
-                                       C.c_void_p(quads.data_ptr()), C.c_void_p(status.data_ptr()),
-                                       int(max_len1), nominal[0], nominal[1]),
+    quads = torch.zeros(qoff + 16, dtype=torch.int32, device=coef.device)
+    aux = torch.zeros(aoff + 16, dtype=torch.int32, device=coef.device)
+    check(L.ojphgpu_ht_decode(_stream_ptr(torch, dev), C.c_void_p(d.data_ptr()), len(descs),
+                              C.c_void_p(dd.data_ptr()), C.c_void_p(coef.data_ptr()),
+                              C.c_void_p(quads.data_ptr()), C.c_void_p(aux.data_ptr()),
+                              C.c_void_p(status.data_ptr())),
           "ht_decode")
     torch.cuda.synchronize(dev)
     return status.cpu().numpy()[:len(descs)]

@@ -8,22 +8,28 @@
 // de-quantise transfer gen_rev/irv_tx_from_cb32 (src/core/codestream/ojph_codestream_gen.cpp:
 // 124-168); zero blocks / failures: codeblock::decode + pull_line (ojph_codeblock.cpp:190-266).
 //
-// Two launches per frame:
+// Three launches per frame:
+//   prep    (ht_dec_prep_kernel)   ONE WAVEFRONT PER CODE-BLOCK.  Byte un-stuffing only looks at the
+//           previous raw byte, so the bit offset of every byte is a wavefront prefix sum (the idea
+//           of the reference's AVX2 decoder, ojph_block_decoder_avx2.cpp:277-386).  The backward
+//           VLC segment and the forward MEL segment are rewritten as flat, un-stuffed bit strings
+//           in an HBM scratch area, padded the way the reference pads (VLC: zeros, MEL: ones).
 //   step 1  (ht_dec_step1_kernel)  The MEL / VLC / U-VLC stage is a serial state machine: where a
-//           codeword starts depends on every earlier codeword and on the neighbour context.  A
-//           wavefront cannot split one block's chain, so the first version of this file ran the
-//           chain as wave-uniform code, one wavefront per block -- 63 of 64 lanes repeated the same
-//           work and the kernel took 4.8 ms per 8K frame (profiles/r01_a_*).  Now ONE LANE owns one
-//           code-block's chain and a wavefront advances 64 independent chains in lock step: the
-//           bit windows (un-stuffed on the fly, 4 bytes at a time) live in registers, the decode
-//           tables in LDS, the significance of the quad row above in two 64-bit masks.  Output:
-//           one 32-bit record per quad {t-word, u_q} in HBM scratch.
-//   step 2  (ht_dec_step2_kernel)  ONE WAVEFRONT PER CODE-BLOCK.  All 64 lanes de-stuff the
-//           MagSgn segment into a flat LDS bit buffer (un-stuffing only looks at the previous raw
-//           byte, so bit offsets are a wavefront prefix sum -- the idea of the reference's AVX2
-//           decoder, ojph_block_decoder_avx2.cpp:277-386).  Then, per quad row: lane = quad, kappa
-//           from the exponents of the row above (LDS), bit offsets from a prefix sum of the m_n,
-//           samples extracted from the flat buffer, de-quantised and stored to the sub-band plane.
+//           codeword starts depends on every earlier codeword and on the neighbour context.  ONE
+//           LANE owns one code-block's chain and a wavefront advances 64 independent chains in
+//           lock step.  Everything that is not on the chain was moved off it: bits come from the
+//           flat strings (a 64-bit window + one prefetched word, no un-stuffing), the adaptive MEL
+//           run-length code is expanded ahead of time into a 64-entry event queue held in a
+//           register pair, the significance of the quad row above lives in two 64-bit masks, the
+//           decode tables in LDS.  Output: one 32-bit record per quad {t-word, u_q}.
+//   step 2  (ht_dec_step2_kernel)  ONE WAVEFRONT PER CODE-BLOCK, ONE LANE PER SAMPLE COLUMN.  A lane
+//           decodes the two samples of its column in the current quad row -- they are adjacent in
+//           the MagSgn bit string, so a wavefront prefix sum of the lanes' bit counts gives every
+//           lane its offset -- and keeps the exponent of its bottom sample for the next row's
+//           kappa, which neighbours fetch with DPP moves (no LDS, no barrier).  Each row of 64
+//           de-quantised samples leaves as one coalesced 256-byte store.  MagSgn bytes are
+//           un-stuffed 256 at a time into a small LDS ring, so LDS use does not depend on the
+//           size of the code-block and the CU stays fully occupied.
 // SigProp / MagRef passes (:1318-1609) are not implemented yet: blocks carrying them decode
 // their cleanup pass only -- identical to the reference for streams of its own encoder, which
 // never emits these passes (ojph_block_encoder.cpp:548).
@@ -41,6 +47,19 @@ __device__ uint16_t g_dec_uvlc1[256];
 namespace {
 
 constexpr int WAVES = 4;
+constexpr uint32_t RING_WORDS = 256;          // step 2: 8 Kbit of un-stuffed MagSgn per wavefront (>= 4160 + 2048 + 32 in flight)
+constexpr uint32_t RING_MASK = RING_WORDS - 1;
+constexpr uint32_t ROW_BITS_MAX = 64 * 2 * 32; // a quad row of 64 columns consumes at most this many bits
+constexpr uint32_t EXP_BYTES = 1024 + 8;      // wide blocks (> 64 columns): exponent row in LDS
+
+// words of the flat VLC / MEL strings of a cleanup segment with MEL+VLC length scup (incl. 2 pad words)
+__host__ __device__ __forceinline__ uint32_t vlc_words(uint32_t scup) { return ((scup - 2u) * 8u + 4u + 31u) / 32u + 2u; }
+__host__ __device__ __forceinline__ uint32_t mel_words(uint32_t scup) { return ((scup - 1u) * 8u + 31u) / 32u + 2u; }
+__host__ __device__ __forceinline__ uint32_t aux_words(uint32_t len1)
+{
+  const uint32_t s = len1 < 2u ? 2u : (len1 > 4079u ? 4079u : len1);
+  return vlc_words(s) + mel_words(s);
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -50,7 +69,7 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // wave64 inclusive prefix sum with DPP adds (row shifts inside 16-lane rows, then row broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
   int x = (int)v;
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
@@ -61,6 +80,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
   return (uint32_t)x;
 }
+// value of lane-1 / lane+1 (0 at the ends); quad_perm swap of lanes 2k <-> 2k+1
+__device__ __forceinline__ uint32_t from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t from_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }  // quad_perm:[1,0,3,2]
 
 __device__ __forceinline__ uint32_t mel_exp(uint32_t k)      // {0,0,0,1,1,1,2,2,2,3,3,4,5}
 {
@@ -80,99 +103,155 @@ __device__ __forceinline__ uint32_t check_block(const ojphgpu_cb_desc& d, const 
   return scup;
 }
 
+__device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v, uint32_t n)
+{
+  if (n == 0) return;
+  const uint32_t w = pos >> 5, sh = pos & 31;
+  atomicOr(&buf[w], v << sh);
+  if (sh + n > 32) atomicOr(&buf[w + 1], v >> (32 - sh));
+}
+
+// -------------------------------------------------------------------------------------------------
+// prep: one wavefront = one code-block; VLC (backward) and MEL (forward) segments -> flat bit strings
+// -------------------------------------------------------------------------------------------------
+// One stream: `count` bytes, byte k given by get(k) (with its predecessor for the stuffing rule);
+// bits(b, prev) = number of payload bits of byte b; REV = string is consumed MSB first (MEL).
+template <bool MEL>
+__device__ void flatten(const uint8_t* __restrict__ cb, uint32_t lcup, uint32_t scup, uint32_t* __restrict__ out,
+                        uint32_t* lds, int lane)
+{
+  const uint32_t count = MEL ? scup - 1u : scup - 2u;
+  for (int i = lane; i < 68; i += 64) lds[i] = 0;
+  wave_sync();
+  uint32_t cursor = 0, wpos = 0;
+  if (!MEL) {                                              // rev_init (block_decoder32.cpp:380-400)
+    const uint32_t d = cb[lcup - 2];
+    const uint32_t t = d >> 4;
+    if (lane == 0) lds[0] = t;
+    cursor = 4u - ((t & 7u) == 7u ? 1u : 0u);
+    wave_sync();
+  }
+  for (uint32_t base = 0; base < count; base += 256) {
+    const uint32_t k0 = base + 4u * (uint32_t)lane;
+    uint32_t val = 0, nb = 0;
+    if (k0 < count) {
+      uint32_t prev;
+      if (MEL) prev = k0 ? cb[lcup - scup + k0 - 1] : 0u;
+      else prev = k0 ? cb[lcup - 2 - k0] : (cb[lcup - 2] | 0xFu);
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t k = k0 + j;
+        if (k < count) {
+          uint32_t b, n;
+          if (MEL) {                                       // mel_read (:93-157): after 0xFF only 7 bits, MSB first
+            b = cb[lcup - scup + k];
+            if (k == count - 1) b |= 0xFu;                 // the last MEL byte shares its low nibble with VLC (:116)
+            n = 8u - (prev == 0xFFu ? 1u : 0u);
+            const uint32_t payload = __brev(b & ((1u << n) - 1u)) >> (32u - n);    // stream order = MSB first
+            val |= payload << nb;
+          } else {                                         // rev_read (:308-359): > 0x8F then x1111111 -> 7 bits
+            b = cb[lcup - 3 - k];
+            n = 8u - ((prev > 0x8Fu && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
+            val |= (b & ((1u << n) - 1u)) << nb;
+          }
+          nb += n; prev = b;
+        }
+      }
+    }
+    const uint32_t incl = wave_incl_scan(nb);
+    or_bits(lds, cursor + incl - nb, val, nb);
+    const uint32_t T = cursor + rdlane(incl, 63);
+    wave_sync();
+    const uint32_t nfull = T >> 5;
+    for (uint32_t i = lane; i < nfull; i += 64) out[wpos + i] = MEL ? __brev(lds[i]) : lds[i];
+    const uint32_t carry = lds[nfull];
+    wave_sync();
+    for (int i = lane; i < 68; i += 64) lds[i] = 0;
+    wave_sync();
+    if (lane == 0) lds[0] = carry;
+    wave_sync();
+    wpos += nfull; cursor = T & 31u;
+  }
+  if (lane == 0) {
+    uint32_t w = lds[0];
+    if (cursor) {
+      if (MEL) w = __brev(w | (0xFFFFFFFFu << cursor));    // past the end the MEL segment continues with 1s (:98)
+      out[wpos++] = w;
+    }
+    out[wpos] = MEL ? 0xFFFFFFFFu : 0u;                   // ... and the VLC segment with 0s (:313-331)
+    out[wpos + 1] = MEL ? 0xFFFFFFFFu : 0u;
+  }
+  wave_sync();
+}
+
+__global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data, uint32_t* __restrict__ aux)
+{
+  __shared__ uint32_t s_buf[WAVES][68];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t bi = blockIdx.x * WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) return;
+  const uint8_t* cb = data + d.data_off;
+  const uint32_t scup = check_block(d, cb);
+  if (scup == 0) return;
+  uint32_t* out = aux + d.reserved;
+  flatten<false>(cb, d.len1, scup, out, s_buf[wave], lane);
+  flatten<true>(cb, d.len1, scup, out + vlc_words(scup), s_buf[wave], lane);
+}
+
 // -------------------------------------------------------------------------------------------------
 // step 1: one lane = one code-block
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
-{
-  uint32_t v; __builtin_memcpy(&v, p, 4); return v;
-}
-
-// Both readers keep the NEXT four raw bytes in a register, loaded one refill ahead, so the HBM/L2
-// latency of the byte stream never sits on the serial decode chain.
-struct VlcReader {          // backward reader with un-stuffing (block_decoder32.cpp:308-439)
-  const uint8_t* p; int left; uint64_t tmp; uint32_t bits, unstuff, nxt;
-  __device__ __forceinline__ void fetch() {           // raw bytes p, p-1, p-2, p-3 -> nxt (first byte on top)
-    if (left >= 4) nxt = load_u32_unaligned(p - 3);
-    else {
-      nxt = 0;
-      if (left > 0) nxt |= (uint32_t)p[0] << 24;
-      if (left > 1) nxt |= (uint32_t)p[-1] << 16;
-      if (left > 2) nxt |= (uint32_t)p[-2] << 8;
-    }
-  }
-  __device__ __forceinline__ void init(const uint8_t* cb, uint32_t lcup, uint32_t scup) {
-    const uint32_t d = cb[lcup - 2];
-    tmp = d >> 4;
-    bits = 4u - (((uint32_t)tmp & 7u) == 7u ? 1u : 0u);
-    unstuff = (d | 0xFu) > 0x8Fu;
-    p = cb + lcup - 3; left = (int)scup - 2;
-    fetch(); refill(); refill();
+struct FlatLsb {            // VLC: flat bits, LSB first; 64-bit window, two words requested ahead
+  const uint32_t* w; uint32_t idx, last, n, nx0, nx1; uint64_t win;
+  __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
+    w = p; last = nwords - 1u; nx0 = p[0]; nx1 = p[last < 1u ? last : 1u]; idx = 2; win = 0; n = 0;
+    refill(); refill();
   }
   __device__ __forceinline__ void refill() {
-    if (bits > 32) return;
-    const uint32_t v = nxt;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                     // bytes past the segment read as 0 (:313-331)
-      const uint32_t b = (v >> (24 - 8 * k)) & 0xFFu;
-      const uint32_t nb = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
-      tmp |= (uint64_t)(b & ((1u << nb) - 1u)) << bits;
-      bits += nb;
-      unstuff = b > 0x8Fu;
+    if (n <= 32u) {
+      win |= (uint64_t)nx0 << n; n += 32u;
+      nx0 = nx1; nx1 = w[idx < last ? idx : last]; ++idx;
     }
-    p -= 4; left = left > 4 ? left - 4 : 0;
-    fetch();
   }
-  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)tmp; }
-  __device__ __forceinline__ void skip(uint32_t n) { tmp >>= n; bits -= n; }
+  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)win; }
+  __device__ __forceinline__ void skip(uint32_t k) { win >>= k; n -= k; }
 };
 
-struct MelReader {          // forward, MSB first, 0xFF -> 7 bits (block_decoder32.cpp:93-269)
-  const uint8_t* p; int left; uint64_t tmp; int bits; uint32_t unstuff, nxt; uint32_t k, run, one;
-  __device__ __forceinline__ void fetch() {           // raw bytes p .. p+3 -> nxt (first byte in the LSB)
-    if (left >= 4) { nxt = load_u32_unaligned(p); if (left == 4) nxt |= 0x0F000000u; }   // last byte |= 0xF (:116)
-    else {
-      nxt = 0xFFFFFFFFu;                              // past the end the segment continues with 0xFF (:98)
-      if (left > 0) nxt = (nxt & ~0xFFu) | (uint32_t)p[0] | (left == 1 ? 0xFu : 0u);
-      if (left > 1) nxt = (nxt & ~0xFF00u) | (((uint32_t)p[1] | (left == 2 ? 0xFu : 0u)) << 8);
-      if (left > 2) nxt = (nxt & ~0xFF0000u) | (((uint32_t)p[2] | (left == 3 ? 0xFu : 0u)) << 16);
-    }
+struct MelQueue {           // MEL: flat bits, MSB first, decoded ahead into a queue of events
+  const uint32_t* w; uint32_t idx, last, n, nx0, nx1, k, nev; uint64_t win, ev;
+  __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
+    w = p; last = nwords - 1u; nx0 = p[0]; nx1 = p[last < 1u ? last : 1u]; idx = 2; win = 0; n = 0; k = 0; nev = 0; ev = 0;
   }
-  __device__ __forceinline__ void init(const uint8_t* cb, uint32_t lcup, uint32_t scup) {
-    p = cb + lcup - scup; left = (int)scup - 1; tmp = 0; bits = 0; unstuff = 0; k = 0; run = 0; one = 0;
-    fetch(); refill();
-  }
-  __device__ __forceinline__ void refill() {
-    if (bits > 32) return;
-    const uint32_t v = nxt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t b = (v >> (8 * i)) & 0xFFu;
-      const int nb = 8 - (int)unstuff;
-      tmp |= (uint64_t)(b & ((1u << nb) - 1u)) << (64 - bits - nb);
-      bits += nb;
-      unstuff = (b == 0xFF);
-    }
-    p += 4; left = left > 4 ? left - 4 : 0;
-    fetch();
-  }
-  __device__ __forceinline__ uint32_t sym() {     // T.814 decodeMELSym; same runs as :170-269
-    if (run == 0 && one == 0) {
+  // T.814 decodeMELSym, run by run (same runs as block_decoder32.cpp:170-269): keeps >= 32 events queued
+  __device__ __forceinline__ void fill() {
+    while (nev <= 31u) {
+      if (n <= 32u) {
+        win |= (uint64_t)nx0 << (32u - n); n += 32u;
+        nx0 = nx1; nx1 = w[idx < last ? idx : last]; ++idx;
+      }
       const uint32_t e = mel_exp(k);
-      if (tmp >> 63) { run = 1u << e; k = k < 12 ? k + 1 : 12; tmp <<= 1; bits -= 1; }
+      if (win >> 63) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }   // 2^e zeros, no one
       else {
-        run = e ? (uint32_t)((tmp << 1) >> (64 - e)) : 0u;
-        k = k > 0 ? k - 1 : 0; one = 1; tmp <<= (e + 1); bits -= (int)(e + 1);
+        const uint32_t run = e ? (uint32_t)((win << 1) >> (64u - e)) : 0u;                 // run zeros, then a one
+        ev |= 1ull << (nev + run); nev += run + 1u;
+        k = k > 0u ? k - 1u : 0u; win <<= (e + 1u); n -= (e + 1u);
       }
     }
-    if (run > 0) { run--; return 0; }
-    one = 0; return 1;
+  }
+  __device__ __forceinline__ uint32_t take(bool use) {      // next event if `use`, queue untouched otherwise
+    const uint32_t b = (uint32_t)ev & 1u;
+    const uint32_t s = use ? 1u : 0u;
+    ev >>= s; nev -= s;
+    return b;
   }
 };
 
 __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
-    uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
+    const uint32_t* __restrict__ aux, uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
 {
   __shared__ uint16_t s_vlc[2048];
   __shared__ uint16_t s_uvlc0[320];
@@ -191,68 +270,98 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   const uint32_t scup = check_block(d, cb);
   if (scup == 0) { block_status[bi] = 1; return; }
   block_status[bi] = 0;
-  const uint32_t lcup = d.len1;
   const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
   uint32_t* rec = quads + d.scratch_cap;          // QH rows of QW records
 
-  VlcReader vlc; vlc.init(cb, lcup, scup);
-  MelReader mel; mel.init(cb, lcup, scup);
+  FlatLsb vlc; vlc.init(aux + d.reserved, vlc_words(scup));
+  MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
 
   const bool small = QW <= 64;                    // significance of the row above fits two 64-bit masks
-  uint64_t a_prev = 0, b_prev = 0, a_cur = 0, b_cur = 0;   // bit x: rho bit 1 (bottom-left) / bit 3 (bottom-right)
-  for (uint32_t qy = 0; qy < QH; ++qy) {
-    const uint16_t* tbl = s_vlc + (qy ? 1024 : 0);
-    uint32_t* row = rec + qy * QW;
-    const uint32_t* above = row - QW;
+  uint64_t a_prev = 0, b_prev = 0;                // bit x: rho bit 1 (bottom-left) / bit 3 (bottom-right) of quad x
+
+  // ---- initial quad row (block_decoder32.cpp:854-975) ----
+  {
     uint32_t tleft = 0;
-    a_cur = 0; b_cur = 0;
+    uint64_t a_cur = 0, b_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      uint32_t t[2] = { 0, 0 };
       vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
-      mel.refill();                       // > 32 bits: a pair consumes at most 3 symbols of <= 6 bits
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint32_t x = qx + j;
-        if (x < QW) {
-          uint32_t c_q;
-          if (qy == 0) c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);              // :903,:934
-          else {
-            c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1);                         // :1022,:1059
-            uint32_t nw, nn_l, nn_r, ne;     // sigma of columns 2x-1, 2x, 2x+1, 2x+2 of the sample row above
-            if (small) {
-              nw = x ? (uint32_t)(b_prev >> (x - 1)) & 1u : 0u;
-              nn_l = (uint32_t)(a_prev >> x) & 1u; nn_r = (uint32_t)(b_prev >> x) & 1u;
-              ne = x + 1 < 64 ? (uint32_t)(a_prev >> (x + 1)) & 1u : 0u;
-            } else {
-              nw = x ? (above[x - 1] >> 7) & 1u : 0u;
-              const uint32_t up = above[x];
-              nn_l = (up >> 5) & 1u; nn_r = (up >> 7) & 1u;
-              ne = x + 1 < QW ? (above[x + 1] >> 5) & 1u : 0u;
-            }
-            c_q |= (nw | nn_l) << 7;                                                        // :990,:1024,:1026
-            c_q |= (nn_r | ne) << 9;                                                        // :991,:1027
-          }
-          uint32_t tv = tbl[c_q + (vlc.peek() & 0x7Fu)];
-          if (c_q == 0) { if (mel.sym() == 0) tv = 0; }                                     // :882-894
-          vlc.skip(tv & 7u);
-          t[j] = tv; tleft = tv;
-          if (small) { a_cur |= (uint64_t)((tv >> 5) & 1u) << x; b_cur |= (uint64_t)((tv >> 7) & 1u) << x; }
-        }
+      mel.fill();                         // >= 32 events queued: a pair consumes at most 3
+      uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
+      uint32_t t0 = s_vlc[c_q + (vlc.peek() & 0x7Fu)];
+      if (mel.take(c_q == 0) == 0 && c_q == 0) t0 = 0;                                      // :882-894
+      vlc.skip(t0 & 7u);
+      uint32_t t1 = 0;
+      if (qx + 1 < QW) {
+        c_q = ((t0 & 0x10u) << 3) | ((t0 & 0xE0u) << 2);                                    // :934
+        t1 = s_vlc[c_q + (vlc.peek() & 0x7Fu)];
+        if (mel.take(c_q == 0) == 0 && c_q == 0) t1 = 0;
+        vlc.skip(t1 & 7u);
       }
-      uint32_t mode = ((t[0] & 0x8u) << 3) | ((t[1] & 0x8u) << 4);
-      uint32_t entry;
-      if (qy == 0) {
-        if (mode == 0xC0u) { if (mel.sym()) mode += 0x40u; }                                // :943-952
-        entry = s_uvlc0[mode + (vlc.peek() & 0x3Fu)];
-      } else entry = s_uvlc1[mode + (vlc.peek() & 0x3Fu)];
+      tleft = t1;
+      if (small) {
+        a_cur |= (uint64_t)((t0 >> 5) & 1u) << qx; b_cur |= (uint64_t)((t0 >> 7) & 1u) << qx;
+        a_cur |= (uint64_t)((t1 >> 5) & 1u) << (qx + 1); b_cur |= (uint64_t)((t1 >> 7) & 1u) << (qx + 1);
+      }
+      uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
+      if (mel.take(mode == 0xC0u) && mode == 0xC0u) mode += 0x40u;                          // :943-952
+      uint32_t entry = s_uvlc0[mode + (vlc.peek() & 0x3Fu)];
       vlc.skip(entry & 7u); entry >>= 3;
       uint32_t len = entry & 0xFu;
       const uint32_t tmp = vlc.peek() & ((1u << len) - 1u);
       vlc.skip(len); entry >>= 4;
       len = entry & 7u; entry >>= 3;
-      const uint32_t kap = qy == 0 ? 1u : 0u;                                               // :971-974 / :1082-1085
-      const uint32_t u0 = kap + (entry & 7u) + (tmp & ~(0xFFu << len));
-      const uint32_t u1 = kap + (entry >> 3) + (tmp >> len);
+      const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
+      const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
+      rec[qx] = t0 | (u0 << 16);
+      if (qx + 1 < QW) rec[qx + 1] = t1 | (u1 << 16);
+    }
+    a_prev = a_cur; b_prev = b_cur;
+  }
+  // ---- other quad rows (:977-1089) ----
+  for (uint32_t qy = 1; qy < QH; ++qy) {
+    const uint16_t* tbl = s_vlc + 1024;
+    uint32_t* row = rec + qy * QW;
+    const uint32_t* above = row - QW;
+    uint32_t tleft = 0;
+    uint64_t a_cur = 0, b_cur = 0;
+    for (uint32_t qx = 0; qx < QW; qx += 2) {
+      vlc.refill();
+      mel.fill();
+      uint32_t t[2] = { 0, 0 };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t x = qx + j;
+        if (x < QW) {
+          uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1);                   // :1022,:1059
+          uint32_t nw, nn_l, nn_r, ne;     // sigma of columns 2x-1, 2x, 2x+1, 2x+2 of the sample row above
+          if (small) {
+            nw = (uint32_t)((b_prev << 1) >> x) & 1u;
+            nn_l = (uint32_t)(a_prev >> x) & 1u; nn_r = (uint32_t)(b_prev >> x) & 1u;
+            ne = (uint32_t)((a_prev >> 1) >> x) & 1u;
+          } else {
+            nw = x ? (above[x - 1] >> 7) & 1u : 0u;
+            const uint32_t up = above[x];
+            nn_l = (up >> 5) & 1u; nn_r = (up >> 7) & 1u;
+            ne = x + 1 < QW ? (above[x + 1] >> 5) & 1u : 0u;
+          }
+          c_q |= (nw | nn_l) << 7;                                                          // :990,:1024,:1026
+          c_q |= (nn_r | ne) << 9;                                                          // :991,:1027
+          uint32_t tv = tbl[c_q + (vlc.peek() & 0x7Fu)];
+          if (mel.take(c_q == 0) == 0 && c_q == 0) tv = 0;
+          vlc.skip(tv & 7u);
+          t[j] = tv; tleft = tv;
+          if (small) { a_cur |= (uint64_t)((tv >> 5) & 1u) << x; b_cur |= (uint64_t)((tv >> 7) & 1u) << x; }
+        }
+      }
+      const uint32_t mode = ((t[0] & 0x8u) << 3) | ((t[1] & 0x8u) << 4);
+      uint32_t entry = s_uvlc1[mode + (vlc.peek() & 0x3Fu)];
+      vlc.skip(entry & 7u); entry >>= 3;
+      uint32_t len = entry & 0xFu;
+      const uint32_t tmp = vlc.peek() & ((1u << len) - 1u);
+      vlc.skip(len); entry >>= 4;
+      len = entry & 7u; entry >>= 3;
+      const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
+      const uint32_t u1 = (entry >> 3) + (tmp >> len);
       row[qx] = t[0] | (u0 << 16);
       if (qx + 1 < QW) row[qx + 1] = t[1] | (u1 << 16);
     }
@@ -261,63 +370,23 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
 }
 
 // -------------------------------------------------------------------------------------------------
-// step 2: one wavefront = one code-block
+// step 2: one wavefront = one code-block, one lane = one sample column
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v, uint32_t n)
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
 {
-  if (n == 0) return;
-  const uint32_t w = pos >> 5, sh = pos & 31;
-  atomicOr(&buf[w], v << sh);
-  if (sh + n > 32) atomicOr(&buf[w + 1], v >> (32 - sh));
-}
-
-__device__ __forceinline__ uint32_t get32(const uint32_t* buf, uint32_t pos)
-{
-  const uint32_t w = pos >> 5, sh = pos & 31;
-  return __funnelshift_r(buf[w], buf[w + 1], sh);
-}
-
-// De-stuffs n bytes (forward order, "after 0xFF only 7 bits") into the flat LSB-first bit buffer.
-// Returns the number of bits written (wave-uniform).  (block_decoder32.cpp:609-653)
-__device__ uint32_t destuff_forward(const uint8_t* __restrict__ src, uint32_t n, uint32_t* flat, int lane)
-{
-  uint32_t total = 0;
-  for (uint32_t base = 0; base < n; base += 256) {
-    const uint32_t i0 = base + 4u * (uint32_t)lane;
-    uint32_t prev = (i0 > 0 && i0 - 1 < n) ? src[i0 - 1] : 0u;
-    uint32_t val = 0, nb = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t i = i0 + k;
-      if (i < n) {
-        const uint32_t b = src[i];
-        const uint32_t bits = prev == 0xFF ? 7u : 8u;
-        val |= (b & ((1u << bits) - 1u)) << nb; nb += bits;
-        prev = b;
-      }
-    }
-    const uint32_t incl = wave_incl_scan(nb, lane);
-    or_bits(flat, total + incl - nb, val, nb);
-    total += rdlane(incl, 63);
-  }
-  return total;
+  uint32_t v; __builtin_memcpy(&v, p, 4); return v;
 }
 
 __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
-    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
-    uint32_t ms_words, uint32_t exp_words)
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ uint32_t s_ring[WAVES][RING_WORDS];
+  __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t bi = blockIdx.x * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
-  const uint32_t wave_words = ms_words + 2 * exp_words;
-  uint32_t* f_ms = smem + (uint32_t)wave * wave_words;
-  uint8_t* vexp_a = reinterpret_cast<uint8_t*>(f_ms + ms_words);
-  uint8_t* vexp_b = vexp_a + exp_words * 4;
-
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   if (W == 0 || H == 0) return;
   uint32_t* dst = coef + d.coef_off;
@@ -336,118 +405,198 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
   const uint32_t ms_len = lcup - scup;
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1;
-  if (((ms_len + 3) >> 2) + 2 > ms_words || 2 * QW + 8 > exp_words * 4) {        // LDS sized too small
-    zero_block(); if (lane == 0) block_status[bi] = 2; return;
-  }
-  const uint32_t used_words = ((ms_len + 3) >> 2) + 2;
-  for (uint32_t i = lane; i < used_words; i += 64) f_ms[i] = 0;
-  for (uint32_t i = lane; i < 2 * exp_words; i += 64) (f_ms + ms_words)[i] = 0;
+  const bool wide = W > 64;
+
+  uint32_t* ring = s_ring[wave];
+  for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
+  if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(&s_exp[wave][0][0])[i] = 0;
   wave_sync();
-  const uint32_t ms_bits = destuff_forward(cb, ms_len, f_ms, lane);
-  wave_sync();
+
+  // un-stuffs the next 256 MagSgn bytes into the ring ("after 0xFF only 7 bits", :609-653)
+  uint32_t dst_bits = 0, src_pos = 0, mpos = 0;     // bits un-stuffed, bytes consumed, bits decoded (wave-uniform)
+  auto unstuff_chunk = [&]() {
+    const uint32_t wb = (dst_bits + 31u) >> 5;               // words above the current partial word are stale
+    ring[(wb + (uint32_t)lane) & RING_MASK] = 0;
+    if (lane < 2) ring[(wb + 64u + (uint32_t)lane) & RING_MASK] = 0;
+    wave_sync();
+    const uint32_t i0 = src_pos + 4u * (uint32_t)lane;
+    uint32_t val = 0, nb = 0;
+    if (i0 < ms_len) {
+      uint32_t prev = i0 ? cb[i0 - 1] : 0u;
+      uint32_t word;
+      if (i0 + 4 <= ms_len) word = load_u32_unaligned(cb + i0);
+      else {
+        word = cb[i0];
+        if (i0 + 1 < ms_len) word |= (uint32_t)cb[i0 + 1] << 8;
+        if (i0 + 2 < ms_len) word |= (uint32_t)cb[i0 + 2] << 16;
+      }
+      const uint32_t cnt = min(4u, ms_len - i0);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (k < cnt) {
+          const uint32_t b = (word >> (8 * k)) & 0xFFu;
+          const uint32_t bits = prev == 0xFFu ? 7u : 8u;
+          val |= (b & ((1u << bits) - 1u)) << nb; nb += bits;
+          prev = b;
+        }
+      }
+    }
+    const uint32_t incl = wave_incl_scan(nb);
+    const uint32_t pos = dst_bits + incl - nb;
+    if (nb) {
+      const uint32_t w = pos >> 5, sh = pos & 31;
+      atomicOr(&ring[w & RING_MASK], val << sh);
+      if (sh + nb > 32) atomicOr(&ring[(w + 1) & RING_MASK], val >> (32 - sh));
+    }
+    dst_bits += rdlane(incl, 63);
+    src_pos += 256;
+    wave_sync();
+  };
 
   const uint32_t* rec = quads + d.scratch_cap;
   const uint32_t mmsbp2 = missing_msbs + 2;
   const uint32_t shift = 31 - K;
   const float delta = d.delta;
-  uint32_t mpos = 0;                              // wave-uniform bit position in the flat MagSgn stream
+  const uint32_t half = (uint32_t)lane & 1u;
   bool bad = false;
-  uint32_t ent_next = (uint32_t)lane < QW ? rec[lane] : 0u;      // records are fetched one step ahead
+  uint32_t e_prev = 0;                                   // exponent of this column's bottom sample, row above
+  uint32_t ent_next = (uint32_t)lane < W ? rec[lane >> 1] : 0u;      // records are fetched one step ahead
   for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
-    const uint8_t* vexp = (qy & 1) ? vexp_b : vexp_a;     // exponents of the sample row above
-    uint8_t* vnew = (qy & 1) ? vexp_a : vexp_b;           // ... and of this quad row's bottom samples
-    for (uint32_t qb = 0; qb < QW; qb += 64) {
-      const uint32_t qx = qb + (uint32_t)lane;
-      const bool act = qx < QW;
+    const uint8_t* vexp = s_exp[wave][qy & 1];             // wide blocks: exponents of the sample row above (+1 offset)
+    uint8_t* vnew = s_exp[wave][(qy & 1) ^ 1];
+    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+      while (src_pos < ms_len && dst_bits - mpos < ROW_BITS_MAX + 64u) unstuff_chunk();
+      const bool exhausted = src_pos >= ms_len;            // then bits at and beyond dst_bits read as 1 (:609-632)
+      const uint32_t col = c0 + (uint32_t)lane;
+      const bool act = col < W;
+      const uint32_t qx = col >> 1;
       const uint32_t ent = ent_next;
       {
-        uint32_t nqb = qb + 64, nqy = qy;
-        if (nqb >= QW) { nqb = 0; nqy = qy + 1; }
-        const uint32_t nqx = nqb + (uint32_t)lane;
-        ent_next = (nqy < QH && nqx < QW) ? rec[nqy * QW + nqx] : 0u;
+        uint32_t nc0 = c0 + 64, nqy = qy;
+        if (nc0 >= W) { nc0 = 0; nqy = qy + 1; }
+        const uint32_t ncol = nc0 + (uint32_t)lane;
+        ent_next = (nqy < QH && ncol < W) ? rec[nqy * QW + (ncol >> 1)] : 0u;
       }
-      const uint32_t inf = ent & 0xFFFFu;
+      const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
       uint32_t U_q = ent >> 16;
-      if (qy > 0 && act) {
+      if (qy > 0) {
         uint32_t gamma = inf & 0xF0u; gamma &= gamma - 0x10u;                           // :1218
-        // exponents of columns 2qx-1 .. 2qx+2 of the sample row above (vexp is offset by 1)
-        const uint32_t em = max(max((uint32_t)vexp[2 * qx], (uint32_t)vexp[2 * qx + 1]),
-                                max((uint32_t)vexp[2 * qx + 2], (uint32_t)vexp[2 * qx + 3]));
+        uint32_t em;                      // max exponent over columns 2qx-1 .. 2qx+2 of the sample row above
+        if (!wide) {
+          const uint32_t pm = max(e_prev, from_pair(e_prev));
+          const uint32_t e_nx = from_next(e_prev), e_pv = from_prev(e_prev);   // both moves run with every lane enabled
+          const uint32_t side = half ? e_nx : e_pv;
+          em = max(pm, max(side, from_pair(side)));
+        } else {
+          const uint32_t b = 2 * qx;
+          em = act ? max(max((uint32_t)vexp[b], (uint32_t)vexp[b + 1]), max((uint32_t)vexp[b + 2], (uint32_t)vexp[b + 3])) : 0u;
+        }
         U_q += gamma ? max(em, 1u) : 1u;                                                // :1219-1223
       }
       if (__ballot(act && U_q > mmsbp2) != 0ull) { bad = true; break; }                 // :1114,:1224
-      uint32_t m[4], tot = 0;
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn) {
-        m[nn] = (inf & (1u << (4 + nn))) ? U_q - ((inf >> (12 + nn)) & 1u) : 0u;
-        tot += m[nn];
-      }
-      const uint32_t incl = wave_incl_scan(tot, lane);
-      uint32_t at = mpos + incl - tot;
+      // this lane's samples: n0 = (col, 2qy), n1 = (col, 2qy+1); quad bits 2*half and 2*half+1
+      const uint32_t sel = inf >> (2u * half);
+      const uint32_t m0 = (sel & 0x10u) ? U_q - ((sel >> 12) & 1u) : 0u;
+      const uint32_t m1 = (sel & 0x20u) ? U_q - ((sel >> 13) & 1u) : 0u;
+      const uint32_t tot = m0 + m1;
+      const uint32_t incl = wave_incl_scan(tot);
+      const uint32_t at = mpos + incl - tot;
       mpos += rdlane(incl, 63);
-      uint32_t out[4];
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn) {
-        uint32_t val = 0, v_n = 0;
-        if (inf & (1u << (4 + nn))) {
-          uint32_t ms_val;
-          if (at >= ms_bits) ms_val = 0xFFFFFFFFu;                                      // exhausted: feeds 0xFF (:609-632)
-          else {
-            ms_val = get32(f_ms, at);
-            if (at + 32 > ms_bits) ms_val |= 0xFFFFFFFFu << (ms_bits - at);
-          }
-          const uint32_t mn = m[nn];
-          at += mn;
-          val = ms_val << 31;                                                           // :1127-1133
-          v_n = ms_val & ((mn >= 32 ? 0u : (1u << mn)) - 1u);
-          v_n |= ((inf >> (8 + nn)) & 1u) << mn;
-          v_n |= 1u;
-          val |= (v_n + 2u) << (p - 1);
-        }
-        // de-quantise transfer (ojph_codestream_gen.cpp:124-168)
-        const uint32_t mag = val & 0x7FFFFFFFu;
-        if (rev) { const int iv = (int)(mag >> shift); out[nn] = (uint32_t)((val >> 31) ? -iv : iv); }
-        else { const float fv = __fmul_rn((float)mag, delta); out[nn] = __float_as_uint((val >> 31) ? -fv : fv); }
-        if ((nn & 1) && act) vnew[2 * qx + (nn >> 1) + 1] = (uint8_t)(v_n ? 31 - __clz((int)v_n) : 0);
+      const uint32_t wi = at >> 5, sh = at & 31;
+      const uint32_t w0 = ring[wi & RING_MASK], w1 = ring[(wi + 1) & RING_MASK], w2 = ring[(wi + 2) & RING_MASK];
+      uint64_t win = (uint64_t)__funnelshift_r(w0, w1, sh) | ((uint64_t)__funnelshift_r(w1, w2, sh) << 32);
+      if (exhausted) {
+        if (at >= dst_bits) win = ~0ull;
+        else if (at + 64 > dst_bits) win |= ~0ull << (dst_bits - at);
       }
+      uint32_t out0, out1, v1 = 0;
+      {
+        uint32_t val = 0;
+        if (sel & 0x10u) {
+          const uint32_t ms_val = (uint32_t)win;
+          uint32_t v_n = ms_val & ((1u << m0) - 1u);                                    // :1127-1133
+          v_n |= ((sel >> 8) & 1u) << m0;
+          v_n |= 1u;
+          val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
+        }
+        const uint32_t mag = val & 0x7FFFFFFFu;                                         // de-quantise transfer
+        if (rev) { const int iv = (int)(mag >> shift); out0 = (uint32_t)((val >> 31) ? -iv : iv); }
+        else { const float fv = __fmul_rn((float)mag, delta); out0 = __float_as_uint((val >> 31) ? -fv : fv); }
+      }
+      {
+        uint32_t val = 0;
+        if (sel & 0x20u) {
+          const uint32_t ms_val = (uint32_t)(win >> m0);
+          uint32_t v_n = ms_val & ((1u << m1) - 1u);
+          v_n |= ((sel >> 9) & 1u) << m1;
+          v_n |= 1u;
+          val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
+          v1 = v_n;
+        }
+        const uint32_t mag = val & 0x7FFFFFFFu;
+        if (rev) { const int iv = (int)(mag >> shift); out1 = (uint32_t)((val >> 31) ? -iv : iv); }
+        else { const float fv = __fmul_rn((float)mag, delta); out1 = __float_as_uint((val >> 31) ? -fv : fv); }
+      }
+      const uint32_t e_new = v1 ? 31u - (uint32_t)__clz((int)v1) : 0u;
+      if (!wide) e_prev = e_new;
+      else if (act) vnew[col + 1] = (uint8_t)e_new;
       if (act) {
-        const uint32_t x = 2 * qx, y = 2 * qy;
-        const bool c1 = x + 1 < W, r1 = y + 1 < H;
-        uint32_t* o = dst + (size_t)y * pitch + x;
-        o[0] = out[0]; if (c1) o[1] = out[2];
-        if (r1) { o[pitch] = out[1]; if (c1) o[pitch + 1] = out[3]; }
+        const uint32_t y = 2 * qy;
+        uint32_t* o = dst + (size_t)y * pitch + col;
+        o[0] = out0;
+        if (y + 1 < H) o[pitch] = out1;
       }
     }
-    wave_sync();
+    if (wide) wave_sync();
   }
   if (bad) { zero_block(); if (lane == 0) block_status[bi] = 1; }
 }
 
 }  // namespace
 
-extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
-                                  const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
-                                  uint8_t* d_block_status, uint32_t max_len1, uint32_t nominal_w,
-                                  uint32_t nominal_h)
+extern "C" uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1) { return aux_words(len1); }
+
+extern "C" int ojphgpu_ht_decode_prep(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                       const uint8_t* d_data, uint32_t* d_aux)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (!d_blocks || !d_data || !d_aux) return OJPHGPU_E_INVALID;
+  hipLaunchKernelGGL(ht_dec_prep_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream,
+                     d_blocks, n, d_data, d_aux);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                        const uint8_t* d_data, const uint32_t* d_aux, uint32_t* d_quad_scratch,
+                                        uint8_t* d_block_status)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ojphgpu::ensure_tables() != 0) return OJPHGPU_E_HIP;
-  if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
-  if (nominal_w == 0 || nominal_h == 0 || nominal_w > 1024 || nominal_h > 1024) return OJPHGPU_E_INVALID;
-  const uint32_t ms_words = ((max_len1 + 3) >> 2) + 4;
-  const uint32_t exp_words = (nominal_w + 8 + 3) / 4 + 1;
-  const size_t lds = (size_t)WAVES * (ms_words + 2 * exp_words) * 4;
-  if (lds > 160 * 1024) return OJPHGPU_E_INVALID;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(ht_dec_step2_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-    return OJPHGPU_E_HIP;
+  if (!d_blocks || !d_data || !d_aux || !d_quad_scratch || !d_block_status) return OJPHGPU_E_INVALID;
   hipLaunchKernelGGL(ht_dec_step1_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_blocks, n, d_data,
-                     d_quad_scratch, d_block_status);
-  hipLaunchKernelGGL(ht_dec_step2_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, (hipStream_t)stream,
-                     d_blocks, n, d_data, (const uint32_t*)d_quad_scratch, (uint32_t*)d_coef, d_block_status,
-                     ms_words, exp_words);
+                     d_aux, d_quad_scratch, d_block_status);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                        const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
+                                        uint8_t* d_block_status)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
+  hipLaunchKernelGGL(ht_dec_step2_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream,
+                     d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                  const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
+                                  uint32_t* d_aux, uint8_t* d_block_status)
+{
+  int rc = ojphgpu_ht_decode_prep(stream, d_blocks, n, d_data, d_aux);
+  if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step1(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
+  if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step2(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status);
+  return rc;
 }
 
 namespace ojphgpu {

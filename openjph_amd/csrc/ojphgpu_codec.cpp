@@ -369,7 +369,8 @@ extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint
 struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads;
+  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
+  hipEvent_t ht_ev[2] = { nullptr, nullptr };      // between prep | step 1 | step 2
   bool fused_convert = false;
   TileRange tiles{ 0, 0 };
   uint32_t nblocks = 0;                            // code-blocks of the tile range
@@ -384,8 +385,9 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads })
+  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads, &d->aux })
     b->release();
+  for (auto& e : d->ht_ev) if (e) (void)hipEventDestroy(e);
   d->timer.destroy();
   delete d;
 }
@@ -422,7 +424,7 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
   const std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
   d->nblocks = (uint32_t)ids.size();
   std::vector<ojphgpu_cb_desc> bd(ids.size());
-  uint64_t max_off = 0, min_off = ~0ull, nquads = 0;
+  uint64_t max_off = 0, min_off = ~0ull, nquads = 0, naux = 0;
   for (size_t i = 0; i < ids.size(); ++i) {
     const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[ids[i]];
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
@@ -432,6 +434,8 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
     nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2);
+    o.reserved = (uint32_t)naux;                                        // offset of this block's flat VLC / MEL strings
+    naux += ojphgpu_ht_decode_aux_words(c.len1);
     d->max_len1 = std::max(d->max_len1, c.len1);
     if (c.len1 + c.len2) {
       max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
@@ -443,8 +447,9 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
   for (ojphgpu_cb_desc& o : bd) if (o.len1 + o.len2) o.data_off -= min_off; else o.data_off = 0;
   d->data_first = (size_t)min_off;
   d->data_len = (size_t)(max_off - min_off);
-  if (nquads >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
-  if (d->quads.alloc((size_t)nquads * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
+  if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
+  if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
+  for (auto& e : d->ht_ev) if (hipEventCreate(&e) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
@@ -472,9 +477,16 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   const Plan& P = *d->P;
   hipStream_t s = d->stream;
   d->timer.mark(0, s);
-  int rc = ojphgpu_ht_decode(s, (const ojphgpu_cb_desc*)d->cb_descs.p, d->nblocks, (const uint8_t*)d->data.p,
-                             d->arena.p, (uint32_t*)d->quads.p, (uint8_t*)d->status.p, d->max_len1, P.p.block_w,
-                             P.p.block_h);
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p;
+  int rc = ojphgpu_ht_decode_prep(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
+  if (rc) return rc;
+  (void)hipEventRecord(d->ht_ev[0], s);
+  rc = ojphgpu_ht_decode_step1(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p,
+                               (uint32_t*)d->quads.p, (uint8_t*)d->status.p);
+  if (rc) return rc;
+  (void)hipEventRecord(d->ht_ev[1], s);
+  rc = ojphgpu_ht_decode_step2(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p,
+                               (uint8_t*)d->status.p);
   if (rc) return rc;
   d->timer.mark(1, s);
   d->timer.begin_levels();
@@ -531,6 +543,16 @@ extern "C" int ojphgpu_decoder_timing(ojphgpu_decoder* d, float out[4])
 {
   if (!d || !out || !d->ran) return OJPHGPU_E_INVALID;
   return d->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_decoder_ht_timing(ojphgpu_decoder* d, float out[3])
+{
+  if (!d || !out || !d->ran || !d->timer.ok) return OJPHGPU_E_INVALID;
+  if (hipEventSynchronize(d->timer.ev[3]) != hipSuccess) return OJPHGPU_E_HIP;
+  if (hipEventElapsedTime(&out[0], d->timer.ev[0], d->ht_ev[0]) != hipSuccess ||
+      hipEventElapsedTime(&out[1], d->ht_ev[0], d->ht_ev[1]) != hipSuccess ||
+      hipEventElapsedTime(&out[2], d->ht_ev[1], d->timer.ev[1]) != hipSuccess) return OJPHGPU_E_HIP;
+  return OJPHGPU_OK;
 }
 
 extern "C" int ojphgpu_decoder_level_timing(ojphgpu_decoder* d, float* out, uint32_t cap, uint32_t* n)

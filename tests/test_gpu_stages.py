@@ -197,7 +197,7 @@ def test_ht_decode_vs_oracle():
         datas.append(np.frombuffer(coded, np.uint8))
         off += pitch * h; doff += len(coded); max_len = max(max_len, len(coded))
     coef = torch.full((off + 64,), 0x5A5A5A5A, dtype=torch.int32).cuda()
-    status = codec.ht_decode(descs, np.concatenate(datas), coef, max_len, nominal=(1024, 1024))
+    status = codec.ht_decode(descs, np.concatenate(datas), coef)
     got = coef.cpu().numpy()
     assert not status.any(), "failed blocks: %s" % np.nonzero(status)[0][:10]
     for i, (w, h, kmax, dens, amp) in enumerate(cases):
@@ -205,3 +205,49 @@ def test_ht_decode_vs_oracle():
         g = np.lib.stride_tricks.as_strided(got[int(d["coef_off"]):], (h, w), (int(d["pitch"]) * 4, 4))
         assert np.array_equal(g, expect[i]), "decode block %d %s: %d samples differ" % (
             i, cases[i], int((g != expect[i]).sum()))
+
+
+def test_ht_decode_corrupt_segments_match_oracle():
+    """Corrupted / truncated cleanup segments: same accept/reject verdict as the oracle (itself pinned
+    to ojph_decode_codeblock32 on such inputs) and, when accepted, the same samples."""
+    torch = _torch()
+    from openjph_amd import codec
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(21)
+    w = h = 64
+    kmax = 11
+    sm, v = random_block(rng, w, h, w, kmax, 0.5, 700)
+    good = ob.ht_encode(sm, w, h, w, kmax - 1, 0)
+    trials = [good, good[:2], good[:len(good) // 2], good[:-1], b"\x00\x00", b"\xff\xff\xff\xff", good + b"\x00"]
+    for _ in range(120):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 5))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        trials.append(bytes(b))
+    for _ in range(30):                           # damage concentrated in the MEL/VLC tail
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            b[len(b) - 1 - int(rng.integers(0, min(200, len(b))))] = int(rng.integers(0, 256))
+        trials.append(bytes(b))
+    descs = np.zeros(len(trials), codec.cb_desc_dtype)
+    pitch = 64
+    off = doff = 0
+    expect = []
+    for i, t in enumerate(trials):
+        d = descs[i]
+        d["coef_off"], d["pitch"], d["w"], d["h"] = off, pitch, w, h
+        d["K_max"], d["reversible"], d["missing_msbs"] = kmax, 1, kmax - 1
+        d["num_passes"], d["len1"], d["len2"], d["data_off"] = 1, len(t), 0, doff
+        ok, dec = ob.ht_decode(t, w, h, w, kmax - 1)
+        expect.append((ok, ob.dequant_rev(dec, kmax) if ok else np.zeros((h, w), np.int32)))
+        off += pitch * h; doff += len(t)
+    coef = torch.full((off + 64,), 0x5A5A5A5A, dtype=torch.int32).cuda()
+    status = codec.ht_decode(descs, np.frombuffer(b"".join(trials), np.uint8), coef)
+    got = coef.cpu().numpy()
+    n_ok = 0
+    for i, (ok, want) in enumerate(expect):
+        assert (status[i] == 0) == ok, "trial %d: GPU status %d, oracle ok=%s" % (i, status[i], ok)
+        g = got[i * pitch * h:(i + 1) * pitch * h].reshape(h, pitch)[:, :w]
+        assert np.array_equal(g, want), "trial %d: %d samples differ" % (i, int((g != want).sum()))
+        n_ok += ok
+    assert 1 <= n_ok < len(trials)
