@@ -204,49 +204,49 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
 // -------------------------------------------------------------------------------------------------
 // step 1: one lane = one code-block
 // -------------------------------------------------------------------------------------------------
-struct FlatLsb {            // VLC: flat bits, LSB first; 64-bit window, two words requested ahead
-  const uint32_t* w; uint32_t idx, last, n, nx0, nx1; uint64_t win;
+// Both readers take their bits from the flat strings of the prep kernel.  The word that will be
+// appended next is requested unconditionally once per quad pair -- outside any divergent branch, so
+// that the wait for it lands at its use one pair later and never on the chain.
+struct FlatLsb {            // VLC: LSB first; 64-bit window
+  const uint32_t* w; uint32_t idx, last, n, pre; uint64_t win;
   __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
-    w = p; last = nwords - 1u; nx0 = p[0]; nx1 = p[last < 1u ? last : 1u]; idx = 2; win = 0; n = 0;
-    refill(); refill();
+    w = p; last = nwords - 1u;
+    win = (uint64_t)p[0] | ((uint64_t)p[last < 1u ? last : 1u] << 32); n = 64; idx = 2;
+    pre = p[last < 2u ? last : 2u];
   }
-  __device__ __forceinline__ void refill() {
-    if (n <= 32u) {
-      win |= (uint64_t)nx0 << n; n += 32u;
-      nx0 = nx1; nx1 = w[idx < last ? idx : last]; ++idx;
-    }
+  __device__ __forceinline__ void refill() {          // afterwards n > 32
+    if (n <= 32u) { win |= (uint64_t)pre << n; n += 32u; ++idx; }
+    pre = w[idx < last ? idx : last];
   }
-  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)win; }
   __device__ __forceinline__ void skip(uint32_t k) { win >>= k; n -= k; }
 };
 
-struct MelQueue {           // MEL: flat bits, MSB first, decoded ahead into a queue of events
-  const uint32_t* w; uint32_t idx, last, n, nx0, nx1, k, nev; uint64_t win, ev;
+struct MelQueue {           // MEL: MSB first, decoded ahead into a queue of events (bit i of ev = i-th next event)
+  const uint32_t* w; uint32_t idx, last, n, pre, k, nev; uint64_t win, ev;
   __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
-    w = p; last = nwords - 1u; nx0 = p[0]; nx1 = p[last < 1u ? last : 1u]; idx = 2; win = 0; n = 0; k = 0; nev = 0; ev = 0;
+    w = p; last = nwords - 1u;
+    win = ((uint64_t)p[0] << 32) | (uint64_t)p[last < 1u ? last : 1u]; n = 64; idx = 2;
+    pre = p[last < 2u ? last : 2u];
+    k = 0; nev = 0; ev = 0;
   }
-  // T.814 decodeMELSym, run by run (same runs as block_decoder32.cpp:170-269): keeps >= 32 events queued
+  // T.814 decodeMELSym, run by run (same runs as block_decoder32.cpp:170-269).  Afterwards at least
+  // 5 events are queued: the window holds > 32 bits after the refill, a codeword takes <= 6 of them
+  // and yields >= 1 event, and the loop only stops early with >= 32 events queued.
   __device__ __forceinline__ void fill() {
-    while (nev <= 31u) {
-      if (n <= 32u) {
-        win |= (uint64_t)nx0 << (32u - n); n += 32u;
-        nx0 = nx1; nx1 = w[idx < last ? idx : last]; ++idx;
-      }
+    if (n <= 32u) { win |= (uint64_t)pre << (32u - n); n += 32u; ++idx; }
+    pre = w[idx < last ? idx : last];
+    while (nev <= 31u && n >= 6u) {
       const uint32_t e = mel_exp(k);
-      if (win >> 63) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }   // 2^e zeros, no one
+      const uint32_t top = (uint32_t)(win >> 32);
+      if (top >> 31) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }     // 2^e zeros, no one
       else {
-        const uint32_t run = e ? (uint32_t)((win << 1) >> (64u - e)) : 0u;                 // run zeros, then a one
+        const uint32_t run = (top >> (31u - e)) & ((1u << e) - 1u);                          // run zeros, then a one
         ev |= 1ull << (nev + run); nev += run + 1u;
         k = k > 0u ? k - 1u : 0u; win <<= (e + 1u); n -= (e + 1u);
       }
     }
   }
-  __device__ __forceinline__ uint32_t take(bool use) {      // next event if `use`, queue untouched otherwise
-    const uint32_t b = (uint32_t)ev & 1u;
-    const uint32_t s = use ? 1u : 0u;
-    ev >>= s; nev -= s;
-    return b;
-  }
+  __device__ __forceinline__ void drop(uint32_t cnt) { ev >>= cnt; nev -= cnt; }
 };
 
 __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
@@ -276,42 +276,44 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   FlatLsb vlc; vlc.init(aux + d.reserved, vlc_words(scup));
   MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
 
-  const bool small = QW <= 64;                    // significance of the row above fits two 64-bit masks
-  uint64_t a_prev = 0, b_prev = 0;                // bit x: rho bit 1 (bottom-left) / bit 3 (bottom-right) of quad x
+  const bool small = QW <= 32;                    // significance of the row above fits two 32-bit masks
+  uint32_t a_prev = 0, b_prev = 0;                // bit x: rho bit 1 (bottom-left) / bit 3 (bottom-right) of quad x
 
   // ---- initial quad row (block_decoder32.cpp:854-975) ----
   {
-    uint32_t tleft = 0;
-    uint64_t a_cur = 0, b_cur = 0;
+    uint32_t tleft = 0, a_cur = 0, b_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
-      mel.fill();                         // >= 32 events queued: a pair consumes at most 3
+      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 7 + 10 of them
+      mel.fill();                         // >= 5 events queued: a pair consumes at most 3
+      uint32_t v = (uint32_t)vlc.win, used = 0;
+      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
       uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
-      uint32_t t0 = s_vlc[c_q + (vlc.peek() & 0x7Fu)];
-      if (mel.take(c_q == 0) == 0 && c_q == 0) t0 = 0;                                      // :882-894
-      vlc.skip(t0 & 7u);
+      uint32_t t0 = s_vlc[c_q + (v & 0x7Fu)];
+      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }                      // :882-894
+      v >>= (t0 & 7u); used += t0 & 7u;
       uint32_t t1 = 0;
       if (qx + 1 < QW) {
         c_q = ((t0 & 0x10u) << 3) | ((t0 & 0xE0u) << 2);                                    // :934
-        t1 = s_vlc[c_q + (vlc.peek() & 0x7Fu)];
-        if (mel.take(c_q == 0) == 0 && c_q == 0) t1 = 0;
-        vlc.skip(t1 & 7u);
+        t1 = s_vlc[c_q + (v & 0x7Fu)];
+        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
+        v >>= (t1 & 7u); used += t1 & 7u;
       }
       tleft = t1;
       if (small) {
-        a_cur |= (uint64_t)((t0 >> 5) & 1u) << qx; b_cur |= (uint64_t)((t0 >> 7) & 1u) << qx;
-        a_cur |= (uint64_t)((t1 >> 5) & 1u) << (qx + 1); b_cur |= (uint64_t)((t1 >> 7) & 1u) << (qx + 1);
+        a_cur |= (((t0 >> 5) & 1u) | ((t1 >> 4) & 2u)) << qx;
+        b_cur |= (((t0 >> 7) & 1u) | ((t1 >> 6) & 2u)) << qx;
       }
       uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
-      if (mel.take(mode == 0xC0u) && mode == 0xC0u) mode += 0x40u;                          // :943-952
-      uint32_t entry = s_uvlc0[mode + (vlc.peek() & 0x3Fu)];
-      vlc.skip(entry & 7u); entry >>= 3;
+      if (mode == 0xC0u) { if ((evq >> ecnt) & 1u) mode += 0x40u; ecnt++; }                 // :943-952
+      uint32_t entry = s_uvlc0[mode + (v & 0x3Fu)];
+      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
       uint32_t len = entry & 0xFu;
-      const uint32_t tmp = vlc.peek() & ((1u << len) - 1u);
-      vlc.skip(len); entry >>= 4;
+      const uint32_t tmp = v & ((1u << len) - 1u);
+      used += len; entry >>= 4;
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
+      vlc.skip(used); mel.drop(ecnt);
       rec[qx] = t0 | (u0 << 16);
       if (qx + 1 < QW) rec[qx + 1] = t1 | (u1 << 16);
     }
@@ -322,48 +324,58 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
     const uint16_t* tbl = s_vlc + 1024;
     uint32_t* row = rec + qy * QW;
     const uint32_t* above = row - QW;
-    uint32_t tleft = 0;
-    uint64_t a_cur = 0, b_cur = 0;
+    uint32_t tleft = 0, a_cur = 0, b_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       vlc.refill();
       mel.fill();
-      uint32_t t[2] = { 0, 0 };
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint32_t x = qx + j;
-        if (x < QW) {
-          uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1);                   // :1022,:1059
-          uint32_t nw, nn_l, nn_r, ne;     // sigma of columns 2x-1, 2x, 2x+1, 2x+2 of the sample row above
-          if (small) {
-            nw = (uint32_t)((b_prev << 1) >> x) & 1u;
-            nn_l = (uint32_t)(a_prev >> x) & 1u; nn_r = (uint32_t)(b_prev >> x) & 1u;
-            ne = (uint32_t)((a_prev >> 1) >> x) & 1u;
-          } else {
-            nw = x ? (above[x - 1] >> 7) & 1u : 0u;
-            const uint32_t up = above[x];
-            nn_l = (up >> 5) & 1u; nn_r = (up >> 7) & 1u;
-            ne = x + 1 < QW ? (above[x + 1] >> 5) & 1u : 0u;
-          }
-          c_q |= (nw | nn_l) << 7;                                                          // :990,:1024,:1026
-          c_q |= (nn_r | ne) << 9;                                                          // :991,:1027
-          uint32_t tv = tbl[c_q + (vlc.peek() & 0x7Fu)];
-          if (mel.take(c_q == 0) == 0 && c_q == 0) tv = 0;
-          vlc.skip(tv & 7u);
-          t[j] = tv; tleft = tv;
-          if (small) { a_cur |= (uint64_t)((tv >> 5) & 1u) << x; b_cur |= (uint64_t)((tv >> 7) & 1u) << x; }
-        }
+      uint32_t v = (uint32_t)vlc.win, used = 0;
+      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
+      // sigma of the sample row above, columns 2qx-1 .. 2qx+4:  n0 n1 n2 n3 n4 n5
+      uint32_t sg;
+      if (small) {
+        const uint32_t ap = a_prev >> qx, bp = b_prev >> qx, bl = (b_prev << 1) >> qx;
+        sg = (bl & 1u) | ((ap & 1u) << 1) | ((bp & 1u) << 2) | ((ap & 2u) << 2) | ((bp & 2u) << 3) | ((ap & 4u) << 3);
+      } else {
+        const uint32_t up0 = above[qx];
+        const uint32_t upl = qx ? above[qx - 1] : 0u;
+        const uint32_t up1 = qx + 1 < QW ? above[qx + 1] : 0u;
+        const uint32_t up2 = qx + 2 < QW ? above[qx + 2] : 0u;
+        sg = ((upl >> 7) & 1u) | (((up0 >> 5) & 1u) << 1) | (((up0 >> 7) & 1u) << 2) | (((up1 >> 5) & 1u) << 3) |
+             (((up1 >> 7) & 1u) << 4) | (((up2 >> 5) & 1u) << 5);
       }
-      const uint32_t mode = ((t[0] & 0x8u) << 3) | ((t[1] & 0x8u) << 4);
-      uint32_t entry = s_uvlc1[mode + (vlc.peek() & 0x3Fu)];
-      vlc.skip(entry & 7u); entry >>= 3;
+      // quad qx: nw|nn_l -> bit 7, nn_r|ne -> bit 9 (:990-991,:1024-1027)
+      uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1);                       // :1022
+      c_q |= ((sg | (sg >> 1)) & 1u) << 7;
+      c_q |= (((sg >> 2) | (sg >> 3)) & 1u) << 9;
+      uint32_t t0 = tbl[c_q + (v & 0x7Fu)];
+      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }
+      v >>= (t0 & 7u); used += t0 & 7u;
+      uint32_t t1 = 0;
+      if (qx + 1 < QW) {
+        c_q = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1);                                    // :1059
+        c_q |= (((sg >> 2) | (sg >> 3)) & 1u) << 7;
+        c_q |= (((sg >> 4) | (sg >> 5)) & 1u) << 9;
+        t1 = tbl[c_q + (v & 0x7Fu)];
+        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
+        v >>= (t1 & 7u); used += t1 & 7u;
+      }
+      tleft = t1;
+      if (small) {
+        a_cur |= (((t0 >> 5) & 1u) | ((t1 >> 4) & 2u)) << qx;
+        b_cur |= (((t0 >> 7) & 1u) | ((t1 >> 6) & 2u)) << qx;
+      }
+      const uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
+      uint32_t entry = s_uvlc1[mode + (v & 0x3Fu)];
+      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
       uint32_t len = entry & 0xFu;
-      const uint32_t tmp = vlc.peek() & ((1u << len) - 1u);
-      vlc.skip(len); entry >>= 4;
+      const uint32_t tmp = v & ((1u << len) - 1u);
+      used += len; entry >>= 4;
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
       const uint32_t u1 = (entry >> 3) + (tmp >> len);
-      row[qx] = t[0] | (u0 << 16);
-      if (qx + 1 < QW) row[qx + 1] = t[1] | (u1 << 16);
+      vlc.skip(used); mel.drop(ecnt);
+      row[qx] = t0 | (u0 << 16);
+      if (qx + 1 < QW) row[qx + 1] = t1 | (u1 << 16);
     }
     a_prev = a_cur; b_prev = b_cur;
   }
