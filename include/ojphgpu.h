@@ -204,7 +204,7 @@ int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
  * VLC / U-VLC chains, one lane per block -> one 32-bit record per quad in d_quad_scratch), step 2
  * (MagSgn -> de-quantised samples, one wavefront per block, one lane per sample column).
  * For decoding, blocks[i].scratch_cap is the offset (uint32 elements) of block i's per-quad
- * records inside d_quad_scratch (ceil(w/2) * ceil(h/2) records) and blocks[i].reserved the offset
+ * records inside d_quad_scratch (ceil(w/2) * ceil(h/2) records + 1 pad element) and blocks[i].reserved the offset
  * (uint32 elements) of its area inside d_aux, ojphgpu_ht_decode_aux_words(len1) elements long.
  * d_block_status[i] = 0 ok / non-zero failed (block zeroed), mirroring the bool of decode_cb32. */
 uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1);

@@ -235,7 +235,7 @@ def ht_decode(descs: np.ndarray, data: np.ndarray, coef):
     qoff = aoff = 0
     for x in descs:                               # per-quad record / aux offsets (see include/ojphgpu.h)
         x["scratch_cap"] = qoff
-        qoff += ((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2)
+        qoff += ((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2) + 1
         x["reserved"] = aoff
         aoff += int(L.ojphgpu_ht_decode_aux_words(int(x["len1"])))
     d = to_device(descs, dev)

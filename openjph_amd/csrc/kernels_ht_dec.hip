@@ -249,6 +249,17 @@ struct MelQueue {           // MEL: MSB first, decoded ahead into a queue of eve
   __device__ __forceinline__ void drop(uint32_t cnt) { ev >>= cnt; nev -= cnt; }
 };
 
+// Both records of a quad pair leave as ONE 8-byte store, also when the second quad does not exist
+// (odd QW): the extra word lands on the first record of the next row, which is written later, or on
+// the pad element every block's record area ends with.  A fixed number of stores per pair keeps the
+// compiler's vmcnt bookkeeping from ever waiting on a store when it needs a prefetched word.
+struct __attribute__((aligned(4))) U2 { uint32_t x, y; };
+__device__ __forceinline__ void store_pair(uint32_t* p, uint32_t a, uint32_t b)
+{
+  U2 v; v.x = a; v.y = b;
+  *reinterpret_cast<U2*>(p) = v;
+}
+
 __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ aux, uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
@@ -314,8 +325,7 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
       vlc.skip(used); mel.drop(ecnt);
-      rec[qx] = t0 | (u0 << 16);
-      if (qx + 1 < QW) rec[qx + 1] = t1 | (u1 << 16);
+      store_pair(rec + qx, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     a_prev = a_cur; b_prev = b_cur;
   }
@@ -374,8 +384,7 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
       const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
       const uint32_t u1 = (entry >> 3) + (tmp >> len);
       vlc.skip(used); mel.drop(ecnt);
-      row[qx] = t0 | (u0 << 16);
-      if (qx + 1 < QW) row[qx + 1] = t1 | (u1 << 16);
+      store_pair(row + qx, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     a_prev = a_cur; b_prev = b_cur;
   }

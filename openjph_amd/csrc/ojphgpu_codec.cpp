@@ -433,7 +433,7 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
-    nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2);
+    nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2) + 1;    // + 1 pad element (see include/ojphgpu.h)
     o.reserved = (uint32_t)naux;                                        // offset of this block's flat VLC / MEL strings
     naux += ojphgpu_ht_decode_aux_words(c.len1);
     d->max_len1 = std::max(d->max_len1, c.len1);
