@@ -1,6 +1,12 @@
 // openjph_amd/csrc/kernels_ht_enc.hip -- HT cleanup-pass block encoder for gfx950, with the
 // quantise transfer fused into its sample loads.  ONE WAVEFRONT PER CODE-BLOCK.
 //
+// Two kernels share the work: ht_encode_kernel (below, second half of the file) handles blocks up
+// to 64 columns wide -- every block of the nominal 64x64 / 32x32 partitions -- with ONE LANE PER
+// QUAD PAIR, four quad rows per step, and neighbour state exchanged between lanes;
+// ht_encode_wide_kernel (first half, the original formulation: pairs in raster order, neighbours
+// re-read from the block) handles the rare wider shapes (128x32 ... 1024x4).
+//
 // Reference: ojph_encode_codeblock32 (src/core/coding/ojph_block_encoder.cpp:542-1017) and its
 // writers (mel :273-347, vlc :352-407, ms :446-534, terminate_mel_vlc :412-441);
 // quantise transfer gen_rev/irv_tx_to_cb32 (src/core/codestream/ojph_codestream_gen.cpp:59-121);
@@ -38,6 +44,7 @@ constexpr int VLC_WORDS = 64;     // 64 lanes * 30 bits + carry < 256 bytes
 constexpr int MEL_CAP = 192;      // ojph_block_encoder.cpp:554
 constexpr int VLC_CAP = 3072 - MEL_CAP;   // :556
 constexpr int WAVES = 4;
+constexpr uint32_t NARROW_MAX_W = 64;   // blocks up to this width take the lane-per-column kernel
 
 struct WaveLds {
   uint32_t ms[MS_WORDS];
@@ -142,19 +149,20 @@ __device__ __forceinline__ void mel_one(MelState& m, uint8_t* buf, int lane)
   m.run = 0; m.k = m.k > 0 ? m.k - 1 : 0;
 }
 
-__global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
+__global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
     ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ WaveLds s_wave[WAVES];
-  for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
-  __syncthreads();
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t bi = blockIdx.x * WAVES + wave;
-  if (bi >= n) return;
+  const bool mine = bi < n && blocks[bi].w > NARROW_MAX_W;               // narrow blocks belong to ht_encode_kernel
+  if (!__syncthreads_or(mine ? 1 : 0)) return;
+  for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
+  __syncthreads();
+  if (!mine) return;
   const ojphgpu_cb_desc d = blocks[bi];
   WaveLds& L = s_wave[wave];
   const uint32_t W = d.w, H = d.h;
@@ -448,10 +456,10 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   // ---- claim a slot in the compacted output and copy MagSgn | MEL | VLC (:1003-1014) ----
   uint32_t off = 0;
   if (err) total = 0;
-  if (total) {
-    if (lane == 0) off = atomicAdd(cursor, total);
+  if (total) {                                            // slots are 4-byte aligned (ht_encode_kernel stores dwords)
+    if (lane == 0) off = atomicAdd(cursor, (total + 3u) & ~3u);
     off = rdfirst(off);
-    if (off + total > out_cap) { err = 1; total = 0; }
+    if (off + ((total + 3u) & ~3u) > out_cap) { err = 1; total = 0; }
   }
   if (total) {
     const uint32_t scup = mel.pos + v_pos;
@@ -473,6 +481,451 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// narrow blocks (W <= 64): one lane = one quad pair, four quad rows per step
+// -------------------------------------------------------------------------------------------------
+// lane = r * 16 + px: quad row 4 * step + r, quad pair px (sample columns 4 px .. 4 px + 3).  Pairs
+// in lane order are pairs in raster order, so every stream position is a wavefront prefix sum.
+//   * the lane loads its 2 x 4 samples as two 16-byte segments, requested one step ahead;
+//   * what a quad needs from the sample row above (exponents for kappa, significance for the
+//     context) is not recomputed from memory: every lane packs the exponents / significance of
+//     its bottom sample row into one register, the lane 16 positions up (the row above in the same
+//     step, or the last row of the previous step) hands it over with one ds_bpermute, and the left /
+//     right neighbours of that come from DPP wave shifts;
+//   * MagSgn and VLC bits are OR-ed into flat, un-stuffed LDS bit buffers; byte stuffing is
+//     speculative (every lane proposes one byte, a ballot finds the first stuffing event, the
+//     window restarts behind it) and LAZY: a window only runs when all 64 lanes have a full byte,
+//     the < 64 pending bytes stay in the bit buffer until the next step or the final flush;
+//   * coded bytes are staged in LDS (MagSgn grows up from 0, VLC grows down from the end, like
+//     the reference's single buffer) and leave the CU once, as aligned dwords, when the block's
+//     length is known; only blocks that outgrow the stage spill their MagSgn bytes to the HBM
+//     scratch slot.
+constexpr uint32_t OUT_CAP = 5120;      // bytes of coded output staged in LDS per wavefront
+constexpr int PMS_WORDS = 520;          // 64 lanes * 8 samples * 31 bits + < 65 pending bytes
+constexpr int PVLC_WORDS = 80;          // 64 pairs * 30 bits + < 65 pending bytes
+
+struct NarrowLds {
+  uint32_t out[OUT_CAP / 4];
+  uint32_t ms[PMS_WORDS];
+  uint32_t vlc[PVLC_WORDS];
+  uint32_t ev[8];                       // compacted MEL event bits of one step (<= 192)
+  uint8_t  mel[MEL_CAP];
+};
+
+struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t dpp_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }  // wave_shr:1 (0 into lane 0)
+__device__ __forceinline__ uint32_t dpp_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }  // wave_shl:1 (0 into lane 63)
+
+// U-VLC codeword of u (ojph_block_encoder.cpp:196-255), branch-free: prefix | plen<<8 | suffix<<16 | slen<<24
+__device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
+{
+  const uint32_t lo = u < 3u ? 1u : 0u, mid = (u >= 3u && u < 5u) ? 1u : 0u;
+  const uint32_t pre = lo ? u : (mid ? 4u : 0u);
+  const uint32_t pl = u < 3u ? u : 3u;
+  const uint32_t suf = lo ? 0u : (mid ? u - 3u : u - 5u);
+  const uint32_t sl = lo ? 0u : (mid ? 1u : 5u);
+  return pre | (pl << 8) | (suf << 16) | (sl << 24);
+}
+
+__global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
+    uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
+    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
+{
+  __shared__ uint16_t s_vlc[2][2048];
+  __shared__ NarrowLds s_wave[WAVES];
+  for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t bi = blockIdx.x * WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  const uint32_t W = d.w, H = d.h;
+  if (W > NARROW_MAX_W) return;                                           // ht_encode_wide_kernel's
+  if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
+  NarrowLds& L = s_wave[wave];
+  uint8_t* outb = reinterpret_cast<uint8_t*>(L.out);
+  const uint32_t K = d.K_max, p = 31u - K;      // missing_msbs = K_max - 1, p = 30 - missing_msbs
+  const bool rev = d.reversible != 0;
+  const float delta_inv = rev ? 0.0f : __fdiv_rn(1.0f, d.delta);         // ojph_codeblock.cpp:98
+  const uint32_t* src = coef + d.coef_off;
+  const uint32_t pitch = d.pitch;
+  uint8_t* ms_spill = scratch + d.data_off;                              // only used when the LDS stage overflows
+  const uint32_t ms_cap = d.scratch_cap > (uint32_t)VLC_CAP ? d.scratch_cap - VLC_CAP : 0;
+  const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1, PW = (QW + 1) >> 1;
+  const uint32_t nsteps = (QH + 3) >> 2;
+
+  for (int i = lane; i < PMS_WORDS; i += 64) L.ms[i] = 0;
+  for (int i = lane; i < PVLC_WORDS; i += 64) L.vlc[i] = 0;
+  if (lane < 8) L.ev[lane] = 0;
+  wave_sync();
+  if (lane == 0) { L.vlc[0] = 0xF; outb[OUT_CAP - 1] = 0xFF; }            // vlc_init: head byte, 4 bits already used (:365-375)
+  wave_sync();
+
+  // wave-uniform stream state
+  uint32_t ms_pend = 0, ms_k = 0, ms_ff = 0;            // pending bits in L.ms, bytes written, last byte was 0xFF
+  uint32_t v_pend = 4, v_pos = 1, v_prev = 0xFF;        // pending bits in L.vlc, bytes "written" (incl. the head), last byte
+  MelState mel = { 0, 0, 0, 0, 0, 0, 0 };
+  uint32_t err = 0, any_sig = 0;
+  bool spilled = false;
+
+  const uint32_t r = (uint32_t)lane >> 4, px = (uint32_t)lane & 15u;
+  const bool pxok = px < PW;
+  const uint32_t x0 = 4u * px;
+  const bool full4 = x0 + 3 < W;
+  const bool has_q1 = pxok && x0 + 2 < W;
+  uint32_t last_bot = 0;                                 // bottom-row pack of the previous step (all lanes)
+
+  // samples of one quad row of this lane's pair: top[0..3], bot[0..3]
+  auto load_rows = [&](uint32_t qy, uint32_t* top, uint32_t* bot) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { top[k] = 0; bot[k] = 0; }
+    if (!pxok || qy >= QH) return;
+    const uint32_t y0 = 2 * qy;
+    const uint32_t* rp = src + (size_t)y0 * pitch + x0;
+    const bool two = y0 + 1 < H;
+    if (full4) {
+      const U4 a = *reinterpret_cast<const U4*>(rp);
+      top[0] = a.x; top[1] = a.y; top[2] = a.z; top[3] = a.w;
+      if (two) { const U4 b = *reinterpret_cast<const U4*>(rp + pitch); bot[0] = b.x; bot[1] = b.y; bot[2] = b.z; bot[3] = b.w; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x0 + k < W) { top[k] = rp[k]; if (two) bot[k] = rp[pitch + k]; }
+    }
+  };
+
+  // stuffs whole 64-byte windows of the MagSgn bit buffer ("after 0xFF only 7 bits", :471-491);
+  // `flush` also emits the final partial window.  Returns the bit position reached.
+  auto ms_windows = [&](uint32_t T, bool flush) -> uint32_t {
+    uint32_t pos = 0;
+    for (;;) {
+      const uint32_t first_n = ms_ff ? 7u : 8u;
+      if (!flush && pos + first_n + 8u * 63u > T) break;
+      const uint32_t start = pos + (lane == 0 ? 0u : first_n + 8u * (uint32_t)(lane - 1));
+      const uint32_t nb = lane == 0 ? first_n : 8u;
+      const bool ok = start + nb <= T;
+      const uint32_t v = ok ? get_bits(L.ms, start, nb) : 0u;
+      const uint64_t m_ok = __ballot(ok), m_ff = __ballot(ok && v == 0xFF);
+      const uint32_t n_ok = m_ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_ok);
+      const uint32_t f_ff = m_ff ? (uint32_t)__builtin_ctzll(m_ff) : 64u;
+      const uint32_t nc = min(n_ok, f_ff + 1u);
+      if (nc == 0) break;
+      if (!spilled && ms_k + nc + v_pos + 72u > OUT_CAP) {          // the stage is full: MagSgn moves to HBM
+        if (ms_k > ms_cap) { err = 1; break; }
+        for (uint32_t i = lane; i < ms_k; i += 64) ms_spill[i] = outb[i];
+        spilled = true;
+      }
+      if (spilled) {
+        if (ms_k + nc > ms_cap) { err = 1; break; }
+        if ((uint32_t)lane < nc) ms_spill[ms_k + lane] = (uint8_t)v;
+      } else if ((uint32_t)lane < nc) outb[ms_k + lane] = (uint8_t)v;
+      ms_k += nc;
+      pos += first_n + 8u * (nc - 1u);
+      ms_ff = f_ff < n_ok ? 1u : 0u;
+    }
+    return pos;
+  };
+  // same for the VLC buffer: bytes grow downwards, the rule looks at the byte above (:386-405)
+  auto vlc_windows = [&](uint32_t T, bool flush) -> uint32_t {
+    uint32_t pos = 0;
+    for (;;) {
+      if (!flush && pos + 8u * 64u > T) break;
+      const uint32_t start = pos + 8u * (uint32_t)lane;
+      const bool have7 = start + 7 <= T, have8 = start + 8 <= T;
+      const uint32_t v8 = have7 ? get_bits(L.vlc, start, 8) : 0u;     // bits past T are zero
+      uint32_t pv = dpp_prev(v8);
+      if (lane == 0) pv = v_prev;
+      const bool special = have7 && pv > 0x8F && (v8 & 0x7F) == 0x7F;
+      const bool stop = !have8 && !special;
+      const uint64_t m_sp = __ballot(special), m_st = __ballot(stop);
+      const uint32_t fs = m_sp ? (uint32_t)__builtin_ctzll(m_sp) : 64u;
+      const uint32_t ft = m_st ? (uint32_t)__builtin_ctzll(m_st) : 64u;
+      const uint32_t n8 = min(fs, ft);
+      const bool sp = fs < ft;
+      if (n8 == 0 && !sp) break;
+      if (v_pos + n8 + 1 >= (uint32_t)VLC_CAP) { err = 1; break; }
+      if (!spilled && ms_k + v_pos + n8 + 72u > OUT_CAP) {
+        if (ms_k > ms_cap) { err = 1; break; }
+        for (uint32_t i = lane; i < ms_k; i += 64) ms_spill[i] = outb[i];
+        spilled = true;
+      }
+      if ((uint32_t)lane < n8) outb[OUT_CAP - 1 - (v_pos + lane)] = (uint8_t)v8;
+      if (sp && (uint32_t)lane == fs) outb[OUT_CAP - 1 - (v_pos + lane)] = 0x7F;
+      const uint32_t last8 = n8 ? rdlane(v8, (int)(n8 - 1)) : v_prev;
+      v_pos += n8 + (sp ? 1u : 0u);
+      pos += 8u * n8 + (sp ? 7u : 0u);
+      v_prev = sp ? 0x7Fu : last8;
+    }
+    return pos;
+  };
+  // moves the un-emitted bits [pos, T) of a bit buffer to its front and clears the rest
+  auto compact = [&](uint32_t* buf, uint32_t pos, uint32_t T, uint32_t nwords) -> uint32_t {
+    const uint32_t rem = T - pos, nw = (rem + 31u) >> 5;           // nw <= 17
+    const uint32_t w0 = pos >> 5, sh = pos & 31u;
+    uint32_t keep = 0;
+    if ((uint32_t)lane < nw) {
+      keep = __funnelshift_r(buf[w0 + lane], buf[w0 + lane + 1], sh);
+      if (lane == (int)nw - 1 && (rem & 31u)) keep &= (1u << (rem & 31u)) - 1u;
+    }
+    wave_sync();
+    const uint32_t used = min((T >> 5) + 2u, nwords);
+    for (uint32_t i = lane; i < used; i += 64) buf[i] = 0;
+    wave_sync();
+    if ((uint32_t)lane < nw) buf[lane] = keep;
+    wave_sync();
+    return rem;
+  };
+
+  uint32_t ntop[4], nbot[4];
+  load_rows(r, ntop, nbot);
+  for (uint32_t step = 0; step < nsteps && !err; ++step) {
+    const uint32_t qy = 4 * step + r;
+    const bool active = pxok && qy < QH;
+    const bool first_row = qy == 0;
+    uint32_t t[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // quad order: n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1)
+      t[2 * k] = to_sign_mag(ntop[k], rev, p, delta_inv);
+      t[2 * k + 1] = to_sign_mag(nbot[k], rev, p, delta_inv);
+    }
+    if (step + 1 < nsteps) load_rows(qy + 4, ntop, nbot);   // request the next step's samples now
+    uint32_t val[8], e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { val[i] = ((t[i] + t[i]) >> p) & ~1u; e[i] = expo(val[i]); }   // 2*mu_p (:592-595)
+    // ---- the row above: exponents / significance of its samples, columns x0-1 .. x0+4 ----
+    uint32_t botpack = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) botpack |= (e[2 * k + 1] << (6 * k)) | ((val[2 * k + 1] ? 1u : 0u) << (24 + k));
+    const uint32_t give = lane >= 48 ? last_bot : botpack;
+    uint32_t above = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane - 16) & 63) << 2), (int)give);
+    if (first_row || !active) above = 0;
+    uint32_t abl = dpp_prev(above), abr = dpp_next(above);
+    if (px == 0) abl = 0;
+    if (px == 15) abr = 0;
+    last_bot = botpack;
+    uint32_t Eab[6], Sab[6];
+    Eab[0] = (abl >> 18) & 63u; Sab[0] = (abl >> 27) & 1u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Eab[1 + k] = (above >> (6 * k)) & 63u; Sab[1 + k] = (above >> (24 + k)) & 1u; }
+    Eab[5] = abr & 63u; Sab[5] = (abr >> 24) & 1u;
+
+    // ---- per quad symbols ----
+    uint32_t rho_q[2] = { 0, 0 }, emax[2] = { 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (val[i]) rho_q[i >> 2] |= 1u << (i & 3);
+      emax[i >> 2] = max(emax[i >> 2], e[i]);
+    }
+    uint32_t rho_prev = dpp_prev(rho_q[1]);             // rho of the quad to the left of q0
+    if (px == 0) rho_prev = 0;
+    uint32_t cq[2], uq[2], tup[2], msv[8], msl[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t rl = q == 0 ? rho_prev : rho_q[0];
+      uint32_t kappa = 1, c;
+      const uint32_t* E = Eab + 2 * q; const uint32_t* S = Sab + 2 * q;
+      const uint32_t me = max(max(E[0], E[1]), max(E[2], E[3]));
+      const uint32_t c_first = (rl >> 1) | (rl & 1u);                                       // :731,:788
+      const uint32_t c_other = (S[0] | S[1]) | ((S[2] | S[3]) << 2) | ((rl & 4u) >> 1) | ((rl & 8u) >> 2);   // :802,:878,:951,:967,:991
+      c = first_row ? c_first : c_other;
+      if (!first_row && (rho_q[q] & (rho_q[q] - 1u))) kappa = (uint32_t)max(1, (int)me - 1);  // :862,:950
+      const uint32_t U = max(emax[q], kappa), u = U - kappa;
+      uint32_t eps = 0;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) eps |= (uint32_t)(e[q * 4 + nn] == emax[q]) << nn;
+      if (u == 0) eps = 0;
+      const uint32_t tuple = s_vlc[first_row ? 0 : 1][(c << 8) + (rho_q[q] << 4) + eps];
+      cq[q] = c; uq[q] = u; tup[q] = tuple;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        const int i = q * 4 + nn;
+        const uint32_t m = ((rho_q[q] >> nn) & 1u) ? U - ((tuple >> nn) & 1u) : 0u;          // :667-674
+        const uint32_t sv = val[i] - 2u + (t[i] >> 31);                                     // v_n = 2(mu-1)+sign (:601)
+        msl[i] = m;
+        msv[i] = m ? (sv & ((m >= 32 ? 0u : (1u << m)) - 1u)) : 0u;
+      }
+    }
+    any_sig |= (__ballot((rho_q[0] | rho_q[1]) != 0) != 0ull) ? 1u : 0u;
+
+    // ---- VLC bits of the pair: cwd(q0) cwd(q1) then the interleaved U-VLC ----
+    uint32_t vb = 0, vl = 0;
+    bool ev2_valid = false; uint32_t ev2_bit = 0;
+    {
+      const uint32_t u0 = uq[0], u1 = has_q1 ? uq[1] : 0u;
+      const uint32_t l0 = (tup[0] >> 4) & 7u;
+      vb = tup[0] >> 8; vl = l0;
+      if (has_q1) { vb |= (tup[1] >> 8) << vl; vl += (tup[1] >> 4) & 7u; }
+      const bool both_big = first_row && u0 > 2 && u1 > 2;                                   // :766-772
+      const bool one_big = first_row && !both_big && u0 > 2 && u1 > 0;                       // :773-778
+      ev2_valid = first_row && u0 > 0 && u1 > 0; ev2_bit = min(u0, u1) > 2;                   // :763-764
+      const uint32_t w0 = uvlc_word(both_big ? u0 - 2u : u0);
+      uint32_t w1 = uvlc_word(both_big ? u1 - 2u : u1);
+      if (one_big) w1 = (u1 - 1u) | (1u << 8);          // u1 in {1,2} is a single bit, no suffix
+      vb |= (w0 & 0xFFu) << vl; vl += (w0 >> 8) & 0xFFu;                                     // prefix q0, prefix q1,
+      vb |= (w1 & 0xFFu) << vl; vl += (w1 >> 8) & 0xFFu;                                     // suffix q0, suffix q1 (:779-785, :985-988)
+      vb |= ((w0 >> 16) & 0xFFu) << vl; vl += w0 >> 24;
+      vb |= ((w1 >> 16) & 0xFFu) << vl; vl += w1 >> 24;
+      if (!active) { vb = 0; vl = 0; ev2_valid = false; }
+    }
+
+    // ---- MEL events of the pair, compacted in pair order, then run through the adaptive coder ----
+    {
+      const bool ev0_valid = active && cq[0] == 0, ev1_valid = has_q1 && active && cq[1] == 0;
+      const uint32_t ev0_bit = rho_q[0] != 0, ev1_bit = rho_q[1] != 0;
+      const uint32_t cnt = (uint32_t)ev0_valid + (uint32_t)ev1_valid + (uint32_t)ev2_valid;
+      const uint32_t incl = wave_incl_scan(cnt, lane);
+      const uint32_t nev = rdlane(incl, 63);
+      if (nev) {
+        uint32_t at = incl - cnt;
+        if (ev0_valid) { if (ev0_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        if (ev1_valid) { if (ev1_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        if (ev2_valid) { if (ev2_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        wave_sync();
+        uint32_t done = 0;
+        while (done < nev) {                       // wave-uniform: whole zero runs at a time
+          const uint32_t w = done >> 5, sh = done & 31;
+          uint32_t word = rdfirst(L.ev[w]) >> sh;
+          const uint32_t avail = min(32u - sh, nev - done);
+          if (word == 0) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
+          const uint32_t z = (uint32_t)__builtin_ctz(word);
+          if (z >= avail) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
+          mel_zero_run(mel, L.mel, z, lane);
+          mel_one(mel, L.mel, lane);
+          done += z + 1;
+        }
+        wave_sync();
+        if (lane < 8) L.ev[lane] = 0;
+      }
+    }
+
+    // ---- MagSgn: OR the pair's bits into the flat buffer, stuff the full windows ----
+    {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tot += msl[i];
+      const uint32_t incl = wave_incl_scan(tot, lane);
+      const uint32_t T = ms_pend + rdlane(incl, 63);
+      uint32_t at = ms_pend + incl - tot;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { or_bits(L.ms, at, msv[i], msl[i]); at += msl[i]; }
+      wave_sync();
+      const uint32_t pos = ms_windows(T, false);
+      ms_pend = compact(L.ms, pos, T, PMS_WORDS);
+    }
+    // ---- VLC ----
+    {
+      const uint32_t incl = wave_incl_scan(vl, lane);
+      const uint32_t T = v_pend + rdlane(incl, 63);
+      or_bits(L.vlc, v_pend + incl - vl, vb, vl);
+      wave_sync();
+      const uint32_t pos = vlc_windows(T, false);
+      v_pend = compact(L.vlc, pos, T, PVLC_WORDS);
+    }
+  }
+
+  // ---- final flush of both bit buffers: what remains is < 8 bits each ----
+  uint32_t ms_carry = 0, v_carry = 0;
+  if (!err) {
+    uint32_t pos = ms_windows(ms_pend, true);
+    ms_carry = compact(L.ms, pos, ms_pend, PMS_WORDS);
+    pos = vlc_windows(v_pend, true);
+    v_carry = compact(L.vlc, pos, v_pend, PVLC_WORDS);
+  }
+
+  err |= mel.err;
+  uint32_t total = 0, ms_len = ms_k;
+  if (!err && any_sig) {
+    // ---- ms_terminate (:517-534) ----
+    const uint32_t ms_tmp0 = rdfirst(L.ms[0]);
+    if (ms_carry) {
+      const uint32_t maxb = ms_ff ? 7u : 8u, tt = maxb - ms_carry;
+      const uint32_t tmp = ms_tmp0 | ((0xFFu & ((1u << tt) - 1u)) << ms_carry);
+      if (tmp != 0xFF) {
+        if (spilled) { if (ms_len >= ms_cap) err = 1; else if (lane == 0) ms_spill[ms_len] = (uint8_t)tmp; }
+        else if (lane == 0) outb[ms_len] = (uint8_t)tmp;
+        ms_len++;
+      }
+    } else if (ms_ff) ms_len--;
+    // ---- terminate_mel_vlc (:412-441) ----
+    if (mel.run > 0) mel_put(mel, L.mel, 1, 1, lane);
+    const uint32_t need = mel.lastff ? 7u : 8u, remaining = need - mel.nb;
+    const uint32_t mel_tmp = (mel.acc << remaining) & 0xFFu;
+    const uint32_t mel_mask = (0xFFu << remaining) & 0xFFu;
+    const uint32_t vlc_tmp = rdfirst(L.vlc[0]) & 0xFFu;
+    const uint32_t vlc_mask = v_carry ? (0xFFu >> (8 - v_carry)) : 0u;
+    if ((mel_mask | vlc_mask) != 0) {
+      if (mel.pos >= (uint32_t)MEL_CAP) err = 1;
+      else {
+        const uint32_t fuse = mel_tmp | vlc_tmp;
+        if (((((fuse ^ mel_tmp) & mel_mask) | ((fuse ^ vlc_tmp) & vlc_mask)) == 0) && fuse != 0xFF && v_pos > 1) {
+          if (lane == 0) L.mel[mel.pos] = (uint8_t)fuse;
+          mel.pos++;
+        } else {
+          if (v_pos >= (uint32_t)VLC_CAP) err = 1;
+          else {
+            if (lane == 0) { L.mel[mel.pos] = (uint8_t)mel_tmp; outb[OUT_CAP - 1 - v_pos] = (uint8_t)vlc_tmp; }
+            mel.pos++; v_pos++;
+          }
+        }
+      }
+    }
+    err |= mel.err;
+    total = ms_len + mel.pos + v_pos;
+  }
+  wave_sync();
+  __threadfence_block();
+
+  // ---- claim a 4-byte aligned slot in the compacted output: MagSgn | MEL | VLC (:1003-1014) ----
+  uint32_t off = 0;
+  if (err) total = 0;
+  if (total) {
+    if (lane == 0) off = atomicAdd(cursor, (total + 3u) & ~3u);
+    off = rdfirst(off);
+    if (off + ((total + 3u) & ~3u) > out_cap) { err = 1; total = 0; }
+  }
+  if (total) {
+    const uint32_t scup = mel.pos + v_pos;
+    const uint32_t tail = mel.pos + v_pos;
+    if (!spilled && total <= OUT_CAP) {
+      // close the gap: MEL and VLC bytes move down behind the MagSgn bytes (destination <= source)
+      for (uint32_t base = 0; base < tail; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t b = 0;
+        if (i < mel.pos) b = L.mel[i];
+        else if (i < tail) b = outb[OUT_CAP - v_pos + (i - mel.pos)];
+        wave_sync();
+        if (i < tail) {
+          if (i == tail - 1) b = scup >> 4;
+          else if (i == tail - 2) b = (b & 0xF0u) | (scup & 0xFu);
+          outb[ms_len + i] = (uint8_t)b;
+        }
+        wave_sync();
+      }
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out + off);
+      const uint32_t nw = (total + 3u) >> 2;
+      for (uint32_t i = lane; i < nw; i += 64) dst[i] = L.out[i];
+    } else {
+      uint8_t* dst = out + off;
+      for (uint32_t i = lane; i < total; i += 64) {
+        uint32_t b;
+        if (i < ms_len) b = spilled ? ms_spill[i] : outb[i];
+        else if (i < ms_len + mel.pos) b = L.mel[i - ms_len];
+        else b = outb[OUT_CAP - v_pos + (i - ms_len - mel.pos)];
+        if (i == total - 1) b = scup >> 4;
+        else if (i == total - 2) b = (b & 0xF0u) | (scup & 0xFu);
+        dst[i] = (uint8_t)b;
+      }
+    }
+  }
+  if (lane == 0) {
+    results[bi].offset = off; results[bi].length = total;
+    if (err) atomicOr(status, 1u);
+  }
+}
+
 }  // namespace
 
 extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
@@ -484,6 +937,8 @@ extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
   dim3 grid((n + WAVES - 1) / WAVES);
   hipLaunchKernelGGL(ht_encode_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                     (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+  hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
                      (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
