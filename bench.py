@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--workload", default="c3_8k_444_12b_irv97", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="2: the frame being encoded and the frame being decoded are issued on two HIP streams")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch one elementwise kernel of known traffic (PMC unit calibration)")
     args = ap.parse_args()
@@ -94,7 +96,14 @@ def main():
     else:
         my_tiles = (0, plan.num_tiles)
     my_share = my_tiles[1] / plan.num_tiles
-    enc = codec.Encoder(plan=plan, device=local_rank, tiles=my_tiles)
+    # The encode job and the decode job of a step are independent (a transcoder decodes frame n-1's
+    # codestream while frame n is being encoded), so they are issued on two HIP streams and the GPU
+    # overlaps the latency-bound block-decoder chains with the bandwidth-bound transforms.
+    s_enc = torch.cuda.Stream(dev) if args.streams == 2 else torch.cuda.current_stream(dev)
+    s_dec = torch.cuda.Stream(dev) if args.streams == 2 else torch.cuda.current_stream(dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s_enc):
+        enc = codec.Encoder(plan=plan, device=local_rank, tiles=my_tiles)
     t0 = time.perf_counter()
     if tiled:
         enc.run_device(d_img)
@@ -108,8 +117,11 @@ def main():
     else:
         cs = enc.encode(d_img)                   # also serves as the first warm-up + produces the decoder's input
     t_e2e_enc = time.perf_counter() - t0
-    dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s_dec):
+        dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles)
     d_out = torch.zeros_like(d_img) if tiled else torch.empty_like(d_img)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     dec.run_device(d_out)
     torch.cuda.synchronize(dev)
@@ -184,7 +196,12 @@ def main():
         "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels), td["dwt_ms"]),
         "dwt_inverse(level 1)": (8.0 * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
         "ht_encode": ((4.0 + c_rate) * ns, te["ht_ms"]),
-        "ht_decode": ((4.0 + c_rate) * ns, td["ht_ms"]),
+        # block decoder: prep reads the MEL/VLC share of the coded bytes and writes them flat; step 1
+        # reads that and writes one 4-byte record per quad (1 B/sample); step 2 reads the records and
+        # the MagSgn bytes and writes the 4-byte coefficients
+        "ht_dec_prep": (0.4 * c_rate * ns, td["ht_prep_ms"]),
+        "ht_dec_step1": ((0.2 * c_rate + 1.0) * ns, td["ht_step1_ms"]),
+        "ht_dec_step2": ((c_rate + 1.0 + 4.0) * ns, td["ht_step2_ms"]),
     }
     if ct or levels == 0:                        # otherwise the conversion is fused into the top DWT level
         kernels["convert_forward"] = (8.0 * ns, te["convert_ms"])
@@ -215,6 +232,7 @@ def main():
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
                    "tile": list(tile), "frames_per_step": 1 if tiled else world,
                    "sharding": ("%d tiles per GPU of one frame" % my_tiles[1]) if tiled else "one frame per GPU (replicas)",
+                   "hip_streams": args.streams,
                    "coded_bytes_per_sample": round(c_rate, 4),
                    "encode_ms": round(te["total_ms"], 4), "decode_ms": round(td["total_ms"], 4),
                    "encode_Msamples_s": round(ns / te["total_ms"] / 1e3, 1),
