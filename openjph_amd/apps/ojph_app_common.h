@@ -1,0 +1,141 @@
+// openjph_amd/apps/ojph_app_common.h -- small helpers shared by ojph_compress / ojph_expand:
+// command-line parsing in the style of the reference's CLI ("-name value", lists as {a,b},{c,d})
+// and PGM / PPM / raw-planar (.yuv / .raw) image files.  Own code; the option NAMES follow
+// src/apps/ojph_compress/ojph_compress.cpp:380-438 and src/apps/ojph_expand/ojph_expand.cpp.
+#ifndef OJPH_APP_COMMON_H
+#define OJPH_APP_COMMON_H
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct Args {
+  std::vector<std::string> v;
+  Args(int argc, char** argv) { for (int i = 1; i < argc; ++i) v.push_back(argv[i]); }
+  const char* get(const char* name) const {
+    for (size_t i = 0; i + 1 < v.size(); ++i) if (v[i] == name) return v[i + 1].c_str();
+    return nullptr;
+  }
+  bool has(const char* name) const { for (auto& s : v) if (s == name) return true; return false; }
+  static bool to_bool(const char* s) { return s && (!strcmp(s, "true") || !strcmp(s, "1")); }
+  // "{a,b}" or "{a,b},{c,d}" or "a,b" -> flat list of numbers
+  static std::vector<long> numbers(const char* s) {
+    std::vector<long> out;
+    if (!s) return out;
+    const char* p = s;
+    while (*p) {
+      if ((*p >= '0' && *p <= '9') || *p == '-') { char* e; out.push_back(strtol(p, &e, 10)); p = e; }
+      else ++p;
+    }
+    return out;
+  }
+  static std::vector<bool> bools(const char* s) {
+    std::vector<bool> out;
+    if (!s) return out;
+    std::string t(s); size_t pos = 0;
+    while (pos < t.size()) {
+      size_t e = t.find(',', pos); if (e == std::string::npos) e = t.size();
+      std::string w = t.substr(pos, e - pos);
+      out.push_back(w == "true" || w == "1");
+      pos = e + 1;
+    }
+    return out;
+  }
+};
+
+inline bool ends_with(const std::string& s, const char* suf) {
+  size_t n = strlen(suf);
+  if (s.size() < n) return false;
+  for (size_t i = 0; i < n; ++i) if (tolower(s[s.size() - n + i]) != suf[i]) return false;
+  return true;
+}
+
+struct Image {                       // planar int32 samples
+  unsigned width = 0, height = 0, num_comps = 0, bit_depth = 8; bool is_signed = false;
+  std::vector<int> data;
+  int* plane(unsigned c) { return data.data() + (size_t)c * width * height; }
+};
+
+inline int pnm_token(FILE* f) {
+  int c = fgetc(f);
+  for (;;) {
+    while (c == ' ' || c == '\n' || c == '\r' || c == '\t') c = fgetc(f);
+    if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+    break;
+  }
+  int v = 0;
+  while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = fgetc(f); }
+  return v;                              // consumes exactly one whitespace character after the number
+}
+
+inline void read_pnm(const char* name, Image& img) {
+  FILE* f = fopen(name, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + name);
+  char m0 = (char)fgetc(f), m1 = (char)fgetc(f);
+  if (m0 != 'P' || (m1 != '5' && m1 != '6')) { fclose(f); throw std::runtime_error("only binary PGM (P5) / PPM (P6) are supported"); }
+  img.num_comps = m1 == '6' ? 3 : 1;
+  img.width = (unsigned)pnm_token(f); img.height = (unsigned)pnm_token(f);
+  int maxv = pnm_token(f);
+  img.bit_depth = 1; while ((1 << img.bit_depth) <= maxv) ++img.bit_depth;
+  img.is_signed = false;
+  const size_t n = (size_t)img.width * img.height, bps = maxv > 255 ? 2 : 1;
+  std::vector<unsigned char> raw(n * img.num_comps * bps);
+  if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short PNM file"); }
+  fclose(f);
+  img.data.resize(n * img.num_comps);
+  for (size_t i = 0; i < n; ++i)
+    for (unsigned c = 0; c < img.num_comps; ++c) {
+      const unsigned char* p = raw.data() + (i * img.num_comps + c) * bps;
+      img.plane(c)[i] = bps == 2 ? (p[0] << 8) | p[1] : p[0];            // PNM is big-endian
+    }
+}
+
+inline void write_pnm(const char* name, Image& img) {
+  if (img.num_comps != 1 && img.num_comps != 3) throw std::runtime_error("PGM / PPM need 1 or 3 components");
+  FILE* f = fopen(name, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + name);
+  const int maxv = (1 << img.bit_depth) - 1; const size_t bps = maxv > 255 ? 2 : 1;
+  fprintf(f, "P%c\n%u %u\n%d\n", img.num_comps == 3 ? '6' : '5', img.width, img.height, maxv);
+  const size_t n = (size_t)img.width * img.height;
+  std::vector<unsigned char> raw(n * img.num_comps * bps);
+  for (size_t i = 0; i < n; ++i)
+    for (unsigned c = 0; c < img.num_comps; ++c) {
+      int v = img.plane(c)[i]; v = v < 0 ? 0 : (v > maxv ? maxv : v);
+      unsigned char* p = raw.data() + (i * img.num_comps + c) * bps;
+      if (bps == 2) { p[0] = (unsigned char)(v >> 8); p[1] = (unsigned char)v; } else p[0] = (unsigned char)v;
+    }
+  fwrite(raw.data(), 1, raw.size(), f);
+  fclose(f);
+}
+
+// planar raw (.yuv / .raw): 1 byte per sample up to 8 bits, else 2 bytes little-endian (as the reference's yuv reader)
+inline void read_raw(const char* name, Image& img) {
+  FILE* f = fopen(name, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + name);
+  const size_t n = (size_t)img.width * img.height * img.num_comps, bps = img.bit_depth > 8 ? 2 : 1;
+  std::vector<unsigned char> raw(n * bps);
+  if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short raw file"); }
+  fclose(f);
+  img.data.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    int v = bps == 2 ? raw[2 * i] | (raw[2 * i + 1] << 8) : raw[i];
+    if (img.is_signed) { const int sh = 32 - (int)img.bit_depth; v = (int)((unsigned)v << sh) >> sh; }
+    img.data[i] = v;
+  }
+}
+
+inline void write_raw(const char* name, Image& img) {
+  FILE* f = fopen(name, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + name);
+  const size_t n = (size_t)img.width * img.height * img.num_comps, bps = img.bit_depth > 8 ? 2 : 1;
+  std::vector<unsigned char> raw(n * bps);
+  for (size_t i = 0; i < n; ++i) {
+    const int v = img.data[i];
+    if (bps == 2) { raw[2 * i] = (unsigned char)v; raw[2 * i + 1] = (unsigned char)(v >> 8); } else raw[i] = (unsigned char)v;
+  }
+  fwrite(raw.data(), 1, raw.size(), f);
+  fclose(f);
+}
+#endif

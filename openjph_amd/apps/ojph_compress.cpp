@@ -1,0 +1,94 @@
+// openjph_amd/apps/ojph_compress.cpp -- command-line encoder on the GPU path, option-compatible
+// with the reference's ojph_compress for the options the GPU path implements
+// (src/apps/ojph_compress/ojph_compress.cpp:361-1226; defaults :495-510: irreversible, RPCL,
+// 5 decompositions, 64x64 blocks; PPM input switches the colour transform on, :754-757; .yuv /
+// .raw input needs -dims -num_comps -bit_depth [-signed] and is planar without colour transform,
+// :997-1021).  Prints "Elapsed time = ..." like the reference (:1220-1222).
+#include <chrono>
+#include "ojph_app_common.h"
+#include "../../include/ojph_gpu_codestream.h"
+
+static void usage() {
+  printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f]\n"
+         "  [-num_decomps n] [-block_size {w,h}] [-precincts {w,h}] [-prog_order LRCP|RLCP|RPCL|PCRL|CPRL]\n"
+         "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n]\n"
+         "  raw input: -dims {w,h} -num_comps n -bit_depth b [-signed true|false]\n");
+}
+
+int main(int argc, char** argv) {
+  Args a(argc, argv);
+  const char* in = a.get("-i"); const char* out = a.get("-o");
+  if (!in || !out) { usage(); return -1; }
+  try {
+    Image img;
+    const std::string ins(in);
+    const bool pnm = ends_with(ins, ".pgm") || ends_with(ins, ".ppm");
+    if (pnm) read_pnm(in, img);
+    else if (ends_with(ins, ".yuv") || ends_with(ins, ".raw")) {
+      auto dims = Args::numbers(a.get("-dims"));
+      if (dims.size() != 2 || !a.get("-num_comps") || !a.get("-bit_depth"))
+        throw std::runtime_error("raw input needs -dims {w,h} -num_comps n -bit_depth b");
+      img.width = (unsigned)dims[0]; img.height = (unsigned)dims[1];
+      img.num_comps = (unsigned)atoi(a.get("-num_comps"));
+      img.bit_depth = (unsigned)Args::numbers(a.get("-bit_depth"))[0];
+      auto sg = Args::bools(a.get("-signed")); img.is_signed = !sg.empty() && sg[0];
+      auto ds = Args::numbers(a.get("-downsamp"));
+      for (long d : ds) if (d != 1) throw std::runtime_error("-downsamp other than {1,1} is not available on the GPU path");
+      read_raw(in, img);
+    } else throw std::runtime_error("unknown input file extension (pgm, ppm, yuv, raw)");
+
+    const auto t0 = std::chrono::steady_clock::now();
+    ojph::codestream cs;
+    if (a.get("-device")) cs.set_device(atoi(a.get("-device")));
+    ojph::param_siz siz = cs.access_siz();
+    siz.set_image_extent(ojph::point(img.width, img.height));
+    siz.set_num_components(img.num_comps);
+    for (unsigned c = 0; c < img.num_comps; ++c) siz.set_component(c, ojph::point(1, 1), img.bit_depth, img.is_signed);
+    siz.set_image_offset(ojph::point(0, 0));
+    auto ts = Args::numbers(a.get("-tile_size"));
+    siz.set_tile_size(ts.size() == 2 ? ojph::size((unsigned)ts[0], (unsigned)ts[1]) : ojph::size(img.width, img.height));
+    siz.set_tile_offset(ojph::point(0, 0));
+
+    ojph::param_cod cod = cs.access_cod();
+    cod.set_num_decomposition(a.get("-num_decomps") ? (unsigned)atoi(a.get("-num_decomps")) : 5);
+    auto bs = Args::numbers(a.get("-block_size"));
+    cod.set_block_dims(bs.size() == 2 ? (unsigned)bs[0] : 64, bs.size() == 2 ? (unsigned)bs[1] : 64);
+    auto pr = Args::numbers(a.get("-precincts"));
+    if (pr.size() >= 2) {
+      std::vector<ojph::size> ps;
+      for (size_t i = 0; i + 1 < pr.size(); i += 2) ps.push_back(ojph::size((unsigned)pr[i], (unsigned)pr[i + 1]));
+      cod.set_precinct_size((int)ps.size(), ps.data());
+    }
+    cod.set_progression_order(a.get("-prog_order") ? a.get("-prog_order") : "RPCL");
+    const bool reversible = Args::to_bool(a.get("-reversible"));
+    cod.set_reversible(reversible);
+    bool ct = pnm && img.num_comps == 3;                       // PPM turns the colour transform on by default
+    if (a.get("-colour_trans")) ct = Args::to_bool(a.get("-colour_trans"));
+    cod.set_color_transform(ct);
+    if (!reversible && a.get("-qstep")) cs.access_qcd().set_irrev_quant((float)atof(a.get("-qstep")));
+    if (a.get("-tlm_marker")) cs.request_tlm_marker(Args::to_bool(a.get("-tlm_marker")));
+    if (a.get("-profile")) cs.set_profile(a.get("-profile"));
+    cs.set_planar(!ct);
+
+    ojph::j2c_outfile file;
+    file.open(out);
+    cs.write_headers(&file);
+    ojph::ui32 next = 0;
+    ojph::line_buf* line = cs.exchange(nullptr, next);
+    std::vector<unsigned> row(img.num_comps, 0);
+    while (line) {                                   // the codestream says which component it wants next
+      memcpy(line->i32, img.plane(next) + (size_t)row[next] * img.width, img.width * sizeof(int));
+      row[next]++;
+      line = cs.exchange(line, next);
+    }
+    cs.flush();
+    cs.close();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("Elapsed time = %f\n", dt);
+  } catch (const std::exception& e) {
+    const char* w = e.what();
+    if (w && strncmp(w, "ojph error", 10) != 0) printf("%s\n", w);
+    return -1;
+  }
+  return 0;
+}

@@ -19,6 +19,11 @@ def needs_build():
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith("_")]
     deps.append(os.path.join(HERE, "..", "include", "ojphgpu.h"))
+    deps.append(os.path.join(HERE, "..", "include", "ojph_gpu_codestream.h"))
+    deps += [os.path.join(HERE, "apps", f) for f in os.listdir(os.path.join(HERE, "apps")) if f.endswith((".cpp", ".h"))]
+    if not all(os.path.exists(x) for x in (os.path.join(HERE, "libopenjph_gpu.so"), os.path.join(HERE, "apps", "ojph_compress"),
+                                           os.path.join(HERE, "apps", "ojph_expand"))):
+        return True
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -45,7 +50,26 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode(errors="replace"))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     subprocess.check_call(cmd)
+    build_facade(verbose)
     return OUT
+
+
+FACADE = os.path.join(HERE, "libopenjph_gpu.so")
+APPS = os.path.join(HERE, "apps")
+
+
+def build_facade(verbose=False):
+    """libopenjph_gpu.so (the ojph::codestream-compatible C++ facade over the C ABI) and the two
+    command-line tools, all linked against libojphgpu.so with an $ORIGIN rpath."""
+    cmds = [[HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+             os.path.join(CSRC, "ojph_facade.cpp"), "-o", FACADE, "-L" + HERE, "-lojphgpu", "-Wl,-rpath,$ORIGIN"]]
+    for app in ("ojph_compress", "ojph_expand"):
+        cmds.append([HIPCC, "-O2", "-std=c++17", "-Wall", os.path.join(APPS, app + ".cpp"), "-o", os.path.join(APPS, app),
+                     "-L" + HERE, "-lopenjph_gpu", "-lojphgpu", "-Wl,-rpath,$ORIGIN/.."])
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
 
 
 if __name__ == "__main__":

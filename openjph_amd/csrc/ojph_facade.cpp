@@ -1,0 +1,390 @@
+// openjph_amd/csrc/ojph_facade.cpp -- implementation of include/ojph_gpu_codestream.h: the
+// ojph::codestream-compatible C++ facade, built on the C ABI of libojphgpu.so.
+//
+// Behaviour mirrored from the reference (cited per function); the mechanism is different: the
+// frame is collected in one pinned host buffer (exchange() hands out pointers straight into it, so
+// the application writes its samples in place and nothing is copied), flush() runs the batched GPU
+// encoder and writes the codestream, read_headers() slurps the codestream and parses it on the
+// host, the first pull() runs the batched GPU decoder into the frame buffer and every pull()
+// returns a pointer to one of its rows.
+#include "../../include/ojph_gpu_codestream.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/ojphgpu.h"
+
+namespace ojph {
+
+namespace {
+
+// OJPH_ERROR of the reference (ojph_message.cpp:156-171): message to stderr, then
+// std::runtime_error("ojph error")
+[[noreturn]] void ojph_error(ui32 code, const char* fmt, ...)
+{
+  char msg[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(msg, sizeof(msg), fmt, ap); va_end(ap);
+  fprintf(stderr, "ojph error 0x%08X: %s\n", code, msg);
+  throw std::runtime_error("ojph error");
+}
+
+const char* const PROG_NAMES[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
+
+ui32 log2_exact(ui32 v) { ui32 l = 0; while ((1u << l) < v) ++l; return l; }
+
+}  // namespace
+
+// ---- files ---------------------------------------------------------------------------------------
+void j2c_outfile::open(const char* filename)
+{
+  fh = fopen(filename, "wb");
+  if (!fh) ojph_error(0x00060001, "failed to open %s for writing", filename);        // ojph_file.cpp:63
+}
+size_t j2c_outfile::write(const void* ptr, size_t size) { return fwrite(ptr, 1, size, fh); }
+si64 j2c_outfile::tell() { return (si64)ftello(fh); }
+void j2c_outfile::flush() { fflush(fh); }
+void j2c_outfile::close() { if (fh) fclose(fh); fh = nullptr; }
+
+void mem_outfile::open(size_t initial_size, bool) { buf.clear(); buf.reserve(initial_size); pos = 0; is_open = true; }
+size_t mem_outfile::write(const void* ptr, size_t size)
+{
+  if (pos + size > buf.size()) buf.resize(pos + size);
+  memcpy(buf.data() + pos, ptr, size);
+  pos += size;
+  return size;
+}
+int mem_outfile::seek(si64 offset, enum outfile_base::seek origin)
+{
+  si64 np = origin == OJPH_SEEK_SET ? offset : origin == OJPH_SEEK_CUR ? (si64)pos + offset : (si64)buf.size() + offset;
+  if (np < 0 || (size_t)np > buf.size()) return -1;
+  pos = (size_t)np;
+  return 0;
+}
+void mem_outfile::write_to_file(const char* file_name) const
+{
+  FILE* f = fopen(file_name, "wb");
+  if (!f) ojph_error(0x00060003, "failed to open %s for writing", file_name);
+  if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); ojph_error(0x00060004, "failed writing to %s", file_name); }
+  fclose(f);
+}
+
+void j2c_infile::open(const char* filename)
+{
+  fh = fopen(filename, "rb");
+  if (!fh) ojph_error(0x00060002, "failed to open %s for reading", filename);        // ojph_file.cpp:208
+}
+size_t j2c_infile::read(void* ptr, size_t size) { return fread(ptr, 1, size, fh); }
+int j2c_infile::seek(si64 offset, enum infile_base::seek origin) { return fseeko(fh, (off_t)offset, origin); }
+si64 j2c_infile::tell() { return (si64)ftello(fh); }
+void j2c_infile::close() { if (fh) fclose(fh); fh = nullptr; }
+
+size_t mem_infile::read(void* ptr, size_t size)
+{
+  size_t avail = (size_t)(data + sz - cur);
+  size_t n = size < avail ? size : avail;
+  memcpy(ptr, cur, n); cur += n;
+  return n;
+}
+int mem_infile::seek(si64 offset, enum infile_base::seek origin)
+{
+  const ui8* np = origin == OJPH_SEEK_SET ? data + offset : origin == OJPH_SEEK_CUR ? cur + offset : data + sz + offset;
+  if (np < data || np > data + sz) return -1;
+  cur = np;
+  return 0;
+}
+
+// ---- state ---------------------------------------------------------------------------------------
+namespace local {
+
+struct comp_info { point ds; ui32 bit_depth; bool is_signed; bool set; };
+
+struct codestream_state {
+  ojphgpu_params p;
+  std::vector<comp_info> comps;
+  point image_offset, tile_offset;
+  int planar = -1;                    // -1: not chosen (ojph_codestream_local.cpp:89)
+  bool resilient = false;
+  bool headers_written = false, headers_read = false, decoded = false;
+  std::string profile;
+  int device = 0;
+  outfile_base* outfile = nullptr;
+  infile_base* infile = nullptr;
+  ojphgpu_plan* plan = nullptr;
+  ojphgpu_encoder* enc = nullptr;
+  ojphgpu_decoder* dec = nullptr;
+  si32* frame = nullptr; bool frame_pinned = false; size_t frame_elems = 0;
+  std::vector<ui8> stream;            // the whole codestream (decode)
+  std::vector<line_buf> lines;
+  ui32 cur_comp = 0, cur_line = 0;
+  bool exhausted = false;
+
+  codestream_state() { reset_params(); }
+  void reset_params()
+  {
+    memset(&p, 0, sizeof(p));
+    p.reversible = 0; p.num_decomps = 5; p.block_w = 64; p.block_h = 64;      // param_cod defaults (ojph_params_local.h:560-575)
+    p.prog_order = 2; p.qstep = -1.0f;                                      // RPCL; qstep chosen from the bit depth
+    comps.clear(); image_offset = point(0, 0); tile_offset = point(0, 0);
+  }
+  void release()
+  {
+    if (enc) { ojphgpu_encoder_destroy(enc); enc = nullptr; }
+    if (dec) { ojphgpu_decoder_destroy(dec); dec = nullptr; }
+    if (plan) { ojphgpu_plan_destroy(plan); plan = nullptr; }
+    if (frame) { if (frame_pinned) (void)hipHostFree(frame); else free(frame); frame = nullptr; }
+    frame_elems = 0; stream.clear(); lines.clear();
+    headers_written = headers_read = decoded = false; exhausted = false; cur_comp = cur_line = 0;
+    outfile = nullptr; infile = nullptr;
+  }
+  void alloc_frame()
+  {
+    frame_elems = (size_t)p.width * p.height * p.num_comps;
+    void* ptr = nullptr;
+    if (hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
+    else { (void)hipGetLastError(); frame = (si32*)malloc(frame_elems * sizeof(si32)); frame_pinned = false; }
+    if (!frame) ojph_error(0x00030F01, "cannot allocate the %zu-sample frame buffer", frame_elems);
+    lines.assign(p.num_comps, line_buf());
+    for (ui32 c = 0; c < p.num_comps; ++c) {
+      lines[c].size = p.width; lines[c].pre_size = 0; lines[c].flags = line_buf::LFT_32BIT | line_buf::LFT_INTEGER;
+    }
+  }
+  si32* row(ui32 comp, ui32 line) { return frame + ((size_t)comp * p.height + line) * p.width; }
+};
+
+}  // namespace local
+
+using local::codestream_state;
+
+// ---- param_siz -----------------------------------------------------------------------------------
+void param_siz::set_image_extent(point extent) { state->p.width = extent.x; state->p.height = extent.y; }
+void param_siz::set_tile_size(size s) { state->p.tile_w = s.w; state->p.tile_h = s.h; }
+void param_siz::set_image_offset(point offset) { state->image_offset = offset; }
+void param_siz::set_tile_offset(point offset) { state->tile_offset = offset; }
+void param_siz::set_num_components(ui32 num_comps)
+{
+  state->p.num_comps = num_comps;
+  state->comps.assign(num_comps, local::comp_info{ point(1, 1), 8, false, false });
+}
+void param_siz::set_component(ui32 comp_num, const point& downsampling, ui32 bit_depth, bool is_signed)
+{
+  if (comp_num >= state->comps.size())
+    ojph_error(0x00050001, "component number %u is larger than the number of components", comp_num);   // ojph_params.cpp:110
+  state->comps[comp_num] = local::comp_info{ downsampling, bit_depth, is_signed, true };
+}
+point param_siz::get_image_extent() const { return point(state->p.width + state->image_offset.x, state->p.height + state->image_offset.y); }
+point param_siz::get_image_offset() const { return state->image_offset; }
+size param_siz::get_tile_size() const { return size(state->p.tile_w ? state->p.tile_w : state->p.width, state->p.tile_h ? state->p.tile_h : state->p.height); }
+point param_siz::get_tile_offset() const { return state->tile_offset; }
+ui32 param_siz::get_num_components() const { return state->p.num_comps; }
+ui32 param_siz::get_bit_depth(ui32 c) const { return c < state->comps.size() ? state->comps[c].bit_depth : state->p.bit_depth; }
+bool param_siz::is_signed(ui32 c) const { return c < state->comps.size() ? state->comps[c].is_signed : state->p.is_signed != 0; }
+point param_siz::get_downsampling(ui32 c) const { return c < state->comps.size() ? state->comps[c].ds : point(1, 1); }
+ui32 param_siz::get_recon_width(ui32) const { return state->p.width; }
+ui32 param_siz::get_recon_height(ui32) const { return state->p.height; }
+
+// ---- param_cod / param_qcd -----------------------------------------------------------------------
+void param_cod::set_num_decomposition(ui32 n)
+{
+  if (n > 32) ojph_error(0x00050002, "maximum number of decompositions cannot exceed 32");           // ojph_params.cpp:254
+  state->p.num_decomps = n;
+}
+void param_cod::set_block_dims(ui32 width, ui32 height)
+{
+  const ui32 lw = log2_exact(width), lh = log2_exact(height);
+  if (width == 0 || width != (1u << lw) || height == 0 || height != (1u << lh) || lw < 2 || lh < 2 || lw + lh > 12)
+    ojph_error(0x00050011, "incorrect code block dimensions");                                       // ojph_params.cpp:265
+  state->p.block_w = width; state->p.block_h = height;
+}
+void param_cod::set_precinct_size(int num_levels, size* precinct_size)
+{
+  if (num_levels == 0 || precinct_size == nullptr) { state->p.precinct_w = state->p.precinct_h = 0; return; }
+  for (int i = 1; i < num_levels; ++i)
+    if (precinct_size[i].w != precinct_size[0].w || precinct_size[i].h != precinct_size[0].h)
+      ojph_error(0x00050F21, "the GPU path supports one precinct size for all resolutions");
+  state->p.precinct_w = precinct_size[0].w; state->p.precinct_h = precinct_size[0].h;
+}
+void param_cod::set_progression_order(const char* name)
+{
+  for (ui32 i = 0; i < 5; ++i)
+    if (strncasecmp(name, PROG_NAMES[i], 4) == 0 && strlen(name) == 4) { state->p.prog_order = i; return; }
+  ojph_error(0x00050031, "unknown progression order");                                                // ojph_params.cpp:318
+}
+void param_cod::set_color_transform(bool ct) { state->p.color_transform = ct; }
+void param_cod::set_reversible(bool rev) { state->p.reversible = rev; }
+ui32 param_cod::get_num_decompositions() const { return state->p.num_decomps; }
+size param_cod::get_block_dims() const { return size(state->p.block_w, state->p.block_h); }
+size param_cod::get_log_block_dims() const { return size(log2_exact(state->p.block_w), log2_exact(state->p.block_h)); }
+bool param_cod::is_reversible() const { return state->p.reversible != 0; }
+size param_cod::get_precinct_size(ui32) const
+{ return size(state->p.precinct_w ? state->p.precinct_w : 32768, state->p.precinct_h ? state->p.precinct_h : 32768); }
+size param_cod::get_log_precinct_size(ui32 l) const { size s = get_precinct_size(l); return size(log2_exact(s.w), log2_exact(s.h)); }
+int param_cod::get_progression_order() const { return (int)state->p.prog_order; }
+const char* param_cod::get_progression_order_as_string() const { return PROG_NAMES[state->p.prog_order % 5]; }
+bool param_cod::is_using_color_transform() const { return state->p.color_transform != 0; }
+
+void param_qcd::set_irrev_quant(float delta) { state->p.qstep = delta; }
+
+void comment_exchange::set_string(const char* str) { data = str; len = (ui16)strlen(str); Rcom = 1; }
+void comment_exchange::set_data(const char* d, ui16 l) { data = d; len = l; Rcom = 0; }
+
+// ---- codestream ----------------------------------------------------------------------------------
+codestream::codestream() : state(new codestream_state()) {}
+codestream::~codestream() { state->release(); delete state; }
+void codestream::restart() { state->release(); state->reset_params(); state->planar = -1; state->resilient = false; state->profile.clear(); }
+
+void codestream::set_planar(bool planar) { state->planar = planar ? 1 : 0; }
+bool codestream::is_planar() const { return state->planar == 1; }
+void codestream::set_profile(const char* s)
+{
+  if (strcmp(s, "IMF") != 0 && strcmp(s, "BROADCAST") != 0) ojph_error(0x000300A1, "unknown or unsupported profile");   // ojph_codestream_local.cpp:1103
+  state->profile = s;
+}
+void codestream::set_tilepart_divisions(bool at_resolutions, bool at_components)
+{
+  if (at_resolutions || at_components) ojph_error(0x00030F11, "tile-part divisions are not available on the GPU path");
+}
+void codestream::request_tlm_marker(bool needed) { state->p.tlm = needed; }
+bool codestream::is_tlm_requested() { return state->p.tlm != 0; }
+void codestream::set_device(int device) { state->device = device; }
+void codestream::enable_resilience() { state->resilient = true; }
+param_siz codestream::access_siz() { return param_siz(state); }
+param_cod codestream::access_cod() { return param_cod(state); }
+param_qcd codestream::access_qcd() { return param_qcd(state); }
+
+// (ojph_codestream_local.cpp:556-712) validation of the parameter set; the marker segments themselves
+// are written by flush() together with the tile-parts
+void codestream::write_headers(outfile_base* file, const comment_exchange* comments, ui32 num_comments)
+{
+  codestream_state& S = *state;
+  if (S.headers_written) ojph_error(0x00030F02, "write_headers called twice");
+  ojphgpu_params& p = S.p;
+  if (p.num_comps == 0 || p.width == 0 || p.height == 0) ojph_error(0x00040001, "image extent / components have not been set");
+  if (S.image_offset.x || S.image_offset.y || S.tile_offset.x || S.tile_offset.y)
+    ojph_error(0x00030F03, "image / tile offsets are not available on the GPU path");
+  for (ui32 c = 0; c < p.num_comps; ++c) {
+    const local::comp_info& ci = S.comps[c];
+    if (!ci.set) ojph_error(0x00040002, "component %u has not been configured", c);
+    if (ci.ds.x != 1 || ci.ds.y != 1) ojph_error(0x00030F04, "component subsampling is not available on the GPU path");
+    if (ci.bit_depth != S.comps[0].bit_depth || ci.is_signed != S.comps[0].is_signed)
+      ojph_error(0x00030F05, "components of different bit depth / signedness are not available on the GPU path");
+  }
+  p.bit_depth = S.comps[0].bit_depth; p.is_signed = S.comps[0].is_signed;
+  if (p.tile_w >= p.width && p.tile_h >= p.height) p.tile_w = p.tile_h = 0;          // one tile
+  if (p.color_transform && p.num_comps < 3)
+    ojph_error(0x00040013, "color transform can only be employed when the image has 3 or more color components");   // ojph_params.cpp:560
+  if (S.planar == -1) S.planar = p.color_transform ? 0 : 1;        // not chosen: interleaved lines when the colour transform needs all components of a line
+  if (S.planar == 1 && p.color_transform)
+    ojph_error(0x00030021, "the planar interface option cannot be used when colour transform is employed");          // :630
+  if (comments != nullptr && num_comments != 0)
+    ojph_error(0x00030F06, "user COM markers are not available on the GPU path");
+  int rc = ojphgpu_plan_create(&p, &S.plan);
+  if (rc) ojph_error(0x00030F07, "parameters rejected by the GPU path (status %d)", rc);
+  rc = ojphgpu_encoder_create(S.plan, S.device, nullptr, &S.enc);
+  if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
+  S.alloc_frame();
+  S.outfile = file;
+  S.headers_written = true;
+  S.cur_comp = 0; S.cur_line = 0; S.exhausted = false;
+}
+
+// (ojph_codestream_local.cpp:1176-1224) same protocol: NULL in -> first line out; after the last line
+// NULL comes back and next_component is 0
+line_buf* codestream::exchange(line_buf* line, ui32& next_component)
+{
+  codestream_state& S = *state;
+  if (!S.headers_written) ojph_error(0x00030F09, "exchange called before write_headers");
+  if (line) {                                   // the samples are already in place (the line points into the frame)
+    if (S.exhausted) { next_component = 0; return nullptr; }
+    if (S.planar) {
+      if (++S.cur_line >= S.p.height) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) { S.exhausted = true; next_component = 0; return nullptr; } }
+    } else {
+      if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.p.height) { S.exhausted = true; next_component = 0; return nullptr; } }
+    }
+  }
+  next_component = S.cur_comp;
+  line_buf* l = &S.lines[S.cur_comp];
+  l->i32 = S.row(S.cur_comp, S.cur_line);
+  return l;
+}
+
+// (ojph_codestream_local.cpp:1148-1165)
+void codestream::flush()
+{
+  codestream_state& S = *state;
+  if (!S.headers_written) ojph_error(0x00030F0A, "flush called before write_headers");
+  std::vector<ui8> out(S.frame_elems * 2 + (1u << 20));
+  size_t len = 0;
+  int rc = ojphgpu_encode(S.enc, S.frame, out.data(), out.size(), &len);
+  if (rc == OJPHGPU_E_OVERFLOW && len > out.size()) { out.resize(len); rc = ojphgpu_encode(S.enc, S.frame, out.data(), out.size(), &len); }
+  if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
+  if (S.outfile->write(out.data(), len) != len) ojph_error(0x00030071, "Error writing to file");      // :1163
+}
+
+// (ojph_codestream_local.cpp:769-910 + read() :912-1146)
+void codestream::read_headers(infile_base* file)
+{
+  codestream_state& S = *state;
+  S.infile = file;
+  S.stream.clear();
+  ui8 tmp[65536];
+  for (;;) { size_t n = file->read(tmp, sizeof(tmp)); S.stream.insert(S.stream.end(), tmp, tmp + n); if (n < sizeof(tmp)) break; }
+  int rc = ojphgpu_t2_parse(S.stream.data(), S.stream.size(), S.resilient ? 1 : 0, &S.plan);
+  if (rc == OJPHGPU_E_CODESTREAM) ojph_error(0x00030051, "error reading the codestream headers / tile-parts");
+  if (rc) ojph_error(0x00030F0C, "codestream not supported by the GPU path (status %d)", rc);
+  ojphgpu_plan_params(S.plan, &S.p);
+  S.comps.assign(S.p.num_comps, local::comp_info{ point(1, 1), S.p.bit_depth, S.p.is_signed != 0, true });
+  if (S.planar == -1) S.planar = S.p.color_transform ? 0 : 1;                                         // :879
+  S.headers_read = true;
+}
+
+void codestream::restrict_input_resolution(ui32 skipped_res_for_data, ui32 skipped_res_for_recon)
+{
+  if (skipped_res_for_data || skipped_res_for_recon)
+    ojph_error(0x00030F0D, "reduced-resolution decoding is not available on the GPU path");
+}
+
+void codestream::create()
+{
+  codestream_state& S = *state;
+  if (!S.headers_read) ojph_error(0x00030F0E, "create called before read_headers");
+  int rc = ojphgpu_decoder_create(S.plan, S.device, nullptr, &S.dec);
+  if (rc) ojph_error(0x00030F0F, "cannot create the GPU decoder (status %d): no GPU?", rc);
+  S.alloc_frame();
+  S.cur_comp = 0; S.cur_line = 0; S.exhausted = false; S.decoded = false;
+}
+
+// (ojph_codestream_local.cpp:1227-1273)
+line_buf* codestream::pull(ui32& comp_num)
+{
+  codestream_state& S = *state;
+  if (!S.dec) ojph_error(0x00030F10, "pull called before create");
+  if (!S.decoded) {
+    int rc = ojphgpu_decode(S.dec, S.stream.data(), S.stream.size(), S.frame);
+    if (rc == OJPHGPU_E_BLOCK) { if (!S.resilient) ojph_error(0x000300A1, "Error decoding a codeblock"); }   // ojph_codeblock.cpp:214-224
+    else if (rc) ojph_error(0x00030F12, "GPU decode failed (status %d)", rc);
+    S.decoded = true;
+  }
+  if (S.exhausted) { comp_num = 0; return nullptr; }
+  comp_num = S.cur_comp;
+  line_buf* l = &S.lines[S.cur_comp];
+  l->i32 = S.row(S.cur_comp, S.cur_line);
+  if (S.planar) {
+    if (++S.cur_line >= S.p.height) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) S.exhausted = true; }
+  } else {
+    if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.p.height) S.exhausted = true; }
+  }
+  return l;
+}
+
+void codestream::close()
+{
+  codestream_state& S = *state;
+  if (S.infile) S.infile->close();
+  if (S.outfile) S.outfile->close();
+  S.infile = nullptr; S.outfile = nullptr;
+}
+
+}  // namespace ojph
