@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
   const Geo g = make_geo(d, strip_x, lane);
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
   const Geo g = make_geo(d, strip_x, lane);

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data, uint32_t* __restrict__ aux)
 {
   __shared__ uint32_t s_buf[WAVES][68];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const uint32_t bi = blockIdx.x * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 {
   __shared__ uint32_t s_ring[WAVES][RING_WORDS];
   __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const uint32_t bi = blockIdx.x * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];

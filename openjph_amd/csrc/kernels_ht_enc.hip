@@ -156,7 +156,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ WaveLds s_wave[WAVES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const uint32_t bi = blockIdx.x * WAVES + wave;
   const bool mine = bi < n && blocks[bi].w > NARROW_MAX_W;               // narrow blocks belong to ht_encode_kernel
   if (!__syncthreads_or(mine ? 1 : 0)) return;
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const uint32_t bi = blockIdx.x * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
