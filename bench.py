@@ -38,6 +38,8 @@ WORKLOADS = {
     "c2_4k_rgb_8b_rev53": (3840, 2160, 3, 8, True, True, -1.0, (0, 0)),
     "c4_16k_gray_16b_rev53_tiled": (16384, 16384, 1, 16, True, False, -1.0, (1024, 1024)),
     "c1_256_gray_8b_rev53": (256, 256, 1, 8, True, False, -1.0, (0, 0)),
+    # BASELINE config #5: independent 4K 10-bit frames coded as a batch (--frames B per step and per GPU)
+    "c5_4k_444_10b_irv97_batch": (3840, 2160, 3, 10, False, False, -1.0, (0, 0)),
 }
 
 
@@ -54,6 +56,8 @@ def main():
     ap.add_argument("--workload", default="c3_8k_444_12b_irv97", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=0,
+                    help="independent frames coded per step as one batch (default 1; 8 for the c5 batch workload)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: the frame being encoded and the frame being decoded are issued on two HIP streams")
     ap.add_argument("--calibrate", action="store_true",
@@ -78,8 +82,12 @@ def main():
     from tests.synth import synth_image
 
     w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[args.workload]
-    nsamples = w * h * nc
-    img = synth_image(nc, h, w, bd, seed=1234 + rank)
+    frames = args.frames if args.frames > 0 else (8 if "batch" in args.workload else 1)
+    nsamples = w * h * nc * frames
+    if frames > 1:
+        img = np.stack([synth_image(nc, h, w, bd, seed=1234 + rank * frames + f) for f in range(frames)])
+    else:
+        img = synth_image(nc, h, w, bd, seed=1234 + rank)
     d_img = torch.from_numpy(img).to(dev)
     params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
     from openjph_amd.plan import Plan
@@ -87,7 +95,7 @@ def main():
     plan = Plan(params)
     # single-tile frames do not shard (replicas only): every rank codes its own frame (weak scaling).
     # tiled frames shard by contiguous runs of tiles: all ranks share one frame (strong scaling).
-    tiled = plan.num_tiles > 1 and world > 1
+    tiled = plan.num_tiles > 1 and world > 1 and frames == 1
     if tiled:
         img = synth_image(nc, h, w, bd, seed=1234)
         d_img = torch.from_numpy(img).to(dev)
@@ -103,7 +111,7 @@ def main():
     s_dec = torch.cuda.Stream(dev) if args.streams == 2 else torch.cuda.current_stream(dev)
     torch.cuda.synchronize(dev)
     with torch.cuda.stream(s_enc):
-        enc = codec.Encoder(plan=plan, device=local_rank, tiles=my_tiles)
+        enc = codec.Encoder(plan=plan, device=local_rank, tiles=my_tiles if frames == 1 else None, frames=frames)
     t0 = time.perf_counter()
     if tiled:
         enc.run_device(d_img)
@@ -119,7 +127,7 @@ def main():
     t_e2e_enc = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     with torch.cuda.stream(s_dec):
-        dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles)
+        dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles if frames == 1 else None)
     d_out = torch.zeros_like(d_img) if tiled else torch.empty_like(d_img)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -230,7 +238,7 @@ def main():
         "config": {"workload": args.workload, "width": w, "height": h, "components": nc, "bit_depth": bd,
                    "wavelet": "5/3 reversible" if rev else "9/7 irreversible", "qstep": qstep if not rev else None,
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
-                   "tile": list(tile), "frames_per_step": 1 if tiled else world,
+                   "tile": list(tile), "frames_per_step": frames * (1 if tiled else world),
                    "sharding": ("%d tiles per GPU of one frame" % my_tiles[1]) if tiled else "one frame per GPU (replicas)",
                    "hip_streams": args.streams,
                    "coded_bytes_per_sample": round(c_rate, 4),
@@ -245,7 +253,7 @@ def main():
     }
 
     if rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(img, bd, rev, ct, qstep, tile, args.cpu_reps)
+        result["cpu_baseline"] = cpu_baseline(img if frames == 1 else img[0], bd, rev, ct, qstep, tile, args.cpu_reps)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

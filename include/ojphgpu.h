@@ -255,6 +255,14 @@ int  ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* st
 /* D2H + host Tier-2 of the range: its tile-parts only (see ojphgpu_t2_write_tiles) */
 int  ojphgpu_encoder_finish_tiles(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len,
                                   uint32_t* tile_part_len);
+/* An encoder for a BATCH of num_frames independent frames of the plan's shape (video: BASELINE
+ * config "512 independent 4K frames"): one set of launches codes all of them, which is what fills
+ * the GPU when a single frame does not.  d_image / h_image then hold the frames back to back
+ * ([frame][comp][y][x]); every frame gets its own codestream from ojphgpu_encoder_finish_frame. */
+int  ojphgpu_encoder_create_batch(const ojphgpu_plan* plan, int device, void* stream,
+                                  uint32_t num_frames, ojphgpu_encoder** out);
+int  ojphgpu_encoder_finish_frame(ojphgpu_encoder* enc, uint32_t frame, uint8_t* h_out, size_t cap,
+                                  size_t* out_len);
 /* device part only: d_image (int32 planes, resident in HBM) -> coded block bytes in HBM */
 int  ojphgpu_encoder_run_device(ojphgpu_encoder* enc, const int32_t* d_image);
 /* D2H of block bytes + lengths, then host Tier-2 -> complete codestream */
@@ -270,6 +278,13 @@ int  ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void* stream, 
 /* decodes only tiles [tile_first, tile_first + tile_count): writes their region of d_image */
 int  ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream,
                                   uint32_t tile_first, uint32_t tile_count, ojphgpu_decoder** out);
+/* a decoder for a batch: plans[f] = ojphgpu_t2_parse of frame f's codestream; all frames must have
+ * the same geometry.  Upload every frame's bytes with ojphgpu_decoder_upload_frame, then
+ * ojphgpu_decoder_run_device writes d_image = [frame][comp][y][x]. */
+int  ojphgpu_decoder_create_batch(const ojphgpu_plan* const* plans, uint32_t num_frames, int device,
+                                  void* stream, ojphgpu_decoder** out);
+int  ojphgpu_decoder_upload_frame(ojphgpu_decoder* dec, uint32_t frame, const uint8_t* h_codestream,
+                                  size_t len);
 void ojphgpu_decoder_destroy(ojphgpu_decoder* dec);
 /* H2D of the codestream bytes */
 int  ojphgpu_decoder_upload(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len);

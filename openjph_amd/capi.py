@@ -138,6 +138,10 @@ SIGNATURES = {
     "ojphgpu_encoder_finish_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "ojphgpu_decoder_create_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p)]),
+    "ojphgpu_encoder_create_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ojphgpu_encoder_finish_frame": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ojphgpu_decoder_create_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ojphgpu_decoder_upload_frame": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "ojphgpu_encoder_destroy": (None, [C.c_void_p]),
     "ojphgpu_encoder_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_encoder_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

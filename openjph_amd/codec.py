@@ -41,20 +41,27 @@ def to_device(arr: np.ndarray, device=0):
 class Encoder:
     """Whole-frame encoder for one frame shape / parameter set (ojphgpu_encoder)."""
 
-    def __init__(self, params: Params = None, device=0, plan: Plan = None, tiles=None, **kw):
-        """tiles=(first, count) restricts the encoder to a run of tiles (multi-GPU sharding)."""
+    def __init__(self, params: Params = None, device=0, plan: Plan = None, tiles=None, frames=1, **kw):
+        """tiles=(first, count) restricts the encoder to a run of tiles (multi-GPU sharding);
+        frames=B makes it code a batch of B independent frames per run ([B,C,H,W] input)."""
         torch = _torch()
         self.device = device
         self.plan = plan if plan is not None else Plan(params if params is not None else make_params(**kw))
         self.tiles = (0, self.plan.num_tiles) if tiles is None else (int(tiles[0]), int(tiles[1]))
+        self.frames = int(frames)
         self._lib = capi.lib()
         self._h = C.c_void_p()
         with torch.cuda.device(device):
-            check(self._lib.ojphgpu_encoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
-                                                         self.tiles[0], self.tiles[1], C.byref(self._h)),
-                  "encoder_create")
+            if self.frames > 1:
+                assert tiles is None, "a batch encoder codes whole frames"
+                check(self._lib.ojphgpu_encoder_create_batch(self.plan.handle, device, _stream_ptr(torch, device),
+                                                             self.frames, C.byref(self._h)), "encoder_create_batch")
+            else:
+                check(self._lib.ojphgpu_encoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
+                                                             self.tiles[0], self.tiles[1], C.byref(self._h)),
+                      "encoder_create")
         p = self.plan.params
-        self.shape = (p.num_comps, p.height, p.width)
+        self.shape = (p.num_comps, p.height, p.width) if self.frames == 1 else (self.frames, p.num_comps, p.height, p.width)
 
     def __del__(self):
         try:
@@ -75,16 +82,17 @@ class Encoder:
         check(self._lib.ojphgpu_encoder_coded_bytes(self._h, C.byref(n)), "encoder_coded_bytes")
         return int(n.value)
 
-    def finish(self) -> bytes:
+    def finish(self, frame=0) -> bytes:
+        """codestream of frame `frame` of the last run"""
         p = self.plan.params
         cap = int(p.width) * int(p.height) * int(p.num_comps) * 3 + (1 << 20)
         out = np.empty(cap, np.uint8)
         n = C.c_size_t()
-        rc = self._lib.ojphgpu_encoder_finish(self._h, out.ctypes.data, cap, C.byref(n))
+        rc = self._lib.ojphgpu_encoder_finish_frame(self._h, frame, out.ctypes.data, cap, C.byref(n))
         if rc == capi.E_OVERFLOW and n.value > cap:
             cap = int(n.value)
             out = np.empty(cap, np.uint8)
-            rc = self._lib.ojphgpu_encoder_finish(self._h, out.ctypes.data, cap, C.byref(n))
+            rc = self._lib.ojphgpu_encoder_finish_frame(self._h, frame, out.ctypes.data, cap, C.byref(n))
         check(rc, "encoder_finish")
         return out[:n.value].tobytes()
 
@@ -103,12 +111,15 @@ class Encoder:
         check(rc, "encoder_finish_tiles")
         return out[:n.value].tobytes(), lens[:self.tiles[1]].copy()
 
-    def encode(self, image) -> bytes:
-        """image: numpy int32 [C,H,W] (host) or torch int32 tensor on the device."""
+    def encode(self, image):
+        """image: numpy int32 [C,H,W] (host) or torch int32 tensor on the device -> codestream bytes;
+        for a batch encoder [B,C,H,W] -> list of B codestreams."""
         torch = _torch()
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
         self.run_device(image)
+        if self.frames > 1:
+            return [self.finish(f) for f in range(self.frames)]
         return self.finish()
 
     def timing(self):
@@ -122,22 +133,33 @@ class Encoder:
 class Decoder:
     """Whole-frame decoder bound to one parsed codestream layout (ojphgpu_decoder)."""
 
-    def __init__(self, codestream: bytes, device=0, resilient=False, tiles=None):
-        """tiles=(first, count) restricts the decoder to a run of tiles (multi-GPU sharding)."""
+    def __init__(self, codestream, device=0, resilient=False, tiles=None):
+        """codestream: bytes, or a list of codestreams of same-shaped frames (batch decoder, output
+        [B,C,H,W]).  tiles=(first, count) restricts the decoder to a run of tiles (multi-GPU sharding)."""
         torch = _torch()
         self.device = device
         self.resilient = resilient
-        self.plan = parse_codestream(codestream, resilient)
+        streams = list(codestream) if isinstance(codestream, (list, tuple)) else [codestream]
+        self.frames = len(streams)
+        self.plans = [parse_codestream(cs, resilient) for cs in streams]
+        self.plan = self.plans[0]
         self.tiles = (0, self.plan.num_tiles) if tiles is None else (int(tiles[0]), int(tiles[1]))
         self._lib = capi.lib()
         self._h = C.c_void_p()
         with torch.cuda.device(device):
-            check(self._lib.ojphgpu_decoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
-                                                         self.tiles[0], self.tiles[1], C.byref(self._h)),
-                  "decoder_create")
+            if self.frames > 1:
+                assert tiles is None, "a batch decoder decodes whole frames"
+                arr = (C.c_void_p * self.frames)(*[pl.handle.value if hasattr(pl.handle, "value") else pl.handle for pl in self.plans])
+                check(self._lib.ojphgpu_decoder_create_batch(arr, self.frames, device, _stream_ptr(torch, device),
+                                                             C.byref(self._h)), "decoder_create_batch")
+            else:
+                check(self._lib.ojphgpu_decoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
+                                                             self.tiles[0], self.tiles[1], C.byref(self._h)),
+                      "decoder_create")
         p = self.plan.params
-        self.shape = (p.num_comps, p.height, p.width)
-        self.upload(codestream)
+        self.shape = (p.num_comps, p.height, p.width) if self.frames == 1 else (self.frames, p.num_comps, p.height, p.width)
+        for f, cs in enumerate(streams):
+            self.upload(cs, f)
 
     def __del__(self):
         try:
@@ -147,9 +169,9 @@ class Decoder:
         except Exception:
             pass
 
-    def upload(self, codestream: bytes):
+    def upload(self, codestream: bytes, frame=0):
         buf = np.frombuffer(codestream, dtype=np.uint8)
-        check(self._lib.ojphgpu_decoder_upload(self._h, buf.ctypes.data, len(codestream)), "decoder_upload")
+        check(self._lib.ojphgpu_decoder_upload_frame(self._h, frame, buf.ctypes.data, len(codestream)), "decoder_upload")
         _torch().cuda.synchronize(self.device)   # the host buffer may go away after this call
 
     def run_device(self, d_image=None):

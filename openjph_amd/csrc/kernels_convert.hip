@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= d0.w || y >= d0.h) return;
   const size_t plane = (size_t)p.img_w * p.img_h;
-  const size_t src = (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;
+  const size_t src = (size_t)d0.reserved * nc * plane + (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;   // reserved = frame of a batch
   if (p.color) {
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     int r = image[src], g = image[plane + src], b = image[2 * plane + src];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= d0.w || y >= d0.h) return;
   const size_t plane = (size_t)p.img_w * p.img_h;
-  const size_t dst = (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;
+  const size_t dst = (size_t)d0.reserved * nc * plane + (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;   // reserved = frame of a batch
   if (p.color) {
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];

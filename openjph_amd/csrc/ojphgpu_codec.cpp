@@ -118,6 +118,52 @@ void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
   }
 }
 
+// Frame batches: the same plan applied to `nframes` independent frames in one set of launches
+// (config C5: a batch of independent 4K frames).  Frame f lives f * arena_elems further in the arena
+// and f * (comps * width * height) further in the image buffer; descriptors are simply replicated.
+void replicate_levels(std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches, uint32_t nframes, uint64_t arena_elems)
+{
+  if (nframes <= 1) return;
+  std::vector<ojphgpu_dwt_desc> out; std::vector<LevelBatch> nb;
+  for (const LevelBatch& b : batches) {
+    LevelBatch n{ (uint32_t)out.size(), b.count * nframes, b.max_w, b.max_h };
+    for (uint32_t f = 0; f < nframes; ++f)
+      for (uint32_t i = 0; i < b.count; ++i) {
+        ojphgpu_dwt_desc d = descs[b.first + i];
+        const uint64_t o = (uint64_t)f * arena_elems;
+        d.src_off += o; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
+        out.push_back(d);
+      }
+    nb.push_back(n);
+  }
+  descs.swap(out); batches.swap(nb);
+}
+
+void replicate_image_levels(std::vector<ojphgpu_dwt_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
+{
+  if (nframes <= 1 || descs.empty()) return;
+  const size_t n = descs.size();
+  for (uint32_t f = 1; f < nframes; ++f)
+    for (size_t i = 0; i < n; ++i) {
+      ojphgpu_dwt_desc d = descs[i];
+      const uint64_t o = (uint64_t)f * arena_elems;
+      d.src_off += (uint64_t)f * frame_elems; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
+      descs.push_back(d);
+    }
+}
+
+void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems)
+{
+  if (nframes <= 1 || descs.empty()) return;
+  const size_t n = descs.size();
+  for (uint32_t f = 1; f < nframes; ++f)
+    for (size_t i = 0; i < n; ++i) {
+      ojphgpu_convert_desc d = descs[i];
+      d.plane_off += (uint64_t)f * arena_elems; d.reserved = f;          // frame index: selects the image planes
+      descs.push_back(d);
+    }
+}
+
 // plan-order indices of the code-blocks that belong to the tile range
 std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
 {
@@ -172,7 +218,10 @@ struct ojphgpu_encoder {
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
   TileRange tiles{ 0, 0 };
-  std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes
+  uint32_t nframes = 1;                            // frames coded per run_device (batch)
+  bool fetched = false;                            // results / bytes of the last run are on the host
+  uint64_t nbytes = 0;
+  std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes (per frame)
   std::vector<ojphgpu_cb_result> h_results;
   std::vector<uint8_t> h_out;
   Timer timer;
@@ -195,10 +244,26 @@ extern "C" int ojphgpu_encoder_create(const ojphgpu_plan* plan, int device, void
   return ojphgpu_encoder_create_tiles(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), out);
 }
 
+static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first, uint32_t tile_count,
+                          uint32_t nframes, ojphgpu_encoder** out);
+
 extern "C" int ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
                                              uint32_t tile_count, ojphgpu_encoder** out)
 {
-  if (!plan || !out) return OJPHGPU_E_INVALID;
+  return encoder_create(plan, device, stream, tile_first, tile_count, 1, out);
+}
+
+extern "C" int ojphgpu_encoder_create_batch(const ojphgpu_plan* plan, int device, void* stream, uint32_t num_frames,
+                                             ojphgpu_encoder** out)
+{
+  if (!plan) return OJPHGPU_E_INVALID;
+  return encoder_create(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), num_frames, out);
+}
+
+static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first, uint32_t tile_count,
+                          uint32_t nframes, ojphgpu_encoder** out)
+{
+  if (!plan || !out || nframes == 0) return OJPHGPU_E_INVALID;
   *out = nullptr;
   if ((uint64_t)tile_first + tile_count > plan->plan.tiles.size()) return OJPHGPU_E_INVALID;
   HIPCHK(hipSetDevice(device));
@@ -210,12 +275,17 @@ extern "C" int ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device
   auto bail = [&](int rc) { ojphgpu_encoder_destroy(e); return rc; };
 
   e->tiles = TileRange{ tile_first, tile_count };
+  e->nframes = nframes;
   const TileRange tr = e->tiles;
+  const uint64_t frame_elems = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, e->batches);
   std::vector<ojphgpu_dwt_desc> idd;
   if (!e->batches.empty()) build_image_level_descs(P, tr, dd, e->batches.front(), idd);
   e->fused_convert = !idd.empty();
+  replicate_levels(dd, e->batches, nframes, P.arena_elems);
+  replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
+  replicate_converts(cd, nframes, P.arena_elems);
   e->block_ids = blocks_of_tiles(P, tr);
   std::vector<ojphgpu_cb_desc> bd(e->block_ids.size());
   uint64_t scratch_bytes = 0, samples = 0;
@@ -229,16 +299,27 @@ extern "C" int ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
   }
+  if (nframes > 1) {                                      // replicate the block descriptors, frame-major
+    const size_t nb = bd.size();
+    bd.resize(nb * nframes);
+    for (uint32_t f = 1; f < nframes; ++f)
+      for (size_t i = 0; i < nb; ++i) {
+        ojphgpu_cb_desc d = bd[i];
+        d.coef_off += (uint64_t)f * P.arena_elems; d.data_off += (uint64_t)f * scratch_bytes;
+        bd[f * nb + i] = d;
+      }
+    scratch_bytes *= nframes; samples *= nframes;
+  }
   uint64_t cap = std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
   cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
   e->out_cap = (uint32_t)cap;
 
-  if (e->arena.alloc(P.arena_elems * 4) || e->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
+  if (e->arena.alloc(P.arena_elems * 4 * nframes) || e->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       e->img_descs.alloc(idd.size() * sizeof(dd[0])) || e->cb_descs.alloc(bd.size() * sizeof(bd[0])) || e->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       e->scratch.alloc(scratch_bytes) || e->out.alloc(cap) ||
       e->results.alloc(bd.size() * sizeof(ojphgpu_cb_result)) || e->counters.alloc(16))
     return bail(OJPHGPU_E_NOMEM);
-  if (hipMemset(e->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (hipMemset(e->arena.p, 0, P.arena_elems * 4 * nframes) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(e->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!idd.empty() && hipMemcpy(e->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!bd.empty() && hipMemcpy(e->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
@@ -258,7 +339,7 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   e->timer.mark(0, s);
   int rc = OJPHGPU_OK;
   if (!e->fused_convert)
-    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count,
+    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
                                  e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
   if (rc) return rc;
   e->timer.mark(1, s);
@@ -274,12 +355,12 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
     e->timer.mark_level(s);
   }
   e->timer.mark(2, s);
-  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)e->block_ids.size(), e->arena.p,
+  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)e->block_ids.size() * e->nframes, e->arena.p,
                          (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap, (ojphgpu_cb_result*)e->results.p,
                          (uint32_t*)e->counters.p, (uint32_t*)e->counters.p + 1);
   if (rc) return rc;
   e->timer.mark(3, s);
-  e->ran = true;
+  e->ran = true; e->fetched = false;
   return OJPHGPU_OK;
 }
 
@@ -293,22 +374,27 @@ extern "C" int ojphgpu_encoder_coded_bytes(ojphgpu_encoder* e, uint64_t* bytes)
   return c[1] ? OJPHGPU_E_OVERFLOW : OJPHGPU_OK;
 }
 
-// D2H of the block bytes + lengths of the last run; fills the plan-order coded-block table
-static int encoder_fetch(ojphgpu_encoder* e, std::vector<ojphgpu_coded_block>& cb)
+// D2H of the block bytes + lengths of the last run (once per run); fills the plan-order coded-block
+// table of frame `frame`
+static int encoder_fetch(ojphgpu_encoder* e, uint32_t frame, std::vector<ojphgpu_coded_block>& cb)
 {
   const Plan& P = *e->P;
-  uint64_t nbytes = 0;
-  int rc = ojphgpu_encoder_coded_bytes(e, &nbytes);
-  if (rc) return rc;
-  e->h_out.resize((size_t)nbytes + 16);
-  if (!e->h_results.empty())
-    HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, e->h_results.size() * sizeof(ojphgpu_cb_result),
-                          hipMemcpyDeviceToHost, e->stream));
-  if (nbytes) HIPCHK(hipMemcpyAsync(e->h_out.data(), e->out.p, (size_t)nbytes, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (frame >= e->nframes) return OJPHGPU_E_INVALID;
+  if (!e->fetched) {
+    int rc = ojphgpu_encoder_coded_bytes(e, &e->nbytes);
+    if (rc) return rc;
+    e->h_out.resize((size_t)e->nbytes + 16);
+    if (!e->h_results.empty())
+      HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, e->h_results.size() * sizeof(ojphgpu_cb_result),
+                            hipMemcpyDeviceToHost, e->stream));
+    if (e->nbytes) HIPCHK(hipMemcpyAsync(e->h_out.data(), e->out.p, (size_t)e->nbytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->fetched = true;
+  }
   cb.assign(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
-  for (size_t i = 0; i < e->block_ids.size(); ++i) {
-    const ojphgpu_cb_result& r = e->h_results[i];
+  const size_t nb = e->block_ids.size();
+  for (size_t i = 0; i < nb; ++i) {
+    const ojphgpu_cb_result& r = e->h_results[(size_t)frame * nb + i];
     ojphgpu_coded_block& c = cb[e->block_ids[i]];
     c.offset = r.offset; c.len1 = r.length; c.len2 = 0;
     c.missing_msbs = r.length ? P.bands[P.blocks[e->block_ids[i]].band].K_max - 1 : 0;      // ojph_codeblock.cpp:148
@@ -320,9 +406,15 @@ static int encoder_fetch(ojphgpu_encoder* e, std::vector<ojphgpu_coded_block>& c
 extern "C" int ojphgpu_encoder_finish(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len)
 {
   if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
+  return ojphgpu_encoder_finish_frame(e, 0, h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encoder_finish_frame(ojphgpu_encoder* e, uint32_t frame, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
   if (e->tiles.first != 0 || e->tiles.count != e->P->tiles.size()) return OJPHGPU_E_INVALID;   // use _finish_tiles
   std::vector<ojphgpu_coded_block> cb;
-  int rc = encoder_fetch(e, cb);
+  int rc = encoder_fetch(e, frame, cb);
   if (rc) return rc;
   return ojphgpu_t2_write(e->handle, e->h_out.data(), cb.data(), h_out, cap, out_len);
 }
@@ -332,7 +424,7 @@ extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, 
 {
   if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
   std::vector<ojphgpu_coded_block> cb;
-  int rc = encoder_fetch(e, cb);
+  int rc = encoder_fetch(e, 0, cb);
   if (rc) return rc;
   return ojphgpu_t2_write_tiles(e->handle, e->h_out.data(), cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
                                 out_len, tile_part_len);
@@ -342,7 +434,7 @@ extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_
 {
   if (!e || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
-  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4;
+  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4 * e->nframes;
   if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes, hipMemcpyHostToDevice, e->stream));
   int rc = ojphgpu_encoder_run_device(e, (const int32_t*)e->image.p);
@@ -373,7 +465,9 @@ struct ojphgpu_decoder {
   hipEvent_t ht_ev[2] = { nullptr, nullptr };      // between prep | step 1 | step 2
   bool fused_convert = false;
   TileRange tiles{ 0, 0 };
-  uint32_t nblocks = 0;                            // code-blocks of the tile range
+  uint32_t nframes = 1;
+  std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
+  uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
   size_t data_first = 0, data_len = 0;              // byte range of the codestream holding this range's block data
@@ -398,14 +492,41 @@ extern "C" int ojphgpu_decoder_create(const ojphgpu_plan* plan, int device, void
   return ojphgpu_decoder_create_tiles(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), out);
 }
 
+static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, int device, void* stream, uint32_t tile_first,
+                          uint32_t tile_count, ojphgpu_decoder** out);
+
 extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
                                              uint32_t tile_count, ojphgpu_decoder** out)
 {
-  if (!plan || !out) return OJPHGPU_E_INVALID;
+  return decoder_create(&plan, 1, device, stream, tile_first, tile_count, out);
+}
+
+extern "C" int ojphgpu_decoder_create_batch(const ojphgpu_plan* const* plans, uint32_t num_frames, int device, void* stream,
+                                             ojphgpu_decoder** out)
+{
+  if (!plans || num_frames == 0 || !plans[0]) return OJPHGPU_E_INVALID;
+  return decoder_create(plans, num_frames, device, stream, 0, (uint32_t)plans[0]->plan.tiles.size(), out);
+}
+
+static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, int device, void* stream, uint32_t tile_first,
+                          uint32_t tile_count, ojphgpu_decoder** out)
+{
+  if (!plans || !plans[0] || !out || nframes == 0) return OJPHGPU_E_INVALID;
   *out = nullptr;
+  const ojphgpu_plan* plan = plans[0];
   const Plan& P = plan->plan;
   if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
-  if (P.coded.size() != P.blocks.size()) return OJPHGPU_E_INVALID;    // plan must come from ojphgpu_t2_parse
+  for (uint32_t f = 0; f < nframes; ++f) {                              // every frame of a batch has the same geometry
+    if (!plans[f]) return OJPHGPU_E_INVALID;
+    const Plan& Q = plans[f]->plan;
+    if (Q.coded.size() != Q.blocks.size()) return OJPHGPU_E_INVALID;    // plans must come from ojphgpu_t2_parse
+    if (Q.blocks.size() != P.blocks.size() || Q.arena_elems != P.arena_elems || Q.p.width != P.p.width ||
+        Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
+        Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||
+        Q.p.color_transform != P.p.color_transform || Q.p.tile_w != P.p.tile_w || Q.p.tile_h != P.p.tile_h ||
+        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h || Q.p.qstep != P.p.qstep)
+      return OJPHGPU_E_INVALID;
+  }
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   ojphgpu_decoder* d = new (std::nothrow) ojphgpu_decoder();
@@ -414,21 +535,30 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
   auto bail = [&](int rc) { ojphgpu_decoder_destroy(d); return rc; };
 
   d->tiles = TileRange{ tile_first, tile_count };
+  d->nframes = nframes;
   const TileRange tr = d->tiles;
+  const uint64_t frame_elems = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, d->batches);
   std::vector<ojphgpu_dwt_desc> idd;
   if (!d->batches.empty()) build_image_level_descs(P, tr, dd, d->batches.front(), idd);
   d->fused_convert = !idd.empty();
+  replicate_levels(dd, d->batches, nframes, P.arena_elems);
+  replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
+  replicate_converts(cd, nframes, P.arena_elems);
   const std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
-  d->nblocks = (uint32_t)ids.size();
-  std::vector<ojphgpu_cb_desc> bd(ids.size());
-  uint64_t max_off = 0, min_off = ~0ull, nquads = 0, naux = 0;
+  d->nblocks = (uint32_t)(ids.size() * nframes);
+  std::vector<ojphgpu_cb_desc> bd(ids.size() * nframes);
+  uint64_t nquads = 0, naux = 0, data_total = 0;
+  d->f_first.assign(nframes, 0); d->f_len.assign(nframes, 0); d->f_base.assign(nframes, 0);
+  for (uint32_t f = 0; f < nframes; ++f) {
+  const Plan& Q = plans[f]->plan;
+  uint64_t max_off = 0, min_off = ~0ull;
   for (size_t i = 0; i < ids.size(); ++i) {
-    const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = P.coded[ids[i]];
-    ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
-    o.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
+    const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];
+    ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i]; memset(&o, 0, sizeof(o));
+    o.coef_off = (uint64_t)f * P.arena_elems + B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max; o.reversible = (uint8_t)P.p.reversible;
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
@@ -444,17 +574,23 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
   }
   if (min_off > max_off) min_off = max_off = 0;
   min_off &= ~(uint64_t)15;                                             // only this byte range of the codestream is uploaded
-  for (ojphgpu_cb_desc& o : bd) if (o.len1 + o.len2) o.data_off -= min_off; else o.data_off = 0;
-  d->data_first = (size_t)min_off;
-  d->data_len = (size_t)(max_off - min_off);
+  for (size_t i = 0; i < ids.size(); ++i) {
+    ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i];
+    if (o.len1 + o.len2) o.data_off = o.data_off - min_off + data_total; else o.data_off = 0;
+  }
+  d->f_first[f] = (size_t)min_off; d->f_len[f] = (size_t)(max_off - min_off); d->f_base[f] = (size_t)data_total;
+  data_total += ((max_off - min_off) + 63) & ~(uint64_t)63;
+  }
+  d->data_first = d->f_first[0];
+  d->data_len = (size_t)data_total;
   if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   for (auto& e : d->ht_ev) if (hipEventCreate(&e) != hipSuccess) return bail(OJPHGPU_E_HIP);
-  if (d->arena.alloc(P.arena_elems * 4) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
+  if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
     return bail(OJPHGPU_E_NOMEM);
-  if (hipMemset(d->arena.p, 0, P.arena_elems * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  if (hipMemset(d->arena.p, 0, P.arena_elems * 4 * nframes) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(d->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!idd.empty() && hipMemcpy(d->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!bd.empty() && hipMemcpy(d->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
@@ -466,8 +602,15 @@ extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device
 
 extern "C" int ojphgpu_decoder_upload(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len)
 {
-  if (!d || !h_codestream || len < d->data_first + d->data_len) return OJPHGPU_E_INVALID;
-  if (d->data_len) HIPCHK(hipMemcpyAsync(d->data.p, h_codestream + d->data_first, d->data_len, hipMemcpyHostToDevice, d->stream));
+  return ojphgpu_decoder_upload_frame(d, 0, h_codestream, len);
+}
+
+extern "C" int ojphgpu_decoder_upload_frame(ojphgpu_decoder* d, uint32_t frame, const uint8_t* h_codestream, size_t len)
+{
+  if (!d || !h_codestream || frame >= d->nframes || len < d->f_first[frame] + d->f_len[frame]) return OJPHGPU_E_INVALID;
+  if (d->f_len[frame])
+    HIPCHK(hipMemcpyAsync((uint8_t*)d->data.p + d->f_base[frame], h_codestream + d->f_first[frame], d->f_len[frame],
+                          hipMemcpyHostToDevice, d->stream));
   return OJPHGPU_OK;
 }
 
@@ -502,7 +645,7 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   }
   d->timer.mark(2, s);
   if (!d->fused_convert)
-    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count,
+    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
                                  d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
   if (rc) return rc;
   d->timer.mark(3, s);
@@ -526,6 +669,7 @@ extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, s
 {
   if (!d || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
+  if (d->nframes != 1) return OJPHGPU_E_INVALID;           // batches: upload_frame + run_device
   const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4;
   if (!d->image.p && d->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   int rc = ojphgpu_decoder_upload(d, h_codestream, len);

@@ -96,3 +96,32 @@ def test_8k_irreversible_properties():
     assert mse < 4.0 and pae <= 16, (mse, pae)
     bps = len(cs) / img.size
     assert 0.3 < bps < 1.5, bps
+
+
+@pytest.mark.parametrize("kw", [dict(nc=3, h=120, w=200, bd=8, color_transform=True),
+                                dict(nc=1, h=150, w=130, bd=12, reversible=False, qstep=0.002),
+                                dict(nc=1, h=200, w=200, bd=10, tile=(128, 128))],
+                         ids=["rgb-rct", "gray-irv", "tiled"])
+def test_frame_batch_equals_frame_by_frame(kw):
+    """BASELINE config #5 in small: a batch of independent frames through one set of launches gives
+    the same codestreams / images as coding them one by one (and as the oracle)."""
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.plan import Plan, make_params
+    from tests import cpu_pipeline as cp
+    nc, h, w, bd, signed, c = _split(kw)
+    B = 3
+    frames = np.stack([synth_image(nc, h, w, bd, seed=40 + f) for f in range(B)])
+    plan = Plan(make_params(w, h, nc, bit_depth=bd, **c))
+    enc = codec.Encoder(plan=plan, frames=B)
+    streams = enc.encode(frames)
+    assert len(streams) == B
+    for f in range(B):
+        want, *_ = cp.encode(frames[f], bit_depth=bd, **c)
+        assert streams[f] == want, "frame %d" % f
+    dec = codec.Decoder(streams)
+    out = dec.run_device().cpu().numpy()
+    assert dec.failed_blocks() == 0
+    for f in range(B):
+        want_dec, _ = cp.decode(streams[f])
+        assert np.array_equal(out[f], want_dec), "frame %d" % f
