@@ -9,7 +9,7 @@
 // so that a program written against the reference compiles against this header and links
 // libopenjph_gpu.so instead.  The implementation is new: where the reference streams lines
 // through a tile / resolution / sub-band / code-block object tree, this facade collects the frame
-// in a pinned host buffer and hands it to the batched GPU path at flush() (encode) or on the
+// in one host buffer and hands it to the batched GPU path at flush() (encode) or on the
 // first pull() (decode).  Errors are reported as the reference reports OJPH_ERROR:
 // std::runtime_error("ojph error") after the message went to stderr.
 //

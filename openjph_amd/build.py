@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % src)
         if verbose and out:
             sys.stderr.write(out.decode(errors="replace"))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
     subprocess.check_call(cmd)
     build_facade(verbose)
     return OUT

@@ -84,8 +84,7 @@ class Encoder:
 
     def finish(self, frame=0) -> bytes:
         """codestream of frame `frame` of the last run"""
-        p = self.plan.params
-        cap = int(p.width) * int(p.height) * int(p.num_comps) * 3 + (1 << 20)
+        cap = self.coded_bytes() // self.frames * 2 + 64 * self.plan.num_blocks + (1 << 20)
         out = np.empty(cap, np.uint8)
         n = C.c_size_t()
         rc = self._lib.ojphgpu_encoder_finish_frame(self._h, frame, out.ctypes.data, cap, C.byref(n))

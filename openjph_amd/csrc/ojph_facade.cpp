@@ -12,7 +12,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 
 #include "../../include/ojphgpu.h"
@@ -142,8 +144,11 @@ struct codestream_state {
   void alloc_frame()
   {
     frame_elems = (size_t)p.width * p.height * p.num_comps;
+    // one frame per codestream object: pinning 400 MB costs more than the pageable copy it would
+    // speed up (measured on the MI355X host: both ~57 GB/s), so the frame is plain memory; set
+    // OJPH_GPU_PIN=1 for long-lived objects that restart() and reuse their buffers
     void* ptr = nullptr;
-    if (hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
+    if (getenv("OJPH_GPU_PIN") && hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
     else { (void)hipGetLastError(); frame = (si32*)malloc(frame_elems * sizeof(si32)); frame_pinned = false; }
     if (!frame) ojph_error(0x00030F01, "cannot allocate the %zu-sample frame buffer", frame_elems);
     lines.assign(p.num_comps, line_buf());
@@ -315,12 +320,13 @@ void codestream::flush()
 {
   codestream_state& S = *state;
   if (!S.headers_written) ojph_error(0x00030F0A, "flush called before write_headers");
-  std::vector<ui8> out(S.frame_elems * 2 + (1u << 20));
   size_t len = 0;
-  int rc = ojphgpu_encode(S.enc, S.frame, out.data(), out.size(), &len);
-  if (rc == OJPHGPU_E_OVERFLOW && len > out.size()) { out.resize(len); rc = ojphgpu_encode(S.enc, S.frame, out.data(), out.size(), &len); }
+  int rc = ojphgpu_encode(S.enc, S.frame, nullptr, 0, &len);            // runs the GPU path; reports the codestream size
+  if (rc != OJPHGPU_E_OVERFLOW && rc != OJPHGPU_OK) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
+  std::unique_ptr<ui8[]> out(new ui8[len + 16]);
+  rc = ojphgpu_encoder_finish(S.enc, out.get(), len + 16, &len);         // host Tier-2 only (block bytes are already here)
   if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
-  if (S.outfile->write(out.data(), len) != len) ojph_error(0x00030071, "Error writing to file");      // :1163
+  if (S.outfile->write(out.get(), len) != len) ojph_error(0x00030071, "Error writing to file");        // :1163
 }
 
 // (ojph_codestream_local.cpp:769-910 + read() :912-1146)

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace ojphgpu {
@@ -230,6 +231,11 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
   *out_len = total;
   if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
 
+  // markers and packet headers are laid down serially; the code-block bodies -- nearly all of the
+  // bytes -- are queued as copy jobs and moved by a few host threads (at GPU kernel speeds a
+  // single-threaded memcpy of the 90 MB of an 8K frame would dominate the whole encode)
+  struct Job { uint8_t* dst; const uint8_t* src; size_t n; };
+  std::vector<Job> jobs;
   uint8_t* w = out;
   auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
   auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
@@ -252,12 +258,31 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
           for (uint32_t x = 0; x < q.w; ++x) {
             const ojphgpu_coded_block& b = cb[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
             size_t n = (size_t)b.len1 + b.len2;
-            if (n) { memcpy(w, data + b.offset, n); w += n; }
+            if (n) { jobs.push_back(Job{ w, data + b.offset, n }); w += n; }
           }
       }
     }
   }
-  return (size_t)(w - out) == total ? OJPHGPU_OK : OJPHGPU_E_INVALID;
+  if ((size_t)(w - out) != total) return OJPHGPU_E_INVALID;
+  size_t body = 0;
+  for (const Job& j : jobs) body += j.n;
+  unsigned nthreads = std::thread::hardware_concurrency();
+  nthreads = std::min<unsigned>(nthreads ? nthreads : 1, 16);
+  if (body < (4u << 20) || jobs.size() < 64) nthreads = 1;
+  auto run = [&jobs](size_t a, size_t b) { for (size_t i = a; i < b; ++i) memcpy(jobs[i].dst, jobs[i].src, jobs[i].n); };
+  if (nthreads <= 1) run(0, jobs.size());
+  else {
+    std::vector<std::thread> th;
+    size_t start = 0, acc = 0; unsigned made = 0;
+    const size_t share = body / nthreads + 1;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+      acc += jobs[i].n;
+      if (acc >= share && made + 1 < nthreads) { th.emplace_back(run, start, i + 1); start = i + 1; acc = 0; ++made; }
+    }
+    run(start, jobs.size());
+    for (std::thread& x : th) x.join();
+  }
+  return OJPHGPU_OK;
 }
 
 }  // namespace

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -53,6 +56,25 @@ struct DeviceBuf {
   void* p = nullptr; size_t n = 0;
   int alloc(size_t bytes) { n = bytes; return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
   void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+// pinned host staging buffer (grows, never shrinks): D2H lands here at PCIe speed and without the
+// page-fault cost of a fresh pageable allocation
+struct HostBuf {
+  uint8_t* p = nullptr; size_t cap = 0; bool pinned = false; unsigned uses = 0;
+  // the first run of a codec object gets plain memory (pinning costs more than one pageable copy
+  // saves); an object that is run again is a long-lived one and gets a pinned buffer
+  int reserve(size_t bytes) {
+    const bool want_pin = ++uses >= 2;
+    if (bytes <= cap && (pinned || !want_pin)) return 0;
+    release();
+    void* q = nullptr;
+    if (want_pin && hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess) { p = (uint8_t*)q; pinned = true; }
+    else { (void)hipGetLastError(); p = (uint8_t*)malloc(bytes); pinned = false; }
+    cap = p ? bytes : 0;
+    return p ? 0 : -1;
+  }
+  void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
 };
 
 struct LevelBatch { uint32_t first, count, max_w, max_h; };
@@ -223,7 +245,7 @@ struct ojphgpu_encoder {
   uint64_t nbytes = 0;
   std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes (per frame)
   std::vector<ojphgpu_cb_result> h_results;
-  std::vector<uint8_t> h_out;
+  HostBuf h_out, h_res;
   Timer timer;
   bool ran = false;
 };
@@ -234,6 +256,7 @@ extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
   (void)hipSetDevice(e->device);
   for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->img_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
                         &e->results, &e->counters }) b->release();
+  e->h_out.release(); e->h_res.release();
   e->timer.destroy();
   delete e;
 }
@@ -383,12 +406,13 @@ static int encoder_fetch(ojphgpu_encoder* e, uint32_t frame, std::vector<ojphgpu
   if (!e->fetched) {
     int rc = ojphgpu_encoder_coded_bytes(e, &e->nbytes);
     if (rc) return rc;
-    e->h_out.resize((size_t)e->nbytes + 16);
-    if (!e->h_results.empty())
-      HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, e->h_results.size() * sizeof(ojphgpu_cb_result),
-                            hipMemcpyDeviceToHost, e->stream));
-    if (e->nbytes) HIPCHK(hipMemcpyAsync(e->h_out.data(), e->out.p, (size_t)e->nbytes, hipMemcpyDeviceToHost, e->stream));
+    const size_t rbytes = e->h_results.size() * sizeof(ojphgpu_cb_result);
+    if (e->h_out.reserve(std::max<size_t>((size_t)e->nbytes + 16, (size_t)e->out_cap / 4)) || e->h_res.reserve(rbytes + 16))
+      return OJPHGPU_E_NOMEM;
+    if (rbytes) HIPCHK(hipMemcpyAsync(e->h_res.p, e->results.p, rbytes, hipMemcpyDeviceToHost, e->stream));
+    if (e->nbytes) HIPCHK(hipMemcpyAsync(e->h_out.p, e->out.p, (size_t)e->nbytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (rbytes) memcpy(e->h_results.data(), e->h_res.p, rbytes);
     e->fetched = true;
   }
   cb.assign(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
@@ -414,9 +438,17 @@ extern "C" int ojphgpu_encoder_finish_frame(ojphgpu_encoder* e, uint32_t frame, 
   if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
   if (e->tiles.first != 0 || e->tiles.count != e->P->tiles.size()) return OJPHGPU_E_INVALID;   // use _finish_tiles
   std::vector<ojphgpu_coded_block> cb;
+  const bool tm = getenv("OJPHGPU_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
   int rc = encoder_fetch(e, frame, cb);
   if (rc) return rc;
-  return ojphgpu_t2_write(e->handle, e->h_out.data(), cb.data(), h_out, cap, out_len);
+  auto t1 = now();
+  rc = ojphgpu_t2_write(e->handle, e->h_out.p, cb.data(), h_out, cap, out_len);
+  if (tm) fprintf(stderr, "ojphgpu: finish frame %u: D2H %.2f ms, Tier-2 %.2f ms\n", frame,
+                  std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                  std::chrono::duration<double, std::milli>(now() - t1).count());
+  return rc;
 }
 
 extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len,
@@ -426,7 +458,7 @@ extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, 
   std::vector<ojphgpu_coded_block> cb;
   int rc = encoder_fetch(e, 0, cb);
   if (rc) return rc;
-  return ojphgpu_t2_write_tiles(e->handle, e->h_out.data(), cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
+  return ojphgpu_t2_write_tiles(e->handle, e->h_out.p, cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
                                 out_len, tile_part_len);
 }
 
