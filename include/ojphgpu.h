@@ -54,6 +54,8 @@ typedef struct ojphgpu_params {
   uint32_t precinct_w, precinct_h; /* 0 = 32768 (no explicit precincts)                        */
   uint32_t tlm;                  /* codestream::request_tlm_marker                            */
   uint32_t reserved[4];
+  uint8_t  precinct_exps[36];    /* param_cod::set_precinct_size with a list: per resolution (0 =
+                                    lowest) PPx | PPy << 4; all zero = precinct_w/h everywhere  */
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *

@@ -24,6 +24,7 @@ class Params(C.Structure):
         ("prog_order", C.c_uint32), ("qstep", C.c_float),
         ("precinct_w", C.c_uint32), ("precinct_h", C.c_uint32), ("tlm", C.c_uint32),
         ("reserved", C.c_uint32 * 4),
+        ("precinct_exps", C.c_uint8 * 36),
     ]
 
 

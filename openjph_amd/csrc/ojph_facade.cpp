@@ -205,10 +205,16 @@ void param_cod::set_block_dims(ui32 width, ui32 height)
 }
 void param_cod::set_precinct_size(int num_levels, size* precinct_size)
 {
+  memset(state->p.precinct_exps, 0, sizeof(state->p.precinct_exps));
   if (num_levels == 0 || precinct_size == nullptr) { state->p.precinct_w = state->p.precinct_h = 0; return; }
-  for (int i = 1; i < num_levels; ++i)
-    if (precinct_size[i].w != precinct_size[0].w || precinct_size[i].h != precinct_size[0].h)
-      ojph_error(0x00050F21, "the GPU path supports one precinct size for all resolutions");
+  for (ui32 i = 0; i < 33; ++i) {                          // entry i = resolution i (0 = lowest), the last one repeats (ojph_params.cpp:195-211)
+    const size t = precinct_size[(int)i < num_levels ? i : num_levels - 1];
+    if (t.w == 0 || t.h == 0) ojph_error(0x00050021, "precinct width or height cannot be 0");
+    const ui32 px = log2_exact(t.w), py = log2_exact(t.h);
+    if (t.w != (1u << px) || t.h != (1u << py)) ojph_error(0x00050022, "precinct width and height should be a power of 2");
+    if (px > 15 || py > 15) ojph_error(0x00050023, "precinct size is too large");
+    state->p.precinct_exps[i] = (ui8)(px | (py << 4));
+  }
   state->p.precinct_w = precinct_size[0].w; state->p.precinct_h = precinct_size[0].h;
 }
 void param_cod::set_progression_order(const char* name)
@@ -223,8 +229,12 @@ ui32 param_cod::get_num_decompositions() const { return state->p.num_decomps; }
 size param_cod::get_block_dims() const { return size(state->p.block_w, state->p.block_h); }
 size param_cod::get_log_block_dims() const { return size(log2_exact(state->p.block_w), log2_exact(state->p.block_h)); }
 bool param_cod::is_reversible() const { return state->p.reversible != 0; }
-size param_cod::get_precinct_size(ui32) const
-{ return size(state->p.precinct_w ? state->p.precinct_w : 32768, state->p.precinct_h ? state->p.precinct_h : 32768); }
+size param_cod::get_precinct_size(ui32 level_num) const
+{
+  if (level_num < 36 && state->p.precinct_exps[level_num])
+    return size(1u << (state->p.precinct_exps[level_num] & 15), 1u << (state->p.precinct_exps[level_num] >> 4));
+  return size(state->p.precinct_w ? state->p.precinct_w : 32768, state->p.precinct_h ? state->p.precinct_h : 32768);
+}
 size param_cod::get_log_precinct_size(ui32 l) const { size s = get_precinct_size(l); return size(log2_exact(s.w), log2_exact(s.h)); }
 int param_cod::get_progression_order() const { return (int)state->p.prog_order; }
 const char* param_cod::get_progression_order_as_string() const { return PROG_NAMES[state->p.prog_order % 5]; }

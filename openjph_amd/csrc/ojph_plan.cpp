@@ -151,6 +151,14 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
       return fail("precinct size must be a power of two <= 32768");
     if (p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");
   }
+  bool per_res = false;                                         // a list of precinct sizes, one per resolution
+  for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
+  if (per_res) {
+    if (p.num_decomps >= 36) return fail("too many resolutions for a precinct list");
+    for (uint32_t i = 1; i <= p.num_decomps; ++i)
+      if ((p.precinct_exps[i] & 15) == 0 || (p.precinct_exps[i] >> 4) == 0) return fail("precinct size too small");   // ojph_params.cpp:208
+    p.precinct_w = 1u << (p.precinct_exps[0] & 15); p.precinct_h = 1u << (p.precinct_exps[0] >> 4);
+  } else memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
   plan.p = p;
   derive_quant(plan);
 
@@ -187,6 +195,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
         }
         for (uint32_t r = 0; r <= L; ++r) {
           Resolution R; R.tile = t.idx; R.comp = c; R.res = r; R.r = rr[r];
+          if (per_res) { lpw = p.precinct_exps[r] & 15u; lph = p.precinct_exps[r] >> 4; }   // this resolution's precinct size
           R.log_ppw = lpw; R.log_pph = lph;
           for (int i = 0; i < 4; ++i) R.band[i] = -1;
           R.plane_off = 0; R.pitch = 0;

@@ -106,7 +106,9 @@ void write_main_header(const Plan& P, ByteSink& s)
   s.u8(lbw - 2); s.u8(lbh - 2); s.u8(0x40); s.u8(p.reversible ? 1 : 0);
   if (prec) {
     uint32_t a = 0, b = 0; while ((1u << a) < p.precinct_w) ++a; while ((1u << b) < p.precinct_h) ++b;
-    for (uint32_t i = 0; i <= p.num_decomps; ++i) s.u8(a | (b << 4));
+    bool per_res = false;
+    for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
+    for (uint32_t i = 0; i <= p.num_decomps; ++i) s.u8(per_res ? p.precinct_exps[i] : (a | (b << 4)));
   }
   // QCD (ojph_params.cpp:1778-1819)
   uint32_t nb = 1 + 3 * p.num_decomps;
@@ -529,13 +531,16 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
       p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
       use_sop = scod & 2; use_eph = scod & 4;
       if (scod & 1) {
-        uint32_t pw = 0, ph = 0;
+        uint32_t pw = 0, ph = 0; bool uniform = true;
+        if (p.num_decomps >= 36) return OJPHGPU_E_INVALID;
         for (uint32_t i = 0; i <= p.num_decomps; ++i) {
           uint32_t v = r.u8();
+          p.precinct_exps[i] = (uint8_t)v;
           if (i == 0) { pw = v & 0xF; ph = v >> 4; }
-          else if ((v & 0xF) != pw || (v >> 4) != ph) return OJPHGPU_E_INVALID;   // per-resolution precincts: later
+          else if ((v & 0xF) != pw || (v >> 4) != ph) uniform = false;
         }
         p.precinct_w = 1u << pw; p.precinct_h = 1u << ph;
+        if (uniform) memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
       }
       have_cod = true;
     } else if (m == QCD) {

@@ -13,7 +13,7 @@ coded_dtype = np.dtype(CodedBlock)
 
 def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
-                prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False):
+                prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None):
     p = Params()
     p.width, p.height, p.num_comps = width, height, num_comps
     p.bit_depth, p.is_signed = bit_depth, int(is_signed)
@@ -24,6 +24,10 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
     p.prog_order = PROG_ORDERS[prog_order] if isinstance(prog_order, str) else int(prog_order)
     p.qstep = float(qstep)
     p.precinct_w, p.precinct_h = precinct
+    if precincts:                          # list of (w, h) from the lowest resolution up, last one repeated
+        for i in range(num_decomps + 1):
+            pw, ph = precincts[min(i, len(precincts) - 1)]
+            p.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
     p.tlm = int(tlm)
     return p
 

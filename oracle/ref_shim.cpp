@@ -46,6 +46,7 @@ struct ref_params {
   float    qstep;                // irreversible base step; <=0 => library default
   uint32_t precinct_w, precinct_h; // 0 => default (32768); applied to all resolutions
   uint32_t tlm;                  // request TLM marker
+  uint8_t  precinct_exps[36];    // per resolution (0 = lowest): PPx | PPy << 4; all 0 => precinct_w/h for every resolution
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -79,7 +80,14 @@ long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out,
     cod.set_progression_order(po_names[p->prog_order % 5]);
     cod.set_color_transform(p->color_transform != 0);
     cod.set_reversible(p->reversible != 0);
-    if (p->precinct_w && p->precinct_h) {
+    bool per_res = false;
+    for (uint32_t i = 0; i <= p->num_decomps && i < 36; ++i) per_res |= p->precinct_exps[i] != 0;
+    if (per_res) {
+      std::vector<ojph::size> ps;
+      for (uint32_t i = 0; i <= p->num_decomps; ++i)
+        ps.push_back(ojph::size(1u << (p->precinct_exps[i] & 15), 1u << (p->precinct_exps[i] >> 4)));
+      cod.set_precinct_size((int)ps.size(), ps.data());
+    } else if (p->precinct_w && p->precinct_h) {
       std::vector<ojph::size> ps(p->num_decomps + 1, ojph::size(p->precinct_w, p->precinct_h));
       cod.set_precinct_size((int)ps.size(), ps.data());
     }

@@ -24,6 +24,7 @@ class RefParams(C.Structure):
         ("qstep", C.c_float),
         ("precinct_w", C.c_uint32), ("precinct_h", C.c_uint32),
         ("tlm", C.c_uint32),
+        ("precinct_exps", C.c_uint8 * 36),
     ]
 
 
@@ -64,7 +65,7 @@ class Ref:
 
     def encode(self, planes, bit_depth, is_signed=False, reversible=True, num_decomps=5,
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
-               planar=None, qstep=-1.0, precinct=(0, 0), tlm=False):
+               planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None):
         """planes: int32 array [num_comps, H, W]. Returns codestream bytes."""
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         nc, h, w = planes.shape
@@ -74,6 +75,10 @@ class Ref:
                       block[0], block[1], int(color_transform), tile[0], tile[1],
                       PROG_ORDERS[prog_order], int(planar), float(qstep),
                       precinct[0], precinct[1], int(tlm))
+        if precincts:                      # list of (w, h) from the lowest resolution up, last one repeated
+            for i in range(num_decomps + 1):
+                pw, ph = precincts[min(i, len(precincts) - 1)]
+                p.precinct_exps[i] = (pw.bit_length() - 1) | ((ph.bit_length() - 1) << 4)
         ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
         cap = planes.size * 5 + (1 << 20)
         out = np.empty(cap, dtype=np.uint8)
