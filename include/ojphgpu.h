@@ -53,7 +53,7 @@ typedef struct ojphgpu_params {
   float    qstep;                /* param_qcd::set_irrev_quant; <= 0 selects 2^-min(16,B)     */
   uint32_t precinct_w, precinct_h; /* 0 = 32768 (no explicit precincts)                        */
   uint32_t tlm;                  /* codestream::request_tlm_marker                            */
-  uint32_t reserved[4];
+  uint32_t reserved[4];          /* [0] bit 0: vertically causal code-block style (set by the parser) */
   uint8_t  precinct_exps[36];    /* param_cod::set_precinct_size with a list: per resolution (0 =
                                     lowest) PPx | PPy << 4; all zero = precinct_w/h everywhere  */
 } ojphgpu_params;
@@ -177,7 +177,8 @@ typedef struct ojphgpu_cb_desc {     /* one code-block */
   uint64_t coef_off;                 /* element offset of the block's first sample in `d_coef` */
   uint32_t pitch;                    /* elements */
   uint16_t w, h;
-  uint8_t  K_max, reversible, missing_msbs, num_passes;   /* last two: decode only */
+  uint8_t  K_max, reversible, missing_msbs, num_passes;   /* last two: decode only; reversible bit 1
+                                        (decode): vertically causal code-block style */
   float    delta;                    /* irreversible: encode uses 1/delta, decode uses delta */
   uint32_t len1, len2;               /* decode: pass lengths */
   uint64_t data_off;                 /* decode: byte offset of the coded bytes in `d_data`;
@@ -222,6 +223,12 @@ int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_blocks, uint3
 int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                             const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
                             uint8_t* d_block_status);
+/* fourth launch, only needed when some block has num_passes > 1 (foreign codestreams): SigProp +
+ * MagRef passes (ojph_block_decoder32.cpp:1318-1609) over the blocks that carry them; step 2 left
+ * those blocks as sign-magnitude words, this launch refines and de-quantises them.  Bit 1 of
+ * blocks[i].reversible selects the vertically (stripe) causal mode of the code-block style. */
+int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                             const uint8_t* d_data, void* d_coef, const uint8_t* d_block_status);
 
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */

@@ -30,9 +30,9 @@
 //           de-quantised samples leaves as one coalesced 256-byte store.  MagSgn bytes are
 //           un-stuffed 256 at a time into a small LDS ring, so LDS use does not depend on the
 //           size of the code-block and the CU stays fully occupied.
-// SigProp / MagRef passes (:1318-1609) are not implemented yet: blocks carrying them decode
-// their cleanup pass only -- identical to the reference for streams of its own encoder, which
-// never emits these passes (ojph_block_encoder.cpp:548).
+// SigProp / MagRef passes (:1318-1609), which only foreign codestreams carry (the reference's own
+// encoder never emits them, ojph_block_encoder.cpp:548), run in a fourth launch, ht_dec_refine_kernel,
+// that the codec objects skip when no block of the frame has more than one pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ojphgpu.h"
@@ -53,7 +53,7 @@ constexpr uint32_t ROW_BITS_MAX = 64 * 2 * 32; // a quad row of 64 columns consu
 constexpr uint32_t EXP_BYTES = 1024 + 8;      // wide blocks (> 64 columns): exponent row in LDS
 
 // words of the flat VLC / MEL strings of a cleanup segment with MEL+VLC length scup (incl. 2 pad words)
-__host__ __device__ __forceinline__ uint32_t vlc_words(uint32_t scup) { return ((scup - 2u) * 8u + 4u + 31u) / 32u + 2u; }
+__host__ __device__ __forceinline__ uint32_t vlc_words(uint32_t scup) { return ((scup - 2u) * 8u + 4u + 8u + 31u) / 32u + 2u; }
 __host__ __device__ __forceinline__ uint32_t mel_words(uint32_t scup) { return ((scup - 1u) * 8u + 31u) / 32u + 2u; }
 __host__ __device__ __forceinline__ uint32_t aux_words(uint32_t len1)
 {
@@ -116,45 +116,64 @@ __device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v,
 // -------------------------------------------------------------------------------------------------
 // One stream: `count` bytes, byte k given by get(k) (with its predecessor for the stuffing rule);
 // bits(b, prev) = number of payload bits of byte b; REV = string is consumed MSB first (MEL).
+// The reference's byte readers OR every raw byte into their window with all 8 bits and only then
+// advance by 7 or 8 (rev_read :308-359, frwd_read :609-655): after a stuffing event the 7-bit
+// byte's MSB lands on the LSB of the byte that follows.  In a conforming stream that MSB is 0; to
+// stay bit-identical on arbitrary bytes the un-stuffers here work on "effective" bytes
+//   eff[k] = raw[k] | (byte k-1 carried only 7 bits ? raw[k-1] >> 7 : 0)
+// which is a local rule and keeps the whole thing a prefix sum.  (For MEL, MSB first, the stray
+// bit lands on a bit that is already 1, mel_read :126-148, so nothing changes.)
 template <bool MEL>
 __device__ void flatten(const uint8_t* __restrict__ cb, uint32_t lcup, uint32_t scup, uint32_t* __restrict__ out,
                         uint32_t* lds, int lane)
 {
-  const uint32_t count = MEL ? scup - 1u : scup - 2u;
+  // VLC: one zero fill byte is appended so that a stray bit of the last byte is kept (:313-331)
+  const uint32_t real = MEL ? scup - 1u : scup - 2u;
+  const uint32_t count = MEL ? real : real + 1u;
   for (int i = lane; i < 68; i += 64) lds[i] = 0;
   wave_sync();
   uint32_t cursor = 0, wpos = 0;
+  const uint32_t d0 = cb[lcup - 2];
   if (!MEL) {                                              // rev_init (block_decoder32.cpp:380-400)
-    const uint32_t d = cb[lcup - 2];
-    const uint32_t t = d >> 4;
+    const uint32_t t = d0 >> 4;
     if (lane == 0) lds[0] = t;
     cursor = 4u - ((t & 7u) == 7u ? 1u : 0u);
     wave_sync();
   }
+  // VLC raw byte k (k = -1: the byte holding the 4 initial bits, with its low nibble forced to ones)
+  auto vraw = [&](int k) -> uint32_t { return k < 0 ? (d0 | 0xFu) : ((uint32_t)k < real ? (uint32_t)cb[lcup - 3 - k] : 0u); };
   for (uint32_t base = 0; base < count; base += 256) {
     const uint32_t k0 = base + 4u * (uint32_t)lane;
     uint32_t val = 0, nb = 0;
     if (k0 < count) {
-      uint32_t prev;
-      if (MEL) prev = k0 ? cb[lcup - scup + k0 - 1] : 0u;
-      else prev = k0 ? cb[lcup - 2 - k0] : (cb[lcup - 2] | 0xFu);
+      if (MEL) {
+        uint32_t prev = k0 ? cb[lcup - scup + k0 - 1] : 0u;
 #pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) {
-        const uint32_t k = k0 + j;
-        if (k < count) {
-          uint32_t b, n;
-          if (MEL) {                                       // mel_read (:93-157): after 0xFF only 7 bits, MSB first
-            b = cb[lcup - scup + k];
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t k = k0 + j;
+          if (k < count) {                                 // mel_read (:93-157): after 0xFF only 7 bits, MSB first
+            uint32_t b = cb[lcup - scup + k];
             if (k == count - 1) b |= 0xFu;                 // the last MEL byte shares its low nibble with VLC (:116)
-            n = 8u - (prev == 0xFFu ? 1u : 0u);
-            const uint32_t payload = __brev(b & ((1u << n) - 1u)) >> (32u - n);    // stream order = MSB first
-            val |= payload << nb;
-          } else {                                         // rev_read (:308-359): > 0x8F then x1111111 -> 7 bits
-            b = cb[lcup - 3 - k];
-            n = 8u - ((prev > 0x8Fu && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
-            val |= (b & ((1u << n) - 1u)) << nb;
+            const uint32_t n = 8u - (prev == 0xFFu ? 1u : 0u);
+            val |= (__brev(b & ((1u << n) - 1u)) >> (32u - n)) << nb;      // stream order = MSB first
+            nb += n; prev = b;
           }
-          nb += n; prev = b;
+        }
+      } else {
+        // state of the byte before this lane's first one: was it a 7-bit byte, and its raw value
+        uint32_t p1 = vraw((int)k0 - 1), p2 = k0 >= 1 ? vraw((int)k0 - 2) : 0u;
+        bool p1_short = k0 >= 1 && p2 > 0x8Fu && (p1 & 0x7Fu) == 0x7Fu;    // rev_read: > 0x8F then x1111111 -> 7 bits
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t k = k0 + j;
+          if (k < count) {
+            const uint32_t b = vraw((int)k);
+            const bool is_short = p1 > 0x8Fu && (b & 0x7Fu) == 0x7Fu;
+            const uint32_t n = is_short ? 7u : 8u;
+            const uint32_t eff = b | (p1_short ? p1 >> 7 : 0u);
+            val |= (eff & ((1u << n) - 1u)) << nb;
+            nb += n; p1 = b; p1_short = is_short;
+          }
         }
       }
     }
@@ -399,6 +418,21 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
   uint32_t v; __builtin_memcpy(&v, p, 4); return v;
 }
 
+// de-quantise transfer of one sign-magnitude word (ojph_codestream_gen.cpp:124-168)
+__device__ __forceinline__ uint32_t dequantise(uint32_t val, bool rev, uint32_t shift, float delta)
+{
+  const uint32_t mag = val & 0x7FFFFFFFu;
+  if (rev) { const int iv = (int)(mag >> shift); return (uint32_t)((val >> 31) ? -iv : iv); }
+  const float fv = __fmul_rn((float)mag, delta);
+  return __float_as_uint((val >> 31) ? -fv : fv);
+}
+
+// does the block carry SigProp / MagRef passes that will be decoded (block_decoder32.cpp:752-789)?
+__device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
+{
+  return d.num_passes > 1 && d.num_passes <= 3 && d.len2 > 0 && d.missing_msbs < 29;
+}
+
 __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
@@ -413,8 +447,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   if (W == 0 || H == 0) return;
   uint32_t* dst = coef + d.coef_off;
-  const bool rev = d.reversible != 0;
+  const bool rev = (d.reversible & 1u) != 0;
   const uint32_t K = d.K_max;
+  const bool raw_out = needs_refinement(d);                  // SigProp / MagRef follow: keep sign-magnitude words
 
   auto zero_block = [&]() {                                  // mem_clear path, ojph_codeblock.cpp:247
     for (uint32_t y = 0; y < H; ++y)
@@ -445,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const uint32_t i0 = src_pos + 4u * (uint32_t)lane;
     uint32_t val = 0, nb = 0;
     if (i0 < ms_len) {
-      uint32_t prev = i0 ? cb[i0 - 1] : 0u;
+      uint32_t prev = i0 ? cb[i0 - 1] : 0u, prev2 = i0 > 1 ? cb[i0 - 2] : 0u;
       uint32_t word;
       if (i0 + 4 <= ms_len) word = load_u32_unaligned(cb + i0);
       else {
@@ -459,8 +494,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
         if (k < cnt) {
           const uint32_t b = (word >> (8 * k)) & 0xFFu;
           const uint32_t bits = prev == 0xFFu ? 7u : 8u;
-          val |= (b & ((1u << bits) - 1u)) << nb; nb += bits;
-          prev = b;
+          const uint32_t eff = b | (prev2 == 0xFFu ? prev >> 7 : 0u);      // stray MSB of a 7-bit byte (see flatten)
+          val |= (eff & ((1u << bits) - 1u)) << nb; nb += bits;
+          prev2 = prev; prev = b;
         }
       }
     }
@@ -542,9 +578,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
           v_n |= 1u;
           val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
         }
-        const uint32_t mag = val & 0x7FFFFFFFu;                                         // de-quantise transfer
-        if (rev) { const int iv = (int)(mag >> shift); out0 = (uint32_t)((val >> 31) ? -iv : iv); }
-        else { const float fv = __fmul_rn((float)mag, delta); out0 = __float_as_uint((val >> 31) ? -fv : fv); }
+        out0 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       {
         uint32_t val = 0;
@@ -556,9 +590,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
           val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
           v1 = v_n;
         }
-        const uint32_t mag = val & 0x7FFFFFFFu;
-        if (rev) { const int iv = (int)(mag >> shift); out1 = (uint32_t)((val >> 31) ? -iv : iv); }
-        else { const float fv = __fmul_rn((float)mag, delta); out1 = __float_as_uint((val >> 31) ? -fv : fv); }
+        out1 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       const uint32_t e_new = v1 ? 31u - (uint32_t)__clz((int)v1) : 0u;
       if (!wide) e_prev = e_new;
@@ -573,6 +605,158 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     if (wide) wave_sync();
   }
   if (bad) { zero_block(); if (lane == 0) block_status[bi] = 1; }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// refinement: SigProp + MagRef passes (block_decoder32.cpp:1318-1609), one wavefront = one code-block
+// -------------------------------------------------------------------------------------------------
+// Only foreign codestreams carry these passes (the reference encoder emits the cleanup pass alone).
+// Both are serial scans -- a sample's membership in SigProp depends on what its neighbours just
+// became -- so one lane walks them; the wavefront's job is to make that walk cheap: all lanes bring
+// the block (sign-magnitude words left by step 2), its cleanup significance and the refinement
+// bytes into LDS, lane 0 runs the two passes out of LDS, and all lanes de-quantise and store the
+// block in coalesced rows.  Significance: one 16-bit word per 4-row stripe and group of 4 columns,
+// column-major, bit 4*c + r (:1331-1362).
+constexpr int RWAVES = 2;
+constexpr uint32_t SIG_ENTRIES = 1040;        // (stripes + 1) * (groups + 2) 16-bit words, w * h <= 4096
+constexpr uint32_t PREV_ENTRIES = 264;
+
+struct RefineLds {
+  uint32_t smp[4096];
+  uint16_t sigma[SIG_ENTRIES];
+  uint16_t prev_row[PREV_ENTRIES];
+  uint8_t  bytes[2048];
+};
+
+struct FwdBits {            // SigProp: forward, LSB first, after 0xFF only 7 bits, exhausted -> zeros (frwd_read<0> :609-655)
+  const uint8_t* d; int i, n_bytes; uint64_t win; uint32_t n, unstuff;
+  __device__ __forceinline__ void init(const uint8_t* p, int len) { d = p; i = 0; n_bytes = len; win = 0; n = 0; unstuff = 0; }
+  __device__ __forceinline__ uint32_t bit() {
+    if (n == 0) {
+      const uint32_t b = i < n_bytes ? d[i] : 0u; ++i;
+      win |= (uint64_t)b;                               // all 8 bits are OR-ed in, also when only 7 count
+      n = 8u - unstuff; unstuff = (b == 0xFFu);
+    }
+    const uint32_t r = (uint32_t)win & 1u; win >>= 1; --n;
+    return r;
+  }
+};
+
+struct BwdBits {            // MagRef: backward from the end, VLC stuffing rule, starts with unstuff = true (rev_read_mrp :453-545)
+  const uint8_t* d; int i; uint64_t win; uint32_t n, unstuff;
+  __device__ __forceinline__ void init(const uint8_t* p, int len) { d = p; i = len - 1; win = 0; n = 0; unstuff = 1; }
+  __device__ __forceinline__ uint32_t bit() {
+    if (n == 0) {
+      const uint32_t b = i >= 0 ? d[i] : 0u; --i;
+      win |= (uint64_t)b;
+      n = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u); unstuff = b > 0x8Fu;
+    }
+    const uint32_t r = (uint32_t)win & 1u; win >>= 1; --n;
+    return r;
+  }
+};
+
+__global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
+{
+  __shared__ RefineLds s_wave[RWAVES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t bi = blockIdx.x * RWAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (!needs_refinement(d) || d.w == 0 || d.h == 0 || d.len1 == 0 || block_status[bi] != 0) return;
+  RefineLds& L = s_wave[wave];
+  const uint32_t W = d.w, H = d.h, pitch = d.pitch;
+  uint32_t* plane = coef + d.coef_off;
+  const bool rev = (d.reversible & 1u) != 0, causal = (d.reversible & 2u) != 0;
+  const uint32_t p = 30u - d.missing_msbs;
+  const int ngroups = (int)((W + 3) >> 2), nstripes = (int)((H + 3) >> 2), mstr = ngroups + 2;
+
+  for (uint32_t i = lane; i < SIG_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.sigma)[i] = 0;
+  for (uint32_t i = lane; i < PREV_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.prev_row)[i] = 0;
+  wave_sync();
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = lane; x < W; x += 64) {
+      const uint32_t v = plane[(size_t)y * pitch + x];
+      L.smp[y * W + x] = v;
+      if (v) {
+        const uint32_t e = (y >> 2) * (uint32_t)mstr + (x >> 2);
+        atomicOr(reinterpret_cast<uint32_t*>(L.sigma) + (e >> 1), (1u << (4 * (x & 3) + (y & 3))) << (16 * (e & 1)));
+      }
+    }
+  const uint8_t* seg = data + d.data_off + d.len1;
+  const int len2 = (int)d.len2;                              // < 2047 (ojph_precinct.cpp:509)
+  for (int i = lane; i < len2 && i < 2048; i += 64) L.bytes[i] = seg[i];
+  wave_sync();
+
+  if (lane == 0) {
+    // ---- significance propagation (:1364-1558) ----
+    FwdBits spp; spp.init(L.bytes, len2 < 2048 ? len2 : 2048);
+    for (int y = 0; y < (int)H; y += 4) {
+      uint32_t pattern = 0xFFFFu;
+      if ((int)H - y < 4) { pattern = 0x7777u; if ((int)H - y < 3) { pattern = 0x3333u; if ((int)H - y < 2) pattern = 0x1111u; } }
+      uint32_t prev = 0;
+      const uint16_t* cur_sig = L.sigma + (y >> 2) * mstr;
+      const uint16_t* nxt_sig = cur_sig + mstr;
+      for (int x = 0, g = 0; x < (int)W; x += 4, ++g) {
+        int s = x + 4 - (int)W; if (s < 0) s = 0;
+        pattern >>= s * 4;
+        const uint32_t ps = L.prev_row[g] | ((uint32_t)L.prev_row[g + 1] << 16);
+        const uint32_t ns = nxt_sig[g] | ((uint32_t)nxt_sig[g + 1] << 16);
+        uint32_t u = (ps & 0x88888888u) >> 3;                // the row on top
+        if (!causal) u |= (ns & 0x11111111u) << 3;           // the row below
+        const uint32_t cs = cur_sig[g] | ((uint32_t)cur_sig[g + 1] << 16);
+        uint32_t mbr = cs | ((cs & 0x77777777u) << 1) | ((cs & 0xEEEEEEEEu) >> 1) | u;
+        uint32_t t = mbr;
+        mbr |= (t << 4) | (t >> 4) | (prev >> 12);
+        mbr &= pattern; mbr &= ~cs;
+        uint32_t new_sig = mbr;
+        if (new_sig) {
+          const uint32_t inv_sig = ~cs & pattern;
+          for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t b = 1u << (4 * c + r);
+              if (!(new_sig & b)) continue;
+              new_sig &= ~b;
+              if (spp.bit()) {
+                const uint32_t grow = r == 0 ? 0x33u : (r == 1 ? 0x76u : (r == 2 ? 0xECu : 0xC8u));
+                new_sig |= (grow << (4 * c)) & inv_sig;
+              }
+            }
+          new_sig &= 0xFFFFu;
+          for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r)
+              if (new_sig & (1u << (4 * c + r)))
+                L.smp[(uint32_t)(y + r) * W + (uint32_t)(x + c)] = (spp.bit() << 31) | (3u << (p - 2));
+        }
+        new_sig |= cs;
+        L.prev_row[g] = (uint16_t)new_sig;
+        t = new_sig;
+        new_sig |= ((t & 0x7777u) << 1) | ((t & 0xEEEEu) >> 1);
+        prev = (new_sig | u) & 0xF000u;
+      }
+    }
+    // ---- magnitude refinement (:1561-1609) ----
+    if (d.num_passes > 2) {
+      BwdBits mrp; mrp.init(L.bytes, len2 < 2048 ? len2 : 2048);
+      const uint32_t half = 1u << (p - 2);
+      for (int y = 0; y < (int)H; y += 4)
+        for (int x = 0; x < (int)W; ++x) {
+          const uint32_t nib = ((uint32_t)L.sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
+          for (int r = 0; r < 4; ++r)
+            if (nib & (1u << r))
+              L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((1u - mrp.bit()) << (p - 1)) | half;
+        }
+    }
+  }
+  wave_sync();
+  const uint32_t shift = 31 - d.K_max;
+  const float delta = d.delta;
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = lane; x < W; x += 64) plane[(size_t)y * pitch + x] = dequantise(L.smp[y * W + x], rev, shift, delta);
 }
 
 }  // namespace
@@ -612,6 +796,16 @@ extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_bl
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
+extern "C" int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
+                                         const uint8_t* d_data, void* d_coef, const uint8_t* d_block_status)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (!d_blocks || !d_data || !d_coef || !d_block_status) return OJPHGPU_E_INVALID;
+  hipLaunchKernelGGL(ht_dec_refine_kernel, dim3((n + RWAVES - 1) / RWAVES), dim3(64 * RWAVES), 0, (hipStream_t)stream,
+                     d_blocks, n, d_data, (uint32_t*)d_coef, d_block_status);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
 extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                   const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
                                   uint32_t* d_aux, uint8_t* d_block_status)
@@ -619,6 +813,7 @@ extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   int rc = ojphgpu_ht_decode_prep(stream, d_blocks, n, d_data, d_aux);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step1(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step2(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status);
+  if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_refine(stream, d_blocks, n, d_data, d_coef, d_block_status);
   return rc;
 }
 

@@ -529,6 +529,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
       if (style & ~0x48u) return OJPHGPU_E_INVALID;               // only HT (+ vertically causal) styles
       if (wt > 1) return OJPHGPU_E_INVALID;                       // ATK wavelets: not supported
       p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
+      p.reserved[0] = (style & 0x08u) ? 1u : 0u;                  // vertically causal context (SigProp of foreign streams)
       use_sop = scod & 2; use_eph = scod & 4;
       if (scod & 1) {
         uint32_t pw = 0, ph = 0; bool uniform = true;

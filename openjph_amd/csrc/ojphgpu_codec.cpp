@@ -498,6 +498,7 @@ struct ojphgpu_decoder {
   bool fused_convert = false;
   TileRange tiles{ 0, 0 };
   uint32_t nframes = 1;
+  bool any_refine = false;                         // some block carries SigProp / MagRef passes
   std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
   uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
   std::vector<LevelBatch> batches;
@@ -591,8 +592,10 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
     const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];
     ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i]; memset(&o, 0, sizeof(o));
     o.coef_off = (uint64_t)f * P.arena_elems + B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
-    o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max; o.reversible = (uint8_t)P.p.reversible;
+    o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
+    o.reversible = (uint8_t)((P.p.reversible ? 1u : 0u) | ((Q.p.reserved[0] & 1u) << 1));     // bit 1: vertically causal
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
+    if (c.num_passes > 1 && c.len2 > 0) d->any_refine = true;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
     nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2) + 1;    // + 1 pad element (see include/ojphgpu.h)
@@ -663,6 +666,10 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   rc = ojphgpu_ht_decode_step2(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p,
                                (uint8_t*)d->status.p);
   if (rc) return rc;
+  if (d->any_refine) {
+    rc = ojphgpu_ht_decode_refine(s, cbd, d->nblocks, (const uint8_t*)d->data.p, d->arena.p, (const uint8_t*)d->status.p);
+    if (rc) return rc;
+  }
   d->timer.mark(1, s);
   d->timer.begin_levels();
   for (const LevelBatch& b : d->batches) {

@@ -158,6 +158,21 @@ static int fb_put(flatbits* f, uint32_t v, int n)
   f->nbits += n;
   return 1;
 }
+/* The reference's readers OR every raw byte into their window with all 8 bits and only then
+ * advance by 7 or 8 (frwd_read :609-655, rev_read :308-359): after a stuffing event the byte's MSB
+ * lands on the next byte's LSB.  In a conforming stream that MSB is 0; for arbitrary (corrupt)
+ * bytes this is what keeps the restatement bit-identical. */
+static int fb_put_byte(flatbits* f, uint32_t byte, int nb)
+{
+  if ((f->nbits + 8 + 7) / 8 > f->cap_bytes) return 0;
+  uint64_t w; long at = f->nbits >> 3; int sh = (int)(f->nbits & 7);
+  memcpy(&w, f->b + at, 8);
+  w |= (uint64_t)(byte & 0xFFu) << sh;
+  memcpy(f->b + at, &w, 8);
+  f->nbits += nb;
+  return 1;
+}
+
 static uint32_t fb_get(const flatbits* f, long pos, int n)
 {
   if (n <= 0 || (pos >> 3) >= f->cap_bytes) return 0;
@@ -480,16 +495,122 @@ static void destuff_forward(flatbits* f, const uint8_t* d, int n, int extra_byte
   for (int i = 0; i < n + extra_bytes; ++i) {
     int b = i < n ? d[i] : fill;
     int nb = 8 - unstuff;
-    fb_put(f, (uint32_t)b & ((1u << nb) - 1), nb);
+    fb_put_byte(f, (uint32_t)b, nb);
     unstuff = (b == 0xFF);
   }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SigProp + MagRef passes (ojph_block_decoder32.cpp:1318-1609), restated on flat bit strings.   */
+/* ------------------------------------------------------------------------------------------ */
+/* Significance of a 4-row stripe is kept as one 16-bit word per group of 4 columns, column-major:
+ * bit 4*c + r = sample (column c, row r) of the group (:1331-1362).  Both passes read the len2
+ * bytes that follow the cleanup segment: SigProp forward from its start (LSB first, "after 0xFF
+ * only 7 bits", exhausted -> zeros: frwd_read<0> :609-655), MagRef backward from its end (the
+ * VLC stuffing rule with unstuff initially true, exhausted -> zeros: rev_read_mrp :453-545). */
+static uint32_t next_bit(const flatbits* f, long* pos)      /* exhausted streams feed zeros ... */
+{
+  /* ... except for the one bit a stuffed last byte may have OR-ed past the end (see fb_put_byte) */
+  uint32_t b = *pos <= f->nbits ? fb_get(f, *pos, 1) : 0u;
+  ++*pos;
+  return b;
+}
+
+static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_passes, int p,
+                          int width, int height, int stride, uint32_t* out, int stripe_causal)
+{
+  int ngroups = (width + 3) >> 2, nstripes = (height + 3) >> 2;
+  int mstr = ngroups + 2;
+  uint16_t* sigma = (uint16_t*)calloc((size_t)(nstripes + 1) * mstr, 2);
+  uint16_t* prev_row = (uint16_t*)calloc((size_t)mstr, 2);
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x)
+      if (out[(size_t)y * stride + x] != 0)
+        sigma[(y >> 2) * mstr + (x >> 2)] |= (uint16_t)(1u << (4 * (x & 3) + (y & 3)));
+
+  flatbits fspp, fmrp;
+  fb_init(&fspp, len2 + 64); fb_init(&fmrp, len2 + 64);
+  destuff_forward(&fspp, coded + lcup, len2, 0, 0);
+  { int unstuff = 1;
+    for (int i = lcup + len2 - 1; i >= lcup; --i) {
+      int b = coded[i];
+      int nb = 8 - ((unstuff && (b & 0x7F) == 0x7F) ? 1 : 0);
+      fb_put_byte(&fmrp, (uint32_t)b, nb);
+      unstuff = b > 0x8F;
+    } }
+  long spos = 0, mpos = 0;
+#define SPP_BIT() next_bit(&fspp, &spos)
+#define MRP_BIT() next_bit(&fmrp, &mpos)
+
+  /* ---- significance propagation (:1364-1558) ---- */
+  for (int y = 0; y < height; y += 4) {
+    uint32_t pattern = 0xFFFFu;
+    if (height - y < 4) { pattern = 0x7777u; if (height - y < 3) { pattern = 0x3333u; if (height - y < 2) pattern = 0x1111u; } }
+    uint32_t prev = 0;
+    uint16_t* cur_sig = sigma + (y >> 2) * mstr;
+    uint16_t* nxt_sig = cur_sig + mstr;
+    for (int x = 0, g = 0; x < width; x += 4, ++g) {
+      int s = x + 4 - width; if (s < 0) s = 0;
+      pattern >>= s * 4;
+      uint32_t ps = prev_row[g] | ((uint32_t)prev_row[g + 1] << 16);
+      uint32_t ns = nxt_sig[g] | ((uint32_t)nxt_sig[g + 1] << 16);
+      uint32_t u = (ps & 0x88888888u) >> 3;
+      if (!stripe_causal) u |= (ns & 0x11111111u) << 3;
+      uint32_t cs = cur_sig[g] | ((uint32_t)cur_sig[g + 1] << 16);
+      uint32_t mbr = cs | ((cs & 0x77777777u) << 1) | ((cs & 0xEEEEEEEEu) >> 1) | u;
+      uint32_t t = mbr;
+      mbr |= (t << 4) | (t >> 4) | (prev >> 12);
+      mbr &= pattern; mbr &= ~cs;
+      uint32_t new_sig = mbr;
+      if (new_sig) {
+        static const uint32_t grow[4] = { 0x33u, 0x76u, 0xECu, 0xC8u };
+        uint32_t inv_sig = ~cs & pattern;
+        for (int c = 0; c < 4; ++c)
+          for (int r = 0; r < 4; ++r) {
+            uint32_t bit = 1u << (4 * c + r);
+            if (!(new_sig & bit)) continue;
+            new_sig &= ~bit;
+            uint32_t b = SPP_BIT();
+            if (b) new_sig |= (grow[r] << (4 * c)) & inv_sig;
+          }
+        new_sig &= 0xFFFFu;
+        for (int c = 0; c < 4; ++c)
+          for (int r = 0; r < 4; ++r)
+            if (new_sig & (1u << (4 * c + r))) {
+              uint32_t sign = SPP_BIT();
+              out[(size_t)(y + r) * stride + x + c] = (sign << 31) | (3u << (p - 2));
+            }
+      }
+      new_sig |= cs;
+      prev_row[g] = (uint16_t)new_sig;
+      t = new_sig;
+      new_sig |= ((t & 0x7777u) << 1) | ((t & 0xEEEEu) >> 1);
+      prev = (new_sig | u) & 0xF000u;
+    }
+  }
+  /* ---- magnitude refinement (:1561-1609): significant samples of the cleanup pass, column-major ---- */
+  if (num_passes > 2) {
+    uint32_t half = 1u << (p - 2);
+    for (int y = 0; y < height; y += 4)
+      for (int x = 0; x < width; ++x) {
+        uint32_t nib = (sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
+        for (int r = 0; r < 4; ++r)
+          if (nib & (1u << r)) {
+            uint32_t sym = MRP_BIT();
+            out[(size_t)(y + r) * stride + x] ^= ((1u - sym) << (p - 1)) | half;
+          }
+      }
+  }
+#undef SPP_BIT
+#undef MRP_BIT
+  fb_free(&fspp); fb_free(&fmrp);
+  free(sigma); free(prev_row);
 }
 
 int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int missing_msbs,
                   int width, int height, int stride, uint32_t* out, int stripe_causal)
 {
   build_tables();
-  (void)stripe_causal;
   if (num_passes > 1 && len2 == 0) num_passes = 1;
   if (num_passes > 3) return 0;
   if (missing_msbs >= 30) return 0;                         /* block_decoder32.cpp:768-789 */
@@ -528,7 +649,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
     for (int i = lcup - 3; i >= lcup - scup; --i) {
       int b = coded[i];
       int nb = 8 - ((unstuff && (b & 0x7F) == 0x7F) ? 1 : 0);
-      fb_put(&fvlc, (uint32_t)b & ((1u << nb) - 1), nb);
+      fb_put_byte(&fvlc, (uint32_t)b, nb);
       unstuff = b > 0x8F;
     }
     fb_put(&fvlc, 0, 32); fb_put(&fvlc, 0, 32);
@@ -662,9 +783,8 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
   }
 #undef VLC_PEEK
 
-  if (ok && num_passes > 1) {
-    ok = 0; /* SigProp / MagRef restatement: not yet in this oracle */
-  }
+  if (ok && num_passes > 1)
+    refine_passes(coded, lcup, len2, num_passes, p, width, height, stride, out, stripe_causal);
   fb_free(&fmel); fb_free(&fvlc); fb_free(&fms);
   free(qinf); free(quq); free(vrow);
   return ok;

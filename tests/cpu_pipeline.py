@@ -111,6 +111,29 @@ def encode_tiles(plan: Plan, image, first, count):
     return plan.t2_write_tiles(data, coded, first, count)
 
 
+def add_refinement(data, coded, rng, fraction=0.6):
+    """Turns a cleanup-only block table into one where a share of the blocks also carries SigProp
+    (+ MagRef) segments made of random bytes -- what a foreign encoder may emit and the reference's
+    own never does.  The refinement bytes follow the cleanup bytes (ojph_block_decoder32.cpp:742)."""
+    out = coded.copy()
+    chunks, pos = [], 0
+    for k in range(len(coded)):
+        n1 = int(coded[k]["len1"])
+        if n1 == 0:
+            continue
+        o = int(coded[k]["offset"])
+        chunks.append(data[o:o + n1].tobytes())
+        out[k]["offset"] = pos
+        pos += n1
+        if rng.random() < fraction:
+            n2 = int(rng.integers(1, 300))
+            chunks.append(bytes(rng.integers(0, 256, size=n2, dtype=np.uint8)))
+            out[k]["len2"] = n2
+            out[k]["num_passes"] = int(rng.integers(2, 4))
+            pos += n2
+    return np.frombuffer(b"".join(chunks), dtype=np.uint8), out
+
+
 def decode_blocks(plan: Plan, cs: bytes):
     """Oracle HT decode + dequantise of every block into a fresh arena."""
     coded = plan.coded_blocks()
@@ -126,7 +149,8 @@ def decode_blocks(plan: Plan, cs: bytes):
         w, h = int(blk["w"]), int(blk["h"])
         o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
         ok, sm = ob.ht_decode(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
-                              len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]))
+                              len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]),
+                              stripe_causal=bool(plan.params.reserved[0] & 1))
         if not ok:
             raise RuntimeError("oracle failed to decode block %d" % k)
         off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])

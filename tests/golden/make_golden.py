@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
-from tests.golden_cases import BLOCK_CASES, STREAM_CASES, stream_kwargs  # noqa: E402
+from tests.golden_cases import BLOCK_CASES, STREAM_CASES, REFINE_CASES, stream_kwargs, refine_case  # noqa: E402
 
 
 def sha(b):
@@ -53,6 +53,16 @@ def main():
                               "dec_sha256": sha(np.ascontiguousarray(dec[:, :w]).tobytes())})
         if w * h <= 1024:
             blobs["block%d" % i] = np.frombuffer(b, np.uint8)
+    # (a2) blocks with SigProp / MagRef segments (random refinement bytes behind a reference-coded cleanup pass)
+    out["refine"] = []
+    for i in range(len(REFINE_CASES)):
+        q, w, h, stride, kmax, npass, causal, tail = refine_case(i)
+        cup = ref.encode_block(q, kmax - 1, w, h, stride)
+        ok, dec = ref.decode_block(cup + tail, kmax - 1, w, h, stride, len2=len(tail), num_passes=npass, stripe_causal=causal)
+        ok1, dec1 = ref.decode_block(cup + tail, kmax - 1, w, h, stride, len2=len(tail), num_passes=npass, variant=1,
+                                     stripe_causal=causal)
+        assert ok and ok1 and np.array_equal(dec[:, :w], dec1[:, :w])
+        out["refine"].append({"case": i, "dec_sha256": sha(np.ascontiguousarray(dec[:, :w]).tobytes())})
     # (b) codestreams
     for i, case in enumerate(STREAM_CASES):
         img, kw = stream_kwargs(case)

@@ -49,3 +49,31 @@ def stream_kwargs(case, seed=3):
     signed = c.pop("signed", False)
     img = synth_image(nc, h, w, bd, seed=seed, signed=signed)
     return img, dict(c, bit_depth=bd, is_signed=signed)
+
+
+# code-blocks that also carry SigProp (+ MagRef) segments of random bytes:
+# (w, h, K_max, density, amplitude, seed, num_passes, len2, stripe_causal)
+REFINE_CASES = [
+    (64, 64, 10, 0.5, 300, 31, 2, 200, False), (64, 64, 10, 0.5, 300, 31, 3, 200, False),
+    (64, 64, 6, 0.05, 20, 32, 3, 500, False), (64, 64, 14, 0.9, 5000, 33, 3, 1500, True),
+    (32, 32, 9, 0.3, 200, 34, 2, 90, True), (17, 64, 8, 0.4, 100, 35, 3, 77, False),
+    (64, 17, 8, 0.4, 100, 36, 3, 77, False), (4, 1024, 10, 0.4, 400, 37, 3, 300, False),
+    (1024, 4, 10, 0.4, 400, 38, 3, 300, True), (1, 1, 6, 1.0, 20, 39, 3, 5, False),
+    (5, 7, 7, 0.6, 60, 40, 2, 9, False), (63, 61, 12, 0.2, 900, 41, 3, 1, False),
+    (128, 32, 11, 0.5, 900, 42, 3, 2046, False), (64, 64, 30, 0.6, 500000000, 43, 3, 64, False),
+]
+
+
+def refine_case(i):
+    """-> (cleanup bytes from the oracle encoder is NOT used here: callers pass them) parameters + refinement bytes"""
+    import numpy as np
+    w, h, kmax, density, amp, seed, npass, len2, causal = REFINE_CASES[i]
+    rng = np.random.default_rng(seed)
+    from tests.synth import random_block
+    stride = (w + 15) // 16 * 16
+    q, _ = random_block(rng, w, h, stride, kmax, density, amp)
+    q[:, w:] = 0
+    tail = bytes(rng.integers(0, 256, size=len2, dtype=np.uint8))
+    if i % 3 == 0:                       # runs of the bytes the stuffing rules care about
+        tail = bytes((0xFF, 0x7F, 0x8F, 0x90, 0xFF, 0xFF)[j % 6] if (j // 7) % 2 else tail[j] for j in range(len2))
+    return q, w, h, stride, kmax, npass, causal, tail

@@ -18,7 +18,7 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import BLOCK_CASES, STREAM_CASES, stream_kwargs
+from tests.golden_cases import BLOCK_CASES, REFINE_CASES, STREAM_CASES, refine_case, stream_kwargs
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -117,6 +117,71 @@ def test_block_oracle_matches_live_reference(i, ref):
         okr, decr = ref.decode_block(want, kmax - 1, w, h, stride, variant=variant)
         ok, dec = ob.ht_decode(want, w, h, stride, kmax - 1)
         assert ok and okr and np.array_equal(dec[:, :w], decr[:, :w])
+
+
+@pytest.mark.parametrize("i", range(len(REFINE_CASES)))
+def test_refinement_passes_oracle_matches_golden(i):
+    """SigProp + MagRef (ojph_block_decoder32.cpp:1318-1609): random refinement bytes behind a
+    cleanup pass; the reference's decode of them is stored in tests/golden."""
+    from oracle import oraclebind as ob
+    q, w, h, stride, kmax, npass, causal, tail = refine_case(i)
+    cup = ob.ht_encode(q, w, h, stride, kmax - 1)
+    ok, dec = ob.ht_decode(cup + tail, w, h, stride, kmax - 1, len2=len(tail), num_passes=npass, stripe_causal=causal)
+    assert ok and sha(np.ascontiguousarray(dec[:, :w]).tobytes()) == GOLD["refine"][i]["dec_sha256"]
+
+
+def test_refinement_passes_oracle_matches_live_reference(ref):
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(123)
+    shapes = [(64, 64), (32, 32), (17, 64), (64, 17), (5, 7), (4, 1024), (1024, 4), (63, 63), (128, 32), (1, 1)]
+    for it in range(60):
+        w, h = shapes[it % len(shapes)]
+        st = (w + 7) & ~7
+        kmax = int(rng.integers(3, 20))
+        sm, v = random_block(rng, w, h, w, kmax, float(rng.choice([0.02, 0.2, 0.6])), int(min(2 ** kmax - 1, rng.choice([3, 40, 700]))))
+        if not np.any(v[:, :w]):
+            continue
+        cup = ob.ht_encode(sm, w, h, w, kmax - 1)
+        tail = bytes(rng.integers(0, 256, size=int(rng.integers(1, 400)), dtype=np.uint8))
+        for npass in (2, 3):
+            for causal in (False, True):
+                for variant in (0, 1):
+                    okr, decr = ref.decode_block(cup + tail, kmax - 1, w, h, st, len2=len(tail), num_passes=npass,
+                                                 variant=variant, stripe_causal=causal)
+                    ok, dec = ob.ht_decode(cup + tail, w, h, st, kmax - 1, len2=len(tail), num_passes=npass,
+                                           stripe_causal=causal)
+                    assert ok == okr and np.array_equal(dec[:, :w], decr[:, :w])
+
+
+def test_multi_pass_codestream_matches_live_reference(refgen):
+    """A codestream whose blocks carry SigProp / MagRef segments (built with the product's Tier-2
+    writer from random refinement bytes): the reference library decodes it to the same image."""
+    from tests import cpu_pipeline as cp
+    rng = np.random.default_rng(5)
+    for kw in (dict(bit_depth=8), dict(bit_depth=10, reversible=False, qstep=0.004, tile=(128, 128))):
+        img = synth_image(1 if "tile" in kw else 3, 200, 260, kw["bit_depth"], seed=2)
+        cs0, plan, arena, data, coded = cp.encode(img, **kw)
+        data2, coded2 = cp.add_refinement(data, coded, rng)
+        cs = plan.t2_write(data2, coded2)
+        assert len(cs) > len(cs0)
+        want, _ = refgen.decode(cs)
+        got, plan2 = cp.decode(cs)
+        assert int((plan2.coded_blocks()["num_passes"] > 1).sum()) > 10
+        assert np.array_equal(got, want)
+
+
+def test_foreign_codestream_of_the_reference_tree(refgen):
+    """subprojects/js/html/test.j2c (a foreign encoder's stream: per-resolution precincts, ICT, 77
+    blocks with SigProp / MagRef passes) -- only where /root/reference exists."""
+    path = "/root/reference/subprojects/js/html/test.j2c"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    from tests import cpu_pipeline as cp
+    cs = open(path, "rb").read()
+    want, _ = refgen.decode(cs)
+    got, plan = cp.decode(cs)
+    assert int((plan.coded_blocks()["num_passes"] > 1).sum()) == 77
+    assert np.array_equal(got, want)
 
 
 def test_decoder_rejects_what_the_reference_rejects(ref):

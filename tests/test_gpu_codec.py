@@ -125,3 +125,19 @@ def test_frame_batch_equals_frame_by_frame(kw):
     for f in range(B):
         want_dec, _ = cp.decode(streams[f])
         assert np.array_equal(out[f], want_dec), "frame %d" % f
+
+
+def test_multi_pass_codestream_decodes_like_the_oracle():
+    """Foreign-style codestreams (blocks with SigProp / MagRef segments): GPU decode == oracle decode
+    (the oracle is pinned to the reference on such streams by tests/test_cpu_parity.py)."""
+    from openjph_amd import codec
+    from tests import cpu_pipeline as cp
+    rng = np.random.default_rng(5)
+    for kw in (dict(bit_depth=8, color_transform=True), dict(bit_depth=10, reversible=False, qstep=0.004, tile=(128, 128))):
+        img = synth_image(1 if "tile" in kw else 3, 200, 260, kw["bit_depth"], seed=2)
+        cs0, plan, arena, data, coded = cp.encode(img, **kw)
+        data2, coded2 = cp.add_refinement(data, coded, rng)
+        cs = plan.t2_write(data2, coded2)
+        want, _ = cp.decode(cs)
+        got = codec.decode(cs)
+        assert np.array_equal(got, want), "%d samples differ" % int((got != want).sum())

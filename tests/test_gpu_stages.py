@@ -251,3 +251,47 @@ def test_ht_decode_corrupt_segments_match_oracle():
         assert np.array_equal(g, want), "trial %d: %d samples differ" % (i, int((g != want).sum()))
         n_ok += ok
     assert 1 <= n_ok < len(trials)
+
+
+def test_ht_decode_refinement_passes_match_oracle():
+    """SigProp + MagRef passes (the fourth launch, ht_dec_refine_kernel): cleanup segments followed
+    by random refinement bytes, 2 and 3 passes, normal and vertically causal, all block shapes."""
+    torch = _torch()
+    from openjph_amd import codec
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(31)
+    shapes = [(64, 64)] * 4 + [(32, 32), (17, 64), (64, 17), (5, 7), (4, 1024), (1024, 4), (63, 63), (128, 32), (1, 1), (2, 3)]
+    trials = []
+    for it in range(84):
+        w, h = shapes[it % len(shapes)]
+        kmax = int(rng.integers(3, 22))
+        sm, v = random_block(rng, w, h, w, kmax, float(rng.choice([0.02, 0.2, 0.6, 1.0])), int(min(2 ** kmax - 1, rng.choice([3, 40, 700]))))
+        if not np.any(v[:, :w]):
+            continue
+        cup = ob.ht_encode(sm, w, h, w, kmax - 1, 0)
+        tail = bytes(rng.integers(0, 256, size=int(rng.integers(1, 2046 if it % 9 == 0 else 300)), dtype=np.uint8))
+        trials.append((w, h, kmax, cup, tail, int(rng.integers(2, 4)), bool(rng.integers(0, 2)), bool(it % 2)))
+    descs = np.zeros(len(trials), codec.cb_desc_dtype)
+    off = doff = 0
+    datas, expect = [], []
+    for i, (w, h, kmax, cup, tail, npass, causal, rev) in enumerate(trials):
+        pitch = (w + 63) & ~63
+        d = descs[i]
+        d["coef_off"], d["pitch"], d["w"], d["h"] = off, pitch, w, h
+        d["K_max"], d["reversible"], d["missing_msbs"] = kmax, (1 if rev else 0) | (2 if causal else 0), kmax - 1
+        d["delta"] = 0.37 / (1 << 20)
+        d["num_passes"], d["len1"], d["len2"], d["data_off"] = npass, len(cup), len(tail), doff
+        ok, dec = ob.ht_decode(cup + tail, w, h, w, kmax - 1, len2=len(tail), num_passes=npass, stripe_causal=causal)
+        assert ok
+        expect.append(ob.dequant_rev(dec, kmax) if rev else ob.dequant_irv(dec, float(d["delta"])).view(np.int32))
+        datas.append(np.frombuffer(cup + tail, np.uint8))
+        off += pitch * h; doff += len(cup) + len(tail)
+    coef = torch.full((off + 64,), 0x5A5A5A5A, dtype=torch.int32).cuda()
+    status = codec.ht_decode(descs, np.concatenate(datas), coef)
+    got = coef.cpu().numpy()
+    assert not status.any()
+    for i, (w, h, kmax, cup, tail, npass, causal, rev) in enumerate(trials):
+        d = descs[i]
+        g = np.lib.stride_tricks.as_strided(got[int(d["coef_off"]):], (h, w), (int(d["pitch"]) * 4, 4))
+        assert np.array_equal(g, expect[i][:, :w]), "trial %d %s: %d samples differ" % (
+            i, (w, h, kmax, npass, causal, rev), int((g != expect[i][:, :w]).sum()))
