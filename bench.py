@@ -69,10 +69,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # OJPH_BENCH_BACKEND=gloo + OJPH_BENCH_ONE_GPU=1: smoke-test the N > 1 code path on a 1-GPU box
+    # (all ranks share cuda:0, control traffic over gloo).  The driver's runs use the defaults.
+    backend = os.environ.get("OJPH_BENCH_BACKEND", "nccl")
+    if os.environ.get("OJPH_BENCH_ONE_GPU"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -116,8 +121,9 @@ def main():
     if tiled:
         enc.run_device(d_img)
         part, lens = enc.finish_tiles()
-        all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=dev)
-        parts, _ = shard.gather_bytes(part, device=dev)          # RCCL: the final codestream gather
+        cdev = dev if backend == "nccl" else None                # device tensors over RCCL, host tensors over gloo
+        all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=cdev)
+        parts, _ = shard.gather_bytes(part, device=cdev)         # RCCL: the final codestream gather
         cs = shard.assemble(plan.t2_main_header(all_lens), parts) if rank == 0 else None
         box = [cs]
         dist.broadcast_object_list(box, src=0)                   # every rank decodes from the same stream
@@ -169,7 +175,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
