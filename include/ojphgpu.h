@@ -306,10 +306,19 @@ int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t le
 
 /* timing of the last run_device, in milliseconds, measured with HIP events on the codec's own
  * stream: out[0]=convert+colour [1]=DWT [2]=HT block coder [3]=total */
+/* per_launch = 1 (default): every launch is bracketed by HIP events so that the per-stage sums below
+ * are available; 0: only the wall time of the run is recorded (out[3]), the other entries read 0 --
+ * the event pairs cost a few microseconds each, which shows at these kernel durations */
+int  ojphgpu_encoder_set_timing(ojphgpu_encoder* enc, int per_launch);
+int  ojphgpu_decoder_set_timing(ojphgpu_decoder* dec, int per_launch);
 int  ojphgpu_encoder_timing(ojphgpu_encoder* enc, float out[4]);
 int  ojphgpu_decoder_timing(ojphgpu_decoder* dec, float out[4]);
 /* the block decoder's three launches of the last run_device: out[0]=prep [1]=step 1 [2]=step 2 (ms) */
 int  ojphgpu_decoder_ht_timing(ojphgpu_decoder* dec, float out[3]);
+/* the block encoder's launches of the last run_device, in issue order: when the top resolution's
+ * blocks are coded on the side stream (single frames with >= 2 decompositions) there are two --
+ * [0] = those blocks (*n_top of them, concurrent with the lower DWT levels), [1] = the rest */
+int  ojphgpu_encoder_ht_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, uint32_t* n, uint32_t* n_top);
 /* duration (ms) of every DWT level launch of the last run_device, in launch order (encode:
  * highest resolution first; decode: lowest first); *n = number of levels written */
 int  ojphgpu_encoder_level_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, uint32_t* n);

@@ -155,6 +155,9 @@ SIGNATURES = {
     "ojphgpu_decoder_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_decoder_failed_blocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "ojphgpu_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ojphgpu_encoder_ht_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ojphgpu_encoder_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ojphgpu_decoder_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ojphgpu_encoder_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_decoder_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_encoder_level_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -77,6 +77,9 @@ class Encoder:
         assert d_image.is_contiguous()
         check(self._lib.ojphgpu_encoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device")
 
+    def set_timing(self, per_launch: bool):
+        check(self._lib.ojphgpu_encoder_set_timing(self._h, int(per_launch)), "encoder_set_timing")
+
     def coded_bytes(self):
         n = C.c_uint64()
         check(self._lib.ojphgpu_encoder_coded_bytes(self._h, C.byref(n)), "encoder_coded_bytes")
@@ -126,7 +129,16 @@ class Encoder:
         check(self._lib.ojphgpu_encoder_timing(self._h, t), "encoder_timing")
         lv = (C.c_float * 40)(); n = C.c_uint32()
         check(self._lib.ojphgpu_encoder_level_timing(self._h, lv, 40, C.byref(n)), "encoder_level_timing")
-        return dict(convert_ms=t[0], dwt_ms=t[1], ht_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)])
+        ht = (C.c_float * 4)(); nh = C.c_uint32(); ntop = C.c_uint32()
+        check(self._lib.ojphgpu_encoder_ht_timing(self._h, ht, 4, C.byref(nh), C.byref(ntop)), "encoder_ht_timing")
+        return dict(convert_ms=t[0], dwt_ms=t[1], ht_ms=t[2], total_ms=t[3], dwt_levels_ms=[lv[i] for i in range(n.value)],
+                    ht_launches_ms=[ht[i] for i in range(nh.value)])
+
+    def top_blocks(self):
+        """number of block descriptors coded on the side stream (0 = no overlap)"""
+        ht = (C.c_float * 4)(); nh = C.c_uint32(); ntop = C.c_uint32()
+        check(self._lib.ojphgpu_encoder_ht_timing(self._h, ht, 4, C.byref(nh), C.byref(ntop)), "encoder_ht_timing")
+        return int(ntop.value)
 
 
 class Decoder:
@@ -180,6 +192,9 @@ class Decoder:
             d_image = alloc(self.shape, dtype=torch.int32, device="cuda:%d" % self.device)
         check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
         return d_image
+
+    def set_timing(self, per_launch: bool):
+        check(self._lib.ojphgpu_decoder_set_timing(self._h, int(per_launch)), "decoder_set_timing")
 
     def failed_blocks(self):
         n = C.c_uint32()

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
   uint32_t* plane = coef + d.coef_off;
   const bool rev = (d.reversible & 1u) != 0, causal = (d.reversible & 2u) != 0;
   const uint32_t p = 30u - d.missing_msbs;
-  const int ngroups = (int)((W + 3) >> 2), nstripes = (int)((H + 3) >> 2), mstr = ngroups + 2;
+  const int ngroups = (int)((W + 3) >> 2), mstr = ngroups + 2;
 
   for (uint32_t i = lane; i < SIG_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.sigma)[i] = 0;
   for (uint32_t i = lane; i < PREV_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.prev_row)[i] = 0;

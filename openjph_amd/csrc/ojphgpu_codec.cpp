@@ -195,38 +195,57 @@ std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
   return ids;
 }
 
-// HIP events on the codec's own stream: 4 stage marks + one mark after every DWT level launch
-struct Timer {
-  static constexpr int MAXLV = 34;
-  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-  hipEvent_t lv[MAXLV] = { nullptr };
-  int nlv = 0;
+// Timing of one run_device: every launch (or group of launches) is bracketed by a pair of HIP events
+// on the stream it is issued on -- launches of one run may sit on two streams -- and tagged with a
+// kind; per-kind sums and the wall time of the whole run are read back afterwards.
+struct Spans {
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> pool;            // events are created once and reused
+  size_t used = 0;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
   bool ok = false;
-  int init() {
-    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1;
-    for (auto& e : lv) if (hipEventCreate(&e) != hipSuccess) return -1;
-    ok = true; return 0;
+  bool detail = true;                // per-launch spans on; off = only the wall time of the run (two events)
+  int init() { ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess; return ok ? 0 : -1; }
+  void destroy() {
+    for (Span& x : pool) { (void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b); }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    pool.clear();
   }
-  void destroy() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& e : lv) if (e) (void)hipEventDestroy(e); }
-  void mark(int i, hipStream_t s) { if (ok) (void)hipEventRecord(ev[i], s); }
-  void begin_levels() { nlv = 0; }
-  void mark_level(hipStream_t s) { if (ok && nlv < MAXLV) (void)hipEventRecord(lv[nlv++], s); }
-  int read(float out[4]) {
-    if (!ok) return -1;
-    if (hipEventSynchronize(ev[3]) != hipSuccess) return -1;
-    for (int i = 0; i < 3; ++i) if (hipEventElapsedTime(&out[i], ev[i], ev[i + 1]) != hipSuccess) return -1;
-    if (hipEventElapsedTime(&out[3], ev[0], ev[3]) != hipSuccess) return -1;
+  void start(hipStream_t s) { used = 0; if (ok) (void)hipEventRecord(t0, s); }
+  void finish(hipStream_t s) { if (ok) (void)hipEventRecord(t1, s); }
+  int begin(int kind, hipStream_t s) {
+    if (!ok || !detail) return -1;
+    if (used == pool.size()) {
+      Span x{ nullptr, nullptr, kind };
+      if (hipEventCreate(&x.a) != hipSuccess || hipEventCreate(&x.b) != hipSuccess) { ok = false; return -1; }
+      pool.push_back(x);
+    }
+    pool[used].kind = kind;
+    (void)hipEventRecord(pool[used].a, s);
+    return (int)used++;
+  }
+  void end(int id, hipStream_t s) { if (ok && id >= 0) (void)hipEventRecord(pool[(size_t)id].b, s); }
+  // sum of the spans of `kind`; kind < 0: wall time of the run
+  int read(int kind, float* out) {
+    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
+    if (kind < 0) return hipEventElapsedTime(out, t0, t1) == hipSuccess ? 0 : -1;
+    float sum = 0;
+    for (size_t i = 0; i < used; ++i)
+      if (pool[i].kind == kind) { float ms = 0; if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) != hipSuccess) return -1; sum += ms; }
+    *out = sum;
     return 0;
   }
-  // per-level DWT launch durations; `before` = the stage mark preceding the first level
-  int read_levels(int before, float* out, uint32_t cap) {
-    if (!ok) return -1;
-    if (hipEventSynchronize(ev[3]) != hipSuccess) return -1;
-    for (int i = 0; i < nlv && (uint32_t)i < cap; ++i)
-      if (hipEventElapsedTime(&out[i], i == 0 ? ev[before] : lv[i - 1], lv[i]) != hipSuccess) return -1;
-    return nlv;
+  // the individual spans of `kind`, in issue order
+  int read_each(int kind, float* out, uint32_t cap) {
+    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
+    int n = 0;
+    for (size_t i = 0; i < used; ++i)
+      if (pool[i].kind == kind && (uint32_t)n < cap) { if (hipEventElapsedTime(&out[n], pool[i].a, pool[i].b) != hipSuccess) return -1; ++n; }
+    return n;
   }
 };
+enum { SP_CONVERT = 0, SP_DWT = 1, SP_HT_ENC = 2, SP_PREP = 3, SP_STEP1 = 4, SP_STEP2 = 5, SP_REFINE = 6 };
 
 }  // namespace
 
@@ -246,8 +265,14 @@ struct ojphgpu_encoder {
   std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes (per frame)
   std::vector<ojphgpu_cb_result> h_results;
   HostBuf h_out, h_res;
-  Timer timer;
+  Spans timer;
   bool ran = false;
+  // overlap of the block coder with the lower DWT levels: the blocks of the top resolution (3/4 of
+  // the samples) only need the first DWT level, so they are coded on a second stream while the
+  // small, latency-bound launches of levels 2..L run on the main one
+  uint32_t n_top = 0;                              // descriptors [0, n_top) = blocks of the top resolution
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
@@ -257,6 +282,9 @@ extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
   for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->img_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
                         &e->results, &e->counters }) b->release();
   e->h_out.release(); e->h_res.release();
+  if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   e->timer.destroy();
   delete e;
 }
@@ -310,6 +338,15 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
   replicate_converts(cd, nframes, P.arena_elems);
   e->block_ids = blocks_of_tiles(P, tr);
+  if (nframes == 1 && P.p.num_decomps >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
+    auto top = [&](uint32_t id) { return P.bands[P.blocks[id].band].res == P.p.num_decomps; };
+    auto mid = std::stable_partition(e->block_ids.begin(), e->block_ids.end(), top);
+    e->n_top = (uint32_t)(mid - e->block_ids.begin());
+    if (e->n_top == 0 || e->n_top == e->block_ids.size()) e->n_top = 0;
+    else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  }
   std::vector<ojphgpu_cb_desc> bd(e->block_ids.size());
   uint64_t scratch_bytes = 0, samples = 0;
   for (size_t i = 0; i < bd.size(); ++i) {
@@ -358,16 +395,22 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   if (!e || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
   hipStream_t s = e->stream;
+  Spans& T = e->timer;
   HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
-  e->timer.mark(0, s);
+  T.start(s);
   int rc = OJPHGPU_OK;
-  if (!e->fused_convert)
+  if (!e->fused_convert) {
+    const int sp = T.begin(SP_CONVERT, s);
     rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
                                  e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
+    T.end(sp, s);
+  }
   if (rc) return rc;
-  e->timer.mark(1, s);
-  e->timer.begin_levels();
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)e->cb_descs.p;
+  ojphgpu_cb_result* res = (ojphgpu_cb_result*)e->results.p;
+  uint32_t* cnt = (uint32_t*)e->counters.p;
   for (const LevelBatch& b : e->batches) {
+    const int sp = T.begin(SP_DWT, s);
     if (e->fused_convert && &b == &e->batches.front())      // level shift / int->float applied in the loads
       rc = ojphgpu_dwt_forward_image(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
                                      d_image, e->arena.p);
@@ -375,15 +418,34 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
       rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
     if (rc) return rc;
-    e->timer.mark_level(s);
+    T.end(sp, s);
+    if (e->n_top && &b == &e->batches.front()) {            // fork: the top resolution's blocks are ready to be coded
+      HIPCHK(hipEventRecord(e->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+      const int sh = T.begin(SP_HT_ENC, e->side);
+      rc = ojphgpu_ht_encode(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap,
+                             res, cnt, cnt + 1);
+      if (rc) return rc;
+      T.end(sh, e->side);
+      HIPCHK(hipEventRecord(e->ev_join, e->side));
+    }
   }
-  e->timer.mark(2, s);
-  rc = ojphgpu_ht_encode(s, (const ojphgpu_cb_desc*)e->cb_descs.p, (uint32_t)e->block_ids.size() * e->nframes, e->arena.p,
-                         (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap, (ojphgpu_cb_result*)e->results.p,
-                         (uint32_t*)e->counters.p, (uint32_t*)e->counters.p + 1);
+  const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
+  const int sh = T.begin(SP_HT_ENC, s);
+  rc = ojphgpu_ht_encode(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
+                         e->out_cap, res + e->n_top, cnt, cnt + 1);
   if (rc) return rc;
-  e->timer.mark(3, s);
+  T.end(sh, s);
+  if (e->n_top) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));     // join
+  T.finish(s);
   e->ran = true; e->fetched = false;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_set_timing(ojphgpu_encoder* e, int per_launch)
+{
+  if (!e) return OJPHGPU_E_INVALID;
+  e->timer.detail = per_launch != 0;
   return OJPHGPU_OK;
 }
 
@@ -477,13 +539,25 @@ extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_
 extern "C" int ojphgpu_encoder_timing(ojphgpu_encoder* e, float out[4])
 {
   if (!e || !out || !e->ran) return OJPHGPU_E_INVALID;
-  return e->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  if (e->timer.read(SP_CONVERT, &out[0]) || e->timer.read(SP_DWT, &out[1]) || e->timer.read(SP_HT_ENC, &out[2]) ||
+      e->timer.read(-1, &out[3])) return OJPHGPU_E_HIP;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_encoder_ht_timing(ojphgpu_encoder* e, float* out, uint32_t cap, uint32_t* n, uint32_t* n_top)
+{
+  if (!e || !out || !n || !e->ran) return OJPHGPU_E_INVALID;
+  int k = e->timer.read_each(SP_HT_ENC, out, cap);
+  if (k < 0) return OJPHGPU_E_HIP;
+  *n = (uint32_t)k;
+  if (n_top) *n_top = e->n_top;
+  return OJPHGPU_OK;
 }
 
 extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint32_t cap, uint32_t* n)
 {
   if (!e || !out || !n || !e->ran) return OJPHGPU_E_INVALID;
-  int k = e->timer.read_levels(1, out, cap);
+  int k = e->timer.read_each(SP_DWT, out, cap);
   if (k < 0) return OJPHGPU_E_HIP;
   *n = (uint32_t)k;
   return OJPHGPU_OK;
@@ -494,7 +568,12 @@ struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
-  hipEvent_t ht_ev[2] = { nullptr, nullptr };      // between prep | step 1 | step 2
+  // blocks of the top resolution (descriptors [0, n_top)) are decoded on a second stream while the
+  // main one decodes the rest and runs the lower synthesis levels; the serial chains of step 1, which
+  // bound the block decoder, then run for both groups at the same time
+  uint32_t n_top = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fused_convert = false;
   TileRange tiles{ 0, 0 };
   uint32_t nframes = 1;
@@ -504,7 +583,7 @@ struct ojphgpu_decoder {
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
   size_t data_first = 0, data_len = 0;              // byte range of the codestream holding this range's block data
-  Timer timer;
+  Spans timer;
   bool ran = false;
 };
 
@@ -514,7 +593,9 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
   (void)hipSetDevice(d->device);
   for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads, &d->aux })
     b->release();
-  for (auto& e : d->ht_ev) if (e) (void)hipEventDestroy(e);
+  if (d->side) (void)hipStreamDestroy(d->side);
+  if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+  if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   d->timer.destroy();
   delete d;
 }
@@ -580,7 +661,19 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
   replicate_converts(cd, nframes, P.arena_elems);
-  const std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
+  std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
+  // measured on MI355X: unlike in the encoder, the two-stream split does not pay here (both groups
+  // start with the VALU-heavy prep launch and then sit in their serial chains; 0.96 vs 0.91 ms at
+  // 8K), so it stays opt-in
+  if (nframes == 1 && P.p.num_decomps >= 2 && getenv("OJPHGPU_DEC_OVERLAP") != nullptr) {
+    auto top = [&](uint32_t id) { return P.bands[P.blocks[id].band].res == P.p.num_decomps; };
+    auto mid = std::stable_partition(ids.begin(), ids.end(), top);
+    d->n_top = (uint32_t)(mid - ids.begin());
+    if (d->n_top == 0 || d->n_top == ids.size()) d->n_top = 0;
+    else if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  }
   d->nblocks = (uint32_t)(ids.size() * nframes);
   std::vector<ojphgpu_cb_desc> bd(ids.size() * nframes);
   uint64_t nquads = 0, naux = 0, data_total = 0;
@@ -620,7 +713,6 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   d->data_len = (size_t)data_total;
   if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
-  for (auto& e : d->ht_ev) if (hipEventCreate(&e) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
@@ -649,46 +741,81 @@ extern "C" int ojphgpu_decoder_upload_frame(ojphgpu_decoder* d, uint32_t frame, 
   return OJPHGPU_OK;
 }
 
+// the block decoder over descriptors [first, first + count) on stream s
+static int decode_blocks(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uint32_t count)
+{
+  if (count == 0) return OJPHGPU_OK;
+  Spans& T = d->timer;
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p + first;
+  uint8_t* status = (uint8_t*)d->status.p + first;
+  int sp = T.begin(SP_PREP, s);
+  int rc = ojphgpu_ht_decode_prep(s, cbd, count, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
+  if (rc) return rc;
+  T.end(sp, s);
+  sp = T.begin(SP_STEP1, s);
+  rc = ojphgpu_ht_decode_step1(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p, (uint32_t*)d->quads.p, status);
+  if (rc) return rc;
+  T.end(sp, s);
+  sp = T.begin(SP_STEP2, s);
+  rc = ojphgpu_ht_decode_step2(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p, status);
+  if (rc) return rc;
+  T.end(sp, s);
+  if (d->any_refine) {
+    sp = T.begin(SP_REFINE, s);
+    rc = ojphgpu_ht_decode_refine(s, cbd, count, (const uint8_t*)d->data.p, d->arena.p, status);
+    if (rc) return rc;
+    T.end(sp, s);
+  }
+  return OJPHGPU_OK;
+}
+
 extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
 {
   if (!d || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
   hipStream_t s = d->stream;
-  d->timer.mark(0, s);
-  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p;
-  int rc = ojphgpu_ht_decode_prep(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
-  if (rc) return rc;
-  (void)hipEventRecord(d->ht_ev[0], s);
-  rc = ojphgpu_ht_decode_step1(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p,
-                               (uint32_t*)d->quads.p, (uint8_t*)d->status.p);
-  if (rc) return rc;
-  (void)hipEventRecord(d->ht_ev[1], s);
-  rc = ojphgpu_ht_decode_step2(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p,
-                               (uint8_t*)d->status.p);
-  if (rc) return rc;
-  if (d->any_refine) {
-    rc = ojphgpu_ht_decode_refine(s, cbd, d->nblocks, (const uint8_t*)d->data.p, d->arena.p, (const uint8_t*)d->status.p);
+  Spans& T = d->timer;
+  T.start(s);
+  int rc;
+  if (d->n_top) {                                           // fork: top-resolution blocks on the side stream
+    HIPCHK(hipEventRecord(d->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    rc = decode_blocks(d, d->side, 0, d->n_top);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(d->ev_join, d->side));
   }
-  d->timer.mark(1, s);
-  d->timer.begin_levels();
+  rc = decode_blocks(d, s, d->n_top, d->nblocks - d->n_top);
+  if (rc) return rc;
   for (const LevelBatch& b : d->batches) {
-    if (d->fused_convert && &b == &d->batches.back())       // float->int / level shift applied in the stores
+    const bool last = &b == &d->batches.back();
+    if (last && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));     // join before the top synthesis level
+    const int sp = T.begin(SP_DWT, s);
+    if (d->fused_convert && last)                           // float->int / level shift applied in the stores
       rc = ojphgpu_dwt_inverse_image(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
                                      d_image, d->arena.p);
     else
       rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;
-    d->timer.mark_level(s);
+    T.end(sp, s);
   }
-  d->timer.mark(2, s);
-  if (!d->fused_convert)
+  if (d->batches.empty() && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));
+  if (!d->fused_convert) {
+    const int sp = T.begin(SP_CONVERT, s);
     rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
                                  d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
-  if (rc) return rc;
-  d->timer.mark(3, s);
+    if (rc) return rc;
+    T.end(sp, s);
+  }
+  T.finish(s);
   d->ran = true;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_set_timing(ojphgpu_decoder* d, int per_launch)
+{
+  if (!d) return OJPHGPU_E_INVALID;
+  d->timer.detail = per_launch != 0;
   return OJPHGPU_OK;
 }
 
@@ -725,23 +852,24 @@ extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, s
 extern "C" int ojphgpu_decoder_timing(ojphgpu_decoder* d, float out[4])
 {
   if (!d || !out || !d->ran) return OJPHGPU_E_INVALID;
-  return d->timer.read(out) == 0 ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  float a = 0, b = 0, c = 0, r = 0;
+  if (d->timer.read(SP_PREP, &a) || d->timer.read(SP_STEP1, &b) || d->timer.read(SP_STEP2, &c) || d->timer.read(SP_REFINE, &r) ||
+      d->timer.read(SP_DWT, &out[1]) || d->timer.read(SP_CONVERT, &out[2]) || d->timer.read(-1, &out[3])) return OJPHGPU_E_HIP;
+  out[0] = a + b + c + r;
+  return OJPHGPU_OK;
 }
 
 extern "C" int ojphgpu_decoder_ht_timing(ojphgpu_decoder* d, float out[3])
 {
-  if (!d || !out || !d->ran || !d->timer.ok) return OJPHGPU_E_INVALID;
-  if (hipEventSynchronize(d->timer.ev[3]) != hipSuccess) return OJPHGPU_E_HIP;
-  if (hipEventElapsedTime(&out[0], d->timer.ev[0], d->ht_ev[0]) != hipSuccess ||
-      hipEventElapsedTime(&out[1], d->ht_ev[0], d->ht_ev[1]) != hipSuccess ||
-      hipEventElapsedTime(&out[2], d->ht_ev[1], d->timer.ev[1]) != hipSuccess) return OJPHGPU_E_HIP;
+  if (!d || !out || !d->ran) return OJPHGPU_E_INVALID;
+  if (d->timer.read(SP_PREP, &out[0]) || d->timer.read(SP_STEP1, &out[1]) || d->timer.read(SP_STEP2, &out[2])) return OJPHGPU_E_HIP;
   return OJPHGPU_OK;
 }
 
 extern "C" int ojphgpu_decoder_level_timing(ojphgpu_decoder* d, float* out, uint32_t cap, uint32_t* n)
 {
   if (!d || !out || !n || !d->ran) return OJPHGPU_E_INVALID;
-  int k = d->timer.read_levels(1, out, cap);
+  int k = d->timer.read_each(SP_DWT, out, cap);
   if (k < 0) return OJPHGPU_E_HIP;
   *n = (uint32_t)k;
   return OJPHGPU_OK;

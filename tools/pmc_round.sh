@@ -10,6 +10,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python bench.py --steps 3 --warmup 1 --no-cpu-baseline --calibrate 2>&1 | tail -2 ) > gpurun_out/pmc_$C.log
   find gpurun_out/pmc_$C -type f | head -5 >> gpurun_out/pmc_$C.log
 done
-python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.md 2> gpurun_out/pmc_summary.err
+python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic_c3.json > gpurun_out/pmc_summary.md 2> gpurun_out/pmc_summary.err
 cat gpurun_out/pmc_summary.md | head -30
 find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -type f -size +8M -delete

@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
-"""Per-kernel average FETCH_SIZE / WRITE_SIZE from two rocprofv3 --pmc csv passes.
-Usage: pmc_summary.py <dir_fetch> <dir_write>.  Values are the raw counter units (KiB)."""
+"""Per-kernel FETCH_SIZE / WRITE_SIZE from two rocprofv3 --pmc csv passes.
+Usage: pmc_summary.py <dir_fetch> <dir_write> [out.json].  Table values are the raw counter units
+(KiB); the optional JSON holds HBM bytes per launch for bench.py's `roofline.traffic`:
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE counts 64 B per 128-B request on gfx950
+(MI355X_MICROARCH.md, confirmed by the calibration kernel in the same passes)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 
 def load(d):
-    acc = defaultdict(lambda: [0.0, 0])
+    acc = defaultdict(float)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
             val = float(row.get("Counter_Value") or row.get("Counter Value") or 0)
-            did = row.get("Dispatch_Id") or row.get("Dispatch Id")
-            acc[(name, did)][0] += val       # a counter may be split over several rows (per XCC)
-            acc[(name, did)][1] = 1
+            did = int(row.get("Dispatch_Id") or row.get("Dispatch Id") or 0)
+            acc[(name, did)] += val          # a counter may be split over several rows (per XCC)
     per = defaultdict(list)
-    for (name, _), (v, _) in acc.items():
+    for (name, did), v in sorted(acc.items(), key=lambda kv: kv[0][1]):
         per[name].append(v)
     return per
 
@@ -32,6 +35,46 @@ def main():
         f, w = fe.get(n, []), wr.get(n, [])
         short = n if len(n) < 100 else n[:97] + "..."
         print("| `%s` | %d | %.1f | %.1f |" % (short, max(len(f), len(w)), sum(f) / max(len(f), 1), sum(w) / max(len(w), 1)))
+    if len(sys.argv) > 3:
+        def avg(v):
+            return sum(v) / max(len(v), 1)
+
+        def pick(sub, tmpl=None):
+            ks = [k for k in names if sub in k and (tmpl is None or tmpl in k)]
+            return ks[0] if ks else None
+
+        def traffic(k, sel=None):
+            if k is None:
+                return None
+            f, w = fe.get(k, []), wr.get(k, [])
+            if sel is not None:               # launches of one kernel that alternate between two sizes
+                big_f = sorted(f)[len(f) // 2:] if sel == "big" else sorted(f)[:len(f) // 2]
+                big_w = sorted(w)[len(w) // 2:] if sel == "big" else sorted(w)[:len(w) // 2]
+                f, w = big_f, big_w
+            return int((2 * avg(f) + avg(w)) * 1024)
+
+        enc = pick("ht_encode_kernel")
+        two = enc is not None and len(fe.get(enc, [])) >= 4 and max(fe[enc]) > 1.5 * min(fe[enc])
+        out = {
+            "_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from the PMC passes summarised next to this "
+                     "file; x2 = gfx950 FETCH_SIZE correction (calibrated on an elementwise kernel of known traffic in "
+                     "the same passes); multi-launch stages are per frame",
+            "ht_dec_prep": traffic(pick("ht_dec_prep")), "ht_dec_step1": traffic(pick("ht_dec_step1")),
+            "ht_dec_step2": traffic(pick("ht_dec_step2")),
+        }
+        if two:
+            out["ht_encode[top resolution, side stream]"] = traffic(enc, "big")
+            out["ht_encode[lower resolutions]"] = traffic(enc, "small")
+        else:
+            out["ht_encode"] = traffic(enc)
+        for d, img in (("forward", "dwt_forward_kernel<false, true>"), ("inverse", "dwt_inverse_kernel<false, true>")):
+            top = pick(img) or pick("dwt_%s_kernel<true, true>" % d)
+            low = pick("dwt_%s_kernel<false, false>" % d) or pick("dwt_%s_kernel<true, false>" % d)
+            if top and low:
+                nl = len(fe.get(low, [])) // max(len(fe.get(top, [])), 1)
+                out["dwt_%s(all levels)" % d] = traffic(top) + nl * traffic(low)
+                out["dwt_%s(level 1)" % d] = traffic(top)
+        json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
