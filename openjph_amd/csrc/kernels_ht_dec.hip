@@ -287,6 +287,9 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   __shared__ uint16_t s_vlc[2048];
   __shared__ uint16_t s_uvlc0[320];
   __shared__ uint16_t s_uvlc1[256];
+  // these few wavefronts are bound by the latency of their serial chains: when another launch shares
+  // the SIMDs (another stream, or the tail of the prep launch) they should win the issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
   for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
   for (int i = threadIdx.x; i < 256; i += blockDim.x) s_uvlc1[i] = ojphgpu::g_dec_uvlc1[i];
