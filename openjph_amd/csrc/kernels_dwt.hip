@@ -33,6 +33,7 @@
 //   origin) or doubled / halved (odd origin) without the K scaling.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/ojphgpu.h"
 
 namespace {
@@ -98,6 +99,8 @@ struct Geo {
   int j;                 // column-pair index of this lane in "u = x + ox" space
   bool eL, eH, eLn, eHp; // existence of own low/high column and of the neighbours' (j+1 low, j-1 high)
   bool store;            // lane is in the valid (non-halo) zone of its strip
+  int xc;                // first column of the lane's 2-sample row load, clamped into the row
+  bool from_y, from_x;   // clamped load: the low sample arrives in .y / the high sample arrives in .x
 };
 
 __device__ __forceinline__ bool col_exists(int x, int w) { return x >= 0 && x < w; }
@@ -147,6 +150,8 @@ __device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, 
   g.eL = col_exists(xl, g.w); g.eH = col_exists(xh, g.w);
   g.eLn = col_exists(xl + 2, g.w); g.eHp = col_exists(xh - 2, g.w);
   g.store = lane >= HALO && lane < 64 - HALO;
+  g.xc = max(min(xl, g.w - 2), 0);
+  g.from_y = xl > g.xc; g.from_x = xl < g.xc;
   return g;
 }
 
@@ -179,64 +184,59 @@ template <> struct Cv<false> {
   }
 };
 
-struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
+// 8-byte accesses that only promise dword alignment
+template <typename E> struct Vec2 { typedef E type __attribute__((ext_vector_type(2), aligned(4))); };
 
-// loads the lane's two columns of row `row` (plane-relative); missing samples read as 0.
-// IMG: `row` points into an int32 image plane and the samples are converted on the fly.
-template <bool REV, bool IMG>
-__device__ __forceinline__ Pair<typename Wv<REV>::T> load_pair(const void* __restrict__ rowp, const Geo& g, const Conv& cv)
+// Row loads are UNCONDITIONAL: every lane fetches two adjacent samples from a column clamped into
+// the row (and the callers clamp the row into the plane), and what a lane fetched is interpreted
+// only when it is consumed one iteration later (unpack).  No branch around a load and no use of the
+// loaded registers next to it means no wait at the load: the fetch of row pair t+1 is in flight
+// while pair t is lifted.  Samples that do not exist are never read by the lifting steps (pick()).
+template <typename E> struct Raw { E x, y; };
+template <typename E>
+__device__ __forceinline__ Raw<E> load_raw(const void* __restrict__ rowp, const Geo& g)
 {
-  typedef typename Wv<REV>::T T;
-  Pair<T> p; p.l = 0; p.h = 0;
-  const int xl = 2 * g.j - g.ox;
-  if (IMG) {
-    const int* row = (const int*)rowp;
-    int a = 0, b = 0;
-    if (g.eL && g.eH) { const I2 v = *reinterpret_cast<const I2*>(row + xl); a = v.x; b = v.y; }
-    else if (g.eL) a = row[xl];
-    else if (g.eH) b = row[xl + 1];
-    if (g.eL) p.l = Cv<REV>::from_image(a, cv);
-    if (g.eH) p.h = Cv<REV>::from_image(b, cv);
-  } else {
-    const T* row = (const T*)rowp;
-    if (g.ox == 0) {
-      if (g.eL && g.eH) {
-        typedef T V2 __attribute__((ext_vector_type(2)));
-        V2 v = *reinterpret_cast<const V2*>(row + xl);
-        p.l = v.x; p.h = v.y;
-      } else if (g.eL) p.l = row[xl];
-    } else {
-      if (g.eL) p.l = row[xl];
-      if (g.eH) p.h = row[xl + 1];
-    }
-  }
+  const E* row = (const E*)rowp;
+  Raw<E> r;
+  if (g.w == 1) { r.x = row[0]; r.y = r.x; }              // wave-uniform; the only sample is column 0
+  else { const typename Vec2<E>::type v = *reinterpret_cast<const typename Vec2<E>::type*>(row + g.xc); r.x = v.x; r.y = v.y; }
+  return r;
+}
+
+// IMG: the row came from an int32 image plane and is converted here
+template <bool REV, bool IMG, typename E>
+__device__ __forceinline__ Pair<typename Wv<REV>::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
+{
+  Pair<typename Wv<REV>::T> p;
+  const auto a = g.from_y ? v.y : v.x, b = g.from_x ? v.x : v.y;
+  if (IMG) { p.l = Cv<REV>::from_image((int)a, cv); p.h = Cv<REV>::from_image((int)b, cv); }
+  else { p.l = (typename Wv<REV>::T)a; p.h = (typename Wv<REV>::T)b; }
   return p;
 }
 
-template <bool REV, bool IMG>
-__device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
-                                           const Conv& cv)
+// stores the lane's two columns of a row; IMG: E = int, the values were converted by the caller
+template <typename E>
+__device__ __forceinline__ void store_cols(void* __restrict__ rowp, const Geo& g, E l, E h)
 {
-  typedef typename Wv<REV>::T T;
   if (!g.store) return;
+  E* row = (E*)rowp;
   const int xl = 2 * g.j - g.ox;
-  if (IMG) {
-    int* row = (int*)rowp;
-    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
-    if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
-    else if (g.eL) row[xl] = a;
-    else if (g.eH) row[xl + 1] = b;
-  } else {
-    T* row = (T*)rowp;
-    if (g.ox == 0 && g.eL && g.eH) {
-      typedef T V2 __attribute__((ext_vector_type(2)));
-      V2 v; v.x = l; v.y = h;
-      *reinterpret_cast<V2*>(row + xl) = v;
-    } else {
-      if (g.eL) row[xl] = l;
-      if (g.eH) row[xl + 1] = h;
-    }
-  }
+  if (g.eL && g.eH) { typename Vec2<E>::type v; v.x = l; v.y = h; *reinterpret_cast<typename Vec2<E>::type*>(row + xl) = v; }
+  else if (g.eL) row[xl] = l;
+  else if (g.eH) row[xl + 1] = h;
+}
+
+// Memory order inside one iteration of both kernels: consume what the previous iteration fetched,
+// THEN issue the stores of the previous iteration's results, THEN the fetches of the next iteration,
+// then compute.  gfx9 counts loads and stores in one in-order counter; with the stores placed just
+// before the fetches, the wait for those fetches one iteration later also covers the stores and
+// nothing is ever waited for right after it was issued.  arrived() pins that wait to the top of the
+// iteration on every control path (otherwise a path that skips a fetched row leaves the wait to the
+// next write of the same registers -- which comes right after the stores).
+template <typename A>
+__device__ __forceinline__ void arrived(const A& a, const A& b, const A& c, const A& d)
+{
+  asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,6 +249,8 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
+  typedef typename std::conditional<IMG, int, T>::type E;          // element type of the source rows
+  typedef Raw<E> RawRow;
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -267,12 +269,10 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  auto ldrow = [&](int y, bool ex) {                       // image row y of the plane (0 when it does not exist)
-    Pair<T> z; z.l = z.h = 0;
-    return ex ? load_pair<REV, IMG>(src + (size_t)y * sp, g, cv) : z;
+  auto ldrow = [&](int y) {                                // image row y, clamped into the plane
+    return load_raw<E>(src + (size_t)min(max(y, 0), h - 1) * sp, g);
   };
-  auto emit = [&](int t, bool low_row, T vl, T vh) {       // horizontal pass + store of one row
-    horz_analysis<REV>(vl, vh, g);
+  auto put = [&](int t, bool low_row, T vl, T vh) {        // one transformed row -> its two sub-bands
     if (!g.store) return;
     T* lo = low_row ? ll : lh; T* hi = low_row ? hl : hh;
     const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
@@ -283,9 +283,10 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 
   if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
     if (i0 > 0) return;
-    Pair<T> x = ldrow(0, true);
-    if (oy == 0) emit(0, true, x.l, x.h);
-    else emit(0, false, W::dbl(x.l), W::dbl(x.h));
+    Pair<T> x = unpack<REV, IMG>(ldrow(0), g, cv);
+    if (oy != 0) { x.l = W::dbl(x.l); x.h = W::dbl(x.h); }
+    horz_analysis<REV>(x.l, x.h, g);
+    put(0, oy == 0, x.l, x.h);
     return;
   }
 
@@ -293,15 +294,22 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const int t0 = max(i0 - (REV ? 1 : 2), 0);
   Pair<T> xl, xn, a, ap, b, bp, c, cp;   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
   xl.l = xl.h = 0; a = ap = b = bp = c = cp = xl;
-  xl = ldrow(2 * t0 - oy, exL(t0));
-  Pair<T> nh = ldrow(2 * t0 + 1 - oy, exH(t0)), nn = ldrow(2 * t0 + 2 - oy, exL(t0 + 1));   // rows of iteration t0
+  Pair<T> out_lo = xl, out_hi = xl;      // transformed rows of pair out_t, stored one iteration later
+  int out_t = 0; bool has_lo = false, has_hi = false;
+  xl = unpack<REV, IMG>(ldrow(2 * t0 - oy), g, cv);
+  RawRow rh = ldrow(2 * t0 + 1 - oy), rn = ldrow(2 * t0 + 2 - oy);            // rows of iteration t0
   for (int t = t0; t <= i1; ++t) {
-    const Pair<T> xh = nh; xn = nn;
-    const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
+    arrived(rh.x, rh.y, rn.x, rn.y);
+    const Pair<T> xh = unpack<REV, IMG>(rh, g, cv);
+    xn = unpack<REV, IMG>(rn, g, cv);
+    if (has_lo) put(out_t, true, out_lo.l, out_lo.h);
+    if (has_hi) put(out_t, false, out_hi.l, out_hi.h);
+    has_lo = has_hi = false;
     if (t < i1) {                                          // request the rows of iteration t+1 now
-      nh = ldrow(2 * t + 3 - oy, exH(t + 1));
-      nn = ldrow(2 * t + 4 - oy, exL(t + 2));
+      rh = ldrow(2 * t + 3 - oy);
+      rn = ldrow(2 * t + 4 - oy);
     }
+    const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
     // a[t]
     ap = a;
     a.l = W::a0(xh.l, pick(eLt, xl.l, xn.l), pick(eLn, xn.l, xl.l));
@@ -322,11 +330,20 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
     T dl = W::a3(bp.l, pick(eHpp, cp.l, c.l), pick(eHp, c.l, cp.l));
     T dh = W::a3(bp.h, pick(eHpp, cp.h, c.h), pick(eHp, c.h, cp.h));
     if (t - 1 >= i0 && t - 1 < i1) {
-      if (eLp) emit(t - 1, true, W::mulKinv(dl), W::mulKinv(dh));   // ojph_resolution.cpp:674-675
-      if (eHp) emit(t - 1, false, W::mulK(c.l), W::mulK(c.h));      // :663-664
+      out_t = t - 1;
+      if (eLp) {                                           // ojph_resolution.cpp:674-675
+        out_lo.l = W::mulKinv(dl); out_lo.h = W::mulKinv(dh);
+        horz_analysis<REV>(out_lo.l, out_lo.h, g); has_lo = true;
+      }
+      if (eHp) {                                           // :663-664
+        out_hi.l = W::mulK(c.l); out_hi.h = W::mulK(c.h);
+        horz_analysis<REV>(out_hi.l, out_hi.h, g); has_hi = true;
+      }
     }
     xl = xn;
   }
+  if (has_lo) put(out_t, true, out_lo.l, out_lo.h);
+  if (has_hi) put(out_t, false, out_hi.l, out_hi.h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +356,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
+  typedef typename std::conditional<IMG, int, T>::type E;          // element type of the destination rows
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -358,24 +376,31 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t
-  auto fetch = [&](int t, bool low_row, bool ex) {
+  // sub-band columns of this lane, clamped into the bands (what a clamped fetch returns is never used)
+  const int wl = (g.w + 1 - g.ox) >> 1, wh = (g.w + g.ox) >> 1;      // widths of the low / high bands
+  const int cl = min(max(g.j - g.ox, 0), max(wl - 1, 0)), ch = min(max(g.j, 0), max(wh - 1, 0));
+  const int hl_rows = (h + 1 - oy) >> 1, hh_rows = (h + oy) >> 1;    // heights of the low / high row sets
+  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t;
+  // unconditional: row and column are clamped, empty bands (w == 1 or h == 1) are skipped uniformly
+  auto fetch = [&](int t, bool low_row) {
     Pair<T> p; p.l = p.h = 0;
-    if (!ex) return p;
     const T* lo = low_row ? ll : lh; const T* hi = low_row ? hl : hh;
     const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
-    const int r = low_row ? t - oy : t;
-    if (g.eL) p.l = lo[(size_t)r * lop + (g.j - g.ox)];
-    if (g.eH) p.h = hi[(size_t)r * hip + g.j];
+    const int rows = low_row ? hl_rows : hh_rows;
+    if (rows == 0) return p;
+    const int r = min(max(low_row ? t - oy : t, 0), rows - 1);
+    if (wl > 0) p.l = lo[(size_t)r * lop + cl];
+    if (wh > 0) p.h = hi[(size_t)r * hip + ch];
     return p;
   };
   auto horz = [&](Pair<T> p) { horz_synthesis<REV>(p.l, p.h, g); return p; };
+  auto to_out = [&](T v) -> E { if constexpr (IMG) return Cv<REV>::to_image(v, cv); else return v; };
 
   if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
     if (i0 > 0) return;
-    Pair<T> x = horz(fetch(0, oy == 0, true));
+    Pair<T> x = horz(fetch(0, oy == 0));
     if (oy != 0) { x.l = W::halve(x.l); x.h = W::halve(x.h); }
-    store_pair<REV, IMG>(dst, g, x.l, x.h, cv);
+    store_cols<E>(dst, g, to_out(x.l), to_out(x.h));
     return;
   }
 
@@ -383,15 +408,21 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   Pair<T> z; z.l = z.h = 0;
   Pair<T> c = z, cp = z, b = z, bp = z, a = z, ap = z, xL = z, xLp = z;
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
-  Pair<T> nlo = fetch(t0, true, exL(t0)), nhi = fetch(t0, false, exH(t0));       // sub-band rows of iteration t0
+  E o_hl = 0, o_hh = 0, o_ll = 0, o_lh = 0;                // finished rows, stored one iteration later
+  int o_hy = 0, o_ly = 0; bool has_h = false, has_l = false;
+  Pair<T> nlo = fetch(t0, true), nhi = fetch(t0, false);   // sub-band rows of iteration t0
   for (int t = t0; t <= i1 + 1; ++t) {
     const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
     const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
+    arrived(nlo.l, nlo.h, nhi.l, nhi.h);
     Pair<T> dd = nlo, cc = nhi;
-    if (t <= i1) { nlo = fetch(t + 1, true, exL(t + 1)); nhi = fetch(t + 1, false, exH(t + 1)); }   // request t+1 now
     cp = c; c = z;
     if (eLt) { dd = horz(dd); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;     // :855-856
     if (eHt) { c = horz(cc); c.l = W::mulKinv(c.l); c.h = W::mulKinv(c.h); }                // :871-872
+    if (has_h) store_cols<E>(dst + (size_t)o_hy * dp, g, o_hl, o_hh);
+    if (has_l) store_cols<E>(dst + (size_t)o_ly * dp, g, o_ll, o_lh);
+    has_h = has_l = false;
+    if (t <= i1) { nlo = fetch(t + 1, true); nhi = fetch(t + 1, false); }                    // request t+1 now
     // b[t]
     bp = b;
     b.l = W::s0(dd.l, pick(eHp, cp.l, c.l), pick(eHt, c.l, cp.l));
@@ -407,11 +438,11 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     // xH[t-2]
     T xhl = W::s3(ap.l, pick(eLpp, xLp.l, xL.l), pick(eLp, xL.l, xLp.l));
     T xhh = W::s3(ap.h, pick(eLpp, xLp.h, xL.h), pick(eLp, xL.h, xLp.h));
-    if (t - 2 >= i0 && t - 2 < i1 && eHpp)
-      store_pair<REV, IMG>(dst + (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xhl, xhh, cv);
-    if (t - 1 >= i0 && t - 1 < i1 && eLp)
-      store_pair<REV, IMG>(dst + (size_t)(2 * (t - 1) - oy) * dp, g, xL.l, xL.h, cv);
+    if (t - 2 >= i0 && t - 2 < i1 && eHpp) { o_hl = to_out(xhl); o_hh = to_out(xhh); o_hy = 2 * (t - 2) + 1 - oy; has_h = true; }
+    if (t - 1 >= i0 && t - 1 < i1 && eLp) { o_ll = to_out(xL.l); o_lh = to_out(xL.h); o_ly = 2 * (t - 1) - oy; has_l = true; }
   }
+  if (has_h) store_cols<E>(dst + (size_t)o_hy * dp, g, o_hl, o_hh);
+  if (has_l) store_cols<E>(dst + (size_t)o_ly * dp, g, o_ll, o_lh);
 }
 
 // vertical chunk: as tall as possible (less halo recomputation) while the launch still offers
