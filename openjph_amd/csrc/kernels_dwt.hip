@@ -88,8 +88,9 @@ __device__ __forceinline__ float lane_next(float v) { return __int_as_float(lane
 __device__ __forceinline__ float lane_prev(float v) { return __int_as_float(lane_prev(__float_as_int(v))); }
 
 // neighbour selection with the "missing -> use the other one" rule
-template <typename T>
-__device__ __forceinline__ T pick(bool e, T v, T other) { return e ? v : other; }
+// CHK = false: the caller knows every neighbour exists (interior of the plane) and the select folds away
+template <bool CHK = true, typename T>
+__device__ __forceinline__ T pick(bool e, T v, T other) { return CHK ? (e ? v : other) : v; }
 
 template <typename T> struct Pair { T l, h; };
 
@@ -101,43 +102,44 @@ struct Geo {
   bool store;            // lane is in the valid (non-halo) zone of its strip
   int xc;                // first column of the lane's 2-sample row load, clamped into the row
   bool from_y, from_x;   // clamped load: the low sample arrives in .y / the high sample arrives in .x
+  bool inner;            // wave-uniform: every lane of the strip has all its horizontal neighbours
 };
 
 __device__ __forceinline__ bool col_exists(int x, int w) { return x >= 0 && x < w; }
 
-template <bool REV>
+template <bool REV, bool CHK = true>
 __device__ __forceinline__ void horz_analysis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
 {
   typedef typename Wv<REV>::T T;
-  if (g.w == 1) { if (g.ox) vh = Wv<REV>::dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
+  if (CHK && g.w == 1) { if (g.ox) vh = Wv<REV>::dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
   T nl = lane_next(vl);
-  vh = Wv<REV>::a0(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+  vh = Wv<REV>::a0(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
   T ph = lane_prev(vh);
-  vl = Wv<REV>::a1(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+  vl = Wv<REV>::a1(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
   if (!REV) {
     nl = lane_next(vl);
-    vh = Wv<REV>::a2(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+    vh = Wv<REV>::a2(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
     ph = lane_prev(vh);
-    vl = Wv<REV>::a3(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+    vl = Wv<REV>::a3(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
     vl = Wv<REV>::mulKinv(vl); vh = Wv<REV>::mulK(vh);          // ojph_transform.cpp:763-775
   }
 }
 
-template <bool REV>
+template <bool REV, bool CHK = true>
 __device__ __forceinline__ void horz_synthesis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
 {
   typedef typename Wv<REV>::T T;
-  if (g.w == 1) { if (g.ox) vh = Wv<REV>::halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
+  if (CHK && g.w == 1) { if (g.ox) vh = Wv<REV>::halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
   if (!REV) { vl = Wv<REV>::mulK(vl); vh = Wv<REV>::mulKinv(vh); }   // :797-809
   T ph = lane_prev(vh);
-  vl = Wv<REV>::s0(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+  vl = Wv<REV>::s0(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
   T nl = lane_next(vl);
-  vh = Wv<REV>::s1(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+  vh = Wv<REV>::s1(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
   if (!REV) {
     ph = lane_prev(vh);
-    vl = Wv<REV>::s2(vl, pick(g.eHp, ph, vh), pick(g.eH, vh, ph));
+    vl = Wv<REV>::s2(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
     nl = lane_next(vl);
-    vh = Wv<REV>::s3(vh, pick(g.eL, vl, nl), pick(g.eLn, nl, vl));
+    vh = Wv<REV>::s3(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
   }
 }
 
@@ -152,6 +154,7 @@ __device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, 
   g.store = lane >= HALO && lane < 64 - HALO;
   g.xc = max(min(xl, g.w - 2), 0);
   g.from_y = xl > g.xc; g.from_x = xl < g.xc;
+  g.inner = __all(g.eL && g.eH && g.eLn && g.eHp) != 0;
   return g;
 }
 
@@ -214,19 +217,7 @@ __device__ __forceinline__ Pair<typename Wv<REV>::T> unpack(const Raw<E>& v, con
   return p;
 }
 
-// stores the lane's two columns of a row; IMG: E = int, the values were converted by the caller
-template <typename E>
-__device__ __forceinline__ void store_cols(void* __restrict__ rowp, const Geo& g, E l, E h)
-{
-  if (!g.store) return;
-  E* row = (E*)rowp;
-  const int xl = 2 * g.j - g.ox;
-  if (g.eL && g.eH) { typename Vec2<E>::type v; v.x = l; v.y = h; *reinterpret_cast<typename Vec2<E>::type*>(row + xl) = v; }
-  else if (g.eL) row[xl] = l;
-  else if (g.eH) row[xl + 1] = h;
-}
-
-// Memory order inside one iteration of both kernels: consume what the previous iteration fetched,
+// Memory order inside one iteration of the forward kernel: consume what the previous iteration fetched,
 // THEN issue the stores of the previous iteration's results, THEN the fetches of the next iteration,
 // then compute.  gfx9 counts loads and stores in one in-order counter; with the stores placed just
 // before the fetches, the wait for those fetches one iteration later also covers the stores and
@@ -309,41 +300,75 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
       rh = ldrow(2 * t + 3 - oy);
       rn = ldrow(2 * t + 4 - oy);
     }
-    const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
-    // a[t]
-    ap = a;
-    a.l = W::a0(xh.l, pick(eLt, xl.l, xn.l), pick(eLn, xn.l, xl.l));
-    a.h = W::a0(xh.h, pick(eLt, xl.h, xn.h), pick(eLn, xn.h, xl.h));
-    // b[t]
-    const bool eHp = exH(t - 1);
-    Pair<T> bo = b;                       // b[t-1]
-    b.l = W::a1(xl.l, pick(eHp, ap.l, a.l), pick(eHt, a.l, ap.l));
-    b.h = W::a1(xl.h, pick(eHp, ap.h, a.h), pick(eHt, a.h, ap.h));
-    bp = bo;
-    // c[t-1]
-    const bool eLp = exL(t - 1);
-    cp = c;
-    c.l = W::a2(ap.l, pick(eLp, bp.l, b.l), pick(eLt, b.l, bp.l));
-    c.h = W::a2(ap.h, pick(eLp, bp.h, b.h), pick(eLt, b.h, bp.h));
-    // d[t-1]
-    const bool eHpp = exH(t - 2);
-    T dl = W::a3(bp.l, pick(eHpp, cp.l, c.l), pick(eHp, c.l, cp.l));
-    T dh = W::a3(bp.h, pick(eHpp, cp.h, c.h), pick(eHp, c.h, cp.h));
-    if (t - 1 >= i0 && t - 1 < i1) {
-      out_t = t - 1;
-      if (eLp) {                                           // ojph_resolution.cpp:674-675
-        out_lo.l = W::mulKinv(dl); out_lo.h = W::mulKinv(dh);
-        horz_analysis<REV>(out_lo.l, out_lo.h, g); has_lo = true;
+    // interior of the plane (every row t-2 .. t+1 exists, no strip edge): the selects fold away
+    auto lift = [&](auto chk) {
+      constexpr bool CHK = decltype(chk)::value;
+      const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
+      // a[t]
+      ap = a;
+      a.l = W::a0(xh.l, pick<CHK>(eLt, xl.l, xn.l), pick<CHK>(eLn, xn.l, xl.l));
+      a.h = W::a0(xh.h, pick<CHK>(eLt, xl.h, xn.h), pick<CHK>(eLn, xn.h, xl.h));
+      // b[t]
+      const bool eHp = exH(t - 1);
+      Pair<T> bo = b;                       // b[t-1]
+      b.l = W::a1(xl.l, pick<CHK>(eHp, ap.l, a.l), pick<CHK>(eHt, a.l, ap.l));
+      b.h = W::a1(xl.h, pick<CHK>(eHp, ap.h, a.h), pick<CHK>(eHt, a.h, ap.h));
+      bp = bo;
+      // c[t-1]
+      const bool eLp = exL(t - 1);
+      cp = c;
+      c.l = W::a2(ap.l, pick<CHK>(eLp, bp.l, b.l), pick<CHK>(eLt, b.l, bp.l));
+      c.h = W::a2(ap.h, pick<CHK>(eLp, bp.h, b.h), pick<CHK>(eLt, b.h, bp.h));
+      // d[t-1]
+      const bool eHpp = exH(t - 2);
+      T dl = W::a3(bp.l, pick<CHK>(eHpp, cp.l, c.l), pick<CHK>(eHp, c.l, cp.l));
+      T dh = W::a3(bp.h, pick<CHK>(eHpp, cp.h, c.h), pick<CHK>(eHp, c.h, cp.h));
+      if (t - 1 >= i0 && t - 1 < i1) {
+        out_t = t - 1;
+        if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
+          out_lo.l = W::mulKinv(dl); out_lo.h = W::mulKinv(dh);
+          horz_analysis<REV, CHK>(out_lo.l, out_lo.h, g); has_lo = true;
+        }
+        if (!CHK || eHp) {                                   // :663-664
+          out_hi.l = W::mulK(c.l); out_hi.h = W::mulK(c.h);
+          horz_analysis<REV, CHK>(out_hi.l, out_hi.h, g); has_hi = true;
+        }
       }
-      if (eHp) {                                           // :663-664
-        out_hi.l = W::mulK(c.l); out_hi.h = W::mulK(c.h);
-        horz_analysis<REV>(out_hi.l, out_hi.h, g); has_hi = true;
-      }
-    }
+    };
+    if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * (t + 1) - oy < h) lift(std::false_type());
+    else lift(std::true_type());
     xl = xn;
   }
   if (has_lo) put(out_t, true, out_lo.l, out_lo.h);
   if (has_hi) put(out_t, false, out_hi.l, out_hi.h);
+}
+
+struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
+
+template <bool REV, bool IMG>
+__device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
+                                           const Conv& cv)
+{
+  typedef typename Wv<REV>::T T;
+  if (!g.store) return;
+  const int xl = 2 * g.j - g.ox;
+  if (IMG) {
+    int* row = (int*)rowp;
+    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
+    if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
+    else if (g.eL) row[xl] = a;
+    else if (g.eH) row[xl + 1] = b;
+  } else {
+    T* row = (T*)rowp;
+    if (g.ox == 0 && g.eL && g.eH) {
+      typedef T V2 __attribute__((ext_vector_type(2)));
+      V2 v; v.x = l; v.y = h;
+      *reinterpret_cast<V2*>(row + xl) = v;
+    } else {
+      if (g.eL) row[xl] = l;
+      if (g.eH) row[xl + 1] = h;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,7 +381,6 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
-  typedef typename std::conditional<IMG, int, T>::type E;          // element type of the destination rows
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -376,31 +400,24 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  // sub-band columns of this lane, clamped into the bands (what a clamped fetch returns is never used)
-  const int wl = (g.w + 1 - g.ox) >> 1, wh = (g.w + g.ox) >> 1;      // widths of the low / high bands
-  const int cl = min(max(g.j - g.ox, 0), max(wl - 1, 0)), ch = min(max(g.j, 0), max(wh - 1, 0));
-  const int hl_rows = (h + 1 - oy) >> 1, hh_rows = (h + oy) >> 1;    // heights of the low / high row sets
-  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t;
-  // unconditional: row and column are clamped, empty bands (w == 1 or h == 1) are skipped uniformly
-  auto fetch = [&](int t, bool low_row) {
+  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t
+  auto fetch = [&](int t, bool low_row, bool ex) {
     Pair<T> p; p.l = p.h = 0;
+    if (!ex) return p;
     const T* lo = low_row ? ll : lh; const T* hi = low_row ? hl : hh;
     const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
-    const int rows = low_row ? hl_rows : hh_rows;
-    if (rows == 0) return p;
-    const int r = min(max(low_row ? t - oy : t, 0), rows - 1);
-    if (wl > 0) p.l = lo[(size_t)r * lop + cl];
-    if (wh > 0) p.h = hi[(size_t)r * hip + ch];
+    const int r = low_row ? t - oy : t;
+    if (g.eL) p.l = lo[(size_t)r * lop + (g.j - g.ox)];
+    if (g.eH) p.h = hi[(size_t)r * hip + g.j];
     return p;
   };
   auto horz = [&](Pair<T> p) { horz_synthesis<REV>(p.l, p.h, g); return p; };
-  auto to_out = [&](T v) -> E { if constexpr (IMG) return Cv<REV>::to_image(v, cv); else return v; };
 
   if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
     if (i0 > 0) return;
-    Pair<T> x = horz(fetch(0, oy == 0));
+    Pair<T> x = horz(fetch(0, oy == 0, true));
     if (oy != 0) { x.l = W::halve(x.l); x.h = W::halve(x.h); }
-    store_cols<E>(dst, g, to_out(x.l), to_out(x.h));
+    store_pair<REV, IMG>(dst, g, x.l, x.h, cv);
     return;
   }
 
@@ -408,41 +425,42 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   Pair<T> z; z.l = z.h = 0;
   Pair<T> c = z, cp = z, b = z, bp = z, a = z, ap = z, xL = z, xLp = z;
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
-  E o_hl = 0, o_hh = 0, o_ll = 0, o_lh = 0;                // finished rows, stored one iteration later
-  int o_hy = 0, o_ly = 0; bool has_h = false, has_l = false;
-  Pair<T> nlo = fetch(t0, true), nhi = fetch(t0, false);   // sub-band rows of iteration t0
+  Pair<T> nlo = fetch(t0, true, exL(t0)), nhi = fetch(t0, false, exH(t0));       // sub-band rows of iteration t0
   for (int t = t0; t <= i1 + 1; ++t) {
-    const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
-    const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
-    arrived(nlo.l, nlo.h, nhi.l, nhi.h);
-    Pair<T> dd = nlo, cc = nhi;
-    cp = c; c = z;
-    if (eLt) { dd = horz(dd); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;     // :855-856
-    if (eHt) { c = horz(cc); c.l = W::mulKinv(c.l); c.h = W::mulKinv(c.h); }                // :871-872
-    if (has_h) store_cols<E>(dst + (size_t)o_hy * dp, g, o_hl, o_hh);
-    if (has_l) store_cols<E>(dst + (size_t)o_ly * dp, g, o_ll, o_lh);
-    has_h = has_l = false;
-    if (t <= i1) { nlo = fetch(t + 1, true); nhi = fetch(t + 1, false); }                    // request t+1 now
-    // b[t]
-    bp = b;
-    b.l = W::s0(dd.l, pick(eHp, cp.l, c.l), pick(eHt, c.l, cp.l));
-    b.h = W::s0(dd.h, pick(eHp, cp.h, c.h), pick(eHt, c.h, cp.h));
-    // a[t-1]
-    ap = a;
-    a.l = W::s1(cp.l, pick(eLp, bp.l, b.l), pick(eLt, b.l, bp.l));
-    a.h = W::s1(cp.h, pick(eLp, bp.h, b.h), pick(eLt, b.h, bp.h));
-    // xL[t-1]
-    xLp = xL;
-    xL.l = W::s2(bp.l, pick(eHpp, ap.l, a.l), pick(eHp, a.l, ap.l));
-    xL.h = W::s2(bp.h, pick(eHpp, ap.h, a.h), pick(eHp, a.h, ap.h));
-    // xH[t-2]
-    T xhl = W::s3(ap.l, pick(eLpp, xLp.l, xL.l), pick(eLp, xL.l, xLp.l));
-    T xhh = W::s3(ap.h, pick(eLpp, xLp.h, xL.h), pick(eLp, xL.h, xLp.h));
-    if (t - 2 >= i0 && t - 2 < i1 && eHpp) { o_hl = to_out(xhl); o_hh = to_out(xhh); o_hy = 2 * (t - 2) + 1 - oy; has_h = true; }
-    if (t - 1 >= i0 && t - 1 < i1 && eLp) { o_ll = to_out(xL.l); o_lh = to_out(xL.h); o_ly = 2 * (t - 1) - oy; has_l = true; }
+    const Pair<T> in_lo = nlo, in_hi = nhi;
+    if (t <= i1) { nlo = fetch(t + 1, true, exL(t + 1)); nhi = fetch(t + 1, false, exH(t + 1)); }   // request t+1 now
+    // interior of the plane (every row t-2 .. t exists, no strip edge): the selects fold away
+    auto lift = [&](auto chk) {
+      constexpr bool CHK = decltype(chk)::value;
+      const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
+      const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
+      Pair<T> dd = in_lo, cc = in_hi;
+      cp = c; c = z;
+      if (!CHK || eLt) { horz_synthesis<REV, CHK>(dd.l, dd.h, g); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;   // :855-856
+      if (!CHK || eHt) { horz_synthesis<REV, CHK>(cc.l, cc.h, g); c.l = W::mulKinv(cc.l); c.h = W::mulKinv(cc.h); }          // :871-872
+      // b[t]
+      bp = b;
+      b.l = W::s0(dd.l, pick<CHK>(eHp, cp.l, c.l), pick<CHK>(eHt, c.l, cp.l));
+      b.h = W::s0(dd.h, pick<CHK>(eHp, cp.h, c.h), pick<CHK>(eHt, c.h, cp.h));
+      // a[t-1]
+      ap = a;
+      a.l = W::s1(cp.l, pick<CHK>(eLp, bp.l, b.l), pick<CHK>(eLt, b.l, bp.l));
+      a.h = W::s1(cp.h, pick<CHK>(eLp, bp.h, b.h), pick<CHK>(eLt, b.h, bp.h));
+      // xL[t-1]
+      xLp = xL;
+      xL.l = W::s2(bp.l, pick<CHK>(eHpp, ap.l, a.l), pick<CHK>(eHp, a.l, ap.l));
+      xL.h = W::s2(bp.h, pick<CHK>(eHpp, ap.h, a.h), pick<CHK>(eHp, a.h, ap.h));
+      // xH[t-2]
+      T xhl = W::s3(ap.l, pick<CHK>(eLpp, xLp.l, xL.l), pick<CHK>(eLp, xL.l, xLp.l));
+      T xhh = W::s3(ap.h, pick<CHK>(eLpp, xLp.h, xL.h), pick<CHK>(eLp, xL.h, xLp.h));
+      if (t - 2 >= i0 && t - 2 < i1 && (!CHK || eHpp))
+        store_pair<REV, IMG>(dst + (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xhl, xhh, cv);
+      if (t - 1 >= i0 && t - 1 < i1 && (!CHK || eLp))
+        store_pair<REV, IMG>(dst + (size_t)(2 * (t - 1) - oy) * dp, g, xL.l, xL.h, cv);
+    };
+    if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * t + 1 - oy < h) lift(std::false_type());
+    else lift(std::true_type());
   }
-  if (has_h) store_cols<E>(dst + (size_t)o_hy * dp, g, o_hl, o_hh);
-  if (has_l) store_cols<E>(dst + (size_t)o_ly * dp, g, o_ll, o_lh);
 }
 
 // vertical chunk: as tall as possible (less halo recomputation) while the launch still offers
