@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds inside one GPU-box visit: tools/_dbg/ab.sh orig prev ...
+# A/B of library builds inside one GPU-box visit: tools/ab.sh orig prev ...
 cp openjph_amd/libojphgpu.so /tmp/lib_orig.so
 for rep in 1 2; do
 for v in "$@"; do
