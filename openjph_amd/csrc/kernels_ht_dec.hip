@@ -280,6 +280,116 @@ __device__ __forceinline__ void store_pair(uint32_t* p, uint32_t a, uint32_t b)
   *reinterpret_cast<U2*>(p) = v;
 }
 
+// The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
+template <bool NARROW>
+__device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
+                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0, const uint16_t* s_uvlc1)
+{
+  // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
+  // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
+  uint64_t sig_prev = 0;
+
+  // ---- initial quad row (block_decoder32.cpp:854-975) ----
+  {
+    uint32_t tleft = 0; uint64_t sig_cur = 0;
+    for (uint32_t qx = 0; qx < QW; qx += 2) {
+      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 7 + 10 of them
+      mel.fill();                         // >= 5 events queued: a pair consumes at most 3
+      uint32_t v = (uint32_t)vlc.win, used = 0;
+      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
+      uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
+      uint32_t t0 = s_vlc[c_q + (v & 0x7Fu)];
+      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }                      // :882-894
+      v >>= (t0 & 7u); used += t0 & 7u;
+      uint32_t t1 = 0;
+      if (qx + 1 < QW) {
+        c_q = ((t0 & 0x10u) << 3) | ((t0 & 0xE0u) << 2);                                    // :934
+        t1 = s_vlc[c_q + (v & 0x7Fu)];
+        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
+        v >>= (t1 & 7u); used += t1 & 7u;
+      }
+      tleft = t1;
+      if (NARROW) {
+        const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
+        sig_cur |= (uint64_t)nib << (2u * qx);
+      }
+      uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
+      if (mode == 0xC0u) { if ((evq >> ecnt) & 1u) mode += 0x40u; ecnt++; }                 // :943-952
+      uint32_t entry = s_uvlc0[mode + (v & 0x3Fu)];
+      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
+      uint32_t len = entry & 0xFu;
+      const uint32_t tmp = v & ((1u << len) - 1u);
+      used += len; entry >>= 4;
+      len = entry & 7u; entry >>= 3;
+      const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
+      const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
+      vlc.skip(used); mel.drop(ecnt);
+      store_pair(rec + qx, t0 | (u0 << 16), t1 | (u1 << 16));
+    }
+    sig_prev = sig_cur;
+  }
+  // ---- other quad rows (:977-1089) ----
+  const uint16_t* tbl = s_vlc + 1024;
+  for (uint32_t qy = 1; qy < QH; ++qy) {
+    uint32_t* row = rec + qy * QW;
+    const uint32_t* above = row - QW;
+    uint32_t tleft = 0, carry = 0; uint64_t sig_cur = 0;
+    for (uint32_t qx = 0; qx < QW; qx += 2) {
+      vlc.refill();
+      mel.fill();
+      uint32_t v = (uint32_t)vlc.win, used = 0;
+      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
+      // k0 / k1: what the sample row above contributes to the contexts of quad qx / qx+1 (:990-991,
+      // :1024-1027): bit 7 = nw | n, bit 9 = ne | nf, over the columns 2qx-1 .. 2qx+4
+      uint32_t k0, k1;
+      if (NARROW) {
+        const uint32_t w = (uint32_t)(sig_prev >> (2u * qx));      // bit i: column 2qx + i
+        const uint32_t m = (w >> 1) | (w >> 2);                    // bit 0: columns 2qx+1|2qx+2, bit 2: 2qx+3|2qx+4
+        k0 = (((carry | w) & 1u) << 7) | ((m & 1u) << 9);
+        k1 = ((m & 1u) << 7) | ((m & 4u) << 7);
+        carry = (w >> 3) & 1u;                                     // column 2qx+3 = 2(qx+2)-1
+      } else {
+        const uint32_t up0 = above[qx];
+        const uint32_t upl = qx ? above[qx - 1] : 0u;
+        const uint32_t up1 = qx + 1 < QW ? above[qx + 1] : 0u;
+        const uint32_t up2 = qx + 2 < QW ? above[qx + 2] : 0u;
+        const uint32_t sg = ((upl >> 7) & 1u) | (((up0 >> 5) & 1u) << 1) | (((up0 >> 7) & 1u) << 2) | (((up1 >> 5) & 1u) << 3) |
+                            (((up1 >> 7) & 1u) << 4) | (((up2 >> 5) & 1u) << 5);
+        k0 = (((sg | (sg >> 1)) & 1u) << 7) | ((((sg >> 2) | (sg >> 3)) & 1u) << 9);
+        k1 = ((((sg >> 2) | (sg >> 3)) & 1u) << 7) | ((((sg >> 4) | (sg >> 5)) & 1u) << 9);
+      }
+      uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1) | k0;                  // :1022
+      uint32_t t0 = tbl[c_q + (v & 0x7Fu)];
+      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }
+      v >>= (t0 & 7u); used += t0 & 7u;
+      uint32_t t1 = 0;
+      if (qx + 1 < QW) {
+        c_q = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1) | k1;                               // :1059
+        t1 = tbl[c_q + (v & 0x7Fu)];
+        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
+        v >>= (t1 & 7u); used += t1 & 7u;
+      }
+      tleft = t1;
+      if (NARROW) {
+        const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
+        sig_cur |= (uint64_t)nib << (2u * qx);
+      }
+      const uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
+      uint32_t entry = s_uvlc1[mode + (v & 0x3Fu)];
+      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
+      uint32_t len = entry & 0xFu;
+      const uint32_t tmp = v & ((1u << len) - 1u);
+      used += len; entry >>= 4;
+      len = entry & 7u; entry >>= 3;
+      const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
+      const uint32_t u1 = (entry >> 3) + (tmp >> len);
+      vlc.skip(used); mel.drop(ecnt);
+      store_pair(row + qx, t0 | (u0 << 16), t1 | (u1 << 16));
+    }
+    sig_prev = sig_cur;
+  }
+}
+
 __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ aux, uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
@@ -310,107 +420,10 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   FlatLsb vlc; vlc.init(aux + d.reserved, vlc_words(scup));
   MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
 
-  const bool small = QW <= 32;                    // significance of the row above fits two 32-bit masks
-  uint32_t a_prev = 0, b_prev = 0;                // bit x: rho bit 1 (bottom-left) / bit 3 (bottom-right) of quad x
-
-  // ---- initial quad row (block_decoder32.cpp:854-975) ----
-  {
-    uint32_t tleft = 0, a_cur = 0, b_cur = 0;
-    for (uint32_t qx = 0; qx < QW; qx += 2) {
-      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 7 + 10 of them
-      mel.fill();                         // >= 5 events queued: a pair consumes at most 3
-      uint32_t v = (uint32_t)vlc.win, used = 0;
-      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
-      uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
-      uint32_t t0 = s_vlc[c_q + (v & 0x7Fu)];
-      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }                      // :882-894
-      v >>= (t0 & 7u); used += t0 & 7u;
-      uint32_t t1 = 0;
-      if (qx + 1 < QW) {
-        c_q = ((t0 & 0x10u) << 3) | ((t0 & 0xE0u) << 2);                                    // :934
-        t1 = s_vlc[c_q + (v & 0x7Fu)];
-        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
-        v >>= (t1 & 7u); used += t1 & 7u;
-      }
-      tleft = t1;
-      if (small) {
-        a_cur |= (((t0 >> 5) & 1u) | ((t1 >> 4) & 2u)) << qx;
-        b_cur |= (((t0 >> 7) & 1u) | ((t1 >> 6) & 2u)) << qx;
-      }
-      uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
-      if (mode == 0xC0u) { if ((evq >> ecnt) & 1u) mode += 0x40u; ecnt++; }                 // :943-952
-      uint32_t entry = s_uvlc0[mode + (v & 0x3Fu)];
-      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
-      uint32_t len = entry & 0xFu;
-      const uint32_t tmp = v & ((1u << len) - 1u);
-      used += len; entry >>= 4;
-      len = entry & 7u; entry >>= 3;
-      const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
-      const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
-      vlc.skip(used); mel.drop(ecnt);
-      store_pair(rec + qx, t0 | (u0 << 16), t1 | (u1 << 16));
-    }
-    a_prev = a_cur; b_prev = b_cur;
-  }
-  // ---- other quad rows (:977-1089) ----
-  for (uint32_t qy = 1; qy < QH; ++qy) {
-    const uint16_t* tbl = s_vlc + 1024;
-    uint32_t* row = rec + qy * QW;
-    const uint32_t* above = row - QW;
-    uint32_t tleft = 0, a_cur = 0, b_cur = 0;
-    for (uint32_t qx = 0; qx < QW; qx += 2) {
-      vlc.refill();
-      mel.fill();
-      uint32_t v = (uint32_t)vlc.win, used = 0;
-      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
-      // sigma of the sample row above, columns 2qx-1 .. 2qx+4:  n0 n1 n2 n3 n4 n5
-      uint32_t sg;
-      if (small) {
-        const uint32_t ap = a_prev >> qx, bp = b_prev >> qx, bl = (b_prev << 1) >> qx;
-        sg = (bl & 1u) | ((ap & 1u) << 1) | ((bp & 1u) << 2) | ((ap & 2u) << 2) | ((bp & 2u) << 3) | ((ap & 4u) << 3);
-      } else {
-        const uint32_t up0 = above[qx];
-        const uint32_t upl = qx ? above[qx - 1] : 0u;
-        const uint32_t up1 = qx + 1 < QW ? above[qx + 1] : 0u;
-        const uint32_t up2 = qx + 2 < QW ? above[qx + 2] : 0u;
-        sg = ((upl >> 7) & 1u) | (((up0 >> 5) & 1u) << 1) | (((up0 >> 7) & 1u) << 2) | (((up1 >> 5) & 1u) << 3) |
-             (((up1 >> 7) & 1u) << 4) | (((up2 >> 5) & 1u) << 5);
-      }
-      // quad qx: nw|nn_l -> bit 7, nn_r|ne -> bit 9 (:990-991,:1024-1027)
-      uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1);                       // :1022
-      c_q |= ((sg | (sg >> 1)) & 1u) << 7;
-      c_q |= (((sg >> 2) | (sg >> 3)) & 1u) << 9;
-      uint32_t t0 = tbl[c_q + (v & 0x7Fu)];
-      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }
-      v >>= (t0 & 7u); used += t0 & 7u;
-      uint32_t t1 = 0;
-      if (qx + 1 < QW) {
-        c_q = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1);                                    // :1059
-        c_q |= (((sg >> 2) | (sg >> 3)) & 1u) << 7;
-        c_q |= (((sg >> 4) | (sg >> 5)) & 1u) << 9;
-        t1 = tbl[c_q + (v & 0x7Fu)];
-        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
-        v >>= (t1 & 7u); used += t1 & 7u;
-      }
-      tleft = t1;
-      if (small) {
-        a_cur |= (((t0 >> 5) & 1u) | ((t1 >> 4) & 2u)) << qx;
-        b_cur |= (((t0 >> 7) & 1u) | ((t1 >> 6) & 2u)) << qx;
-      }
-      const uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
-      uint32_t entry = s_uvlc1[mode + (v & 0x3Fu)];
-      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
-      uint32_t len = entry & 0xFu;
-      const uint32_t tmp = v & ((1u << len) - 1u);
-      used += len; entry >>= 4;
-      len = entry & 7u; entry >>= 3;
-      const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
-      const uint32_t u1 = (entry >> 3) + (tmp >> len);
-      vlc.skip(used); mel.drop(ecnt);
-      store_pair(row + qx, t0 | (u0 << 16), t1 | (u1 << 16));
-    }
-    a_prev = a_cur; b_prev = b_cur;
-  }
+  // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
+  // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
+  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, s_uvlc1);
+  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, s_uvlc1);
 }
 
 // -------------------------------------------------------------------------------------------------
