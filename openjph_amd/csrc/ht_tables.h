@@ -24,4 +24,13 @@ int upload_enc_tables(const HtTables& t);
 int upload_dec_tables(const HtTables& t);
 
 }  // namespace ojphgpu
+
+struct ojphgpu_cb_desc; struct ojphgpu_cb_result;
+namespace ojphgpu {
+// ojphgpu_ht_encode with the caller's knowledge of which block widths the range holds (kernels_ht_enc.hip)
+int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
+                     uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
+                     int widths);
+
+}  // namespace ojphgpu
 #endif

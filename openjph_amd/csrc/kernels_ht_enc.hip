@@ -930,19 +930,32 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
 
 }  // namespace
 
+namespace ojphgpu {
+// `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones.  Every
+// kernel skips the blocks of the other kind, so a caller that does not know passes 3.
+int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
+                     uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
+                     int widths)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (ensure_tables() != 0) return OJPHGPU_E_HIP;
+  if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
+  dim3 grid((n + WAVES - 1) / WAVES);
+  if (widths & 1)
+    hipLaunchKernelGGL(ht_encode_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+  if (widths & 2)
+    hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+}  // namespace ojphgpu
+
 extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                   const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
                                   ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status)
 {
-  if (n == 0) return OJPHGPU_OK;
-  if (ojphgpu::ensure_tables() != 0) return OJPHGPU_E_HIP;
-  if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
-  dim3 grid((n + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL(ht_encode_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
-                     (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
-  hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
-                     (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
-  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3);
 }
 
 namespace ojphgpu {

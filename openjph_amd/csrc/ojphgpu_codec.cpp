@@ -271,6 +271,7 @@ struct ojphgpu_encoder {
   // the samples) only need the first DWT level, so they are coded on a second stream while the
   // small, latency-bound launches of levels 2..L run on the main one
   uint32_t n_top = 0;                              // descriptors [0, n_top) = blocks of the top resolution
+  int widths_top = 0, widths_rest = 0;             // which block encoder kernels each range needs (bit 0 narrow, bit 1 wide)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -358,6 +359,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     d.missing_msbs = (uint8_t)(B.K_max - 1); d.num_passes = 1; d.delta = B.delta;
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
+    (i < e->n_top ? e->widths_top : e->widths_rest) |= k.r.w > 64 ? 2 : 1;
   }
   if (nframes > 1) {                                      // replicate the block descriptors, frame-major
     const size_t nb = bd.size();
@@ -423,8 +425,8 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
       HIPCHK(hipEventRecord(e->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
       const int sh = T.begin(SP_HT_ENC, e->side);
-      rc = ojphgpu_ht_encode(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p, e->out_cap,
-                             res, cnt, cnt + 1);
+      rc = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
+                                     e->out_cap, res, cnt, cnt + 1, e->widths_top);
       if (rc) return rc;
       T.end(sh, e->side);
       HIPCHK(hipEventRecord(e->ev_join, e->side));
@@ -432,8 +434,8 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   }
   const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
   const int sh = T.begin(SP_HT_ENC, s);
-  rc = ojphgpu_ht_encode(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
-                         e->out_cap, res + e->n_top, cnt, cnt + 1);
+  rc = ojphgpu::ht_encode_launch(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p,
+                                 (uint8_t*)e->out.p, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest);
   if (rc) return rc;
   T.end(sh, s);
   if (e->n_top) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));     // join
