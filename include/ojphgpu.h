@@ -39,6 +39,7 @@ extern "C" {
  * 1. Codestream parameters: what ojph::param_siz / param_cod / param_qcd setters carry
  *    (src/core/openjph/ojph_params.h:68-240).
  * ------------------------------------------------------------------------------------------ */
+#define OJPHGPU_MAX_SUBSAMPLED_COMPS 16
 typedef struct ojphgpu_params {
   uint32_t width, height;        /* param_siz::set_image_extent                               */
   uint32_t num_comps;            /* param_siz::set_num_components  (all comps share the below) */
@@ -56,6 +57,12 @@ typedef struct ojphgpu_params {
   uint32_t reserved[4];          /* [0] bit 0: vertically causal code-block style (set by the parser) */
   uint8_t  precinct_exps[36];    /* param_cod::set_precinct_size with a list: per resolution (0 =
                                     lowest) PPx | PPy << 4; all zero = precinct_w/h everywhere  */
+  /* reference grid (ojph_params.h:68-112).  width/height stay the image SIZE: the extent the
+     reference's set_image_extent takes is image_x0 + width, image_y0 + height.                 */
+  uint32_t image_x0, image_y0;   /* param_siz::set_image_offset                                 */
+  uint32_t tile_x0, tile_y0;     /* param_siz::set_tile_offset (<= image offset)                */
+  uint8_t  comp_dx[OJPHGPU_MAX_SUBSAMPLED_COMPS];   /* param_siz::set_component downsampling of   */
+  uint8_t  comp_dy[OJPHGPU_MAX_SUBSAMPLED_COMPS];   /* component c < 16; 0 = 1; later ones are 1  */
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *
@@ -109,9 +116,16 @@ int  ojphgpu_plan_counts(const ojphgpu_plan* plan, uint64_t out[8]);
 int  ojphgpu_plan_bands(const ojphgpu_plan* plan, ojphgpu_band_info* out, size_t n);
 int  ojphgpu_plan_blocks(const ojphgpu_plan* plan, ojphgpu_block_info* out, size_t n);
 int  ojphgpu_plan_levels(const ojphgpu_plan* plan, ojphgpu_level_info* out, size_t n);
-/* element offset + pitch of tile-component (tile, comp)'s full-resolution plane in the arena */
+/* element offset + pitch of tile-component (tile, comp)'s full-resolution plane in the arena;
+ * rect = x0, y0, w, h of the tile-component on the component's own (sub-sampled) grid */
 int  ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t comp,
                              uint64_t* off, uint32_t* pitch, uint32_t rect[4]);
+/* The image buffer every codec call takes ("frame"): the int32 planes of the components one after
+ * the other, component c being out[2] x out[3] samples (param_siz::get_recon_width / _height),
+ * tightly packed, starting out[4] | out[5] << 32 elements into the frame.  out[0], out[1] = the
+ * component's origin on its own grid (ceil(image offset / sub-sampling)); out[6], out[7] = its
+ * sub-sampling factors.  comp == num_comps: out[4] | out[5] << 32 = elements of one whole frame. */
+int  ojphgpu_plan_comp_info(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
 
 /* ------------------------------------------------------------------------------------------ *
  * 3. Tier-2 on the host: marker segments + packet headers (tag trees, pass lengths) around the
@@ -233,13 +247,16 @@ int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */
   uint32_t pitch, w, h;
-  uint32_t src_x0, src_y0;           /* position inside the image-sized input plane */
-  uint32_t reserved;
+  uint32_t src_x0, src_y0;           /* position inside the component's image plane */
+  uint32_t img_pitch;                /* width of that plane */
+  uint64_t img_off;                  /* element offset of that plane in the image buffer (a frame
+                                        batch adds the frame's offset) */
 } ojphgpu_convert_desc;
 
 /* K10/K11: level shift / int<->float conversion and RCT / ICT (ojph_colour.cpp:238-571 as
- * driven by tile::push/pull, ojph_tile.cpp:332-518).  Image samples are int32 planes of
- * img_w x img_h (component-major), like the i32 line_bufs the reference exchanges. */
+ * driven by tile::push/pull, ojph_tile.cpp:332-518).  Image samples are int32 planes
+ * (component-major, see ojphgpu_plan_comp_info), like the i32 line_bufs the reference exchanges.
+ * With the colour transform the first three components share their geometry. */
 int ojphgpu_convert_forward(void* stream, const ojphgpu_params* params,
                             const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
                             uint32_t max_w, uint32_t max_h, const int32_t* d_image, void* d_arena);

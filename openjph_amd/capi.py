@@ -25,6 +25,8 @@ class Params(C.Structure):
         ("precinct_w", C.c_uint32), ("precinct_h", C.c_uint32), ("tlm", C.c_uint32),
         ("reserved", C.c_uint32 * 4),
         ("precinct_exps", C.c_uint8 * 36),
+        ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
+        ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
     ]
 
 
@@ -87,7 +89,7 @@ class CbResult(C.Structure):
 class ConvertDesc(C.Structure):
     _fields_ = [("plane_off", C.c_uint64), ("pitch", C.c_uint32), ("w", C.c_uint32),
                 ("h", C.c_uint32), ("src_x0", C.c_uint32), ("src_y0", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("img_pitch", C.c_uint32), ("img_off", C.c_uint64)]
 
 
 _lib = None
@@ -98,6 +100,7 @@ SIGNATURES = {
     "ojphgpu_plan_destroy": (None, [C.c_void_p]),
     "ojphgpu_plan_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "ojphgpu_plan_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ojphgpu_plan_comp_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ojphgpu_plan_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ojphgpu_plan_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -60,8 +60,8 @@ class Encoder:
                 check(self._lib.ojphgpu_encoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
                                                              self.tiles[0], self.tiles[1], C.byref(self._h)),
                       "encoder_create")
-        p = self.plan.params
-        self.shape = (p.num_comps, p.height, p.width) if self.frames == 1 else (self.frames, p.num_comps, p.height, p.width)
+        fs = self.plan.frame_shape          # [C,H,W], or flat (frame_elems,) when components differ in size
+        self.shape = fs if self.frames == 1 else (self.frames,) + fs
 
     def __del__(self):
         try:
@@ -72,7 +72,8 @@ class Encoder:
             pass
 
     def run_device(self, d_image):
-        """d_image: int32 torch tensor [C,H,W] resident on the device. Asynchronous."""
+        """d_image: int32 torch tensor [C,H,W] (flat plan.frame_shape for sub-sampled components)
+        resident on the device. Asynchronous."""
         assert d_image.is_cuda and d_image.dtype == _torch().int32 and tuple(d_image.shape) == self.shape
         assert d_image.is_contiguous()
         check(self._lib.ojphgpu_encoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device")
@@ -100,8 +101,7 @@ class Encoder:
 
     def finish_tiles(self):
         """-> (tile-part bytes of this encoder's tile range, Psot per tile)"""
-        p = self.plan.params
-        cap = int(p.width) * int(p.height) * int(p.num_comps) * 3 + (1 << 20)
+        cap = self.plan.frame_elems * 3 + (1 << 20)
         lens = np.zeros(max(self.tiles[1], 1), np.uint32)
         n = C.c_size_t()
         out = np.empty(cap, np.uint8)
@@ -114,9 +114,12 @@ class Encoder:
         return out[:n.value].tobytes(), lens[:self.tiles[1]].copy()
 
     def encode(self, image):
-        """image: numpy int32 [C,H,W] (host) or torch int32 tensor on the device -> codestream bytes;
-        for a batch encoder [B,C,H,W] -> list of B codestreams."""
+        """image: numpy int32 [C,H,W] (host), a list of per-component 2-D arrays (sub-sampled
+        components), or a torch int32 tensor on the device -> codestream bytes; for a batch encoder
+        [B,C,H,W] -> list of B codestreams."""
         torch = _torch()
+        if isinstance(image, (list, tuple)):
+            image = self.plan.pack_frame(image)
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
         self.run_device(image)
@@ -167,8 +170,8 @@ class Decoder:
                 check(self._lib.ojphgpu_decoder_create_tiles(self.plan.handle, device, _stream_ptr(torch, device),
                                                              self.tiles[0], self.tiles[1], C.byref(self._h)),
                       "decoder_create")
-        p = self.plan.params
-        self.shape = (p.num_comps, p.height, p.width) if self.frames == 1 else (self.frames, p.num_comps, p.height, p.width)
+        fs = self.plan.frame_shape
+        self.shape = fs if self.frames == 1 else (self.frames,) + fs
         for f, cs in enumerate(streams):
             self.upload(cs, f)
 

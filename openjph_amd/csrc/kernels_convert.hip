@@ -49,12 +49,11 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   const uint32_t nc = p.num_comps;
   const ojphgpu_convert_desc d0 = descs[tile * nc];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= d0.w || y >= d0.h) return;
-  const size_t plane = (size_t)p.img_w * p.img_h;
-  const size_t src = (size_t)d0.reserved * nc * plane + (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;   // reserved = frame of a batch
-  if (p.color) {
+  auto at = [&](const ojphgpu_convert_desc& d) { return d.img_off + (size_t)(d.src_y0 + y) * d.img_pitch + d.src_x0 + x; };
+  if (p.color) {                                  // the first three components share their geometry
+    if (x >= d0.w || y >= d0.h) return;
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
-    int r = image[src], g = image[plane + src], b = image[2 * plane + src];
+    int r = image[at(d0)], g = image[at(d1)], b = image[at(d2)];
     if (p.reversible) {
       const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
       r += shift; g += shift; b += shift;
@@ -75,7 +74,8 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   }
   for (uint32_t c = 0; c < nc; ++c) {
     const ojphgpu_convert_desc d = descs[tile * nc + c];
-    int v = image[c * plane + src];
+    if (x >= d.w || y >= d.h) continue;           // sub-sampled components are smaller
+    int v = image[at(d)];
     uint32_t o;
     if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
     else o = __float_as_uint(to_float(v, p));
@@ -90,10 +90,9 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
   const uint32_t nc = p.num_comps;
   const ojphgpu_convert_desc d0 = descs[tile * nc];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= d0.w || y >= d0.h) return;
-  const size_t plane = (size_t)p.img_w * p.img_h;
-  const size_t dst = (size_t)d0.reserved * nc * plane + (size_t)(d0.src_y0 + y) * p.img_w + d0.src_x0 + x;   // reserved = frame of a batch
-  if (p.color) {
+  auto at = [&](const ojphgpu_convert_desc& d) { return d.img_off + (size_t)(d.src_y0 + y) * d.img_pitch + d.src_x0 + x; };
+  if (p.color) {                                  // the first three components share their geometry
+    if (x >= d0.w || y >= d0.h) return;
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];
     uint32_t b = arena[d1.plane_off + (size_t)y * d1.pitch + x];
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
-      image[dst] = cr + g + shift; image[plane + dst] = g + shift; image[2 * plane + dst] = cb + g + shift;
+      image[at(d0)] = cr + g + shift; image[at(d1)] = g + shift; image[at(d2)] = cb + g + shift;
     } else {
       const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
       const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
@@ -112,17 +111,18 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
       float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
-      image[dst] = to_int(r, p); image[plane + dst] = to_int(g, p); image[2 * plane + dst] = to_int(bb, p);
+      image[at(d0)] = to_int(r, p); image[at(d1)] = to_int(g, p); image[at(d2)] = to_int(bb, p);
     }
     return;
   }
   for (uint32_t c = 0; c < nc; ++c) {
     const ojphgpu_convert_desc d = descs[tile * nc + c];
+    if (x >= d.w || y >= d.h) continue;
     uint32_t a = arena[d.plane_off + (size_t)y * d.pitch + x];
     int v;
     if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
     else v = to_int(__uint_as_float(a), p);
-    image[c * plane + dst] = v;
+    image[at(d)] = v;
   }
 }
 

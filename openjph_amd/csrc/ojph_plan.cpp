@@ -143,7 +143,39 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
   if (p.color_transform && p.num_comps != 3) return fail("colour transform needs exactly 3 components here");
   if (p.prog_order > 4) return fail("unknown progression order");
-  if (p.tile_w == 0 || p.tile_h == 0) { p.tile_w = p.width; p.tile_h = p.height; }
+  // reference grid: image offset, tile offset, sub-sampling (ojph_params.cpp:88-150 check_validity)
+  if ((uint64_t)p.image_x0 + p.width > 0xFFFFFFFFull || (uint64_t)p.image_y0 + p.height > 0xFFFFFFFFull)
+    return fail("image extent exceeds 2^32 - 1");
+  if (p.tile_x0 > p.image_x0 || p.tile_y0 > p.image_y0) return fail("tile offset has to be smaller than the image offset");
+  const uint32_t X1 = p.image_x0 + p.width, Y1 = p.image_y0 + p.height;            // image extent
+  if (p.tile_w == 0 || p.tile_h == 0) {                 // not set: one tile, sized as write_headers sizes it
+    if ((uint64_t)X1 + p.image_x0 > 0xFFFFFFFFull || (uint64_t)Y1 + p.image_y0 > 0xFFFFFFFFull) return fail("image extent too large");
+    p.tile_w = X1 + p.image_x0; p.tile_h = Y1 + p.image_y0;                        // ojph_codestream_local.cpp:562-570
+  }
+  if ((uint64_t)p.tile_x0 + p.tile_w <= p.image_x0 || (uint64_t)p.tile_y0 + p.tile_h <= p.image_y0)
+    return fail("the top left tile must intersect with the image");
+  plan.comps.resize(p.num_comps);
+  plan.frame_elems = 0;
+  bool subsampled = false;
+  for (uint32_t c = 0; c < p.num_comps; ++c) {
+    CompGeo& g = plan.comps[c];
+    g.dx = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_dx[c] ? p.comp_dx[c] : 1;
+    g.dy = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_dy[c] ? p.comp_dy[c] : 1;
+    subsampled |= g.dx != 1 || g.dy != 1;
+    g.x0 = div_ceil(p.image_x0, g.dx); g.y0 = div_ceil(p.image_y0, g.dy);
+    g.w = div_ceil(X1, g.dx) - g.x0; g.h = div_ceil(Y1, g.dy) - g.y0;             // param_siz::get_recon_width (:330-346)
+    g.frame_off = plan.frame_elems;
+    plan.frame_elems += (uint64_t)g.w * g.h;
+  }
+  for (uint32_t c = 0; c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c) {                    // canonical form: 1 is stored as 1
+    p.comp_dx[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dx : 0;
+    p.comp_dy[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dy : 0;
+  }
+  if (p.color_transform)                                                           // ojph_codestream_local.cpp:586-597
+    for (uint32_t c = 1; c < 3; ++c)
+      if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy)
+        return fail("the colour transform needs the first three components to have the same sub-sampling");
+  (void)subsampled;
   uint32_t lpw = 15, lph = 15;
   if (p.precinct_w && p.precinct_h) {
     lpw = ilog2(p.precinct_w); lph = ilog2(p.precinct_h);
@@ -162,8 +194,8 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   plan.p = p;
   derive_quant(plan);
 
-  plan.ntx = div_ceil(p.width, p.tile_w);
-  plan.nty = div_ceil(p.height, p.tile_h);
+  plan.ntx = div_ceil(X1 - p.tile_x0, p.tile_w);                                   // ojph_codestream_local.cpp:113-123
+  plan.nty = div_ceil(Y1 - p.tile_y0, p.tile_h);
   if ((uint64_t)plan.ntx * plan.nty > 65535) return fail("the number of tiles cannot exceed 65535");
   const uint32_t L = p.num_decomps;
   uint64_t arena = 0;
@@ -178,11 +210,17 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   for (uint32_t ty = 0; ty < plan.nty; ++ty)
     for (uint32_t tx = 0; tx < plan.ntx; ++tx) {
       Tile t; t.idx = ty * plan.ntx + tx;
-      t.r.x0 = tx * p.tile_w; t.r.y0 = ty * p.tile_h;
-      t.r.w = std::min(t.r.x0 + p.tile_w, p.width) - t.r.x0;
-      t.r.h = std::min(t.r.y0 + p.tile_h, p.height) - t.r.y0;
+      {                                                                           // ojph_codestream_local.cpp:133-163
+        const uint64_t gx0 = (uint64_t)p.tile_x0 + (uint64_t)tx * p.tile_w, gy0 = (uint64_t)p.tile_y0 + (uint64_t)ty * p.tile_h;
+        t.r.x0 = (uint32_t)std::max<uint64_t>(gx0, p.image_x0); t.r.y0 = (uint32_t)std::max<uint64_t>(gy0, p.image_y0);
+        t.r.w = (uint32_t)std::min<uint64_t>(gx0 + p.tile_w, X1) - t.r.x0;
+        t.r.h = (uint32_t)std::min<uint64_t>(gy0 + p.tile_h, Y1) - t.r.y0;
+      }
       for (uint32_t c = 0; c < p.num_comps; ++c) {
-        TileComp tc; tc.tile = t.idx; tc.comp = c; tc.r = t.r;     // no sub-sampling
+        const CompGeo& cg = plan.comps[c];
+        TileComp tc; tc.tile = t.idx; tc.comp = c;
+        tc.r.x0 = div_ceil(t.r.x0, cg.dx); tc.r.y0 = div_ceil(t.r.y0, cg.dy);      // ojph_tile.cpp:262-275
+        tc.r.w = div_ceil(t.r.x0 + t.r.w, cg.dx) - tc.r.x0; tc.r.h = div_ceil(t.r.y0 + t.r.h, cg.dy) - tc.r.y0;
         tc.res.assign(L + 1, 0);
         // resolution rectangles, top down (ojph_resolution.cpp:302-330 with band 0)
         std::vector<Rect> rr(L + 1);
@@ -251,7 +289,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
             for (uint32_t y = 0; y < R.nph; ++y)
               for (uint32_t x = 0; x < R.npw; ++x) {
                 Precinct P; P.tile = t.idx; P.comp = c; P.res = r;
-                uint64_t ix = (uint64_t)ds * (xlb + (x << lpw)), iy = (uint64_t)ds * (ylb + (y << lph));
+                uint64_t ix = (uint64_t)ds * cg.dx * (xlb + (x << lpw)), iy = (uint64_t)ds * cg.dy * (ylb + (y << lph));
                 P.img_x = (uint32_t)std::max<uint64_t>(ix, t.r.x0);
                 P.img_y = (uint32_t)std::max<uint64_t>(iy, t.r.y0);
                 for (int i = 0; i < 4; ++i) P.cb[i] = Rect{0, 0, 0, 0};
@@ -467,6 +505,19 @@ extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, 
     if (pitch) *pitch = R.pitch;
   }
   if (rect) { rect[0] = tc.r.x0; rect[1] = tc.r.y0; rect[2] = tc.r.w; rect[3] = tc.r.h; }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_comp_info(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8])
+{
+  if (!plan || !out) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  if (comp > P.p.num_comps) return OJPHGPU_E_INVALID;
+  memset(out, 0, 8 * sizeof(uint32_t));
+  if (comp == P.p.num_comps) { out[4] = (uint32_t)P.frame_elems; out[5] = (uint32_t)(P.frame_elems >> 32); return OJPHGPU_OK; }
+  const CompGeo& g = P.comps[comp];
+  out[0] = g.x0; out[1] = g.y0; out[2] = g.w; out[3] = g.h;
+  out[4] = (uint32_t)g.frame_off; out[5] = (uint32_t)(g.frame_off >> 32); out[6] = g.dx; out[7] = g.dy;
   return OJPHGPU_OK;
 }
 

@@ -74,8 +74,16 @@ struct CodedBlock {             // filled by the codestream parser
   uint64_t offset; uint32_t len1, len2, missing_msbs, num_passes;
 };
 
+struct CompGeo {                // one image component on its own (sub-sampled) grid
+  uint32_t dx, dy;              // sub-sampling factors (XRsiz, YRsiz)
+  uint32_t x0, y0, w, h;        // ceil(image offset / d) and the size up to ceil(image extent / d)
+  uint64_t frame_off;           // element offset of the component's plane in a frame (image buffer)
+};
+
 struct Plan {
   ojphgpu_params p;
+  std::vector<CompGeo> comps;
+  uint64_t frame_elems;         // elements of one frame = sum of the component planes
   uint32_t ntx, nty;
   uint32_t guard_bits;
   std::vector<uint8_t> spqcd8;   // reversible: exponent bytes as written in QCD

@@ -79,10 +79,12 @@ void write_main_header(const Plan& P, ByteSink& s)
   s.u16(SOC);
   // SIZ (ojph_params.cpp:805-851); Rsiz = 0x4000: HTJ2K codestream
   s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000);
-  s.u32(p.width); s.u32(p.height); s.u32(0); s.u32(0);
-  s.u32(p.tile_w); s.u32(p.tile_h); s.u32(0); s.u32(0);
+  s.u32(p.image_x0 + p.width); s.u32(p.image_y0 + p.height); s.u32(p.image_x0); s.u32(p.image_y0);
+  s.u32(p.tile_w); s.u32(p.tile_h); s.u32(p.tile_x0); s.u32(p.tile_y0);
   s.u16(p.num_comps);
-  for (uint32_t c = 0; c < p.num_comps; ++c) { s.u8((p.bit_depth - 1) | (p.is_signed ? 0x80 : 0)); s.u8(1); s.u8(1); }
+  for (uint32_t c = 0; c < p.num_comps; ++c) {
+    s.u8((p.bit_depth - 1) | (p.is_signed ? 0x80 : 0)); s.u8((uint8_t)P.comps[c].dx); s.u8((uint8_t)P.comps[c].dy);
+  }
   // CAP (ojph_params.cpp:968-989, Ccap from ojph_params_local.h:929-945 + get_MAGB :1615-1647)
   uint32_t B = 0;
   if (p.reversible) {
@@ -505,17 +507,20 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     if (m == SIZ) {
       uint32_t rsiz = r.u16();
       if ((rsiz & 0x4000) == 0) return OJPHGPU_E_CODESTREAM;      // not an HTJ2K codestream
-      p.width = r.u32(); p.height = r.u32();
-      uint32_t xo = r.u32(), yo = r.u32();
+      const uint32_t xs = r.u32(), ys = r.u32();                   // image extent
+      p.image_x0 = r.u32(); p.image_y0 = r.u32();
       p.tile_w = r.u32(); p.tile_h = r.u32();
-      uint32_t txo = r.u32(), tyo = r.u32();
-      if (xo || yo || txo || tyo) return OJPHGPU_E_INVALID;        // image / tile offsets: not supported yet
+      p.tile_x0 = r.u32(); p.tile_y0 = r.u32();
+      if (xs <= p.image_x0 || ys <= p.image_y0 || p.tile_w == 0 || p.tile_h == 0) return OJPHGPU_E_CODESTREAM;   // ojph_params_local.h:235-249
+      p.width = xs - p.image_x0; p.height = ys - p.image_y0;
       p.num_comps = r.u16();
       if (L != 38 + 3 * p.num_comps || p.num_comps == 0) return OJPHGPU_E_CODESTREAM;
       for (uint32_t c = 0; c < p.num_comps; ++c) {
         uint32_t ss = r.u8(), xr = r.u8(), yr = r.u8();
         uint32_t bd = (ss & 0x7F) + 1, sg = ss >> 7;
-        if (xr != 1 || yr != 1) return OJPHGPU_E_INVALID;         // sub-sampled components: not supported yet
+        if (xr == 0 || yr == 0) return OJPHGPU_E_CODESTREAM;
+        if ((xr != 1 || yr != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return OJPHGPU_E_INVALID;
+        if (c < OJPHGPU_MAX_SUBSAMPLED_COMPS) { p.comp_dx[c] = (uint8_t)xr; p.comp_dy[c] = (uint8_t)yr; }
         if (c == 0) { p.bit_depth = bd; p.is_signed = sg; }
         else if (bd != p.bit_depth || sg != p.is_signed) return OJPHGPU_E_INVALID;
       }
@@ -559,16 +564,11 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     r.pos = next;
   }
   if (!have_siz || !have_cod || !have_qcd) return OJPHGPU_E_CODESTREAM;
-  if (p.tile_w >= p.width && p.tile_h >= p.height) { /* single tile */ }
   ojphgpu_plan* h = new (std::nothrow) ojphgpu_plan();
   if (!h) return OJPHGPU_E_NOMEM;
-  ojphgpu_params pp = p;
-  if (pp.tile_w > pp.width) pp.tile_w = pp.width;     // geometry is identical; markers keep the original
-  if (pp.tile_h > pp.height) pp.tile_h = pp.height;
-  int rc = build_plan(pp, h->plan);
+  int rc = build_plan(p, h->plan);
   if (rc != OJPHGPU_OK) { delete h; return rc; }
   Plan& P = h->plan;
-  P.p.tile_w = p.tile_w; P.p.tile_h = p.tile_h;
   // the codestream's own quantisation parameters override the derived ones
   P.sqcd = sqcd; P.guard_bits = sqcd >> 5;
   if (p.reversible) { if ((sqcd & 0x1F) != 0 || q8.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.spqcd8 = q8; }

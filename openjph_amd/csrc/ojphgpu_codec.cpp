@@ -109,14 +109,14 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
 {
   out.clear();
   if (P.p.color_transform || P.p.num_decomps == 0) return;
-  const uint64_t plane = (uint64_t)P.p.width * P.p.height;
   size_t k = 0;
   for (const ojphgpu_level_info& lv : P.levels) {
     if (lv.res != P.p.num_decomps || !tr.has(lv.tile)) continue;
     ojphgpu_dwt_desc d = descs[top.first + k++];
     const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
-    d.src_off = (uint64_t)lv.comp * plane + (uint64_t)tc.r.y0 * P.p.width + tc.r.x0;
-    d.src_pitch = P.p.width;
+    const CompGeo& g = P.comps[lv.comp];
+    d.src_off = g.frame_off + (uint64_t)(tc.r.y0 - g.y0) * g.w + (tc.r.x0 - g.x0);
+    d.src_pitch = g.w;
     out.push_back(d);
   }
 }
@@ -133,7 +133,9 @@ void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       ojphgpu_convert_desc d; memset(&d, 0, sizeof(d));
       if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
       else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
-      d.w = tc.r.w; d.h = tc.r.h; d.src_x0 = tc.r.x0; d.src_y0 = tc.r.y0;
+      const CompGeo& g = P.comps[c];
+      d.w = tc.r.w; d.h = tc.r.h; d.src_x0 = tc.r.x0 - g.x0; d.src_y0 = tc.r.y0 - g.y0;
+      d.img_pitch = g.w; d.img_off = g.frame_off;
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
@@ -174,14 +176,14 @@ void replicate_image_levels(std::vector<ojphgpu_dwt_desc>& descs, uint32_t nfram
     }
 }
 
-void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems)
+void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
 {
   if (nframes <= 1 || descs.empty()) return;
   const size_t n = descs.size();
   for (uint32_t f = 1; f < nframes; ++f)
     for (size_t i = 0; i < n; ++i) {
       ojphgpu_convert_desc d = descs[i];
-      d.plane_off += (uint64_t)f * arena_elems; d.reserved = f;          // frame index: selects the image planes
+      d.plane_off += (uint64_t)f * arena_elems; d.img_off += (uint64_t)f * frame_elems;
       descs.push_back(d);
     }
 }
@@ -329,7 +331,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   e->tiles = TileRange{ tile_first, tile_count };
   e->nframes = nframes;
   const TileRange tr = e->tiles;
-  const uint64_t frame_elems = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
+  const uint64_t frame_elems = P.frame_elems;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, e->batches);
   std::vector<ojphgpu_dwt_desc> idd;
   if (!e->batches.empty()) build_image_level_descs(P, tr, dd, e->batches.front(), idd);
@@ -337,7 +339,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   replicate_levels(dd, e->batches, nframes, P.arena_elems);
   replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
-  replicate_converts(cd, nframes, P.arena_elems);
+  replicate_converts(cd, nframes, P.arena_elems, P.frame_elems);
   e->block_ids = blocks_of_tiles(P, tr);
   if (nframes == 1 && P.p.num_decomps >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
     auto top = [&](uint32_t id) { return P.bands[P.blocks[id].band].res == P.p.num_decomps; };
@@ -530,7 +532,7 @@ extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_
 {
   if (!e || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
-  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4 * e->nframes;
+  const size_t bytes = (size_t)P.frame_elems * 4 * e->nframes;
   if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes, hipMemcpyHostToDevice, e->stream));
   int rc = ojphgpu_encoder_run_device(e, (const int32_t*)e->image.p);
@@ -653,7 +655,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   d->tiles = TileRange{ tile_first, tile_count };
   d->nframes = nframes;
   const TileRange tr = d->tiles;
-  const uint64_t frame_elems = (uint64_t)P.p.width * P.p.height * P.p.num_comps;
+  const uint64_t frame_elems = P.frame_elems;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, d->batches);
   std::vector<ojphgpu_dwt_desc> idd;
   if (!d->batches.empty()) build_image_level_descs(P, tr, dd, d->batches.front(), idd);
@@ -662,7 +664,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
-  replicate_converts(cd, nframes, P.arena_elems);
+  replicate_converts(cd, nframes, P.arena_elems, P.frame_elems);
   std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
   // measured on MI355X: unlike in the encoder, the two-stream split does not pay here (both groups
   // start with the VALU-heavy prep launch and then sit in their serial chains; 0.96 vs 0.91 ms at
@@ -838,7 +840,7 @@ extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, s
   if (!d || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
   if (d->nframes != 1) return OJPHGPU_E_INVALID;           // batches: upload_frame + run_device
-  const size_t bytes = (size_t)P.p.width * P.p.height * P.p.num_comps * 4;
+  const size_t bytes = (size_t)P.frame_elems * 4;
   if (!d->image.p && d->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   int rc = ojphgpu_decoder_upload(d, h_codestream, len);
   if (rc) return rc;

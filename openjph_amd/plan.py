@@ -13,7 +13,10 @@ coded_dtype = np.dtype(CodedBlock)
 
 def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
-                prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None):
+                prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
+                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0)):
+    """width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
+    (dx, dy) per component (param_siz::set_component), default 1,1."""
     p = Params()
     p.width, p.height, p.num_comps = width, height, num_comps
     p.bit_depth, p.is_signed = bit_depth, int(is_signed)
@@ -29,6 +32,13 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
             pw, ph = precincts[min(i, len(precincts) - 1)]
             p.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
     p.tlm = int(tlm)
+    p.image_x0, p.image_y0 = image_offset
+    p.tile_x0, p.tile_y0 = tile_offset
+    if downsampling:
+        if len(downsampling) > 16:
+            raise ValueError("sub-sampling factors can be given for the first 16 components")
+        for c, (dx, dy) in enumerate(downsampling):
+            p.comp_dx[c], p.comp_dy[c] = int(dx), int(dy)
     return p
 
 
@@ -65,6 +75,47 @@ class Plan:
                 self.handle = None
         except Exception:
             pass
+
+    def comp_info(self, comp):
+        """-> dict(x0, y0, w, h, frame_off, dx, dy) of component `comp` (see ojphgpu_plan_comp_info)"""
+        out = (C.c_uint32 * 8)()
+        check(self._lib.ojphgpu_plan_comp_info(self.handle, comp, out))
+        v = [int(x) for x in out]
+        return dict(x0=v[0], y0=v[1], w=v[2], h=v[3], frame_off=v[4] | (v[5] << 32), dx=v[6], dy=v[7])
+
+    @property
+    def frame_elems(self):
+        out = (C.c_uint32 * 8)()
+        check(self._lib.ojphgpu_plan_comp_info(self.handle, int(self.params.num_comps), out))
+        return int(out[4]) | (int(out[5]) << 32)
+
+    @property
+    def frame_shape(self):
+        """[C,H,W] when every component has the same size, else the flat (frame_elems,)"""
+        ci = [self.comp_info(c) for c in range(int(self.params.num_comps))]
+        if all((c["w"], c["h"]) == (ci[0]["w"], ci[0]["h"]) for c in ci):
+            return (len(ci), ci[0]["h"], ci[0]["w"])
+        return (self.frame_elems,)
+
+    def pack_frame(self, planes):
+        """list of per-component 2-D arrays -> the frame layout every codec call takes"""
+        if len(self.frame_shape) == 3:
+            return np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.int32) for q in planes]))
+        out = np.empty(self.frame_elems, np.int32)
+        for c, q in enumerate(planes):
+            i = self.comp_info(c)
+            assert tuple(np.shape(q)) == (i["h"], i["w"]), "component %d must be %dx%d" % (c, i["h"], i["w"])
+            out[i["frame_off"]:i["frame_off"] + i["w"] * i["h"]] = np.asarray(q, dtype=np.int32).ravel()
+        return out
+
+    def unpack_frame(self, frame):
+        """frame (numpy, either layout) -> list of per-component 2-D arrays"""
+        flat = np.asarray(frame).reshape(-1)
+        out = []
+        for c in range(int(self.params.num_comps)):
+            i = self.comp_info(c)
+            out.append(flat[i["frame_off"]:i["frame_off"] + i["w"] * i["h"]].reshape(i["h"], i["w"]))
+        return out
 
     def comp_plane(self, tile, comp):
         off, pitch, rect = C.c_uint64(), C.c_uint32(), (C.c_uint32 * 4)()

@@ -47,6 +47,9 @@ struct ref_params {
   uint32_t precinct_w, precinct_h; // 0 => default (32768); applied to all resolutions
   uint32_t tlm;                  // request TLM marker
   uint8_t  precinct_exps[36];    // per resolution (0 = lowest): PPx | PPy << 4; all 0 => precinct_w/h for every resolution
+  uint32_t image_x0, image_y0;   // image offset; width/height are the image SIZE (extent = offset + size)
+  uint32_t tile_x0, tile_y0;     // tile offset
+  uint8_t  comp_dx[16], comp_dy[16];   // sub-sampling of component c < 16; 0 => 1
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -68,10 +71,14 @@ long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out,
     ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
     ojph::codestream cs;
     ojph::param_siz siz = cs.access_siz();
-    siz.set_image_extent(ojph::point(p->width, p->height));
+    siz.set_image_extent(ojph::point(p->image_x0 + p->width, p->image_y0 + p->height));
     siz.set_num_components(p->num_comps);
-    for (uint32_t c = 0; c < p->num_comps; ++c)
-      siz.set_component(c, ojph::point(1, 1), p->bit_depth, p->is_signed != 0);
+    for (uint32_t c = 0; c < p->num_comps; ++c) {
+      ojph::point ds(c < 16 && p->comp_dx[c] ? p->comp_dx[c] : 1, c < 16 && p->comp_dy[c] ? p->comp_dy[c] : 1);
+      siz.set_component(c, ds, p->bit_depth, p->is_signed != 0);
+    }
+    siz.set_image_offset(ojph::point(p->image_x0, p->image_y0));
+    siz.set_tile_offset(ojph::point(p->tile_x0, p->tile_y0));
     if (p->tile_w && p->tile_h)
       siz.set_tile_size(ojph::size(p->tile_w, p->tile_h));
     ojph::param_cod cod = cs.access_cod();
@@ -100,20 +107,20 @@ long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out,
     mf.open();
     cs.write_headers(&mf);
 
+    // the library says which component's line it wants next (planar, interleaved, sub-sampled alike)
+    std::vector<uint32_t> row(p->num_comps, 0), cw(p->num_comps), ch(p->num_comps);
+    uint64_t lines = 0;
+    for (uint32_t c = 0; c < p->num_comps; ++c) {
+      cw[c] = siz.get_recon_width(c); ch[c] = siz.get_recon_height(c); lines += ch[c];
+    }
     ojph::ui32 next_comp = 0;
     ojph::line_buf* line = cs.exchange(NULL, next_comp);
-    if (p->planar) {
-      for (uint32_t c = 0; c < p->num_comps; ++c)
-        for (uint32_t y = 0; y < p->height; ++y) {
-          memcpy(line->i32, planes[next_comp] + (size_t)y * p->width, sizeof(int32_t) * p->width);
-          line = cs.exchange(line, next_comp);
-        }
-    } else {
-      for (uint32_t y = 0; y < p->height; ++y)
-        for (uint32_t c = 0; c < p->num_comps; ++c) {
-          memcpy(line->i32, planes[next_comp] + (size_t)y * p->width, sizeof(int32_t) * p->width);
-          line = cs.exchange(line, next_comp);
-        }
+    for (uint64_t i = 0; i < lines; ++i) {
+      const uint32_t c = next_comp;
+      if (line == NULL || c >= p->num_comps || row[c] >= ch[c]) { cs.close(); return 0; }
+      memcpy(line->i32, planes[c] + (size_t)row[c] * cw[c], sizeof(int32_t) * cw[c]);
+      row[c]++;
+      line = cs.exchange(line, next_comp);
     }
     cs.flush();
     long len = (long)mf.tell();
@@ -144,22 +151,20 @@ int ref_decode(const uint8_t* data, long len, int32_t* const* planes, uint32_t* 
       info[0] = w; info[1] = h; info[2] = nc; info[3] = siz.get_bit_depth(0);
       info[4] = siz.is_signed(0) ? 1 : 0; info[5] = cs.access_cod().is_reversible() ? 1 : 0;
     }
+    if (info) {                      // per component (up to 16): recon width, height from info[8] on
+      for (uint32_t c = 0; c < nc && c < 16; ++c) { info[8 + 2 * c] = siz.get_recon_width(c); info[9 + 2 * c] = siz.get_recon_height(c); }
+    }
     if (planes == NULL) { cs.close(); return 0; }
     cs.create();
-    if (cs.is_planar()) {
-      for (uint32_t c = 0; c < nc; ++c)
-        for (uint32_t y = 0; y < h; ++y) {
-          ojph::ui32 cn;
-          ojph::line_buf* l = cs.pull(cn);
-          memcpy(planes[cn] + (size_t)y * w, l->i32, sizeof(int32_t) * w);
-        }
-    } else {
-      for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t c = 0; c < nc; ++c) {
-          ojph::ui32 cn;
-          ojph::line_buf* l = cs.pull(cn);
-          memcpy(planes[cn] + (size_t)y * w, l->i32, sizeof(int32_t) * w);
-        }
+    std::vector<uint32_t> row(nc, 0), cw(nc), chh(nc);
+    uint64_t lines = 0;
+    for (uint32_t c = 0; c < nc; ++c) { cw[c] = siz.get_recon_width(c); chh[c] = siz.get_recon_height(c); lines += chh[c]; }
+    for (uint64_t i = 0; i < lines; ++i) {
+      ojph::ui32 cn;
+      ojph::line_buf* l = cs.pull(cn);
+      if (l == NULL || cn >= nc || row[cn] >= chh[cn]) { cs.close(); return -3; }
+      memcpy(planes[cn] + (size_t)row[cn] * cw[cn], l->i32, sizeof(int32_t) * cw[cn]);
+      row[cn]++;
     }
     cs.close();
     return 0;

@@ -25,6 +25,8 @@ class RefParams(C.Structure):
         ("precinct_w", C.c_uint32), ("precinct_h", C.c_uint32),
         ("tlm", C.c_uint32),
         ("precinct_exps", C.c_uint8 * 36),
+        ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
+        ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
     ]
 
 
@@ -65,10 +67,19 @@ class Ref:
 
     def encode(self, planes, bit_depth, is_signed=False, reversible=True, num_decomps=5,
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
-               planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None):
-        """planes: int32 array [num_comps, H, W]. Returns codestream bytes."""
-        planes = np.ascontiguousarray(planes, dtype=np.int32)
-        nc, h, w = planes.shape
+               planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
+               downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None):
+        """planes: int32 array [num_comps, H, W], or a list of per-component 2-D arrays when the
+        components are sub-sampled (then size=(W, H) is the image size on the reference grid).
+        Returns codestream bytes."""
+        if isinstance(planes, (list, tuple)):
+            planes = [np.ascontiguousarray(q, dtype=np.int32) for q in planes]
+            nc = len(planes)
+            w, h = size if size is not None else (planes[0].shape[1], planes[0].shape[0])
+        else:
+            planes = np.ascontiguousarray(planes, dtype=np.int32)
+            nc, h, w = planes.shape
+            planes = [planes[c] for c in range(nc)]
         if planar is None:
             planar = not color_transform
         p = RefParams(w, h, nc, bit_depth, int(is_signed), int(reversible), num_decomps,
@@ -79,8 +90,12 @@ class Ref:
             for i in range(num_decomps + 1):
                 pw, ph = precincts[min(i, len(precincts) - 1)]
                 p.precinct_exps[i] = (pw.bit_length() - 1) | ((ph.bit_length() - 1) << 4)
+        p.image_x0, p.image_y0 = image_offset
+        p.tile_x0, p.tile_y0 = tile_offset
+        for c, (dx, dy) in enumerate(downsampling or []):
+            p.comp_dx[c], p.comp_dy[c] = dx, dy
         ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
-        cap = planes.size * 5 + (1 << 20)
+        cap = sum(q.size for q in planes) * 5 + (1 << 20)
         out = np.empty(cap, dtype=np.uint8)
         n = self.lib.ref_encode(C.byref(p), ptrs, out.ctypes.data, cap)
         if n <= 0:
@@ -89,13 +104,20 @@ class Ref:
 
     def decode(self, data: bytes, resilient=False):
         buf = np.frombuffer(data, dtype=np.uint8)
-        info = np.zeros(8, dtype=np.uint32)
+        info = np.zeros(8 + 32, dtype=np.uint32)
         r = self.lib.ref_decode(buf.ctypes.data, len(data), None, info.ctypes.data, int(resilient))
         if r != 0:
             raise RuntimeError("reference read_headers failed (%d)" % r)
         w, h, nc = int(info[0]), int(info[1]), int(info[2])
-        planes = np.zeros((nc, h, w), dtype=np.int32)
-        ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
+        dims = [(int(info[9 + 2 * c]), int(info[8 + 2 * c])) if c < 16 else (h, w) for c in range(nc)]
+        uniform = all(d == dims[0] for d in dims)
+        if uniform:
+            planes = np.zeros((nc, h, w), dtype=np.int32)
+            views = [planes[c] for c in range(nc)]
+        else:                              # sub-sampled components: a list of 2-D arrays
+            planes = [np.zeros(d, dtype=np.int32) for d in dims]
+            views = planes
+        ptrs = (C.c_void_p * nc)(*[v.ctypes.data for v in views])
         r = self.lib.ref_decode(buf.ctypes.data, len(data), ptrs, info.ctypes.data, int(resilient))
         if r != 0:
             raise RuntimeError("reference decode failed (%d)" % r)

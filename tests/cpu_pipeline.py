@@ -16,9 +16,11 @@ def _view(arena, off, pitch, w, h, dtype):
 
 
 def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
-    """image: int32 [C,H,W]. Returns the arena (uint32) after convert + all DWT levels.
+    """image: int32 [C,H,W], or a list of per-component planes (sub-sampled components).  Returns
+    the arena (uint32) after convert + all DWT levels.
     tiles=(first, count) restricts the work to a run of tiles (sharding tests)."""
     p = plan.params
+    comps = [plan.comp_info(c) for c in range(p.num_comps)]
     rev = bool(p.reversible)
     dt = np.int32 if rev else np.float32
     arena = np.zeros(plan.arena_elems, np.uint32)
@@ -28,7 +30,8 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
         planes = []
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
-            src = np.ascontiguousarray(image[c, y0:y0 + h, x0:x0 + w], dtype=np.int32)
+            x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]           # position inside the component's own plane
+            src = np.ascontiguousarray(image[c][y0:y0 + h, x0:x0 + w], dtype=np.int32)
             if rev:
                 shift = 0 if p.is_signed else -(1 << (p.bit_depth - 1))
                 dst = src + shift
@@ -95,9 +98,14 @@ def encode_blocks(plan: Plan, arena, tiles=None):
     return data, coded
 
 
-def encode(image, **kw):
-    image = np.ascontiguousarray(image, dtype=np.int32)
-    nc, h, w = image.shape
+def encode(image, size=None, **kw):
+    """image: int32 [C,H,W], or a list of per-component planes with size=(W, H) on the reference grid"""
+    if isinstance(image, (list, tuple)):
+        nc = len(image)
+        w, h = size if size is not None else (image[0].shape[1], image[0].shape[0])
+    else:
+        image = np.ascontiguousarray(image, dtype=np.int32)
+        nc, h, w = image.shape
     plan = Plan(make_params(w, h, nc, **kw))
     arena = forward_stages(plan, image)
     data, coded = encode_blocks(plan, arena)
@@ -106,7 +114,7 @@ def encode(image, **kw):
 
 def encode_tiles(plan: Plan, image, first, count):
     """Oracle pipeline over a run of tiles -> (tile-part bytes, Psot per tile)."""
-    arena = forward_stages(plan, np.ascontiguousarray(image, dtype=np.int32), (first, count))
+    arena = forward_stages(plan, image, (first, count))
     data, coded = encode_blocks(plan, arena, (first, count))
     return plan.t2_write_tiles(data, coded, first, count)
 
@@ -178,7 +186,8 @@ def inverse_stages(plan: Plan, arena):
         hh = _view(arena, int(lv["hh_off"]), int(lv["hh_pitch"]), hw, hh_, dt)
         dst = (ob.dwt53_inv if rev else ob.dwt97_inv)(ll, hl, lh, hh, w, h, xe, ye)
         _view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt)[:] = dst
-    image = np.zeros((p.num_comps, p.height, p.width), np.int32)
+    comps = [plan.comp_info(c) for c in range(p.num_comps)]
+    image = [np.zeros((ci["h"], ci["w"]), np.int32) for ci in comps]
     for t in range(plan.num_tiles):
         planes = []
         for c in range(p.num_comps):
@@ -198,8 +207,9 @@ def inverse_stages(plan: Plan, arena):
             else:
                 out = np.empty(v.shape, np.int32)
                 lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, p.bit_depth, int(p.is_signed))
-            image[c, y0:y0 + h, x0:x0 + w] = out
-    return image
+            x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]
+            image[c][y0:y0 + h, x0:x0 + w] = out
+    return np.stack(image) if len(plan.frame_shape) == 3 else image
 
 
 def decode(cs: bytes):

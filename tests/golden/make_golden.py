@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
-from tests.golden_cases import BLOCK_CASES, STREAM_CASES, REFINE_CASES, stream_kwargs, refine_case  # noqa: E402
+from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, stream_kwargs, refine_case,  # noqa: E402
+                                grid_kwargs)
 
 
 def sha(b):
@@ -71,6 +72,17 @@ def main():
         dec, _ = r.decode(cs)
         out["streams"].append({"case": i, "len": len(cs), "sha256": sha(cs),
                                "dec_sha256": sha(dec.astype(np.int32).tobytes())})
+    # (b2) general reference grid: sub-sampling, image / tile offsets
+    out["grid"] = []
+    for i, case in enumerate(GRID_CASES):
+        planes, kw, size = grid_kwargs(case)
+        r = ref if kw.get("reversible", True) else refgen
+        cs = r.encode(planes, size=size, **kw)
+        dec, _ = r.decode(cs)
+        dec = [dec[c] for c in range(len(planes))]
+        assert [d.shape for d in dec] == [q.shape for q in planes]
+        out["grid"].append({"case": i, "len": len(cs), "sha256": sha(cs),
+                            "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
     cs = ref.encode(c1_image(), 8)
     out["ka1"] = {"len": len(cs), "sha256": sha(cs), "fnv1a64": refbind.fnv1a64(cs)}
     with open(os.path.join(HERE, "golden.json"), "w") as f:

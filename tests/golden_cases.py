@@ -42,6 +42,43 @@ STREAM_CASES = [
 ]
 
 
+# codestreams on a general reference grid: sub-sampled components, image offset, tile offset
+# (the reference's own tests: -downsamp {1,1},{2,2},{2,2}, -image_offset {1,0}, tiles of 33x33)
+GRID_CASES = [
+    dict(w=352, h=288, bd=8, ds=[(1, 1), (2, 2), (2, 2)], reversible=False, qstep=0.1),           # CIF 4:2:0
+    dict(w=101, h=67, bd=8, ds=[(1, 1), (2, 2), (2, 2)], num_decomps=3),
+    dict(w=130, h=70, bd=10, ds=[(1, 1), (2, 1), (2, 1)], num_decomps=2, tile=(64, 32), prog_order="PCRL"),   # 4:2:2
+    dict(w=97, h=53, bd=8, ds=[(1, 1)], image_offset=(1, 0), reversible=False, num_decomps=4, qstep=0.1),
+    dict(w=1, h=300, bd=8, ds=[(1, 1)], image_offset=(1, 0), num_decomps=5),                      # tall and narrow at an odd origin
+    dict(w=97, h=53, bd=8, ds=[(1, 1)] * 3, image_offset=(5, 3), tile=(33, 33), tile_offset=(2, 1),
+         color_transform=True, num_decomps=3, prog_order="CPRL"),
+    dict(w=120, h=90, bd=12, ds=[(1, 1), (2, 2), (4, 1)], image_offset=(3, 7), tile=(50, 40), tile_offset=(1, 2),
+         num_decomps=3, precinct=(32, 32)),
+    dict(w=200, h=150, bd=8, ds=[(1, 1), (2, 2), (2, 2), (1, 1)], reversible=False, qstep=0.02, tile=(128, 128),
+         prog_order="RLCP", tlm=True),
+    dict(w=64, h=64, bd=8, ds=[(1, 1), (3, 5)], image_offset=(7, 11), num_decomps=2, prog_order="LRCP"),
+]
+
+
+def grid_kwargs(case, seed=5):
+    """-> (list of per-component int32 planes, kwargs for plan.make_params / refbind.Ref.encode,
+    (W, H) on the reference grid)"""
+    import numpy as np
+    c = dict(case)
+    w, h, bd, ds = c.pop("w"), c.pop("h"), c.pop("bd"), c.pop("ds")
+    ox, oy = c.get("image_offset", (0, 0))
+    rng = np.random.default_rng(seed)
+    planes = []
+    for i, (dx, dy) in enumerate(ds):
+        cw = -(-(ox + w) // dx) - -(-ox // dx)
+        ch = -(-(oy + h) // dy) - -(-oy // dy)
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        smooth = (np.sin(xx / (7.0 + i)) + np.cos(yy / (5.0 + 2 * i))) * (1 << (bd - 3)) + (1 << (bd - 1))
+        noise = rng.integers(-(1 << max(bd - 5, 0)), (1 << max(bd - 5, 0)) + 1, size=(ch, cw))
+        planes.append(np.clip(smooth + noise, 0, (1 << bd) - 1).astype(np.int32))
+    return planes, dict(c, bit_depth=bd, downsampling=ds), (w, h)
+
+
 def stream_kwargs(case, seed=3):
     """-> (image int32 [C,H,W], kwargs understood by plan.make_params / refbind.Ref.encode)"""
     c = dict(case)

@@ -18,7 +18,8 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import BLOCK_CASES, REFINE_CASES, STREAM_CASES, refine_case, stream_kwargs
+from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, STREAM_CASES, grid_kwargs, refine_case,
+                                stream_kwargs)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -246,6 +247,60 @@ def test_codestream_matches_live_reference(i, ref, refgen):
     dec, _ = cp.decode(want)
     wdec, _ = r.decode(want)
     assert np.array_equal(dec, wdec)
+
+
+def _planes_bytes(planes):
+    return b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in planes)
+
+
+def _as_list(dec, n):
+    return [dec[c] for c in range(n)]
+
+
+@pytest.mark.parametrize("i", range(len(GRID_CASES)), ids=lambda i: "grid%d" % i)
+def test_grid_codestream_matches_golden(i):
+    """Sub-sampled components, image offsets and tile offsets: plan geometry + Tier-2 + oracle stages
+    against the stored reference codestreams (ojph_codestream_local.cpp:113-163, ojph_tile.cpp:253-289)."""
+    from tests import cpu_pipeline as cp
+    planes, kw, size = grid_kwargs(GRID_CASES[i])
+    g = GOLD["grid"][i]
+    cs, plan, *_ = cp.encode(planes, size=size, **kw)
+    assert len(cs) == g["len"], "codestream size %d, reference %d" % (len(cs), g["len"])
+    assert sha(cs) == g["sha256"]
+    assert [(c["h"], c["w"]) for c in (plan.comp_info(k) for k in range(len(planes)))] == [q.shape for q in planes]
+    dec, _ = cp.decode(cs)
+    dec = _as_list(dec, len(planes))
+    assert sha(_planes_bytes(dec)) == g["dec_sha256"]
+    if kw.get("reversible", True):
+        assert all(np.array_equal(a, b) for a, b in zip(dec, planes))
+
+
+@pytest.mark.parametrize("i", [0, 2, 5, 6])
+def test_grid_codestream_matches_live_reference(i, ref, refgen):
+    from tests import cpu_pipeline as cp
+    planes, kw, size = grid_kwargs(GRID_CASES[i], seed=12)
+    r = ref if kw.get("reversible", True) else refgen
+    want = r.encode(planes, size=size, **kw)
+    cs, *_ = cp.encode(planes, size=size, **kw)
+    assert cs == want
+    dec, _ = cp.decode(want)
+    wdec, _ = r.decode(want)
+    assert all(np.array_equal(a, b) for a, b in zip(_as_list(dec, len(planes)), _as_list(wdec, len(planes))))
+
+
+def test_grid_parameter_validation():
+    """the reference's SIZ rules (ojph_params_local.h:235-249) and the colour-transform rule (:455-480)"""
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 1, image_offset=(2, 2), tile_offset=(3, 0)))          # tile offset > image offset
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 1, image_offset=(40, 0), tile=(32, 32)))              # first tile misses the image
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 3, color_transform=True, downsampling=[(1, 1), (2, 2), (2, 2)]))
+    pl = Plan(make_params(64, 64, 3, downsampling=[(1, 1), (2, 2), (2, 2)]))
+    assert pl.frame_shape == (64 * 64 + 2 * 32 * 32,)
+    assert Plan(make_params(64, 64, 3)).frame_shape == (3, 64, 64)
 
 
 def test_irreversible_tolerance_vs_simd_reference(ref):

@@ -58,6 +58,32 @@ def test_encode_decode_matches_oracle(case):
         assert np.array_equal(dec, img)
 
 
+@pytest.mark.parametrize("i", range(9), ids=lambda i: "grid%d" % i)
+def test_grid_encode_decode_matches_oracle(i):
+    """sub-sampled components, image and tile offsets (tests/golden_cases.py GRID_CASES): the GPU
+    codec against the oracle pipeline and against the stored digests of the reference's codestreams"""
+    import hashlib
+    import json
+    import os
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    from tests import cpu_pipeline as cp
+    from tests.golden_cases import GRID_CASES, grid_kwargs
+    planes, kw, size = grid_kwargs(GRID_CASES[i])
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["grid"][i]
+    enc = codec.Encoder(make_params(size[0], size[1], len(planes), **kw))
+    got = enc.encode(planes)
+    want, plan, *_ = cp.encode(planes, size=size, **kw)
+    assert got == want
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
+    dec = codec.Decoder(want)
+    out = plan.unpack_frame(dec.decode())
+    want_dec, _ = cp.decode(want)
+    for c in range(len(planes)):
+        assert np.array_equal(out[c], want_dec[c]), "component %d differs" % c
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
+
+
 def test_c1_matches_reference_bytes(ref):
     """BASELINE config #1 (256x256 8-bit, 5/3): identical bytes to the reference library."""
     from openjph_amd import codec
