@@ -52,10 +52,30 @@ inline bool ends_with(const std::string& s, const char* suf) {
   return true;
 }
 
-struct Image {                       // planar int32 samples
+struct Image {                       // planar int32 samples; sub-sampled components have their own size
   unsigned width = 0, height = 0, num_comps = 0, bit_depth = 8; bool is_signed = false;
+  std::vector<unsigned> cw, ch;      // per component (empty until layout() is called)
+  std::vector<size_t> off;
   std::vector<int> data;
-  int* plane(unsigned c) { return data.data() + (size_t)c * width * height; }
+  // component c is ceil(width / dx[c]) x ceil(height / dy[c]) unless explicit sizes are given
+  void layout(const std::vector<unsigned>& dx = {}, const std::vector<unsigned>& dy = {}) {
+    cw.assign(num_comps, width); ch.assign(num_comps, height); off.assign(num_comps, 0);
+    size_t total = 0;
+    for (unsigned c = 0; c < num_comps; ++c) {
+      if (c < dx.size() && dx[c] > 1) cw[c] = (width + dx[c] - 1) / dx[c];
+      if (c < dy.size() && dy[c] > 1) ch[c] = (height + dy[c] - 1) / dy[c];
+      off[c] = total; total += (size_t)cw[c] * ch[c];
+    }
+    data.resize(total);
+  }
+  void layout_sizes(const std::vector<unsigned>& w, const std::vector<unsigned>& h) {
+    cw = w; ch = h; off.assign(num_comps, 0);
+    size_t total = 0;
+    for (unsigned c = 0; c < num_comps; ++c) { off[c] = total; total += (size_t)cw[c] * ch[c]; }
+    data.resize(total);
+  }
+  size_t samples() const { return data.size(); }
+  int* plane(unsigned c) { return data.data() + off[c]; }
 };
 
 inline int pnm_token(FILE* f) {
@@ -84,7 +104,7 @@ inline void read_pnm(const char* name, Image& img) {
   std::vector<unsigned char> raw(n * img.num_comps * bps);
   if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short PNM file"); }
   fclose(f);
-  img.data.resize(n * img.num_comps);
+  img.layout();
   for (size_t i = 0; i < n; ++i)
     for (unsigned c = 0; c < img.num_comps; ++c) {
       const unsigned char* p = raw.data() + (i * img.num_comps + c) * bps;
@@ -94,6 +114,8 @@ inline void read_pnm(const char* name, Image& img) {
 
 inline void write_pnm(const char* name, Image& img) {
   if (img.num_comps != 1 && img.num_comps != 3) throw std::runtime_error("PGM / PPM need 1 or 3 components");
+  for (unsigned c = 0; c < img.num_comps; ++c)
+    if (img.cw[c] != img.width || img.ch[c] != img.height) throw std::runtime_error("PGM / PPM cannot hold sub-sampled components; write a .yuv");
   FILE* f = fopen(name, "wb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
   const int maxv = (1 << img.bit_depth) - 1; const size_t bps = maxv > 255 ? 2 : 1;
@@ -114,11 +136,10 @@ inline void write_pnm(const char* name, Image& img) {
 inline void read_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "rb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
-  const size_t n = (size_t)img.width * img.height * img.num_comps, bps = img.bit_depth > 8 ? 2 : 1;
+  const size_t n = img.samples(), bps = img.bit_depth > 8 ? 2 : 1;    // img.layout() was called: planes follow each other
   std::vector<unsigned char> raw(n * bps);
   if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short raw file"); }
   fclose(f);
-  img.data.resize(n);
   for (size_t i = 0; i < n; ++i) {
     int v = bps == 2 ? raw[2 * i] | (raw[2 * i + 1] << 8) : raw[i];
     if (img.is_signed) { const int sh = 32 - (int)img.bit_depth; v = (int)((unsigned)v << sh) >> sh; }
@@ -129,7 +150,7 @@ inline void read_raw(const char* name, Image& img) {
 inline void write_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "wb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
-  const size_t n = (size_t)img.width * img.height * img.num_comps, bps = img.bit_depth > 8 ? 2 : 1;
+  const size_t n = img.samples(), bps = img.bit_depth > 8 ? 2 : 1;
   std::vector<unsigned char> raw(n * bps);
   for (size_t i = 0; i < n; ++i) {
     const int v = img.data[i];

@@ -4,6 +4,7 @@
 // 5 decompositions, 64x64 blocks; PPM input switches the colour transform on, :754-757; .yuv /
 // .raw input needs -dims -num_comps -bit_depth [-signed] and is planar without colour transform,
 // :997-1021).  Prints "Elapsed time = ..." like the reference (:1220-1222).
+#include <algorithm>
 #include <chrono>
 #include "ojph_app_common.h"
 #include "../../include/ojph_gpu_codestream.h"
@@ -12,7 +13,8 @@ static void usage() {
   printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f]\n"
          "  [-num_decomps n] [-block_size {w,h}] [-precincts {w,h}] [-prog_order LRCP|RLCP|RPCL|PCRL|CPRL]\n"
          "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n]\n"
-         "  raw input: -dims {w,h} -num_comps n -bit_depth b [-signed true|false]\n");
+         "  [-image_offset {x,y}] [-tile_offset {x,y}]\n"
+         "  raw input: -dims {w,h} -num_comps n -bit_depth b [-signed true|false] [-downsamp {x,y},{x,y},...]\n");
 }
 
 int main(int argc, char** argv) {
@@ -21,6 +23,7 @@ int main(int argc, char** argv) {
   if (!in || !out) { usage(); return -1; }
   try {
     Image img;
+    std::vector<unsigned> dsx, dsy;                  // -downsamp {x,y} per component; the last pair repeats (ojph_compress.cpp:1003-1016)
     const std::string ins(in);
     const bool pnm = ends_with(ins, ".pgm") || ends_with(ins, ".ppm");
     if (pnm) read_pnm(in, img);
@@ -33,7 +36,13 @@ int main(int argc, char** argv) {
       img.bit_depth = (unsigned)Args::numbers(a.get("-bit_depth"))[0];
       auto sg = Args::bools(a.get("-signed")); img.is_signed = !sg.empty() && sg[0];
       auto ds = Args::numbers(a.get("-downsamp"));
-      for (long d : ds) if (d != 1) throw std::runtime_error("-downsamp other than {1,1} is not available on the GPU path");
+      if (ds.size() % 2) throw std::runtime_error("-downsamp takes {x,y} pairs");
+      for (unsigned c = 0; c < img.num_comps && !ds.empty(); ++c) {
+        const size_t k = std::min<size_t>(c, ds.size() / 2 - 1);
+        if (ds[2 * k] < 1 || ds[2 * k + 1] < 1 || ds[2 * k] > 255 || ds[2 * k + 1] > 255) throw std::runtime_error("-downsamp factors must be 1..255");
+        dsx.push_back((unsigned)ds[2 * k]); dsy.push_back((unsigned)ds[2 * k + 1]);
+      }
+      img.layout(dsx, dsy);
       read_raw(in, img);
     } else throw std::runtime_error("unknown input file extension (pgm, ppm, yuv, raw)");
 
@@ -41,13 +50,19 @@ int main(int argc, char** argv) {
     ojph::codestream cs;
     if (a.get("-device")) cs.set_device(atoi(a.get("-device")));
     ojph::param_siz siz = cs.access_siz();
-    siz.set_image_extent(ojph::point(img.width, img.height));
+    auto io = Args::numbers(a.get("-image_offset")), to = Args::numbers(a.get("-tile_offset"));
+    const ojph::point image_offset(io.size() == 2 ? (unsigned)io[0] : 0, io.size() == 2 ? (unsigned)io[1] : 0);
+    if ((image_offset.x || image_offset.y) && !dsx.empty())
+      for (unsigned c = 0; c < img.num_comps; ++c)
+        if (dsx[c] != 1 || dsy[c] != 1) throw std::runtime_error("-image_offset together with -downsamp: the planes of the input file would not match the reference grid");
+    siz.set_image_extent(ojph::point(image_offset.x + img.width, image_offset.y + img.height));       // ojph_compress.cpp:681-683
     siz.set_num_components(img.num_comps);
-    for (unsigned c = 0; c < img.num_comps; ++c) siz.set_component(c, ojph::point(1, 1), img.bit_depth, img.is_signed);
-    siz.set_image_offset(ojph::point(0, 0));
+    for (unsigned c = 0; c < img.num_comps; ++c)
+      siz.set_component(c, ojph::point(c < dsx.size() ? dsx[c] : 1, c < dsy.size() ? dsy[c] : 1), img.bit_depth, img.is_signed);
+    siz.set_image_offset(image_offset);
     auto ts = Args::numbers(a.get("-tile_size"));
-    siz.set_tile_size(ts.size() == 2 ? ojph::size((unsigned)ts[0], (unsigned)ts[1]) : ojph::size(img.width, img.height));
-    siz.set_tile_offset(ojph::point(0, 0));
+    siz.set_tile_size(ts.size() == 2 ? ojph::size((unsigned)ts[0], (unsigned)ts[1]) : ojph::size(0, 0));
+    siz.set_tile_offset(ojph::point(to.size() == 2 ? (unsigned)to[0] : 0, to.size() == 2 ? (unsigned)to[1] : 0));
 
     ojph::param_cod cod = cs.access_cod();
     cod.set_num_decomposition(a.get("-num_decomps") ? (unsigned)atoi(a.get("-num_decomps")) : 5);
@@ -77,7 +92,8 @@ int main(int argc, char** argv) {
     ojph::line_buf* line = cs.exchange(nullptr, next);
     std::vector<unsigned> row(img.num_comps, 0);
     while (line) {                                   // the codestream says which component it wants next
-      memcpy(line->i32, img.plane(next) + (size_t)row[next] * img.width, img.width * sizeof(int));
+      if (row[next] < img.ch[next])
+        memcpy(line->i32, img.plane(next) + (size_t)row[next] * img.cw[next], img.cw[next] * sizeof(int));
       row[next]++;
       line = cs.exchange(line, next);
     }

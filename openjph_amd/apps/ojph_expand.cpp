@@ -25,7 +25,9 @@ int main(int argc, char** argv) {
     img.num_comps = siz.get_num_components();
     img.width = siz.get_recon_width(0); img.height = siz.get_recon_height(0);
     img.bit_depth = siz.get_bit_depth(0); img.is_signed = siz.is_signed(0);
-    img.data.resize((size_t)img.width * img.height * img.num_comps);
+    std::vector<unsigned> cw, ch; size_t total_lines = 0;
+    for (unsigned c = 0; c < img.num_comps; ++c) { cw.push_back(siz.get_recon_width(c)); ch.push_back(siz.get_recon_height(c)); total_lines += ch.back(); }
+    img.layout_sizes(cw, ch);
     const std::string outs(out);
     const bool pnm = ends_with(outs, ".pgm") || ends_with(outs, ".ppm");
     if (ends_with(outs, ".pgm") && img.num_comps != 1) throw std::runtime_error("a .pgm output needs a 1-component codestream");
@@ -35,10 +37,11 @@ int main(int argc, char** argv) {
     cs.create();
     std::vector<unsigned> row(img.num_comps, 0);
     ojph::ui32 comp = 0;
-    for (size_t i = 0; i < (size_t)img.height * img.num_comps; ++i) {
+    for (size_t i = 0; i < total_lines; ++i) {
       ojph::line_buf* line = cs.pull(comp);
       if (!line) break;
-      memcpy(img.plane(comp) + (size_t)row[comp] * img.width, line->i32, img.width * sizeof(int));
+      if (row[comp] < img.ch[comp])
+        memcpy(img.plane(comp) + (size_t)row[comp] * img.cw[comp], line->i32, img.cw[comp] * sizeof(int));
       row[comp]++;
     }
     cs.close();

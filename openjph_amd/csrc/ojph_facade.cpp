@@ -118,6 +118,8 @@ struct codestream_state {
   ojphgpu_encoder* enc = nullptr;
   ojphgpu_decoder* dec = nullptr;
   si32* frame = nullptr; bool frame_pinned = false; size_t frame_elems = 0;
+  std::vector<ui32> cw, ch; std::vector<size_t> coff;   // component planes inside the frame (ojphgpu_plan_comp_info)
+  std::vector<si32> spare;                              // a line nobody reads (interleaved exchange past a short component)
   std::vector<ui8> stream;            // the whole codestream (decode)
   std::vector<line_buf> lines;
   ui32 cur_comp = 0, cur_line = 0;
@@ -143,7 +145,16 @@ struct codestream_state {
   }
   void alloc_frame()
   {
-    frame_elems = (size_t)p.width * p.height * p.num_comps;
+    cw.assign(p.num_comps, 0); ch.assign(p.num_comps, 0); coff.assign(p.num_comps, 0);
+    ui32 info[8], widest = 0;
+    for (ui32 c = 0; c < p.num_comps; ++c) {
+      ojphgpu_plan_comp_info(plan, c, info);
+      cw[c] = info[2]; ch[c] = info[3]; coff[c] = (size_t)info[4] | ((size_t)info[5] << 32);
+      widest = cw[c] > widest ? cw[c] : widest;
+    }
+    ojphgpu_plan_comp_info(plan, p.num_comps, info);
+    frame_elems = (size_t)info[4] | ((size_t)info[5] << 32);
+    spare.assign(widest, 0);
     // one frame per codestream object: pinning 400 MB costs more than the pageable copy it would
     // speed up (measured on the MI355X host: both ~57 GB/s), so the frame is plain memory; set
     // OJPH_GPU_PIN=1 for long-lived objects that restart() and reuse their buffers
@@ -153,10 +164,23 @@ struct codestream_state {
     if (!frame) ojph_error(0x00030F01, "cannot allocate the %zu-sample frame buffer", frame_elems);
     lines.assign(p.num_comps, line_buf());
     for (ui32 c = 0; c < p.num_comps; ++c) {
-      lines[c].size = p.width; lines[c].pre_size = 0; lines[c].flags = line_buf::LFT_32BIT | line_buf::LFT_INTEGER;
+      lines[c].size = cw[c]; lines[c].pre_size = 0; lines[c].flags = line_buf::LFT_32BIT | line_buf::LFT_INTEGER;
     }
   }
-  si32* row(ui32 comp, ui32 line) { return frame + ((size_t)comp * p.height + line) * p.width; }
+  si32* row(ui32 comp, ui32 line) { return line < ch[comp] ? frame + coff[comp] + (size_t)line * cw[comp] : spare.data(); }
+  // what param_siz::get_recon_width / _height report (ojph_params.cpp:330-346), also before the plan exists
+  ui32 recon_w(ui32 c) const
+  {
+    const ui32 d = c < comps.size() && comps[c].ds.x ? comps[c].ds.x : 1;
+    const ui64 x1 = (ui64)image_offset.x + p.width;
+    return (ui32)((x1 + d - 1) / d - ((ui64)image_offset.x + d - 1) / d);
+  }
+  ui32 recon_h(ui32 c) const
+  {
+    const ui32 d = c < comps.size() && comps[c].ds.y ? comps[c].ds.y : 1;
+    const ui64 y1 = (ui64)image_offset.y + p.height;
+    return (ui32)((y1 + d - 1) / d - ((ui64)image_offset.y + d - 1) / d);
+  }
 };
 
 }  // namespace local
@@ -164,9 +188,20 @@ struct codestream_state {
 using local::codestream_state;
 
 // ---- param_siz -----------------------------------------------------------------------------------
-void param_siz::set_image_extent(point extent) { state->p.width = extent.x; state->p.height = extent.y; }
+// the state keeps the image SIZE in p.width / p.height and the offset next to it: the extent the
+// reference's setter takes is their sum, whichever of the two setters is called first
+void param_siz::set_image_extent(point extent)
+{
+  state->p.width = extent.x > state->image_offset.x ? extent.x - state->image_offset.x : 0;
+  state->p.height = extent.y > state->image_offset.y ? extent.y - state->image_offset.y : 0;
+}
 void param_siz::set_tile_size(size s) { state->p.tile_w = s.w; state->p.tile_h = s.h; }
-void param_siz::set_image_offset(point offset) { state->image_offset = offset; }
+void param_siz::set_image_offset(point offset)
+{
+  const point extent = get_image_extent();
+  state->image_offset = offset;
+  set_image_extent(extent);
+}
 void param_siz::set_tile_offset(point offset) { state->tile_offset = offset; }
 void param_siz::set_num_components(ui32 num_comps)
 {
@@ -181,14 +216,18 @@ void param_siz::set_component(ui32 comp_num, const point& downsampling, ui32 bit
 }
 point param_siz::get_image_extent() const { return point(state->p.width + state->image_offset.x, state->p.height + state->image_offset.y); }
 point param_siz::get_image_offset() const { return state->image_offset; }
-size param_siz::get_tile_size() const { return size(state->p.tile_w ? state->p.tile_w : state->p.width, state->p.tile_h ? state->p.tile_h : state->p.height); }
+size param_siz::get_tile_size() const
+{
+  const point e = get_image_extent();                       // not set: what write_headers would choose (ojph_codestream_local.cpp:562-570)
+  return size(state->p.tile_w ? state->p.tile_w : e.x + state->image_offset.x, state->p.tile_h ? state->p.tile_h : e.y + state->image_offset.y);
+}
 point param_siz::get_tile_offset() const { return state->tile_offset; }
 ui32 param_siz::get_num_components() const { return state->p.num_comps; }
 ui32 param_siz::get_bit_depth(ui32 c) const { return c < state->comps.size() ? state->comps[c].bit_depth : state->p.bit_depth; }
 bool param_siz::is_signed(ui32 c) const { return c < state->comps.size() ? state->comps[c].is_signed : state->p.is_signed != 0; }
 point param_siz::get_downsampling(ui32 c) const { return c < state->comps.size() ? state->comps[c].ds : point(1, 1); }
-ui32 param_siz::get_recon_width(ui32) const { return state->p.width; }
-ui32 param_siz::get_recon_height(ui32) const { return state->p.height; }
+ui32 param_siz::get_recon_width(ui32 c) const { return state->recon_w(c); }
+ui32 param_siz::get_recon_height(ui32 c) const { return state->recon_h(c); }
 
 // ---- param_cod / param_qcd -----------------------------------------------------------------------
 void param_cod::set_num_decomposition(ui32 n)
@@ -277,20 +316,24 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
   if (S.headers_written) ojph_error(0x00030F02, "write_headers called twice");
   ojphgpu_params& p = S.p;
   if (p.num_comps == 0 || p.width == 0 || p.height == 0) ojph_error(0x00040001, "image extent / components have not been set");
-  if (S.image_offset.x || S.image_offset.y || S.tile_offset.x || S.tile_offset.y)
-    ojph_error(0x00030F03, "image / tile offsets are not available on the GPU path");
+  if (S.tile_offset.x > S.image_offset.x || S.tile_offset.y > S.image_offset.y)
+    ojph_error(0x00040002, "Tile offset has to be smaller than the image offset");                     // ojph_params_local.h:240
+  p.image_x0 = S.image_offset.x; p.image_y0 = S.image_offset.y; p.tile_x0 = S.tile_offset.x; p.tile_y0 = S.tile_offset.y;
+  memset(p.comp_dx, 0, sizeof(p.comp_dx)); memset(p.comp_dy, 0, sizeof(p.comp_dy));
   for (ui32 c = 0; c < p.num_comps; ++c) {
     const local::comp_info& ci = S.comps[c];
     if (!ci.set) ojph_error(0x00040002, "component %u has not been configured", c);
-    if (ci.ds.x != 1 || ci.ds.y != 1) ojph_error(0x00030F04, "component subsampling is not available on the GPU path");
+    if (ci.ds.x == 0 || ci.ds.y == 0 || ci.ds.x > 255 || ci.ds.y > 255) ojph_error(0x00030F04, "component sub-sampling factors must be 1..255");
+    if ((ci.ds.x != 1 || ci.ds.y != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS)
+      ojph_error(0x00030F04, "sub-sampling is available for the first %d components on the GPU path", OJPHGPU_MAX_SUBSAMPLED_COMPS);
+    if (c < OJPHGPU_MAX_SUBSAMPLED_COMPS) { p.comp_dx[c] = (uint8_t)ci.ds.x; p.comp_dy[c] = (uint8_t)ci.ds.y; }
     if (ci.bit_depth != S.comps[0].bit_depth || ci.is_signed != S.comps[0].is_signed)
       ojph_error(0x00030F05, "components of different bit depth / signedness are not available on the GPU path");
   }
   p.bit_depth = S.comps[0].bit_depth; p.is_signed = S.comps[0].is_signed;
-  if (p.tile_w >= p.width && p.tile_h >= p.height) p.tile_w = p.tile_h = 0;          // one tile
   if (p.color_transform && p.num_comps < 3)
     ojph_error(0x00040013, "color transform can only be employed when the image has 3 or more color components");   // ojph_params.cpp:560
-  if (S.planar == -1) S.planar = p.color_transform ? 0 : 1;        // not chosen: interleaved lines when the colour transform needs all components of a line
+  if (S.planar == -1) S.planar = p.color_transform ? 1 : 0;        // not chosen: the reference's rule (ojph_codestream_local.cpp:622-623)
   if (S.planar == 1 && p.color_transform)
     ojph_error(0x00030021, "the planar interface option cannot be used when colour transform is employed");          // :630
   if (comments != nullptr && num_comments != 0)
@@ -313,10 +356,10 @@ line_buf* codestream::exchange(line_buf* line, ui32& next_component)
   if (!S.headers_written) ojph_error(0x00030F09, "exchange called before write_headers");
   if (line) {                                   // the samples are already in place (the line points into the frame)
     if (S.exhausted) { next_component = 0; return nullptr; }
-    if (S.planar) {
-      if (++S.cur_line >= S.p.height) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) { S.exhausted = true; next_component = 0; return nullptr; } }
-    } else {
-      if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.p.height) { S.exhausted = true; next_component = 0; return nullptr; } }
+    if (S.planar) {                             // one component at a time, each with its own height (:1195-1207)
+      if (++S.cur_line >= S.ch[S.cur_comp]) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) { S.exhausted = true; next_component = 0; return nullptr; } }
+    } else {                                    // every component for every line of component 0 (:1208-1219)
+      if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.ch[0]) { S.exhausted = true; next_component = 0; return nullptr; } }
     }
   }
   next_component = S.cur_comp;
@@ -352,6 +395,9 @@ void codestream::read_headers(infile_base* file)
   if (rc) ojph_error(0x00030F0C, "codestream not supported by the GPU path (status %d)", rc);
   ojphgpu_plan_params(S.plan, &S.p);
   S.comps.assign(S.p.num_comps, local::comp_info{ point(1, 1), S.p.bit_depth, S.p.is_signed != 0, true });
+  for (ui32 c = 0; c < S.p.num_comps && c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c)
+    S.comps[c].ds = point(S.p.comp_dx[c] ? S.p.comp_dx[c] : 1, S.p.comp_dy[c] ? S.p.comp_dy[c] : 1);
+  S.image_offset = point(S.p.image_x0, S.p.image_y0); S.tile_offset = point(S.p.tile_x0, S.p.tile_y0);
   if (S.planar == -1) S.planar = S.p.color_transform ? 0 : 1;                                         // :879
   S.headers_read = true;
 }
@@ -388,9 +434,9 @@ line_buf* codestream::pull(ui32& comp_num)
   line_buf* l = &S.lines[S.cur_comp];
   l->i32 = S.row(S.cur_comp, S.cur_line);
   if (S.planar) {
-    if (++S.cur_line >= S.p.height) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) S.exhausted = true; }
+    if (++S.cur_line >= S.ch[S.cur_comp]) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) S.exhausted = true; }
   } else {
-    if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.p.height) S.exhausted = true; }
+    if (++S.cur_comp >= S.p.num_comps) { S.cur_comp = 0; if (++S.cur_line >= S.ch[0]) S.exhausted = true; }
   }
   return l;
 }

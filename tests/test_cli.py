@@ -112,3 +112,39 @@ def test_cli_raw_planar_12bit_irreversible(tmp_path):
     dec = np.fromfile(back, dtype="<u2").reshape(3, 120, 160).astype(np.int32)
     want_dec, _ = cp.decode(want)
     assert np.array_equal(dec, want_dec)
+
+
+@pytest.mark.gpu
+def test_cli_yuv420_and_image_offset(tmp_path):
+    """the reference's own CLI cases: -downsamp {1,1},{2,2},{2,2} on a CIF frame
+    (tests/test_executables.cpp:1437-1464) and -image_offset {1,0} on a tall, narrow image (:1491)"""
+    from tests import cpu_pipeline as cp
+    from tests.golden_cases import GRID_CASES, grid_kwargs
+    planes, kw, size = grid_kwargs(GRID_CASES[0])                       # 352x288 4:2:0, 9/7, qstep 0.1
+    src = tmp_path / "foreman.yuv"
+    with open(src, "wb") as f:
+        for q in planes:
+            f.write(q.astype("u1").tobytes())
+    j2c = tmp_path / "out.j2c"
+    r = run([COMPRESS, "-i", str(src), "-o", str(j2c), "-qstep", "0.1", "-dims", "{352,288}", "-num_comps", "3",
+             "-downsamp", "{1,1},{2,2},{2,2}", "-bit_depth", "8,8,8", "-signed", "false,false,false"])
+    assert r.returncode == 0, r.stdout
+    want, *_ = cp.encode(planes, size=size, **kw)
+    assert open(j2c, "rb").read() == want
+    back = tmp_path / "back.yuv"
+    r = run([EXPAND, "-i", str(j2c), "-o", str(back)])
+    assert r.returncode == 0, r.stdout
+    want_dec, _ = cp.decode(want)
+    got = np.fromfile(back, dtype="u1").astype(np.int32)
+    assert np.array_equal(got, np.concatenate([np.clip(q, 0, 255).ravel() for q in want_dec]))
+
+    img = synth_image(1, 300, 1, 8, seed=9)                             # tall and narrow, origin at x = 1
+    write_pnm(tmp_path / "t.pgm", img, 8)
+    r = run([COMPRESS, "-i", str(tmp_path / "t.pgm"), "-o", str(tmp_path / "t.j2c"), "-reversible", "true",
+             "-image_offset", "{1,0}"])
+    assert r.returncode == 0, r.stdout
+    want, *_ = cp.encode([img[0]], size=(1, 300), bit_depth=8, downsampling=[(1, 1)], image_offset=(1, 0))
+    assert open(tmp_path / "t.j2c", "rb").read() == want
+    r = run([EXPAND, "-i", str(tmp_path / "t.j2c"), "-o", str(tmp_path / "t_back.pgm")])
+    assert r.returncode == 0, r.stdout
+    assert np.array_equal(read_pnm(tmp_path / "t_back.pgm"), img)
