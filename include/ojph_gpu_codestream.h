@@ -15,7 +15,7 @@
 //
 // Not every knob of the reference exists behind the GPU path: all
 // components must share bit depth / signedness (sub-sampling, image and tile offsets are
-// supported), no tile-part divisions, no reduced-resolution decoding, no user COM markers.  Such
+// supported, and so is reduced-resolution decoding), no tile-part divisions, no user COM markers.  Such
 // requests fail loudly in write_headers() / read_headers() / the setter.
 #ifndef OJPH_GPU_CODESTREAM_H
 #define OJPH_GPU_CODESTREAM_H

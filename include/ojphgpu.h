@@ -154,6 +154,12 @@ int  ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile
 int  ojphgpu_t2_parse(const uint8_t* h_codestream, size_t len, int resilient, ojphgpu_plan** out);
 /* after ojphgpu_t2_parse: per-block coded info (offsets are into the parsed codestream) */
 int  ojphgpu_plan_coded_blocks(const ojphgpu_plan* plan, ojphgpu_coded_block* out, size_t n);
+/* codestream::restrict_input_resolution (ojph_codestream_local.cpp:883-900) on a parsed plan, before
+ * a decoder is created from it: the top `skipped_res_for_data` resolutions are not decoded and the
+ * top `skipped_res_for_recon` (<= the former) are not synthesised.  The frame of the decoder -- and
+ * what ojphgpu_plan_comp_info reports -- shrinks to ceil(size / 2^skipped_res_for_recon). */
+int  ojphgpu_plan_restrict_resolution(ojphgpu_plan* plan, uint32_t skipped_res_for_data,
+                                      uint32_t skipped_res_for_recon);
 
 /* ------------------------------------------------------------------------------------------ *
  * 4. Batched device stages.  Descriptor arrays live in device memory.

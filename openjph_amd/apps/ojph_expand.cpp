@@ -1,6 +1,6 @@
 // openjph_amd/apps/ojph_expand.cpp -- command-line decoder on the GPU path, option-compatible with
 // the reference's ojph_expand (src/apps/ojph_expand/ojph_expand.cpp:75-438): -i, -o, -skip_res
-// (only 0 on the GPU path), -resilient.  Output: .pgm (1 component), .ppm (3 components), .yuv /
+// ({n} or {for_data,for_recon}), -resilient.  Output: .pgm (1 component), .ppm (3 components), .yuv /
 // .raw (planar).  Prints "Elapsed time = ..." (:204).
 #include <chrono>
 #include "ojph_app_common.h"

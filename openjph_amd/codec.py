@@ -147,15 +147,20 @@ class Encoder:
 class Decoder:
     """Whole-frame decoder bound to one parsed codestream layout (ojphgpu_decoder)."""
 
-    def __init__(self, codestream, device=0, resilient=False, tiles=None):
+    def __init__(self, codestream, device=0, resilient=False, tiles=None, skip_res=None):
         """codestream: bytes, or a list of codestreams of same-shaped frames (batch decoder, output
-        [B,C,H,W]).  tiles=(first, count) restricts the decoder to a run of tiles (multi-GPU sharding)."""
+        [B,C,H,W]).  tiles=(first, count) restricts the decoder to a run of tiles (multi-GPU sharding).
+        skip_res=n or (for_data, for_recon): reduced-resolution decoding (codestream::restrict_input_resolution)."""
         torch = _torch()
         self.device = device
         self.resilient = resilient
         streams = list(codestream) if isinstance(codestream, (list, tuple)) else [codestream]
         self.frames = len(streams)
         self.plans = [parse_codestream(cs, resilient) for cs in streams]
+        if skip_res:
+            a, b = (skip_res, skip_res) if isinstance(skip_res, int) else skip_res
+            for pl in self.plans:
+                pl.restrict_resolution(a, b)
         self.plan = self.plans[0]
         self.tiles = (0, self.plan.num_tiles) if tiles is None else (int(tiles[0]), int(tiles[1]))
         self._lib = capi.lib()
@@ -228,8 +233,8 @@ def encode(image: np.ndarray, device=0, **kw) -> bytes:
     return Encoder(make_params(w, h, nc, **kw), device=device).encode(image)
 
 
-def decode(codestream: bytes, device=0, resilient=False) -> np.ndarray:
-    return Decoder(codestream, device=device, resilient=resilient).decode()
+def decode(codestream: bytes, device=0, resilient=False, skip_res=None) -> np.ndarray:
+    return Decoder(codestream, device=device, resilient=resilient, skip_res=skip_res).decode()
 
 
 # -------------------------------------------------------------------------------------------------

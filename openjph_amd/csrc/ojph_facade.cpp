@@ -108,6 +108,7 @@ struct codestream_state {
   std::vector<comp_info> comps;
   point image_offset, tile_offset;
   int planar = -1;                    // -1: not chosen (ojph_codestream_local.cpp:89)
+  ui32 skip_recon = 0;                // resolutions left out of the reconstruction (restrict_input_resolution)
   bool resilient = false;
   bool headers_written = false, headers_read = false, decoded = false;
   std::string profile;
@@ -131,7 +132,7 @@ struct codestream_state {
     memset(&p, 0, sizeof(p));
     p.reversible = 0; p.num_decomps = 5; p.block_w = 64; p.block_h = 64;      // param_cod defaults (ojph_params_local.h:560-575)
     p.prog_order = 2; p.qstep = -1.0f;                                      // RPCL; qstep chosen from the bit depth
-    comps.clear(); image_offset = point(0, 0); tile_offset = point(0, 0);
+    comps.clear(); image_offset = point(0, 0); tile_offset = point(0, 0); skip_recon = 0;
   }
   void release()
   {
@@ -171,13 +172,13 @@ struct codestream_state {
   // what param_siz::get_recon_width / _height report (ojph_params.cpp:330-346), also before the plan exists
   ui32 recon_w(ui32 c) const
   {
-    const ui32 d = c < comps.size() && comps[c].ds.x ? comps[c].ds.x : 1;
+    const ui64 d = (ui64)(c < comps.size() && comps[c].ds.x ? comps[c].ds.x : 1) << skip_recon;
     const ui64 x1 = (ui64)image_offset.x + p.width;
     return (ui32)((x1 + d - 1) / d - ((ui64)image_offset.x + d - 1) / d);
   }
   ui32 recon_h(ui32 c) const
   {
-    const ui32 d = c < comps.size() && comps[c].ds.y ? comps[c].ds.y : 1;
+    const ui64 d = (ui64)(c < comps.size() && comps[c].ds.y ? comps[c].ds.y : 1) << skip_recon;
     const ui64 y1 = (ui64)image_offset.y + p.height;
     return (ui32)((y1 + d - 1) / d - ((ui64)image_offset.y + d - 1) / d);
   }
@@ -402,10 +403,20 @@ void codestream::read_headers(infile_base* file)
   S.headers_read = true;
 }
 
+// (ojph_codestream_local.cpp:883-900)
 void codestream::restrict_input_resolution(ui32 skipped_res_for_data, ui32 skipped_res_for_recon)
 {
-  if (skipped_res_for_data || skipped_res_for_recon)
-    ojph_error(0x00030F0D, "reduced-resolution decoding is not available on the GPU path");
+  codestream_state& S = *state;
+  if (!S.headers_read) ojph_error(0x00030F0D, "restrict_input_resolution called before read_headers");
+  if (skipped_res_for_data < skipped_res_for_recon)
+    ojph_error(0x000300A1, "skipped_resolution for data %d must be equal or smaller than skipped_resolution for reconstruction %d",
+               skipped_res_for_data, skipped_res_for_recon);
+  if (skipped_res_for_data > S.p.num_decomps)
+    ojph_error(0x000300A2, "skipped_resolution for data %d must be smaller than the number of decomposition levels %d",
+               skipped_res_for_data, S.p.num_decomps);
+  if (ojphgpu_plan_restrict_resolution(S.plan, skipped_res_for_data, skipped_res_for_recon) != OJPHGPU_OK)
+    ojph_error(0x00030F0D, "the GPU path rejected the resolution restriction");
+  S.skip_recon = skipped_res_for_recon;
 }
 
 void codestream::create()

@@ -494,7 +494,7 @@ extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, 
   const Plan& P = plan->plan;
   if (tile >= P.tiles.size() || comp >= P.p.num_comps) return OJPHGPU_E_INVALID;
   const TileComp& tc = P.tcomps[P.tiles[tile].comps[comp]];
-  uint32_t L = P.p.num_decomps;
+  uint32_t L = P.p.num_decomps - P.skip_recon;              // reduced-resolution decoding reconstructs a lower resolution
   const Resolution& R = P.ress[tc.res[L]];
   if (L == 0) {
     const Band& B = P.bands[(size_t)R.band[0]];
@@ -504,7 +504,28 @@ extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, 
     if (off) *off = R.plane_off;
     if (pitch) *pitch = R.pitch;
   }
-  if (rect) { rect[0] = tc.r.x0; rect[1] = tc.r.y0; rect[2] = tc.r.w; rect[3] = tc.r.h; }
+  if (rect) { rect[0] = R.r.x0; rect[1] = R.r.y0; rect[2] = R.r.w; rect[3] = R.r.h; }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_restrict_resolution(ojphgpu_plan* plan, uint32_t skipped_res_for_data, uint32_t skipped_res_for_recon)
+{
+  if (!plan) return OJPHGPU_E_INVALID;
+  Plan& P = plan->plan;
+  if (P.coded.size() != P.blocks.size()) return OJPHGPU_E_INVALID;           // a parsed codestream only
+  if (skipped_res_for_data < skipped_res_for_recon) return OJPHGPU_E_INVALID; // ojph_codestream_local.cpp:886-890
+  if (skipped_res_for_data > P.p.num_decomps) return OJPHGPU_E_INVALID;       // :891-895
+  P.skip_read = skipped_res_for_data; P.skip_recon = skipped_res_for_recon;
+  // the reconstructed components: sub-sampling grows by 2^skip_recon (ojph_params.cpp:930-946)
+  const uint64_t X1 = (uint64_t)P.p.image_x0 + P.p.width, Y1 = (uint64_t)P.p.image_y0 + P.p.height;
+  P.frame_elems = 0;
+  for (CompGeo& g : P.comps) {
+    const uint64_t fx = (uint64_t)g.dx << P.skip_recon, fy = (uint64_t)g.dy << P.skip_recon;
+    g.x0 = (uint32_t)((P.p.image_x0 + fx - 1) / fx); g.y0 = (uint32_t)((P.p.image_y0 + fy - 1) / fy);
+    g.w = (uint32_t)((X1 + fx - 1) / fx) - g.x0; g.h = (uint32_t)((Y1 + fy - 1) / fy) - g.y0;
+    g.frame_off = P.frame_elems;
+    P.frame_elems += (uint64_t)g.w * g.h;
+  }
   return OJPHGPU_OK;
 }
 

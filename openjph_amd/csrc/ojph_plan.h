@@ -84,6 +84,10 @@ struct Plan {
   ojphgpu_params p;
   std::vector<CompGeo> comps;
   uint64_t frame_elems;         // elements of one frame = sum of the component planes
+  // reduced-resolution decoding (codestream::restrict_input_resolution): the top skip_read
+  // resolutions are not decoded (their blocks count as empty), the top skip_recon are not
+  // synthesised; comps / frame_elems then describe the smaller reconstructed frame
+  uint32_t skip_read = 0, skip_recon = 0;
   uint32_t ntx, nty;
   uint32_t guard_bits;
   std::vector<uint8_t> spqcd8;   // reversible: exponent bytes as written in QCD

@@ -84,7 +84,7 @@ struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t 
 
 void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
 {
-  const uint32_t L = P.p.num_decomps;
+  const uint32_t L = P.p.num_decomps - P.skip_recon;       // reduced-resolution decoding stops below the top levels
   descs.clear(); batches.clear();
   for (uint32_t r = L; r >= 1; --r) {
     LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0 };
@@ -108,14 +108,16 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
                              std::vector<ojphgpu_dwt_desc>& out)
 {
   out.clear();
-  if (P.p.color_transform || P.p.num_decomps == 0) return;
+  const uint32_t L = P.p.num_decomps - P.skip_recon;
+  if (P.p.color_transform || L == 0) return;
   size_t k = 0;
   for (const ojphgpu_level_info& lv : P.levels) {
-    if (lv.res != P.p.num_decomps || !tr.has(lv.tile)) continue;
+    if (lv.res != L || !tr.has(lv.tile)) continue;
     ojphgpu_dwt_desc d = descs[top.first + k++];
     const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
     const CompGeo& g = P.comps[lv.comp];
-    d.src_off = g.frame_off + (uint64_t)(tc.r.y0 - g.y0) * g.w + (tc.r.x0 - g.x0);
+    const Rect& rr = P.ress[tc.res[L]].r;                   // the tile-component at the reconstructed resolution
+    d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
     d.src_pitch = g.w;
     out.push_back(d);
   }
@@ -124,7 +126,7 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
 void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
 {
   descs.clear(); max_w = max_h = 0;
-  const uint32_t L = P.p.num_decomps;
+  const uint32_t L = P.p.num_decomps - P.skip_recon;
   for (const Tile& t : P.tiles) {
     if (!tr.has(t.idx)) continue;
     for (uint32_t c = 0; c < P.p.num_comps; ++c) {
@@ -134,7 +136,7 @@ void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
       else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
       const CompGeo& g = P.comps[c];
-      d.w = tc.r.w; d.h = tc.r.h; d.src_x0 = tc.r.x0 - g.x0; d.src_y0 = tc.r.y0 - g.y0;
+      d.w = R.r.w; d.h = R.r.h; d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
       d.img_pitch = g.w; d.img_off = g.frame_off;
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
@@ -192,8 +194,11 @@ void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nfram
 std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
 {
   std::vector<uint32_t> ids;
-  for (size_t i = 0; i < P.blocks.size(); ++i)
-    if (tr.has(P.bands[P.blocks[i].band].tile)) ids.push_back((uint32_t)i);
+  const uint32_t top = P.p.num_decomps - P.skip_read;      // resolutions above are not decoded: their bands stay zero
+  for (size_t i = 0; i < P.blocks.size(); ++i) {
+    const Band& B = P.bands[P.blocks[i].band];
+    if (tr.has(B.tile) && B.res <= top) ids.push_back((uint32_t)i);
+  }
   return ids;
 }
 
@@ -320,6 +325,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   if (!plan || !out || nframes == 0) return OJPHGPU_E_INVALID;
   *out = nullptr;
   if ((uint64_t)tile_first + tile_count > plan->plan.tiles.size()) return OJPHGPU_E_INVALID;
+  if (plan->plan.skip_read || plan->plan.skip_recon) return OJPHGPU_E_INVALID;     // a decoding-only restriction
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   ojphgpu_encoder* e = new (std::nothrow) ojphgpu_encoder();
@@ -638,6 +644,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
     if (!plans[f]) return OJPHGPU_E_INVALID;
     const Plan& Q = plans[f]->plan;
     if (Q.coded.size() != Q.blocks.size()) return OJPHGPU_E_INVALID;    // plans must come from ojphgpu_t2_parse
+    if (Q.skip_read != P.skip_read || Q.skip_recon != P.skip_recon) return OJPHGPU_E_INVALID;
     if (Q.blocks.size() != P.blocks.size() || Q.arena_elems != P.arena_elems || Q.p.width != P.p.width ||
         Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
         Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||

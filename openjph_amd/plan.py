@@ -52,6 +52,7 @@ class Plan:
             check(self._lib.ojphgpu_plan_create(C.byref(params), C.byref(h)), "plan_create")
             handle = h
         self.handle = handle
+        self.skip = (0, 0)
         cnt = (C.c_uint64 * 8)()
         check(self._lib.ojphgpu_plan_counts(self.handle, cnt))
         (self.num_tiles, self.num_bands, self.num_blocks, self.num_levels, self.arena_elems,
@@ -75,6 +76,14 @@ class Plan:
                 self.handle = None
         except Exception:
             pass
+
+    def restrict_resolution(self, skipped_res_for_data, skipped_res_for_recon=None):
+        """codestream::restrict_input_resolution on a parsed plan (before a Decoder is created from it)"""
+        if skipped_res_for_recon is None:
+            skipped_res_for_recon = skipped_res_for_data
+        check(self._lib.ojphgpu_plan_restrict_resolution(self.handle, int(skipped_res_for_data), int(skipped_res_for_recon)),
+              "plan_restrict_resolution")
+        self.skip = (int(skipped_res_for_data), int(skipped_res_for_recon))
 
     def comp_info(self, comp):
         """-> dict(x0, y0, w, h, frame_off, dx, dy) of component `comp` (see ojphgpu_plan_comp_info)"""

@@ -135,7 +135,16 @@ long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out,
 
 // Decodes to int32 planes (caller allocates num_comps * width * height).  Fills info[0..5] =
 // width,height,num_comps,bit_depth,is_signed,reversible.  Returns 0 on success.
+int ref_decode_skip(const uint8_t* data, long len, int32_t* const* planes, uint32_t* info, int resilient,
+                    uint32_t skip_read, uint32_t skip_recon);
+
 int ref_decode(const uint8_t* data, long len, int32_t* const* planes, uint32_t* info, int resilient)
+{
+  return ref_decode_skip(data, len, planes, info, resilient, 0, 0);
+}
+
+int ref_decode_skip(const uint8_t* data, long len, int32_t* const* planes, uint32_t* info, int resilient,
+                    uint32_t skip_read, uint32_t skip_recon)
 {
   try {
     ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
@@ -144,6 +153,7 @@ int ref_decode(const uint8_t* data, long len, int32_t* const* planes, uint32_t* 
     ojph::codestream cs;
     if (resilient) cs.enable_resilience();
     cs.read_headers(&in);
+    if (skip_read || skip_recon) cs.restrict_input_resolution(skip_read, skip_recon);
     ojph::param_siz siz = cs.access_siz();
     uint32_t nc = siz.get_num_components();
     uint32_t w = siz.get_recon_width(0), h = siz.get_recon_height(0);

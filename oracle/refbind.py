@@ -53,6 +53,8 @@ class Ref:
         L.ref_encode.argtypes = [C.POINTER(RefParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_long]
         L.ref_decode.restype = C.c_int
         L.ref_decode.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.ref_decode_skip.restype = C.c_int
+        L.ref_decode_skip.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
         L.ref_encode_block32.restype = C.c_long
         L.ref_encode_block32.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p, C.c_long]
@@ -102,10 +104,11 @@ class Ref:
             raise RuntimeError("reference encode failed (%d)" % n)
         return out[:n].tobytes()
 
-    def decode(self, data: bytes, resilient=False):
+    def decode(self, data: bytes, resilient=False, skip=(0, 0)):
+        """skip = (skipped_res_for_data, skipped_res_for_recon) of codestream::restrict_input_resolution"""
         buf = np.frombuffer(data, dtype=np.uint8)
         info = np.zeros(8 + 32, dtype=np.uint32)
-        r = self.lib.ref_decode(buf.ctypes.data, len(data), None, info.ctypes.data, int(resilient))
+        r = self.lib.ref_decode_skip(buf.ctypes.data, len(data), None, info.ctypes.data, int(resilient), skip[0], skip[1])
         if r != 0:
             raise RuntimeError("reference read_headers failed (%d)" % r)
         w, h, nc = int(info[0]), int(info[1]), int(info[2])
@@ -118,7 +121,7 @@ class Ref:
             planes = [np.zeros(d, dtype=np.int32) for d in dims]
             views = planes
         ptrs = (C.c_void_p * nc)(*[v.ctypes.data for v in views])
-        r = self.lib.ref_decode(buf.ctypes.data, len(data), ptrs, info.ctypes.data, int(resilient))
+        r = self.lib.ref_decode_skip(buf.ctypes.data, len(data), ptrs, info.ctypes.data, int(resilient), skip[0], skip[1])
         if r != 0:
             raise RuntimeError("reference decode failed (%d)" % r)
         return planes, dict(bit_depth=int(info[3]), is_signed=bool(info[4]),

@@ -143,8 +143,10 @@ def add_refinement(data, coded, rng, fraction=0.6):
 
 
 def decode_blocks(plan: Plan, cs: bytes):
-    """Oracle HT decode + dequantise of every block into a fresh arena."""
+    """Oracle HT decode + dequantise of every block into a fresh arena (blocks of resolutions the
+    plan was told not to read stay zero)."""
     coded = plan.coded_blocks()
+    top_read = int(plan.params.num_decomps) - plan.skip[0]
     rev = bool(plan.params.reversible)
     arena = np.zeros(plan.arena_elems, np.uint32)
     buf = np.frombuffer(cs, dtype=np.uint8)
@@ -154,6 +156,8 @@ def decode_blocks(plan: Plan, cs: bytes):
             continue
         blk = plan.blocks[k]
         band = plan.bands[int(blk["band"])]
+        if int(band["res"]) > top_read:
+            continue
         w, h = int(blk["w"]), int(blk["h"])
         o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
         ok, sm = ob.ht_decode(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
@@ -174,9 +178,11 @@ def inverse_stages(plan: Plan, arena):
     rev = bool(p.reversible)
     dt = np.int32 if rev else np.float32
     lib = ob.lib()
-    for lv in plan.levels[::-1]:
+    top = int(p.num_decomps) - plan.skip[1]                 # the resolution that is reconstructed
+    order = sorted(range(len(plan.levels)), key=lambda i: int(plan.levels[i]["res"]))
+    for lv in (plan.levels[i] for i in order):
         w, h = int(lv["w"]), int(lv["h"])
-        if w == 0 or h == 0:
+        if w == 0 or h == 0 or int(lv["res"]) > top:
             continue
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
         lw, hw, lh_, hh_ = ob.band_dims(w, h, xe, ye)
@@ -212,7 +218,10 @@ def inverse_stages(plan: Plan, arena):
     return np.stack(image) if len(plan.frame_shape) == 3 else image
 
 
-def decode(cs: bytes):
+def decode(cs: bytes, skip=None):
+    """skip = (skipped_res_for_data, skipped_res_for_recon): reduced-resolution decoding"""
     plan = parse_codestream(cs)
+    if skip:
+        plan.restrict_resolution(*skip)
     arena = decode_blocks(plan, cs)
     return inverse_stages(plan, arena), plan

@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
-from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, stream_kwargs, refine_case,  # noqa: E402
-                                grid_kwargs)
+from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, stream_kwargs,  # noqa: E402
+                                refine_case, grid_kwargs, skip_case)
 
 
 def sha(b):
@@ -82,6 +82,16 @@ def main():
         dec = [dec[c] for c in range(len(planes))]
         assert [d.shape for d in dec] == [q.shape for q in planes]
         out["grid"].append({"case": i, "len": len(cs), "sha256": sha(cs),
+                            "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
+    # (b3) reduced-resolution decoding
+    out["skip"] = []
+    for i in range(len(SKIP_CASES)):
+        planes, kw, size, skip = skip_case(i)
+        r = ref if kw.get("reversible", True) else refgen
+        cs = r.encode(planes if size else np.stack(planes), **(dict(kw, size=size) if size else kw))
+        dec, _ = r.decode(cs, skip=skip)
+        dec = [dec[c] for c in range(len(planes))]
+        out["skip"].append({"case": i, "shapes": [list(d.shape) for d in dec],
                             "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
     cs = ref.encode(c1_image(), 8)
     out["ka1"] = {"len": len(cs), "sha256": sha(cs), "fnv1a64": refbind.fnv1a64(cs)}

@@ -60,6 +60,25 @@ GRID_CASES = [
 ]
 
 
+# reduced-resolution decoding (codestream::restrict_input_resolution): (family, case index,
+# skipped_res_for_data, skipped_res_for_recon)
+SKIP_CASES = [
+    ("grid", 0, 1, 1), ("grid", 0, 2, 1), ("grid", 0, 5, 5), ("grid", 0, 5, 0), ("grid", 2, 2, 2), ("grid", 5, 1, 1),
+    ("grid", 5, 3, 3), ("grid", 6, 2, 1), ("grid", 7, 2, 2), ("stream", 1, 1, 1), ("stream", 3, 3, 2), ("stream", 4, 1, 1),
+    ("stream", 19, 2, 2), ("stream", 9, 1, 1), ("stream", 12, 5, 5),
+]
+
+
+def skip_case(i):
+    """-> (planes list, encode kwargs, size or None, (skip_read, skip_recon))"""
+    fam, k, a, b = SKIP_CASES[i]
+    if fam == "grid":
+        planes, kw, size = grid_kwargs(GRID_CASES[k])
+        return planes, kw, size, (a, b)
+    img, kw = stream_kwargs(STREAM_CASES[k])
+    return [img[c] for c in range(img.shape[0])], kw, None, (a, b)
+
+
 def grid_kwargs(case, seed=5):
     """-> (list of per-component int32 planes, kwargs for plan.make_params / refbind.Ref.encode,
     (W, H) on the reference grid)"""

@@ -148,3 +148,20 @@ def test_cli_yuv420_and_image_offset(tmp_path):
     r = run([EXPAND, "-i", str(tmp_path / "t.j2c"), "-o", str(tmp_path / "t_back.pgm")])
     assert r.returncode == 0, r.stdout
     assert np.array_equal(read_pnm(tmp_path / "t_back.pgm"), img)
+
+
+@pytest.mark.gpu
+def test_cli_skip_res(tmp_path):
+    """ojph_expand -skip_res 2 and -skip_res 3,1 (ojph_expand.cpp:163-190)"""
+    from tests import cpu_pipeline as cp
+    img = synth_image(3, 200, 300, 8, seed=5)
+    cs, *_ = cp.encode(img, bit_depth=8, color_transform=True)
+    j2c = tmp_path / "a.j2c"
+    open(j2c, "wb").write(cs)
+    for arg, skip in (("2", (2, 2)), ("{3,1}", (3, 1))):
+        r = run([EXPAND, "-i", str(j2c), "-o", str(tmp_path / "o.ppm"), "-skip_res", arg])
+        assert r.returncode == 0, r.stdout
+        want, _ = cp.decode(cs, skip=skip)
+        assert np.array_equal(read_pnm(tmp_path / "o.ppm"), np.clip(want, 0, 255))
+    r = run([EXPAND, "-i", str(j2c), "-o", str(tmp_path / "o.ppm"), "-skip_res", "6"])
+    assert r.returncode != 0 and b"ojph error" in r.stdout

@@ -18,8 +18,8 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, STREAM_CASES, grid_kwargs, refine_case,
-                                stream_kwargs)
+from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, grid_kwargs, refine_case,
+                                skip_case, stream_kwargs)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -286,6 +286,36 @@ def test_grid_codestream_matches_live_reference(i, ref, refgen):
     dec, _ = cp.decode(want)
     wdec, _ = r.decode(want)
     assert all(np.array_equal(a, b) for a, b in zip(_as_list(dec, len(planes)), _as_list(wdec, len(planes))))
+
+
+@pytest.mark.parametrize("i", range(len(SKIP_CASES)), ids=lambda i: "%s%d-skip%d_%d" % SKIP_CASES[i])
+def test_reduced_resolution_decode_matches_golden(i):
+    """codestream::restrict_input_resolution (ojph_codestream_local.cpp:883-900): resolutions that are
+    not read decode as zeros, resolutions that are not reconstructed shrink the output"""
+    from tests import cpu_pipeline as cp
+    planes, kw, size, skip = skip_case(i)
+    cs, *_ = cp.encode(planes if size else np.stack(planes), **(dict(kw, size=size) if size else kw))
+    dec, _ = cp.decode(cs, skip=skip)
+    dec = _as_list(dec, len(planes))
+    g = GOLD["skip"][i]
+    assert [list(d.shape) for d in dec] == g["shapes"]
+    assert sha(_planes_bytes(dec)) == g["dec_sha256"]
+
+
+def test_reduced_resolution_validation():
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params, parse_codestream
+    from tests import cpu_pipeline as cp
+    cs, *_ = cp.encode(synth_image(1, 64, 64, 8, seed=1), bit_depth=8, num_decomps=3)
+    pl = parse_codestream(cs)
+    with pytest.raises(capi.OjphError):
+        pl.restrict_resolution(1, 2)                      # data < recon (:886)
+    with pytest.raises(capi.OjphError):
+        pl.restrict_resolution(4, 4)                      # more than the decomposition levels (:891)
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 1)).restrict_resolution(1, 1)   # not a parsed codestream
+    pl.restrict_resolution(3, 1)
+    assert pl.frame_shape == (1, 32, 32)
 
 
 def test_grid_parameter_validation():

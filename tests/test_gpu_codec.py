@@ -84,6 +84,28 @@ def test_grid_encode_decode_matches_oracle(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+@pytest.mark.parametrize("i", range(15), ids=lambda i: "skip%d" % i)
+def test_reduced_resolution_decode_matches_oracle(i):
+    """codestream::restrict_input_resolution on the GPU decoder against the oracle pipeline and the
+    stored digests of the reference's output (tests/golden_cases.py SKIP_CASES)"""
+    import hashlib
+    import json
+    import os
+    from openjph_amd import codec
+    from tests import cpu_pipeline as cp
+    from tests.golden_cases import skip_case
+    planes, kw, size, skip = skip_case(i)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["skip"][i]
+    cs, *_ = cp.encode(planes if size else np.stack(planes), **(dict(kw, size=size) if size else kw))
+    dec = codec.Decoder(cs, skip_res=skip)
+    out = dec.plan.unpack_frame(dec.decode())
+    assert [list(q.shape) for q in out] == gold["shapes"]
+    want, _ = cp.decode(cs, skip=skip)
+    for c in range(len(planes)):
+        assert np.array_equal(out[c], want[c]), "component %d differs" % c
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
+
+
 def test_c1_matches_reference_bytes(ref):
     """BASELINE config #1 (256x256 8-bit, 5/3): identical bytes to the reference library."""
     from openjph_amd import codec
