@@ -360,9 +360,12 @@ struct Reader {
 
 struct HeaderReader {      // ojph_bitbuffer_read.h:66-176
   const uint8_t* d; size_t pos, end;
+  bool phys;                 // `end` is the end of the file, short of what Psot announced
   uint32_t tmp = 0; int avail = 0; bool unstuff = false; bool exhausted = false;
+  bool threw = false;        // bb_read found the FILE short: the reference throws there, wherever the bit was wanted (:82-83)
   bool fill() {
     if (pos < end) { uint8_t t = d[pos++]; tmp = t; avail = 8 - (unstuff ? 1 : 0); unstuff = (t == 0xFF); return true; }
+    if (phys) threw = true;
     tmp = 0; avail = 8 - (unstuff ? 1 : 0); unstuff = false; exhausted = true; return false;
   }
   bool bit(uint32_t& b) { bool r = true; if (avail == 0) r = fill(); b = (tmp >> --avail) & 1; return r; }
@@ -381,13 +384,42 @@ struct HeaderReader {      // ojph_bitbuffer_read.h:66-176
 }  // namespace
 
 // Parses one packet starting at d[pos]; fills coded[] for the blocks of the precinct.
-// Returns 0, or OJPHGPU_E_CODESTREAM.
-static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end,
+// Returns 0, OJPHGPU_E_CODESTREAM when the packet HEADER cannot be read (precinct::parse throws,
+// ojph_precinct.cpp:380-500: an error unless the codestream is read resiliently), or
+// PACKET_DATA_ENDED when the code-block BYTES run out (:545-556: no error in either mode -- the
+// broken block and everything after it in the tile-part count as not coded).
+enum { PACKET_DATA_ENDED = 1 };
+
+static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
+                             bool use_sop, bool use_eph);
+
+static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
                         bool use_sop, bool use_eph)
+{
+  const int rc = parse_packet_impl(P, pc, d, pos, end, phys, use_sop, use_eph);
+  if (rc == OJPHGPU_E_CODESTREAM) {              // blocks that got lengths from the broken header never get bytes
+    const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
+    for (int s = 0; s < 4; ++s) {
+      if (R.band[s] < 0) continue;
+      const Band& B = P.bands[(size_t)R.band[s]];
+      if (B.empty) continue;
+      const Rect& q = pc.cb[s];
+      for (uint32_t y = 0; y < q.h; ++y)
+        for (uint32_t x = 0; x < q.w; ++x) {
+          CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
+          k.len1 = k.len2 = 0; k.num_passes = 0;
+        }
+    }
+  }
+  return rc;
+}
+
+static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
+                             bool use_sop, bool use_eph)
 {
   const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
   if (use_sop && pos + 6 <= end && d[pos] == 0xFF && d[pos + 1] == 0x91) pos += 6;
-  HeaderReader bb{ d, pos, end };
+  HeaderReader bb{ d, pos, end, phys };
   bool empty_packet = true;
   for (int s = 0; s < 4; ++s) {
     if (R.band[s] < 0) continue;
@@ -397,7 +429,8 @@ static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& p
     if (q.w == 0 || q.h == 0) continue;
     if (empty_packet) {
       uint32_t b; bb.bit(b);
-      if (b == 0) { bb.terminate(); pos = bb.pos; if (use_eph && pos + 2 <= end) pos += 2; return 0; }
+      if (bb.threw) return OJPHGPU_E_CODESTREAM;
+      if (b == 0) { bb.terminate(); pos = bb.pos; if (use_eph && pos + 2 <= end) pos += 2; return bb.threw ? OJPHGPU_E_CODESTREAM : 0; }
       empty_packet = false;
     }
     uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
@@ -467,9 +500,11 @@ static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& p
   }
   if (empty_packet) { uint32_t b; bb.bit(b); }
   bb.terminate();
+  if (bb.threw) return OJPHGPU_E_CODESTREAM;
   pos = bb.pos;
   if (use_eph && pos + 2 <= end && d[pos] == 0xFF && d[pos + 1] == 0x92) pos += 2;
   // body
+  bool ended = false;
   for (int s = 0; s < 4; ++s) {
     if (R.band[s] < 0) continue;
     const Band& B = P.bands[(size_t)R.band[s]];
@@ -480,11 +515,11 @@ static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& p
         CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
         size_t nbytes = (size_t)k.len1 + k.len2;
         if (!nbytes) continue;
-        if (pos + nbytes > end) { k.len1 = k.len2 = 0; k.num_passes = 0; pos = end; return OJPHGPU_E_CODESTREAM; }
+        if (ended || pos + nbytes > end) { k.len1 = k.len2 = 0; k.num_passes = 0; pos = end; ended = true; continue; }
         k.offset = pos; pos += nbytes;
       }
   }
-  return 0;
+  return ended ? PACKET_DATA_ENDED : 0;
 }
 
 extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
@@ -585,16 +620,20 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   std::vector<size_t> next_pkt(P.tiles.size(), 0);
   int status = OJPHGPU_OK;
   // tile-parts
+  // What a truncated file means follows codestream::read (ojph_codestream_local.cpp:912-1113): the
+  // file ending where the next SOT / EOC is expected is only reported ("File terminated early",
+  // :1104-1108), and so is a tile-part shorter than its Psot whose packets end inside code-block
+  // bytes; a cut inside an SOT, a tile-part header or a packet header is an error unless resilient.
   for (;;) {
-    if (!r.ok(2)) { status = OJPHGPU_E_CODESTREAM; break; }
+    if (!r.ok(2)) break;                                                // :1103-1108
     size_t sot_pos = r.pos;
     uint32_t m = r.u16();
     if (m == EOC) break;
     if (m != SOT || !r.ok(10)) { status = OJPHGPU_E_CODESTREAM; break; }
     uint32_t lsot = r.u16(), isot = r.u16(), psot = r.u32(); r.u8(); r.u8();
     if (lsot != 10 || isot >= P.tiles.size()) { status = OJPHGPU_E_CODESTREAM; break; }
-    size_t tp_end = psot ? sot_pos + psot : (len >= 2 ? len - 2 : len);
-    if (tp_end > len) { tp_end = len; status = OJPHGPU_E_CODESTREAM; }
+    const size_t tp_nominal = psot ? sot_pos + psot : (len >= 2 ? len - 2 : len);   // where Psot says the tile-part ends
+    const size_t tp_end = std::min(tp_nominal, len);
     bool bad = false;
     for (;;) {                                   // tile-part header markers up to SOD
       if (!r.ok(2)) { bad = true; break; }
@@ -609,13 +648,17 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     if (bad) { status = OJPHGPU_E_CODESTREAM; break; }
     const Tile& T = P.tiles[isot];
     size_t pos = r.pos;
-    while (pos < tp_end && next_pkt[isot] < T.packets.size()) {
-      int prc = parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], d, pos, tp_end, use_sop, use_eph);
+    // packets are parsed while Psot promises more bytes (tile::parse_tile_header, ojph_tile.cpp:792-905);
+    // when the file ends first, a packet whose code-block bytes are cut is tolerated, and the next
+    // packet -- if the tile has one -- fails on its first header bit
+    while (pos < tp_nominal && next_pkt[isot] < T.packets.size()) {
+      int prc = parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], d, pos, tp_end, tp_nominal > len, use_sop, use_eph);
       next_pkt[isot]++;
+      if (prc == PACKET_DATA_ENDED) continue;
       if (prc != 0) { status = prc; break; }
     }
-    r.pos = tp_end;
-    if (status != OJPHGPU_OK) break;
+    r.pos = tp_end;                                                     // tile::parse_tile_header ends with a seek to here
+    if (status != OJPHGPU_OK && !resilient) break;
   }
   if (status != OJPHGPU_OK && !resilient) { delete h; return status; }
   *out = h;

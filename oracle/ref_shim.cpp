@@ -147,7 +147,7 @@ int ref_decode_skip(const uint8_t* data, long len, int32_t* const* planes, uint3
                     uint32_t skip_read, uint32_t skip_recon)
 {
   try {
-    ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
+    ojph::set_message_level(getenv("REF_SHIM_VERBOSE") ? ojph::OJPH_MSG_ALL_MSG : ojph::OJPH_MSG_NO_MSG);
     ojph::mem_infile in;
     in.open(data, (size_t)len);
     ojph::codestream cs;

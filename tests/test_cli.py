@@ -165,3 +165,20 @@ def test_cli_skip_res(tmp_path):
         assert np.array_equal(read_pnm(tmp_path / "o.ppm"), np.clip(want, 0, 255))
     r = run([EXPAND, "-i", str(j2c), "-o", str(tmp_path / "o.ppm"), "-skip_res", "6"])
     assert r.returncode != 0 and b"ojph error" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_truncated_file_needs_resilient(tmp_path):
+    from tests import cpu_pipeline as cp
+    img = synth_image(1, 256, 256, 8, seed=4)
+    cs, *_ = cp.encode(img, bit_depth=8)
+    part = cs[:len(cs) // 8]                              # the cut lands in a packet that is followed by others
+    open(tmp_path / "t.j2c", "wb").write(part)
+    r = run([EXPAND, "-i", str(tmp_path / "t.j2c"), "-o", str(tmp_path / "t.pgm")])
+    assert r.returncode != 0 and b"ojph error" in r.stdout
+    r = run([EXPAND, "-i", str(tmp_path / "t.j2c"), "-o", str(tmp_path / "t.pgm"), "-resilient", "true"])
+    assert r.returncode == 0, r.stdout
+    from openjph_amd.plan import parse_codestream
+    pl = parse_codestream(part, resilient=True)
+    want = cp.inverse_stages(pl, cp.decode_blocks(pl, part))
+    assert np.array_equal(read_pnm(tmp_path / "t.pgm"), np.clip(want, 0, 255))

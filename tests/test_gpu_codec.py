@@ -106,6 +106,30 @@ def test_reduced_resolution_decode_matches_oracle(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+def test_truncated_codestream_decodes_like_oracle():
+    """tests/test_truncated_decode.cpp on the GPU decoder: a full frame from whatever was received
+    when resilient, an error for a cut the parser detects when not"""
+    from openjph_amd import capi, codec
+    from openjph_amd.plan import parse_codestream
+    from tests import cpu_pipeline as cp
+    y, x = np.mgrid[0:256, 0:256]
+    img = ((x * 7 + y * 13 + ((x * y) >> 3)) & 0xFF).astype(np.int32)[None]
+    cs, *_ = cp.encode(img, bit_depth=8, num_decomps=5)
+    detected = 0
+    for cut in range(1, 16):
+        part = cs[:len(cs) * cut // 16]
+        got = codec.Decoder(part, resilient=True).decode()
+        pl = parse_codestream(part, resilient=True)
+        want = cp.inverse_stages(pl, cp.decode_blocks(pl, part))
+        assert got.shape == (1, 256, 256) and np.array_equal(got, want), "cut %d" % cut
+        try:
+            again = codec.Decoder(part).decode()
+            assert np.array_equal(again, want)          # an undetectable cut decodes the same way in both modes
+        except capi.OjphError:
+            detected += 1
+    assert 0 < detected < 15
+
+
 def test_c1_matches_reference_bytes(ref):
     """BASELINE config #1 (256x256 8-bit, 5/3): identical bytes to the reference library."""
     from openjph_amd import codec
