@@ -122,7 +122,7 @@ def main():
         enc.run_device(d_img)
         part, lens = enc.finish_tiles()
         cdev = dev if backend == "nccl" else None                # device tensors over RCCL, host tensors over gloo
-        all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=cdev)
+        all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=cdev, parts_per_tile=plan.parts_per_tile)
         parts, _ = shard.gather_bytes(part, device=cdev)         # RCCL: the final codestream gather
         cs = shard.assemble(plan.t2_main_header(all_lens), parts) if rank == 0 else None
         box = [cs]

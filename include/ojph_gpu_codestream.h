@@ -14,9 +14,9 @@
 // std::runtime_error("ojph error") after the message went to stderr.
 //
 // Not every knob of the reference exists behind the GPU path: all
-// components must share bit depth / signedness (sub-sampling, image and tile offsets are
-// supported, and so is reduced-resolution decoding), no tile-part divisions, no user COM markers.  Such
-// requests fail loudly in write_headers() / read_headers() / the setter.
+// components must share bit depth / signedness.  Sub-sampling, image and tile offsets, tile-part
+// divisions, user COM markers, the IMF / BROADCAST profile checks and reduced-resolution decoding
+// are supported.  What is not fails loudly in write_headers() / read_headers() / the setter.
 #ifndef OJPH_GPU_CODESTREAM_H
 #define OJPH_GPU_CODESTREAM_H
 
@@ -207,8 +207,8 @@ public:
   void set_planar(bool planar);
   void set_profile(const char* s);
   void set_tilepart_divisions(bool at_resolutions, bool at_components);
-  bool is_tilepart_division_at_resolutions() { return false; }
-  bool is_tilepart_division_at_components() { return false; }
+  bool is_tilepart_division_at_resolutions();
+  bool is_tilepart_division_at_components();
   void request_tlm_marker(bool needed);
   bool is_tlm_requested();
 

@@ -54,7 +54,10 @@ typedef struct ojphgpu_params {
   float    qstep;                /* param_qcd::set_irrev_quant; <= 0 selects 2^-min(16,B)     */
   uint32_t precinct_w, precinct_h; /* 0 = 32768 (no explicit precincts)                        */
   uint32_t tlm;                  /* codestream::request_tlm_marker                            */
-  uint32_t reserved[4];          /* [0] bit 0: vertically causal code-block style (set by the parser) */
+  uint32_t reserved[4];          /* [0] bit 0: vertically causal code-block style (set by the parser)
+                                    [1] codestream::set_tilepart_divisions: bit 0 = a tile-part per
+                                        resolution, bit 1 = per component (what the progression
+                                        order cannot honour is dropped as write_headers drops it) */
   uint8_t  precinct_exps[36];    /* param_cod::set_precinct_size with a list: per resolution (0 =
                                     lowest) PPx | PPy << 4; all zero = precinct_w/h everywhere  */
   /* reference grid (ojph_params.h:68-112).  width/height stay the image SIZE: the extent the
@@ -113,6 +116,13 @@ int  ojphgpu_plan_params(const ojphgpu_plan* plan, ojphgpu_params* out);
 /* counts: out[0]=tiles [1]=bands [2]=blocks [3]=dwt levels [4]=coefficient arena elements
  *         [5]=max coded bytes of one block [6]=precincts [7]=tile-comps */
 int  ojphgpu_plan_counts(const ojphgpu_plan* plan, uint64_t out[8]);
+/* user COM marker segments written after the library's own one (the `comments` argument of
+ * codestream::write_headers, ojph_codestream_local.cpp:686-703): n segments, segment i = len[i] bytes
+ * at data[i] with registration value rcom[i] (1 = Latin text, 0 = binary).  Replaces earlier ones. */
+int  ojphgpu_plan_set_comments(ojphgpu_plan* plan, const uint8_t* const* data, const uint16_t* len,
+                               const uint16_t* rcom, uint32_t n);
+/* tile-parts every tile is written in (1 without tile-part divisions) */
+int  ojphgpu_plan_tile_parts(const ojphgpu_plan* plan, uint32_t* parts_per_tile);
 int  ojphgpu_plan_bands(const ojphgpu_plan* plan, ojphgpu_band_info* out, size_t n);
 int  ojphgpu_plan_blocks(const ojphgpu_plan* plan, ojphgpu_block_info* out, size_t n);
 int  ojphgpu_plan_levels(const ojphgpu_plan* plan, ojphgpu_level_info* out, size_t n);
@@ -140,8 +150,9 @@ int  ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* h_block_data,
                       const ojphgpu_coded_block* blocks, uint8_t* h_out, size_t cap,
                       size_t* out_len);
 /* The same in pieces, for tile-sharded encoding (tiles are independent: own DWT, blocks, packets
- * and tile-part, ojph_tile.cpp:584-774): the tile-parts (SOT .. last packet) of tiles
- * [tile_first, tile_first + tile_count) -- tile_part_len[i] receives Psot of tile tile_first + i --
+ * and tile-parts, ojph_tile.cpp:584-774): the tile-parts (SOT .. last packet) of tiles
+ * [tile_first, tile_first + tile_count) -- tile_part_len[i * parts_per_tile + k] receives Psot of
+ * tile-part k of tile tile_first + i --
  * and the main header (SOC .. last main-header marker; needs every tile's Psot only when a TLM
  * marker was requested).  codestream = main header | tile-parts in tile order | EOC (0xFFD9). */
 int  ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* h_block_data,

@@ -13,7 +13,7 @@ static void usage() {
   printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f]\n"
          "  [-num_decomps n] [-block_size {w,h}] [-precincts {w,h}] [-prog_order LRCP|RLCP|RPCL|PCRL|CPRL]\n"
          "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n]\n"
-         "  [-image_offset {x,y}] [-tile_offset {x,y}]\n"
+         "  [-image_offset {x,y}] [-tile_offset {x,y}] [-tileparts R|C|RC] [-profile IMF|BROADCAST] [-com \"text\"]\n"
          "  raw input: -dims {w,h} -num_comps n -bit_depth b [-signed true|false] [-downsamp {x,y},{x,y},...]\n");
 }
 
@@ -83,11 +83,18 @@ int main(int argc, char** argv) {
     if (!reversible && a.get("-qstep")) cs.access_qcd().set_irrev_quant((float)atof(a.get("-qstep")));
     if (a.get("-tlm_marker")) cs.request_tlm_marker(Args::to_bool(a.get("-tlm_marker")));
     if (a.get("-profile")) cs.set_profile(a.get("-profile"));
+    if (a.get("-tileparts")) {                                  // ojph_compress.cpp:324-356: letters R and / or C
+      const std::string tp(a.get("-tileparts"));
+      for (char ch : tp) if (ch != 'R' && ch != 'C') throw std::runtime_error("could not interpret -tileparts fields; allowed values are \"R\" \"C\" and \"RC\"");
+      cs.set_tilepart_divisions(tp.find('R') != std::string::npos, tp.find('C') != std::string::npos);
+    }
     cs.set_planar(!ct);
 
     ojph::j2c_outfile file;
     file.open(out);
-    cs.write_headers(&file);
+    ojph::comment_exchange com;
+    if (a.get("-com")) com.set_string(a.get("-com"));
+    cs.write_headers(&file, a.get("-com") ? &com : nullptr, a.get("-com") ? 1 : 0);
     ojph::ui32 next = 0;
     ojph::line_buf* line = cs.exchange(nullptr, next);
     std::vector<unsigned> row(img.num_comps, 0);

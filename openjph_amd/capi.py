@@ -101,6 +101,9 @@ SIGNATURES = {
     "ojphgpu_plan_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "ojphgpu_plan_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ojphgpu_plan_tile_parts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                            C.c_uint32]),
     "ojphgpu_plan_restrict_resolution": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "ojphgpu_plan_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ojphgpu_plan_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

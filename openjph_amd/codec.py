@@ -102,7 +102,7 @@ class Encoder:
     def finish_tiles(self):
         """-> (tile-part bytes of this encoder's tile range, Psot per tile)"""
         cap = self.plan.frame_elems * 3 + (1 << 20)
-        lens = np.zeros(max(self.tiles[1], 1), np.uint32)
+        lens = np.zeros(max(self.tiles[1], 1) * self.plan.parts_per_tile, np.uint32)
         n = C.c_size_t()
         out = np.empty(cap, np.uint8)
         rc = self._lib.ojphgpu_encoder_finish_tiles(self._h, out.ctypes.data, cap, C.byref(n), lens.ctypes.data)
@@ -111,7 +111,7 @@ class Encoder:
             out = np.empty(cap, np.uint8)
             rc = self._lib.ojphgpu_encoder_finish_tiles(self._h, out.ctypes.data, cap, C.byref(n), lens.ctypes.data)
         check(rc, "encoder_finish_tiles")
-        return out[:n.value].tobytes(), lens[:self.tiles[1]].copy()
+        return out[:n.value].tobytes(), lens[:self.tiles[1] * self.plan.parts_per_tile].copy()
 
     def encode(self, image):
         """image: numpy int32 [C,H,W] (host), a list of per-component 2-D arrays (sub-sampled

@@ -299,8 +299,10 @@ void codestream::set_profile(const char* s)
 }
 void codestream::set_tilepart_divisions(bool at_resolutions, bool at_components)
 {
-  if (at_resolutions || at_components) ojph_error(0x00030F11, "tile-part divisions are not available on the GPU path");
+  state->p.reserved[1] = (at_resolutions ? 1u : 0u) | (at_components ? 2u : 0u);
 }
+bool codestream::is_tilepart_division_at_resolutions() { return (state->p.reserved[1] & 1u) != 0; }
+bool codestream::is_tilepart_division_at_components() { return (state->p.reserved[1] & 2u) != 0; }
 void codestream::request_tlm_marker(bool needed) { state->p.tlm = needed; }
 bool codestream::is_tlm_requested() { return state->p.tlm != 0; }
 void codestream::set_device(int device) { state->device = device; }
@@ -308,6 +310,75 @@ void codestream::enable_resilience() { state->resilient = true; }
 param_siz codestream::access_siz() { return param_siz(state); }
 param_cod codestream::access_cod() { return param_cod(state); }
 param_qcd codestream::access_qcd() { return param_qcd(state); }
+
+// IMF / BROADCAST profile rules (ojph_codestream_local.cpp:293-553): the profile only constrains the
+// parameters; it also asks for a TLM marker and one tile-part per component
+static void check_profile(codestream_state& S)
+{
+  const ojphgpu_params& p = S.p;
+  const bool imf = S.profile == "IMF";
+  const ui32 eb = imf ? 0x000300C0 : 0x000300B0;                   // the reference's error code families
+  const char* nm = imf ? "IMF" : "broadcast";
+  const ui32 ex = p.width + S.image_offset.x, ey = p.height + S.image_offset.y;
+  const ui32 L = p.num_decomps;
+  if (imf && !(ex <= 8192 && ey <= 6224))
+    ojph_error(p.reversible ? 0x000300C1 : 0x000300C2, "Image dimensions do not meet any of the %s IMF profiles", p.reversible ? "lossless" : "lossy");
+  if (S.image_offset.x || S.image_offset.y) ojph_error(eb + (imf ? 3 : 1), "For %s profile, image offset (XOsiz, YOsiz) has to be 0.", nm);
+  if (S.tile_offset.x || S.tile_offset.y) ojph_error(eb + (imf ? 4 : 2), "For %s profile, tile offset (XTOsiz, YTOsiz) has to be 0.", nm);
+  if (p.num_comps > (imf ? 3u : 4u)) ojph_error(eb + (imf ? 5 : 3), "For %s profile, the number of components has to be less or equal to %d", nm, imf ? 3 : 4);
+  bool ds1 = true, ds2 = true, bd_ok = true;
+  for (ui32 c = 0; c < p.num_comps; ++c) {
+    const local::comp_info& ci = S.comps[c];
+    ds1 &= ci.ds.y == 1 && ci.ds.x == 1;
+    ds2 &= ci.ds.y == 1 && ci.ds.x == ((c == 1 || c == 2) ? 2u : 1u);
+    bd_ok &= ci.bit_depth >= 8 && ci.bit_depth <= (imf ? 16u : 12u) && !ci.is_signed;
+  }
+  if (!ds1 && !ds2)
+    ojph_error(eb + (imf ? 6 : 4), "For %s profile, either no component downsampling is used, or the x-dimension of the 2nd and 3rd "
+               "components is downsampled by 2.", nm);
+  if (!bd_ok) ojph_error(eb + (imf ? 7 : 5), "For %s profile, compnent bit_depth has to be between 8 and %d bits inclusively, and the samples must be unsigned", nm, imf ? 16 : 12);
+  auto lg = [](ui32 v) { ui32 k = 0; while ((1u << k) < v) ++k; return k; };
+  const ui32 lbw = lg(p.block_w), lbh = lg(p.block_h);
+  if (imf) { if (lbw != 5 || lbh != 5) ojph_error(0x000300C8, "For IMF profile, codeblock dimensions are restricted. Use \"-block_size {32,32}\" at the commandline"); }
+  else {
+    if (L == 0 || L > 5) ojph_error(0x000300B6, "For broadcast profile, number of decompositions has to be between1 and 5 inclusively.");
+    if (lbw < 5 || lbw > 7) ojph_error(0x000300B7, "For broadcast profile, codeblock dimensions are restricted such that codeblock width has to be either 32, 64, or 128.");
+    if (lbh < 5 || lbh > 7) ojph_error(0x000300B8, "For broadcast profile, codeblock dimensions are restricted such that codeblock height has to be either 32, 64, or 128.");
+  }
+  // precincts: {128,128} for the lowest resolution, {256,256} above -- the reference's loop keeps only
+  // the verdict of the LAST resolution when there is more than one (:380-383, :518-522)
+  auto pp = [&](ui32 r, ui32& w, ui32& h) {
+    bool per_res = false;
+    for (ui32 i = 0; i <= L && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
+    if (per_res) { w = p.precinct_exps[r] & 15u; h = p.precinct_exps[r] >> 4; }
+    else if (p.precinct_w && p.precinct_h) { w = lg(p.precinct_w); h = lg(p.precinct_h); }
+    else { w = h = 15; }
+  };
+  ui32 w, h; pp(0, w, h);
+  bool pz = w == 7 && h == 7;
+  for (ui32 i = 1; i <= L; ++i) { pp(i, w, h); pz = w == 8 && h == 8; }
+  if (!pz) ojph_error(imf ? 0x000300C9 : 0x000300B9, "For %s profile, precinct sizes are restricted. Use \"-precincts {128,128},{256,256}\" at the commandline", nm);
+  if (p.prog_order != 4) ojph_error(imf ? 0x000300CA : 0x000300BA, "For %s profile, the CPRL progression order must be used. Use \"-prog_order CPRL\".", nm);
+  const ui32 tw = p.tile_w ? p.tile_w : ex + S.image_offset.x, th = p.tile_h ? p.tile_h : ey + S.image_offset.y;
+  const ui32 tiles = ((ex + tw - 1) / tw) * ((ey + th - 1) / th);
+  if (imf) {
+    const bool rev = p.reversible != 0;
+    bool k2 = ex <= 2048 && ey <= 1556 && L <= 5, k4 = ex <= 4096 && ey <= 3112 && L <= 6, k8 = L <= 7;
+    if (L == 0 || (!k2 && !k4 && !k8))
+      ojph_error(0x000300CB, "Number of decompositions does not match the IMF profile dictated by wavelet reversibility and image dimensions.");
+    if (tiles > 1) {
+      if (!rev) ojph_error(0x000300CC, "Lossy IMF profile must have one tile.");
+      k2 &= tw == 1024 && th == 1024 && ((tw >= 1024 && L <= 4) || (tw >= 2048 && L <= 5));
+      k4 &= ((tw == 1024 && th == 1024) || (tw == 2048 && th == 2048)) && ((tw >= 1024 && L <= 4) || (tw >= 2048 && L <= 5) || (tw >= 4096 && L <= 6));
+      k8 &= ((tw == 1024 && th == 1024) || (tw == 2048 && th == 2048) || (tw == 4096 && th == 4096)) &&
+            ((tw >= 1024 && L <= 4) || (tw >= 2048 && L <= 5) || (tw >= 4096 && L <= 6) || (tw >= 8192 && L <= 7));
+      if (!k2 && !k4 && !k8)
+        ojph_error(0x000300CD, "Number of decompositions does not match the IMF profile dictated by wavelet reversibility and image dimensions and tiles.");
+    }
+  } else if (tiles != 1 && tiles != 4) ojph_error(0x000300BB, "The broadcast profile can only have 1 or 4 tiles");
+  S.p.tlm = 1;                                                     // need_tlm = true; tile-parts at components only
+  S.p.reserved[1] = 2;
+}
 
 // (ojph_codestream_local.cpp:556-712) validation of the parameter set; the marker segments themselves
 // are written by flush() together with the tile-parts
@@ -337,10 +408,15 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
   if (S.planar == -1) S.planar = p.color_transform ? 1 : 0;        // not chosen: the reference's rule (ojph_codestream_local.cpp:622-623)
   if (S.planar == 1 && p.color_transform)
     ojph_error(0x00030021, "the planar interface option cannot be used when colour transform is employed");          // :630
-  if (comments != nullptr && num_comments != 0)
-    ojph_error(0x00030F06, "user COM markers are not available on the GPU path");
+  if (!S.profile.empty()) check_profile(S);
   int rc = ojphgpu_plan_create(&p, &S.plan);
   if (rc) ojph_error(0x00030F07, "parameters rejected by the GPU path (status %d)", rc);
+  if (comments != nullptr && num_comments != 0) {                  // ojph_codestream_local.cpp:686-703
+    std::vector<const uint8_t*> d(num_comments); std::vector<uint16_t> l(num_comments), r(num_comments);
+    for (ui32 i = 0; i < num_comments; ++i) { d[i] = (const uint8_t*)comments[i].data; l[i] = comments[i].len; r[i] = comments[i].Rcom; }
+    if (ojphgpu_plan_set_comments(S.plan, d.data(), l.data(), r.data(), num_comments) != OJPHGPU_OK)
+      ojph_error(0x00030F06, "COM marker segments rejected");
+  }
   rc = ojphgpu_encoder_create(S.plan, S.device, nullptr, &S.enc);
   if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
   S.alloc_frame();

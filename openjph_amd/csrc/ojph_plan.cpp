@@ -191,6 +191,17 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
       if ((p.precinct_exps[i] & 15) == 0 || (p.precinct_exps[i] >> 4) == 0) return fail("precinct size too small");   // ojph_params.cpp:208
     p.precinct_w = 1u << (p.precinct_exps[0] & 15); p.precinct_h = 1u << (p.precinct_exps[0] >> 4);
   } else memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
+  {                                                   // ojph_codestream_local.cpp:582-620, ojph_tile.cpp:225-250
+    uint32_t div = p.reserved[1] & 3u;
+    if ((p.prog_order == 0 || p.prog_order == 1) && div == 2) div |= 1;     // LRCP / RLCP: per component means per resolution and component
+    if (p.prog_order == 2) div &= ~2u;                                      // RPCL: only per resolution
+    if (p.prog_order == 3) div = 0;                                         // PCRL: none
+    if (p.prog_order == 4) div &= ~1u;                                      // CPRL: only per component
+    p.reserved[1] = div;
+    plan.tilepart_div = div;
+    plan.parts_per_tile = div == 0 ? 1 : div == 1 ? p.num_decomps + 1 : div == 2 ? p.num_comps : p.num_comps * (p.num_decomps + 1);
+    if (plan.parts_per_tile > 255) return fail("a tile cannot have more than 255 tile parts");
+  }
   plan.p = p;
   derive_quant(plan);
 
@@ -450,6 +461,26 @@ extern "C" int ojphgpu_plan_counts(const ojphgpu_plan* plan, uint64_t out[8])
   out[0] = P.tiles.size(); out[1] = P.bands.size(); out[2] = P.blocks.size();
   out[3] = P.levels.size(); out[4] = P.arena_elems; out[5] = P.max_block_bytes;
   out[6] = P.precincts.size(); out[7] = P.tcomps.size();
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_set_comments(ojphgpu_plan* plan, const uint8_t* const* data, const uint16_t* len,
+                                          const uint16_t* rcom, uint32_t n)
+{
+  if (!plan || (n && (!data || !len || !rcom))) return OJPHGPU_E_INVALID;
+  std::vector<Plan::Comment> c(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (len[i] > 65531 || (len[i] && !data[i])) return OJPHGPU_E_INVALID;    // Lcom = len + 4 is 16 bits
+    c[i].rcom = rcom[i]; c[i].data.assign(data[i], data[i] + len[i]);
+  }
+  plan->plan.comments.swap(c);
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_tile_parts(const ojphgpu_plan* plan, uint32_t* parts_per_tile)
+{
+  if (!plan || !parts_per_tile) return OJPHGPU_E_INVALID;
+  *parts_per_tile = plan->plan.parts_per_tile;
   return OJPHGPU_OK;
 }
 

@@ -88,6 +88,11 @@ struct Plan {
   // resolutions are not decoded (their blocks count as empty), the top skip_recon are not
   // synthesised; comps / frame_elems then describe the smaller reconstructed frame
   uint32_t skip_read = 0, skip_recon = 0;
+  // tile-part divisions after the progression order had its say (ojph_codestream_local.cpp:582-620):
+  // bit 0 = a tile-part per resolution, bit 1 = per component
+  uint32_t tilepart_div = 0, parts_per_tile = 1;
+  struct Comment { uint16_t rcom; std::vector<uint8_t> data; };
+  std::vector<Comment> comments;   // user COM segments of the main header
   uint32_t ntx, nty;
   uint32_t guard_bits;
   std::vector<uint8_t> spqcd8;   // reversible: exponent bytes as written in QCD

@@ -121,6 +121,9 @@ void write_main_header(const Plan& P, ByteSink& s)
   // (ojph_codestream_local.cpp:678-696)
   static const char ver[] = "OpenJPH Ver 0.31.0.";
   s.u16(COM); s.u16((uint32_t)strlen(ver) + 4); s.u16(1); s.bytes(ver, strlen(ver));
+  for (const Plan::Comment& c : P.comments) {       // :686-703
+    s.u16(COM); s.u16((uint32_t)c.data.size() + 4); s.u16(c.rcom); s.bytes((const char*)c.data.data(), c.data.size());
+  }
 }
 
 // Encodes the header of one packet (one precinct).  Returns false for an empty packet.
@@ -209,28 +212,49 @@ using namespace ojphgpu;
 
 namespace {
 
+// the tile-part a packet belongs to (tile::flush: TPsot = r, c, or c + r * num_comps)
+uint32_t part_of(const Plan& P, const Precinct& pc)
+{
+  switch (P.tilepart_div) {
+    case 1: return pc.res;
+    case 2: return pc.comp;
+    case 3: return pc.comp + pc.res * P.p.num_comps;
+    default: return 0;
+  }
+}
+
 // Tile-parts of tiles [t0, t1): SOT + SOD + packets (tile::flush, ojph_tile.cpp:584-774).  Tiles
-// are independent of each other, which is what lets ranks shard them.  len_out[t - t0] receives
-// Psot of tile t.  Returns 0 / OJPHGPU_E_OVERFLOW with *out_len = bytes needed.
+// are independent of each other, which is what lets ranks shard them.  len_out[(t - t0) *
+// parts_per_tile + k] receives Psot of tile-part k of tile t.  Returns 0 / OJPHGPU_E_OVERFLOW with
+// *out_len = bytes needed.
 int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_block* cb, size_t t0, size_t t1,
                      uint8_t* out, size_t cap, size_t* out_len, uint32_t* len_out)
 {
   // packet headers first (sizes are needed for Psot / TLM)
   struct Pkt { std::vector<uint8_t> hdr; bool coded; };
+  const uint32_t ppt = P.parts_per_tile;
   std::vector<std::vector<Pkt>> tile_pkts(t1 - t0);
-  std::vector<uint64_t> tile_bytes(t1 - t0, 0);
+  std::vector<uint64_t> part_bytes((t1 - t0) * ppt, 0);
   size_t total = 0;
   for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
     tile_pkts[t - t0].resize(T.packets.size());
+    uint32_t last_part = 0;
     for (size_t i = 0; i < T.packets.size(); ++i) {
       Pkt& k = tile_pkts[t - t0][i]; uint64_t body = 0;
-      k.coded = write_packet_header(P, P.precincts[T.packets[i]], cb, k.hdr, body);
-      tile_bytes[t - t0] += k.coded ? k.hdr.size() + body : 1;
+      const Precinct& pc = P.precincts[T.packets[i]];
+      k.coded = write_packet_header(P, pc, cb, k.hdr, body);
+      const uint32_t part = part_of(P, pc);
+      if (part < last_part || part >= ppt) return OJPHGPU_E_INVALID;       // a tile-part is a run of the packet sequence
+      last_part = part;
+      part_bytes[(t - t0) * ppt + part] += k.coded ? k.hdr.size() + body : 1;
     }
-    if (tile_bytes[t - t0] + 14 > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
-    if (len_out) len_out[t - t0] = (uint32_t)tile_bytes[t - t0] + 14;
-    total += 14 + tile_bytes[t - t0];
+    for (uint32_t k = 0; k < ppt; ++k) {
+      const uint64_t b = part_bytes[(t - t0) * ppt + k];
+      if (b + 14 > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
+      if (len_out) len_out[(t - t0) * ppt + k] = (uint32_t)b + 14;
+      total += 14 + b;
+    }
   }
   *out_len = total;
   if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
@@ -245,13 +269,20 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
   auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
   for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
-    u16(SOT); u16(10); u16(T.idx); u32((uint32_t)tile_bytes[t - t0] + 14); *w++ = 0; *w++ = 1;
-    u16(SOD);
+    uint32_t next_part = 0;                          // tile-parts are written in order, empty ones included
+    auto open_parts_up_to = [&](uint32_t part) {
+      for (; next_part <= part; ++next_part) {
+        u16(SOT); u16(10); u16(T.idx); u32((uint32_t)part_bytes[(t - t0) * ppt + next_part] + 14);
+        *w++ = (uint8_t)next_part; *w++ = (uint8_t)ppt;
+        u16(SOD);
+      }
+    };
     for (size_t i = 0; i < T.packets.size(); ++i) {
       const Pkt& k = tile_pkts[t - t0][i];
+      const Precinct& pc = P.precincts[T.packets[i]];
+      open_parts_up_to(part_of(P, pc));
       if (!k.coded) { *w++ = 0; continue; }
       memcpy(w, k.hdr.data(), k.hdr.size()); w += k.hdr.size();
-      const Precinct& pc = P.precincts[T.packets[i]];
       const Resolution& R = P.ress[P.tcomps[T.comps[pc.comp]].res[pc.res]];
       for (int s = 0; s < 4; ++s) {
         if (R.band[s] < 0) continue;
@@ -266,6 +297,7 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
           }
       }
     }
+    open_parts_up_to(ppt - 1);
   }
   if ((size_t)(w - out) != total) return OJPHGPU_E_INVALID;
   size_t body = 0;
@@ -310,7 +342,9 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   ByteSink hdr;
   write_main_header(P, hdr);
   size_t total = hdr.v.size();
-  if (P.p.tlm) total += 6 + 6 * P.tiles.size();
+  const size_t nparts = P.tiles.size() * P.parts_per_tile;
+  if (P.p.tlm && 4 + 6 * nparts > 65535) return OJPHGPU_E_INVALID;
+  if (P.p.tlm) total += 6 + 6 * nparts;
   *out_len = total;
   if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
   uint8_t* w = out;
@@ -318,8 +352,9 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
   auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
   if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
-    u16(TLM); u16(4 + 6 * (uint32_t)P.tiles.size()); *w++ = 0; *w++ = 0x60;
-    for (size_t t = 0; t < P.tiles.size(); ++t) { u16((uint32_t)t); u32(tile_part_len[t]); }
+    u16(TLM); u16(4 + 6 * (uint32_t)nparts); *w++ = 0; *w++ = 0x60;
+    for (size_t t = 0; t < P.tiles.size(); ++t)
+      for (uint32_t k = 0; k < P.parts_per_tile; ++k) { u16((uint32_t)t); u32(tile_part_len[t * P.parts_per_tile + k]); }
   }
   return OJPHGPU_OK;
 }
@@ -331,7 +366,7 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
   if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
   const size_t nt = P.tiles.size();
-  std::vector<uint32_t> lens(nt, 0);
+  std::vector<uint32_t> lens(nt * P.parts_per_tile, 0);
   size_t hlen = 0, tlen = 0;
   int rc = ojphgpu_t2_write_main_header(plan, lens.data(), nullptr, 0, &hlen);       // size only (independent of lens)
   if (rc != OJPHGPU_E_OVERFLOW && rc != OJPHGPU_OK) return rc;

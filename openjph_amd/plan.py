@@ -14,9 +14,10 @@ coded_dtype = np.dtype(CodedBlock)
 def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
-                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0)):
+                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts=""):
     """width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
-    (dx, dy) per component (param_siz::set_component), default 1,1."""
+    (dx, dy) per component (param_siz::set_component), default 1,1; tileparts: "", "R", "C" or "RC"
+    (codestream::set_tilepart_divisions)."""
     p = Params()
     p.width, p.height, p.num_comps = width, height, num_comps
     p.bit_depth, p.is_signed = bit_depth, int(is_signed)
@@ -32,6 +33,7 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
             pw, ph = precincts[min(i, len(precincts) - 1)]
             p.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
     p.tlm = int(tlm)
+    p.reserved[1] = (1 if "R" in tileparts else 0) | (2 if "C" in tileparts else 0)
     p.image_x0, p.image_y0 = image_offset
     p.tile_x0, p.tile_y0 = tile_offset
     if downsampling:
@@ -59,6 +61,9 @@ class Plan:
          self.max_block_bytes, self.num_precincts, self.num_tcomps) = [int(v) for v in cnt]
         self.params = Params()
         check(self._lib.ojphgpu_plan_params(self.handle, C.byref(self.params)))
+        ppt = C.c_uint32()
+        check(self._lib.ojphgpu_plan_tile_parts(self.handle, C.byref(ppt)))
+        self.parts_per_tile = int(ppt.value)
         self.bands = np.zeros(self.num_bands, band_dtype)
         self.blocks = np.zeros(self.num_blocks, block_dtype)
         self.levels = np.zeros(self.num_levels, level_dtype)
@@ -76,6 +81,15 @@ class Plan:
                 self.handle = None
         except Exception:
             pass
+
+    def set_comments(self, comments):
+        """user COM segments of the main header: a list of str (Latin text, Rcom = 1) or bytes (Rcom = 0)"""
+        n = len(comments)
+        raw = [c.encode("latin-1") if isinstance(c, str) else bytes(c) for c in comments]
+        data = (C.c_char_p * max(n, 1))(*raw)
+        lens = (C.c_uint16 * max(n, 1))(*[len(b) for b in raw])
+        rcom = (C.c_uint16 * max(n, 1))(*[1 if isinstance(c, str) else 0 for c in comments])
+        check(self._lib.ojphgpu_plan_set_comments(self.handle, data, lens, rcom, n), "plan_set_comments")
 
     def restrict_resolution(self, skipped_res_for_data, skipped_res_for_recon=None):
         """codestream::restrict_input_resolution on a parsed plan (before a Decoder is created from it)"""
@@ -158,7 +172,7 @@ class Plan:
         """Tile-parts of tiles [tile_first, tile_first+tile_count) -> (bytes, Psot per tile)."""
         block_data = np.ascontiguousarray(block_data, dtype=np.uint8)
         coded = np.ascontiguousarray(coded, dtype=coded_dtype)
-        lens = np.zeros(max(tile_count, 1), np.uint32)
+        lens = np.zeros(max(tile_count, 1) * self.parts_per_tile, np.uint32)
         need = C.c_size_t()
         rc = self._lib.ojphgpu_t2_write_tiles(self.handle, block_data.ctypes.data, coded.ctypes.data, tile_first,
                                               tile_count, None, 0, C.byref(need), lens.ctypes.data)
@@ -168,13 +182,13 @@ class Plan:
         check(self._lib.ojphgpu_t2_write_tiles(self.handle, block_data.ctypes.data, coded.ctypes.data, tile_first,
                                                tile_count, out.ctypes.data, out.size, C.byref(need), lens.ctypes.data),
               "t2_write_tiles")
-        return out[:need.value].tobytes(), lens[:tile_count].copy()
+        return out[:need.value].tobytes(), lens[:tile_count * self.parts_per_tile].copy()
 
     def t2_main_header(self, tile_part_len=None) -> bytes:
         """SOC .. end of the main header; tile_part_len (Psot of every tile) feeds the TLM marker."""
         lens = None if tile_part_len is None else np.ascontiguousarray(tile_part_len, dtype=np.uint32)
-        if lens is not None and lens.size != self.num_tiles:
-            raise ValueError("tile_part_len must have one entry per tile")
+        if lens is not None and lens.size != self.num_tiles * self.parts_per_tile:
+            raise ValueError("tile_part_len must have one entry per tile-part")
         need = C.c_size_t()
         ptr = None if lens is None else lens.ctypes.data
         rc = self._lib.ojphgpu_t2_write_main_header(self.handle, ptr, None, 0, C.byref(need))

@@ -62,14 +62,15 @@ def gather_bytes(payload: bytes, group=None, dst=0, device=None):
     return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)], sizes
 
 
-def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None):
-    """All ranks learn Psot of every tile (needed by the TLM marker and for file offsets)."""
+def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None, parts_per_tile=1):
+    """All ranks learn Psot of every tile-part (needed by the TLM marker and for file offsets);
+    lens holds parts_per_tile entries per tile of this rank's run."""
     import torch
     import torch.distributed as dist
     dev = device if device is not None else "cpu"
-    full = torch.zeros(num_tiles, dtype=torch.int64, device=dev)
+    full = torch.zeros(num_tiles * parts_per_tile, dtype=torch.int64, device=dev)
     if len(lens):
-        full[first:first + len(lens)] = torch.from_numpy(np.asarray(lens, dtype=np.int64)).to(dev)
+        full[first * parts_per_tile:first * parts_per_tile + len(lens)] = torch.from_numpy(np.asarray(lens, dtype=np.int64)).to(dev)
     dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
     return full.cpu().numpy().astype(np.uint32)
 
@@ -83,7 +84,7 @@ def encode_sharded(encode_tiles, plan, group=None, device=None):
     rank = dist.get_rank(group)
     first, count = tile_range(plan.num_tiles, rank, world)
     part, lens = encode_tiles(first, count) if count else (b"", np.zeros(0, np.uint32))
-    all_lens = gather_tile_lengths(lens, plan.num_tiles, first, group, device)
+    all_lens = gather_tile_lengths(lens, plan.num_tiles, first, group, device, plan.parts_per_tile)
     parts, _ = gather_bytes(part, group, 0, device)
     if rank != 0:
         return None

@@ -50,6 +50,7 @@ struct ref_params {
   uint32_t image_x0, image_y0;   // image offset; width/height are the image SIZE (extent = offset + size)
   uint32_t tile_x0, tile_y0;     // tile offset
   uint8_t  comp_dx[16], comp_dy[16];   // sub-sampling of component c < 16; 0 => 1
+  uint32_t tilepart_div;         // bit 0: tile-parts at resolutions, bit 1: at components
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -65,7 +66,17 @@ int ref_simd_level(void)
 
 // planes: num_comps pointers to int32 rows (width*height each).  Returns codestream length or
 // a negative number on error / insufficient capacity (-needed).
+long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* out, long out_cap,
+                   const char* profile, const char* com);
+
 long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out, long out_cap)
+{
+  return ref_encode_ex(p, planes, out, out_cap, NULL, NULL);
+}
+
+// profile: NULL / "IMF" / "BROADCAST" (codestream::set_profile); com: NULL or a user COM string
+long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* out, long out_cap,
+                   const char* profile, const char* com)
 {
   try {
     ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
@@ -102,10 +113,14 @@ long ref_encode(const ref_params* p, const int32_t* const* planes, uint8_t* out,
       cs.access_qcd().set_irrev_quant(p->qstep);
     cs.set_planar(p->planar != 0);
     if (p->tlm) cs.request_tlm_marker(true);
+    if (p->tilepart_div) cs.set_tilepart_divisions((p->tilepart_div & 1) != 0, (p->tilepart_div & 2) != 0);
 
+    if (profile && profile[0]) cs.set_profile(profile);
     ojph::mem_outfile mf;
     mf.open();
-    cs.write_headers(&mf);
+    ojph::comment_exchange ce;
+    if (com) ce.set_string(com);
+    cs.write_headers(&mf, com ? &ce : NULL, com ? 1 : 0);
 
     // the library says which component's line it wants next (planar, interleaved, sub-sampled alike)
     std::vector<uint32_t> row(p->num_comps, 0), cw(p->num_comps), ch(p->num_comps);

@@ -27,6 +27,7 @@ class RefParams(C.Structure):
         ("precinct_exps", C.c_uint8 * 36),
         ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
+        ("tilepart_div", C.c_uint32),
     ]
 
 
@@ -51,6 +52,8 @@ class Ref:
         L = self.lib
         L.ref_encode.restype = C.c_long
         L.ref_encode.argtypes = [C.POINTER(RefParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_long]
+        L.ref_encode_ex.restype = C.c_long
+        L.ref_encode_ex.argtypes = [C.POINTER(RefParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_long, C.c_char_p, C.c_char_p]
         L.ref_decode.restype = C.c_int
         L.ref_decode.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.ref_decode_skip.restype = C.c_int
@@ -70,7 +73,8 @@ class Ref:
     def encode(self, planes, bit_depth, is_signed=False, reversible=True, num_decomps=5,
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
                planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
-               downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None):
+               downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None, tileparts="",
+               profile=None, com=None):
         """planes: int32 array [num_comps, H, W], or a list of per-component 2-D arrays when the
         components are sub-sampled (then size=(W, H) is the image size on the reference grid).
         Returns codestream bytes."""
@@ -94,12 +98,14 @@ class Ref:
                 p.precinct_exps[i] = (pw.bit_length() - 1) | ((ph.bit_length() - 1) << 4)
         p.image_x0, p.image_y0 = image_offset
         p.tile_x0, p.tile_y0 = tile_offset
+        p.tilepart_div = (1 if "R" in tileparts else 0) | (2 if "C" in tileparts else 0)
         for c, (dx, dy) in enumerate(downsampling or []):
             p.comp_dx[c], p.comp_dy[c] = dx, dy
         ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])
         cap = sum(q.size for q in planes) * 5 + (1 << 20)
         out = np.empty(cap, dtype=np.uint8)
-        n = self.lib.ref_encode(C.byref(p), ptrs, out.ctypes.data, cap)
+        n = self.lib.ref_encode_ex(C.byref(p), ptrs, out.ctypes.data, cap,
+                                   profile.encode() if profile else None, com.encode("latin-1") if com is not None else None)
         if n <= 0:
             raise RuntimeError("reference encode failed (%d)" % n)
         return out[:n].tobytes()

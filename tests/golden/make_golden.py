@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
-from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, stream_kwargs,  # noqa: E402
-                                refine_case, grid_kwargs, skip_case)
+from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, TILEPART_CASES,  # noqa: E402
+                                stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case)
 
 
 def sha(b):
@@ -83,6 +83,13 @@ def main():
         assert [d.shape for d in dec] == [q.shape for q in planes]
         out["grid"].append({"case": i, "len": len(cs), "sha256": sha(cs),
                             "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
+    # (b4) tile-part divisions, user COM segment, BROADCAST profile
+    out["tileparts"] = []
+    for i in range(len(TILEPART_CASES)):
+        img, kw = tilepart_case(i)
+        r = ref if kw.get("reversible", True) else refgen
+        cs = r.encode(img, **kw)
+        out["tileparts"].append({"case": i, "len": len(cs), "sha256": sha(cs)})
     # (b3) reduced-resolution decoding
     out["skip"] = []
     for i in range(len(SKIP_CASES)):

@@ -60,6 +60,21 @@ GRID_CASES = [
 ]
 
 
+# tile-part divisions (codestream::set_tilepart_divisions) on a 3-component 150x200 image:
+# (progression order, divisions, further kwargs)
+TILEPART_CASES = [
+    ("LRCP", "R", {}), ("LRCP", "C", {}), ("RLCP", "RC", dict(tile=(64, 64), tlm=True)), ("RPCL", "R", dict(precinct=(64, 64), num_decomps=3)),
+    ("RPCL", "RC", {}), ("PCRL", "RC", {}), ("CPRL", "C", dict(tile=(64, 64), tlm=True)), ("CPRL", "R", {}),
+    ("RPCL", "R", dict(tlm=True, reversible=False, qstep=0.05)),
+]
+
+
+def tilepart_case(i):
+    po, tp, extra = TILEPART_CASES[i]
+    img = synth_image(3, 150, 200, 8, seed=2)
+    return img, dict(bit_depth=8, prog_order=po, tileparts=tp, **extra)
+
+
 # reduced-resolution decoding (codestream::restrict_input_resolution): (family, case index,
 # skipped_res_for_data, skipped_res_for_recon)
 SKIP_CASES = [

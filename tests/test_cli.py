@@ -182,3 +182,39 @@ def test_cli_truncated_file_needs_resilient(tmp_path):
     pl = parse_codestream(part, resilient=True)
     want = cp.inverse_stages(pl, cp.decode_blocks(pl, part))
     assert np.array_equal(read_pnm(tmp_path / "t.pgm"), np.clip(want, 0, 255))
+
+
+@pytest.mark.gpu
+def test_cli_tileparts_com_and_broadcast_profile(tmp_path):
+    """-tileparts, -com and -profile BROADCAST (which forces a TLM marker and tile-parts at
+    components, ojph_codestream_local.cpp:456-553); expectations from the oracle pipeline, whose
+    tile-part / COM writing is pinned to the reference by tests/test_cpu_parity.py"""
+    from openjph_amd.plan import Plan, make_params
+    from tests import cpu_pipeline as cp
+    img = synth_image(3, 150, 200, 8, seed=2)
+    write_pnm(tmp_path / "a.ppm", img, 8)
+    r = run([COMPRESS, "-i", str(tmp_path / "a.ppm"), "-o", str(tmp_path / "a.j2c"), "-reversible", "true", "-prog_order", "LRCP",
+             "-tileparts", "RC", "-tlm_marker", "true", "-com", "made on a GPU"])
+    assert r.returncode == 0, r.stdout
+    plan = Plan(make_params(200, 150, 3, bit_depth=8, color_transform=True, prog_order="LRCP", tileparts="RC", tlm=True))
+    plan.set_comments(["made on a GPU"])
+    data, coded = cp.encode_blocks(plan, cp.forward_stages(plan, img))
+    assert open(tmp_path / "a.j2c", "rb").read() == plan.t2_write(data, coded)
+    r = run([EXPAND, "-i", str(tmp_path / "a.j2c"), "-o", str(tmp_path / "b.ppm")])
+    assert r.returncode == 0 and np.array_equal(read_pnm(tmp_path / "b.ppm"), img)
+
+    # BROADCAST: 4:2:2 10-bit, CPRL, {128,128},{256,256} precincts
+    planes = [synth_image(1, 120, 256, 10, seed=3)[0], synth_image(1, 120, 128, 10, seed=4)[0], synth_image(1, 120, 128, 10, seed=5)[0]]
+    with open(tmp_path / "v.yuv", "wb") as f:
+        for q in planes:
+            f.write(q.astype("<u2").tobytes())
+    args = [COMPRESS, "-i", str(tmp_path / "v.yuv"), "-o", str(tmp_path / "v.j2c"), "-dims", "{256,120}", "-num_comps", "3", "-bit_depth", "10",
+            "-signed", "false", "-downsamp", "{1,1},{2,1},{2,1}", "-qstep", "0.01", "-profile", "BROADCAST", "-prog_order", "CPRL",
+            "-precincts", "{128,128},{256,256}"]
+    r = run(args)
+    assert r.returncode == 0, r.stdout
+    want, *_ = cp.encode(planes, size=(256, 120), bit_depth=10, downsampling=[(1, 1), (2, 1), (2, 1)], reversible=False, qstep=0.01,
+                         prog_order="CPRL", precincts=[(128, 128), (256, 256)], tlm=True, tileparts="C")
+    assert open(tmp_path / "v.j2c", "rb").read() == want
+    r = run(args[:-4] + ["-prog_order", "RPCL", "-precincts", "{128,128},{256,256}"])        # the profile wants CPRL
+    assert r.returncode != 0 and b"CPRL" in r.stdout

@@ -18,8 +18,8 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, grid_kwargs, refine_case,
-                                skip_case, stream_kwargs)
+from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES, grid_kwargs,
+                                refine_case, skip_case, stream_kwargs, tilepart_case)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -358,6 +358,41 @@ def test_truncated_codestreams_behave_like_the_reference(k, ref):
                 assert np.array_equal(got, want), "cut at %d of %d, resilient=%s" % (n, len(cs), resilient)
             detected += want is None
     assert detected > 0
+
+
+@pytest.mark.parametrize("i", range(len(TILEPART_CASES)), ids=lambda i: "%s-%s" % TILEPART_CASES[i][:2])
+def test_tilepart_divisions_match_golden(i):
+    """tile::flush with tile-part divisions (ojph_tile.cpp:584-774) and the TLM entries per tile-part
+    (:529-580); what a progression order cannot honour is dropped (ojph_codestream_local.cpp:582-620)"""
+    from tests import cpu_pipeline as cp
+    img, kw = tilepart_case(i)
+    g = GOLD["tileparts"][i]
+    cs, plan, *_ = cp.encode(img, **kw)
+    assert len(cs) == g["len"] and sha(cs) == g["sha256"]
+    dec, _ = cp.decode(cs)                                  # the parser walks the tile-parts back
+    if kw.get("reversible", True):
+        assert np.array_equal(dec, img)
+
+
+def test_tileparts_comments_profile_match_live_reference(ref):
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params
+    from tests import cpu_pipeline as cp
+    img = synth_image(3, 150, 200, 8, seed=7)
+    for po in ("LRCP", "RLCP", "RPCL", "PCRL", "CPRL"):
+        for tp in ("R", "C", "RC"):
+            kw = dict(bit_depth=8, prog_order=po, tileparts=tp, tile=(96, 96), tlm=True)
+            cs, *_ = cp.encode(img, **kw)
+            assert cs == ref.encode(img, **kw), (po, tp)
+    plan = Plan(make_params(200, 150, 3, bit_depth=8))
+    plan.set_comments(["a comment", b"\x00\x01binary"])
+    data, coded = cp.encode_blocks(plan, cp.forward_stages(plan, img))
+    got = plan.t2_write(data, coded)
+    assert b"a comment" in got[:400] and b"\x00\x01binary" in got[:400]
+    plan.set_comments(["a comment"])
+    assert plan.t2_write(data, coded) == ref.encode(img, 8, com="a comment")
+    with pytest.raises(capi.OjphError):                      # 40 components x 7 resolutions > 255 tile-parts
+        Plan(make_params(64, 64, 40, num_decomps=6, prog_order="LRCP", tileparts="RC"))
 
 
 def test_grid_parameter_validation():

@@ -56,6 +56,7 @@ SHARD_CASES = [
     dict(nc=1, h=256, w=256, bd=8, kw=dict(tile=(64, 64), tlm=True)),                # TLM needs every Psot
     dict(nc=3, h=100, w=260, bd=8, kw=dict(tile=(128, 128), color_transform=True)),  # 3 tiles on 2 ranks
     dict(nc=1, h=64, w=64, bd=8, kw=dict()),                                         # 1 tile: rank 1 idle
+    dict(nc=3, h=200, w=200, bd=8, kw=dict(tile=(64, 64), tlm=True, prog_order="CPRL", tileparts="C")),   # 3 tile-parts per tile in the TLM
 ]
 
 
@@ -65,7 +66,7 @@ def test_sharded_encode_gloo_matches_single_process(ci, world):
     import torch.multiprocessing as mp
     from tests import cpu_pipeline as cp
     case = SHARD_CASES[ci]
-    if world == 3 and ci not in (0, 1):
+    if world == 3 and ci not in (0, 1, 4):
         pytest.skip("covered at world_size 2")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
