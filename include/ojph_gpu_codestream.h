@@ -14,9 +14,11 @@
 // std::runtime_error("ojph error") after the message went to stderr.
 //
 // Not every knob of the reference exists behind the GPU path: all
-// components must share bit depth / signedness.  Sub-sampling, image and tile offsets, tile-part
-// divisions, user COM markers, the IMF / BROADCAST profile checks and reduced-resolution decoding
-// are supported.  What is not fails loudly in write_headers() / read_headers() / the setter.
+// no per-component COD / step-size overrides (COC, set_irrev_quant(comp, ..)), no 64-bit samples,
+// no Part-2 wavelets.  Sub-sampling, components of different bit depth / signedness, image and
+// tile offsets, tile-part divisions, user COM markers, qfactor, the IMF / BROADCAST profile checks
+// and reduced-resolution decoding are supported.  What is not fails loudly in write_headers() /
+// read_headers() / the setter.
 #ifndef OJPH_GPU_CODESTREAM_H
 #define OJPH_GPU_CODESTREAM_H
 
@@ -183,6 +185,7 @@ class param_qcd {
 public:
   explicit param_qcd(local::codestream_state* s) : state(s) {}
   void set_irrev_quant(float delta);
+  void set_qfactor(ui8 qfactor);              // 1..100: visually weighted step sizes, a QCC per component
 private:
   local::codestream_state* state;
 };

@@ -57,7 +57,8 @@ typedef struct ojphgpu_params {
   uint32_t reserved[4];          /* [0] bit 0: vertically causal code-block style (set by the parser)
                                     [1] codestream::set_tilepart_divisions: bit 0 = a tile-part per
                                         resolution, bit 1 = per component (what the progression
-                                        order cannot honour is dropped as write_headers drops it) */
+                                        order cannot honour is dropped as write_headers drops it)
+                                    [2] param_qcd::set_qfactor: 1..100, 0 = not set            */
   uint8_t  precinct_exps[36];    /* param_cod::set_precinct_size with a list: per resolution (0 =
                                     lowest) PPx | PPy << 4; all zero = precinct_w/h everywhere  */
   /* reference grid (ojph_params.h:68-112).  width/height stay the image SIZE: the extent the
@@ -66,6 +67,9 @@ typedef struct ojphgpu_params {
   uint32_t tile_x0, tile_y0;     /* param_siz::set_tile_offset (<= image offset)                */
   uint8_t  comp_dx[OJPHGPU_MAX_SUBSAMPLED_COMPS];   /* param_siz::set_component downsampling of   */
   uint8_t  comp_dy[OJPHGPU_MAX_SUBSAMPLED_COMPS];   /* component c < 16; 0 = 1; later ones are 1  */
+  uint8_t  comp_depth[OJPHGPU_MAX_SUBSAMPLED_COMPS]; /* set_component bit depth of component c < 16 */
+                                                     /* when it differs from bit_depth; 0 = same   */
+  uint8_t  comp_sign[OJPHGPU_MAX_SUBSAMPLED_COMPS];  /* 0 = is_signed, 1 = unsigned, 2 = signed    */
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *
@@ -136,6 +140,8 @@ int  ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t c
  * component's origin on its own grid (ceil(image offset / sub-sampling)); out[6], out[7] = its
  * sub-sampling factors.  comp == num_comps: out[4] | out[5] << 32 = elements of one whole frame. */
 int  ojphgpu_plan_comp_info(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
+/* bit depth and signedness of a component (param_siz::get_bit_depth / is_signed) */
+int  ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp, uint32_t* bit_depth, uint32_t* is_signed);
 
 /* ------------------------------------------------------------------------------------------ *
  * 3. Tier-2 on the host: marker segments + packet headers (tag trees, pass lengths) around the
@@ -268,6 +274,8 @@ typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint32_t img_pitch;                /* width of that plane */
   uint64_t img_off;                  /* element offset of that plane in the image buffer (a frame
                                         batch adds the frame's offset) */
+  uint32_t fmt;                      /* bit depth | signed << 8 of the component; 0 = from params */
+  uint32_t reserved;
 } ojphgpu_convert_desc;
 
 /* K10/K11: level shift / int<->float conversion and RCT / ICT (ojph_colour.cpp:238-571 as

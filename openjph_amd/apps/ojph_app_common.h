@@ -54,6 +54,9 @@ inline bool ends_with(const std::string& s, const char* suf) {
 
 struct Image {                       // planar int32 samples; sub-sampled components have their own size
   unsigned width = 0, height = 0, num_comps = 0, bit_depth = 8; bool is_signed = false;
+  std::vector<unsigned> depth; std::vector<bool> sgn;   // per component where given (else bit_depth / is_signed)
+  unsigned bd(unsigned c) const { return c < depth.size() ? depth[c] : bit_depth; }
+  bool sg(unsigned c) const { return c < sgn.size() ? (bool)sgn[c] : is_signed; }
   std::vector<unsigned> cw, ch;      // per component (empty until layout() is called)
   std::vector<size_t> off;
   std::vector<int> data;
@@ -136,27 +139,34 @@ inline void write_pnm(const char* name, Image& img) {
 inline void read_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "rb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
-  const size_t n = img.samples(), bps = img.bit_depth > 8 ? 2 : 1;    // img.layout() was called: planes follow each other
-  std::vector<unsigned char> raw(n * bps);
-  if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short raw file"); }
-  fclose(f);
-  for (size_t i = 0; i < n; ++i) {
-    int v = bps == 2 ? raw[2 * i] | (raw[2 * i + 1] << 8) : raw[i];
-    if (img.is_signed) { const int sh = 32 - (int)img.bit_depth; v = (int)((unsigned)v << sh) >> sh; }
-    img.data[i] = v;
+  // img.layout() was called: planes follow each other, each with its own sample size
+  for (unsigned c = 0; c < img.num_comps; ++c) {
+    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = img.bd(c) > 8 ? 2 : 1;
+    std::vector<unsigned char> raw(n * bps);
+    if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short raw file"); }
+    int* dst = img.plane(c);
+    for (size_t i = 0; i < n; ++i) {
+      int v = bps == 2 ? raw[2 * i] | (raw[2 * i + 1] << 8) : raw[i];
+      if (img.sg(c)) { const int sh = 32 - (int)img.bd(c); v = (int)((unsigned)v << sh) >> sh; }
+      dst[i] = v;
+    }
   }
+  fclose(f);
 }
 
 inline void write_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "wb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
-  const size_t n = img.samples(), bps = img.bit_depth > 8 ? 2 : 1;
-  std::vector<unsigned char> raw(n * bps);
-  for (size_t i = 0; i < n; ++i) {
-    const int v = img.data[i];
-    if (bps == 2) { raw[2 * i] = (unsigned char)v; raw[2 * i + 1] = (unsigned char)(v >> 8); } else raw[i] = (unsigned char)v;
+  for (unsigned c = 0; c < img.num_comps; ++c) {
+    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = img.bd(c) > 8 ? 2 : 1;
+    std::vector<unsigned char> raw(n * bps);
+    const int* src = img.plane(c);
+    for (size_t i = 0; i < n; ++i) {
+      const int v = src[i];
+      if (bps == 2) { raw[2 * i] = (unsigned char)v; raw[2 * i + 1] = (unsigned char)(v >> 8); } else raw[i] = (unsigned char)v;
+    }
+    fwrite(raw.data(), 1, raw.size(), f);
   }
-  fwrite(raw.data(), 1, raw.size(), f);
   fclose(f);
 }
 #endif

@@ -10,7 +10,7 @@
 #include "../../include/ojph_gpu_codestream.h"
 
 static void usage() {
-  printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f]\n"
+  printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f | -qfactor 1..100]\n"
          "  [-num_decomps n] [-block_size {w,h}] [-precincts {w,h}] [-prog_order LRCP|RLCP|RPCL|PCRL|CPRL]\n"
          "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n]\n"
          "  [-image_offset {x,y}] [-tile_offset {x,y}] [-tileparts R|C|RC] [-profile IMF|BROADCAST] [-com \"text\"]\n"
@@ -33,8 +33,13 @@ int main(int argc, char** argv) {
         throw std::runtime_error("raw input needs -dims {w,h} -num_comps n -bit_depth b");
       img.width = (unsigned)dims[0]; img.height = (unsigned)dims[1];
       img.num_comps = (unsigned)atoi(a.get("-num_comps"));
-      img.bit_depth = (unsigned)Args::numbers(a.get("-bit_depth"))[0];
+      auto bdl = Args::numbers(a.get("-bit_depth"));           // one value, or one per component (the last repeats)
+      img.bit_depth = (unsigned)bdl[0];
       auto sg = Args::bools(a.get("-signed")); img.is_signed = !sg.empty() && sg[0];
+      for (unsigned c = 0; c < img.num_comps; ++c) {
+        img.depth.push_back((unsigned)bdl[std::min<size_t>(c, bdl.size() - 1)]);
+        img.sgn.push_back(sg.empty() ? false : (bool)sg[std::min<size_t>(c, sg.size() - 1)]);
+      }
       auto ds = Args::numbers(a.get("-downsamp"));
       if (ds.size() % 2) throw std::runtime_error("-downsamp takes {x,y} pairs");
       for (unsigned c = 0; c < img.num_comps && !ds.empty(); ++c) {
@@ -58,7 +63,7 @@ int main(int argc, char** argv) {
     siz.set_image_extent(ojph::point(image_offset.x + img.width, image_offset.y + img.height));       // ojph_compress.cpp:681-683
     siz.set_num_components(img.num_comps);
     for (unsigned c = 0; c < img.num_comps; ++c)
-      siz.set_component(c, ojph::point(c < dsx.size() ? dsx[c] : 1, c < dsy.size() ? dsy[c] : 1), img.bit_depth, img.is_signed);
+      siz.set_component(c, ojph::point(c < dsx.size() ? dsx[c] : 1, c < dsy.size() ? dsy[c] : 1), img.bd(c), img.sg(c));
     siz.set_image_offset(image_offset);
     auto ts = Args::numbers(a.get("-tile_size"));
     siz.set_tile_size(ts.size() == 2 ? ojph::size((unsigned)ts[0], (unsigned)ts[1]) : ojph::size(0, 0));
@@ -80,7 +85,13 @@ int main(int argc, char** argv) {
     bool ct = pnm && img.num_comps == 3;                       // PPM turns the colour transform on by default
     if (a.get("-colour_trans")) ct = Args::to_bool(a.get("-colour_trans"));
     cod.set_color_transform(ct);
+    if (a.get("-qfactor") && a.get("-qstep")) throw std::runtime_error("-qfactor and -qstep cannot be used together");   // ojph_compress.cpp:644-649
+    if (a.get("-qfactor") && (atoi(a.get("-qfactor")) < 1 || atoi(a.get("-qfactor")) > 100)) throw std::runtime_error("-qfactor must be between 1 and 100");
     if (!reversible && a.get("-qstep")) cs.access_qcd().set_irrev_quant((float)atof(a.get("-qstep")));
+    if (!reversible && a.get("-qfactor")) {
+      if (img.num_comps != 1 && img.num_comps != 3) throw std::runtime_error("-qfactor is only supported for images with 1 or 3 components");   // :921-926
+      cs.access_qcd().set_qfactor((ojph::ui8)atoi(a.get("-qfactor")));
+    }
     if (a.get("-tlm_marker")) cs.request_tlm_marker(Args::to_bool(a.get("-tlm_marker")));
     if (a.get("-profile")) cs.set_profile(a.get("-profile"));
     if (a.get("-tileparts")) {                                  // ojph_compress.cpp:324-356: letters R and / or C

@@ -26,7 +26,10 @@ int main(int argc, char** argv) {
     img.width = siz.get_recon_width(0); img.height = siz.get_recon_height(0);
     img.bit_depth = siz.get_bit_depth(0); img.is_signed = siz.is_signed(0);
     std::vector<unsigned> cw, ch; size_t total_lines = 0;
-    for (unsigned c = 0; c < img.num_comps; ++c) { cw.push_back(siz.get_recon_width(c)); ch.push_back(siz.get_recon_height(c)); total_lines += ch.back(); }
+    for (unsigned c = 0; c < img.num_comps; ++c) {
+      cw.push_back(siz.get_recon_width(c)); ch.push_back(siz.get_recon_height(c)); total_lines += ch.back();
+      img.depth.push_back(siz.get_bit_depth(c)); img.sgn.push_back(siz.is_signed(c));
+    }
     img.layout_sizes(cw, ch);
     const std::string outs(out);
     const bool pnm = ends_with(outs, ".pgm") || ends_with(outs, ".ppm");

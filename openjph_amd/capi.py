@@ -27,6 +27,7 @@ class Params(C.Structure):
         ("precinct_exps", C.c_uint8 * 36),
         ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
+        ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16),
     ]
 
 
@@ -89,7 +90,7 @@ class CbResult(C.Structure):
 class ConvertDesc(C.Structure):
     _fields_ = [("plane_off", C.c_uint64), ("pitch", C.c_uint32), ("w", C.c_uint32),
                 ("h", C.c_uint32), ("src_x0", C.c_uint32), ("src_y0", C.c_uint32),
-                ("img_pitch", C.c_uint32), ("img_off", C.c_uint64)]
+                ("img_pitch", C.c_uint32), ("img_off", C.c_uint64), ("fmt", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -102,6 +103,7 @@ SIGNATURES = {
     "ojphgpu_plan_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_tile_parts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_plan_comp_format": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                             C.c_uint32]),
     "ojphgpu_plan_restrict_resolution": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -42,6 +42,13 @@ __device__ __forceinline__ int to_int(float f, const ConvParams& p)
   return v + half;
 }
 
+// the component's own bit depth / signedness when its descriptor carries one
+__device__ __forceinline__ ConvParams with_fmt(ConvParams p, const ojphgpu_convert_desc& d)
+{
+  if (d.fmt) { p.bit_depth = d.fmt & 0xFFu; p.is_signed = (d.fmt >> 8) & 1u; }
+  return p;
+}
+
 __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
                                                               const int* __restrict__ image, uint32_t* __restrict__ arena)
 {
@@ -50,8 +57,10 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   const ojphgpu_convert_desc d0 = descs[tile * nc];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   auto at = [&](const ojphgpu_convert_desc& d) { return d.img_off + (size_t)(d.src_y0 + y) * d.img_pitch + d.src_x0 + x; };
-  if (p.color) {                                  // the first three components share their geometry
-    if (x >= d0.w || y >= d0.h) return;
+  const ConvParams pc = p;                        // launch-wide parameters; p becomes the component's
+  uint32_t c_first = 0;                           // components past the colour-transformed triple go the plain way
+  if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
+    p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     int r = image[at(d0)], g = image[at(d1)], b = image[at(d2)];
     if (p.reversible) {
@@ -70,11 +79,11 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
       arena[d1.plane_off + (size_t)y * d1.pitch + x] = __float_as_uint(cb);
       arena[d2.plane_off + (size_t)y * d2.pitch + x] = __float_as_uint(cr);
     }
-    return;
   }
-  for (uint32_t c = 0; c < nc; ++c) {
+  for (uint32_t c = c_first; c < nc; ++c) {
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;           // sub-sampled components are smaller
+    p = with_fmt(pc, d);
     int v = image[at(d)];
     uint32_t o;
     if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
@@ -91,8 +100,10 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
   const ojphgpu_convert_desc d0 = descs[tile * nc];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   auto at = [&](const ojphgpu_convert_desc& d) { return d.img_off + (size_t)(d.src_y0 + y) * d.img_pitch + d.src_x0 + x; };
-  if (p.color) {                                  // the first three components share their geometry
-    if (x >= d0.w || y >= d0.h) return;
+  const ConvParams pc = p;                        // launch-wide parameters; p becomes the component's
+  uint32_t c_first = 0;
+  if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
+    p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];
     uint32_t b = arena[d1.plane_off + (size_t)y * d1.pitch + x];
@@ -113,11 +124,11 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
       image[at(d0)] = to_int(r, p); image[at(d1)] = to_int(g, p); image[at(d2)] = to_int(bb, p);
     }
-    return;
   }
-  for (uint32_t c = 0; c < nc; ++c) {
+  for (uint32_t c = c_first; c < nc; ++c) {
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;
+    p = with_fmt(pc, d);
     uint32_t a = arena[d.plane_off + (size_t)y * d.pitch + x];
     int v;
     if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));

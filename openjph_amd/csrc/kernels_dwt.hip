@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   typedef typename std::conditional<IMG, int, T>::type E;          // element type of the source rows
   typedef Raw<E> RawRow;
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;

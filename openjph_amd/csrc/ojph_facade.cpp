@@ -281,6 +281,11 @@ const char* param_cod::get_progression_order_as_string() const { return PROG_NAM
 bool param_cod::is_using_color_transform() const { return state->p.color_transform != 0; }
 
 void param_qcd::set_irrev_quant(float delta) { state->p.qstep = delta; }
+void param_qcd::set_qfactor(ui8 qfactor)
+{
+  if (qfactor < 1 || qfactor > 100) ojph_error(0x00050181, "Qfactor must be between 1 and 100, but was set to %i.", (int)qfactor);   // ojph_params.cpp:1487
+  state->p.reserved[2] = qfactor;
+}
 
 void comment_exchange::set_string(const char* str) { data = str; len = (ui16)strlen(str); Rcom = 1; }
 void comment_exchange::set_data(const char* d, ui16 l) { data = d; len = l; Rcom = 0; }
@@ -392,6 +397,7 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
     ojph_error(0x00040002, "Tile offset has to be smaller than the image offset");                     // ojph_params_local.h:240
   p.image_x0 = S.image_offset.x; p.image_y0 = S.image_offset.y; p.tile_x0 = S.tile_offset.x; p.tile_y0 = S.tile_offset.y;
   memset(p.comp_dx, 0, sizeof(p.comp_dx)); memset(p.comp_dy, 0, sizeof(p.comp_dy));
+  memset(p.comp_depth, 0, sizeof(p.comp_depth)); memset(p.comp_sign, 0, sizeof(p.comp_sign));
   for (ui32 c = 0; c < p.num_comps; ++c) {
     const local::comp_info& ci = S.comps[c];
     if (!ci.set) ojph_error(0x00040002, "component %u has not been configured", c);
@@ -399,8 +405,11 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
     if ((ci.ds.x != 1 || ci.ds.y != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS)
       ojph_error(0x00030F04, "sub-sampling is available for the first %d components on the GPU path", OJPHGPU_MAX_SUBSAMPLED_COMPS);
     if (c < OJPHGPU_MAX_SUBSAMPLED_COMPS) { p.comp_dx[c] = (uint8_t)ci.ds.x; p.comp_dy[c] = (uint8_t)ci.ds.y; }
-    if (ci.bit_depth != S.comps[0].bit_depth || ci.is_signed != S.comps[0].is_signed)
-      ojph_error(0x00030F05, "components of different bit depth / signedness are not available on the GPU path");
+    if (ci.bit_depth != S.comps[0].bit_depth || ci.is_signed != S.comps[0].is_signed) {
+      if (c >= OJPHGPU_MAX_SUBSAMPLED_COMPS)
+        ojph_error(0x00030F05, "a bit depth / signedness of its own is available for the first %d components on the GPU path", OJPHGPU_MAX_SUBSAMPLED_COMPS);
+      p.comp_depth[c] = (uint8_t)ci.bit_depth; p.comp_sign[c] = ci.is_signed ? 2 : 1;
+    }
   }
   p.bit_depth = S.comps[0].bit_depth; p.is_signed = S.comps[0].is_signed;
   if (p.color_transform && p.num_comps < 3)
@@ -472,8 +481,12 @@ void codestream::read_headers(infile_base* file)
   if (rc) ojph_error(0x00030F0C, "codestream not supported by the GPU path (status %d)", rc);
   ojphgpu_plan_params(S.plan, &S.p);
   S.comps.assign(S.p.num_comps, local::comp_info{ point(1, 1), S.p.bit_depth, S.p.is_signed != 0, true });
-  for (ui32 c = 0; c < S.p.num_comps && c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c)
+  for (ui32 c = 0; c < S.p.num_comps && c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c) {
     S.comps[c].ds = point(S.p.comp_dx[c] ? S.p.comp_dx[c] : 1, S.p.comp_dy[c] ? S.p.comp_dy[c] : 1);
+    uint32_t bd = 0, sg = 0;
+    ojphgpu_plan_comp_format(S.plan, c, &bd, &sg);
+    S.comps[c].bit_depth = bd; S.comps[c].is_signed = sg != 0;
+  }
   S.image_offset = point(S.p.image_x0, S.p.image_y0); S.tile_offset = point(S.p.tile_x0, S.p.tile_y0);
   if (S.planar == -1) S.planar = S.p.color_transform ? 0 : 1;                                         // :879
   S.headers_read = true;

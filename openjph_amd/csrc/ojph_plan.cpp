@@ -39,14 +39,42 @@ static const float energy97_h[34] = { 1.4425e+00f, 1.9669e+00f, 2.8839e+00f, 4.1
 static inline uint32_t div_ceil(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline uint32_t ilog2(uint32_t v) { uint32_t r = 0; while ((1u << (r + 1)) <= v && r < 31) ++r; return r; }
 
-// ojph_params.cpp:1495-1540 (reversible) and :1542-1613 (irreversible)
-void derive_quant(Plan& plan)
+// Visual weights of the qfactor mode, per colour format and component type: levels 1..6 x (HH, LH|HL,
+// LH|HL ordering of the reference's table) + LL (ojph_params.cpp:600-793, visual_weights)
+enum { VW_420 = 1, VW_422 = 2, VW_444 = 3, VW_ERR = 4 };
+static const float vw_cb420[19] = { 0.2724f, 0.5128f, 0.5128f, 0.6692f, 0.9382f, 0.9382f, 1.0888f, 1.3046f, 1.3046f, 1.4156f, 1.5594f,
+                                    1.5594f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f };
+static const float vw_cr420[19] = { 0.5196f, 0.8260f, 0.8260f, 1.0080f, 1.2928f, 1.2928f, 1.4440f, 1.6508f, 1.6508f, 1.7538f, 1.8848f,
+                                    1.8848f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f, 2.0f };
+static const float vw_cb422[19] = { 0.1220f, 0.1220f, 0.3626f, 0.3626f, 0.3626f, 0.6634f, 0.6634f, 0.6634f, 0.9225f, 0.9225f, 0.9225f,
+                                    1.1027f, 1.1027f, 1.1027f, 1.4142f, 1.4142f, 1.4142f, 1.4142f, 1.4142f };
+static const float vw_cr422[19] = { 0.2595f, 0.2595f, 0.5841f, 0.5841f, 0.5841f, 0.9141f, 0.9141f, 0.9141f, 1.1673f, 1.1673f, 1.1673f,
+                                    1.3328f, 1.3328f, 1.3328f, 1.4142f, 1.4142f, 1.4142f, 1.4142f, 1.4142f };
+static const float vw_cb444[19] = { 0.0263f, 0.0863f, 0.0863f, 0.1362f, 0.2564f, 0.2564f, 0.3346f, 0.4691f, 0.4691f, 0.5444f, 0.6523f,
+                                    0.6523f, 0.7078f, 0.7797f, 0.7797f, 1.0f, 1.0f, 1.0f, 1.0f };
+static const float vw_cr444[19] = { 0.0773f, 0.1835f, 0.1835f, 0.2598f, 0.4130f, 0.4130f, 0.5040f, 0.6464f, 0.6464f, 0.7220f, 0.8254f,
+                                    0.8254f, 0.8769f, 0.9424f, 0.9424f, 1.0f, 1.0f, 1.0f, 1.0f };
+static const float vw_y[19] = { 0.0901f, 0.2758f, 0.2758f, 0.7018f, 0.8378f, 0.8378f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f,
+                                1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+static const float vw_none[19] = { 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1 };
+
+static float vw_get(const float* v, uint32_t level, uint32_t band)      // visual_weights::get_weight (:660-672)
+{
+  if (band == 0) return v[18];
+  level = std::min<uint32_t>(level, 6);
+  return v[(level - 1) * 3 + (3 - band)];
+}
+
+// One QCD / QCC: param_qcd::make_quant_steps for component `comp` (ojph_params.cpp:1434-1460) with
+// set_rev_quant (:1495-1540) or set_irrev_quant (:1542-1599).  ctype 0 Y, 1 Cb, 2 Cr; qfactor 0 = unset.
+static bool make_quant(const Plan& plan, uint32_t comp, uint32_t qfactor, uint32_t ctype, QuantSet& q, std::string& err,
+                       uint32_t base_depth)
 {
   const ojphgpu_params& p = plan.p;
-  uint32_t D = p.num_decomps;
-  plan.spqcd8.clear(); plan.spqcd16.clear();
+  const uint32_t D = p.num_decomps, depth = plan.comps[comp].bit_depth;
+  q.q8.clear(); q.q16.clear();
   if (p.reversible) {
-    uint32_t B = p.bit_depth + (p.color_transform ? 1 : 0);
+    uint32_t B = depth + ((comp < 3 && p.color_transform) ? 1 : 0);
     std::vector<uint32_t> e;
     double bl = bibo53_l[D];
     uint32_t X = (uint32_t)std::ceil(std::log(bl * bl) / M_LN2);
@@ -59,58 +87,107 @@ void derive_quant(Plan& plan)
       X = (uint32_t)std::ceil(std::log(h * h) / M_LN2);
       e.push_back(B + X); mx = std::max(mx, B + X);
     }
+    if (mx > 38) { err = "bit depth, colour transform and wavelet need more than 38 bits"; return false; }   // :1520-1525
     int guard = std::max(1, (int)mx - 31);
-    plan.guard_bits = (uint32_t)guard;
-    plan.sqcd = (uint8_t)(guard << 5);
-    for (uint32_t v : e) plan.spqcd8.push_back((uint8_t)((v - guard) << 3));
-  } else {
-    plan.guard_bits = 1;
-    plan.sqcd = (uint8_t)((1 << 5) | 0x2);
-    float base = p.qstep;
-    if (!(base > 0.0f)) {                                  // ojph_params.cpp:1456-1460
-      uint32_t t = std::min<uint32_t>(16, p.bit_depth);
-      base = 1.0f / (float)(1 << t);
-    }
-    auto enc = [&](float delta) {                          // encode_SPqcd :1602-1613
-      int exp = 0;
-      while (delta < 1.0f) { exp++; delta *= 2.0f; }
-      int mant = (int)std::round(delta * (float)(1 << 11)) - (1 << 11);
-      mant = mant < (1 << 11) ? mant : 0x7FF;
-      plan.spqcd16.push_back((uint16_t)((exp << 11) | mant));
-    };
-    // no qfactor: g_c = 1, w_b = pow(1, 1) = 1
-    float gl = energy97_l[D];
-    enc(base / (gl * gl * 1.0f * 1.0f));
-    for (uint32_t d = D; d > 0; --d) {
-      float l = energy97_l[d], h = energy97_h[d - 1];
-      enc(base / (h * l * 1.0f * 1.0f));
-      enc(base / (l * h * 1.0f * 1.0f));
-      enc(base / (h * h * 1.0f * 1.0f));
-    }
+    q.guard_bits = (uint32_t)guard;
+    q.sqcd = (uint8_t)(guard << 5);
+    for (uint32_t v : e) q.q8.push_back((uint8_t)((v - guard) << 3));
+    return true;
   }
+  q.guard_bits = 1;
+  q.sqcd = (uint8_t)((1 << 5) | 0x2);
+  float base = p.qstep;
+  if (!(base > 0.0f)) {                                  // :1451-1455; a QCC made because the component differs
+    uint32_t t = std::min<uint32_t>(16, base_depth);     // inherits the QCD's base step (:1426)
+    base = 1.0f / (float)(1 << t);
+  }
+  float g_c = 1.0f, delta_ref = base, power = 1.0f;
+  const float* weights = vw_none;
+  if (qfactor) {                                         // :1553-1575
+    const CompGeo& g = plan.comps[comp];
+    const uint32_t fmt = (g.dx == 2 && g.dy == 2) ? VW_420 : (g.dx == 2 && g.dy == 1) ? VW_422 : (g.dx == 1 && g.dy == 1) ? VW_444 : VW_ERR;
+    if (fmt == VW_ERR) { err = "Qfactor can only be used on components with 4:4:4, 4:2:2 or 4:2:0 sampling"; return false; }
+    if (ctype == 0 && g.dx != 1 && g.dy != 1) { err = "Qfactor can only be used for a Y or luminance component when it is not downsampled."; return false; }
+    g_c = ctype == 0 ? 1.0f : ctype == 1 ? 1.8051f / 1.7321f : 1.5734f / 1.7321f;
+    // visual_weights::get_delta_ref (:690-722)
+    const float t0 = 65, t1 = 97, a0 = 0.04f, a1 = 0.10f;
+    const float m_t0 = 2.0f * (1.0f - t0 / 100.0f), m_t1 = 2.0f * (1.0f - t1 / 100.0f);
+    const float m_q = qfactor < 50 ? 50.0f / (float)qfactor : 2.0f * (1.0f - (float)qfactor / 100.0f);
+    float alpha_q;
+    if (qfactor <= 65) { power = 1.0f; alpha_q = a0; }
+    else if (qfactor < 97) {
+      power = std::log(m_q) - std::log(m_t1);
+      power /= std::log(m_t0) - std::log(m_t1);
+      alpha_q = a1 * std::pow(a0 / a1, power);
+    } else { power = 0.0f; alpha_q = a1; }
+    const float eps = std::sqrt(0.5f) * std::ldexp(1.0f, -(int)depth);
+    delta_ref = alpha_q * m_q + eps;
+    weights = ctype == 0 ? vw_y : ctype == 1 ? (fmt == VW_420 ? vw_cb420 : fmt == VW_422 ? vw_cb422 : vw_cb444)
+                                             : (fmt == VW_420 ? vw_cr420 : fmt == VW_422 ? vw_cr422 : vw_cr444);
+  }
+  auto enc = [&](float delta) {                          // encode_SPqcd :1602-1613
+    int exp = 0;
+    while (delta < 1.0f) { exp++; delta *= 2.0f; }
+    int mant = (int)std::round(delta * (float)(1 << 11)) - (1 << 11);
+    mant = mant < (1 << 11) ? mant : 0x7FF;
+    q.q16.push_back((uint16_t)((exp << 11) | mant));
+  };
+  float gl = energy97_l[D];
+  float w_b = std::pow(vw_get(weights, D, 0), power);
+  enc(delta_ref / (gl * gl * g_c * w_b));
+  for (uint32_t d = D; d > 0; --d) {
+    float l = energy97_l[d], h = energy97_h[d - 1];
+    w_b = std::pow(vw_get(weights, d, 1), power); enc(delta_ref / (h * l * g_c * w_b));
+    w_b = std::pow(vw_get(weights, d, 2), power); enc(delta_ref / (l * h * g_c * w_b));
+    w_b = std::pow(vw_get(weights, d, 3), power); enc(delta_ref / (h * h * g_c * w_b));
+  }
+  return true;
+}
+
+// param_qcd::check_validity (ojph_params.cpp:1359-1432): with a qfactor every component gets a QCC
+// (Y / Cb / Cr weights for the first three of >= 3 components, Y otherwise) and the QCD is made
+// from component 0; without, components whose bit depth or signedness differ from the QCD's get one
+bool derive_quant(Plan& plan)
+{
+  const ojphgpu_params& p = plan.p;
+  const uint32_t nc = p.num_comps, qf = p.reserved[2];
+  plan.qcc.assign(nc, QuantSet());
+  if (qf) for (uint32_t c = 0; c < nc; ++c) plan.qcc[c].present = true;
+  if (!make_quant(plan, 0, qf, 0, plan.qcd, plan.error, plan.comps[0].bit_depth)) return false;
+  for (uint32_t c = 0; c < nc; ++c) {
+    if (!plan.qcc[c].present) {
+      if (plan.comps[c].bit_depth == plan.comps[0].bit_depth && plan.comps[c].is_signed == plan.comps[0].is_signed) continue;   // is_qcc_needed (:1463-1475)
+      plan.qcc[c].present = true;
+    }
+    const uint32_t ctype = (qf && nc >= 3 && c < 3) ? c : 0;
+    if (!make_quant(plan, c, qf, ctype, plan.qcc[c], plan.error, plan.comps[0].bit_depth)) return false;
+  }
+  return true;
 }
 
 static inline uint32_t band_index(uint32_t res, uint32_t band) { return res ? (res - 1) * 3 + band : 0; }
 
-uint32_t band_Kmax(const Plan& plan, uint32_t res, uint32_t band)   // ojph_params.cpp:1715-1749
+uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)   // ojph_params.cpp:1715-1749
 {
+  const QuantSet& q = plan.quant(comp);
   uint32_t idx = band_index(res, band);
   if (plan.p.reversible) {
-    idx = std::min<uint32_t>(idx, (uint32_t)plan.spqcd8.size() - 1);
-    uint32_t nb = plan.spqcd8[idx] >> 3;
+    idx = std::min<uint32_t>(idx, (uint32_t)q.q8.size() - 1);
+    uint32_t nb = q.q8[idx] >> 3;
     nb = nb == 0 ? 0 : nb - 1;
-    return nb + plan.guard_bits;
+    return nb + q.guard_bits;
   }
-  idx = std::min<uint32_t>(idx, (uint32_t)plan.spqcd16.size() - 1);
-  return (uint32_t)(plan.spqcd16[idx] >> 11) - 1 + plan.guard_bits;
+  idx = std::min<uint32_t>(idx, (uint32_t)q.q16.size() - 1);
+  return (uint32_t)(q.q16[idx] >> 11) - 1 + q.guard_bits;
 }
 
-float band_delta(const Plan& plan, uint32_t res, uint32_t band)    // ojph_params.cpp:1650-1681
+float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)    // ojph_params.cpp:1650-1681
 {
   static const float arr[4] = { 1.0f, 2.0f, 2.0f, 4.0f };
-  uint32_t idx = std::min<uint32_t>(band_index(res, band), (uint32_t)plan.spqcd16.size() - 1);
-  int eps = plan.spqcd16[idx] >> 11;
-  float mantissa = (float)((plan.spqcd16[idx] & 0x7FF) | 0x800) * arr[band];
+  const QuantSet& q = plan.quant(comp);
+  uint32_t idx = std::min<uint32_t>(band_index(res, band), (uint32_t)q.q16.size() - 1);
+  int eps = q.q16[idx] >> 11;
+  float mantissa = (float)((q.q16[idx] & 0x7FF) | 0x800) * arr[band];
   mantissa /= (float)(1 << 11);
   mantissa /= (float)(1u << eps);
   return mantissa;
@@ -141,7 +218,8 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   if ((1u << lbw) != p.block_w || (1u << lbh) != p.block_h || lbw < 2 || lbh < 2 ||
       lbw > 10 || lbh > 10 || lbw + lbh > 12)
     return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
-  if (p.color_transform && p.num_comps != 3) return fail("colour transform needs exactly 3 components here");
+  if (p.color_transform && p.num_comps < 3)
+    return fail("color transform can only be employed when the image has 3 or more color components");   // ojph_params_local.h:450-453
   if (p.prog_order > 4) return fail("unknown progression order");
   // reference grid: image offset, tile offset, sub-sampling (ojph_params.cpp:88-150 check_validity)
   if ((uint64_t)p.image_x0 + p.width > 0xFFFFFFFFull || (uint64_t)p.image_y0 + p.height > 0xFFFFFFFFull)
@@ -166,15 +244,24 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     g.w = div_ceil(X1, g.dx) - g.x0; g.h = div_ceil(Y1, g.dy) - g.y0;             // param_siz::get_recon_width (:330-346)
     g.frame_off = plan.frame_elems;
     plan.frame_elems += (uint64_t)g.w * g.h;
+    g.bit_depth = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_depth[c] ? p.comp_depth[c] : p.bit_depth;
+    g.is_signed = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_sign[c] ? p.comp_sign[c] == 2 : p.is_signed != 0;
+    if (g.bit_depth < 1 || g.bit_depth > 26) return fail("bit depth unsupported (32-bit sample path only)");
   }
+  for (uint32_t c = 0; c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c) {                    // canonical form: 0 where the default applies
+    p.comp_depth[c] = c < p.num_comps && plan.comps[c].bit_depth != p.bit_depth ? (uint8_t)plan.comps[c].bit_depth : 0;
+    p.comp_sign[c] = c < p.num_comps && plan.comps[c].is_signed != (p.is_signed != 0) ? (plan.comps[c].is_signed ? 2 : 1) : 0;
+  }
+  if (p.reserved[2] > 100) return fail("Qfactor must be between 1 and 100");       // ojph_params.cpp:1487
   for (uint32_t c = 0; c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c) {                    // canonical form: 1 is stored as 1
     p.comp_dx[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dx : 0;
     p.comp_dy[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dy : 0;
   }
   if (p.color_transform)                                                           // ojph_codestream_local.cpp:586-597
     for (uint32_t c = 1; c < 3; ++c)
-      if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy)
-        return fail("the colour transform needs the first three components to have the same sub-sampling");
+      if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy ||
+          plan.comps[c].bit_depth != plan.comps[0].bit_depth || plan.comps[c].is_signed != plan.comps[0].is_signed)
+        return fail("the colour transform needs the first three components to have the same sub-sampling, bit depth and signedness");   // ojph_params_local.h:455-490
   (void)subsampled;
   uint32_t lpw = 15, lph = 15;
   if (p.precinct_w && p.precinct_h) {
@@ -203,7 +290,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     if (plan.parts_per_tile > 255) return fail("a tile cannot have more than 255 tile parts");
   }
   plan.p = p;
-  derive_quant(plan);
+  if (!derive_quant(plan)) return OJPHGPU_E_INVALID;
 
   plan.ntx = div_ceil(X1 - p.tile_x0, p.tile_w);                                   // ojph_codestream_local.cpp:113-123
   plan.nty = div_ceil(Y1 - p.tile_y0, p.tile_h);
@@ -258,10 +345,10 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
               B.r.w = ((trx1 - (b & 1) + 1) >> 1) - B.r.x0;
               B.r.h = ((try1 - (b >> 1) + 1) >> 1) - B.r.y0;
             } else B.r = R.r;
-            B.K_max = band_Kmax(plan, r, b);
+            B.K_max = band_Kmax(plan, c, r, b);
             B.delta = 0.0f; B.delta_inv = 0.0f;
             if (!p.reversible) {                                   // ojph_subband.cpp:156-164
-              float d = band_delta(plan, r, b);
+              float d = band_delta(plan, c, r, b);
               d /= (float)(1u << (31 - B.K_max));
               B.delta = d; B.delta_inv = 1.0f / d;
             }
@@ -536,6 +623,14 @@ extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, 
     if (pitch) *pitch = R.pitch;
   }
   if (rect) { rect[0] = R.r.x0; rect[1] = R.r.y0; rect[2] = R.r.w; rect[3] = R.r.h; }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp, uint32_t* bit_depth, uint32_t* is_signed)
+{
+  if (!plan || comp >= plan->plan.p.num_comps) return OJPHGPU_E_INVALID;
+  if (bit_depth) *bit_depth = plan->plan.comps[comp].bit_depth;
+  if (is_signed) *is_signed = plan->plan.comps[comp].is_signed ? 1 : 0;
   return OJPHGPU_OK;
 }
 

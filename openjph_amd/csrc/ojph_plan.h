@@ -78,6 +78,14 @@ struct CompGeo {                // one image component on its own (sub-sampled) 
   uint32_t dx, dy;              // sub-sampling factors (XRsiz, YRsiz)
   uint32_t x0, y0, w, h;        // ceil(image offset / d) and the size up to ceil(image extent / d)
   uint64_t frame_off;           // element offset of the component's plane in a frame (image buffer)
+  uint32_t bit_depth; bool is_signed;
+};
+
+struct QuantSet {               // contents of a QCD / QCC marker segment (ojph_params_local.h:690-830)
+  uint8_t sqcd = 0; uint32_t guard_bits = 0;
+  std::vector<uint8_t> q8;      // reversible: exponent bytes as written
+  std::vector<uint16_t> q16;    // irreversible: exponent << 11 | mantissa
+  bool present = false;         // QCC: the component has its own marker segment
 };
 
 struct Plan {
@@ -94,10 +102,9 @@ struct Plan {
   struct Comment { uint16_t rcom; std::vector<uint8_t> data; };
   std::vector<Comment> comments;   // user COM segments of the main header
   uint32_t ntx, nty;
-  uint32_t guard_bits;
-  std::vector<uint8_t> spqcd8;   // reversible: exponent bytes as written in QCD
-  std::vector<uint16_t> spqcd16; // irreversible
-  uint8_t sqcd;
+  QuantSet qcd;                  // the main header's QCD
+  std::vector<QuantSet> qcc;     // per component; .present = the component has a QCC of its own
+  const QuantSet& quant(uint32_t comp) const { return comp < qcc.size() && qcc[comp].present ? qcc[comp] : qcd; }
   std::vector<Tile> tiles;
   std::vector<TileComp> tcomps;
   std::vector<Resolution> ress;
@@ -113,10 +120,11 @@ struct Plan {
 
 // builds everything from p (p.tile_w/h == 0 -> single tile). Returns 0 or OJPHGPU_E_INVALID.
 int build_plan(const ojphgpu_params& p, Plan& plan);
-// derives QCD contents (ojph_params.cpp:1495-1613)
-void derive_quant(Plan& plan);
-uint32_t band_Kmax(const Plan& plan, uint32_t res, uint32_t band);
-float band_delta(const Plan& plan, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
+// derives the QCD / QCC contents (ojph_params.cpp:1359-1613); false + plan.error when the
+// parameters cannot be quantised (qfactor on an unsupported sampling format)
+bool derive_quant(Plan& plan);
+uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);
+float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
 // worst-case coded size of a block of w*h samples with K_max magnitude bits
 uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max);
 

@@ -83,19 +83,23 @@ void write_main_header(const Plan& P, ByteSink& s)
   s.u32(p.tile_w); s.u32(p.tile_h); s.u32(p.tile_x0); s.u32(p.tile_y0);
   s.u16(p.num_comps);
   for (uint32_t c = 0; c < p.num_comps; ++c) {
-    s.u8((p.bit_depth - 1) | (p.is_signed ? 0x80 : 0)); s.u8((uint8_t)P.comps[c].dx); s.u8((uint8_t)P.comps[c].dy);
+    s.u8((P.comps[c].bit_depth - 1) | (P.comps[c].is_signed ? 0x80 : 0)); s.u8((uint8_t)P.comps[c].dx); s.u8((uint8_t)P.comps[c].dy);
   }
   // CAP (ojph_params.cpp:968-989, Ccap from ojph_params_local.h:929-945 + get_MAGB :1615-1647)
   uint32_t B = 0;
-  if (p.reversible) {
-    for (uint8_t e : P.spqcd8) B = std::max<uint32_t>(B, (uint32_t)(e >> 3) + P.guard_bits - 1);
-  } else {
-    uint32_t D = p.num_decomps;
-    for (size_t i = 0; i < P.spqcd16.size(); ++i) {
-      uint32_t nb = D - (i ? (uint32_t)(i - 1) / 3 : 0);
-      B = std::max<uint32_t>(B, (uint32_t)(P.spqcd16[i] >> 11) + P.guard_bits - nb);
+  auto magb = [&](const QuantSet& q) {              // param_qcd::get_MAGB walks the QCD and every QCC
+    if (p.reversible) {
+      for (uint8_t e : q.q8) B = std::max<uint32_t>(B, (uint32_t)(e >> 3) + q.guard_bits - 1);
+    } else {
+      uint32_t D = p.num_decomps;
+      for (size_t i = 0; i < q.q16.size(); ++i) {
+        uint32_t nb = D - (i ? (uint32_t)(i - 1) / 3 : 0);
+        B = std::max<uint32_t>(B, (uint32_t)(q.q16[i] >> 11) + q.guard_bits - nb);
+      }
     }
-  }
+  };
+  magb(P.qcd);
+  for (const QuantSet& q : P.qcc) if (q.present) magb(q);
   uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : 13 + (B >> 2));
   uint32_t Ccap = (p.reversible ? 0u : 0x0020u) | Bp;
   s.u16(CAP); s.u16(8); s.u32(0x00020000); s.u16(Ccap);
@@ -115,8 +119,18 @@ void write_main_header(const Plan& P, ByteSink& s)
   // QCD (ojph_params.cpp:1778-1819)
   uint32_t nb = 1 + 3 * p.num_decomps;
   s.u16(QCD);
-  if (p.reversible) { s.u16(3 + nb); s.u8(P.sqcd); for (uint8_t e : P.spqcd8) s.u8(e); }
-  else { s.u16(3 + 2 * nb); s.u8(P.sqcd); for (uint16_t e : P.spqcd16) s.u16(e); }
+  if (p.reversible) { s.u16(3 + nb); s.u8(P.qcd.sqcd); for (uint8_t e : P.qcd.q8) s.u8(e); }
+  else { s.u16(3 + 2 * nb); s.u8(P.qcd.sqcd); for (uint16_t e : P.qcd.q16) s.u16(e); }
+  // QCC of the components that have one (ojph_params.cpp:1822-1887), in component order
+  for (uint32_t c = 0; c < p.num_comps; ++c) {
+    const QuantSet& q = P.qcc[c];
+    if (!q.present) continue;
+    const uint32_t cw = p.num_comps < 257 ? 1 : 2;
+    s.u16(QCC); s.u16(3 + cw + (p.reversible ? nb : 2 * nb));
+    if (cw == 1) s.u8(c); else s.u16(c);
+    s.u8(q.sqcd);
+    if (p.reversible) for (uint8_t e : q.q8) s.u8(e); else for (uint16_t e : q.q16) s.u16(e);
+  }
   // COM: the reference identifies itself; byte-identical output needs the same string
   // (ojph_codestream_local.cpp:678-696)
   static const char ver[] = "OpenJPH Ver 0.31.0.";
@@ -566,6 +580,8 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   ojphgpu_params p; memset(&p, 0, sizeof(p));
   bool have_siz = false, have_cod = false, have_qcd = false;
   uint8_t scod = 0, sqcd = 0; std::vector<uint8_t> q8; std::vector<uint16_t> q16;
+  struct Qcc { uint32_t comp; QuantSet q; };
+  std::vector<Qcc> qccs;
   bool use_sop = false, use_eph = false;
   for (;;) {
     if (!r.ok(4)) return OJPHGPU_E_CODESTREAM;
@@ -592,7 +608,10 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
         if ((xr != 1 || yr != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return OJPHGPU_E_INVALID;
         if (c < OJPHGPU_MAX_SUBSAMPLED_COMPS) { p.comp_dx[c] = (uint8_t)xr; p.comp_dy[c] = (uint8_t)yr; }
         if (c == 0) { p.bit_depth = bd; p.is_signed = sg; }
-        else if (bd != p.bit_depth || sg != p.is_signed) return OJPHGPU_E_INVALID;
+        else if (bd != p.bit_depth || sg != p.is_signed) {
+          if (c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return OJPHGPU_E_INVALID;      // per-component formats: first 16 components
+          p.comp_depth[c] = (uint8_t)bd; p.comp_sign[c] = sg ? 2 : 1;
+        }
       }
       have_siz = true;
     } else if (m == COD) {
@@ -626,9 +645,21 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
       else if ((sqcd & 0x1F) == 2) for (uint32_t i = 0; i < n / 2; ++i) q16.push_back((uint16_t)r.u16());
       else return OJPHGPU_E_INVALID;                              // scalar derived: not supported
       have_qcd = true;
+    } else if (m == QCC) {                                         // ojph_params.cpp:1950-2018
+      if (!have_siz) return OJPHGPU_E_CODESTREAM;
+      const uint32_t cw = p.num_comps < 257 ? 1 : 2;
+      if (L < 3 + cw) return OJPHGPU_E_CODESTREAM;
+      Qcc k; k.comp = cw == 1 ? r.u8() : r.u16();
+      k.q.sqcd = (uint8_t)r.u8(); k.q.guard_bits = k.q.sqcd >> 5; k.q.present = true;
+      uint32_t n = L - 3 - cw;
+      if ((k.q.sqcd & 0x1F) == 0) for (uint32_t i = 0; i < n; ++i) k.q.q8.push_back((uint8_t)r.u8());
+      else if ((k.q.sqcd & 0x1F) == 2) for (uint32_t i = 0; i < n / 2; ++i) k.q.q16.push_back((uint16_t)r.u16());
+      else return OJPHGPU_E_INVALID;
+      if (n == 0 || k.comp >= p.num_comps) return OJPHGPU_E_CODESTREAM;
+      qccs.push_back(k);
     } else if (m == TLM) {
       p.tlm = 1;
-    } else if (m == COC || m == QCC || m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
+    } else if (m == COC || m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
       return OJPHGPU_E_INVALID;                                    // per-component / Part-2 markers: later
     }
     r.pos = next;
@@ -640,13 +671,19 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   if (rc != OJPHGPU_OK) { delete h; return rc; }
   Plan& P = h->plan;
   // the codestream's own quantisation parameters override the derived ones
-  P.sqcd = sqcd; P.guard_bits = sqcd >> 5;
-  if (p.reversible) { if ((sqcd & 0x1F) != 0 || q8.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.spqcd8 = q8; }
-  else { if ((sqcd & 0x1F) != 2 || q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.spqcd16 = q16; }
+  P.qcd.sqcd = sqcd; P.qcd.guard_bits = sqcd >> 5;
+  P.qcd.q8.clear(); P.qcd.q16.clear();
+  if (p.reversible) { if ((sqcd & 0x1F) != 0 || q8.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.qcd.q8 = q8; }
+  else { if ((sqcd & 0x1F) != 2 || q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.qcd.q16 = q16; }
+  P.qcc.assign(p.num_comps, QuantSet());                       // only the markers of the codestream count
+  for (const Qcc& k : qccs) {
+    if ((k.q.sqcd & 0x1F) != (p.reversible ? 0u : 2u)) { delete h; return OJPHGPU_E_CODESTREAM; }
+    P.qcc[k.comp] = k.q;
+  }
   for (Band& B : P.bands) {
-    B.K_max = band_Kmax(P, B.res, B.band);
+    B.K_max = band_Kmax(P, B.comp, B.res, B.band);
     if (!p.reversible) {
-      float dlt = band_delta(P, B.res, B.band);
+      float dlt = band_delta(P, B.comp, B.res, B.band);
       dlt /= (float)(1u << (31 - B.K_max));
       B.delta = dlt; B.delta_inv = 1.0f / dlt;
     }

@@ -119,6 +119,7 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
     const Rect& rr = P.ress[tc.res[L]].r;                   // the tile-component at the reconstructed resolution
     d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
     d.src_pitch = g.w;
+    d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
     out.push_back(d);
   }
 }
@@ -137,7 +138,7 @@ void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
       const CompGeo& g = P.comps[c];
       d.w = R.r.w; d.h = R.r.h; d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
-      d.img_pitch = g.w; d.img_off = g.frame_off;
+      d.img_pitch = g.w; d.img_off = g.frame_off; d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u);
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }

@@ -14,10 +14,12 @@ coded_dtype = np.dtype(CodedBlock)
 def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
-                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts=""):
+                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts="", bit_depths=None, signs=None,
+                qfactor=0):
     """width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
     (dx, dy) per component (param_siz::set_component), default 1,1; tileparts: "", "R", "C" or "RC"
-    (codestream::set_tilepart_divisions)."""
+    (codestream::set_tilepart_divisions); bit_depths / signs: per-component lists where they differ
+    from bit_depth / is_signed; qfactor: 1..100 (param_qcd::set_qfactor), 0 = not set."""
     p = Params()
     p.width, p.height, p.num_comps = width, height, num_comps
     p.bit_depth, p.is_signed = bit_depth, int(is_signed)
@@ -34,6 +36,11 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
             p.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
     p.tlm = int(tlm)
     p.reserved[1] = (1 if "R" in tileparts else 0) | (2 if "C" in tileparts else 0)
+    p.reserved[2] = int(qfactor)
+    for c, bd in enumerate(bit_depths or []):
+        p.comp_depth[c] = int(bd)
+    for c, sg in enumerate(signs or []):
+        p.comp_sign[c] = 2 if sg else 1
     p.image_x0, p.image_y0 = image_offset
     p.tile_x0, p.tile_y0 = tile_offset
     if downsampling:
@@ -105,6 +112,12 @@ class Plan:
         check(self._lib.ojphgpu_plan_comp_info(self.handle, comp, out))
         v = [int(x) for x in out]
         return dict(x0=v[0], y0=v[1], w=v[2], h=v[3], frame_off=v[4] | (v[5] << 32), dx=v[6], dy=v[7])
+
+    def comp_format(self, comp):
+        """-> (bit depth, is_signed) of component `comp`"""
+        bd, sg = C.c_uint32(), C.c_uint32()
+        check(self._lib.ojphgpu_plan_comp_format(self.handle, comp, C.byref(bd), C.byref(sg)))
+        return int(bd.value), bool(sg.value)
 
     @property
     def frame_elems(self):

@@ -51,6 +51,8 @@ struct ref_params {
   uint32_t tile_x0, tile_y0;     // tile offset
   uint8_t  comp_dx[16], comp_dy[16];   // sub-sampling of component c < 16; 0 => 1
   uint32_t tilepart_div;         // bit 0: tile-parts at resolutions, bit 1: at components
+  uint8_t  comp_depth[16], comp_sign[16];   // per component where it differs: depth (0 = bit_depth), 1 unsigned / 2 signed (0 = is_signed)
+  uint32_t qfactor;              // 0 = not set
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -86,7 +88,9 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
     siz.set_num_components(p->num_comps);
     for (uint32_t c = 0; c < p->num_comps; ++c) {
       ojph::point ds(c < 16 && p->comp_dx[c] ? p->comp_dx[c] : 1, c < 16 && p->comp_dy[c] ? p->comp_dy[c] : 1);
-      siz.set_component(c, ds, p->bit_depth, p->is_signed != 0);
+      const uint32_t bd = c < 16 && p->comp_depth[c] ? p->comp_depth[c] : p->bit_depth;
+      const bool sg = c < 16 && p->comp_sign[c] ? p->comp_sign[c] == 2 : p->is_signed != 0;
+      siz.set_component(c, ds, bd, sg);
     }
     siz.set_image_offset(ojph::point(p->image_x0, p->image_y0));
     siz.set_tile_offset(ojph::point(p->tile_x0, p->tile_y0));
@@ -111,6 +115,7 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
     }
     if (!p->reversible && p->qstep > 0.0f)
       cs.access_qcd().set_irrev_quant(p->qstep);
+    if (p->qfactor) cs.access_qcd().set_qfactor((ojph::ui8)p->qfactor);
     cs.set_planar(p->planar != 0);
     if (p->tlm) cs.request_tlm_marker(true);
     if (p->tilepart_div) cs.set_tilepart_divisions((p->tilepart_div & 1) != 0, (p->tilepart_div & 2) != 0);

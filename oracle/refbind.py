@@ -28,6 +28,7 @@ class RefParams(C.Structure):
         ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
         ("tilepart_div", C.c_uint32),
+        ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16), ("qfactor", C.c_uint32),
     ]
 
 
@@ -74,7 +75,7 @@ class Ref:
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
                planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None, tileparts="",
-               profile=None, com=None):
+               profile=None, com=None, bit_depths=None, signs=None, qfactor=0):
         """planes: int32 array [num_comps, H, W], or a list of per-component 2-D arrays when the
         components are sub-sampled (then size=(W, H) is the image size on the reference grid).
         Returns codestream bytes."""
@@ -99,6 +100,11 @@ class Ref:
         p.image_x0, p.image_y0 = image_offset
         p.tile_x0, p.tile_y0 = tile_offset
         p.tilepart_div = (1 if "R" in tileparts else 0) | (2 if "C" in tileparts else 0)
+        for c, bd in enumerate(bit_depths or []):
+            p.comp_depth[c] = bd
+        for c, sg in enumerate(signs or []):
+            p.comp_sign[c] = 2 if sg else 1
+        p.qfactor = int(qfactor)
         for c, (dx, dy) in enumerate(downsampling or []):
             p.comp_dx[c], p.comp_dy[c] = dx, dy
         ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])

@@ -32,12 +32,13 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]           # position inside the component's own plane
             src = np.ascontiguousarray(image[c][y0:y0 + h, x0:x0 + w], dtype=np.int32)
+            bd, sg = plan.comp_format(c)
             if rev:
-                shift = 0 if p.is_signed else -(1 << (p.bit_depth - 1))
+                shift = 0 if sg else -(1 << (bd - 1))
                 dst = src + shift
             else:
                 dst = np.empty(src.shape, np.float32)
-                lib.ojo_irv_to_float(src.ctypes.data, dst.ctypes.data, src.size, p.bit_depth, int(p.is_signed))
+                lib.ojo_irv_to_float(src.ctypes.data, dst.ctypes.data, src.size, bd, int(sg))
             planes.append((off, pitch, w, h, dst))
         if p.color_transform:
             r, g, b = [np.ascontiguousarray(pl[4]) for pl in planes[:3]]
@@ -208,11 +209,12 @@ def inverse_stages(plan: Plan, arena):
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
             v = planes[c]
+            bd, sg = plan.comp_format(c)
             if rev:
-                out = v + (0 if p.is_signed else (1 << (p.bit_depth - 1)))
+                out = v + (0 if sg else (1 << (bd - 1)))
             else:
                 out = np.empty(v.shape, np.int32)
-                lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, p.bit_depth, int(p.is_signed))
+                lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, bd, int(sg))
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]
             image[c][y0:y0 + h, x0:x0 + w] = out
     return np.stack(image) if len(plan.frame_shape) == 3 else image

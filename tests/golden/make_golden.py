@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
 from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, TILEPART_CASES,  # noqa: E402
-                                stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case)
+                                FORMAT_CASES, stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case, format_case)
 
 
 def sha(b):
@@ -90,6 +90,18 @@ def main():
         r = ref if kw.get("reversible", True) else refgen
         cs = r.encode(img, **kw)
         out["tileparts"].append({"case": i, "len": len(cs), "sha256": sha(cs)})
+    # (b5) per-component bit depth / signedness (QCC) and qfactor
+    out["formats"] = []
+    for i in range(len(FORMAT_CASES)):
+        planes, kw, size = format_case(i)
+        kw = dict(kw)
+        bd, sg = kw.pop("bit_depth"), kw.pop("is_signed")
+        r = ref if kw.get("reversible", True) else refgen
+        cs = r.encode(planes, bd, is_signed=sg, size=size, **kw)
+        dec, _ = r.decode(cs)
+        dec = [dec[c] for c in range(len(planes))]
+        out["formats"].append({"case": i, "len": len(cs), "sha256": sha(cs),
+                               "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
     # (b3) reduced-resolution decoding
     out["skip"] = []
     for i in range(len(SKIP_CASES)):

@@ -60,6 +60,37 @@ GRID_CASES = [
 ]
 
 
+# components of different bit depth / signedness (QCC marker segments) and the qfactor mode
+# (visually weighted steps, a QCC for every component): w, h, sub-sampling, depths, signs, kwargs
+FORMAT_CASES = [
+    dict(w=120, h=90, ds=[(1, 1)] * 3, depths=[8, 10, 12], signs=[False, False, True], kw=dict(num_decomps=3)),
+    dict(w=120, h=90, ds=[(1, 1)] * 2, depths=[12, 8], signs=[False, True], kw=dict(reversible=False, num_decomps=4)),
+    dict(w=100, h=80, ds=[(1, 1)] * 4, depths=[8, 8, 8, 16], signs=[False] * 4, kw=dict(tile=(64, 64), prog_order="CPRL", color_transform=True)),
+    dict(w=128, h=96, ds=[(1, 1), (2, 2), (2, 2)], depths=[8, 8, 8], signs=[False] * 3, kw=dict(reversible=False, qfactor=50)),
+    dict(w=128, h=96, ds=[(1, 1), (2, 1), (2, 1)], depths=[10, 10, 10], signs=[False] * 3, kw=dict(reversible=False, qfactor=85, num_decomps=6)),
+    dict(w=200, h=150, ds=[(1, 1)] * 3, depths=[8, 8, 8], signs=[False] * 3, kw=dict(reversible=False, qfactor=30, color_transform=True)),
+    dict(w=100, h=80, ds=[(1, 1)], depths=[12], signs=[False], kw=dict(reversible=False, qfactor=99)),
+    dict(w=100, h=80, ds=[(1, 1)] * 3, depths=[8, 8, 8], signs=[False] * 3, kw=dict(qfactor=70, color_transform=True)),
+    dict(w=90, h=70, ds=[(1, 1)] * 3, depths=[8, 16, 10], signs=[False, True, False], kw=dict(reversible=False, qstep=0.01, tile=(50, 50))),
+]
+
+
+def format_case(i, seed=8):
+    """-> (planes, kwargs for plan.make_params / refbind.Ref.encode (bit_depth / is_signed = component 0's), (W, H))"""
+    import numpy as np
+    c = FORMAT_CASES[i]
+    rng = np.random.default_rng(seed + i)
+    planes = []
+    for (dx, dy), bd, sg in zip(c["ds"], c["depths"], c["signs"]):
+        cw, ch = -(-c["w"] // dx), -(-c["h"] // dy)
+        lo, hi = (-(1 << (bd - 1)), 1 << (bd - 1)) if sg else (0, 1 << bd)
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        base = ((np.sin(xx / 9.0) + np.cos(yy / 7.0)) * 0.2 + 0.5) * (hi - lo) + lo
+        planes.append(np.clip(base + rng.integers(-3, 4, (ch, cw)), lo, hi - 1).astype(np.int32))
+    kw = dict(c["kw"], bit_depth=c["depths"][0], is_signed=c["signs"][0], downsampling=c["ds"], bit_depths=c["depths"], signs=c["signs"])
+    return planes, kw, (c["w"], c["h"])
+
+
 # tile-part divisions (codestream::set_tilepart_divisions) on a 3-component 150x200 image:
 # (progression order, divisions, further kwargs)
 TILEPART_CASES = [

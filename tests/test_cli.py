@@ -218,3 +218,35 @@ def test_cli_tileparts_com_and_broadcast_profile(tmp_path):
     assert open(tmp_path / "v.j2c", "rb").read() == want
     r = run(args[:-4] + ["-prog_order", "RPCL", "-precincts", "{128,128},{256,256}"])        # the profile wants CPRL
     assert r.returncode != 0 and b"CPRL" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_qfactor_and_mixed_bit_depths(tmp_path):
+    """-qfactor 50 on the 4:2:0 CIF frame (tests/test_executables.cpp:1648-1665) and a raw file whose
+    components differ in bit depth and signedness (QCC marker segments)"""
+    from tests import cpu_pipeline as cp
+    from tests.golden_cases import GRID_CASES, grid_kwargs, format_case
+    planes, kw, size = grid_kwargs(GRID_CASES[0])
+    with open(tmp_path / "f.yuv", "wb") as f:
+        for q in planes:
+            f.write(q.astype("u1").tobytes())
+    r = run([COMPRESS, "-i", str(tmp_path / "f.yuv"), "-o", str(tmp_path / "f.j2c"), "-qfactor", "50", "-dims", "{352,288}",
+             "-num_comps", "3", "-downsamp", "{1,1},{2,2},{2,2}", "-bit_depth", "8,8,8", "-signed", "false,false,false"])
+    assert r.returncode == 0, r.stdout
+    want, *_ = cp.encode(planes, size=size, bit_depth=8, downsampling=[(1, 1), (2, 2), (2, 2)], reversible=False, qfactor=50)
+    assert open(tmp_path / "f.j2c", "rb").read() == want
+    r = run([COMPRESS, "-i", str(tmp_path / "f.yuv"), "-o", str(tmp_path / "f.j2c"), "-qfactor", "50", "-qstep", "0.1", "-dims", "{352,288}",
+             "-num_comps", "3", "-bit_depth", "8"])
+    assert r.returncode != 0
+
+    planes, kw, size = format_case(0)                                   # 8-bit, 10-bit, signed 12-bit
+    with open(tmp_path / "m.raw", "wb") as f:
+        f.write(planes[0].astype("u1").tobytes()); f.write(planes[1].astype("<u2").tobytes()); f.write(planes[2].astype("<i2").tobytes())
+    r = run([COMPRESS, "-i", str(tmp_path / "m.raw"), "-o", str(tmp_path / "m.j2c"), "-reversible", "true", "-num_decomps", "3",
+             "-dims", "{120,90}", "-num_comps", "3", "-bit_depth", "8,10,12", "-signed", "false,false,true"])
+    assert r.returncode == 0, r.stdout
+    want, *_ = cp.encode(planes, size=size, **kw)
+    assert open(tmp_path / "m.j2c", "rb").read() == want
+    r = run([EXPAND, "-i", str(tmp_path / "m.j2c"), "-o", str(tmp_path / "m_back.raw")])
+    assert r.returncode == 0, r.stdout
+    assert open(tmp_path / "m_back.raw", "rb").read() == open(tmp_path / "m.raw", "rb").read()

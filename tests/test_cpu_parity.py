@@ -18,8 +18,8 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES, grid_kwargs,
-                                refine_case, skip_case, stream_kwargs, tilepart_case)
+from tests.golden_cases import (BLOCK_CASES, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
+                                format_case, grid_kwargs, refine_case, skip_case, stream_kwargs, tilepart_case)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -393,6 +393,37 @@ def test_tileparts_comments_profile_match_live_reference(ref):
     assert plan.t2_write(data, coded) == ref.encode(img, 8, com="a comment")
     with pytest.raises(capi.OjphError):                      # 40 components x 7 resolutions > 255 tile-parts
         Plan(make_params(64, 64, 40, num_decomps=6, prog_order="LRCP", tileparts="RC"))
+
+
+@pytest.mark.parametrize("i", range(len(FORMAT_CASES)), ids=lambda i: "fmt%d" % i)
+def test_component_formats_and_qfactor_match_golden(i):
+    """components of different bit depth / signedness get their own QCC (ojph_params.cpp:1411-1432);
+    the qfactor mode derives visually weighted steps and a QCC for every component (:1378-1407,
+    :1553-1599).  Marker segments, K_max / step sizes and the per-component level shift are all
+    pinned here against the reference's codestreams."""
+    from tests import cpu_pipeline as cp
+    planes, kw, size = format_case(i)
+    g = GOLD["formats"][i]
+    cs, plan, *_ = cp.encode(planes, size=size, **kw)
+    assert len(cs) == g["len"] and sha(cs) == g["sha256"]
+    dec, _ = cp.decode(cs)
+    dec = _as_list(dec, len(planes))
+    assert sha(_planes_bytes(dec)) == g["dec_sha256"]
+    if kw.get("reversible", True):
+        assert all(np.array_equal(a, b) for a, b in zip(dec, planes))
+
+
+def test_qfactor_validation():
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 1, reversible=False, qfactor=101))
+    with pytest.raises(capi.OjphError):                     # 4:1:1-like sampling has no weight table
+        Plan(make_params(64, 64, 3, reversible=False, qfactor=50, downsampling=[(1, 1), (4, 1), (4, 1)]))
+    with pytest.raises(capi.OjphError):                     # the colour transform needs one sample format
+        Plan(make_params(64, 64, 3, color_transform=True, bit_depths=[8, 10, 8]))
+    pl = Plan(make_params(64, 64, 3, bit_depths=[8, 12, 8], signs=[False, True, False]))
+    assert [pl.comp_format(c) for c in range(3)] == [(8, False), (12, True), (8, False)]
 
 
 def test_grid_parameter_validation():
