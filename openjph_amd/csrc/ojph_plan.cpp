@@ -257,6 +257,10 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     p.comp_dx[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dx : 0;
     p.comp_dy[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dy : 0;
   }
+  if (p.prog_order == 2 || p.prog_order == 3)                                      // ojph_params_local.h:488-499
+    for (const CompGeo& g : plan.comps)
+      if ((g.dx & (g.dx - 1)) || (g.dy & (g.dy - 1)))
+        return fail("For RPCL and PCRL progression orders, component downsampling factors have to be powers of 2");
   if (p.color_transform)                                                           // ojph_codestream_local.cpp:586-597
     for (uint32_t c = 1; c < 3; ++c)
       if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy ||

@@ -81,7 +81,7 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
                    const char* profile, const char* com)
 {
   try {
-    ojph::set_message_level(ojph::OJPH_MSG_NO_MSG);
+    ojph::set_message_level(getenv("REF_SHIM_VERBOSE") ? ojph::OJPH_MSG_ALL_MSG : ojph::OJPH_MSG_NO_MSG);
     ojph::codestream cs;
     ojph::param_siz siz = cs.access_siz();
     siz.set_image_extent(ojph::point(p->image_x0 + p->width, p->image_y0 + p->height));
@@ -133,6 +133,9 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
     for (uint32_t c = 0; c < p->num_comps; ++c) {
       cw[c] = siz.get_recon_width(c); ch[c] = siz.get_recon_height(c); lines += ch[c];
     }
+    // (interleaved exchange asks for every component on every line of component 0,
+    // ojph_codestream_local.cpp:1208-1219; with components of different height the library would be
+    // handed a row it cannot place and spin in exchange() -- such a request is refused here)
     ojph::ui32 next_comp = 0;
     ojph::line_buf* line = cs.exchange(NULL, next_comp);
     for (uint64_t i = 0; i < lines; ++i) {

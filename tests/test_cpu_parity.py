@@ -481,3 +481,37 @@ def test_plan_geometry_block_counts():
     p = Plan(make_params(4096, 2048, 1, bit_depth=16, tile=(1024, 1024)))
     assert p.num_tiles == 8 and p.num_blocks == 8 * 259
     assert Plan(make_params(256, 256, 1, bit_depth=8)).num_blocks == 25
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_random_parameter_sets_match_live_reference(chunk, ref, refgen):
+    """120 seeded random parameter sets (tests/random_cases.py): the oracle pipeline + plan + Tier-2
+    emit the reference's bytes, decode to the reference's samples, and reject what it rejects"""
+    from openjph_amd import capi
+    from tests import cpu_pipeline as cp
+    from tests.random_cases import random_case
+    compared = 0
+    for seed in range(chunk * 20, chunk * 20 + 20):
+        planes, kw, size = random_case(seed)
+        if any(q.size == 0 for q in planes):
+            continue
+        lib = ref if kw["reversible"] else refgen
+        k2 = dict(kw)
+        bd, sg = k2.pop("bit_depth"), k2.pop("is_signed")
+        try:
+            want = lib.encode(planes, bd, is_signed=sg, size=size, **k2)
+        except RuntimeError:
+            want = None
+        try:
+            got, *_ = cp.encode(planes, size=size, **kw)
+        except capi.OjphError:
+            got = None
+        assert (want is None) == (got is None), "seed %d: %s" % (seed, kw)
+        if want is None:
+            continue
+        assert got == want, "seed %d: %s" % (seed, kw)
+        dec, _ = cp.decode(want)
+        rdec, _ = lib.decode(want)
+        assert all(np.array_equal(dec[c], rdec[c]) for c in range(len(planes))), "seed %d" % seed
+        compared += 1
+    assert compared >= 12

@@ -126,6 +126,35 @@ def test_component_formats_and_qfactor_on_gpu(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_parameter_sets_on_gpu(chunk):
+    """the seeded random parameter sets of tests/random_cases.py (odd sizes, offsets, sub-sampling,
+    mixed formats, every progression order, tile-parts): GPU codec == oracle pipeline, byte for byte
+    and sample for sample"""
+    from openjph_amd import capi, codec
+    from openjph_amd.plan import make_params
+    from tests import cpu_pipeline as cp
+    from tests.random_cases import random_case
+    done = 0
+    for seed in range(chunk * 30, chunk * 30 + 30):
+        planes, kw, size = random_case(seed)
+        if any(q.size == 0 for q in planes):
+            continue
+        try:
+            want, plan, *_ = cp.encode(planes, size=size, **kw)
+        except capi.OjphError:
+            continue                                      # a parameter set the reference rejects, too
+        got = codec.Encoder(make_params(size[0], size[1], len(planes), **kw)).encode(planes)
+        assert got == want, "seed %d: %s" % (seed, kw)
+        dec = codec.Decoder(want)
+        out = dec.plan.unpack_frame(dec.decode())
+        wdec, _ = cp.decode(want)
+        for c in range(len(planes)):
+            assert np.array_equal(out[c], wdec[c]), "seed %d component %d: %s" % (seed, c, kw)
+        done += 1
+    assert done >= 20
+
+
 def test_truncated_codestream_decodes_like_oracle():
     """tests/test_truncated_decode.cpp on the GPU decoder: a full frame from whatever was received
     when resilient, an error for a cut the parser detects when not"""
