@@ -12,12 +12,17 @@ int main(int argc, char** argv) {
   if (!in || !out) { printf("ojph_expand (GPU path) -i in.j2c -o out.{pgm,ppm,yuv,raw} [-skip_res n] [-resilient true] [-device n]\n"); return -1; }
   try {
     const auto t0 = std::chrono::steady_clock::now();
+    const bool verbose = getenv("OJPH_APP_TIMING") != nullptr;       // phase times on stderr
+    auto lap = [&](const char* what) {
+      if (verbose) fprintf(stderr, "ojph_expand: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     ojph::codestream cs;
     if (a.get("-device")) cs.set_device(atoi(a.get("-device")));
     if (Args::to_bool(a.get("-resilient"))) cs.enable_resilience();
     ojph::j2c_infile file;
     file.open(in);
     cs.read_headers(&file);
+    lap("file read + headers parsed");
     auto sk = Args::numbers(a.get("-skip_res"));
     if (!sk.empty()) cs.restrict_input_resolution((ojph::ui32)sk[0], (ojph::ui32)(sk.size() > 1 ? sk[1] : sk[0]));
     ojph::param_siz siz = cs.access_siz();
@@ -38,17 +43,21 @@ int main(int argc, char** argv) {
     if (!pnm && !ends_with(outs, ".yuv") && !ends_with(outs, ".raw")) throw std::runtime_error("unknown output file extension (pgm, ppm, yuv, raw)");
     cs.set_planar(!pnm || img.num_comps == 1);
     cs.create();
+    lap("decoder created");
     std::vector<unsigned> row(img.num_comps, 0);
     ojph::ui32 comp = 0;
     for (size_t i = 0; i < total_lines; ++i) {
       ojph::line_buf* line = cs.pull(comp);
+      if (i == 0) lap("first line (frame decoded)");
       if (!line) break;
       if (row[comp] < img.ch[comp])
         memcpy(img.plane(comp) + (size_t)row[comp] * img.cw[comp], line->i32, img.cw[comp] * sizeof(int));
       row[comp]++;
     }
     cs.close();
+    lap("all lines pulled");
     if (pnm) write_pnm(out, img); else write_raw(out, img);
+    lap("output file written");
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("Elapsed time = %f\n", dt);
   } catch (const std::exception& e) {

@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 
 #include "../../include/ojphgpu.h"
@@ -291,7 +293,16 @@ void comment_exchange::set_string(const char* str) { data = str; len = (ui16)str
 void comment_exchange::set_data(const char* d, ui16 l) { data = d; len = l; Rcom = 0; }
 
 // ---- codestream ----------------------------------------------------------------------------------
-codestream::codestream() : state(new codestream_state()) {}
+// The HIP runtime takes ~0.1 s to come up in a fresh process; the first codestream object starts
+// that in the background so it overlaps with the caller reading its input file and setting
+// parameters (every HIP call made later simply waits for the initialisation to finish).
+static void warm_up_gpu_runtime()
+{
+  static std::once_flag once;
+  std::call_once(once, [] { std::thread([] { (void)hipFree(nullptr); }).detach(); });
+}
+
+codestream::codestream() : state(new codestream_state()) { warm_up_gpu_runtime(); }
 codestream::~codestream() { state->release(); delete state; }
 void codestream::restart() { state->release(); state->reset_params(); state->planar = -1; state->resilient = false; state->profile.clear(); }
 
