@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   typedef Wv<REV> W;
   typedef typename std::conditional<IMG, int, T>::type E;          // element type of the source rows
   typedef Raw<E> RawRow;
+  // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
+  // block-coder launch of the side stream, its wavefronts go first
+  __builtin_amdgcn_s_setprio(2);
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
   if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
+  // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
+  // block-coder launch of the side stream, its wavefronts go first
+  __builtin_amdgcn_s_setprio(2);
   const ojphgpu_dwt_desc d = descs[blockIdx.z];
   if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
