@@ -496,7 +496,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const uint32_t i0 = src_pos + 4u * (uint32_t)lane;
     uint32_t val = 0, nb = 0;
     if (i0 < ms_len) {
-      uint32_t prev = i0 ? cb[i0 - 1] : 0u, prev2 = i0 > 1 ? cb[i0 - 2] : 0u;
+      // the lane's four bytes and the four before them (i0 is a multiple of 4)
+      const uint32_t pw = i0 ? load_u32_unaligned(cb + i0 - 4) : 0u;
       uint32_t word;
       if (i0 + 4 <= ms_len) word = load_u32_unaligned(cb + i0);
       else {
@@ -505,16 +506,19 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
         if (i0 + 2 < ms_len) word |= (uint32_t)cb[i0 + 2] << 16;
       }
       const uint32_t cnt = min(4u, ms_len - i0);
-#pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) {
-        if (k < cnt) {
-          const uint32_t b = (word >> (8 * k)) & 0xFFu;
-          const uint32_t bits = prev == 0xFFu ? 7u : 8u;
-          const uint32_t eff = b | (prev2 == 0xFFu ? prev >> 7 : 0u);      // stray MSB of a 7-bit byte (see flatten)
-          val |= (eff & ((1u << bits) - 1u)) << nb; nb += bits;
-          prev2 = prev; prev = b;
-        }
-      }
+      const uint32_t valid = cnt == 4u ? 0xFFFFFFFFu : (1u << (8u * cnt)) - 1u;
+      // all four bytes at once: byte k of P / P2 is the raw byte k-1 / k-2 of the stream
+      const uint32_t P = (word << 8) | (pw >> 24), P2 = (word << 16) | (pw >> 16);
+      auto is_ff = [](uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; };   // 0x80 in every byte that is 0xFF
+      const uint32_t S = is_ff(P) & valid;                          // 0x80 in byte k: byte k follows an 0xFF and carries 7 bits
+      const uint32_t stray = (is_ff(P2) >> 7) & (P >> 7) & 0x01010101u;     // MSB of a 7-bit byte, OR-ed onto the next byte's LSB (see flatten)
+      uint32_t x = ((word | stray) & valid) & ~S;                 // the bits that count, still in byte positions
+      // close the gaps: a 7-bit byte hands every bit above it one position down (top byte: nothing above)
+      x = (S & 0x00800000u) ? (x & 0x007FFFFFu) | ((x >> 1) & 0xFF800000u) : x;
+      x = (S & 0x00008000u) ? (x & 0x00007FFFu) | ((x >> 1) & 0xFFFF8000u) : x;
+      x = (S & 0x00000080u) ? (x & 0x0000007Fu) | ((x >> 1) & 0xFFFFFF80u) : x;
+      val = x;
+      nb = 8u * cnt - (uint32_t)__popc(S);
     }
     const uint32_t incl = wave_incl_scan(nb);
     const uint32_t pos = dst_bits + incl - nb;
