@@ -221,7 +221,8 @@ typedef struct ojphgpu_cb_desc {     /* one code-block */
   uint64_t data_off;                 /* decode: byte offset of the coded bytes in `d_data`;
                                         encode: byte offset of this block's scratch slot */
   uint32_t scratch_cap;              /* encode: bytes available at data_off; decode: offset of the
-                                        block's per-quad records in d_quad_scratch (elements) */
+                                        block's first per-quad record in d_quad_scratch (elements),
+                                        see ojphgpu_ht_decode_layout */
   uint32_t reserved;                 /* decode: offset of the block's area in d_aux (elements) */
 } ojphgpu_cb_desc;
 
@@ -243,11 +244,21 @@ int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
  * un-stuffs the VLC and MEL segments into flat bit strings in d_aux), step 1 (the serial MEL /
  * VLC / U-VLC chains, one lane per block -> one 32-bit record per quad in d_quad_scratch), step 2
  * (MagSgn -> de-quantised samples, one wavefront per block, one lane per sample column).
- * For decoding, blocks[i].scratch_cap is the offset (uint32 elements) of block i's per-quad
- * records inside d_quad_scratch (ceil(w/2) * ceil(h/2) records + 1 pad element) and blocks[i].reserved the offset
- * (uint32 elements) of its area inside d_aux, ojphgpu_ht_decode_aux_words(len1) elements long.
+ * The scratch of the two intermediate products is laid out by ojphgpu_ht_decode_layout, which fills
+ * blocks[i].scratch_cap and blocks[i].reserved of the HOST copy of the descriptors before they are
+ * uploaded:
+ *  - per-quad records: step 1 advances 64 blocks per wavefront (descriptors 64g .. 64g+63 of a
+ *    launch), one quad PAIR per lane and iteration, so the records of such a group are interleaved
+ *    pair-major -- pair p of the group's lane l sits at group base + 2 * (64 p + l) -- and every store
+ *    of the wavefront is one contiguous 512-byte segment.  blocks[i].scratch_cap = offset (uint32
+ *    elements) of the block's pair 0; pair p = quad row * ceil(QW / 2) + quad pair follows 128 p
+ *    elements further.  A launch over a sub-range must start at a multiple of 64 descriptors of the
+ *    array that was laid out.
+ *  - blocks[i].reserved = offset (uint32 elements) of the block's flat VLC / MEL strings inside
+ *    d_aux, ojphgpu_ht_decode_aux_words(len1) elements long.
  * d_block_status[i] = 0 ok / non-zero failed (block zeroed), mirroring the bool of decode_cb32. */
 uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1);
+int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h_blocks, uint32_t n, uint64_t* quad_elems, uint64_t* aux_elems);
 int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                       const uint8_t* d_data, void* d_coef, uint32_t* d_quad_scratch,
                       uint32_t* d_aux, uint8_t* d_block_status);

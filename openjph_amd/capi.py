@@ -103,6 +103,7 @@ SIGNATURES = {
     "ojphgpu_plan_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_tile_parts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_ht_decode_layout": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_format": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                             C.c_uint32]),

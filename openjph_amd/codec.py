@@ -275,13 +275,10 @@ def ht_decode(descs: np.ndarray, data: np.ndarray, coef):
     torch = _torch()
     dev = coef.device.index
     L = capi.lib()
-    descs = descs.copy()
-    qoff = aoff = 0
-    for x in descs:                               # per-quad record / aux offsets (see include/ojphgpu.h)
-        x["scratch_cap"] = qoff
-        qoff += ((int(x["w"]) + 1) // 2) * ((int(x["h"]) + 1) // 2) + 1
-        x["reserved"] = aoff
-        aoff += int(L.ojphgpu_ht_decode_aux_words(int(x["len1"])))
+    descs = np.ascontiguousarray(descs.copy())
+    q, a = C.c_uint64(), C.c_uint64()             # per-quad record / aux offsets (see include/ojphgpu.h)
+    check(L.ojphgpu_ht_decode_layout(descs.ctypes.data, len(descs), C.byref(q), C.byref(a)), "ht_decode_layout")
+    qoff, aoff = int(q.value), int(a.value)
     d = to_device(descs, dev)
     dd = to_device(np.concatenate([np.asarray(data, np.uint8), np.zeros(64, np.uint8)]), dev)
     status = torch.zeros(len(descs) + 16, dtype=torch.uint8, device=coef.device)

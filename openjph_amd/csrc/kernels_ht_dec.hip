@@ -34,6 +34,7 @@
 // encoder never emits them, ojph_block_encoder.cpp:548), run in a fourth launch, ht_dec_refine_kernel,
 // that the codec objects skip when no block of the frame has more than one pass.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "../../include/ojphgpu.h"
 #include "ht_tables.h"
@@ -280,6 +281,8 @@ __device__ __forceinline__ void store_pair(uint32_t* p, uint32_t a, uint32_t b)
   *reinterpret_cast<U2*>(p) = v;
 }
 
+constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad pairs of one block (64 blocks x 2 records)
+
 // The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
 template <bool NARROW>
 __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
@@ -288,6 +291,7 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
   // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
   uint64_t sig_prev = 0;
+  const uint32_t PW = (QW + 1) >> 1;              // quad pairs per row
 
   // ---- initial quad row (block_decoder32.cpp:854-975) ----
   {
@@ -324,15 +328,16 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
       vlc.skip(used); mel.drop(ecnt);
-      store_pair(rec + qx, t0 | (u0 << 16), t1 | (u1 << 16));
+      store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
   }
   // ---- other quad rows (:977-1089) ----
   const uint16_t* tbl = s_vlc + 1024;
   for (uint32_t qy = 1; qy < QH; ++qy) {
-    uint32_t* row = rec + qy * QW;
-    const uint32_t* above = row - QW;
+    uint32_t* row = rec + (size_t)qy * PW * REC_STRIDE;                 // quad pair px of this row: row + px * REC_STRIDE
+    const uint32_t* above = row - (size_t)PW * REC_STRIDE;
+    auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
     uint32_t tleft = 0, carry = 0; uint64_t sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       vlc.refill();
@@ -349,10 +354,10 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
         k1 = ((m & 1u) << 7) | ((m & 4u) << 7);
         carry = (w >> 3) & 1u;                                     // column 2qx+3 = 2(qx+2)-1
       } else {
-        const uint32_t up0 = above[qx];
-        const uint32_t upl = qx ? above[qx - 1] : 0u;
-        const uint32_t up1 = qx + 1 < QW ? above[qx + 1] : 0u;
-        const uint32_t up2 = qx + 2 < QW ? above[qx + 2] : 0u;
+        const uint32_t up0 = above_rec(qx);
+        const uint32_t upl = qx ? above_rec(qx - 1) : 0u;
+        const uint32_t up1 = qx + 1 < QW ? above_rec(qx + 1) : 0u;
+        const uint32_t up2 = qx + 2 < QW ? above_rec(qx + 2) : 0u;
         const uint32_t sg = ((upl >> 7) & 1u) | (((up0 >> 5) & 1u) << 1) | (((up0 >> 7) & 1u) << 2) | (((up1 >> 5) & 1u) << 3) |
                             (((up1 >> 7) & 1u) << 4) | (((up2 >> 5) & 1u) << 5);
         k0 = (((sg | (sg >> 1)) & 1u) << 7) | ((((sg >> 2) | (sg >> 3)) & 1u) << 9);
@@ -384,7 +389,7 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
       const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
       const uint32_t u1 = (entry >> 3) + (tmp >> len);
       vlc.skip(used); mel.drop(ecnt);
-      store_pair(row + qx, t0 | (u0 << 16), t1 | (u1 << 16));
+      store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
   }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   if (scup == 0) { block_status[bi] = 1; return; }
   block_status[bi] = 0;
   const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
-  uint32_t* rec = quads + d.scratch_cap;          // QH rows of QW records
+  uint32_t* rec = quads + d.scratch_cap;          // pair p of this block: rec + 128 p (interleaved with the wavefront's other 63 blocks)
 
   FlatLsb vlc; vlc.init(aux + d.reserved, vlc_words(scup));
   MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
@@ -539,7 +544,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t half = (uint32_t)lane & 1u;
   bool bad = false;
   uint32_t e_prev = 0;                                   // exponent of this column's bottom sample, row above
-  uint32_t ent_next = (uint32_t)lane < W ? rec[lane >> 1] : 0u;      // records are fetched one step ahead
+  const uint32_t PW = (QW + 1) >> 1;
+  auto rec_at = [&](uint32_t qy_, uint32_t qx_) { return rec[(size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u)]; };
+  uint32_t ent_next = (uint32_t)lane < W ? rec_at(0, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
   for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
     const uint8_t* vexp = s_exp[wave][qy & 1];             // wide blocks: exponents of the sample row above (+1 offset)
     uint8_t* vnew = s_exp[wave][(qy & 1) ^ 1];
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
         uint32_t nc0 = c0 + 64, nqy = qy;
         if (nc0 >= W) { nc0 = 0; nqy = qy + 1; }
         const uint32_t ncol = nc0 + (uint32_t)lane;
-        ent_next = (nqy < QH && ncol < W) ? rec[nqy * QW + (ncol >> 1)] : 0u;
+        ent_next = (nqy < QH && ncol < W) ? rec_at(nqy, ncol >> 1) : 0u;
       }
       const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
       uint32_t U_q = ent >> 16;
@@ -782,6 +789,30 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
 }  // namespace
 
 extern "C" uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1) { return aux_words(len1); }
+
+extern "C" int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h, uint32_t n, uint64_t* quad_elems, uint64_t* aux_elems)
+{
+  if ((!h && n) || !quad_elems || !aux_elems) return OJPHGPU_E_INVALID;
+  uint64_t q = 0, a = 0;
+  for (uint32_t g = 0; g < n; g += 64) {                      // the 64 blocks one step-1 wavefront advances together
+    const uint32_t m = n - g < 64u ? n - g : 64u;
+    uint64_t pairs = 1;
+    for (uint32_t l = 0; l < m; ++l) {
+      const uint64_t qw = ((uint64_t)h[g + l].w + 1) >> 1, qh = ((uint64_t)h[g + l].h + 1) >> 1;
+      pairs = std::max<uint64_t>(pairs, ((qw + 1) >> 1) * qh);
+    }
+    for (uint32_t l = 0; l < m; ++l) {
+      if (q + 2 * l > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
+      h[g + l].scratch_cap = (uint32_t)(q + 2 * l);
+      h[g + l].reserved = (uint32_t)a;
+      a += aux_words(h[g + l].len1);
+    }
+    q += (uint64_t)REC_STRIDE * pairs;
+  }
+  if (q > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
+  *quad_elems = q; *aux_elems = a;
+  return OJPHGPU_OK;
+}
 
 extern "C" int ojphgpu_ht_decode_prep(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                        const uint8_t* d_data, uint32_t* d_aux)

@@ -702,10 +702,6 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) d->any_refine = true;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
-    o.scratch_cap = (uint32_t)nquads;                                   // offset of this block's per-quad records
-    nquads += (uint64_t)((k.r.w + 1) / 2) * ((k.r.h + 1) / 2) + 1;    // + 1 pad element (see include/ojphgpu.h)
-    o.reserved = (uint32_t)naux;                                        // offset of this block's flat VLC / MEL strings
-    naux += ojphgpu_ht_decode_aux_words(c.len1);
     d->max_len1 = std::max(d->max_len1, c.len1);
     if (c.len1 + c.len2) {
       max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
@@ -723,6 +719,16 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   }
   d->data_first = d->f_first[0];
   d->data_len = (size_t)data_total;
+  // scratch of step 1's records and of the flat VLC / MEL strings; the two launch ranges of the
+  // (opt-in) two-stream mode are laid out separately, each starts a fresh group of 64 blocks
+  {
+    uint64_t q1 = 0, a1 = 0, q2 = 0, a2 = 0;
+    if (ojphgpu_ht_decode_layout(bd.data(), d->n_top, &q1, &a1) != OJPHGPU_OK ||
+        ojphgpu_ht_decode_layout(bd.data() + d->n_top, (uint32_t)bd.size() - d->n_top, &q2, &a2) != OJPHGPU_OK)
+      return bail(OJPHGPU_E_INVALID);
+    for (size_t i = d->n_top; i < bd.size(); ++i) { bd[i].scratch_cap += (uint32_t)q1; bd[i].reserved += (uint32_t)a1; }
+    nquads = q1 + q2; naux = a1 + a2;
+  }
   if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
