@@ -43,9 +43,10 @@ WORKLOADS = {
 }
 
 
-def dwt_alg_bytes(nsamples, levels):
-    """each level reads its input once and writes its four sub-bands once, 4-byte elements"""
-    return 8.0 * nsamples * sum(4.0 ** -l for l in range(levels))
+def dwt_alg_bytes(nsamples, levels, container=32):
+    """each level reads its input once and writes its four sub-bands once, 4-byte elements; the image
+    side of the top level moves container / 8 bytes per sample"""
+    return 8.0 * nsamples * sum(4.0 ** -l for l in range(levels)) - (4.0 - container / 8.0) * nsamples * (1 if levels else 0)
 
 
 def main():
@@ -58,6 +59,10 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
                     help="independent frames coded per step as one batch (default 1; 8 for the c5 batch workload)")
+    ap.add_argument("--container", type=int, default=16, choices=(16, 32),
+                    help="bits of the sample containers of the frames in HBM: 16 = int16 / uint16 planes (how 8..16-bit frames "
+                         "exist in files and capture buffers; the default), 32 = int32 planes (what the reference's line_buf "
+                         "exchanges line by line)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: the frame being encoded and the frame being decoded are issued on two HIP streams")
     ap.add_argument("--calibrate", action="store_true",
@@ -93,7 +98,9 @@ def main():
         img = np.stack([synth_image(nc, h, w, bd, seed=1234 + rank * frames + f) for f in range(frames)])
     else:
         img = synth_image(nc, h, w, bd, seed=1234 + rank)
-    d_img = torch.from_numpy(img).to(dev)
+    def to_dev(a):                               # the frame as it sits in HBM
+        return torch.from_numpy(a.astype(np.int16) if args.container == 16 else a).to(dev)
+    d_img = to_dev(img)
     params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
     from openjph_amd.plan import Plan
     from openjph_amd import shard
@@ -103,7 +110,7 @@ def main():
     tiled = plan.num_tiles > 1 and world > 1 and frames == 1
     if tiled:
         img = synth_image(nc, h, w, bd, seed=1234)
-        d_img = torch.from_numpy(img).to(dev)
+        d_img = to_dev(img)
         my_tiles = shard.tile_range(plan.num_tiles, rank, world)
         assert my_tiles[1] > 0, "more ranks than tiles"
     else:
@@ -146,9 +153,9 @@ def main():
         for t in range(my_tiles[0], my_tiles[0] + my_tiles[1]):
             _, _, (x0, y0, tw, th) = plan.comp_plane(t, 0)
             mask[:, y0:y0 + th, x0:x0 + tw] = True
-        err = ((d_out - d_img).abs() * mask).max().item()
+        err = ((d_out.int() - d_img.int()).abs() * mask).max().item()
     else:
-        err = (d_out - d_img).abs().max().item()
+        err = (d_out.int() - d_img.int()).abs().max().item()
     if rev:
         assert err == 0, "reversible round trip is not lossless"
     coded_bytes = enc.coded_bytes()
@@ -207,10 +214,10 @@ def main():
             acc[k] = [x / reps for x in v] if isinstance(v, list) else v / reps
     ns = nsamples_rank
     kernels = {
-        "dwt_forward(all levels)": (dwt_alg_bytes(ns, levels), te["dwt_ms"]),
-        "dwt_forward(level 1)": (8.0 * ns, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
-        "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels), td["dwt_ms"]),
-        "dwt_inverse(level 1)": (8.0 * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
+        "dwt_forward(all levels)": (dwt_alg_bytes(ns, levels, args.container), te["dwt_ms"]),
+        "dwt_forward(level 1)": ((4.0 + args.container / 8.0) * ns, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
+        "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels, args.container), td["dwt_ms"]),
+        "dwt_inverse(level 1)": ((4.0 + args.container / 8.0) * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
         "ht_encode": ((4.0 + c_rate) * ns, te["ht_ms"]),            # all launches of the block encoder (sum)
         # block decoder: prep reads the MEL/VLC share of the coded bytes and writes them flat; step 1
         # reads that and writes one 4-byte record per quad (1 B/sample); step 2 reads the records and
@@ -262,7 +269,7 @@ def main():
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
                    "tile": list(tile), "frames_per_step": frames * (1 if tiled else world),
                    "sharding": ("%d tiles per GPU of one frame" % my_tiles[1]) if tiled else "one frame per GPU (replicas)",
-                   "hip_streams": args.streams,
+                   "hip_streams": args.streams, "sample_container_bits": args.container,
                    "coded_bytes_per_sample": round(c_rate, 4),
                    "encode_ms": round(te["total_ms"], 4), "decode_ms": round(td["total_ms"], 4),
                    "encode_Msamples_s": round(ns / te["total_ms"] / 1e3, 1),

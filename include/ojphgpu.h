@@ -206,6 +206,15 @@ int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_
 int ojphgpu_dwt_forward_image(void* stream, const ojphgpu_params* params,
                               const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w,
                               uint32_t max_h, const int32_t* d_image, void* d_base);
+/* the same with the image samples in 16-bit containers: int16 (two's complement) for signed
+ * components, uint16 otherwise; bit depths up to 16.  Halves the HBM traffic of the image side of
+ * the top level (and the PCIe traffic of whoever fills / drains the image buffer). */
+int ojphgpu_dwt_forward_image16(void* stream, const ojphgpu_params* params,
+                                const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                                const uint16_t* d_image, void* d_base);
+int ojphgpu_dwt_inverse_image16(void* stream, const ojphgpu_params* params,
+                                const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                                uint16_t* d_image, void* d_base);
 int ojphgpu_dwt_inverse_image(void* stream, const ojphgpu_params* params,
                               const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w,
                               uint32_t max_h, int32_t* d_image, void* d_base);
@@ -299,6 +308,13 @@ int ojphgpu_convert_forward(void* stream, const ojphgpu_params* params,
 int ojphgpu_convert_inverse(void* stream, const ojphgpu_params* params,
                             const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
                             uint32_t max_w, uint32_t max_h, int32_t* d_image, const void* d_arena);
+/* 16-bit sample containers (see ojphgpu_dwt_forward_image16) */
+int ojphgpu_convert_forward16(void* stream, const ojphgpu_params* params,
+                              const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                              uint32_t max_w, uint32_t max_h, const uint16_t* d_image, void* d_arena);
+int ojphgpu_convert_inverse16(void* stream, const ojphgpu_params* params,
+                              const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                              uint32_t max_w, uint32_t max_h, uint16_t* d_image, const void* d_arena);
 
 /* ------------------------------------------------------------------------------------------ *
  * 5. Whole-frame codec objects: what an ojph::codestream-compatible facade calls from
@@ -327,6 +343,10 @@ int  ojphgpu_encoder_finish_frame(ojphgpu_encoder* enc, uint32_t frame, uint8_t*
                                   size_t* out_len);
 /* device part only: d_image (int32 planes, resident in HBM) -> coded block bytes in HBM */
 int  ojphgpu_encoder_run_device(ojphgpu_encoder* enc, const int32_t* d_image);
+/* the frame in 16-bit containers (same plane layout, 2-byte elements; int16 for signed components,
+ * uint16 otherwise; every component at most 16 bits deep) */
+int  ojphgpu_encoder_run_device16(ojphgpu_encoder* enc, const uint16_t* d_image);
+int  ojphgpu_encode16(ojphgpu_encoder* enc, const uint16_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len);
 /* D2H of block bytes + lengths, then host Tier-2 -> complete codestream */
 int  ojphgpu_encoder_finish(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len);
 /* convenience: H2D + run_device + finish */
@@ -352,6 +372,8 @@ void ojphgpu_decoder_destroy(ojphgpu_decoder* dec);
 int  ojphgpu_decoder_upload(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len);
 /* device part only: coded bytes in HBM -> d_image (int32 planes) */
 int  ojphgpu_decoder_run_device(ojphgpu_decoder* dec, int32_t* d_image);
+int  ojphgpu_decoder_run_device16(ojphgpu_decoder* dec, uint16_t* d_image);     /* 16-bit containers */
+int  ojphgpu_decode16(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len, uint16_t* h_image);
 /* number of code-blocks that failed to decode in the last run (synchronises) */
 int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
 int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len,

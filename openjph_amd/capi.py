@@ -103,6 +103,18 @@ SIGNATURES = {
     "ojphgpu_plan_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_tile_parts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_dwt_forward_image16": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p]),
+    "ojphgpu_dwt_inverse_image16": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p]),
+    "ojphgpu_convert_forward16": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_void_p]),
+    "ojphgpu_convert_inverse16": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_void_p]),
+    "ojphgpu_encoder_run_device16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ojphgpu_encode16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ojphgpu_decoder_run_device16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ojphgpu_decode16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_ht_decode_layout": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_format": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),

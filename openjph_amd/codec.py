@@ -74,8 +74,12 @@ class Encoder:
     def run_device(self, d_image):
         """d_image: int32 torch tensor [C,H,W] (flat plan.frame_shape for sub-sampled components)
         resident on the device. Asynchronous."""
-        assert d_image.is_cuda and d_image.dtype == _torch().int32 and tuple(d_image.shape) == self.shape
-        assert d_image.is_contiguous()
+        torch = _torch()
+        assert d_image.is_cuda and tuple(d_image.shape) == self.shape and d_image.is_contiguous()
+        if d_image.dtype in (torch.int16, torch.uint16):     # 16-bit containers: int16 for signed components, else uint16
+            check(self._lib.ojphgpu_encoder_run_device16(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device16")
+            return
+        assert d_image.dtype == torch.int32
         check(self._lib.ojphgpu_encoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device")
 
     def set_timing(self, per_launch: bool):
@@ -121,7 +125,10 @@ class Encoder:
         if isinstance(image, (list, tuple)):
             image = self.plan.pack_frame(image)
         if isinstance(image, np.ndarray):
-            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
+            if image.dtype in (np.int16, np.uint16):         # stays 16 bits wide on its way to and in HBM
+                image = torch.from_numpy(np.ascontiguousarray(image).view(np.int16)).to("cuda:%d" % self.device)
+            else:
+                image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
         self.run_device(image)
         if self.frames > 1:
             return [self.finish(f) for f in range(self.frames)]
@@ -193,12 +200,16 @@ class Decoder:
         check(self._lib.ojphgpu_decoder_upload_frame(self._h, frame, buf.ctypes.data, len(codestream)), "decoder_upload")
         _torch().cuda.synchronize(self.device)   # the host buffer may go away after this call
 
-    def run_device(self, d_image=None):
+    def run_device(self, d_image=None, dtype=None):
+        """dtype / d_image.dtype torch.int16 or torch.uint16: samples in 16-bit containers"""
         torch = _torch()
         if d_image is None:
             alloc = torch.empty if self.tiles == (0, self.plan.num_tiles) else torch.zeros
-            d_image = alloc(self.shape, dtype=torch.int32, device="cuda:%d" % self.device)
-        check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
+            d_image = alloc(self.shape, dtype=dtype or torch.int32, device="cuda:%d" % self.device)
+        if d_image.dtype in (torch.int16, torch.uint16):
+            check(self._lib.ojphgpu_decoder_run_device16(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device16")
+        else:
+            check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
         return d_image
 
     def set_timing(self, per_launch: bool):

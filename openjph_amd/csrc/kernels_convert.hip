@@ -49,8 +49,14 @@ __device__ __forceinline__ ConvParams with_fmt(ConvParams p, const ojphgpu_conve
   return p;
 }
 
+// S: container of the image samples -- int (32-bit) or short (16-bit: two's complement for signed
+// components, the full unsigned range otherwise)
+template <typename S> __device__ __forceinline__ int sample_in(S v, const ConvParams&) { return (int)v; }
+template <> __device__ __forceinline__ int sample_in<short>(short v, const ConvParams& p) { return p.is_signed ? (int)v : (int)(unsigned short)v; }
+
+template <typename S>
 __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
-                                                              const int* __restrict__ image, uint32_t* __restrict__ arena)
+                                                              const S* __restrict__ image, uint32_t* __restrict__ arena)
 {
   const uint32_t tile = blockIdx.z;
   const uint32_t nc = p.num_comps;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
     p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
-    int r = image[at(d0)], g = image[at(d1)], b = image[at(d2)];
+    int r = sample_in<S>(image[at(d0)], p), g = sample_in<S>(image[at(d1)], p), b = sample_in<S>(image[at(d2)], p);
     if (p.reversible) {
       const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
       r += shift; g += shift; b += shift;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;           // sub-sampled components are smaller
     p = with_fmt(pc, d);
-    int v = image[at(d)];
+    int v = sample_in<S>(image[at(d)], p);
     uint32_t o;
     if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
     else o = __float_as_uint(to_float(v, p));
@@ -92,8 +98,9 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   }
 }
 
+template <typename S>
 __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
-                                                              int* __restrict__ image, const uint32_t* __restrict__ arena)
+                                                              S* __restrict__ image, const uint32_t* __restrict__ arena)
 {
   const uint32_t tile = blockIdx.z;
   const uint32_t nc = p.num_comps;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
-      image[at(d0)] = cr + g + shift; image[at(d1)] = g + shift; image[at(d2)] = cb + g + shift;
+      image[at(d0)] = (S)(cr + g + shift); image[at(d1)] = (S)(g + shift); image[at(d2)] = (S)(cb + g + shift);
     } else {
       const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
       const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
       float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
-      image[at(d0)] = to_int(r, p); image[at(d1)] = to_int(g, p); image[at(d2)] = to_int(bb, p);
+      image[at(d0)] = (S)to_int(r, p); image[at(d1)] = (S)to_int(g, p); image[at(d2)] = (S)to_int(bb, p);
     }
   }
   for (uint32_t c = c_first; c < nc; ++c) {
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
     int v;
     if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
     else v = to_int(__uint_as_float(a), p);
-    image[at(d)] = v;
+    image[at(d)] = (S)v;
   }
 }
 
@@ -154,8 +161,20 @@ extern "C" int ojphgpu_convert_forward(void* stream, const ojphgpu_params* param
   if (!params || !d_descs || !d_image || !d_arena) return OJPHGPU_E_INVALID;
   if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   dim3 grid((max_w + 255) / 256, max_h, n_tiles);
-  hipLaunchKernelGGL(convert_forward_kernel, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+  hipLaunchKernelGGL(convert_forward_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
                      d_image, (uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_convert_forward16(void* stream, const ojphgpu_params* params,
+                                          const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                                          uint32_t max_w, uint32_t max_h, const uint16_t* d_image, void* d_arena)
+{
+  if (!params || !d_descs || !d_image || !d_arena || params->bit_depth > 16) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_forward_kernel<short>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     (const short*)d_image, (uint32_t*)d_arena);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
@@ -166,7 +185,19 @@ extern "C" int ojphgpu_convert_inverse(void* stream, const ojphgpu_params* param
   if (!params || !d_descs || !d_image || !d_arena) return OJPHGPU_E_INVALID;
   if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   dim3 grid((max_w + 255) / 256, max_h, n_tiles);
-  hipLaunchKernelGGL(convert_inverse_kernel, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+  hipLaunchKernelGGL(convert_inverse_kernel<int>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
                      d_image, (const uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_convert_inverse16(void* stream, const ojphgpu_params* params,
+                                          const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                                          uint32_t max_w, uint32_t max_h, uint16_t* d_image, const void* d_arena)
+{
+  if (!params || !d_descs || !d_image || !d_arena || params->bit_depth > 16) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_inverse_kernel<short>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     (short*)d_image, (const uint32_t*)d_arena);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }

@@ -187,8 +187,14 @@ template <> struct Cv<false> {
   }
 };
 
-// 8-byte accesses that only promise dword alignment
-template <typename E> struct Vec2 { typedef E type __attribute__((ext_vector_type(2), aligned(4))); };
+// two-sample accesses that only promise the alignment of one sample
+template <typename E> struct Vec2 { typedef E type __attribute__((ext_vector_type(2), aligned(sizeof(E) < 4 ? sizeof(E) : 4))); };
+
+// element type of the plane a kernel variant reads / writes: IMG = 0 the arena (T), 32 an int32
+// image, 16 a 16-bit image (two's complement for signed components, else unsigned)
+template <int IMG, typename T> struct ImgElem { typedef T type; };
+template <typename T> struct ImgElem<32, T> { typedef int type; };
+template <typename T> struct ImgElem<16, T> { typedef short type; };
 
 // Row loads are UNCONDITIONAL: every lane fetches two adjacent samples from a column clamped into
 // the row (and the callers clamp the row into the plane), and what a lane fetched is interpreted
@@ -207,12 +213,15 @@ __device__ __forceinline__ Raw<E> load_raw(const void* __restrict__ rowp, const 
 }
 
 // IMG: the row came from an int32 image plane and is converted here
-template <bool REV, bool IMG, typename E>
+template <bool REV, int IMG, typename E>
 __device__ __forceinline__ Pair<typename Wv<REV>::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
 {
   Pair<typename Wv<REV>::T> p;
   const auto a = g.from_y ? v.y : v.x, b = g.from_x ? v.x : v.y;
-  if (IMG) { p.l = Cv<REV>::from_image((int)a, cv); p.h = Cv<REV>::from_image((int)b, cv); }
+  if (IMG == 16) {                               // unsigned components occupy the full 16 bits
+    const int ia = cv.is_signed ? (int)a : (int)(unsigned short)a, ib = cv.is_signed ? (int)b : (int)(unsigned short)b;
+    p.l = Cv<REV>::from_image(ia, cv); p.h = Cv<REV>::from_image(ib, cv);
+  } else if (IMG) { p.l = Cv<REV>::from_image((int)a, cv); p.h = Cv<REV>::from_image((int)b, cv); }
   else { p.l = (typename Wv<REV>::T)a; p.h = (typename Wv<REV>::T)b; }
   return p;
 }
@@ -233,14 +242,14 @@ __device__ __forceinline__ void arrived(const A& a, const A& b, const A& c, cons
 // ---------------------------------------------------------------------------------------------
 // forward: plane (or image plane, IMG) -> LL, HL, LH, HH
 // ---------------------------------------------------------------------------------------------
-template <bool REV, bool IMG>
+template <bool REV, int IMG>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           typename Wv<REV>::T* __restrict__ base,
-                                                          const int* __restrict__ image, Conv cv, int row_pairs)
+                                                          const void* __restrict__ image, Conv cv, int row_pairs)
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
-  typedef typename std::conditional<IMG, int, T>::type E;          // element type of the source rows
+  typedef typename ImgElem<IMG, T>::type E;                        // element type of the source rows
   typedef Raw<E> RawRow;
   // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
   // block-coder launch of the side stream, its wavefronts go first
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   if (i0 >= npy) return;
   const int i1 = min(i0 + row_pairs, npy);
 
-  const char* src = IMG ? (const char*)(image + d.src_off) : (const char*)(base + d.src_off);
-  const size_t sp = (size_t)d.src_pitch * 4;
+  const char* src = IMG ? (const char*)image + d.src_off * sizeof(E) : (const char*)(base + d.src_off);
+  const size_t sp = (size_t)d.src_pitch * sizeof(E);
   T* ll = base + d.ll_off; T* hl = base + d.hl_off; T* lh = base + d.lh_off; T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
@@ -349,14 +358,20 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 
 struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
 
-template <bool REV, bool IMG>
+template <bool REV, int IMG>
 __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
                                            const Conv& cv)
 {
   typedef typename Wv<REV>::T T;
   if (!g.store) return;
   const int xl = 2 * g.j - g.ox;
-  if (IMG) {
+  if (IMG == 16) {
+    short* row = (short*)rowp;
+    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
+    if (g.eL && g.eH) { typename Vec2<short>::type v; v.x = (short)a; v.y = (short)b; *reinterpret_cast<typename Vec2<short>::type*>(row + xl) = v; }
+    else if (g.eL) row[xl] = (short)a;
+    else if (g.eH) row[xl + 1] = (short)b;
+  } else if (IMG) {
     int* row = (int*)rowp;
     const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
     if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
@@ -378,10 +393,10 @@ __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g
 // ---------------------------------------------------------------------------------------------
 // inverse: LL, HL, LH, HH -> plane (or image plane, IMG)
 // ---------------------------------------------------------------------------------------------
-template <bool REV, bool IMG>
+template <bool REV, int IMG>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           typename Wv<REV>::T* __restrict__ base,
-                                                          int* __restrict__ image, Conv cv, int row_pairs)
+                                                          void* __restrict__ image, Conv cv, int row_pairs)
 {
   typedef typename Wv<REV>::T T;
   typedef Wv<REV> W;
@@ -401,8 +416,9 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   if (i0 >= npy) return;
   const int i1 = min(i0 + row_pairs, npy);
 
-  char* dst = IMG ? (char*)(image + d.src_off) : (char*)(base + d.src_off);
-  const size_t dp = (size_t)d.src_pitch * 4;
+  typedef typename ImgElem<IMG, T>::type E;                        // element type of the destination rows
+  char* dst = IMG ? (char*)image + d.src_off * sizeof(E) : (char*)(base + d.src_off);
+  const size_t dp = (size_t)d.src_pitch * sizeof(E);
   const T* ll = base + d.ll_off; const T* hl = base + d.hl_off;
   const T* lh = base + d.lh_off; const T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
@@ -494,9 +510,10 @@ dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h, int rp)
   return dim3((sx + 3) / 4, (npy + rp - 1) / rp, n);
 }
 
+// container: 0 = no image (arena planes only), 32 = int32 image samples, 16 = 16-bit image samples
 template <bool FWD>
 int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
-           void* d_base, int32_t* d_image, Conv cv)
+           void* d_base, void* d_image, Conv cv, int container = 32)
 {
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
@@ -504,13 +521,11 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   const dim3 grid = dwt_grid(n, max_w, max_h, rp);
   hipStream_t s = (hipStream_t)stream;
 #define OJPH_LAUNCH(K, REV, IMG, TP) hipLaunchKernelGGL((K<REV, IMG>), grid, dim3(256), 0, s, d_descs, (TP*)d_base, d_image, cv, rp)
-  if (FWD) {
-    if (reversible) { if (d_image) OJPH_LAUNCH(dwt_forward_kernel, true, true, int); else OJPH_LAUNCH(dwt_forward_kernel, true, false, int); }
-    else { if (d_image) OJPH_LAUNCH(dwt_forward_kernel, false, true, float); else OJPH_LAUNCH(dwt_forward_kernel, false, false, float); }
-  } else {
-    if (reversible) { if (d_image) OJPH_LAUNCH(dwt_inverse_kernel, true, true, int); else OJPH_LAUNCH(dwt_inverse_kernel, true, false, int); }
-    else { if (d_image) OJPH_LAUNCH(dwt_inverse_kernel, false, true, float); else OJPH_LAUNCH(dwt_inverse_kernel, false, false, float); }
-  }
+#define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, TP); else if (container == 16) OJPH_LAUNCH(K, REV, 16, TP); \
+                                         else OJPH_LAUNCH(K, REV, 32, TP); } while (0)
+  if (FWD) { if (reversible) OJPH_LAUNCH_IMG(dwt_forward_kernel, true, int); else OJPH_LAUNCH_IMG(dwt_forward_kernel, false, float); }
+  else { if (reversible) OJPH_LAUNCH_IMG(dwt_inverse_kernel, true, int); else OJPH_LAUNCH_IMG(dwt_inverse_kernel, false, float); }
+#undef OJPH_LAUNCH_IMG
 #undef OJPH_LAUNCH
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
@@ -543,4 +558,21 @@ extern "C" int ojphgpu_dwt_inverse_image(void* stream, const ojphgpu_params* par
   if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 31) return OJPHGPU_E_INVALID;
   return launch<false>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, d_image,
                        Conv{ (int)params->bit_depth, (int)params->is_signed });
+}
+
+// the same with the image samples in 16-bit containers (int16 for signed components, else uint16)
+extern "C" int ojphgpu_dwt_forward_image16(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                            uint32_t n, uint32_t max_w, uint32_t max_h, const uint16_t* d_image, void* d_base)
+{
+  if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 16) return OJPHGPU_E_INVALID;
+  return launch<true>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, const_cast<uint16_t*>(d_image),
+                      Conv{ (int)params->bit_depth, (int)params->is_signed }, 16);
+}
+
+extern "C" int ojphgpu_dwt_inverse_image16(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                            uint32_t n, uint32_t max_w, uint32_t max_h, uint16_t* d_image, void* d_base)
+{
+  if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 16) return OJPHGPU_E_INVALID;
+  return launch<false>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, d_image,
+                       Conv{ (int)params->bit_depth, (int)params->is_signed }, 16);
 }

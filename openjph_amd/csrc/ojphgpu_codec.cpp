@@ -401,10 +401,17 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   return OJPHGPU_OK;
 }
 
-extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image)
+static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container);
+
+extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image) { return encoder_run(e, d_image, 32); }
+extern "C" int ojphgpu_encoder_run_device16(ojphgpu_encoder* e, const uint16_t* d_image) { return encoder_run(e, d_image, 16); }
+
+// container: 32 = int32 samples, 16 = 16-bit samples (int16 for signed components, else uint16)
+static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
 {
   if (!e || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
+  if (container == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
   hipStream_t s = e->stream;
   Spans& T = e->timer;
   HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
@@ -412,8 +419,11 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   int rc = OJPHGPU_OK;
   if (!e->fused_convert) {
     const int sp = T.begin(SP_CONVERT, s);
-    rc = ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
-                                 e->conv_max_w, e->conv_max_h, d_image, e->arena.p);
+    rc = container == 16
+       ? ojphgpu_convert_forward16(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
+                                   e->conv_max_w, e->conv_max_h, (const uint16_t*)d_image, e->arena.p)
+       : ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
+                                 e->conv_max_w, e->conv_max_h, (const int32_t*)d_image, e->arena.p);
     T.end(sp, s);
   }
   if (rc) return rc;
@@ -423,8 +433,11 @@ extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_i
   for (const LevelBatch& b : e->batches) {
     const int sp = T.begin(SP_DWT, s);
     if (e->fused_convert && &b == &e->batches.front())      // level shift / int->float applied in the loads
-      rc = ojphgpu_dwt_forward_image(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
-                                     d_image, e->arena.p);
+      rc = container == 16
+         ? ojphgpu_dwt_forward_image16(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
+                                       (const uint16_t*)d_image, e->arena.p)
+         : ojphgpu_dwt_forward_image(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
+                                     (const int32_t*)d_image, e->arena.p);
     else
       rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
@@ -535,16 +548,26 @@ extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, 
                                 out_len, tile_part_len);
 }
 
-extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
+static int encode_host(ojphgpu_encoder* e, const void* h_image, int container, uint8_t* h_out, size_t cap, size_t* out_len)
 {
   if (!e || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
-  const size_t bytes = (size_t)P.frame_elems * 4 * e->nframes;
+  const size_t bytes = (size_t)P.frame_elems * 4 * e->nframes;          // sized for the wider container, used by both
   if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
-  HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes, hipMemcpyHostToDevice, e->stream));
-  int rc = ojphgpu_encoder_run_device(e, (const int32_t*)e->image.p);
+  HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes / (container == 16 ? 2 : 1), hipMemcpyHostToDevice, e->stream));
+  int rc = encoder_run(e, e->image.p, container);
   if (rc) return rc;
   return ojphgpu_encoder_finish(e, h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encode(ojphgpu_encoder* e, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  return encode_host(e, h_image, 32, h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_encode16(ojphgpu_encoder* e, const uint16_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
+{
+  return encode_host(e, h_image, 16, h_out, cap, out_len);
 }
 
 extern "C" int ojphgpu_encoder_timing(ojphgpu_encoder* e, float out[4])
@@ -787,10 +810,17 @@ static int decode_blocks(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uint
   return OJPHGPU_OK;
 }
 
-extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
+static int decoder_run(ojphgpu_decoder* d, void* d_image, int container);
+static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, void* h_image, int container);
+
+extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image) { return decoder_run(d, d_image, 32); }
+extern "C" int ojphgpu_decoder_run_device16(ojphgpu_decoder* d, uint16_t* d_image) { return decoder_run(d, d_image, 16); }
+
+static int decoder_run(ojphgpu_decoder* d, void* d_image, int container)
 {
   if (!d || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
+  if (container == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
   hipStream_t s = d->stream;
   Spans& T = d->timer;
   T.start(s);
@@ -809,8 +839,11 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
     if (last && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));     // join before the top synthesis level
     const int sp = T.begin(SP_DWT, s);
     if (d->fused_convert && last)                           // float->int / level shift applied in the stores
-      rc = ojphgpu_dwt_inverse_image(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
-                                     d_image, d->arena.p);
+      rc = container == 16
+         ? ojphgpu_dwt_inverse_image16(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
+                                       (uint16_t*)d_image, d->arena.p)
+         : ojphgpu_dwt_inverse_image(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
+                                     (int32_t*)d_image, d->arena.p);
     else
       rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
@@ -820,8 +853,11 @@ extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image)
   if (d->batches.empty() && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));
   if (!d->fused_convert) {
     const int sp = T.begin(SP_CONVERT, s);
-    rc = ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
-                                 d->conv_max_w, d->conv_max_h, d_image, d->arena.p);
+    rc = container == 16
+       ? ojphgpu_convert_inverse16(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
+                                   d->conv_max_w, d->conv_max_h, (uint16_t*)d_image, d->arena.p)
+       : ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
+                                 d->conv_max_w, d->conv_max_h, (int32_t*)d_image, d->arena.p);
     if (rc) return rc;
     T.end(sp, s);
   }
@@ -851,6 +887,16 @@ extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count
 
 extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, int32_t* h_image)
 {
+  return decode_host(d, h_codestream, len, h_image, 32);
+}
+
+extern "C" int ojphgpu_decode16(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, uint16_t* h_image)
+{
+  return decode_host(d, h_codestream, len, h_image, 16);
+}
+
+static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, void* h_image, int container)
+{
   if (!d || !h_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
   if (d->nframes != 1) return OJPHGPU_E_INVALID;           // batches: upload_frame + run_device
@@ -858,9 +904,9 @@ extern "C" int ojphgpu_decode(ojphgpu_decoder* d, const uint8_t* h_codestream, s
   if (!d->image.p && d->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   int rc = ojphgpu_decoder_upload(d, h_codestream, len);
   if (rc) return rc;
-  rc = ojphgpu_decoder_run_device(d, (int32_t*)d->image.p);
+  rc = decoder_run(d, d->image.p, container);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes, hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (container == 16 ? 2 : 1), hipMemcpyDeviceToHost, d->stream));
   uint32_t failed = 0;
   rc = ojphgpu_decoder_failed_blocks(d, &failed);
   if (rc) return rc;

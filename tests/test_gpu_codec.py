@@ -155,6 +155,31 @@ def test_random_parameter_sets_on_gpu(chunk):
     assert done >= 20
 
 
+@pytest.mark.parametrize("case", [
+    dict(nc=3, h=131, w=257, bd=10), dict(nc=1, h=300, w=501, bd=16, tile=(128, 128)), dict(nc=3, h=200, w=300, bd=8, color_transform=True),
+    dict(nc=1, h=97, w=113, bd=12, signed=True, num_decomps=2), dict(nc=3, h=240, w=321, bd=12, reversible=False, qstep=0.001),
+    dict(nc=3, h=200, w=300, bd=8, reversible=False, color_transform=True), dict(nc=1, h=64, w=1, bd=8), dict(nc=1, h=5, w=7, bd=8, num_decomps=0),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_16bit_sample_containers(case):
+    """the frame handed over as int16 / uint16 planes (ojphgpu_encoder_run_device16 /
+    ojphgpu_decoder_run_device16): same codestream bytes and the same samples as with int32 planes"""
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    nc, h, w, bd, signed, kw = _split(case)
+    img = synth_image(nc, h, w, bd, seed=3, signed=signed)
+    kw = dict(kw, bit_depth=bd, is_signed=signed)
+    enc = codec.Encoder(make_params(w, h, nc, **kw))
+    want = enc.encode(img)
+    small = img.astype(np.int16) if signed else img.astype(np.uint16)
+    assert enc.encode(small) == want
+    dec = codec.Decoder(want)
+    ref_out = dec.decode()
+    out16 = dec.run_device(dtype=torch.int16).cpu().numpy()
+    got = out16.astype(np.int32) if signed else out16.view(np.uint16).astype(np.int32)
+    assert np.array_equal(got, ref_out)
+
+
 def test_truncated_codestream_decodes_like_oracle():
     """tests/test_truncated_decode.cpp on the GPU decoder: a full frame from whatever was received
     when resilient, an error for a cut the parser detects when not"""
