@@ -602,10 +602,9 @@ struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
-  // blocks of the top resolution (descriptors [0, n_top)) are decoded on a second stream while the
-  // main one decodes the rest and runs the lower synthesis levels; the serial chains of step 1, which
-  // bound the block decoder, then run for both groups at the same time
-  uint32_t n_top = 0;
+  // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
+  // levels with step 2, see decoder_create)
+  uint32_t n_low = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fused_convert = false;
@@ -697,15 +696,21 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
   replicate_converts(cd, nframes, P.arena_elems, P.frame_elems);
   std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
-  // measured on MI355X: unlike in the encoder, the two-stream split does not pay here (both groups
-  // start with the VALU-heavy prep launch and then sit in their serial chains; 0.96 vs 0.91 ms at
-  // 8K), so it stays opt-in
-  if (nframes == 1 && P.p.num_decomps >= 2 && getenv("OJPHGPU_DEC_OVERLAP") != nullptr) {
-    auto top = [&](uint32_t id) { return P.bands[P.blocks[id].band].res == P.p.num_decomps; };
-    auto mid = std::stable_partition(ids.begin(), ids.end(), top);
-    d->n_top = (uint32_t)(mid - ids.begin());
-    if (d->n_top == 0 || d->n_top == ids.size()) d->n_top = 0;
-    else if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+  // Overlap of the lower synthesis levels with the block decoder: the blocks below the top
+  // resolution come first in descriptor order; once step 2 has produced them, the small, latency-bound
+  // launches of levels L .. 2 run on a second stream while step 2 works through the top resolution's
+  // blocks (3/4 of the samples) on the main one.  Prep and step 1 stay single launches over all blocks:
+  // step 1 costs one serial chain however few blocks it is given, splitting it would pay that twice
+  // (measured: 0.96 vs 0.91 ms at 8K with every stage split in two).
+  const uint32_t top_res = P.p.num_decomps - P.skip_recon;
+  if (nframes == 1 && top_res >= 2 && d->batches.size() >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
+    auto low = [&](uint32_t id) { return P.bands[P.blocks[id].band].res < top_res; };
+    auto mid = std::stable_partition(ids.begin(), ids.end(), low);
+    d->n_low = (uint32_t)(mid - ids.begin());
+    int prio_lo = 0, prio_hi = 0;                         // the short launches of the side stream go first at the dispatcher
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (d->n_low == 0 || d->n_low == ids.size()) d->n_low = 0;
+    else if (hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
              hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
   }
@@ -742,16 +747,9 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   }
   d->data_first = d->f_first[0];
   d->data_len = (size_t)data_total;
-  // scratch of step 1's records and of the flat VLC / MEL strings; the two launch ranges of the
-  // (opt-in) two-stream mode are laid out separately, each starts a fresh group of 64 blocks
-  {
-    uint64_t q1 = 0, a1 = 0, q2 = 0, a2 = 0;
-    if (ojphgpu_ht_decode_layout(bd.data(), d->n_top, &q1, &a1) != OJPHGPU_OK ||
-        ojphgpu_ht_decode_layout(bd.data() + d->n_top, (uint32_t)bd.size() - d->n_top, &q2, &a2) != OJPHGPU_OK)
-      return bail(OJPHGPU_E_INVALID);
-    for (size_t i = d->n_top; i < bd.size(); ++i) { bd[i].scratch_cap += (uint32_t)q1; bd[i].reserved += (uint32_t)a1; }
-    nquads = q1 + q2; naux = a1 + a2;
-  }
+  // scratch of step 1's records and of the flat VLC / MEL strings (prep and step 1 are single launches
+  // over all descriptors)
+  if (ojphgpu_ht_decode_layout(bd.data(), (uint32_t)bd.size(), &nquads, &naux) != OJPHGPU_OK) return bail(OJPHGPU_E_INVALID);
   if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
@@ -782,23 +780,33 @@ extern "C" int ojphgpu_decoder_upload_frame(ojphgpu_decoder* d, uint32_t frame, 
   return OJPHGPU_OK;
 }
 
-// the block decoder over descriptors [first, first + count) on stream s
-static int decode_blocks(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uint32_t count)
+// prep + step 1 of every block (one launch each: step 1 costs one serial chain however few blocks it gets)
+static int decode_chains(ojphgpu_decoder* d, hipStream_t s)
+{
+  if (d->nblocks == 0) return OJPHGPU_OK;
+  Spans& T = d->timer;
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p;
+  uint8_t* status = (uint8_t*)d->status.p;
+  int sp = T.begin(SP_PREP, s);
+  int rc = ojphgpu_ht_decode_prep(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
+  if (rc) return rc;
+  T.end(sp, s);
+  sp = T.begin(SP_STEP1, s);
+  rc = ojphgpu_ht_decode_step1(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p, (uint32_t*)d->quads.p, status);
+  if (rc) return rc;
+  T.end(sp, s);
+  return OJPHGPU_OK;
+}
+
+// step 2 (+ the refinement passes) over descriptors [first, first + count) on stream s
+static int decode_samples(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uint32_t count)
 {
   if (count == 0) return OJPHGPU_OK;
   Spans& T = d->timer;
   const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p + first;
   uint8_t* status = (uint8_t*)d->status.p + first;
-  int sp = T.begin(SP_PREP, s);
-  int rc = ojphgpu_ht_decode_prep(s, cbd, count, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
-  if (rc) return rc;
-  T.end(sp, s);
-  sp = T.begin(SP_STEP1, s);
-  rc = ojphgpu_ht_decode_step1(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p, (uint32_t*)d->quads.p, status);
-  if (rc) return rc;
-  T.end(sp, s);
-  sp = T.begin(SP_STEP2, s);
-  rc = ojphgpu_ht_decode_step2(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p, status);
+  int sp = T.begin(SP_STEP2, s);
+  int rc = ojphgpu_ht_decode_step2(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p, status);
   if (rc) return rc;
   T.end(sp, s);
   if (d->any_refine) {
@@ -824,33 +832,36 @@ static int decoder_run(ojphgpu_decoder* d, void* d_image, int container)
   hipStream_t s = d->stream;
   Spans& T = d->timer;
   T.start(s);
-  int rc;
-  if (d->n_top) {                                           // fork: top-resolution blocks on the side stream
+  int rc = decode_chains(d, s);
+  if (rc) return rc;
+  rc = decode_samples(d, s, 0, d->n_low ? d->n_low : d->nblocks);
+  if (rc) return rc;
+  if (d->n_low) {                                           // fork: the lower synthesis levels on the side stream
     HIPCHK(hipEventRecord(d->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
-    rc = decode_blocks(d, d->side, 0, d->n_top);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(d->ev_join, d->side));
   }
-  rc = decode_blocks(d, s, d->n_top, d->nblocks - d->n_top);
-  if (rc) return rc;
   for (const LevelBatch& b : d->batches) {
     const bool last = &b == &d->batches.back();
-    if (last && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));     // join before the top synthesis level
-    const int sp = T.begin(SP_DWT, s);
+    hipStream_t ls = (d->n_low && !last) ? d->side : s;
+    if (last && d->n_low) {                                 // meanwhile, on the main stream: the top resolution's blocks
+      HIPCHK(hipEventRecord(d->ev_join, d->side));
+      rc = decode_samples(d, s, d->n_low, d->nblocks - d->n_low);
+      if (rc) return rc;
+      HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));         // join before the top synthesis level
+    }
+    const int sp = T.begin(SP_DWT, ls);
     if (d->fused_convert && last)                           // float->int / level shift applied in the stores
       rc = container == 16
-         ? ojphgpu_dwt_inverse_image16(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
+         ? ojphgpu_dwt_inverse_image16(ls, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
                                        (uint16_t*)d_image, d->arena.p)
-         : ojphgpu_dwt_inverse_image(s, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
+         : ojphgpu_dwt_inverse_image(ls, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
                                      (int32_t*)d_image, d->arena.p);
     else
-      rc = ojphgpu_dwt_inverse(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
+      rc = ojphgpu_dwt_inverse(ls, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;
-    T.end(sp, s);
+    T.end(sp, ls);
   }
-  if (d->batches.empty() && d->n_top) HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));
   if (!d->fused_convert) {
     const int sp = T.begin(SP_CONVERT, s);
     rc = container == 16
