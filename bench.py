@@ -280,21 +280,27 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic},
         "kernels": kinfo,
     }
-    if "dwt_forward(all levels)" in kernels and kernels["dwt_forward(all levels)"][1] > 0:
+    if "dwt_forward(level 1)" in kernels and kernels["dwt_forward(level 1)"][1] > 0:
         # the HBM-bound kernel family of the path (north_star sets its roofline target on it); the
-        # block coder launches above are bound by integer VALU issue, not by HBM
-        (bf, mf), (bi_, mi) = kernels["dwt_forward(all levels)"], kernels["dwt_inverse(all levels)"]
+        # block coder launches above are bound by integer VALU issue, not by HBM.  Level 1 -- the two
+        # launches that move 69 % of the DWT's bytes -- runs alone on the GPU; the small launches of
+        # the lower levels share it with the block coder of the other stream (encoder: side stream,
+        # decoder: step 2 of the top resolution), which stretches their durations: both figures are given.
+        (bf, mf), (bi_, mi) = kernels["dwt_forward(level 1)"], kernels["dwt_inverse(level 1)"]
+        (af, amf), (ai, ami) = kernels["dwt_forward(all levels)"], kernels["dwt_inverse(all levels)"]
         ach = (bf + bi_) / 1e6 / (mf + mi)
+        ach_all = (af + ai) / 1e6 / (amf + ami)
         tr = None
         try:
             w_ = pmc.get(args.workload, {})
-            tr = w_.get("dwt_forward(all levels)", 0) + w_.get("dwt_inverse(all levels)", 0) or None
+            tr = w_.get("dwt_forward(level 1)", 0) + w_.get("dwt_inverse(level 1)", 0) or None
         except Exception:
             pass
-        result["roofline_dwt"] = {"kernel": "dwt_forward + dwt_inverse (all levels, %d launches)" % (2 * levels), "bound": "hbm",
+        result["roofline_dwt"] = {"kernel": "dwt_forward + dwt_inverse (level 1, 2 launches)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr}
-
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr,
+                                  "all_levels": {"launches": 2 * levels, "achieved": round(ach_all, 1),
+                                                 "frac": round(ach_all / HBM_PEAK_GBS, 4)}}
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(img if frames == 1 else img[0], bd, rev, ct, qstep, tile, args.cpu_reps)
     if rank == 0:

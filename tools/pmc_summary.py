@@ -60,16 +60,23 @@ def main():
                      "file; x2 = gfx950 FETCH_SIZE correction (calibrated on an elementwise kernel of known traffic in "
                      "the same passes); multi-launch stages are per frame",
             "ht_dec_prep": traffic(pick("ht_dec_prep")), "ht_dec_step1": traffic(pick("ht_dec_step1")),
-            "ht_dec_step2": traffic(pick("ht_dec_step2")),
         }
+        s2 = pick("ht_dec_step2")                            # two launches per frame when the decoder overlaps the lower
+        if s2 is not None:                                   # synthesis levels with the top resolution's blocks
+            per_frame = max(1, round(len(fe.get(s2, [])) / max(len(fe.get(pick("ht_dec_step1"), [])), 1)))
+            out["ht_dec_step2"] = traffic(s2) * per_frame
         if two:
             out["ht_encode[top resolution, side stream]"] = traffic(enc, "big")
             out["ht_encode[lower resolutions]"] = traffic(enc, "small")
         else:
             out["ht_encode"] = traffic(enc)
-        for d, img in (("forward", "dwt_forward_kernel<false, true>"), ("inverse", "dwt_inverse_kernel<false, true>")):
-            top = pick(img) or pick("dwt_%s_kernel<true, true>" % d)
-            low = pick("dwt_%s_kernel<false, false>" % d) or pick("dwt_%s_kernel<true, false>" % d)
+        # template arguments: <reversible, image container bits (0 = arena planes only)>
+        for d in ("forward", "inverse"):
+            top = None
+            for rev in ("false", "true"):
+                for bits in ("16", "32"):
+                    top = top or pick("dwt_%s_kernel<%s, %s>" % (d, rev, bits))
+            low = pick("dwt_%s_kernel<false, 0>" % d) or pick("dwt_%s_kernel<true, 0>" % d)
             if top and low:
                 nl = len(fe.get(low, [])) // max(len(fe.get(top, [])), 1)
                 out["dwt_%s(all levels)" % d] = traffic(top) + nl * traffic(low)
