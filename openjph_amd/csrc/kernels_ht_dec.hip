@@ -462,7 +462,12 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  const uint32_t bi = blockIdx.x * WAVES + wave;
+  // Workgroup k of a launch runs on XCD k % 8, each XCD with its own L2.  The per-quad records of 64
+  // consecutive blocks share their cache lines (pair-major interleave, see ojphgpu_ht_decode_layout), so
+  // consecutive blocks are given to ONE XCD: XCD x works through the x-th contiguous eighth of the blocks.
+  const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, xcd = blockIdx.x & 7u;
+  const uint32_t wg = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+  const uint32_t bi = wg * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
