@@ -177,6 +177,20 @@ public:
   bool packets_may_use_sop() const { return false; }
   bool packets_use_eph() const { return false; }
   bool get_block_vertical_causality() const { return false; }
+  // COC marker segments (ojph_params.h:146-158): the first call for a component creates its COC from
+  // the SPcod defaults (5 decompositions, 64x64 blocks, wavelet_trans 0 = the 9/7, 32768x32768
+  // precincts; ojph_params_local.h:344-353), not from the COD; later calls modify it.  Components 0..15.
+  void set_num_decomposition(ui32 comp_idx, ui32 num_decompositions);
+  void set_block_dims(ui32 comp_idx, ui32 width, ui32 height);
+  void set_precinct_size(ui32 comp_idx, int num_levels, size* precinct_size);
+  void set_reversible(ui32 comp_idx, bool reversible);
+  ui32 get_num_decompositions(ui32 comp_idx) const;
+  size get_block_dims(ui32 comp_idx) const;
+  size get_log_block_dims(ui32 comp_idx) const;
+  bool is_reversible(ui32 comp_idx) const;
+  size get_precinct_size(ui32 comp_idx, ui32 level_num) const;
+  size get_log_precinct_size(ui32 comp_idx, ui32 level_num) const;
+  bool get_block_vertical_causality(ui32) const { return false; }
 private:
   local::codestream_state* state;
 };

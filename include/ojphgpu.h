@@ -40,6 +40,21 @@ extern "C" {
  *    (src/core/openjph/ojph_params.h:68-240).
  * ------------------------------------------------------------------------------------------ */
 #define OJPHGPU_MAX_SUBSAMPLED_COMPS 16
+#define OJPHGPU_MAX_COC_COMPS 16
+/* A COC marker segment: what param_cod's comp_idx setters build (ojph_params.h:146-151,
+ * ojph_params.cpp:255-282).  The reference starts a new COC from the SPcod defaults -- 5
+ * decompositions, 64x64 blocks, wavelet_trans 0 (the 9/7), no precincts (ojph_params_local.h:344-353)
+ * -- not from the COD; the facade does the same. */
+typedef struct ojphgpu_coc {
+  uint8_t  rank;                   /* 0: the component follows the COD.  k >= 1: it has a COC, the k-th one
+                                      created (COCs are written in creation order, ojph_params.cpp:1081-1094) */
+  uint8_t  reversible;             /* param_cod::set_reversible(comp_idx, ..)                       */
+  uint8_t  num_decomps;            /* param_cod::set_num_decomposition(comp_idx, ..)                */
+  uint8_t  log_block_w, log_block_h; /* param_cod::set_block_dims(comp_idx, ..), log2 (2..10)        */
+  uint8_t  has_precincts;          /* param_cod::set_precinct_size(comp_idx, ..): precinct_exps[0..num_decomps] */
+  uint8_t  reserved[2];            /* are PPx | PPy << 4 per resolution; 0 = 32768 x 32768 everywhere */
+  uint8_t  precinct_exps[36];
+} ojphgpu_coc;
 typedef struct ojphgpu_params {
   uint32_t width, height;        /* param_siz::set_image_extent                               */
   uint32_t num_comps;            /* param_siz::set_num_components  (all comps share the below) */
@@ -70,6 +85,7 @@ typedef struct ojphgpu_params {
   uint8_t  comp_depth[OJPHGPU_MAX_SUBSAMPLED_COMPS]; /* set_component bit depth of component c < 16 */
                                                      /* when it differs from bit_depth; 0 = same   */
   uint8_t  comp_sign[OJPHGPU_MAX_SUBSAMPLED_COMPS];  /* 0 = is_signed, 1 = unsigned, 2 = signed    */
+  ojphgpu_coc coc[OJPHGPU_MAX_COC_COMPS];            /* per-component coding style of component c < 16 */
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *
@@ -142,6 +158,10 @@ int  ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, uint32_t c
 int  ojphgpu_plan_comp_info(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
 /* bit depth and signedness of a component (param_siz::get_bit_depth / is_signed) */
 int  ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp, uint32_t* bit_depth, uint32_t* is_signed);
+/* coding style of a component, from its COC or the COD (param_cod's comp_idx getters,
+ * ojph_params.cpp:374-399): out[0] decompositions, [1] reversible, [2] [3] log2 code-block width /
+ * height, [4] 1 = the component has a COC, [5] decompositions left after restrict_resolution */
+int  ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
 
 /* ------------------------------------------------------------------------------------------ *
  * 3. Tier-2 on the host: marker segments + packet headers (tag trees, pass lengths) around the
@@ -294,7 +314,9 @@ typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint32_t img_pitch;                /* width of that plane */
   uint64_t img_off;                  /* element offset of that plane in the image buffer (a frame
                                         batch adds the frame's offset) */
-  uint32_t fmt;                      /* bit depth | signed << 8 of the component; 0 = from params */
+  uint32_t fmt;                      /* bit depth | signed << 8 of the component; 0 = from params;
+                                        | 0x200 when bit 10 says which conversion the component takes
+                                        (1 = reversible level shift, 0 = to float): components with a COC */
   uint32_t reserved;
 } ojphgpu_convert_desc;
 

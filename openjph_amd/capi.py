@@ -14,6 +14,15 @@ OK, E_INVALID, E_NOMEM, E_HIP, E_CODESTREAM, E_OVERFLOW, E_BLOCK = 0, -1, -2, -3
 PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
 
 
+class Coc(C.Structure):
+    """ojphgpu_coc: a COC marker segment (per-component coding style)"""
+    _fields_ = [
+        ("rank", C.c_uint8), ("reversible", C.c_uint8), ("num_decomps", C.c_uint8),
+        ("log_block_w", C.c_uint8), ("log_block_h", C.c_uint8), ("has_precincts", C.c_uint8),
+        ("reserved", C.c_uint8 * 2), ("precinct_exps", C.c_uint8 * 36),
+    ]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32), ("num_comps", C.c_uint32),
@@ -28,6 +37,7 @@ class Params(C.Structure):
         ("image_x0", C.c_uint32), ("image_y0", C.c_uint32), ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32),
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
         ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16),
+        ("coc", Coc * 16),
     ]
 
 
@@ -117,6 +127,7 @@ SIGNATURES = {
     "ojphgpu_decode16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_ht_decode_layout": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_format": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ojphgpu_plan_comp_style": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                             C.c_uint32]),
     "ojphgpu_plan_restrict_resolution": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -42,10 +42,11 @@ __device__ __forceinline__ int to_int(float f, const ConvParams& p)
   return v + half;
 }
 
-// the component's own bit depth / signedness when its descriptor carries one
+// the component's own bit depth / signedness / kind of conversion when its descriptor carries one
 __device__ __forceinline__ ConvParams with_fmt(ConvParams p, const ojphgpu_convert_desc& d)
 {
   if (d.fmt) { p.bit_depth = d.fmt & 0xFFu; p.is_signed = (d.fmt >> 8) & 1u; }
+  if (d.fmt & 0x200u) p.reversible = (d.fmt >> 10) & 1u;     // the component's own wavelet (COC)
   return p;
 }
 

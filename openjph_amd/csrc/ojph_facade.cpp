@@ -282,6 +282,68 @@ int param_cod::get_progression_order() const { return (int)state->p.prog_order; 
 const char* param_cod::get_progression_order_as_string() const { return PROG_NAMES[state->p.prog_order % 5]; }
 bool param_cod::is_using_color_transform() const { return state->p.color_transform != 0; }
 
+// COC interface (ojph_params.cpp:255-282, :374-399; get_or_add_coc :1341-1348)
+static ojphgpu_coc& coc_of(local::codestream_state* state, ui32 comp_idx)
+{
+  if (comp_idx >= OJPHGPU_MAX_COC_COMPS)
+    ojph_error(0x00050091, "per-component coding styles (COC) are supported for components 0..%d", OJPHGPU_MAX_COC_COMPS - 1);
+  ojphgpu_coc& k = state->p.coc[comp_idx];
+  if (k.rank == 0) {
+    ui32 made = 0;
+    for (const ojphgpu_coc& o : state->p.coc) made = std::max<ui32>(made, o.rank);
+    memset(&k, 0, sizeof(k));
+    k.rank = (ui8)(made + 1); k.num_decomps = 5; k.log_block_w = 6; k.log_block_h = 6; k.reversible = 0;
+  }
+  return k;
+}
+static const ojphgpu_coc* coc_if(const local::codestream_state* state, ui32 comp_idx)
+{
+  return comp_idx < OJPHGPU_MAX_COC_COMPS && state->p.coc[comp_idx].rank ? &state->p.coc[comp_idx] : nullptr;
+}
+void param_cod::set_num_decomposition(ui32 comp_idx, ui32 n)
+{
+  ojphgpu_coc& k = coc_of(state, comp_idx);
+  if (n > 32) ojph_error(0x00050001, "maximum number of decompositions cannot exceed 32");
+  k.num_decomps = (ui8)n;
+}
+void param_cod::set_block_dims(ui32 comp_idx, ui32 width, ui32 height)
+{
+  ojphgpu_coc& k = coc_of(state, comp_idx);
+  const ui32 lw = log2_exact(width), lh = log2_exact(height);
+  if (width == 0 || width != (1u << lw) || height == 0 || height != (1u << lh) || lw < 2 || lh < 2 || lw + lh > 12)
+    ojph_error(0x00050011, "incorrect code block dimensions");
+  k.log_block_w = (ui8)lw; k.log_block_h = (ui8)lh;
+}
+void param_cod::set_precinct_size(ui32 comp_idx, int num_levels, size* precinct_size)
+{
+  ojphgpu_coc& k = coc_of(state, comp_idx);
+  memset(k.precinct_exps, 0, sizeof(k.precinct_exps));
+  if (num_levels == 0 || precinct_size == nullptr) { k.has_precincts = 0; return; }
+  k.has_precincts = 1;
+  for (ui32 i = 0; i <= k.num_decomps; ++i) {              // uses the decompositions set so far (ojph_params.cpp:195)
+    const size t = precinct_size[(int)i < num_levels ? i : num_levels - 1];
+    if (t.w == 0 || t.h == 0) ojph_error(0x00050021, "precinct width or height cannot be 0");
+    const ui32 px = log2_exact(t.w), py = log2_exact(t.h);
+    if (t.w != (1u << px) || t.h != (1u << py)) ojph_error(0x00050022, "precinct width and height should be a power of 2");
+    if (px > 15 || py > 15) ojph_error(0x00050023, "precinct size is too large");
+    if (i > 0 && (px == 0 || py == 0)) ojph_error(0x00050024, "precinct size is too small");
+    k.precinct_exps[i] = (ui8)(px | (py << 4));
+  }
+}
+void param_cod::set_reversible(ui32 comp_idx, bool reversible) { coc_of(state, comp_idx).reversible = reversible ? 1 : 0; }
+ui32 param_cod::get_num_decompositions(ui32 c) const { const ojphgpu_coc* k = coc_if(state, c); return k ? k->num_decomps : get_num_decompositions(); }
+size param_cod::get_log_block_dims(ui32 c) const { const ojphgpu_coc* k = coc_if(state, c); return k ? size(k->log_block_w, k->log_block_h) : get_log_block_dims(); }
+size param_cod::get_block_dims(ui32 c) const { const size l = get_log_block_dims(c); return size(1u << l.w, 1u << l.h); }
+bool param_cod::is_reversible(ui32 c) const { const ojphgpu_coc* k = coc_if(state, c); return k ? k->reversible != 0 : is_reversible(); }
+size param_cod::get_log_precinct_size(ui32 c, ui32 level_num) const
+{
+  const ojphgpu_coc* k = coc_if(state, c);
+  if (!k) return get_log_precinct_size(level_num);
+  if (!k->has_precincts || level_num >= 36) return size(15, 15);
+  return size(k->precinct_exps[level_num] & 15u, k->precinct_exps[level_num] >> 4);
+}
+size param_cod::get_precinct_size(ui32 c, ui32 level_num) const { const size l = get_log_precinct_size(c, level_num); return size(1u << l.w, 1u << l.h); }
+
 void param_qcd::set_irrev_quant(float delta) { state->p.qstep = delta; }
 void param_qcd::set_qfactor(ui8 qfactor)
 {

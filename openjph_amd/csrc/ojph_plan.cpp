@@ -67,13 +67,15 @@ static float vw_get(const float* v, uint32_t level, uint32_t band)      // visua
 
 // One QCD / QCC: param_qcd::make_quant_steps for component `comp` (ojph_params.cpp:1434-1460) with
 // set_rev_quant (:1495-1540) or set_irrev_quant (:1542-1599).  ctype 0 Y, 1 Cb, 2 Cr; qfactor 0 = unset.
-static bool make_quant(const Plan& plan, uint32_t comp, uint32_t qfactor, uint32_t ctype, QuantSet& q, std::string& err,
-                       uint32_t base_depth)
+// `st` = the COD (for the QCD) or the component's own coding style; `base` = the base step handed down
+// (<= 0: not set, 2^-min(16, depth) of this component, :1451-1455); the step actually used comes back in it.
+static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint32_t qfactor, uint32_t ctype, QuantSet& q,
+                       std::string& err, float& base)
 {
   const ojphgpu_params& p = plan.p;
-  const uint32_t D = p.num_decomps, depth = plan.comps[comp].bit_depth;
+  const uint32_t D = st.L, depth = plan.comps[comp].bit_depth;
   q.q8.clear(); q.q16.clear();
-  if (p.reversible) {
+  if (st.rev) {
     uint32_t B = depth + ((comp < 3 && p.color_transform) ? 1 : 0);
     std::vector<uint32_t> e;
     double bl = bibo53_l[D];
@@ -96,9 +98,8 @@ static bool make_quant(const Plan& plan, uint32_t comp, uint32_t qfactor, uint32
   }
   q.guard_bits = 1;
   q.sqcd = (uint8_t)((1 << 5) | 0x2);
-  float base = p.qstep;
-  if (!(base > 0.0f)) {                                  // :1451-1455; a QCC made because the component differs
-    uint32_t t = std::min<uint32_t>(16, base_depth);     // inherits the QCD's base step (:1426)
+  if (!(base > 0.0f)) {                                  // :1451-1455
+    uint32_t t = std::min<uint32_t>(16, depth);
     base = 1.0f / (float)(1 << t);
   }
   float g_c = 1.0f, delta_ref = base, power = 1.0f;
@@ -144,23 +145,32 @@ static bool make_quant(const Plan& plan, uint32_t comp, uint32_t qfactor, uint32
   return true;
 }
 
-// param_qcd::check_validity (ojph_params.cpp:1359-1432): with a qfactor every component gets a QCC
-// (Y / Cb / Cr weights for the first three of >= 3 components, Y otherwise) and the QCD is made
-// from component 0; without, components whose bit depth or signedness differ from the QCD's get one
+// param_qcd::check_validity (ojph_params.cpp:1359-1432).  The QCD is made with the COD's style for the
+// first component that has no COC (component 0 when all have one).  With a qfactor every component
+// gets a QCC (Y / Cb / Cr weights for the first three of >= 3 components, Y otherwise); without, a
+// component gets one when its decompositions, bit depth, signedness or wavelet differ from what the
+// QCD was made for (is_qcc_needed, :1470-1481); such a QCC inherits the QCD's base step (:1426).
 bool derive_quant(Plan& plan)
 {
   const ojphgpu_params& p = plan.p;
   const uint32_t nc = p.num_comps, qf = p.reserved[2];
   plan.qcc.assign(nc, QuantSet());
+  uint32_t qcd_comp = 0;
+  for (uint32_t c = 0; c < nc; ++c) if (plan.style(c).rank == 0) { qcd_comp = c; break; }
   if (qf) for (uint32_t c = 0; c < nc; ++c) plan.qcc[c].present = true;
-  if (!make_quant(plan, 0, qf, 0, plan.qcd, plan.error, plan.comps[0].bit_depth)) return false;
+  float qcd_base = p.qstep > 0.0f ? p.qstep : -1.0f;
+  if (!make_quant(plan, plan.cod, qcd_comp, qf, 0, plan.qcd, plan.error, qcd_base)) return false;   // a reversible COD leaves the base unset
   for (uint32_t c = 0; c < nc; ++c) {
+    const CodStyle& st = plan.style(c);
+    float base = -1.0f;
     if (!plan.qcc[c].present) {
-      if (plan.comps[c].bit_depth == plan.comps[0].bit_depth && plan.comps[c].is_signed == plan.comps[0].is_signed) continue;   // is_qcc_needed (:1463-1475)
+      if (st.L == plan.cod.L && st.rev == plan.cod.rev && plan.comps[c].bit_depth == plan.comps[qcd_comp].bit_depth &&
+          plan.comps[c].is_signed == plan.comps[qcd_comp].is_signed) continue;
       plan.qcc[c].present = true;
+      base = qcd_base;
     }
     const uint32_t ctype = (qf && nc >= 3 && c < 3) ? c : 0;
-    if (!make_quant(plan, c, qf, ctype, plan.qcc[c], plan.error, plan.comps[0].bit_depth)) return false;
+    if (!make_quant(plan, st, c, qf, ctype, plan.qcc[c], plan.error, base)) return false;
   }
   return true;
 }
@@ -171,7 +181,7 @@ uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)
 {
   const QuantSet& q = plan.quant(comp);
   uint32_t idx = band_index(res, band);
-  if (plan.p.reversible) {
+  if ((q.sqcd & 0x1F) == 0) {                            // the style of the marker segment decides, as in the reference
     idx = std::min<uint32_t>(idx, (uint32_t)q.q8.size() - 1);
     uint32_t nb = q.q8[idx] >> 3;
     nb = nb == 0 ? 0 : nb - 1;
@@ -214,9 +224,9 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   if (p.num_decomps > 32) return fail("too many decompositions");
   if (p.block_w == 0) p.block_w = 64;
   if (p.block_h == 0) p.block_h = 64;
-  uint32_t lbw = ilog2(p.block_w), lbh = ilog2(p.block_h);
-  if ((1u << lbw) != p.block_w || (1u << lbh) != p.block_h || lbw < 2 || lbh < 2 ||
-      lbw > 10 || lbh > 10 || lbw + lbh > 12)
+  const uint32_t lbw = ilog2(p.block_w), lbh = ilog2(p.block_h);
+  auto block_ok = [](uint32_t a, uint32_t b) { return a >= 2 && b >= 2 && a <= 10 && b <= 10 && a + b <= 12; };
+  if ((1u << lbw) != p.block_w || (1u << lbh) != p.block_h || !block_ok(lbw, lbh))
     return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
   if (p.color_transform && p.num_comps < 3)
     return fail("color transform can only be employed when the image has 3 or more color components");   // ojph_params_local.h:450-453
@@ -267,21 +277,55 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
           plan.comps[c].bit_depth != plan.comps[0].bit_depth || plan.comps[c].is_signed != plan.comps[0].is_signed)
         return fail("the colour transform needs the first three components to have the same sub-sampling, bit depth and signedness");   // ojph_params_local.h:455-490
   (void)subsampled;
-  uint32_t lpw = 15, lph = 15;
-  if (p.precinct_w && p.precinct_h) {
-    lpw = ilog2(p.precinct_w); lph = ilog2(p.precinct_h);
-    if ((1u << lpw) != p.precinct_w || (1u << lph) != p.precinct_h || lpw > 15 || lph > 15)
-      return fail("precinct size must be a power of two <= 32768");
-    if (p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");
+  // the COD's style
+  plan.cod = CodStyle();
+  plan.cod.L = p.num_decomps; plan.cod.lbw = lbw; plan.cod.lbh = lbh; plan.cod.rev = p.reversible != 0;
+  plan.cod.causal = (p.reserved[0] & 1u) != 0;
+  {
+    uint32_t lpw = 15, lph = 15;
+    if (p.precinct_w && p.precinct_h) {
+      lpw = ilog2(p.precinct_w); lph = ilog2(p.precinct_h);
+      if ((1u << lpw) != p.precinct_w || (1u << lph) != p.precinct_h || lpw > 15 || lph > 15)
+        return fail("precinct size must be a power of two <= 32768");
+      if (p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");
+    }
+    bool per_res = false;                                         // a list of precinct sizes, one per resolution
+    for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
+    if (per_res) {
+      if (p.num_decomps >= 36) return fail("too many resolutions for a precinct list");
+      for (uint32_t i = 1; i <= p.num_decomps; ++i)
+        if ((p.precinct_exps[i] & 15) == 0 || (p.precinct_exps[i] >> 4) == 0) return fail("precinct size too small");   // ojph_params.cpp:208
+      p.precinct_w = 1u << (p.precinct_exps[0] & 15); p.precinct_h = 1u << (p.precinct_exps[0] >> 4);
+    } else memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
+    plan.cod.has_prec = p.precinct_w && p.precinct_h;
+    if (plan.cod.has_prec)
+      for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) plan.cod.pexp[i] = per_res ? p.precinct_exps[i] : (uint8_t)(lpw | (lph << 4));
   }
-  bool per_res = false;                                         // a list of precinct sizes, one per resolution
-  for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
-  if (per_res) {
-    if (p.num_decomps >= 36) return fail("too many resolutions for a precinct list");
-    for (uint32_t i = 1; i <= p.num_decomps; ++i)
-      if ((p.precinct_exps[i] & 15) == 0 || (p.precinct_exps[i] >> 4) == 0) return fail("precinct size too small");   // ojph_params.cpp:208
-    p.precinct_w = 1u << (p.precinct_exps[0] & 15); p.precinct_h = 1u << (p.precinct_exps[0] >> 4);
-  } else memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
+  // the COCs (components beyond the 16th follow the COD)
+  plan.coc.assign(p.num_comps, CodStyle());
+  plan.max_decomps = 0;
+  for (uint32_t c = 0; c < OJPHGPU_MAX_COC_COMPS; ++c) {
+    ojphgpu_coc& k = p.coc[c];
+    if (c >= p.num_comps || k.rank == 0) { memset(&k, 0, sizeof(k)); continue; }   // canonical form
+    CodStyle& st = plan.coc[c];
+    st.rank = k.rank; st.L = k.num_decomps; st.lbw = k.log_block_w; st.lbh = k.log_block_h; st.rev = k.reversible != 0;
+    k.reversible = st.rev ? 1 : 0; k.reserved[0] &= 1; k.reserved[1] = 0;      // reserved[0] bit 0: vertically causal (parser)
+    st.causal = k.reserved[0] != 0;
+    if (st.L > 32) return fail("too many decompositions");
+    if (!block_ok(st.lbw, st.lbh)) return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
+    st.has_prec = k.has_precincts != 0;
+    k.has_precincts = st.has_prec ? 1 : 0;
+    if (st.has_prec) {
+      for (uint32_t i = 0; i <= st.L; ++i) {
+        st.pexp[i] = k.precinct_exps[i];
+        if (i && ((st.pexp[i] & 15) == 0 || (st.pexp[i] >> 4) == 0)) return fail("precinct size too small");
+      }
+      for (uint32_t i = st.L + 1; i < 36; ++i) k.precinct_exps[i] = 0;
+    } else memset(k.precinct_exps, 0, sizeof(k.precinct_exps));
+  }
+  for (uint32_t c = 0; c < p.num_comps; ++c) plan.max_decomps = std::max(plan.max_decomps, plan.style(c).L);
+  if (p.color_transform && (plan.style(0).rev != plan.style(1).rev || plan.style(1).rev != plan.style(2).rev))
+    return fail("When the colour transform is employed, all colour components must undergo either reversible or irreversible wavelet transform");   // ojph_tile.cpp:147-163
   {                                                   // ojph_codestream_local.cpp:582-620, ojph_tile.cpp:225-250
     uint32_t div = p.reserved[1] & 3u;
     if ((p.prog_order == 0 || p.prog_order == 1) && div == 2) div |= 1;     // LRCP / RLCP: per component means per resolution and component
@@ -290,8 +334,14 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     if (p.prog_order == 4) div &= ~1u;                                      // CPRL: only per component
     p.reserved[1] = div;
     plan.tilepart_div = div;
-    plan.parts_per_tile = div == 0 ? 1 : div == 1 ? p.num_decomps + 1 : div == 2 ? p.num_comps : p.num_comps * (p.num_decomps + 1);
-    if (plan.parts_per_tile > 255) return fail("a tile cannot have more than 255 tile parts");
+    // RC divisions number the tile-parts c + r * num_comps and skip the (c, r) a component with fewer
+    // decompositions does not have (ojph_tile.cpp:637-652); the 255 limit counts the ones that exist (:84-103)
+    const uint32_t ML = plan.max_decomps;
+    plan.parts_per_tile = div == 0 ? 1 : div == 1 ? ML + 1 : div == 2 ? p.num_comps : p.num_comps * (ML + 1);
+    uint32_t existing = plan.parts_per_tile;
+    if (div == 3) { existing = 0; for (uint32_t c = 0; c < p.num_comps; ++c) existing += plan.style(c).L + 1; }
+    if (existing > 255) return fail("a tile cannot have more than 255 tile parts");
+    if (plan.parts_per_tile > 255) return fail("tile-part numbers beyond 255 (components with fewer decompositions leave gaps)");
   }
   plan.p = p;
   if (!derive_quant(plan)) return OJPHGPU_E_INVALID;
@@ -299,7 +349,6 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   plan.ntx = div_ceil(X1 - p.tile_x0, p.tile_w);                                   // ojph_codestream_local.cpp:113-123
   plan.nty = div_ceil(Y1 - p.tile_y0, p.tile_h);
   if ((uint64_t)plan.ntx * plan.nty > 65535) return fail("the number of tiles cannot exceed 65535");
-  const uint32_t L = p.num_decomps;
   uint64_t arena = 0;
   auto alloc = [&](uint32_t w, uint32_t h, uint32_t& pitch) {
     pitch = (std::max<uint32_t>(w, 1) + 63u) & ~63u;
@@ -320,6 +369,8 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
       }
       for (uint32_t c = 0; c < p.num_comps; ++c) {
         const CompGeo& cg = plan.comps[c];
+        const CodStyle& st = plan.style(c);
+        const uint32_t L = st.L, lbw = st.lbw, lbh = st.lbh;
         TileComp tc; tc.tile = t.idx; tc.comp = c;
         tc.r.x0 = div_ceil(t.r.x0, cg.dx); tc.r.y0 = div_ceil(t.r.y0, cg.dy);      // ojph_tile.cpp:262-275
         tc.r.w = div_ceil(t.r.x0 + t.r.w, cg.dx) - tc.r.x0; tc.r.h = div_ceil(t.r.y0 + t.r.h, cg.dy) - tc.r.y0;
@@ -335,7 +386,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
         }
         for (uint32_t r = 0; r <= L; ++r) {
           Resolution R; R.tile = t.idx; R.comp = c; R.res = r; R.r = rr[r];
-          if (per_res) { lpw = p.precinct_exps[r] & 15u; lph = p.precinct_exps[r] >> 4; }   // this resolution's precinct size
+          const uint32_t lpw = st.lpw(r), lph = st.lph(r);       // this resolution's precinct size
           R.log_ppw = lpw; R.log_pph = lph;
           for (int i = 0; i < 4; ++i) R.band[i] = -1;
           R.plane_off = 0; R.pitch = 0;
@@ -351,7 +402,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
             } else B.r = R.r;
             B.K_max = band_Kmax(plan, c, r, b);
             B.delta = 0.0f; B.delta_inv = 0.0f;
-            if (!p.reversible) {                                   // ojph_subband.cpp:156-164
+            if (!st.rev) {                                         // ojph_subband.cpp:156-164
               float d = band_delta(plan, c, r, b);
               d /= (float)(1u << (31 - B.K_max));
               B.delta = d; B.delta_inv = 1.0f / d;
@@ -458,9 +509,13 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     auto res_of = [&](uint32_t c, uint32_t r) -> const Resolution& {
       return plan.ress[plan.tcomps[t.comps[c]].res[r]];
     };
-    uint32_t nc = p.num_comps;
+    // a component with fewer decompositions than the largest simply has no resolution r > its own
+    // (tile_comp::write_precincts / get_top_left_precinct find nothing left to write, ojph_tile_comp.cpp:116-160)
+    const uint32_t nc = p.num_comps, L = plan.max_decomps;
+    auto has = [&](uint32_t c, uint32_t r) { return r <= plan.style(c).L; };
     std::vector<std::vector<uint32_t>> cur(nc, std::vector<uint32_t>(L + 1, 0));
     auto top = [&](uint32_t c, uint32_t r, uint32_t& x, uint32_t& y) {
+      if (!has(c, r)) return false;
       const Resolution& R = res_of(c, r);
       if (cur[c][r] >= R.npw * R.nph) return false;
       const Precinct& P = plan.precincts[R.first_precinct + cur[c][r]];
@@ -473,6 +528,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     if (p.prog_order == 0 || p.prog_order == 1) {
       for (uint32_t r = 0; r <= L; ++r)
         for (uint32_t c = 0; c < nc; ++c) {
+          if (!has(c, r)) continue;
           const Resolution& R = res_of(c, r);
           for (uint32_t i = 0; i < R.npw * R.nph; ++i) emit(c, r);
         }
@@ -616,7 +672,7 @@ extern "C" int ojphgpu_plan_comp_plane(const ojphgpu_plan* plan, uint32_t tile, 
   const Plan& P = plan->plan;
   if (tile >= P.tiles.size() || comp >= P.p.num_comps) return OJPHGPU_E_INVALID;
   const TileComp& tc = P.tcomps[P.tiles[tile].comps[comp]];
-  uint32_t L = P.p.num_decomps - P.skip_recon;              // reduced-resolution decoding reconstructs a lower resolution
+  uint32_t L = P.recon_decomps(comp);                       // reduced-resolution decoding reconstructs a lower resolution
   const Resolution& R = P.ress[tc.res[L]];
   if (L == 0) {
     const Band& B = P.bands[(size_t)R.band[0]];
@@ -638,13 +694,26 @@ extern "C" int ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp,
   return OJPHGPU_OK;
 }
 
+extern "C" int ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8])
+{
+  if (!plan || !out || comp >= plan->plan.p.num_comps) return OJPHGPU_E_INVALID;
+  const CodStyle& st = plan->plan.style(comp);
+  memset(out, 0, 8 * sizeof(uint32_t));
+  out[0] = st.L; out[1] = st.rev ? 1 : 0; out[2] = st.lbw; out[3] = st.lbh; out[4] = st.rank ? 1 : 0;
+  out[5] = plan->plan.recon_decomps(comp);
+  return OJPHGPU_OK;
+}
+
 extern "C" int ojphgpu_plan_restrict_resolution(ojphgpu_plan* plan, uint32_t skipped_res_for_data, uint32_t skipped_res_for_recon)
 {
   if (!plan) return OJPHGPU_E_INVALID;
   Plan& P = plan->plan;
   if (P.coded.size() != P.blocks.size()) return OJPHGPU_E_INVALID;           // a parsed codestream only
   if (skipped_res_for_data < skipped_res_for_recon) return OJPHGPU_E_INVALID; // ojph_codestream_local.cpp:886-890
-  if (skipped_res_for_data > P.p.num_decomps) return OJPHGPU_E_INVALID;       // :891-895
+  if (skipped_res_for_data > P.p.num_decomps) return OJPHGPU_E_INVALID;       // :891-895 (the COD's count)
+  for (uint32_t c = 0; c < P.p.num_comps; ++c)                                // a component with fewer decompositions than are
+    if (skipped_res_for_recon > P.style(c).L) return OJPHGPU_E_INVALID;       // dropped: the reference's arithmetic wraps there
+  if (skipped_res_for_data > P.max_decomps) return OJPHGPU_E_INVALID;
   P.skip_read = skipped_res_for_data; P.skip_recon = skipped_res_for_recon;
   // the reconstructed components: sub-sampling grows by 2^skip_recon (ojph_params.cpp:930-946)
   const uint64_t X1 = (uint64_t)P.p.image_x0 + P.p.width, Y1 = (uint64_t)P.p.image_y0 + P.p.height;

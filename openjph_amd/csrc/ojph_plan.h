@@ -13,6 +13,7 @@
 #ifndef OJPH_PLAN_H
 #define OJPH_PLAN_H
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -81,6 +82,18 @@ struct CompGeo {                // one image component on its own (sub-sampled) 
   uint32_t bit_depth; bool is_signed;
 };
 
+struct CodStyle {                // the COD, or the COC of one component, resolved (ojph_params_local.h:344-383)
+  uint32_t L = 5;               // decompositions
+  uint32_t lbw = 6, lbh = 6;    // log2 of the nominal code-block size
+  bool rev = false;
+  bool causal = false;          // vertically causal code-block style (foreign codestreams; set by the parser)
+  bool has_prec = false;        // Scod / Scoc bit 0: precinct sizes are listed
+  uint8_t pexp[36] = { 0 };     // PPx | PPy << 4 per resolution when has_prec
+  uint32_t rank = 0;            // COC: creation order (1..); 0 = this is the COD
+  uint32_t lpw(uint32_t r) const { return has_prec ? (pexp[r] & 15u) : 15u; }
+  uint32_t lph(uint32_t r) const { return has_prec ? (pexp[r] >> 4) : 15u; }
+};
+
 struct QuantSet {               // contents of a QCD / QCC marker segment (ojph_params_local.h:690-830)
   uint8_t sqcd = 0; uint32_t guard_bits = 0;
   std::vector<uint8_t> q8;      // reversible: exponent bytes as written
@@ -102,6 +115,16 @@ struct Plan {
   struct Comment { uint16_t rcom; std::vector<uint8_t> data; };
   std::vector<Comment> comments;   // user COM segments of the main header
   uint32_t ntx, nty;
+  CodStyle cod;                  // the main header's COD
+  std::vector<CodStyle> coc;     // per component; .rank != 0 = the component has a COC of its own
+  const CodStyle& style(uint32_t comp) const { return comp < coc.size() && coc[comp].rank ? coc[comp] : cod; }
+  uint32_t max_decomps = 0;      // over the components
+  // decompositions of a component that are synthesised / the top resolution whose blocks are decoded
+  uint32_t recon_decomps(uint32_t comp) const { return style(comp).L - skip_recon; }
+  uint32_t top_read_res(uint32_t comp) const { return std::min(max_decomps - skip_read, style(comp).L - skip_recon); }
+  // RC tile-part divisions number the parts c + r * num_comps; a component with fewer decompositions
+  // than the largest has no part (c, r > its own), the number stays unused (ojph_tile.cpp:637-652)
+  bool part_exists(uint32_t k) const { return tilepart_div != 3 || k / p.num_comps <= style(k % p.num_comps).L; }
   QuantSet qcd;                  // the main header's QCD
   std::vector<QuantSet> qcc;     // per component; .present = the component has a QCC of its own
   const QuantSet& quant(uint32_t comp) const { return comp < qcc.size() && qcc[comp].present ? qcc[comp] : qcd; }

@@ -87,11 +87,11 @@ void write_main_header(const Plan& P, ByteSink& s)
   }
   // CAP (ojph_params.cpp:968-989, Ccap from ojph_params_local.h:929-945 + get_MAGB :1615-1647)
   uint32_t B = 0;
-  auto magb = [&](const QuantSet& q) {              // param_qcd::get_MAGB walks the QCD and every QCC
-    if (p.reversible) {
+  auto magb = [&](const QuantSet& q) {              // param_qcd::get_MAGB walks the QCD and every QCC, each by its own style
+    if ((q.sqcd & 0x1F) == 0) {
       for (uint8_t e : q.q8) B = std::max<uint32_t>(B, (uint32_t)(e >> 3) + q.guard_bits - 1);
     } else {
-      uint32_t D = p.num_decomps;
+      uint32_t D = ((uint32_t)q.q16.size() - 1) / 3;
       for (size_t i = 0; i < q.q16.size(); ++i) {
         uint32_t nb = D - (i ? (uint32_t)(i - 1) / 3 : 0);
         B = std::max<uint32_t>(B, (uint32_t)(q.q16[i] >> 11) + q.guard_bits - nb);
@@ -101,35 +101,42 @@ void write_main_header(const Plan& P, ByteSink& s)
   magb(P.qcd);
   for (const QuantSet& q : P.qcc) if (q.present) magb(q);
   uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : 13 + (B >> 2));
-  uint32_t Ccap = (p.reversible ? 0u : 0x0020u) | Bp;
+  uint32_t Ccap = (P.cod.rev ? 0u : 0x0020u) | Bp;             // the COD's wavelet decides the bit
   s.u16(CAP); s.u16(8); s.u32(0x00020000); s.u16(Ccap);
   // COD (ojph_params.cpp:1035-1078)
-  bool prec = p.precinct_w && p.precinct_h;
-  s.u16(COD); s.u16(12 + (prec ? 1 + p.num_decomps : 0));
-  s.u8(prec ? 1 : 0); s.u8(p.prog_order); s.u16(1); s.u8(p.color_transform ? 1 : 0);
-  s.u8(p.num_decomps);
-  uint32_t lbw = 0, lbh = 0; while ((1u << lbw) < p.block_w) ++lbw; while ((1u << lbh) < p.block_h) ++lbh;
-  s.u8(lbw - 2); s.u8(lbh - 2); s.u8(0x40); s.u8(p.reversible ? 1 : 0);
-  if (prec) {
-    uint32_t a = 0, b = 0; while ((1u << a) < p.precinct_w) ++a; while ((1u << b) < p.precinct_h) ++b;
-    bool per_res = false;
-    for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
-    for (uint32_t i = 0; i <= p.num_decomps; ++i) s.u8(per_res ? p.precinct_exps[i] : (a | (b << 4)));
+  auto spcod = [&](const CodStyle& st) {
+    s.u8(st.L); s.u8(st.lbw - 2); s.u8(st.lbh - 2); s.u8(0x40); s.u8(st.rev ? 1 : 0);
+    if (st.has_prec) for (uint32_t i = 0; i <= st.L; ++i) s.u8(st.pexp[i]);
+  };
+  s.u16(COD); s.u16(12 + (P.cod.has_prec ? 1 + P.cod.L : 0));
+  s.u8(P.cod.has_prec ? 1 : 0); s.u8(p.prog_order); s.u16(1); s.u8(p.color_transform ? 1 : 0);
+  spcod(P.cod);
+  // COC of the components that have one, in the order they were created (:1081-1143)
+  {
+    std::vector<uint32_t> order;
+    for (uint32_t c = 0; c < p.num_comps && c < (uint32_t)P.coc.size(); ++c) if (P.coc[c].rank) order.push_back(c);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return P.coc[a].rank < P.coc[b].rank; });
+    const uint32_t cw = p.num_comps < 257 ? 1 : 2;
+    for (uint32_t c : order) {
+      const CodStyle& st = P.coc[c];
+      s.u16(COC); s.u16(8 + cw + (st.has_prec ? 1 + st.L : 0));
+      if (cw == 1) s.u8(c); else s.u16(c);
+      s.u8(st.has_prec ? 1 : 0);
+      spcod(st);
+    }
   }
   // QCD (ojph_params.cpp:1778-1819)
-  uint32_t nb = 1 + 3 * p.num_decomps;
-  s.u16(QCD);
-  if (p.reversible) { s.u16(3 + nb); s.u8(P.qcd.sqcd); for (uint8_t e : P.qcd.q8) s.u8(e); }
-  else { s.u16(3 + 2 * nb); s.u8(P.qcd.sqcd); for (uint16_t e : P.qcd.q16) s.u16(e); }
+  auto spqcd = [&](const QuantSet& q) { s.u8(q.sqcd); if ((q.sqcd & 0x1F) == 0) for (uint8_t e : q.q8) s.u8(e); else for (uint16_t e : q.q16) s.u16(e); };
+  auto qbytes = [](const QuantSet& q) { return (uint32_t)((q.sqcd & 0x1F) == 0 ? q.q8.size() : 2 * q.q16.size()); };
+  s.u16(QCD); s.u16(3 + qbytes(P.qcd)); spqcd(P.qcd);
   // QCC of the components that have one (ojph_params.cpp:1822-1887), in component order
   for (uint32_t c = 0; c < p.num_comps; ++c) {
     const QuantSet& q = P.qcc[c];
     if (!q.present) continue;
     const uint32_t cw = p.num_comps < 257 ? 1 : 2;
-    s.u16(QCC); s.u16(3 + cw + (p.reversible ? nb : 2 * nb));
+    s.u16(QCC); s.u16(3 + cw + qbytes(q));
     if (cw == 1) s.u8(c); else s.u16(c);
-    s.u8(q.sqcd);
-    if (p.reversible) for (uint8_t e : q.q8) s.u8(e); else for (uint16_t e : q.q16) s.u16(e);
+    spqcd(q);
   }
   // COM: the reference identifies itself; byte-identical output needs the same string
   // (ojph_codestream_local.cpp:678-696)
@@ -266,6 +273,7 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
     for (uint32_t k = 0; k < ppt; ++k) {
       const uint64_t b = part_bytes[(t - t0) * ppt + k];
       if (b + 14 > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
+      if (!P.part_exists(k)) { if (len_out) len_out[(t - t0) * ppt + k] = 0; continue; }   // length 0 = no such tile-part
       if (len_out) len_out[(t - t0) * ppt + k] = (uint32_t)b + 14;
       total += 14 + b;
     }
@@ -286,6 +294,7 @@ int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_blo
     uint32_t next_part = 0;                          // tile-parts are written in order, empty ones included
     auto open_parts_up_to = [&](uint32_t part) {
       for (; next_part <= part; ++next_part) {
+        if (!P.part_exists(next_part)) continue;
         u16(SOT); u16(10); u16(T.idx); u32((uint32_t)part_bytes[(t - t0) * ppt + next_part] + 14);
         *w++ = (uint8_t)next_part; *w++ = (uint8_t)ppt;
         u16(SOD);
@@ -356,7 +365,9 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   ByteSink hdr;
   write_main_header(P, hdr);
   size_t total = hdr.v.size();
-  const size_t nparts = P.tiles.size() * P.parts_per_tile;
+  size_t per_tile = 0;
+  for (uint32_t k = 0; k < P.parts_per_tile; ++k) per_tile += P.part_exists(k) ? 1 : 0;
+  const size_t nparts = P.tiles.size() * per_tile;
   if (P.p.tlm && 4 + 6 * nparts > 65535) return OJPHGPU_E_INVALID;
   if (P.p.tlm) total += 6 + 6 * nparts;
   *out_len = total;
@@ -368,7 +379,8 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
     u16(TLM); u16(4 + 6 * (uint32_t)nparts); *w++ = 0; *w++ = 0x60;
     for (size_t t = 0; t < P.tiles.size(); ++t)
-      for (uint32_t k = 0; k < P.parts_per_tile; ++k) { u16((uint32_t)t); u32(tile_part_len[t * P.parts_per_tile + k]); }
+      for (uint32_t k = 0; k < P.parts_per_tile; ++k)
+        if (P.part_exists(k)) { u16((uint32_t)t); u32(tile_part_len[t * P.parts_per_tile + k]); }
   }
   return OJPHGPU_OK;
 }
@@ -583,6 +595,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   struct Qcc { uint32_t comp; QuantSet q; };
   std::vector<Qcc> qccs;
   bool use_sop = false, use_eph = false;
+  uint32_t num_cocs = 0;
   for (;;) {
     if (!r.ok(4)) return OJPHGPU_E_CODESTREAM;
     uint32_t m = r.u16();
@@ -659,8 +672,31 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
       qccs.push_back(k);
     } else if (m == TLM) {
       p.tlm = 1;
-    } else if (m == COC || m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
-      return OJPHGPU_E_INVALID;                                    // per-component / Part-2 markers: later
+    } else if (m == COC) {                                         // param_cod::read_coc (ojph_params.cpp:1206-1276)
+      if (!have_siz) return OJPHGPU_E_CODESTREAM;
+      const uint32_t cw = p.num_comps < 257 ? 1 : 2;
+      if (L < 8 + cw) return OJPHGPU_E_CODESTREAM;
+      const uint32_t comp = cw == 1 ? r.u8() : r.u16();
+      const uint32_t scoc = r.u8(), nd = r.u8(), xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
+      if (nd & 0x80) return OJPHGPU_E_INVALID;                     // DFS-defined decomposition: Part 2, not supported
+      if (nd > 32 || xcb > 8 || ycb > 8 || xcb + ycb > 8 || (style & 0x40) != 0x40 || (style & 0xB7) != 0) return OJPHGPU_E_CODESTREAM;   // :1240-1249
+      if (wt > 1) return OJPHGPU_E_INVALID;                        // ATK wavelets: not supported
+      if (L != 8 + cw + ((scoc & 1) ? 1 + nd : 0)) return OJPHGPU_E_CODESTREAM;
+      if (comp < p.num_comps) {                                    // one for a component that does not exist is only reported (:803-808)
+        if (comp >= OJPHGPU_MAX_COC_COMPS) return OJPHGPU_E_INVALID;   // per-component styles: first 16 components
+        ojphgpu_coc& k = p.coc[comp];
+        if (k.rank) return OJPHGPU_E_CODESTREAM;                   // two COCs for one component (:809-812)
+        k.rank = (uint8_t)++num_cocs; k.reversible = wt == 1; k.num_decomps = (uint8_t)nd;
+        k.log_block_w = (uint8_t)(xcb + 2); k.log_block_h = (uint8_t)(ycb + 2);
+        k.has_precincts = scoc & 1; k.reserved[0] = (style & 0x08u) ? 1 : 0;
+        if (scoc & 1)
+          for (uint32_t i = 0; i <= nd; ++i) {
+            k.precinct_exps[i] = (uint8_t)r.u8();
+            if (i && ((k.precinct_exps[i] & 0xF) == 0 || (k.precinct_exps[i] >> 4) == 0)) return OJPHGPU_E_CODESTREAM;   // :1256-1264
+          }
+      }
+    } else if (m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
+      return OJPHGPU_E_INVALID;                                    // Part-2 / unsupported markers
     }
     r.pos = next;
   }
@@ -670,19 +706,22 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   int rc = build_plan(p, h->plan);
   if (rc != OJPHGPU_OK) { delete h; return rc; }
   Plan& P = h->plan;
-  // the codestream's own quantisation parameters override the derived ones
+  // the codestream's own quantisation parameters override the derived ones; a reversibly transformed
+  // component needs reversible-style steps and the other way round (the reference would read the
+  // wrong union member; here the codestream is refused)
   P.qcd.sqcd = sqcd; P.qcd.guard_bits = sqcd >> 5;
-  P.qcd.q8.clear(); P.qcd.q16.clear();
-  if (p.reversible) { if ((sqcd & 0x1F) != 0 || q8.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.qcd.q8 = q8; }
-  else { if ((sqcd & 0x1F) != 2 || q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; } P.qcd.q16 = q16; }
+  P.qcd.q8 = q8; P.qcd.q16 = q16;
+  if (q8.empty() && q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; }
   P.qcc.assign(p.num_comps, QuantSet());                       // only the markers of the codestream count
   for (const Qcc& k : qccs) {
-    if ((k.q.sqcd & 0x1F) != (p.reversible ? 0u : 2u)) { delete h; return OJPHGPU_E_CODESTREAM; }
+    if (P.qcc[k.comp].present) { delete h; return OJPHGPU_E_CODESTREAM; }   // two QCCs for one component (:827-830)
     P.qcc[k.comp] = k.q;
   }
+  for (uint32_t c = 0; c < p.num_comps; ++c)
+    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { delete h; return OJPHGPU_E_CODESTREAM; }
   for (Band& B : P.bands) {
     B.K_max = band_Kmax(P, B.comp, B.res, B.band);
-    if (!p.reversible) {
+    if (!P.style(B.comp).rev) {
       float dlt = band_delta(P, B.comp, B.res, B.band);
       dlt /= (float)(1u << (31 - B.K_max));
       B.delta = dlt; B.delta_inv = 1.0f / dlt;
@@ -690,6 +729,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   }
   P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
   std::vector<size_t> next_pkt(P.tiles.size(), 0);
+  std::vector<uint32_t> next_part(P.tiles.size(), 0);
   int status = OJPHGPU_OK;
   // tile-parts
   // What a truncated file means follows codestream::read (ojph_codestream_local.cpp:912-1113): the
@@ -702,8 +742,9 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     uint32_t m = r.u16();
     if (m == EOC) break;
     if (m != SOT || !r.ok(10)) { status = OJPHGPU_E_CODESTREAM; break; }
-    uint32_t lsot = r.u16(), isot = r.u16(), psot = r.u32(); r.u8(); r.u8();
+    uint32_t lsot = r.u16(), isot = r.u16(), psot = r.u32(); const uint32_t tpsot = r.u8(); r.u8();
     if (lsot != 10 || isot >= P.tiles.size()) { status = OJPHGPU_E_CODESTREAM; break; }
+    if (tpsot != next_part[isot]++ && !resilient) { status = OJPHGPU_E_CODESTREAM; break; }   // "wrong tile part index" (ojph_tile.cpp:780-787)
     const size_t tp_nominal = psot ? sot_pos + psot : (len >= 2 ? len - 2 : len);   // where Psot says the tile-part ends
     const size_t tp_end = std::min(tp_nominal, len);
     bool bad = false;

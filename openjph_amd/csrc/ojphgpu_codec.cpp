@@ -77,106 +77,130 @@ struct HostBuf {
   void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
 };
 
-struct LevelBatch { uint32_t first, count, max_w, max_h; };
+// One DWT launch: the levels `depth` steps below the top of their component, of the components with
+// the same wavelet.  Without COCs that is one batch per resolution; with them a component may have
+// fewer levels than another, or the other wavelet, and a depth splits in two.
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; };
 
-// DWT descriptors grouped by resolution so that one launch handles every tile-component
+// DWT descriptors grouped so that one launch handles every tile-component
 struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
+
+template <typename F>
+void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, F f)
+{
+  for (const ojphgpu_level_info& lv : P.levels) {
+    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev) continue;
+    const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
+    if (L > depth && lv.res == L - depth) f(lv);
+  }
+}
+
+uint32_t max_recon_decomps(const Plan& P)
+{
+  uint32_t m = 0;
+  for (uint32_t c = 0; c < P.p.num_comps; ++c) m = std::max(m, P.recon_decomps(c));
+  return m;
+}
 
 void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
 {
-  const uint32_t L = P.p.num_decomps - P.skip_recon;       // reduced-resolution decoding stops below the top levels
   descs.clear(); batches.clear();
-  for (uint32_t r = L; r >= 1; --r) {
-    LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0 };
-    for (const ojphgpu_level_info& lv : P.levels) {
-      if (lv.res != r || !tr.has(lv.tile)) continue;
-      ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
-      d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
-      d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
-      d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
-      descs.push_back(d);
-      b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
+  const uint32_t depths = max_recon_decomps(P);
+  for (uint32_t depth = 0; depth < depths; ++depth)
+    for (int rev = 0; rev < 2; ++rev) {
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1 };
+      for_levels_of(P, tr, depth, rev != 0, [&](const ojphgpu_level_info& lv) {
+        ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
+        d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
+        d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
+        d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
+        descs.push_back(d);
+        b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
+      });
+      if (b.count) batches.push_back(b);
     }
-    batches.push_back(b);
-  }
 }
 
-// Descriptors of the top DWT level with the un-decomposed plane addressed inside the image-sized
-// int32 component planes (for ojphgpu_dwt_forward_image / _inverse_image).  Empty when the fused
-// path does not apply (colour transform, or no decomposition).
-void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojphgpu_dwt_desc>& descs, const LevelBatch& top,
+// Descriptors of the top DWT level of every component with the un-decomposed plane addressed inside
+// the image-sized component planes (for ojphgpu_dwt_forward_image / _inverse_image); batch.img_first
+// points at them.  None when the fused path does not apply (colour transform).
+void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches,
                              std::vector<ojphgpu_dwt_desc>& out)
 {
   out.clear();
-  const uint32_t L = P.p.num_decomps - P.skip_recon;
-  if (P.p.color_transform || L == 0) return;
-  size_t k = 0;
-  for (const ojphgpu_level_info& lv : P.levels) {
-    if (lv.res != L || !tr.has(lv.tile)) continue;
-    ojphgpu_dwt_desc d = descs[top.first + k++];
-    const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
-    const CompGeo& g = P.comps[lv.comp];
-    const Rect& rr = P.ress[tc.res[L]].r;                   // the tile-component at the reconstructed resolution
-    d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
-    d.src_pitch = g.w;
-    d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
-    out.push_back(d);
+  if (P.p.color_transform) return;
+  for (LevelBatch& b : batches) {
+    if (b.depth != 0 || b.count == 0) continue;
+    b.img_first = (int)out.size();
+    size_t k = 0;
+    for_levels_of(P, tr, 0, b.rev, [&](const ojphgpu_level_info& lv) {
+      ojphgpu_dwt_desc d = descs[b.first + k++];
+      const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
+      const CompGeo& g = P.comps[lv.comp];
+      const Rect& rr = P.ress[tc.res[lv.res]].r;              // the tile-component at the reconstructed resolution
+      d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
+      d.src_pitch = g.w;
+      d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
+      out.push_back(d);
+    });
   }
 }
 
-void build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
+// One descriptor per tile and component, in that order; a component whose conversion is fused into
+// its top DWT level (no colour transform, at least one level) gets an empty one.  Returns whether
+// any component is left for the conversion kernels.
+bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
 {
   descs.clear(); max_w = max_h = 0;
-  const uint32_t L = P.p.num_decomps - P.skip_recon;
+  bool any = false;
   for (const Tile& t : P.tiles) {
     if (!tr.has(t.idx)) continue;
     for (uint32_t c = 0; c < P.p.num_comps; ++c) {
+      const uint32_t L = P.recon_decomps(c);
       const TileComp& tc = P.tcomps[t.comps[c]];
       const Resolution& R = P.ress[tc.res[L]];
       ojphgpu_convert_desc d; memset(&d, 0, sizeof(d));
       if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
       else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
       const CompGeo& g = P.comps[c];
-      d.w = R.r.w; d.h = R.r.h; d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
-      d.img_pitch = g.w; d.img_off = g.frame_off; d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u);
+      d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
+      d.img_pitch = g.w; d.img_off = g.frame_off;
+      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u);   // 0x200: bit 10 says which conversion
+      if (P.p.color_transform || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
   }
+  return any;
 }
 
 // Frame batches: the same plan applied to `nframes` independent frames in one set of launches
 // (config C5: a batch of independent 4K frames).  Frame f lives f * arena_elems further in the arena
-// and f * (comps * width * height) further in the image buffer; descriptors are simply replicated.
-void replicate_levels(std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches, uint32_t nframes, uint64_t arena_elems)
+// and f * frame_elems further in the image buffer; descriptors are simply replicated, batch by batch.
+void replicate_levels(std::vector<ojphgpu_dwt_desc>& descs, std::vector<ojphgpu_dwt_desc>& img_descs, std::vector<LevelBatch>& batches,
+                      uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
 {
   if (nframes <= 1) return;
-  std::vector<ojphgpu_dwt_desc> out; std::vector<LevelBatch> nb;
+  std::vector<ojphgpu_dwt_desc> out, iout; std::vector<LevelBatch> nb;
   for (const LevelBatch& b : batches) {
-    LevelBatch n{ (uint32_t)out.size(), b.count * nframes, b.max_w, b.max_h };
+    LevelBatch n = b;
+    n.first = (uint32_t)out.size(); n.count = b.count * nframes;
+    if (b.img_first >= 0) n.img_first = (int)iout.size();
     for (uint32_t f = 0; f < nframes; ++f)
       for (uint32_t i = 0; i < b.count; ++i) {
-        ojphgpu_dwt_desc d = descs[b.first + i];
         const uint64_t o = (uint64_t)f * arena_elems;
+        ojphgpu_dwt_desc d = descs[b.first + i];
         d.src_off += o; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
         out.push_back(d);
+        if (b.img_first >= 0) {
+          d = img_descs[(size_t)b.img_first + i];
+          d.src_off += (uint64_t)f * frame_elems; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
+          iout.push_back(d);
+        }
       }
     nb.push_back(n);
   }
-  descs.swap(out); batches.swap(nb);
-}
-
-void replicate_image_levels(std::vector<ojphgpu_dwt_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
-{
-  if (nframes <= 1 || descs.empty()) return;
-  const size_t n = descs.size();
-  for (uint32_t f = 1; f < nframes; ++f)
-    for (size_t i = 0; i < n; ++i) {
-      ojphgpu_dwt_desc d = descs[i];
-      const uint64_t o = (uint64_t)f * arena_elems;
-      d.src_off += (uint64_t)f * frame_elems; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
-      descs.push_back(d);
-    }
+  descs.swap(out); img_descs.swap(iout); batches.swap(nb);
 }
 
 void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
@@ -195,10 +219,9 @@ void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nfram
 std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
 {
   std::vector<uint32_t> ids;
-  const uint32_t top = P.p.num_decomps - P.skip_read;      // resolutions above are not decoded: their bands stay zero
   for (size_t i = 0; i < P.blocks.size(); ++i) {
     const Band& B = P.bands[P.blocks[i].band];
-    if (tr.has(B.tile) && B.res <= top) ids.push_back((uint32_t)i);
+    if (tr.has(B.tile) && B.res <= P.top_read_res(B.comp)) ids.push_back((uint32_t)i);   // resolutions above are not decoded: their bands stay zero
   }
   return ids;
 }
@@ -263,7 +286,7 @@ struct ojphgpu_encoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, scratch, out, results, counters;
-  bool fused_convert = false;
+  bool need_convert = false;                       // some component is not converted inside its top DWT level
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
   TileRange tiles{ 0, 0 };
@@ -341,15 +364,13 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   const uint64_t frame_elems = P.frame_elems;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, e->batches);
   std::vector<ojphgpu_dwt_desc> idd;
-  if (!e->batches.empty()) build_image_level_descs(P, tr, dd, e->batches.front(), idd);
-  e->fused_convert = !idd.empty();
-  replicate_levels(dd, e->batches, nframes, P.arena_elems);
-  replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
-  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
+  build_image_level_descs(P, tr, dd, e->batches, idd);
+  replicate_levels(dd, idd, e->batches, nframes, P.arena_elems, frame_elems);
+  std::vector<ojphgpu_convert_desc> cd; e->need_convert = build_convert_descs(P, tr, cd, e->conv_max_w, e->conv_max_h);
   replicate_converts(cd, nframes, P.arena_elems, P.frame_elems);
   e->block_ids = blocks_of_tiles(P, tr);
-  if (nframes == 1 && P.p.num_decomps >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
-    auto top = [&](uint32_t id) { return P.bands[P.blocks[id].band].res == P.p.num_decomps; };
+  if (nframes == 1 && max_recon_decomps(P) >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
+    auto top = [&](uint32_t id) { const Band& B = P.bands[P.blocks[id].band]; return B.res == P.style(B.comp).L; };
     auto mid = std::stable_partition(e->block_ids.begin(), e->block_ids.end(), top);
     e->n_top = (uint32_t)(mid - e->block_ids.begin());
     if (e->n_top == 0 || e->n_top == e->block_ids.size()) e->n_top = 0;
@@ -364,7 +385,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     samples += (uint64_t)k.r.w * k.r.h;
     ojphgpu_cb_desc& d = bd[i]; memset(&d, 0, sizeof(d));
     d.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; d.pitch = B.pitch;
-    d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)P.p.reversible;
+    d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)(P.style(B.comp).rev ? 1 : 0);
     d.missing_msbs = (uint8_t)(B.K_max - 1); d.num_passes = 1; d.delta = B.delta;
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
@@ -417,7 +438,7 @@ static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
   HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
   T.start(s);
   int rc = OJPHGPU_OK;
-  if (!e->fused_convert) {
+  if (e->need_convert) {
     const int sp = T.begin(SP_CONVERT, s);
     rc = container == 16
        ? ojphgpu_convert_forward16(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
@@ -430,30 +451,37 @@ static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
   const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)e->cb_descs.p;
   ojphgpu_cb_result* res = (ojphgpu_cb_result*)e->results.p;
   uint32_t* cnt = (uint32_t*)e->counters.p;
-  for (const LevelBatch& b : e->batches) {
+  bool forked = false;
+  auto fork_top = [&]() -> int {                            // the top resolution's blocks are ready to be coded
+    forked = true;
+    HIPCHK(hipEventRecord(e->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    const int sh = T.begin(SP_HT_ENC, e->side);
+    int r2 = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
+                                       e->out_cap, res, cnt, cnt + 1, e->widths_top);
+    if (r2) return r2;
+    T.end(sh, e->side);
+    HIPCHK(hipEventRecord(e->ev_join, e->side));
+    return OJPHGPU_OK;
+  };
+  for (size_t i = 0; i < e->batches.size(); ++i) {
+    const LevelBatch& b = e->batches[i];
     const int sp = T.begin(SP_DWT, s);
-    if (e->fused_convert && &b == &e->batches.front())      // level shift / int->float applied in the loads
+    if (b.img_first >= 0) {                                 // level shift / int->float applied in the loads
+      ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
+      const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)e->img_descs.p + b.img_first;
       rc = container == 16
-         ? ojphgpu_dwt_forward_image16(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
-                                       (const uint16_t*)d_image, e->arena.p)
-         : ojphgpu_dwt_forward_image(s, &P.p, (const ojphgpu_dwt_desc*)e->img_descs.p, b.count, b.max_w, b.max_h,
-                                     (const int32_t*)d_image, e->arena.p);
-    else
-      rc = ojphgpu_dwt_forward(s, (int)P.p.reversible, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
+         ? ojphgpu_dwt_forward_image16(s, &pp, idesc, b.count, b.max_w, b.max_h, (const uint16_t*)d_image, e->arena.p)
+         : ojphgpu_dwt_forward_image(s, &pp, idesc, b.count, b.max_w, b.max_h, (const int32_t*)d_image, e->arena.p);
+    } else
+      rc = ojphgpu_dwt_forward(s, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
     if (rc) return rc;
     T.end(sp, s);
-    if (e->n_top && &b == &e->batches.front()) {            // fork: the top resolution's blocks are ready to be coded
-      HIPCHK(hipEventRecord(e->ev_fork, s));
-      HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-      const int sh = T.begin(SP_HT_ENC, e->side);
-      rc = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
-                                     e->out_cap, res, cnt, cnt + 1, e->widths_top);
-      if (rc) return rc;
-      T.end(sh, e->side);
-      HIPCHK(hipEventRecord(e->ev_join, e->side));
-    }
+    const bool top_done = b.depth == 0 && (i + 1 == e->batches.size() || e->batches[i + 1].depth != 0);
+    if (e->n_top && top_done && (rc = fork_top()) != 0) return rc;
   }
+  if (e->n_top && !forked && (rc = fork_top()) != 0) return rc;
   const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
   const int sh = T.begin(SP_HT_ENC, s);
   rc = ojphgpu::ht_encode_launch(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p,
@@ -607,7 +635,7 @@ struct ojphgpu_decoder {
   uint32_t n_low = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool fused_convert = false;
+  bool need_convert = false;                       // some component is not converted inside its top DWT level
   TileRange tiles{ 0, 0 };
   uint32_t nframes = 1;
   bool any_refine = false;                         // some block carries SigProp / MagRef passes
@@ -672,7 +700,8 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
         Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
         Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||
         Q.p.color_transform != P.p.color_transform || Q.p.tile_w != P.p.tile_w || Q.p.tile_h != P.p.tile_h ||
-        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h || Q.p.qstep != P.p.qstep)
+        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h || Q.p.qstep != P.p.qstep ||
+        memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
       return OJPHGPU_E_INVALID;
   }
   HIPCHK(hipSetDevice(device));
@@ -688,12 +717,10 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   const uint64_t frame_elems = P.frame_elems;
   std::vector<ojphgpu_dwt_desc> dd; build_level_batches(P, tr, dd, d->batches);
   std::vector<ojphgpu_dwt_desc> idd;
-  if (!d->batches.empty()) build_image_level_descs(P, tr, dd, d->batches.front(), idd);
-  d->fused_convert = !idd.empty();
-  replicate_levels(dd, d->batches, nframes, P.arena_elems);
-  replicate_image_levels(idd, nframes, P.arena_elems, frame_elems);
+  build_image_level_descs(P, tr, dd, d->batches, idd);
+  replicate_levels(dd, idd, d->batches, nframes, P.arena_elems, frame_elems);
   std::reverse(d->batches.begin(), d->batches.end());                 // synthesis: lowest resolution first
-  std::vector<ojphgpu_convert_desc> cd; build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
+  std::vector<ojphgpu_convert_desc> cd; d->need_convert = build_convert_descs(P, tr, cd, d->conv_max_w, d->conv_max_h);
   replicate_converts(cd, nframes, P.arena_elems, P.frame_elems);
   std::vector<uint32_t> ids = blocks_of_tiles(P, tr);
   // Overlap of the lower synthesis levels with the block decoder: the blocks below the top
@@ -702,9 +729,9 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   // blocks (3/4 of the samples) on the main one.  Prep and step 1 stay single launches over all blocks:
   // step 1 costs one serial chain however few blocks it is given, splitting it would pay that twice
   // (measured: 0.96 vs 0.91 ms at 8K with every stage split in two).
-  const uint32_t top_res = P.p.num_decomps - P.skip_recon;
-  if (nframes == 1 && top_res >= 2 && d->batches.size() >= 2 && getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
-    auto low = [&](uint32_t id) { return P.bands[P.blocks[id].band].res < top_res; };
+  if (nframes == 1 && max_recon_decomps(P) >= 2 && d->batches.size() >= 2 && d->batches.front().depth > 0 &&
+      getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
+    auto low = [&](uint32_t id) { const Band& B = P.bands[P.blocks[id].band]; return B.res < P.recon_decomps(B.comp); };
     auto mid = std::stable_partition(ids.begin(), ids.end(), low);
     d->n_low = (uint32_t)(mid - ids.begin());
     int prio_lo = 0, prio_hi = 0;                         // the short launches of the side stream go first at the dispatcher
@@ -726,7 +753,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
     ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i]; memset(&o, 0, sizeof(o));
     o.coef_off = (uint64_t)f * P.arena_elems + B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
-    o.reversible = (uint8_t)((P.p.reversible ? 1u : 0u) | ((Q.p.reserved[0] & 1u) << 1));     // bit 1: vertically causal
+    o.reversible = (uint8_t)((P.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) d->any_refine = true;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
@@ -840,29 +867,34 @@ static int decoder_run(ojphgpu_decoder* d, void* d_image, int container)
     HIPCHK(hipEventRecord(d->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
   }
+  bool joined = false;
+  auto finish_blocks = [&]() -> int {                       // meanwhile, on the main stream: the top resolution's blocks
+    joined = true;
+    HIPCHK(hipEventRecord(d->ev_join, d->side));
+    int r2 = decode_samples(d, s, d->n_low, d->nblocks - d->n_low);
+    if (r2) return r2;
+    HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));           // join before the top synthesis level
+    return OJPHGPU_OK;
+  };
   for (const LevelBatch& b : d->batches) {
-    const bool last = &b == &d->batches.back();
-    hipStream_t ls = (d->n_low && !last) ? d->side : s;
-    if (last && d->n_low) {                                 // meanwhile, on the main stream: the top resolution's blocks
-      HIPCHK(hipEventRecord(d->ev_join, d->side));
-      rc = decode_samples(d, s, d->n_low, d->nblocks - d->n_low);
-      if (rc) return rc;
-      HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));         // join before the top synthesis level
-    }
+    const bool top = b.depth == 0;                          // the last level of its components (there may be two such launches)
+    hipStream_t ls = (d->n_low && !top) ? d->side : s;
+    if (top && d->n_low && !joined && (rc = finish_blocks()) != 0) return rc;
     const int sp = T.begin(SP_DWT, ls);
-    if (d->fused_convert && last)                           // float->int / level shift applied in the stores
+    if (b.img_first >= 0) {                                 // float->int / level shift applied in the stores
+      ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
+      const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)d->img_descs.p + b.img_first;
       rc = container == 16
-         ? ojphgpu_dwt_inverse_image16(ls, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
-                                       (uint16_t*)d_image, d->arena.p)
-         : ojphgpu_dwt_inverse_image(ls, &P.p, (const ojphgpu_dwt_desc*)d->img_descs.p, b.count, b.max_w, b.max_h,
-                                     (int32_t*)d_image, d->arena.p);
-    else
-      rc = ojphgpu_dwt_inverse(ls, (int)P.p.reversible, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
+         ? ojphgpu_dwt_inverse_image16(ls, &pp, idesc, b.count, b.max_w, b.max_h, (uint16_t*)d_image, d->arena.p)
+         : ojphgpu_dwt_inverse_image(ls, &pp, idesc, b.count, b.max_w, b.max_h, (int32_t*)d_image, d->arena.p);
+    } else
+      rc = ojphgpu_dwt_inverse(ls, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;
     T.end(sp, ls);
   }
-  if (!d->fused_convert) {
+  if (d->n_low && !joined && (rc = finish_blocks()) != 0) return rc;
+  if (d->need_convert) {
     const int sp = T.begin(SP_CONVERT, s);
     rc = container == 16
        ? ojphgpu_convert_inverse16(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,

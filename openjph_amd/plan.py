@@ -15,8 +15,11 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                 downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts="", bit_depths=None, signs=None,
-                qfactor=0):
-    """width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
+                qfactor=0, coc=None):
+    """coc: {component: dict(reversible=, num_decomps=, block=(w, h), precincts=[(w, h), ...])} -- COC
+    marker segments in the order of the dict (param_cod's comp_idx setters); whatever a dict leaves
+    out keeps the reference's COC defaults (9/7, 5 decompositions, 64x64, no precincts), NOT the COD's.
+    width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
     (dx, dy) per component (param_siz::set_component), default 1,1; tileparts: "", "R", "C" or "RC"
     (codestream::set_tilepart_divisions); bit_depths / signs: per-component lists where they differ
     from bit_depth / is_signed; qfactor: 1..100 (param_qcd::set_qfactor), 0 = not set."""
@@ -43,6 +46,21 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
         p.comp_sign[c] = 2 if sg else 1
     p.image_x0, p.image_y0 = image_offset
     p.tile_x0, p.tile_y0 = tile_offset
+    for rank, (c, st) in enumerate((coc or {}).items()):
+        if not 0 <= int(c) < 16:
+            raise ValueError("per-component coding styles can be given for the first 16 components")
+        k = p.coc[int(c)]
+        k.rank = rank + 1
+        k.reversible = int(bool(st.get("reversible", False)))
+        k.num_decomps = int(st.get("num_decomps", 5))
+        bw, bh = st.get("block", (64, 64))
+        k.log_block_w, k.log_block_h = int(bw).bit_length() - 1, int(bh).bit_length() - 1
+        pl = st.get("precincts")
+        if pl:
+            k.has_precincts = 1
+            for i in range(k.num_decomps + 1):
+                pw, ph = pl[min(i, len(pl) - 1)]
+                k.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
     if downsampling:
         if len(downsampling) > 16:
             raise ValueError("sub-sampling factors can be given for the first 16 components")
@@ -118,6 +136,14 @@ class Plan:
         bd, sg = C.c_uint32(), C.c_uint32()
         check(self._lib.ojphgpu_plan_comp_format(self.handle, comp, C.byref(bd), C.byref(sg)))
         return int(bd.value), bool(sg.value)
+
+    def comp_style(self, comp):
+        """coding style of component `comp` (its COC, else the COD): dict(num_decomps, reversible,
+        log_block=(w, h), has_coc, recon_decomps = levels left after restrict_resolution)"""
+        out = (C.c_uint32 * 8)()
+        check(self._lib.ojphgpu_plan_comp_style(self.handle, comp, out))
+        return dict(num_decomps=int(out[0]), reversible=bool(out[1]), log_block=(int(out[2]), int(out[3])),
+                    has_coc=bool(out[4]), recon_decomps=int(out[5]))
 
     @property
     def frame_elems(self):

@@ -53,6 +53,11 @@ struct ref_params {
   uint32_t tilepart_div;         // bit 0: tile-parts at resolutions, bit 1: at components
   uint8_t  comp_depth[16], comp_sign[16];   // per component where it differs: depth (0 = bit_depth), 1 unsigned / 2 signed (0 = is_signed)
   uint32_t qfactor;              // 0 = not set
+  // COC marker segments (param_cod's comp_idx setters).  Entry k describes the k-th component that gets
+  // one, in creation order; mask says which setters are called (1 decompositions, 2 block size,
+  // 4 precincts, 8 reversible) -- what is not set keeps the library's COC defaults
+  struct { uint8_t comp, mask, reversible, num_decomps, log_bw, log_bh, pad[2]; uint8_t precinct_exps[36]; } coc[16];
+  uint32_t num_coc;
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -113,7 +118,19 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
       std::vector<ojph::size> ps(p->num_decomps + 1, ojph::size(p->precinct_w, p->precinct_h));
       cod.set_precinct_size((int)ps.size(), ps.data());
     }
-    if (!p->reversible && p->qstep > 0.0f)
+    for (uint32_t k = 0; k < p->num_coc && k < 16; ++k) {
+      const auto& q = p->coc[k];
+      if (q.mask & 1) cod.set_num_decomposition(q.comp, q.num_decomps);
+      if (q.mask & 2) cod.set_block_dims(q.comp, 1u << q.log_bw, 1u << q.log_bh);
+      if (q.mask & 4) {
+        const uint32_t nd = cod.get_num_decompositions(q.comp);
+        std::vector<ojph::size> ps;
+        for (uint32_t i = 0; i <= nd; ++i) ps.push_back(ojph::size(1u << (q.precinct_exps[i] & 15), 1u << (q.precinct_exps[i] >> 4)));
+        cod.set_precinct_size(q.comp, (int)ps.size(), ps.data());
+      }
+      if (q.mask & 8) cod.set_reversible(q.comp, q.reversible != 0);
+    }
+    if (p->qstep > 0.0f && (!p->reversible || p->num_coc))
       cs.access_qcd().set_irrev_quant(p->qstep);
     if (p->qfactor) cs.access_qcd().set_qfactor((ojph::ui8)p->qfactor);
     cs.set_planar(p->planar != 0);

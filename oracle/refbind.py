@@ -12,6 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
 
 
+class RefCoc(C.Structure):
+    _fields_ = [("comp", C.c_uint8), ("mask", C.c_uint8), ("reversible", C.c_uint8), ("num_decomps", C.c_uint8),
+                ("log_bw", C.c_uint8), ("log_bh", C.c_uint8), ("pad", C.c_uint8 * 2), ("precinct_exps", C.c_uint8 * 36)]
+
+
 class RefParams(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32), ("num_comps", C.c_uint32),
@@ -29,6 +34,7 @@ class RefParams(C.Structure):
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
         ("tilepart_div", C.c_uint32),
         ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16), ("qfactor", C.c_uint32),
+        ("coc", RefCoc * 16), ("num_coc", C.c_uint32),
     ]
 
 
@@ -75,7 +81,7 @@ class Ref:
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
                planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None, tileparts="",
-               profile=None, com=None, bit_depths=None, signs=None, qfactor=0):
+               profile=None, com=None, bit_depths=None, signs=None, qfactor=0, coc=None):
         """planes: int32 array [num_comps, H, W], or a list of per-component 2-D arrays when the
         components are sub-sampled (then size=(W, H) is the image size on the reference grid).
         Returns codestream bytes."""
@@ -105,6 +111,22 @@ class Ref:
         for c, sg in enumerate(signs or []):
             p.comp_sign[c] = 2 if sg else 1
         p.qfactor = int(qfactor)
+        for k, (c, st) in enumerate((coc or {}).items()):      # only the setters the dict names are called
+            q = p.coc[k]
+            q.comp = int(c)
+            if "num_decomps" in st:
+                q.mask |= 1; q.num_decomps = int(st["num_decomps"])
+            if "block" in st:
+                q.mask |= 2; q.log_bw, q.log_bh = st["block"][0].bit_length() - 1, st["block"][1].bit_length() - 1
+            if st.get("precincts"):
+                q.mask |= 4
+                nd = int(st.get("num_decomps", 5))
+                for i in range(nd + 1):
+                    pw, ph = st["precincts"][min(i, len(st["precincts"]) - 1)]
+                    q.precinct_exps[i] = (pw.bit_length() - 1) | ((ph.bit_length() - 1) << 4)
+            if "reversible" in st:
+                q.mask |= 8; q.reversible = int(bool(st["reversible"]))
+            p.num_coc = k + 1
         for c, (dx, dy) in enumerate(downsampling or []):
             p.comp_dx[c], p.comp_dy[c] = dx, dy
         ptrs = (C.c_void_p * nc)(*[planes[c].ctypes.data for c in range(nc)])

@@ -21,8 +21,7 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
     tiles=(first, count) restricts the work to a run of tiles (sharding tests)."""
     p = plan.params
     comps = [plan.comp_info(c) for c in range(p.num_comps)]
-    rev = bool(p.reversible)
-    dt = np.int32 if rev else np.float32
+    revs = [plan.comp_style(c)["reversible"] for c in range(p.num_comps)]      # per component (COC)
     arena = np.zeros(plan.arena_elems, np.uint32)
     lib = ob.lib()
     t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
@@ -33,7 +32,7 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]           # position inside the component's own plane
             src = np.ascontiguousarray(image[c][y0:y0 + h, x0:x0 + w], dtype=np.int32)
             bd, sg = plan.comp_format(c)
-            if rev:
+            if revs[c]:
                 shift = 0 if sg else -(1 << (bd - 1))
                 dst = src + shift
             else:
@@ -43,16 +42,18 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
         if p.color_transform:
             r, g, b = [np.ascontiguousarray(pl[4]) for pl in planes[:3]]
             y = np.empty_like(r); cb = np.empty_like(r); cr = np.empty_like(r)
-            f = lib.ojo_rct_fwd if rev else lib.ojo_ict_fwd
+            f = lib.ojo_rct_fwd if revs[0] else lib.ojo_ict_fwd
             f(r.ctypes.data, g.ctypes.data, b.ctypes.data, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.size)
             for i, v in enumerate((y, cb, cr)):
                 planes[i] = planes[i][:4] + (v,)
-        for off, pitch, w, h, v in planes:
-            _view(arena, off, pitch, w, h, dt)[:] = v
+        for c, (off, pitch, w, h, v) in enumerate(planes):
+            _view(arena, off, pitch, w, h, np.int32 if revs[c] else np.float32)[:] = v
     for lv in plan.levels:
         w, h = int(lv["w"]), int(lv["h"])
         if w == 0 or h == 0 or not (t_first <= int(lv["tile"]) < t_first + t_count):
             continue
+        rev = revs[int(lv["comp"])]
+        dt = np.int32 if rev else np.float32
         src = np.ascontiguousarray(_view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt))
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
         ll, hl, lh, hh = (ob.dwt53_fwd if rev else ob.dwt97_fwd)(src, xe, ye)
@@ -68,7 +69,7 @@ def quantise_block(plan, arena, k):
     band = plan.bands[int(blk["band"])]
     w, h = int(blk["w"]), int(blk["h"])
     off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
-    rev = bool(plan.params.reversible)
+    rev = plan.comp_style(int(band["comp"]))["reversible"]
     raw = np.ascontiguousarray(_view(arena, off, int(band["pitch"]), w, h, np.int32 if rev else np.float32))
     if rev:
         q, mx = ob.quant_rev(raw, int(band["K_max"]))
@@ -147,8 +148,11 @@ def decode_blocks(plan: Plan, cs: bytes):
     """Oracle HT decode + dequantise of every block into a fresh arena (blocks of resolutions the
     plan was told not to read stay zero)."""
     coded = plan.coded_blocks()
-    top_read = int(plan.params.num_decomps) - plan.skip[0]
-    rev = bool(plan.params.reversible)
+    nc = int(plan.params.num_comps)
+    styles = [plan.comp_style(c) for c in range(nc)]
+    max_decomps = max(st["num_decomps"] for st in styles)
+    # resolutions read (by number, counted from the largest decomposition) and not above what is reconstructed
+    top_read = [min(max_decomps - plan.skip[0], st["recon_decomps"]) for st in styles]
     arena = np.zeros(plan.arena_elems, np.uint32)
     buf = np.frombuffer(cs, dtype=np.uint8)
     for k in range(plan.num_blocks):
@@ -157,8 +161,9 @@ def decode_blocks(plan: Plan, cs: bytes):
             continue
         blk = plan.blocks[k]
         band = plan.bands[int(blk["band"])]
-        if int(band["res"]) > top_read:
+        if int(band["res"]) > top_read[int(band["comp"])]:
             continue
+        rev = styles[int(band["comp"])]["reversible"]
         w, h = int(blk["w"]), int(blk["h"])
         o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
         ok, sm = ob.ht_decode(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
@@ -176,15 +181,16 @@ def decode_blocks(plan: Plan, cs: bytes):
 
 def inverse_stages(plan: Plan, arena):
     p = plan.params
-    rev = bool(p.reversible)
-    dt = np.int32 if rev else np.float32
+    styles = [plan.comp_style(c) for c in range(p.num_comps)]
+    revs = [st["reversible"] for st in styles]
     lib = ob.lib()
-    top = int(p.num_decomps) - plan.skip[1]                 # the resolution that is reconstructed
     order = sorted(range(len(plan.levels)), key=lambda i: int(plan.levels[i]["res"]))
     for lv in (plan.levels[i] for i in order):
         w, h = int(lv["w"]), int(lv["h"])
-        if w == 0 or h == 0 or int(lv["res"]) > top:
+        if w == 0 or h == 0 or int(lv["res"]) > styles[int(lv["comp"])]["recon_decomps"]:   # the resolution that is reconstructed
             continue
+        rev = revs[int(lv["comp"])]
+        dt = np.int32 if rev else np.float32
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
         lw, hw, lh_, hh_ = ob.band_dims(w, h, xe, ye)
         ll = _view(arena, int(lv["ll_off"]), int(lv["ll_pitch"]), lw, lh_, dt)
@@ -199,18 +205,18 @@ def inverse_stages(plan: Plan, arena):
         planes = []
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
-            planes.append(np.ascontiguousarray(_view(arena, off, pitch, w, h, dt)))
+            planes.append(np.ascontiguousarray(_view(arena, off, pitch, w, h, np.int32 if revs[c] else np.float32)))
         if p.color_transform:
             y, cb, cr = planes[:3]
             r = np.empty_like(y); g = np.empty_like(y); b = np.empty_like(y)
-            f = lib.ojo_rct_inv if rev else lib.ojo_ict_inv
+            f = lib.ojo_rct_inv if revs[0] else lib.ojo_ict_inv
             f(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.ctypes.data, g.ctypes.data, b.ctypes.data, y.size)
             planes[:3] = [r, g, b]
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
             v = planes[c]
             bd, sg = plan.comp_format(c)
-            if rev:
+            if revs[c]:
                 out = v + (0 if sg else (1 << (bd - 1)))
             else:
                 out = np.empty(v.shape, np.int32)
