@@ -712,8 +712,7 @@ extern "C" int ojphgpu_plan_restrict_resolution(ojphgpu_plan* plan, uint32_t ski
   if (skipped_res_for_data < skipped_res_for_recon) return OJPHGPU_E_INVALID; // ojph_codestream_local.cpp:886-890
   if (skipped_res_for_data > P.p.num_decomps) return OJPHGPU_E_INVALID;       // :891-895 (the COD's count)
   for (uint32_t c = 0; c < P.p.num_comps; ++c)                                // a component with fewer decompositions than are
-    if (skipped_res_for_recon > P.style(c).L) return OJPHGPU_E_INVALID;       // dropped: the reference's arithmetic wraps there
-  if (skipped_res_for_data > P.max_decomps) return OJPHGPU_E_INVALID;
+    if (skipped_res_for_data > P.style(c).L) return OJPHGPU_E_INVALID;        // skipped: the reference's arithmetic wraps there
   P.skip_read = skipped_res_for_data; P.skip_recon = skipped_res_for_recon;
   // the reconstructed components: sub-sampling grows by 2^skip_recon (ojph_params.cpp:930-946)
   const uint64_t X1 = (uint64_t)P.p.image_x0 + P.p.width, Y1 = (uint64_t)P.p.image_y0 + P.p.height;

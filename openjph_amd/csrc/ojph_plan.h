@@ -121,7 +121,8 @@ struct Plan {
   uint32_t max_decomps = 0;      // over the components
   // decompositions of a component that are synthesised / the top resolution whose blocks are decoded
   uint32_t recon_decomps(uint32_t comp) const { return style(comp).L - skip_recon; }
-  uint32_t top_read_res(uint32_t comp) const { return std::min(max_decomps - skip_read, style(comp).L - skip_recon); }
+  // (resolution::skipped_res_for_read counts from the component's own top, ojph_resolution.cpp:254-255)
+  uint32_t top_read_res(uint32_t comp) const { return style(comp).L - skip_read; }
   // RC tile-part divisions number the parts c + r * num_comps; a component with fewer decompositions
   // than the largest has no part (c, r > its own), the number stays unused (ojph_tile.cpp:637-652)
   bool part_exists(uint32_t k) const { return tilepart_div != 3 || k / p.num_comps <= style(k % p.num_comps).L; }

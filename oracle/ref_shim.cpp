@@ -123,9 +123,8 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
       if (q.mask & 1) cod.set_num_decomposition(q.comp, q.num_decomps);
       if (q.mask & 2) cod.set_block_dims(q.comp, 1u << q.log_bw, 1u << q.log_bh);
       if (q.mask & 4) {
-        const uint32_t nd = cod.get_num_decompositions(q.comp);
-        std::vector<ojph::size> ps;
-        for (uint32_t i = 0; i <= nd; ++i) ps.push_back(ojph::size(1u << (q.precinct_exps[i] & 15), 1u << (q.precinct_exps[i] >> 4)));
+        std::vector<ojph::size> ps;                          // pad[0] = number of sizes given (the library repeats the last one)
+        for (uint32_t i = 0; i < q.pad[0]; ++i) ps.push_back(ojph::size(1u << (q.precinct_exps[i] & 15), 1u << (q.precinct_exps[i] >> 4)));
         cod.set_precinct_size(q.comp, (int)ps.size(), ps.data());
       }
       if (q.mask & 8) cod.set_reversible(q.comp, q.reversible != 0);

@@ -120,9 +120,8 @@ class Ref:
                 q.mask |= 2; q.log_bw, q.log_bh = st["block"][0].bit_length() - 1, st["block"][1].bit_length() - 1
             if st.get("precincts"):
                 q.mask |= 4
-                nd = int(st.get("num_decomps", 5))
-                for i in range(nd + 1):
-                    pw, ph = st["precincts"][min(i, len(st["precincts"]) - 1)]
+                q.pad[0] = len(st["precincts"])
+                for i, (pw, ph) in enumerate(st["precincts"]):
                     q.precinct_exps[i] = (pw.bit_length() - 1) | ((ph.bit_length() - 1) << 4)
             if "reversible" in st:
                 q.mask |= 8; q.reversible = int(bool(st["reversible"]))

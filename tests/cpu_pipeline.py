@@ -150,9 +150,8 @@ def decode_blocks(plan: Plan, cs: bytes):
     coded = plan.coded_blocks()
     nc = int(plan.params.num_comps)
     styles = [plan.comp_style(c) for c in range(nc)]
-    max_decomps = max(st["num_decomps"] for st in styles)
-    # resolutions read (by number, counted from the largest decomposition) and not above what is reconstructed
-    top_read = [min(max_decomps - plan.skip[0], st["recon_decomps"]) for st in styles]
+    # resolutions read: counted from the component's own top (ojph_resolution.cpp:254-255)
+    top_read = [st["num_decomps"] - plan.skip[0] for st in styles]
     arena = np.zeros(plan.arena_elems, np.uint32)
     buf = np.frombuffer(cs, dtype=np.uint8)
     for k in range(plan.num_blocks):

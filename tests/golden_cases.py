@@ -91,6 +91,60 @@ def format_case(i, seed=8):
     return planes, kw, (c["w"], c["h"])
 
 
+# per-component coding styles (COC marker segments, param_cod's comp_idx setters): decompositions, block
+# size, precincts and wavelet of single components; the first one is the reference's own
+# tests/test_mixed_coc.cpp (4 components, the last one reversible inside an irreversible codestream).
+# (components, w, h, depths or one depth, kwargs incl. coc={component: settings}, skip or None)
+COC_CASES = [
+    dict(nc=4, w=64, h=64, bd=8, kw=dict(reversible=False, qstep=0.01, coc={3: dict(reversible=True)})),
+    dict(nc=3, w=200, h=150, bd=8, kw=dict(reversible=True, coc={1: dict(reversible=True, num_decomps=2, block=(32, 32))})),
+    dict(nc=3, w=200, h=150, bd=10, kw=dict(reversible=False, prog_order="LRCP",
+                                            coc={0: dict(num_decomps=3), 2: dict(reversible=True, num_decomps=1, block=(16, 64))})),
+    dict(nc=2, w=130, h=97, bd=8, kw=dict(reversible=True, prog_order="CPRL", num_decomps=2,
+                                          coc={1: dict(reversible=True, num_decomps=4, precincts=[(32, 32), (64, 64)])})),
+    dict(nc=3, w=130, h=97, bd=12, kw=dict(reversible=True, prog_order="PCRL", num_decomps=3, coc={2: dict(reversible=False, num_decomps=0)})),
+    dict(nc=3, w=130, h=97, bd=8, kw=dict(reversible=False, prog_order="RLCP", tileparts="RC", tlm=True, num_decomps=3,
+                                          coc={2: dict(reversible=False, num_decomps=1)}), resilient=True),   # tile-part numbers with gaps
+    dict(nc=3, w=130, h=97, bd=8, kw=dict(reversible=False, prog_order="RPCL", tileparts="R", tlm=True, num_decomps=2, tile=(64, 64),
+                                          coc={1: dict(reversible=True, num_decomps=4)})),
+    dict(nc=3, w=160, h=120, bd=8, kw=dict(reversible=True, num_decomps=4, tile=(96, 96), prog_order="CPRL", tileparts="C",
+                                           coc={2: dict(reversible=True, num_decomps=2), 0: dict(reversible=True, num_decomps=4, block=(128, 16))})),   # creation order 2, 0
+    dict(nc=4, w=100, h=80, bd=8, kw=dict(reversible=True, color_transform=True, num_decomps=3,
+                                          coc={3: dict(reversible=False, num_decomps=2)})),                   # RCT on 0..2, a 9/7 alpha-like plane
+    dict(nc=3, w=128, h=96, bd=8, kw=dict(reversible=False, qfactor=60, coc={1: dict(reversible=False, num_decomps=3)})),
+    dict(nc=3, w=128, h=96, depths=[8, 12, 10], signs=[False, True, False],
+         kw=dict(reversible=False, qstep=0.02, coc={1: dict(reversible=True, num_decomps=3), 2: dict(reversible=False, num_decomps=5, block=(32, 32))})),
+    dict(nc=3, w=128, h=96, bd=8, ds=[(1, 1), (2, 2), (2, 2)], kw=dict(reversible=True, coc={1: dict(reversible=True, num_decomps=3), 2: dict(reversible=True, num_decomps=3)})),
+    dict(nc=3, w=150, h=110, bd=8, kw=dict(reversible=True, num_decomps=4, coc={2: dict(reversible=True, num_decomps=3)}), skip=(1, 1)),
+    dict(nc=3, w=150, h=110, bd=8, kw=dict(reversible=False, num_decomps=3, prog_order="LRCP", coc={0: dict(reversible=False, num_decomps=5)}), skip=(2, 1)),
+    dict(nc=2, w=64, h=64, bd=8, kw=dict(reversible=True, num_decomps=0, coc={1: dict(reversible=True, num_decomps=0, block=(32, 32))})),
+]
+
+
+def coc_case(i, seed=21):
+    """-> (planes, kwargs for plan.make_params / refbind.Ref.encode, (W, H), skip or None, resilient)"""
+    import numpy as np
+    c = COC_CASES[i]
+    nc = c["nc"]
+    depths = c.get("depths", [c.get("bd", 8)] * nc)
+    signs = c.get("signs", [False] * nc)
+    ds = c.get("ds", [(1, 1)] * nc)
+    rng = np.random.default_rng(seed + i)
+    planes = []
+    for (dx, dy), bd, sg in zip(ds, depths, signs):
+        cw, ch = -(-c["w"] // dx), -(-c["h"] // dy)
+        lo, hi = (-(1 << (bd - 1)), 1 << (bd - 1)) if sg else (0, 1 << bd)
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        base = ((np.sin(xx / 8.0) + np.cos(yy / 6.0)) * 0.2 + 0.5) * (hi - lo) + lo
+        planes.append(np.clip(base + rng.integers(-4, 5, (ch, cw)), lo, hi - 1).astype(np.int32))
+    kw = dict(c["kw"], bit_depth=depths[0], is_signed=signs[0])
+    if "depths" in c:
+        kw.update(bit_depths=depths, signs=signs)
+    if "ds" in c:
+        kw.update(downsampling=ds)
+    return planes, kw, (c["w"], c["h"]), c.get("skip"), c.get("resilient", False)
+
+
 # tile-part divisions (codestream::set_tilepart_divisions) on a 3-component 150x200 image:
 # (progression order, divisions, further kwargs)
 TILEPART_CASES = [

@@ -61,3 +61,32 @@ def random_case(seed):
         q = np.clip(base + rng.integers(-(hi - lo) // 16 - 1, (hi - lo) // 16 + 2, base.shape), lo, hi - 1).astype(np.int32)
         planes.append(q[:ch, :cw])
     return planes, kw, (w, h)
+
+
+def random_coc_case(seed):
+    """random_case plus COC marker segments on a random subset of the components (their own
+    decompositions, block size, precincts, wavelet), in a random creation order"""
+    planes, kw, size = random_case(7000 + seed)
+    rng = np.random.default_rng(99000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    nc = len(planes)
+    order = [int(c) for c in rng.permutation(nc)][:int(rng.integers(1, nc + 1))]
+    coc = {}
+    for c in order:
+        st = {}
+        if rng.random() < 0.8:
+            st["num_decomps"] = int(rng.integers(0, 6))
+        if rng.random() < 0.5:
+            st["block"] = pick([(64, 64), (32, 32), (16, 64), (128, 32), (8, 8)])
+        if rng.random() < 0.3 and st.get("num_decomps", 5) > 0:
+            st["precincts"] = [(pick([32, 64, 128]), pick([32, 64, 128])) for _ in range(int(rng.integers(1, 3)))]
+        if rng.random() < 0.7:
+            # mostly the wavelet the colour transform needs on its three components
+            st["reversible"] = kw["reversible"] if (kw["color_transform"] and c < 3 and rng.random() < 0.9) else bool(rng.random() < 0.5)
+        elif kw["color_transform"] and c < 3 and kw["reversible"]:
+            st["reversible"] = True                        # (a COC starts from the 9/7)
+        if not st:                                         # a COC exists once one of its setters was called
+            st["num_decomps"] = int(rng.integers(0, 6))
+        coc[c] = st
+    kw["coc"] = coc
+    return planes, kw, size

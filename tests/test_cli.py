@@ -94,6 +94,28 @@ def test_cli_round_trip_matches_oracle(tmp_path, case):
 
 
 @pytest.mark.gpu
+def test_facade_component_coding_styles(tmp_path):
+    """tests/facade/coc_roundtrip.cpp: the scenario of the reference's tests/test_mixed_coc.cpp (and two
+    more) through the ojph::codestream-compatible facade's COC setters / getters; its codestreams
+    are byte-identical to the oracle-built ones (which tests/test_cpu_parity.py pins to the reference)"""
+    from tests import cpu_pipeline as cp
+    exe = os.path.join(ROOT, "openjph_amd", "apps", "facade_coc_roundtrip")
+    r = run([exe, str(tmp_path / "f")])
+    assert r.returncode == 0 and b"all checks passed" in r.stdout, r.stdout
+
+    def image(w, h, nc, bd, coc_comp):
+        y, x = np.mgrid[0:h, 0:w]
+        return np.stack([((x + y * w) % (1 << bd)) if c == coc_comp else (((x * 3 + y * 5 + c * 17) >> 1) % (1 << bd))
+                         for c in range(nc)]).astype(np.int32)
+    for name, (w, h, nc, bd, cc), coc in (
+            ("mixed", (64, 64, 4, 8, 3), {3: dict(reversible=True)}),
+            ("short", (150, 100, 3, 10, 1), {1: dict(num_decomps=2, block=(32, 32), reversible=True)}),
+            ("flat", (150, 100, 3, 8, 0), {0: dict(num_decomps=0, reversible=False)})):
+        want, *_ = cp.encode(image(w, h, nc, bd, cc), bit_depth=bd, reversible=False, qstep=0.01, coc=coc)
+        assert open(tmp_path / ("f_%s.j2c" % name), "rb").read() == want, name
+
+
+@pytest.mark.gpu
 def test_cli_raw_planar_12bit_irreversible(tmp_path):
     """the C3 family at a small size: planar .yuv, 12 bit, 9/7, qstep 0.001"""
     from tests import cpu_pipeline as cp

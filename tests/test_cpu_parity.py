@@ -18,7 +18,7 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
+from tests.golden_cases import (BLOCK_CASES, COC_CASES, coc_case, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
                                 format_case, grid_kwargs, refine_case, skip_case, stream_kwargs, tilepart_case)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
@@ -413,6 +413,64 @@ def test_component_formats_and_qfactor_match_golden(i):
         assert all(np.array_equal(a, b) for a, b in zip(dec, planes))
 
 
+@pytest.mark.parametrize("i", range(len(COC_CASES)), ids=lambda i: "coc%d" % i)
+def test_component_coding_styles_match_golden(i):
+    """COC marker segments (param_cod's comp_idx setters, ojph_params.cpp:255-282): a component with
+    its own decompositions / block size / precincts / wavelet.  Pinned against the reference's
+    codestreams: marker order (COD, COCs in creation order, QCD made for the first component without
+    a COC, QCCs where is_qcc_needed says so), packet sequences when components run out of resolutions,
+    tile-part numbering with gaps, and the decoded samples (also at reduced resolution).  Case 0 is
+    the reference's own tests/test_mixed_coc.cpp."""
+    from tests import cpu_pipeline as cp
+    from openjph_amd.plan import parse_codestream
+    planes, kw, size, skip, resilient = coc_case(i)
+    g = GOLD["coc"][i]
+    cs, plan, *_ = cp.encode(planes, size=size, **kw)
+    assert len(cs) == g["len"] and sha(cs) == g["sha256"]
+    for c, st in kw["coc"].items():
+        got = plan.comp_style(c)
+        assert got["has_coc"] and got["reversible"] == bool(st.get("reversible", False)) and got["num_decomps"] == st.get("num_decomps", 5)
+    pl = parse_codestream(cs, resilient=resilient)
+    for c in range(len(planes)):                            # what read_headers reports per component (test_mixed_coc.cpp:139-150)
+        assert pl.comp_style(c) == plan.comp_style(c)
+    if skip:
+        pl.restrict_resolution(*skip)
+    dec = _as_list(cp.inverse_stages(pl, cp.decode_blocks(pl, cs)), len(planes))
+    assert [list(d.shape) for d in dec] == g["shapes"]
+    assert sha(_planes_bytes(dec)) == g["dec_sha256"]
+    if not skip:
+        for c in range(len(planes)):                        # a reversibly coded component comes back exactly
+            if plan.comp_style(c)["reversible"] and not (kw.get("color_transform") and c < 3 and not kw.get("reversible", True)):
+                assert np.array_equal(dec[c], planes[c]), c
+
+
+def test_coc_validation_and_gapped_tile_parts():
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params, parse_codestream
+    from tests import cpu_pipeline as cp
+    with pytest.raises(capi.OjphError):                     # colour transform over components of different wavelets (ojph_tile.cpp:147-163)
+        Plan(make_params(64, 64, 3, color_transform=True, reversible=True, coc={1: dict(reversible=False)}))
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 2, coc={1: dict(num_decomps=33)}))
+    with pytest.raises(capi.OjphError):
+        Plan(make_params(64, 64, 2, coc={1: dict(block=(2048, 2))}))
+    with pytest.raises(ValueError):
+        make_params(64, 64, 20, coc={17: dict(num_decomps=1)})
+    # RC tile-parts of components with different decompositions leave gaps in the tile-part numbers:
+    # the reference refuses its own codestream ("wrong tile part index") unless it reads resiliently
+    planes, kw, size, _, _ = coc_case(5)
+    cs, *_ = cp.encode(planes, size=size, **kw)
+    with pytest.raises(capi.OjphError):
+        parse_codestream(cs)
+    assert parse_codestream(cs, resilient=True).num_blocks > 0
+    # reduced resolution beyond what a component has is refused (the reference's arithmetic wraps there)
+    planes, kw, size, _, _ = coc_case(4)                     # component 2 has no decomposition at all
+    cs, *_ = cp.encode(planes, size=size, **kw)
+    pl = parse_codestream(cs)
+    with pytest.raises(capi.OjphError):
+        pl.restrict_resolution(1, 1)
+
+
 def test_qfactor_validation():
     from openjph_amd import capi
     from openjph_amd.plan import Plan, make_params
@@ -481,6 +539,49 @@ def test_plan_geometry_block_counts():
     p = Plan(make_params(4096, 2048, 1, bit_depth=16, tile=(1024, 1024)))
     assert p.num_tiles == 8 and p.num_blocks == 8 * 259
     assert Plan(make_params(256, 256, 1, bit_depth=8)).num_blocks == 25
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_coc_parameter_sets_match_live_reference(chunk, refgen):
+    """80 seeded random parameter sets with COC marker segments on random components
+    (tests/random_cases.py: random_coc_case): same bytes as the reference, same samples, the same
+    refusals -- also of its own codestreams when RC tile-parts leave gaps in the numbering"""
+    from openjph_amd import capi
+    from tests import cpu_pipeline as cp
+    from tests.random_cases import random_coc_case
+    compared = 0
+    for seed in range(chunk * 20, chunk * 20 + 20):
+        planes, kw, size = random_coc_case(seed)
+        if any(q.size == 0 for q in planes):
+            continue
+        k2 = dict(kw)
+        bd, sg = k2.pop("bit_depth"), k2.pop("is_signed")
+        try:
+            want = refgen.encode(planes, bd, is_signed=sg, size=size, **k2)
+        except RuntimeError:
+            want = None
+        try:
+            got, *_ = cp.encode(planes, size=size, **kw)
+        except capi.OjphError:
+            got = None
+        assert (want is None) == (got is None), "seed %d: %s" % (seed, kw)
+        if want is None:
+            continue
+        assert got == want, "seed %d: %s" % (seed, kw)
+        try:
+            rdec, _ = refgen.decode(want)
+        except RuntimeError:
+            rdec = None
+        try:
+            dec, _ = cp.decode(want)
+        except capi.OjphError:
+            dec = None
+        assert (rdec is None) == (dec is None), "seed %d: %s" % (seed, kw)
+        if rdec is None:
+            continue
+        assert all(np.array_equal(dec[c], rdec[c]) for c in range(len(planes))), "seed %d" % seed
+        compared += 1
+    assert compared >= 8
 
 
 @pytest.mark.parametrize("chunk", range(6))

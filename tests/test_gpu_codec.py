@@ -126,6 +126,59 @@ def test_component_formats_and_qfactor_on_gpu(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+@pytest.mark.parametrize("i", range(15), ids=lambda i: "coc%d" % i)
+def test_component_coding_styles_on_gpu(i):
+    """COC marker segments: components with their own decompositions / block size / precincts /
+    wavelet (the DWT launches split by depth below each component's top and by wavelet, the block
+    coder and the conversion take the wavelet from their descriptors): GPU codec == reference
+    digests, also at reduced resolution.  Case 0 is the reference's tests/test_mixed_coc.cpp."""
+    import hashlib
+    import json
+    import os
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    from tests.golden_cases import coc_case
+    planes, kw, size, skip, resilient = coc_case(i)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["coc"][i]
+    got = codec.Encoder(make_params(size[0], size[1], len(planes), **kw)).encode(planes)
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
+    dec = codec.Decoder(got, resilient=resilient, skip_res=skip)
+    out = dec.plan.unpack_frame(dec.decode())
+    assert [list(q.shape) for q in out] == gold["shapes"]
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_random_coc_parameter_sets_on_gpu(chunk):
+    """seeded random parameter sets with COC marker segments on random components
+    (tests/random_cases.py: random_coc_case): GPU codec == oracle pipeline"""
+    from openjph_amd import capi, codec
+    from openjph_amd.plan import make_params
+    from tests import cpu_pipeline as cp
+    from tests.random_cases import random_coc_case
+    done = 0
+    for seed in range(chunk * 40, chunk * 40 + 40):
+        planes, kw, size = random_coc_case(seed)
+        if any(q.size == 0 for q in planes):
+            continue
+        try:
+            want, plan, *_ = cp.encode(planes, size=size, **kw)
+        except capi.OjphError:
+            continue                                      # a parameter set the reference rejects, too
+        got = codec.Encoder(make_params(size[0], size[1], len(planes), **kw)).encode(planes)
+        assert got == want, "seed %d: %s" % (seed, kw)
+        try:
+            wdec, _ = cp.decode(want)
+        except capi.OjphError:
+            continue                                      # tile-part numbers with gaps
+        dec = codec.Decoder(want)
+        out = dec.plan.unpack_frame(dec.decode())
+        for c in range(len(planes)):
+            assert np.array_equal(out[c], wdec[c]), "seed %d component %d: %s" % (seed, c, kw)
+        done += 1
+    assert done >= 20
+
+
 @pytest.mark.parametrize("chunk", range(4))
 def test_random_parameter_sets_on_gpu(chunk):
     """the seeded random parameter sets of tests/random_cases.py (odd sizes, offsets, sub-sampling,
