@@ -204,6 +204,20 @@ private:
   local::codestream_state* state;
 };
 
+// NLT marker segments (ojph_params.h:299-345): type 0 (none) and type 3 (binary complement <-> sign
+// magnitude for signed components) are what the reference supports; entries for components 0..15
+class param_nlt {
+public:
+  enum special_comp_num : ui16 { ALL_COMPS = 65535 };
+  enum nonlinearity : ui8 { OJPH_NLT_NO_NLT = 0, OJPH_NLT_GAMMA_STYLE_NLT = 1, OJPH_NLT_LUT_STYLE_NLT = 2,
+                            OJPH_NLT_BINARY_COMPLEMENT_NLT = 3, OJPH_NLT_UNDEFINED = 255 };
+  explicit param_nlt(local::codestream_state* s) : state(s) {}
+  void set_nonlinear_transform(ui32 comp_num, ui8 nl_type);
+  bool get_nonlinear_transform(ui32 comp_num, ui8& bit_depth, bool& is_signed, ui8& nl_type) const;
+private:
+  local::codestream_state* state;
+};
+
 class comment_exchange {
 public:
   comment_exchange() : data(nullptr), len(0), Rcom(0) {}
@@ -244,6 +258,7 @@ public:
   param_siz access_siz();
   param_cod access_cod();
   param_qcd access_qcd();
+  param_nlt access_nlt();
   bool is_planar() const;
 
   // GPU-path extras (not in the reference): device ordinal used by flush() / create()

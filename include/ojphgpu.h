@@ -86,6 +86,14 @@ typedef struct ojphgpu_params {
                                                      /* when it differs from bit_depth; 0 = same   */
   uint8_t  comp_sign[OJPHGPU_MAX_SUBSAMPLED_COMPS];  /* 0 = is_signed, 1 = unsigned, 2 = signed    */
   ojphgpu_coc coc[OJPHGPU_MAX_COC_COMPS];            /* per-component coding style of component c < 16 */
+  /* NLT marker segments: param_nlt::set_nonlinear_transform (ojph_params.h:299-345).  Values: 0 = not
+     set, 1 = type 0 (no non-linearity) set, 4 = type 3 (binary complement <-> sign magnitude, the only
+     other type the reference supports) set.  nlt_default = the ALL_COMPS entry; nlt_comp[c] / nlt_rank[c]
+     = component c < 16 and the order its entry was created in (1..); nlt_bd_* = BDnlt as read by the
+     parser (0 when the plan was not parsed). */
+  uint8_t  nlt_default, nlt_bd_default;
+  uint8_t  nlt_comp[OJPHGPU_MAX_COC_COMPS], nlt_rank[OJPHGPU_MAX_COC_COMPS], nlt_bd[OJPHGPU_MAX_COC_COMPS];
+  uint8_t  nlt_reserved[2];
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *
@@ -160,7 +168,8 @@ int  ojphgpu_plan_comp_info(const ojphgpu_plan* plan, uint32_t comp, uint32_t ou
 int  ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp, uint32_t* bit_depth, uint32_t* is_signed);
 /* coding style of a component, from its COC or the COD (param_cod's comp_idx getters,
  * ojph_params.cpp:374-399): out[0] decompositions, [1] reversible, [2] [3] log2 code-block width /
- * height, [4] 1 = the component has a COC, [5] decompositions left after restrict_resolution */
+ * height, [4] 1 = the component has a COC, [5] decompositions left after restrict_resolution,
+ * [6] 1 = the type 3 non-linearity applies to the component (NLT marker segment, signed component) */
 int  ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
 
 /* ------------------------------------------------------------------------------------------ *
@@ -316,7 +325,8 @@ typedef struct ojphgpu_convert_desc { /* one tile-component */
                                         batch adds the frame's offset) */
   uint32_t fmt;                      /* bit depth | signed << 8 of the component; 0 = from params;
                                         | 0x200 when bit 10 says which conversion the component takes
-                                        (1 = reversible level shift, 0 = to float): components with a COC */
+                                        (1 = reversible level shift, 0 = to float): components with a COC;
+                                        | 0x800: NLT type 3 (negative v <-> -v - 2^(B-1) - 1, ojph_colour.cpp:273-311) */
   uint32_t reserved;
 } ojphgpu_convert_desc;
 

@@ -38,6 +38,9 @@ class Params(C.Structure):
         ("comp_dx", C.c_uint8 * 16), ("comp_dy", C.c_uint8 * 16),
         ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16),
         ("coc", Coc * 16),
+        ("nlt_default", C.c_uint8), ("nlt_bd_default", C.c_uint8),
+        ("nlt_comp", C.c_uint8 * 16), ("nlt_rank", C.c_uint8 * 16), ("nlt_bd", C.c_uint8 * 16),
+        ("nlt_reserved", C.c_uint8 * 2),
     ]
 
 

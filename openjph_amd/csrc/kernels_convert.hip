@@ -17,6 +17,7 @@ namespace {
 
 struct ConvParams {
   uint32_t img_w, img_h, num_comps, bit_depth, is_signed, reversible, color;
+  uint32_t nlt3;       // type 3 non-linearity of a signed component (gen_rev_convert_nlt_type3, ojph_colour.cpp:273-311)
 };
 
 constexpr float ALPHA_RF = 0.299f, ALPHA_GF = 0.587f, ALPHA_BF = 0.114f;
@@ -47,7 +48,15 @@ __device__ __forceinline__ ConvParams with_fmt(ConvParams p, const ojphgpu_conve
 {
   if (d.fmt) { p.bit_depth = d.fmt & 0xFFu; p.is_signed = (d.fmt >> 8) & 1u; }
   if (d.fmt & 0x200u) p.reversible = (d.fmt >> 10) & 1u;     // the component's own wavelet (COC)
+  p.nlt3 = (d.fmt >> 11) & 1u;
   return p;
+}
+
+// type 3 non-linearity: negative values v <-> -v - (2^(B-1) + 1); its own inverse, applied to the integer
+// sample on the way in and on the way out (ojph_tile.cpp:352-354, :446-448; ojph_colour.cpp:344-352, :406-412)
+__device__ __forceinline__ int nlt3_map(int v, const ConvParams& p)
+{
+  return (p.nlt3 && v < 0) ? -v - (int)((1u << (p.bit_depth - 1)) + 1u) : v;
 }
 
 // S: container of the image samples -- int (32-bit) or short (16-bit: two's complement for signed
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
     p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
-    int r = sample_in<S>(image[at(d0)], p), g = sample_in<S>(image[at(d1)], p), b = sample_in<S>(image[at(d2)], p);
+    int r = nlt3_map(sample_in<S>(image[at(d0)], p), p), g = nlt3_map(sample_in<S>(image[at(d1)], p), p), b = nlt3_map(sample_in<S>(image[at(d2)], p), p);
     if (p.reversible) {
       const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
       r += shift; g += shift; b += shift;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;           // sub-sampled components are smaller
     p = with_fmt(pc, d);
-    int v = sample_in<S>(image[at(d)], p);
+    int v = nlt3_map(sample_in<S>(image[at(d)], p), p);
     uint32_t o;
     if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
     else o = __float_as_uint(to_float(v, p));
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
-      image[at(d0)] = (S)(cr + g + shift); image[at(d1)] = (S)(g + shift); image[at(d2)] = (S)(cb + g + shift);
+      image[at(d0)] = (S)nlt3_map(cr + g + shift, p); image[at(d1)] = (S)nlt3_map(g + shift, p); image[at(d2)] = (S)nlt3_map(cb + g + shift, p);
     } else {
       const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
       const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
       float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
-      image[at(d0)] = (S)to_int(r, p); image[at(d1)] = (S)to_int(g, p); image[at(d2)] = (S)to_int(bb, p);
+      image[at(d0)] = (S)nlt3_map(to_int(r, p), p); image[at(d1)] = (S)nlt3_map(to_int(g, p), p); image[at(d2)] = (S)nlt3_map(to_int(bb, p), p);
     }
   }
   for (uint32_t c = c_first; c < nc; ++c) {
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
     int v;
     if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
     else v = to_int(__uint_as_float(a), p);
-    image[at(d)] = (S)v;
+    image[at(d)] = (S)nlt3_map(v, p);
   }
 }
 
@@ -149,7 +158,7 @@ ConvParams make(const ojphgpu_params* q)
 {
   ConvParams p;
   p.img_w = q->width; p.img_h = q->height; p.num_comps = q->num_comps; p.bit_depth = q->bit_depth;
-  p.is_signed = q->is_signed; p.reversible = q->reversible; p.color = q->color_transform;
+  p.is_signed = q->is_signed; p.reversible = q->reversible; p.color = q->color_transform; p.nlt3 = 0;
   return p;
 }
 

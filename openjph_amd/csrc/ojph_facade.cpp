@@ -344,6 +344,37 @@ size param_cod::get_log_precinct_size(ui32 c, ui32 level_num) const
 }
 size param_cod::get_precinct_size(ui32 c, ui32 level_num) const { const size l = get_log_precinct_size(c, level_num); return size(1u << l.w, 1u << l.h); }
 
+// ---- param_nlt (ojph_params.cpp:441-458, :2176-2208) ---------------------------------------------
+void param_nlt::set_nonlinear_transform(ui32 comp_num, ui8 nl_type)
+{
+  if (nl_type != OJPH_NLT_NO_NLT && nl_type != OJPH_NLT_BINARY_COMPLEMENT_NLT)
+    ojph_error(0x00050171, "Nonliearities other than type 0 (No Nonlinearity) or type  3 (Binary Binary Complement to Sign Magnitude Conversion) are not supported yet");
+  ojphgpu_params& p = state->p;
+  if (comp_num == ALL_COMPS) { p.nlt_default = (ui8)(nl_type + 1); return; }
+  if (comp_num >= OJPHGPU_MAX_COC_COMPS) ojph_error(0x00050172, "NLT entries are supported for components 0..%d on the GPU path", OJPHGPU_MAX_COC_COMPS - 1);
+  if (p.nlt_comp[comp_num] == 0) {
+    ui32 made = 0;
+    for (ui8 r : p.nlt_rank) made = std::max<ui32>(made, r);
+    p.nlt_rank[comp_num] = (ui8)(made + 1);
+  }
+  p.nlt_comp[comp_num] = (ui8)(nl_type + 1);
+}
+bool param_nlt::get_nonlinear_transform(ui32 comp_num, ui8& bit_depth, bool& is_signed, ui8& nl_type) const
+{
+  const ojphgpu_params& p = state->p;
+  const bool own = comp_num < OJPHGPU_MAX_COC_COMPS && p.nlt_comp[comp_num] != 0;
+  if (!own && p.nlt_default == 0) return false;
+  const ui8 bd = own ? p.nlt_bd[comp_num] : p.nlt_bd_default;
+  if (p.nlt_reserved[0]) { bit_depth = (ui8)((bd & 0x7F) + 1); is_signed = (bd & 0x80) != 0; }   // as read from the codestream
+  else {                                                                                          // before write_headers fills BDnlt
+    const ui32 c = comp_num < state->comps.size() ? comp_num : 0;
+    bit_depth = (ui8)(c < state->comps.size() ? state->comps[c].bit_depth : p.bit_depth);
+    is_signed = c < state->comps.size() ? state->comps[c].is_signed : p.is_signed != 0;
+  }
+  nl_type = (ui8)((own ? p.nlt_comp[comp_num] : p.nlt_default) - 1);
+  return true;
+}
+
 void param_qcd::set_irrev_quant(float delta) { state->p.qstep = delta; }
 void param_qcd::set_qfactor(ui8 qfactor)
 {
@@ -388,6 +419,7 @@ void codestream::enable_resilience() { state->resilient = true; }
 param_siz codestream::access_siz() { return param_siz(state); }
 param_cod codestream::access_cod() { return param_cod(state); }
 param_qcd codestream::access_qcd() { return param_qcd(state); }
+param_nlt codestream::access_nlt() { return param_nlt(state); }
 
 // IMF / BROADCAST profile rules (ojph_codestream_local.cpp:293-553): the profile only constrains the
 // parameters; it also asks for a TLM marker and one tile-part per component

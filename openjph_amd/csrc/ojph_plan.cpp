@@ -175,6 +175,63 @@ bool derive_quant(Plan& plan)
   return true;
 }
 
+bool derive_nlt(Plan& plan, bool parsed)
+{
+  ojphgpu_params& p = plan.p;
+  const uint32_t nc = p.num_comps;
+  plan.nlt.clear(); plan.nlt3.assign(nc, 0); plan.any_nlt3 = false;
+  auto valid = [](uint8_t v) { return v == 0 || v == 1 || v == 4; };
+  if (!valid(p.nlt_default)) { plan.error = "unsupported non-linearity type"; return false; }
+  struct Obj { int comp; bool enabled; uint8_t type, bd; uint32_t rank; };
+  Obj D{ -1, p.nlt_default != 0, (uint8_t)(p.nlt_default ? p.nlt_default - 1 : 0), p.nlt_bd_default, 0 };
+  std::vector<Obj> objs;                                   // per-component entries, in creation order
+  for (uint32_t c = 0; c < OJPHGPU_MAX_COC_COMPS; ++c) {
+    if (!valid(p.nlt_comp[c])) { plan.error = "unsupported non-linearity type"; return false; }
+    if (c >= nc || p.nlt_comp[c] == 0) { p.nlt_comp[c] = p.nlt_rank[c] = p.nlt_bd[c] = 0; continue; }   // (:2320-2331 trims what does not exist)
+    objs.push_back(Obj{ (int)c, true, (uint8_t)(p.nlt_comp[c] - 1), p.nlt_bd[c], p.nlt_rank[c] });
+  }
+  std::stable_sort(objs.begin(), objs.end(), [](const Obj& a, const Obj& b) { return a.rank < b.rank; });
+  auto obj = [&](uint32_t c) -> Obj* { for (Obj& o : objs) if (o.comp == (int)c) return &o; return nullptr; };
+  auto bd_of = [&](uint32_t c) { return (uint8_t)((plan.comps[c].bit_depth - 1) | (plan.comps[c].is_signed ? 0x80 : 0)); };
+  const bool any = D.enabled || !objs.empty();
+  if (any && !parsed) {                                     // check_validity, on the way to write_headers
+    if (D.enabled && D.type == 0) D.enabled = false;
+    if (D.enabled && D.type == 3) {
+      bool all_same = true; int first = -1;
+      for (uint32_t c = 0; c < nc; ++c) {
+        Obj* o = obj(c);
+        if (!o) { if (first >= 0) all_same = all_same && bd_of(c) == bd_of((uint32_t)first); else first = (int)c; }
+        else o->bd = bd_of(c);
+      }
+      if (all_same && first >= 0) D.bd = bd_of((uint32_t)first);
+      else if (!all_same) {
+        D.enabled = false;
+        for (uint32_t c = 0; c < nc; ++c)
+          if (!obj(c)) {
+            if (c >= OJPHGPU_MAX_COC_COMPS) { plan.error = "NLT entries are supported for components 0..15"; return false; }
+            objs.push_back(Obj{ (int)c, true, 3, bd_of(c), 0 });
+          }
+      }
+    } else
+      for (Obj& o : objs) o.bd = bd_of((uint32_t)o.comp);
+  }
+  if (D.enabled) plan.nlt.push_back(NltSeg{ 65535, D.bd, D.type });
+  for (const Obj& o : objs) plan.nlt.push_back(NltSeg{ (uint16_t)o.comp, o.bd, o.type });
+  for (uint32_t c = 0; c < nc; ++c) {                       // get_nonlinear_transform + the check of ojph_tile.cpp:292-300
+    const Obj* o = obj(c);
+    const Obj* e = o ? o : (D.enabled ? &D : nullptr);
+    if (!e) continue;
+    uint32_t bd = (uint32_t)(e->bd & 0x7F) + 1; bd = bd <= 38 ? bd : 38;
+    if (bd != plan.comps[c].bit_depth || ((e->bd & 0x80) != 0) != plan.comps[c].is_signed) {
+      plan.error = "Mismatch between Ssiz from the SIZ marker segment and BDnlt from an NLT marker segment";
+      return false;
+    }
+    plan.nlt3[c] = e->type == 3 && plan.comps[c].is_signed;
+    plan.any_nlt3 |= plan.nlt3[c] != 0;
+  }
+  return true;
+}
+
 static inline uint32_t band_index(uint32_t res, uint32_t band) { return res ? (res - 1) * 3 + band : 0; }
 
 uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)   // ojph_params.cpp:1715-1749
@@ -345,6 +402,8 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   }
   plan.p = p;
   if (!derive_quant(plan)) return OJPHGPU_E_INVALID;
+  const bool parsed_nlt = p.nlt_bd_default != 0 || std::any_of(p.nlt_bd, p.nlt_bd + OJPHGPU_MAX_COC_COMPS, [](uint8_t v) { return v != 0; }) || p.nlt_reserved[0] != 0;
+  if (!derive_nlt(plan, parsed_nlt)) return OJPHGPU_E_INVALID;
 
   plan.ntx = div_ceil(X1 - p.tile_x0, p.tile_w);                                   // ojph_codestream_local.cpp:113-123
   plan.nty = div_ceil(Y1 - p.tile_y0, p.tile_h);
@@ -701,6 +760,7 @@ extern "C" int ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, 
   memset(out, 0, 8 * sizeof(uint32_t));
   out[0] = st.L; out[1] = st.rev ? 1 : 0; out[2] = st.lbw; out[3] = st.lbh; out[4] = st.rank ? 1 : 0;
   out[5] = plan->plan.recon_decomps(comp);
+  out[6] = plan->plan.nlt3[comp];
   return OJPHGPU_OK;
 }
 

@@ -101,8 +101,13 @@ struct QuantSet {               // contents of a QCD / QCC marker segment (ojph_
   bool present = false;         // QCC: the component has its own marker segment
 };
 
+struct NltSeg { uint16_t comp; uint8_t bd, type; };   // an NLT marker segment as written (Cnlt 65535 = all components)
+
 struct Plan {
   ojphgpu_params p;
+  std::vector<NltSeg> nlt;       // the main header's NLT segments, in writing order
+  std::vector<uint8_t> nlt3;     // per component: the type 3 non-linearity applies (signed component, type 3 in force)
+  bool any_nlt3 = false;
   std::vector<CompGeo> comps;
   uint64_t frame_elems;         // elements of one frame = sum of the component planes
   // reduced-resolution decoding (codestream::restrict_input_resolution): the top skip_read
@@ -147,6 +152,9 @@ int build_plan(const ojphgpu_params& p, Plan& plan);
 // derives the QCD / QCC contents (ojph_params.cpp:1359-1613); false + plan.error when the
 // parameters cannot be quantised (qfactor on an unsupported sampling format)
 bool derive_quant(Plan& plan);
+// param_nlt::check_validity / get_nonlinear_transform (ojph_params.cpp:2087-2208): the NLT segments to
+// write and the components the type 3 non-linearity applies to; parsed = the plan comes from a codestream
+bool derive_nlt(Plan& plan, bool parsed);
 uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);
 float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
 // worst-case coded size of a block of w*h samples with K_max magnitude bits

@@ -78,7 +78,7 @@ void write_main_header(const Plan& P, ByteSink& s)
   const ojphgpu_params& p = P.p;
   s.u16(SOC);
   // SIZ (ojph_params.cpp:805-851); Rsiz = 0x4000: HTJ2K codestream
-  s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000);
+  s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000 | (P.nlt.empty() ? 0 : 0x8200));   // RSIZ_EXT | RSIZ_NLT with NLT segments (:2168-2170)
   s.u32(p.image_x0 + p.width); s.u32(p.image_y0 + p.height); s.u32(p.image_x0); s.u32(p.image_y0);
   s.u32(p.tile_w); s.u32(p.tile_h); s.u32(p.tile_x0); s.u32(p.tile_y0);
   s.u16(p.num_comps);
@@ -138,6 +138,8 @@ void write_main_header(const Plan& P, ByteSink& s)
     if (cw == 1) s.u8(c); else s.u16(c);
     spqcd(q);
   }
+  // NLT segments: the ALL_COMPS entry first, then the components' in creation order (ojph_params.cpp:2210-2235)
+  for (const NltSeg& n : P.nlt) { s.u16(NLT); s.u16(6); s.u16(n.comp); s.u8(n.bd); s.u8(n.type); }
   // COM: the reference identifies itself; byte-identical output needs the same string
   // (ojph_codestream_local.cpp:678-696)
   static const char ver[] = "OpenJPH Ver 0.31.0.";
@@ -595,7 +597,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   struct Qcc { uint32_t comp; QuantSet q; };
   std::vector<Qcc> qccs;
   bool use_sop = false, use_eph = false;
-  uint32_t num_cocs = 0;
+  uint32_t num_cocs = 0, num_nlts = 0;
   for (;;) {
     if (!r.ok(4)) return OJPHGPU_E_CODESTREAM;
     uint32_t m = r.u16();
@@ -695,7 +697,18 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
             if (i && ((k.precinct_exps[i] & 0xF) == 0 || (k.precinct_exps[i] >> 4) == 0)) return OJPHGPU_E_CODESTREAM;   // :1256-1264
           }
       }
-    } else if (m == RGN || m == POC || m == PPM || m == NLT || m == DFS || m == ATK) {
+    } else if (m == NLT) {                                  // param_nlt::read (ojph_params.cpp:2238-2266)
+      if (L != 6) return OJPHGPU_E_CODESTREAM;
+      const uint32_t comp = r.u16(), bd = r.u8(), type = r.u8();
+      if (type != 0 && type != 3) return OJPHGPU_E_INVALID;      // gamma / LUT styles: the reference refuses them, too
+      p.nlt_reserved[0] = 1;                                       // BDnlt values come from the codestream
+      if (comp == 65535) { p.nlt_default = (uint8_t)(type + 1); p.nlt_bd_default = (uint8_t)bd; }
+      else if (!have_siz || comp < p.num_comps) {
+        if (comp >= OJPHGPU_MAX_COC_COMPS) return OJPHGPU_E_INVALID;   // per-component entries: first 16 components
+        if (p.nlt_comp[comp] == 0) p.nlt_rank[comp] = (uint8_t)++num_nlts;
+        p.nlt_comp[comp] = (uint8_t)(type + 1); p.nlt_bd[comp] = (uint8_t)bd;
+      }
+    } else if (m == RGN || m == POC || m == PPM || m == DFS || m == ATK) {
       return OJPHGPU_E_INVALID;                                    // Part-2 / unsupported markers
     }
     r.pos = next;

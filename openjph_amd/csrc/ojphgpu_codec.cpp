@@ -128,7 +128,7 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
                              std::vector<ojphgpu_dwt_desc>& out)
 {
   out.clear();
-  if (P.p.color_transform) return;
+  if (P.p.color_transform || P.any_nlt3) return;          // those conversions live in the conversion kernels
   for (LevelBatch& b : batches) {
     if (b.depth != 0 || b.count == 0) continue;
     b.img_first = (int)out.size();
@@ -165,8 +165,8 @@ bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       const CompGeo& g = P.comps[c];
       d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
       d.img_pitch = g.w; d.img_off = g.frame_off;
-      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u);   // 0x200: bit 10 says which conversion
-      if (P.p.color_transform || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u);   // 0x200: bit 10 says which conversion
+      if (P.p.color_transform || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }

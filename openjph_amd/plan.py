@@ -15,8 +15,10 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                 downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts="", bit_depths=None, signs=None,
-                qfactor=0, coc=None):
-    """coc: {component: dict(reversible=, num_decomps=, block=(w, h), precincts=[(w, h), ...])} -- COC
+                qfactor=0, coc=None, nlt=None):
+    """nlt: {component or "all": 0 or 3} -- param_nlt::set_nonlinear_transform calls in the order of the
+    dict ("all" = the ALL_COMPS entry; 3 = binary complement <-> sign magnitude, 0 = none).
+    coc: {component: dict(reversible=, num_decomps=, block=(w, h), precincts=[(w, h), ...])} -- COC
     marker segments in the order of the dict (param_cod's comp_idx setters); whatever a dict leaves
     out keeps the reference's COC defaults (9/7, 5 decompositions, 64x64, no precincts), NOT the COD's.
     width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
@@ -61,6 +63,19 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
             for i in range(k.num_decomps + 1):
                 pw, ph = pl[min(i, len(pl) - 1)]
                 k.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
+    rank = 0
+    for c, t in (nlt or {}).items():
+        if int(t) not in (0, 3):
+            raise ValueError("only the non-linearity types 0 and 3 exist in the reference")
+        if c == "all":
+            p.nlt_default = int(t) + 1
+            continue
+        if not 0 <= int(c) < 16:
+            raise ValueError("NLT entries can be given for the first 16 components")
+        if p.nlt_comp[int(c)] == 0:
+            rank += 1
+            p.nlt_rank[int(c)] = rank
+        p.nlt_comp[int(c)] = int(t) + 1
     if downsampling:
         if len(downsampling) > 16:
             raise ValueError("sub-sampling factors can be given for the first 16 components")
@@ -139,11 +154,12 @@ class Plan:
 
     def comp_style(self, comp):
         """coding style of component `comp` (its COC, else the COD): dict(num_decomps, reversible,
-        log_block=(w, h), has_coc, recon_decomps = levels left after restrict_resolution)"""
+        log_block=(w, h), has_coc, recon_decomps = levels left after restrict_resolution, nlt3 = the type 3
+        non-linearity applies)"""
         out = (C.c_uint32 * 8)()
         check(self._lib.ojphgpu_plan_comp_style(self.handle, comp, out))
         return dict(num_decomps=int(out[0]), reversible=bool(out[1]), log_block=(int(out[2]), int(out[3])),
-                    has_coc=bool(out[4]), recon_decomps=int(out[5]))
+                    has_coc=bool(out[4]), recon_decomps=int(out[5]), nlt3=bool(out[6]))
 
     @property
     def frame_elems(self):

@@ -58,6 +58,9 @@ struct ref_params {
   // 4 precincts, 8 reversible) -- what is not set keeps the library's COC defaults
   struct { uint8_t comp, mask, reversible, num_decomps, log_bw, log_bh, pad[2]; uint8_t precinct_exps[36]; } coc[16];
   uint32_t num_coc;
+  // param_nlt::set_nonlinear_transform calls, in order: component (65535 = ALL_COMPS) and type
+  struct { uint16_t comp; uint8_t type, pad; } nlt[17];
+  uint32_t num_nlt;
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -132,6 +135,8 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
     if (p->qstep > 0.0f && (!p->reversible || p->num_coc))
       cs.access_qcd().set_irrev_quant(p->qstep);
     if (p->qfactor) cs.access_qcd().set_qfactor((ojph::ui8)p->qfactor);
+    for (uint32_t k = 0; k < p->num_nlt && k < 17; ++k)
+      cs.access_nlt().set_nonlinear_transform(p->nlt[k].comp, p->nlt[k].type);
     cs.set_planar(p->planar != 0);
     if (p->tlm) cs.request_tlm_marker(true);
     if (p->tilepart_div) cs.set_tilepart_divisions((p->tilepart_div & 1) != 0, (p->tilepart_div & 2) != 0);

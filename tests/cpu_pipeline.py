@@ -22,6 +22,7 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
     p = plan.params
     comps = [plan.comp_info(c) for c in range(p.num_comps)]
     revs = [plan.comp_style(c)["reversible"] for c in range(p.num_comps)]      # per component (COC)
+    nlt3 = [plan.comp_style(c)["nlt3"] for c in range(p.num_comps)]
     arena = np.zeros(plan.arena_elems, np.uint32)
     lib = ob.lib()
     t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
@@ -32,6 +33,8 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]           # position inside the component's own plane
             src = np.ascontiguousarray(image[c][y0:y0 + h, x0:x0 + w], dtype=np.int32)
             bd, sg = plan.comp_format(c)
+            if nlt3[c]:                                          # gen_rev_convert_nlt_type3 (ojph_colour.cpp:273-311), irv :406-412
+                src = np.where(src >= 0, src, -src - ((1 << (bd - 1)) + 1)).astype(np.int32)
             if revs[c]:
                 shift = 0 if sg else -(1 << (bd - 1))
                 dst = src + shift
@@ -220,6 +223,8 @@ def inverse_stages(plan: Plan, arena):
             else:
                 out = np.empty(v.shape, np.int32)
                 lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, bd, int(sg))
+            if styles[c]["nlt3"]:                               # the same mapping on the way out (ojph_tile.cpp:446-448)
+                out = np.where(out >= 0, out, -out - ((1 << (bd - 1)) + 1)).astype(np.int32)
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]
             image[c][y0:y0 + h, x0:x0 + w] = out
     return np.stack(image) if len(plan.frame_shape) == 3 else image

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
 from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, TILEPART_CASES,  # noqa: E402
-                                FORMAT_CASES, COC_CASES, coc_case, stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case, format_case)
+                                FORMAT_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case, format_case)
 
 
 def sha(b):
@@ -115,6 +115,20 @@ def main():
         dec, _ = r.decode(cs, resilient=resilient, skip=skip or (0, 0))
         dec = [dec[c] for c in range(len(planes))]
         out["coc"].append({"case": i, "len": len(cs), "sha256": sha(cs), "shapes": [list(d.shape) for d in dec],
+                           "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
+    # (b7) NLT marker segments (type 3 non-linearity)
+    out["nlt"] = []
+    for i in range(len(NLT_CASES)):
+        planes, kw, size = nlt_case(i)
+        kw = dict(kw)
+        bd, sg = kw.pop("bit_depth"), kw.pop("is_signed")
+        all_rev = kw.get("reversible", True) and all(st.get("reversible", False) for st in kw.get("coc", {}).values())
+        r = ref if all_rev else refgen
+        cs = r.encode(planes, bd, is_signed=sg, size=size, **kw)
+        assert len(cs) > 0
+        dec, _ = r.decode(cs)
+        dec = [dec[c] for c in range(len(planes))]
+        out["nlt"].append({"case": i, "len": len(cs), "sha256": sha(cs),
                            "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
     # (b3) reduced-resolution decoding
     out["skip"] = []

@@ -145,6 +145,41 @@ def coc_case(i, seed=21):
     return planes, kw, (c["w"], c["h"]), c.get("skip"), c.get("resilient", False)
 
 
+# NLT marker segments (param_nlt::set_nonlinear_transform): the type 3 non-linearity on signed
+# components, the ALL_COMPS entry with components of one / of different formats (the library then writes
+# one segment or one per component, ojph_params.cpp:2087-2170), explicit type 0 entries, creation order
+NLT_CASES = [
+    dict(w=100, h=80, depths=[8] * 3, signs=[True] * 3, kw=dict(reversible=True, nlt={"all": 3})),
+    dict(w=100, h=80, depths=[8, 10, 12], signs=[True, False, True], kw=dict(reversible=True, nlt={"all": 3}, num_decomps=3)),
+    dict(w=100, h=80, depths=[12] * 3, signs=[True] * 3, kw=dict(reversible=False, qstep=0.001, nlt={"all": 3, 1: 0})),
+    dict(w=100, h=80, depths=[10] * 3, signs=[True] * 3, kw=dict(reversible=True, color_transform=True, nlt={2: 3, 0: 3, 1: 3})),
+    dict(w=64, h=64, depths=[16], signs=[True], kw=dict(reversible=True, nlt={0: 3}, num_decomps=0)),
+    dict(w=64, h=64, depths=[8, 8], signs=[False, True], kw=dict(reversible=True, nlt={"all": 0, 1: 3}, tile=(40, 40))),
+    dict(w=90, h=70, depths=[8, 8, 8], signs=[True] * 3, kw=dict(reversible=False, color_transform=True, qstep=0.01, nlt={"all": 3})),
+    dict(w=90, h=70, depths=[12, 12], signs=[True, True], ds=[(1, 1), (2, 2)],
+         kw=dict(reversible=False, nlt={"all": 3}, coc={1: dict(reversible=True, num_decomps=2)})),
+]
+
+
+def nlt_case(i, seed=33):
+    """-> (planes with negative samples, kwargs for plan.make_params / refbind.Ref.encode, (W, H))"""
+    import numpy as np
+    c = NLT_CASES[i]
+    rng = np.random.default_rng(seed + i)
+    planes = []
+    ds = c.get("ds", [(1, 1)] * len(c["depths"]))
+    for (dx, dy), bd, sg in zip(ds, c["depths"], c["signs"]):
+        cw, ch = -(-c["w"] // dx), -(-c["h"] // dy)
+        lo, hi = (-(1 << (bd - 1)), 1 << (bd - 1)) if sg else (0, 1 << bd)
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        base = ((np.sin(xx / 9.0) + np.cos(yy / 7.0)) * 0.3 + 0.5) * (hi - lo) + lo
+        planes.append(np.clip(base + rng.integers(-5, 6, (ch, cw)), lo, hi - 1).astype(np.int32))
+    kw = dict(c["kw"], bit_depth=c["depths"][0], is_signed=c["signs"][0], bit_depths=c["depths"], signs=c["signs"])
+    if "ds" in c:
+        kw["downsampling"] = ds
+    return planes, kw, (c["w"], c["h"])
+
+
 # tile-part divisions (codestream::set_tilepart_divisions) on a 3-component 150x200 image:
 # (progression order, divisions, further kwargs)
 TILEPART_CASES = [

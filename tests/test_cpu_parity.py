@@ -18,7 +18,7 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, COC_CASES, coc_case, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
+from tests.golden_cases import (BLOCK_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
                                 format_case, grid_kwargs, refine_case, skip_case, stream_kwargs, tilepart_case)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
@@ -442,6 +442,48 @@ def test_component_coding_styles_match_golden(i):
         for c in range(len(planes)):                        # a reversibly coded component comes back exactly
             if plan.comp_style(c)["reversible"] and not (kw.get("color_transform") and c < 3 and not kw.get("reversible", True)):
                 assert np.array_equal(dec[c], planes[c]), c
+
+
+@pytest.mark.parametrize("i", range(len(NLT_CASES)), ids=lambda i: "nlt%d" % i)
+def test_nonlinearity_type3_matches_golden(i):
+    """NLT marker segments (param_nlt, ojph_params.cpp:2087-2266) and the type 3 non-linearity on signed
+    components (negative v <-> -v - 2^(B-1) - 1 around the level shift / float conversion,
+    ojph_colour.cpp:273-311, :344-352, :406-412; ojph_tile.cpp:352-365, :446-460): which segments the
+    library writes for an ALL_COMPS request over components of one or of several formats, Rsiz flags,
+    coded bytes and decoded samples, against the reference's codestreams."""
+    from tests import cpu_pipeline as cp
+    planes, kw, size = nlt_case(i)
+    g = GOLD["nlt"][i]
+    cs, plan, *_ = cp.encode(planes, size=size, **kw)
+    assert len(cs) == g["len"] and sha(cs) == g["sha256"]
+    assert any(plan.comp_style(c)["nlt3"] for c in range(len(planes)))
+    dec, pl = cp.decode(cs)
+    dec = _as_list(dec, len(planes))
+    assert [pl.comp_style(c)["nlt3"] for c in range(len(planes))] == [plan.comp_style(c)["nlt3"] for c in range(len(planes))]
+    assert sha(_planes_bytes(dec)) == g["dec_sha256"]
+    for c in range(len(planes)):
+        if plan.comp_style(c)["reversible"] and not (kw.get("color_transform") and c < 3 and not kw.get("reversible", True)):
+            assert np.array_equal(dec[c], planes[c]), c
+
+
+def test_nlt_validation():
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params, parse_codestream
+    from tests import cpu_pipeline as cp
+    with pytest.raises(ValueError):
+        make_params(64, 64, 1, nlt={0: 1})                   # gamma style: not in the reference either
+    with pytest.raises(ValueError):
+        make_params(64, 64, 20, nlt={16: 3})
+    # unsigned components: the segment is written, nothing changes in the samples
+    img = np.arange(64 * 64, dtype=np.int32).reshape(1, 64, 64) % 251
+    a, pa, *_ = cp.encode(img, bit_depth=8, nlt={"all": 3})
+    b, *_ = cp.encode(img, bit_depth=8)
+    assert not pa.comp_style(0)["nlt3"] and len(a) == len(b) + 8 and a[6:8] == b"\xc2\x00" and b[6:8] == b"\x40\x00"
+    # a BDnlt that contradicts the SIZ marker segment is refused (ojph_tile.cpp:292-299)
+    k = a.find(b"\xff\x76")
+    bad = bytearray(a); bad[k + 6] ^= 0x80
+    with pytest.raises(capi.OjphError):
+        parse_codestream(bytes(bad))
 
 
 def test_coc_validation_and_gapped_tile_parts():

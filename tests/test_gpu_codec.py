@@ -148,6 +148,37 @@ def test_component_coding_styles_on_gpu(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+@pytest.mark.parametrize("i", range(8), ids=lambda i: "nlt%d" % i)
+def test_nonlinearity_type3_on_gpu(i):
+    """NLT type 3 on signed components (conversion kernels, descriptor bit 0x800; the fused
+    conversion of the DWT's top level steps aside): GPU codec == reference digests, with int32 and
+    with 16-bit sample containers"""
+    import hashlib
+    import json
+    import os
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    from tests.golden_cases import nlt_case
+    planes, kw, size = nlt_case(i)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["nlt"][i]
+    enc = codec.Encoder(make_params(size[0], size[1], len(planes), **kw))
+    got = enc.encode(planes)
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
+    dec = codec.Decoder(got)
+    out = dec.plan.unpack_frame(dec.decode())
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
+    same_shape = len({q.shape for q in planes}) == 1
+    if same_shape and all(bd <= 16 for bd in kw["bit_depths"]) and len(set(kw["signs"])) == 1:   # 16-bit containers, one dtype per frame
+        signed = kw["signs"][0]
+        img = np.stack(planes)
+        small = img.astype(np.int16) if signed else img.astype(np.uint16)
+        assert enc.encode(small) == got
+        out16 = dec.run_device(dtype=torch.int16).cpu().numpy()
+        back = out16.astype(np.int32) if signed else out16.view(np.uint16).astype(np.int32)
+        assert np.array_equal(back, np.stack(out))
+
+
 @pytest.mark.parametrize("chunk", range(2))
 def test_random_coc_parameter_sets_on_gpu(chunk):
     """seeded random parameter sets with COC marker segments on random components
