@@ -200,6 +200,14 @@ public:
   explicit param_qcd(local::codestream_state* s) : state(s) {}
   void set_irrev_quant(float delta);
   void set_qfactor(ui8 qfactor);              // 1..100: visually weighted step sizes, a QCC per component
+  enum comp_type : ui8 { OJPH_COMP_Y = 0, OJPH_COMP_CB = 1, OJPH_COMP_CR = 2, OJPH_COMP_UNDEFINED = 0xFF };
+  static comp_type ui8_2_comp_type(ui8 c) { return c <= OJPH_COMP_CR ? static_cast<comp_type>(c) : OJPH_COMP_UNDEFINED; }
+  // a QCC for one component (0..15) with its own quality factor and visual weights (ojph_params.h:251-254)
+  void set_qfactor(ui32 comp_idx, comp_type ctype, ui8 qfactor);
+  // as in the reference (ojph_params.cpp:2011-2018: get_qcc never returns NULL), this reaches the
+  // component's QCC only when set_qfactor(comp_idx, ..) made one -- where the quality factor then
+  // wins -- and otherwise sets the base step of the QCD
+  void set_irrev_quant(ui32 comp_idx, float delta);
 private:
   local::codestream_state* state;
 };

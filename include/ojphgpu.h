@@ -94,6 +94,11 @@ typedef struct ojphgpu_params {
   uint8_t  nlt_default, nlt_bd_default;
   uint8_t  nlt_comp[OJPHGPU_MAX_COC_COMPS], nlt_rank[OJPHGPU_MAX_COC_COMPS], nlt_bd[OJPHGPU_MAX_COC_COMPS];
   uint8_t  nlt_reserved[2];
+  /* param_qcd::set_qfactor(comp_idx, ctype, qfactor) (ojph_params.h:251-254): a QCC for component
+     c < 16 with its own quality factor (1..100; 0 = not set), the visual weights of ctype (0 Y, 1 Cb,
+     2 Cr) and its place in the creation order (QCCs are written in that order, then the ones the
+     library adds, ojph_params.cpp:1822-1834) */
+  uint8_t  qcc_qfactor[OJPHGPU_MAX_COC_COMPS], qcc_ctype[OJPHGPU_MAX_COC_COMPS], qcc_rank[OJPHGPU_MAX_COC_COMPS];
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *

@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("nlt_default", C.c_uint8), ("nlt_bd_default", C.c_uint8),
         ("nlt_comp", C.c_uint8 * 16), ("nlt_rank", C.c_uint8 * 16), ("nlt_bd", C.c_uint8 * 16),
         ("nlt_reserved", C.c_uint8 * 2),
+        ("qcc_qfactor", C.c_uint8 * 16), ("qcc_ctype", C.c_uint8 * 16), ("qcc_rank", C.c_uint8 * 16),
     ]
 
 

@@ -376,6 +376,24 @@ bool param_nlt::get_nonlinear_transform(ui32 comp_num, ui8& bit_depth, bool& is_
 }
 
 void param_qcd::set_irrev_quant(float delta) { state->p.qstep = delta; }
+void param_qcd::set_irrev_quant(ui32 comp_idx, float delta)
+{
+  if (comp_idx < OJPHGPU_MAX_COC_COMPS && state->p.qcc_qfactor[comp_idx]) return;   // that QCC's quality factor takes precedence (ojph_params.cpp:1456-1459)
+  state->p.qstep = delta;
+}
+void param_qcd::set_qfactor(ui32 comp_idx, comp_type ctype, ui8 qfactor)
+{
+  if (qfactor < 1 || qfactor > 100) ojph_error(0x00050191, "Qfactor must be between 1 and 100, but was set to %i.", (int)qfactor);   // ojph_params.cpp:2025
+  if (ctype > OJPH_COMP_CR) ojph_error(0x00050192, "the component type must be Y, Cb or Cr");
+  if (comp_idx >= OJPHGPU_MAX_COC_COMPS) ojph_error(0x00050193, "per-component quality factors are supported for components 0..%d on the GPU path", OJPHGPU_MAX_COC_COMPS - 1);
+  ojphgpu_params& p = state->p;
+  if (p.qcc_qfactor[comp_idx] == 0) {
+    ui32 made = 0;
+    for (ui8 r : p.qcc_rank) made = std::max<ui32>(made, r);
+    p.qcc_rank[comp_idx] = (ui8)(made + 1);
+  }
+  p.qcc_qfactor[comp_idx] = qfactor; p.qcc_ctype[comp_idx] = (ui8)ctype;
+}
 void param_qcd::set_qfactor(ui8 qfactor)
 {
   if (qfactor < 1 || qfactor > 100) ojph_error(0x00050181, "Qfactor must be between 1 and 100, but was set to %i.", (int)qfactor);   // ojph_params.cpp:1487

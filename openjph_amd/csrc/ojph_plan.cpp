@@ -152,25 +152,37 @@ static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint
 // QCD was made for (is_qcc_needed, :1470-1481); such a QCC inherits the QCD's base step (:1426).
 bool derive_quant(Plan& plan)
 {
-  const ojphgpu_params& p = plan.p;
+  ojphgpu_params& p = plan.p;
   const uint32_t nc = p.num_comps, qf = p.reserved[2];
   plan.qcc.assign(nc, QuantSet());
+  plan.qcc_order.clear();
+  // QCCs the user made (param_qcd::set_qfactor(comp_idx, ..)), in creation order
+  std::vector<uint32_t> user;
+  for (uint32_t c = 0; c < OJPHGPU_MAX_COC_COMPS; ++c) {
+    if (c >= nc || p.qcc_qfactor[c] == 0) { p.qcc_qfactor[c] = p.qcc_ctype[c] = p.qcc_rank[c] = 0; continue; }
+    if (p.qcc_qfactor[c] > 100 || p.qcc_ctype[c] > 2) { plan.error = "Qfactor must be between 1 and 100, the component type Y, Cb or Cr"; return false; }
+    user.push_back(c);
+  }
+  std::stable_sort(user.begin(), user.end(), [&](uint32_t a, uint32_t b) { return p.qcc_rank[a] < p.qcc_rank[b]; });
+  for (uint32_t c : user) { plan.qcc[c].present = true; plan.qcc_order.push_back(c); }
   uint32_t qcd_comp = 0;
-  for (uint32_t c = 0; c < nc; ++c) if (plan.style(c).rank == 0) { qcd_comp = c; break; }
-  if (qf) for (uint32_t c = 0; c < nc; ++c) plan.qcc[c].present = true;
+  for (uint32_t c = 0; c < nc; ++c) if (plan.style(c).rank == 0 && !plan.qcc[c].present) { qcd_comp = c; break; }
+  if (qf) for (uint32_t c = 0; c < nc; ++c) if (!plan.qcc[c].present) { plan.qcc[c].present = true; plan.qcc_order.push_back(c); }
   float qcd_base = p.qstep > 0.0f ? p.qstep : -1.0f;
   if (!make_quant(plan, plan.cod, qcd_comp, qf, 0, plan.qcd, plan.error, qcd_base)) return false;   // a reversible COD leaves the base unset
   for (uint32_t c = 0; c < nc; ++c) {
     const CodStyle& st = plan.style(c);
     float base = -1.0f;
+    const bool own = c < OJPHGPU_MAX_COC_COMPS && p.qcc_qfactor[c] != 0;
     if (!plan.qcc[c].present) {
       if (st.L == plan.cod.L && st.rev == plan.cod.rev && plan.comps[c].bit_depth == plan.comps[qcd_comp].bit_depth &&
           plan.comps[c].is_signed == plan.comps[qcd_comp].is_signed) continue;
-      plan.qcc[c].present = true;
+      plan.qcc[c].present = true; plan.qcc_order.push_back(c);
       base = qcd_base;
     }
-    const uint32_t ctype = (qf && nc >= 3 && c < 3) ? c : 0;
-    if (!make_quant(plan, st, c, qf, ctype, plan.qcc[c], plan.error, base)) return false;
+    const uint32_t cqf = own ? p.qcc_qfactor[c] : qf;
+    const uint32_t ctype = own ? p.qcc_ctype[c] : ((qf && nc >= 3 && c < 3) ? c : 0);
+    if (!make_quant(plan, st, c, cqf, ctype, plan.qcc[c], plan.error, base)) return false;
   }
   return true;
 }

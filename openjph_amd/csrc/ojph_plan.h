@@ -133,6 +133,7 @@ struct Plan {
   bool part_exists(uint32_t k) const { return tilepart_div != 3 || k / p.num_comps <= style(k % p.num_comps).L; }
   QuantSet qcd;                  // the main header's QCD
   std::vector<QuantSet> qcc;     // per component; .present = the component has a QCC of its own
+  std::vector<uint32_t> qcc_order; // components with a QCC in the order the segments are written
   const QuantSet& quant(uint32_t comp) const { return comp < qcc.size() && qcc[comp].present ? qcc[comp] : qcd; }
   std::vector<Tile> tiles;
   std::vector<TileComp> tcomps;

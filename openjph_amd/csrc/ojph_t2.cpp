@@ -129,8 +129,11 @@ void write_main_header(const Plan& P, ByteSink& s)
   auto spqcd = [&](const QuantSet& q) { s.u8(q.sqcd); if ((q.sqcd & 0x1F) == 0) for (uint8_t e : q.q8) s.u8(e); else for (uint16_t e : q.q16) s.u16(e); };
   auto qbytes = [](const QuantSet& q) { return (uint32_t)((q.sqcd & 0x1F) == 0 ? q.q8.size() : 2 * q.q16.size()); };
   s.u16(QCD); s.u16(3 + qbytes(P.qcd)); spqcd(P.qcd);
-  // QCC of the components that have one (ojph_params.cpp:1822-1887), in component order
-  for (uint32_t c = 0; c < p.num_comps; ++c) {
+  // QCC of the components that have one (ojph_params.cpp:1822-1887): the ones the user made first,
+  // then the ones check_validity added, by component
+  std::vector<uint32_t> qorder = P.qcc_order;
+  if (qorder.empty()) for (uint32_t c = 0; c < p.num_comps; ++c) if (P.qcc[c].present) qorder.push_back(c);
+  for (uint32_t c : qorder) {
     const QuantSet& q = P.qcc[c];
     if (!q.present) continue;
     const uint32_t cw = p.num_comps < 257 ? 1 : 2;
@@ -730,6 +733,8 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     if (P.qcc[k.comp].present) { delete h; return OJPHGPU_E_CODESTREAM; }   // two QCCs for one component (:827-830)
     P.qcc[k.comp] = k.q;
   }
+  P.qcc_order.clear();
+  for (uint32_t c = 0; c < p.num_comps; ++c) if (P.qcc[c].present) P.qcc_order.push_back(c);
   for (uint32_t c = 0; c < p.num_comps; ++c)
     if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { delete h; return OJPHGPU_E_CODESTREAM; }
   for (Band& B : P.bands) {

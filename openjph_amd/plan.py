@@ -15,8 +15,10 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                 downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts="", bit_depths=None, signs=None,
-                qfactor=0, coc=None, nlt=None):
-    """nlt: {component or "all": 0 or 3} -- param_nlt::set_nonlinear_transform calls in the order of the
+                qfactor=0, coc=None, nlt=None, qfactors=None):
+    """qfactors: {component: (ctype, qfactor)} with ctype "Y", "Cb" or "Cr" -- param_qcd::set_qfactor(comp_idx,
+    ctype, qfactor) calls in the order of the dict (a QCC per named component).
+    nlt: {component or "all": 0 or 3} -- param_nlt::set_nonlinear_transform calls in the order of the
     dict ("all" = the ALL_COMPS entry; 3 = binary complement <-> sign magnitude, 0 = none).
     coc: {component: dict(reversible=, num_decomps=, block=(w, h), precincts=[(w, h), ...])} -- COC
     marker segments in the order of the dict (param_cod's comp_idx setters); whatever a dict leaves
@@ -63,6 +65,10 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
             for i in range(k.num_decomps + 1):
                 pw, ph = pl[min(i, len(pl) - 1)]
                 k.precinct_exps[i] = (int(pw).bit_length() - 1) | ((int(ph).bit_length() - 1) << 4)
+    for rank, (c, (ctype, qf)) in enumerate((qfactors or {}).items()):
+        if not 0 <= int(c) < 16:
+            raise ValueError("per-component quality factors can be given for the first 16 components")
+        p.qcc_qfactor[int(c)], p.qcc_ctype[int(c)], p.qcc_rank[int(c)] = int(qf), ("Y", "Cb", "Cr").index(ctype), rank + 1
     rank = 0
     for c, t in (nlt or {}).items():
         if int(t) not in (0, 3):

@@ -61,6 +61,9 @@ struct ref_params {
   // param_nlt::set_nonlinear_transform calls, in order: component (65535 = ALL_COMPS) and type
   struct { uint16_t comp; uint8_t type, pad; } nlt[17];
   uint32_t num_nlt;
+  // param_qcd::set_qfactor(comp, ctype, qfactor) calls, in order
+  struct { uint8_t comp, ctype, qfactor, pad; } cqf[16];
+  uint32_t num_cqf;
 };
 
 static const char* po_names[5] = { "LRCP", "RLCP", "RPCL", "PCRL", "CPRL" };
@@ -135,6 +138,8 @@ long ref_encode_ex(const ref_params* p, const int32_t* const* planes, uint8_t* o
     if (p->qstep > 0.0f && (!p->reversible || p->num_coc))
       cs.access_qcd().set_irrev_quant(p->qstep);
     if (p->qfactor) cs.access_qcd().set_qfactor((ojph::ui8)p->qfactor);
+    for (uint32_t k = 0; k < p->num_cqf && k < 16; ++k)
+      cs.access_qcd().set_qfactor(p->cqf[k].comp, ojph::param_qcd::ui8_2_comp_type(p->cqf[k].ctype), p->cqf[k].qfactor);
     for (uint32_t k = 0; k < p->num_nlt && k < 17; ++k)
       cs.access_nlt().set_nonlinear_transform(p->nlt[k].comp, p->nlt[k].type);
     cs.set_planar(p->planar != 0);

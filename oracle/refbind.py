@@ -17,6 +17,10 @@ class RefCoc(C.Structure):
                 ("log_bw", C.c_uint8), ("log_bh", C.c_uint8), ("pad", C.c_uint8 * 2), ("precinct_exps", C.c_uint8 * 36)]
 
 
+class RefCqf(C.Structure):
+    _fields_ = [("comp", C.c_uint8), ("ctype", C.c_uint8), ("qfactor", C.c_uint8), ("pad", C.c_uint8)]
+
+
 class RefNlt(C.Structure):
     _fields_ = [("comp", C.c_uint16), ("type", C.c_uint8), ("pad", C.c_uint8)]
 
@@ -40,6 +44,7 @@ class RefParams(C.Structure):
         ("comp_depth", C.c_uint8 * 16), ("comp_sign", C.c_uint8 * 16), ("qfactor", C.c_uint32),
         ("coc", RefCoc * 16), ("num_coc", C.c_uint32),
         ("nlt", RefNlt * 17), ("num_nlt", C.c_uint32),
+        ("cqf", RefCqf * 16), ("num_cqf", C.c_uint32),
     ]
 
 
@@ -86,7 +91,7 @@ class Ref:
                block=(64, 64), color_transform=False, tile=(0, 0), prog_order="RPCL",
                planar=None, qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), size=None, tileparts="",
-               profile=None, com=None, bit_depths=None, signs=None, qfactor=0, coc=None, nlt=None):
+               profile=None, com=None, bit_depths=None, signs=None, qfactor=0, coc=None, nlt=None, qfactors=None):
         """planes: int32 array [num_comps, H, W], or a list of per-component 2-D arrays when the
         components are sub-sampled (then size=(W, H) is the image size on the reference grid).
         Returns codestream bytes."""
@@ -116,6 +121,9 @@ class Ref:
         for c, sg in enumerate(signs or []):
             p.comp_sign[c] = 2 if sg else 1
         p.qfactor = int(qfactor)
+        for k, (c, (ctype, qf)) in enumerate((qfactors or {}).items()):   # set_qfactor(comp, ctype, qfactor) calls, in order
+            p.cqf[k].comp, p.cqf[k].ctype, p.cqf[k].qfactor = int(c), ("Y", "Cb", "Cr").index(ctype), int(qf)
+            p.num_cqf = k + 1
         for k, (c, t) in enumerate((nlt or {}).items()):       # set_nonlinear_transform calls, in order
             p.nlt[k].comp, p.nlt[k].type = (65535 if c == "all" else int(c)), int(t)
             p.num_nlt = k + 1

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 from oracle import refbind                      # noqa: E402
 from tests.synth import synth_image, c1_image, random_block, ka2_block   # noqa: E402
 from tests.golden_cases import (BLOCK_CASES, STREAM_CASES, REFINE_CASES, GRID_CASES, SKIP_CASES, TILEPART_CASES,  # noqa: E402
-                                FORMAT_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case, format_case)
+                                FORMAT_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, CQF_CASES, cqf_case, stream_kwargs, refine_case, grid_kwargs, skip_case, tilepart_case, format_case)
 
 
 def sha(b):
@@ -130,6 +130,17 @@ def main():
         dec = [dec[c] for c in range(len(planes))]
         out["nlt"].append({"case": i, "len": len(cs), "sha256": sha(cs),
                            "dec_sha256": sha(b"".join(np.ascontiguousarray(d, dtype=np.int32).tobytes() for d in dec))})
+    # (b8) quality factors of single components
+    out["cqf"] = []
+    for i in range(len(CQF_CASES)):
+        img, kw = cqf_case(i)
+        kw = dict(kw)
+        bd = kw.pop("bit_depth")
+        cs = refgen.encode(img, bd, **kw)
+        assert len(cs) > 0
+        dec, _ = refgen.decode(cs)
+        out["cqf"].append({"case": i, "len": len(cs), "sha256": sha(cs),
+                           "dec_sha256": sha(np.ascontiguousarray(dec, dtype=np.int32).tobytes())})
     # (b3) reduced-resolution decoding
     out["skip"] = []
     for i in range(len(SKIP_CASES)):

@@ -145,6 +145,22 @@ def coc_case(i, seed=21):
     return planes, kw, (c["w"], c["h"]), c.get("skip"), c.get("resilient", False)
 
 
+# param_qcd::set_qfactor(comp_idx, ctype, qfactor): quality factors of single components -- their QCCs
+# come first, in creation order, then the ones the library adds (3 or 4 components of 120x90, 8 bit)
+CQF_CASES = [
+    dict(nc=3, kw=dict(reversible=False, qfactors={1: ("Cb", 40), 0: ("Y", 80)})),
+    dict(nc=3, kw=dict(reversible=False, qfactor=60, qfactors={2: ("Cr", 30)})),
+    dict(nc=3, kw=dict(reversible=False, qstep=0.02, qfactors={2: ("Y", 90)}, coc={1: dict(num_decomps=3)})),
+    dict(nc=3, kw=dict(reversible=True, qfactors={1: ("Y", 50)})),
+    dict(nc=4, kw=dict(reversible=False, color_transform=True, qfactors={0: ("Y", 70), 1: ("Cb", 70), 2: ("Cr", 70)})),
+]
+
+
+def cqf_case(i):
+    c = CQF_CASES[i]
+    return synth_image(c["nc"], 90, 120, 8, seed=4), dict(c["kw"], bit_depth=8)
+
+
 # NLT marker segments (param_nlt::set_nonlinear_transform): the type 3 non-linearity on signed
 # components, the ALL_COMPS entry with components of one / of different formats (the library then writes
 # one segment or one per component, ojph_params.cpp:2087-2170), explicit type 0 entries, creation order

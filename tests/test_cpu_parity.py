@@ -18,7 +18,7 @@ import re
 import numpy as np
 import pytest
 
-from tests.golden_cases import (BLOCK_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
+from tests.golden_cases import (BLOCK_CASES, COC_CASES, coc_case, NLT_CASES, nlt_case, CQF_CASES, cqf_case, FORMAT_CASES, GRID_CASES, REFINE_CASES, SKIP_CASES, STREAM_CASES, TILEPART_CASES,
                                 format_case, grid_kwargs, refine_case, skip_case, stream_kwargs, tilepart_case)
 from tests.synth import c1_image, ka2_block, random_block, synth_image
 
@@ -464,6 +464,20 @@ def test_nonlinearity_type3_matches_golden(i):
     for c in range(len(planes)):
         if plan.comp_style(c)["reversible"] and not (kw.get("color_transform") and c < 3 and not kw.get("reversible", True)):
             assert np.array_equal(dec[c], planes[c]), c
+
+
+@pytest.mark.parametrize("i", range(len(CQF_CASES)), ids=lambda i: "cqf%d" % i)
+def test_component_quality_factors_match_golden(i):
+    """param_qcd::set_qfactor(comp_idx, ctype, qfactor) (ojph_params.cpp:2021-2035): a QCC per named
+    component with its own visual weights; marker order (user-made QCCs first), the component the QCD
+    is made for, and the interplay with the top-level qfactor, qstep and COCs against the reference"""
+    from tests import cpu_pipeline as cp
+    img, kw = cqf_case(i)
+    g = GOLD["cqf"][i]
+    cs, plan, *_ = cp.encode(img, **kw)
+    assert len(cs) == g["len"] and sha(cs) == g["sha256"]
+    dec, _ = cp.decode(cs)
+    assert sha(np.ascontiguousarray(dec, dtype=np.int32).tobytes()) == g["dec_sha256"]
 
 
 def test_nlt_validation():

@@ -148,6 +148,23 @@ def test_component_coding_styles_on_gpu(i):
     assert hashlib.sha256(b"".join(np.ascontiguousarray(q, dtype=np.int32).tobytes() for q in out)).hexdigest() == gold["dec_sha256"]
 
 
+@pytest.mark.parametrize("i", range(5), ids=lambda i: "cqf%d" % i)
+def test_component_quality_factors_on_gpu(i):
+    """quality factors of single components (a QCC each): GPU codec == reference digests"""
+    import hashlib
+    import json
+    import os
+    from openjph_amd import codec
+    from openjph_amd.plan import make_params
+    from tests.golden_cases import cqf_case
+    img, kw = cqf_case(i)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["cqf"][i]
+    got = codec.Encoder(make_params(img.shape[2], img.shape[1], img.shape[0], **kw)).encode(img)
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
+    out = codec.Decoder(got).decode()
+    assert hashlib.sha256(np.ascontiguousarray(out, dtype=np.int32).tobytes()).hexdigest() == gold["dec_sha256"]
+
+
 @pytest.mark.parametrize("i", range(8), ids=lambda i: "nlt%d" % i)
 def test_nonlinearity_type3_on_gpu(i):
     """NLT type 3 on signed components (conversion kernels, descriptor bit 0x800; the fused
