@@ -327,6 +327,9 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     g.is_signed = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_sign[c] ? p.comp_sign[c] == 2 : p.is_signed != 0;
     if (g.bit_depth < 1 || g.bit_depth > 26) return fail("bit depth unsupported (32-bit sample path only)");
   }
+  // nothing beyond what a device could hold is planned: a frame of 2^36 samples is 256 GB of int32
+  // coefficients, and block / band indices are 32 bits wide
+  if (plan.frame_elems > (1ull << 36)) return fail("frame too large for the device path (more than 2^36 samples)");
   for (uint32_t c = 0; c < OJPHGPU_MAX_SUBSAMPLED_COMPS; ++c) {                    // canonical form: 0 where the default applies
     p.comp_depth[c] = c < p.num_comps && plan.comps[c].bit_depth != p.bit_depth ? (uint8_t)plan.comps[c].bit_depth : 0;
     p.comp_sign[c] = c < p.num_comps && plan.comps[c].is_signed != (p.is_signed != 0) ? (plan.comps[c].is_signed ? 2 : 1) : 0;
@@ -496,6 +499,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
                   uint32_t cy1 = std::min(y1, yl + ((by + 1) << B.ycb));
                   k.r.x0 = cx0 - B.r.x0; k.r.y0 = cy0 - B.r.y0; k.r.w = cx1 - cx0; k.r.h = cy1 - cy0;
                   plan.blocks.push_back(k);
+                  if (plan.blocks.size() > 0x3FFFFFFFull) return fail("too many code-blocks");
                   plan.max_block_bytes = std::max(plan.max_block_bytes,
                                                   block_scratch_bytes(k.r.w, k.r.h, B.K_max));
                 }
@@ -655,10 +659,11 @@ using namespace ojphgpu;
 extern "C" int ojphgpu_plan_create(const ojphgpu_params* params, ojphgpu_plan** out)
 {
   if (!params || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
   ojphgpu_plan* h = new (std::nothrow) ojphgpu_plan();
   if (!h) return OJPHGPU_E_NOMEM;
-  int rc = build_plan(*params, h->plan);
-  if (rc != OJPHGPU_OK) { delete h; *out = nullptr; return rc; }
+  const int rc = no_throw([&] { return build_plan(*params, h->plan); });
+  if (rc != OJPHGPU_OK) { delete h; return rc; }
   *out = h;
   return OJPHGPU_OK;
 }
@@ -686,13 +691,15 @@ extern "C" int ojphgpu_plan_set_comments(ojphgpu_plan* plan, const uint8_t* cons
                                           const uint16_t* rcom, uint32_t n)
 {
   if (!plan || (n && (!data || !len || !rcom))) return OJPHGPU_E_INVALID;
-  std::vector<Plan::Comment> c(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    if (len[i] > 65531 || (len[i] && !data[i])) return OJPHGPU_E_INVALID;    // Lcom = len + 4 is 16 bits
-    c[i].rcom = rcom[i]; c[i].data.assign(data[i], data[i] + len[i]);
-  }
-  plan->plan.comments.swap(c);
-  return OJPHGPU_OK;
+  return no_throw([&] {
+    std::vector<Plan::Comment> c(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (len[i] > 65531 || (len[i] && !data[i])) return (int)OJPHGPU_E_INVALID;    // Lcom = len + 4 is 16 bits
+      c[i].rcom = rcom[i]; c[i].data.assign(data[i], data[i] + len[i]);
+    }
+    plan->plan.comments.swap(c);
+    return (int)OJPHGPU_OK;
+  });
 }
 
 extern "C" int ojphgpu_plan_tile_parts(const ojphgpu_plan* plan, uint32_t* parts_per_tile)

@@ -14,6 +14,7 @@
 #define OJPH_PLAN_H
 
 #include <algorithm>
+#include <new>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -160,6 +161,16 @@ uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)
 float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
 // worst-case coded size of a block of w*h samples with K_max magnitude bits
 uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max);
+
+// Nothing may leave the C ABI as a C++ exception (a codestream from anywhere can ask for tables the
+// host cannot hold): entry points that build containers run their bodies through this.
+template <typename F>
+int no_throw(F f)
+{
+  try { return f(); }
+  catch (const std::bad_alloc&) { return OJPHGPU_E_NOMEM; }
+  catch (...) { return OJPHGPU_E_INVALID; }
+}
 
 }  // namespace ojphgpu
 

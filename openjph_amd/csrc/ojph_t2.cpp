@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -358,7 +359,7 @@ extern "C" int ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* d
   if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
   if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
-  return write_tile_parts(P, data, cb, tile_first, (size_t)tile_first + tile_count, out, cap, out_len, tile_part_len);
+  return no_throw([&] { return write_tile_parts(P, data, cb, tile_first, (size_t)tile_first + tile_count, out, cap, out_len, tile_part_len); });
 }
 
 extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile_part_len, uint8_t* out,
@@ -367,6 +368,7 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   if (!plan || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
   if (P.p.tlm && !tile_part_len) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
   ByteSink hdr;
   write_main_header(P, hdr);
   size_t total = hdr.v.size();
@@ -388,6 +390,7 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
         if (P.part_exists(k)) { u16((uint32_t)t); u32(tile_part_len[t * P.parts_per_tile + k]); }
   }
   return OJPHGPU_OK;
+  });
 }
 
 extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
@@ -397,6 +400,7 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
   if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
   const size_t nt = P.tiles.size();
+  return no_throw([&]() -> int {
   std::vector<uint32_t> lens(nt * P.parts_per_tile, 0);
   size_t hlen = 0, tlen = 0;
   int rc = ojphgpu_t2_write_main_header(plan, lens.data(), nullptr, 0, &hlen);       // size only (independent of lens)
@@ -409,6 +413,7 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
   if (rc) return rc;
   out[hlen + tlen] = (uint8_t)(EOC >> 8); out[hlen + tlen + 1] = (uint8_t)EOC;
   return OJPHGPU_OK;
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -588,9 +593,21 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
   return ended ? PACKET_DATA_ENDED : 0;
 }
 
+static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out);
+
 extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
 {
   if (!d || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  ojphgpu_plan* made = nullptr;                    // owned here until the parse has succeeded
+  const int rc = no_throw([&] { return t2_parse(d, len, resilient, &made); });
+  if (rc != OJPHGPU_OK) { return rc; }
+  *out = made;
+  return OJPHGPU_OK;
+}
+
+static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
+{
   *out = nullptr;
   Reader r{ d, len, 0 };
   if (!r.ok(2) || r.u16() != SOC) return OJPHGPU_E_CODESTREAM;
@@ -717,26 +734,27 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     r.pos = next;
   }
   if (!have_siz || !have_cod || !have_qcd) return OJPHGPU_E_CODESTREAM;
-  ojphgpu_plan* h = new (std::nothrow) ojphgpu_plan();
+  std::unique_ptr<ojphgpu_plan> hold(new (std::nothrow) ojphgpu_plan());   // freed on every way out but the last
+  ojphgpu_plan* h = hold.get();
   if (!h) return OJPHGPU_E_NOMEM;
   int rc = build_plan(p, h->plan);
-  if (rc != OJPHGPU_OK) { delete h; return rc; }
+  if (rc != OJPHGPU_OK) { return rc; }
   Plan& P = h->plan;
   // the codestream's own quantisation parameters override the derived ones; a reversibly transformed
   // component needs reversible-style steps and the other way round (the reference would read the
   // wrong union member; here the codestream is refused)
   P.qcd.sqcd = sqcd; P.qcd.guard_bits = sqcd >> 5;
   P.qcd.q8 = q8; P.qcd.q16 = q16;
-  if (q8.empty() && q16.empty()) { delete h; return OJPHGPU_E_CODESTREAM; }
+  if (q8.empty() && q16.empty()) { return OJPHGPU_E_CODESTREAM; }
   P.qcc.assign(p.num_comps, QuantSet());                       // only the markers of the codestream count
   for (const Qcc& k : qccs) {
-    if (P.qcc[k.comp].present) { delete h; return OJPHGPU_E_CODESTREAM; }   // two QCCs for one component (:827-830)
+    if (P.qcc[k.comp].present) { return OJPHGPU_E_CODESTREAM; }   // two QCCs for one component (:827-830)
     P.qcc[k.comp] = k.q;
   }
   P.qcc_order.clear();
   for (uint32_t c = 0; c < p.num_comps; ++c) if (P.qcc[c].present) P.qcc_order.push_back(c);
   for (uint32_t c = 0; c < p.num_comps; ++c)
-    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { delete h; return OJPHGPU_E_CODESTREAM; }
+    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { return OJPHGPU_E_CODESTREAM; }
   for (Band& B : P.bands) {
     B.K_max = band_Kmax(P, B.comp, B.res, B.band);
     if (!P.style(B.comp).rev) {
@@ -773,7 +791,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
       if (!r.ok(2)) { bad = true; break; }
       uint32_t L = r.u16();
       if (L < 2 || !r.ok(L - 2)) { bad = true; break; }
-      if (mk != PLT && mk != COM) { delete h; return OJPHGPU_E_INVALID; }
+      if (mk != PLT && mk != COM) { return OJPHGPU_E_INVALID; }
       r.pos += L - 2;
     }
     if (bad) { status = OJPHGPU_E_CODESTREAM; break; }
@@ -791,7 +809,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
     r.pos = tp_end;                                                     // tile::parse_tile_header ends with a seek to here
     if (status != OJPHGPU_OK && !resilient) break;
   }
-  if (status != OJPHGPU_OK && !resilient) { delete h; return status; }
-  *out = h;
+  if (status != OJPHGPU_OK && !resilient) { return status; }
+  *out = hold.release();
   return OJPHGPU_OK;
 }

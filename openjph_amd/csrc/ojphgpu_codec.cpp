@@ -333,14 +333,14 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
 extern "C" int ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
                                              uint32_t tile_count, ojphgpu_encoder** out)
 {
-  return encoder_create(plan, device, stream, tile_first, tile_count, 1, out);
+  return no_throw([&] { return encoder_create(plan, device, stream, tile_first, tile_count, 1, out); });
 }
 
 extern "C" int ojphgpu_encoder_create_batch(const ojphgpu_plan* plan, int device, void* stream, uint32_t num_frames,
                                              ojphgpu_encoder** out)
 {
   if (!plan) return OJPHGPU_E_INVALID;
-  return encoder_create(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), num_frames, out);
+  return no_throw([&] { return encoder_create(plan, device, stream, 0, (uint32_t)plan->plan.tiles.size(), num_frames, out); });
 }
 
 static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first, uint32_t tile_count,
@@ -354,9 +354,10 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   ojphgpu_encoder* e = new (std::nothrow) ojphgpu_encoder();
   if (!e) return OJPHGPU_E_NOMEM;
+  struct Owner { ojphgpu_encoder* p; ~Owner() { if (p) ojphgpu_encoder_destroy(p); } } owner{ e };   // also when a container throws
   const Plan& P = plan->plan;
   e->handle = plan; e->P = &P; e->device = device; e->stream = (hipStream_t)stream;
-  auto bail = [&](int rc) { ojphgpu_encoder_destroy(e); return rc; };
+  auto bail = [&](int rc) { return rc; };
 
   e->tiles = TileRange{ tile_first, tile_count };
   e->nframes = nframes;
@@ -418,6 +419,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   if (!cd.empty() && hipMemcpy(e->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   e->h_results.resize(bd.size());
   if (e->timer.init() != 0) return bail(OJPHGPU_E_HIP);
+  owner.p = nullptr;
   *out = e;
   return OJPHGPU_OK;
 }
@@ -551,6 +553,7 @@ extern "C" int ojphgpu_encoder_finish_frame(ojphgpu_encoder* e, uint32_t frame, 
 {
   if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
   if (e->tiles.first != 0 || e->tiles.count != e->P->tiles.size()) return OJPHGPU_E_INVALID;   // use _finish_tiles
+  return no_throw([&]() -> int {
   std::vector<ojphgpu_coded_block> cb;
   const bool tm = getenv("OJPHGPU_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -563,17 +566,20 @@ extern "C" int ojphgpu_encoder_finish_frame(ojphgpu_encoder* e, uint32_t frame, 
                   std::chrono::duration<double, std::milli>(t1 - t0).count(),
                   std::chrono::duration<double, std::milli>(now() - t1).count());
   return rc;
+  });
 }
 
 extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, size_t cap, size_t* out_len,
                                              uint32_t* tile_part_len)
 {
   if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
-  std::vector<ojphgpu_coded_block> cb;
-  int rc = encoder_fetch(e, 0, cb);
-  if (rc) return rc;
-  return ojphgpu_t2_write_tiles(e->handle, e->h_out.p, cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
-                                out_len, tile_part_len);
+  return no_throw([&]() -> int {
+    std::vector<ojphgpu_coded_block> cb;
+    int rc = encoder_fetch(e, 0, cb);
+    if (rc) return rc;
+    return ojphgpu_t2_write_tiles(e->handle, e->h_out.p, cb.data(), e->tiles.first, e->tiles.count, h_out, cap,
+                                  out_len, tile_part_len);
+  });
 }
 
 static int encode_host(ojphgpu_encoder* e, const void* h_image, int container, uint8_t* h_out, size_t cap, size_t* out_len)
@@ -673,14 +679,14 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
 extern "C" int ojphgpu_decoder_create_tiles(const ojphgpu_plan* plan, int device, void* stream, uint32_t tile_first,
                                              uint32_t tile_count, ojphgpu_decoder** out)
 {
-  return decoder_create(&plan, 1, device, stream, tile_first, tile_count, out);
+  return no_throw([&] { return decoder_create(&plan, 1, device, stream, tile_first, tile_count, out); });
 }
 
 extern "C" int ojphgpu_decoder_create_batch(const ojphgpu_plan* const* plans, uint32_t num_frames, int device, void* stream,
                                              ojphgpu_decoder** out)
 {
   if (!plans || num_frames == 0 || !plans[0]) return OJPHGPU_E_INVALID;
-  return decoder_create(plans, num_frames, device, stream, 0, (uint32_t)plans[0]->plan.tiles.size(), out);
+  return no_throw([&] { return decoder_create(plans, num_frames, device, stream, 0, (uint32_t)plans[0]->plan.tiles.size(), out); });
 }
 
 static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, int device, void* stream, uint32_t tile_first,
@@ -708,8 +714,9 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   ojphgpu_decoder* d = new (std::nothrow) ojphgpu_decoder();
   if (!d) return OJPHGPU_E_NOMEM;
+  struct Owner { ojphgpu_decoder* p; ~Owner() { if (p) ojphgpu_decoder_destroy(p); } } owner{ d };   // also when a container throws
   d->P = &P; d->device = device; d->stream = (hipStream_t)stream;
-  auto bail = [&](int rc) { ojphgpu_decoder_destroy(d); return rc; };
+  auto bail = [&](int rc) { return rc; };
 
   d->tiles = TileRange{ tile_first, tile_count };
   d->nframes = nframes;
@@ -789,6 +796,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   if (!bd.empty() && hipMemcpy(d->cb_descs.p, bd.data(), bd.size() * sizeof(bd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!cd.empty() && hipMemcpy(d->conv_descs.p, cd.data(), cd.size() * sizeof(cd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (d->timer.init() != 0) return bail(OJPHGPU_E_HIP);
+  owner.p = nullptr;
   *out = d;
   return OJPHGPU_OK;
 }

@@ -147,9 +147,10 @@ def add_refinement(data, coded, rng, fraction=0.6):
     return np.frombuffer(b"".join(chunks), dtype=np.uint8), out
 
 
-def decode_blocks(plan: Plan, cs: bytes):
+def decode_blocks(plan: Plan, cs: bytes, resilient=False):
     """Oracle HT decode + dequantise of every block into a fresh arena (blocks of resolutions the
-    plan was told not to read stay zero)."""
+    plan was told not to read stay zero).  resilient: a block the decoder refuses stays zero
+    (ojph_codeblock.cpp:214-224) instead of raising."""
     coded = plan.coded_blocks()
     nc = int(plan.params.num_comps)
     styles = [plan.comp_style(c) for c in range(nc)]
@@ -172,6 +173,8 @@ def decode_blocks(plan: Plan, cs: bytes):
                               len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]),
                               stripe_causal=bool(plan.params.reserved[0] & 1))
         if not ok:
+            if resilient:
+                continue
             raise RuntimeError("oracle failed to decode block %d" % k)
         off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
         if rev:

@@ -480,6 +480,67 @@ def test_component_quality_factors_match_golden(i):
     assert sha(np.ascontiguousarray(dec, dtype=np.int32).tobytes()) == g["dec_sha256"]
 
 
+def test_absurd_sizes_are_refused_not_fatal():
+    """nothing leaves the C ABI as a C++ exception: a frame no device could hold, or tables the host
+    cannot allocate, come back as a status (the process used to die in std::bad_alloc)"""
+    from openjph_amd import capi
+    from openjph_amd.plan import Plan, make_params
+    for w, h, kw in [(1 << 31, 1 << 31, dict(block=(4, 4))), (4000000, 4000000, dict(block=(4, 4), num_decomps=0)),
+                     (1 << 20, 1 << 20, dict(tile=(4096, 4096)))]:
+        with pytest.raises(capi.OjphError):
+            Plan(make_params(w, h, 1, **kw))
+
+
+def test_parser_survives_mutated_codestreams():
+    """a few hundred random mutations (bit flips, overwritten / removed / inserted bytes, cuts; mostly
+    in the main header) of codestreams with tiles, tile-parts, COC and NLT segments: the parser returns a
+    plan or an error, in both modes, and every code-block it reports lies inside the buffer"""
+    import random
+    from openjph_amd import capi
+    from openjph_amd.plan import parse_codestream
+    from tests import cpu_pipeline as cp
+    img = synth_image(3, 70, 90, 8, seed=1)
+    seeds = [bytes(cp.encode(img, bit_depth=8, **kw)[0]) for kw in (
+        dict(), dict(reversible=False, qstep=0.05), dict(tile=(32, 32), tlm=True, prog_order="CPRL", tileparts="C"),
+        dict(color_transform=True, precinct=(32, 32), prog_order="PCRL"))]
+    for i in (0, 2, 5):
+        pl, kw, size, _, _ = coc_case(i)
+        seeds.append(bytes(cp.encode(pl, size=size, **kw)[0]))
+    pl, kw, size = nlt_case(1)
+    seeds.append(bytes(cp.encode(pl, size=size, **kw)[0]))
+    rng = random.Random(7)
+    parsed = refused = 0
+    for _ in range(400):
+        b = bytearray(rng.choice(seeds))
+        hdr_end = b.find(b"\xff\x90")
+        for _ in range(rng.randint(1, 4)):
+            pos = min(rng.randrange(2, hdr_end + 40) if rng.random() < 0.7 else rng.randrange(len(b)), len(b) - 1)
+            mode = rng.random()
+            if mode < 0.5:
+                b[pos] ^= 1 << rng.randrange(8)
+            elif mode < 0.7:
+                b[pos] = rng.randrange(256)
+            elif mode < 0.8:
+                del b[pos:pos + rng.randint(1, 8)]
+            elif mode < 0.9:
+                b[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 8)))
+            else:
+                b = b[:max(pos, 4)]
+            if len(b) < 4:
+                break
+        for resilient in (False, True):
+            try:
+                p = parse_codestream(bytes(b), resilient=resilient)
+            except capi.OjphError:
+                refused += 1
+                continue
+            parsed += 1
+            cb = p.coded_blocks()
+            if len(cb):
+                assert int((cb["offset"].astype(np.int64) + cb["len1"] + cb["len2"]).max()) <= len(b)
+    assert parsed > 50 and refused > 50
+
+
 def test_nlt_validation():
     from openjph_amd import capi
     from openjph_amd.plan import Plan, make_params, parse_codestream

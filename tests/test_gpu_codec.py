@@ -281,6 +281,43 @@ def test_16bit_sample_containers(case):
     assert np.array_equal(got, ref_out)
 
 
+def test_corrupted_block_bytes_decode_like_oracle():
+    """bit flips and overwritten bytes inside the code-block bodies (the parser does not see them): the
+    GPU block decoder must neither hang nor read out of bounds, refuse exactly the blocks the reference
+    algorithm refuses (they stay zero when resilient) and produce the very same -- wrong -- samples for
+    the ones it accepts"""
+    import random
+    from openjph_amd import capi, codec
+    from openjph_amd.plan import parse_codestream
+    from tests import cpu_pipeline as cp
+    img = synth_image(3, 96, 128, 10, seed=9)
+    rng = random.Random(3)
+    checked = refused_blocks = 0
+    for kw in (dict(num_decomps=3), dict(reversible=False, qstep=0.01, num_decomps=2, block=(32, 32))):
+        cs = bytes(cp.encode(img, bit_depth=10, **kw)[0])
+        body0 = cs.find(b"\xff\x93") + 2
+        for _ in range(12):
+            b = bytearray(cs)
+            for _ in range(rng.randint(1, 6)):
+                pos = rng.randrange(body0, len(b) - 2)
+                if rng.random() < 0.6:
+                    b[pos] ^= 1 << rng.randrange(8)
+                else:
+                    b[pos] = rng.choice([0xFF, 0x00, 0x7F, rng.randrange(256)])
+            b = bytes(b)
+            try:
+                pl = parse_codestream(b, resilient=True)
+            except capi.OjphError:
+                continue
+            want = cp.inverse_stages(pl, cp.decode_blocks(pl, b, resilient=True))
+            dec = codec.Decoder(b, resilient=True)
+            got = dec.decode()
+            assert np.array_equal(got, want)
+            refused_blocks += dec.failed_blocks()
+            checked += 1
+    assert checked >= 12
+
+
 def test_truncated_codestream_decodes_like_oracle():
     """tests/test_truncated_decode.cpp on the GPU decoder: a full frame from whatever was received
     when resilient, an error for a cut the parser detects when not"""
