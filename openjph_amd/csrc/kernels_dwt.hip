@@ -18,9 +18,10 @@
 //     recomputation) so no inter-wave exchange is needed.
 //   * the rows of iteration t+1 are requested before iteration t computes and stores, so the
 //     HBM latency of the row stream overlaps the lifting arithmetic of the previous row pair.
-//   * the number of row pairs a wavefront walks (its vertical chunk) is chosen per launch so
-//     that every level of the pyramid fills the 256 CUs: 64 at full resolution, down to 8 at
-//     the small levels, where the kernel is otherwise bound by the length of the serial walk.
+//   * the number of row pairs a wavefront walks (its vertical chunk) is chosen per launch
+//     (pick_row_pairs): at most 20, so that a large plane takes two or three rounds of workgroups
+//     whose reads and writes mix at HBM, down to 8 at the small levels, where the kernel is
+//     otherwise bound by the length of the serial walk.
 //   * the first analysis level can read the int32 image planes directly (level shift / int ->
 //     float conversion of ojph_colour.cpp:238-436 applied in the load), and the last synthesis
 //     level can write them (float -> int with rounding + clamp), which removes one full
