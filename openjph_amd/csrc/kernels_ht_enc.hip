@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 //     length is known; only blocks that outgrow the stage spill their MagSgn bytes to the HBM
 //     scratch slot.
 constexpr uint32_t OUT_CAP = 5120;      // bytes of coded output staged in LDS per wavefront
-constexpr int PMS_WORDS = 520;          // 64 lanes * 8 samples * 31 bits + < 65 pending bytes
+constexpr int PMS_WORDS = 576;          // 64 lanes * 8 samples * 31 bits + < 257 pending bytes (a window is 256 bytes)
 constexpr int PVLC_WORDS = 80;          // 64 pairs * 30 bits + < 65 pending bytes
 
 struct NarrowLds {
@@ -599,20 +599,33 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
     }
   };
 
-  // stuffs whole 64-byte windows of the MagSgn bit buffer ("after 0xFF only 7 bits", :471-491);
-  // `flush` also emits the final partial window.  Returns the bit position reached.
+  // Stuffs whole 256-byte windows of the MagSgn bit buffer ("after 0xFF only 7 bits", :471-491): a lane
+  // takes four consecutive bytes, speculating that none of the window's bytes is 0xFF; the window is cut
+  // behind the first 0xFF (the byte after it carries 7 bits and shifts everything that follows) and the
+  // next one starts there.  `flush` also emits the final partial window.  Returns the bit position reached.
   auto ms_windows = [&](uint32_t T, bool flush) -> uint32_t {
     uint32_t pos = 0;
     for (;;) {
       const uint32_t first_n = ms_ff ? 7u : 8u;
-      if (!flush && pos + first_n + 8u * 63u > T) break;
-      const uint32_t start = pos + (lane == 0 ? 0u : first_n + 8u * (uint32_t)(lane - 1));
-      const uint32_t nb = lane == 0 ? first_n : 8u;
-      const bool ok = start + nb <= T;
-      const uint32_t v = ok ? get_bits(L.ms, start, nb) : 0u;
-      const uint64_t m_ok = __ballot(ok), m_ff = __ballot(ok && v == 0xFF);
-      const uint32_t n_ok = m_ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_ok);
-      const uint32_t f_ff = m_ff ? (uint32_t)__builtin_ctzll(m_ff) : 64u;
+      if (!flush && pos + first_n + 8u * 255u > T) break;
+      // byte j of the window starts at bit pos + (j ? first_n + 8 (j - 1) : 0)
+      const uint32_t start = pos + (lane == 0 ? 0u : first_n + 8u * (4u * (uint32_t)lane - 1u));
+      const uint32_t lead = lane == 0 ? first_n : 8u;                 // bits of the lane's first byte
+      uint32_t v = 0, cnt = 0;                                        // the lane's bits; its complete bytes (0..4)
+      if (start + lead <= T) {
+        const uint32_t w = start >> 5, sh = start & 31u;
+        v = __funnelshift_r(L.ms[w], L.ms[w + 1], sh);               // bits past T are zero
+        cnt = min(4u, 1u + ((T - start - lead) >> 3));
+      }
+      // the four bytes in byte positions (lane 0's first byte may have 7 bits)
+      const uint32_t bytes = (lane == 0 && first_n == 7u) ? ((v & 0x7Fu) | ((v >> 7) << 8)) : v;
+      const uint32_t have = cnt == 4u ? 0xFFFFFFFFu : (1u << (8u * cnt)) - 1u;
+      const uint32_t ffm = (((bytes & 0x7F7F7F7Fu) + 0x01010101u) & bytes & 0x80808080u) & have;   // 0x80 in every complete byte that is 0xFF
+      const uint64_t m_full = __ballot(cnt == 4u), m_ff = __ballot(ffm != 0u);
+      const uint32_t nfull = m_full == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_full);
+      const uint32_t n_ok = nfull == 64u ? 256u : 4u * nfull + rdlane(cnt, (int)nfull);
+      uint32_t f_ff = 256u;
+      if (m_ff) { const uint32_t lf = (uint32_t)__builtin_ctzll(m_ff); f_ff = 4u * lf + ((uint32_t)__builtin_ctz(rdlane(ffm, (int)lf)) >> 3); }
       const uint32_t nc = min(n_ok, f_ff + 1u);
       if (nc == 0) break;
       if (!spilled && ms_k + nc + v_pos + 72u > OUT_CAP) {          // the stage is full: MagSgn moves to HBM
@@ -620,10 +633,13 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
         for (uint32_t i = lane; i < ms_k; i += 64) ms_spill[i] = outb[i];
         spilled = true;
       }
-      if (spilled) {
-        if (ms_k + nc > ms_cap) { err = 1; break; }
-        if ((uint32_t)lane < nc) ms_spill[ms_k + lane] = (uint8_t)v;
-      } else if ((uint32_t)lane < nc) outb[ms_k + lane] = (uint8_t)v;
+      if (spilled && ms_k + nc > ms_cap) { err = 1; break; }
+      uint8_t* dstb = (spilled ? ms_spill : outb) + ms_k + 4u * (uint32_t)lane;
+      const uint32_t mine = nc > 4u * (uint32_t)lane ? min(4u, nc - 4u * (uint32_t)lane) : 0u;
+      if (mine > 0) dstb[0] = (uint8_t)bytes;
+      if (mine > 1) dstb[1] = (uint8_t)(bytes >> 8);
+      if (mine > 2) dstb[2] = (uint8_t)(bytes >> 16);
+      if (mine > 3) dstb[3] = (uint8_t)(bytes >> 24);
       ms_k += nc;
       pos += first_n + 8u * (nc - 1u);
       ms_ff = f_ff < n_ok ? 1u : 0u;
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   };
   // moves the un-emitted bits [pos, T) of a bit buffer to its front and clears the rest
   auto compact = [&](uint32_t* buf, uint32_t pos, uint32_t T, uint32_t nwords) -> uint32_t {
-    const uint32_t rem = T - pos, nw = (rem + 31u) >> 5;           // nw <= 17
+    const uint32_t rem = T - pos, nw = (rem + 31u) >> 5;           // nw <= 64 (MagSgn: < 2048 pending bits), <= 17 (VLC)
     const uint32_t w0 = pos >> 5, sh = pos & 31u;
     uint32_t keep = 0;
     if ((uint32_t)lane < nw) {
