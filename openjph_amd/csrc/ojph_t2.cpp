@@ -421,11 +421,15 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// Bounds-checked big-endian reader: a read past `lim` (the end of the marker segment being parsed, or
+// of the file) returns 0 and sets `bad` instead of touching memory outside the codestream.
 struct Reader {
   const uint8_t* d; size_t n, pos;
-  bool ok(size_t k) const { return pos + k <= n; }
-  uint32_t u8() { return d[pos++]; }
-  uint32_t u16() { uint32_t v = ((uint32_t)d[pos] << 8) | d[pos + 1]; pos += 2; return v; }
+  size_t lim = 0; bool bad = false;
+  Reader(const uint8_t* d_, size_t n_, size_t pos_) : d(d_), n(n_), pos(pos_), lim(n_) {}
+  bool ok(size_t k) const { return k <= n && pos <= n - k; }
+  uint32_t u8() { if (pos >= lim) { bad = true; return 0; } return d[pos++]; }
+  uint32_t u16() { uint32_t v = u8(); return (v << 8) | u8(); }
   uint32_t u32() { uint32_t v = u16(); return (v << 16) | u16(); }
 };
 
@@ -609,7 +613,7 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
 static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
 {
   *out = nullptr;
-  Reader r{ d, len, 0 };
+  Reader r(d, len, 0);
   if (!r.ok(2) || r.u16() != SOC) return OJPHGPU_E_CODESTREAM;
   ojphgpu_params p; memset(&p, 0, sizeof(p));
   bool have_siz = false, have_cod = false, have_qcd = false;
@@ -625,6 +629,9 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
     uint32_t L = r.u16();
     if (L < 2 || !r.ok(L - 2)) return OJPHGPU_E_CODESTREAM;
     size_t next = r.pos + L - 2;
+    r.lim = next;                                                  // no field of this segment lies beyond it
+    // shortest legal segment per marker (T.800 A.5 / A.6): checked before any field is read
+    if ((m == SIZ && L < 41) || (m == COD && L < 12) || (m == QCD && L < 4)) return OJPHGPU_E_CODESTREAM;
     if (m == SIZ) {
       uint32_t rsiz = r.u16();
       if ((rsiz & 0x4000) == 0) return OJPHGPU_E_CODESTREAM;      // not an HTJ2K codestream
@@ -660,6 +667,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
       p.reserved[0] = (style & 0x08u) ? 1u : 0u;                  // vertically causal context (SigProp of foreign streams)
       use_sop = scod & 2; use_eph = scod & 4;
+      if (L != 12 + ((scod & 1) ? 1 + p.num_decomps : 0)) return OJPHGPU_E_CODESTREAM;   // ojph_params.cpp:1201-1202
       if (scod & 1) {
         uint32_t pw = 0, ph = 0; bool uniform = true;
         if (p.num_decomps >= 36) return OJPHGPU_E_INVALID;
@@ -731,8 +739,10 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
     } else if (m == RGN || m == POC || m == PPM || m == DFS || m == ATK) {
       return OJPHGPU_E_INVALID;                                    // Part-2 / unsupported markers
     }
-    r.pos = next;
+    if (r.bad) return OJPHGPU_E_CODESTREAM;                        // a field ran past its segment
+    r.pos = next; r.lim = r.n;
   }
+  r.lim = r.n;
   if (!have_siz || !have_cod || !have_qcd) return OJPHGPU_E_CODESTREAM;
   std::unique_ptr<ojphgpu_plan> hold(new (std::nothrow) ojphgpu_plan());   // freed on every way out but the last
   ojphgpu_plan* h = hold.get();
@@ -757,6 +767,11 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
     if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { return OJPHGPU_E_CODESTREAM; }
   for (Band& B : P.bands) {
     B.K_max = band_Kmax(P, B.comp, B.res, B.band);
+    // K_max of a parsed QCD / QCC is whatever the codestream says: an exponent of 0 with no guard bit
+    // wraps below zero, and more than 31 magnitude bits is the reference's 64-bit sample path
+    // (ojph_codeblock.cpp:74-99), which this library does not have -- neither may reach 31 - K_max
+    if ((int32_t)B.K_max < 0) return OJPHGPU_E_CODESTREAM;
+    if (B.K_max > 31) return OJPHGPU_E_INVALID;
     if (!P.style(B.comp).rev) {
       float dlt = band_delta(P, B.comp, B.res, B.band);
       dlt /= (float)(1u << (31 - B.K_max));

@@ -19,6 +19,66 @@ def synth_image(nc, h, w, bit_depth, seed=1234, signed=False):
     return img
 
 
+# ---------------------------------------------------------------------------------------------
+# The BASELINE workloads exactly as SURVEY.md section 8(d) specifies them.  The survey's known
+# answers (appendix B: KA-3 = 16 674 994 bytes for C2, KA-4 = 72 601 187 bytes / MSE 1.81186 /
+# PAE 8 for C3 with the generic reference build) are reproduced by ONE numpy Generator,
+# default_rng(1234), that draws C2's noise first -- N(0, 6^2), shape (3, 2160, 3840) -- and then, from
+# the continued stream, C3's -- N(0, 40^2), shape (3, 4320, 7680); float64 arithmetic, clip, then
+# truncation to the integer container (found by search against the reference built here; pinned by
+# tests/test_survey_ka.py and tests/golden/survey_ka.json).
+# ---------------------------------------------------------------------------------------------
+def _family(h, w, mid, a, b, c, px, py, pxy):
+    """mid + a sin(x/px) + b cos(y/py) + c sin((x+y)/pxy), evaluated in float64 in this order (the
+    terms depend on x, y and x + y only, so they come from 1-D tables: same values as an mgrid)"""
+    x = np.arange(w, dtype=np.float64)
+    y = np.arange(h, dtype=np.float64)
+    s = np.arange(w + h, dtype=np.float64)
+    base = (mid + a * np.sin(x / px))[None, :] + (b * np.cos(y / py))[:, None]
+    t = c * np.sin(s / pxy)
+    idx = np.arange(h)[:, None] + np.arange(w)[None, :]
+    return base + t[idx]
+
+
+def _noisy(base, noise, maxval):
+    return np.clip(base[None] + noise, 0, maxval).astype(np.uint16).astype(np.int32)
+
+
+def survey_c2(seed=1234):
+    """C2: 3840x2160x3 8-bit (KA-3 with the default seed)."""
+    rng = np.random.default_rng(seed)
+    return _noisy(_family(2160, 3840, 128, 60, 50, 20, 97, 61, 13), rng.normal(0, 6, (3, 2160, 3840)), 255)
+
+
+def survey_c3(seed=1234, rows=4320):
+    """C3: 7680x4320x3 12-bit planar (KA-4 with the default seed).  rows < 4320 gives the top rows of
+    the same image (the noise of a (3, rows, 7680) prefix is NOT a prefix of the full draw, so the
+    full noise is drawn and cut)."""
+    rng = np.random.default_rng(seed)
+    rng.normal(0, 6, (3, 2160, 3840))                  # C2's draw comes first in the survey's stream
+    noise = rng.normal(0, 40, (3, 4320, 7680))
+    img = _noisy(_family(4320, 7680, 2048, 900, 800, 300, 197, 161, 23), noise, 4095)
+    return img if rows >= 4320 else np.ascontiguousarray(img[:, :rows])
+
+
+def survey_c4(seed=1234, size=16384):
+    """C4: 16384x16384x1 16-bit, 'the same family scaled to 16 bits' (C2's formula x 256)."""
+    rng = np.random.default_rng(seed)
+    base = _family(size, size, 32768, 15360, 12800, 5120, 97, 61, 13)
+    out = np.empty((1, size, size), dtype=np.int32)
+    step = 2048                                          # in slabs: the float64 noise of the whole image would take 2 GB
+    for r0 in range(0, size, step):
+        n = rng.normal(0, 1536, (min(step, size - r0), size))
+        out[0, r0:r0 + n.shape[0]] = np.clip(base[r0:r0 + n.shape[0]] + n, 0, 65535).astype(np.uint16)
+    return out
+
+
+def survey_c5(frame=0, seed=1234):
+    """C5: one 3840x2160x3 10-bit frame of the batch, 'the C2 family scaled to 10 bits, seed = 1234 + frame'."""
+    rng = np.random.default_rng(seed + frame)
+    return _noisy(_family(2160, 3840, 512, 240, 200, 80, 97, 61, 13), rng.normal(0, 24, (3, 2160, 3840)), 1023)
+
+
 def c1_image():
     """BASELINE config #1 / reference tests/test_truncated_decode.cpp:111."""
     y, x = np.mgrid[0:256, 0:256]
