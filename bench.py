@@ -43,10 +43,29 @@ WORKLOADS = {
 }
 
 
+def workload_image(name, seed_offset=0, frame=0):
+    """the workload's input exactly as SURVEY.md section 8(d) specifies it (tests/synth.py survey_*: C2 and
+    C3 reproduce the survey's known answers KA-3 / KA-4 with seed_offset 0); [C, H, W] int32"""
+    from tests import synth
+    if name.startswith("c3"):
+        return synth.survey_c3(seed=1234 + seed_offset)
+    if name.startswith("c2"):
+        return synth.survey_c2(seed=1234 + seed_offset)
+    if name.startswith("c4"):
+        return synth.survey_c4(seed=1234 + seed_offset)
+    if name.startswith("c5"):
+        return synth.survey_c5(frame=frame, seed=1234 + seed_offset)
+    return synth.c1_image()
+
+
 def dwt_alg_bytes(nsamples, levels, container=32):
     """each level reads its input once and writes its four sub-bands once, 4-byte elements; the image
     side of the top level moves container / 8 bytes per sample"""
     return 8.0 * nsamples * sum(4.0 ** -l for l in range(levels)) - (4.0 - container / 8.0) * nsamples * (1 if levels else 0)
+
+
+def plan_is_tiled(tile):
+    return tile[0] > 0
 
 
 def main():
@@ -74,10 +93,9 @@ def main():
     # the all-core CPU figure forks worker processes: done first, before this process owns a GPU context
     cpu_all = None
     if rank == 0 and not args.no_cpu_baseline:
-        from tests.synth import synth_image as _synth
         w_, h_, nc_, bd_, rev_, ct_, qstep_, _tile = WORKLOADS[args.workload]
         try:
-            cpu_all = cpu_baseline_all_cores(_synth(nc_, min(h_, 2048), w_, bd_, seed=1234), bd_, rev_, ct_, qstep_)
+            cpu_all = cpu_baseline_all_cores(workload_image(args.workload)[:, :min(h_, 2048)], bd_, rev_, ct_, qstep_)
         except Exception as e:                     # the single-thread figure stands on its own
             cpu_all = {"value": None, "error": str(e)[:200]}
     import torch
@@ -98,15 +116,14 @@ def main():
 
     from openjph_amd import codec
     from openjph_amd.plan import make_params
-    from tests.synth import synth_image
 
     w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[args.workload]
     frames = args.frames if args.frames > 0 else (8 if "batch" in args.workload else 1)
     nsamples = w * h * nc * frames
     if frames > 1:
-        img = np.stack([synth_image(nc, h, w, bd, seed=1234 + rank * frames + f) for f in range(frames)])
+        img = np.stack([workload_image(args.workload, 0, rank * frames + f) for f in range(frames)])
     else:
-        img = synth_image(nc, h, w, bd, seed=1234 + rank)
+        img = workload_image(args.workload, 0 if plan_is_tiled(tile) else rank)
     def to_dev(a):                               # the frame as it sits in HBM
         return torch.from_numpy(a.astype(np.int16) if args.container == 16 else a).to(dev)
     d_img = to_dev(img)
@@ -118,8 +135,7 @@ def main():
     # tiled frames shard by contiguous runs of tiles: all ranks share one frame (strong scaling).
     tiled = plan.num_tiles > 1 and world > 1 and frames == 1
     if tiled:
-        img = synth_image(nc, h, w, bd, seed=1234)
-        d_img = to_dev(img)
+        d_img = to_dev(img)                      # all ranks share the one frame
         my_tiles = shard.tile_range(plan.num_tiles, rank, world)
         assert my_tiles[1] > 0, "more ranks than tiles"
     else:

@@ -162,6 +162,17 @@ float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band); 
 // worst-case coded size of a block of w*h samples with K_max magnitude bits
 uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max);
 
+// Tier-2 writer as a layout (ojph_t2.cpp): `blob` holds every byte of the output that is not a code-block
+// byte (markers, packet headers) in codestream order; a job places n bytes at output position dst, taken
+// from the blob (blob = 1, src = offset in it) or from the code-block data (blob = 0, src = the block's
+// offset in it).  Executed by memcpy on the host (t2_place_host) or by a kernel on the device (the frame
+// pipeline), so that the coded bytes need not pass through a host copy.
+struct T2Job { uint64_t dst, src; uint32_t n, blob; };
+struct T2Layout { std::vector<uint8_t> blob; std::vector<T2Job> jobs; uint64_t total = 0; };
+int t2_layout_tiles(const Plan& P, const ojphgpu_coded_block* cb, size_t t0, size_t t1, T2Layout& L, uint32_t* len_out);
+int t2_layout_codestream(const Plan& P, const ojphgpu_coded_block* cb, T2Layout& L);
+void t2_place_host(const T2Layout& L, const uint8_t* data, uint8_t* out);
+
 // Nothing may leave the C ABI as a C++ exception (a codestream from anywhere can ask for tables the
 // host cannot hold): entry points that build containers run their bodies through this.
 template <typename F>

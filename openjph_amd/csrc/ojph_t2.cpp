@@ -13,10 +13,12 @@
 //                          bit reader                         ojph_bitbuffer_read.h:66-176
 #include "ojph_plan.h"
 
+#include "ojph_pool.h"
+
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <memory>
-#include <thread>
 #include <vector>
 
 namespace ojphgpu {
@@ -36,30 +38,14 @@ struct ByteSink {
   void bytes(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; v.insert(v.end(), b, b + n); }
 };
 
-// MSB-first bit writer with the 0xFF -> 7-bit rule of packet headers
-struct HeaderBits {
-  std::vector<uint8_t>& out;
-  int avail = 8; uint32_t tmp = 0;
-  explicit HeaderBits(std::vector<uint8_t>& o) : out(o) {}
-  void bit(uint32_t b) {
-    --avail; tmp |= (b & 1u) << avail;
-    if (avail <= 0) { out.push_back((uint8_t)tmp); avail = (tmp != 0xFF) ? 8 : 7; tmp = 0; }
-  }
-  void bits(uint32_t data, int n) { for (int i = n - 1; i >= 0; --i) bit(data >> i); }
-  void zeros(int n) { for (int i = 0; i < n; ++i) bit(0); }
-  void terminate() { if (avail < 8) out.push_back((uint8_t)tmp); }
-};
-
 inline uint32_t log2ceil(uint32_t x) { uint32_t t = 31 - (uint32_t)__builtin_clz(x); return t + ((x & (x - 1)) ? 1 : 0); }
 inline int bitlen(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
 
-// Tag tree storage laid out like the reference's (ojph_precinct.cpp:58-84): level l is a flat
-// array of 4^(levels-1-l) entries pre-filled with `fill`, addressed x + y * ceil(w / 2^l) with no
-// bounds check.  The encoder's min-reduction reads (2x+1, 2y) even when 2x+1 == row width, which
-// wraps into the next row (or into the fill value); byte-identical headers need the same reads.
+// Tag tree storage of the PARSER, laid out like the reference's (ojph_precinct.cpp:58-84): level l is a
+// flat array addressed x + y * ceil(w / 2^l); lv[levels] is the virtual parent of the root (value 0).
 struct TagTree {
   uint32_t w, h, levels;
-  std::vector<std::vector<uint8_t>> lv;   // lv[levels] is the virtual parent of the root (value 0)
+  std::vector<std::vector<uint8_t>> lv;
   void init(uint32_t w_, uint32_t h_, uint32_t levels_, uint8_t fill) {
     w = w_; h = h_; levels = levels_; lv.assign(levels + 1, std::vector<uint8_t>());
     for (uint32_t l = 0; l < levels; ++l)
@@ -153,91 +139,183 @@ void write_main_header(const Plan& P, ByteSink& s)
   }
 }
 
-// Encodes the header of one packet (one precinct).  Returns false for an empty packet.
-bool write_packet_header(const Plan& P, const Precinct& pc, const ojphgpu_coded_block* cb,
-                         std::vector<uint8_t>& hdr, uint64_t& body_bytes)
+// ---------------------------------------------------------------------------------------------
+// Packet headers (precinct::prepare_precinct + precinct::write, ojph_precinct.cpp:94-324), organised
+// for a machine with many host cores next to a GPU:
+//   1. the UNIT of work is one sub-band of one packet: its inclusion / missing-MSB tag trees and the
+//      per-block fields depend on nothing outside it, so every unit is coded independently (in
+//      parallel, ojph_pool.h) into an UN-stuffed, MSB-first bit string;
+//   2. a packet header is the concatenation of its units' bit strings behind the "non-empty" bit,
+//      pushed through the header's 0xFF -> 7-bit stuffing rule (bb_put_bit, ojph_bitbuffer_write.h:
+//      83-147) in one pass -- again independent per packet;
+//   3. tile-part lengths and the byte position of every code-block follow from prefix sums.
+// The result is a LAYOUT: the bytes that are not code-block bytes (markers + packet headers) as one
+// blob, and a list of placement jobs "n bytes at dst come from the blob / from the block data at
+// src".  The host writer executes the jobs with memcpy; the frame pipeline hands them to a kernel so
+// that the coded bytes never pass through a host copy (ojphgpu_pipe.cpp).
+// ---------------------------------------------------------------------------------------------
+
+// un-stuffed MSB-first bit string
+struct BitString {
+  std::vector<uint8_t> v;
+  uint64_t acc = 0; int cnt = 0;                  // cnt bits pending in the low end of acc
+  uint64_t nbits = 0;
+  void put(uint32_t value, int n) {                // the low n bits of value, n <= 32
+    if (n <= 0) return;
+    acc = (acc << n) | (value & (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)));
+    cnt += n; nbits += (uint64_t)n;
+    while (cnt >= 8) { cnt -= 8; v.push_back((uint8_t)(acc >> cnt)); }
+  }
+  void zeros(int n) { while (n > 0) { const int k = n > 32 ? 32 : n; put(0, k); n -= k; } }
+  void finish() { if (cnt) v.push_back((uint8_t)(acc << (8 - cnt))); cnt = 0; }
+};
+
+// packet-header byte writer: MSB-first, a byte that follows 0xFF carries 7 bits
+struct StuffWriter {
+  std::vector<uint8_t>& out;
+  uint32_t tmp = 0; int avail = 8;
+  explicit StuffWriter(std::vector<uint8_t>& o) : out(o) {}
+  void bit(uint32_t b) {
+    --avail; tmp |= (b & 1u) << avail;
+    if (avail == 0) { out.push_back((uint8_t)tmp); avail = (tmp != 0xFF) ? 8 : 7; tmp = 0; }
+  }
+  void zeros(int n) { for (int i = 0; i < n; ++i) bit(0); }
+  // nbits bits of an un-stuffed MSB-first string, a field of up to `avail` bits at a time
+  void append(const uint8_t* src, uint64_t nbits) {
+    uint64_t pos = 0;
+    while (pos < nbits) {
+      const int take = (int)std::min<uint64_t>((uint64_t)avail, nbits - pos);
+      const size_t byte = (size_t)(pos >> 3); const int off = (int)(pos & 7);
+      uint32_t w = (uint32_t)src[byte] << 8;
+      if (off + take > 8) w |= src[byte + 1];
+      const uint32_t field = (w >> (16 - off - take)) & ((1u << take) - 1u);
+      avail -= take; tmp |= field << avail; pos += (uint64_t)take;
+      if (avail == 0) { out.push_back((uint8_t)tmp); avail = (tmp != 0xFF) ? 8 : 7; tmp = 0; }
+    }
+  }
+  void terminate() { if (avail < 8) out.push_back((uint8_t)tmp); }
+};
+
+struct Unit {                     // one sub-band of one packet
+  uint32_t pkt;                   // index into the packet list being coded
+  int band;                       // 0..3
+  BitString bits;
+  uint64_t body = 0;              // code-block bytes of the unit
+  bool any = false;               // some block of the unit is coded
+};
+
+// Tag-tree value pyramid with the reference's storage rule (ojph_precinct.cpp:58-84, 128-170): level l is
+// a flat array addressed x + y * W_l, W_l = ceil(w / 2^l), pre-filled with 255; the min-reduction reads
+// (2x+1, 2y), (2x, 2y+1), (2x+1, 2y+1) of the level below WITHOUT a bounds check, so at an odd width the
+// "right" child is the first entry of the next row and at an odd height the "lower" children are fill
+// values.  Byte-identical headers need exactly these reads; they never reach beyond (H_l + 1) * W_l.
+struct Pyramid {
+  std::vector<uint8_t> val, flag;
+  std::vector<size_t> off; std::vector<uint32_t> W, H;
+  uint32_t levels = 0;
+  void shape(uint32_t w, uint32_t h, uint32_t levels_) {
+    levels = levels_; off.assign(levels + 1, 0); W.assign(levels, 0); H.assign(levels, 0);
+    size_t total = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+      W[l] = (w + (1u << l) - 1) >> l; H[l] = (h + (1u << l) - 1) >> l;
+      off[l] = total; total += (size_t)(H[l] + 1) * W[l] + 2;
+    }
+    off[levels] = total;                              // the virtual parent of the root: one entry, value 0
+    val.assign(total + 1, 255); val[total] = 0;
+    flag.assign(total + 1, 0);
+  }
+  uint8_t* level(uint32_t l) { return val.data() + off[l]; }
+  void reduce() {
+    for (uint32_t l = 1; l < levels; ++l) {
+      const uint8_t* c = level(l - 1); uint8_t* p = level(l);
+      const size_t cw = W[l - 1];
+      for (uint32_t y = 0; y < H[l]; ++y)
+        for (uint32_t x = 0; x < W[l]; ++x) {
+          const size_t i = (size_t)2 * x + (size_t)2 * y * cw;
+          p[x + (size_t)y * W[l]] = std::min(std::min(c[i], c[i + 1]), std::min(c[i + cw], c[i + cw + 1]));
+        }
+    }
+  }
+  size_t node(uint32_t x, uint32_t y, uint32_t l) const { return l >= levels ? off[levels] : off[l] + (x >> l) + (size_t)(y >> l) * W[l]; }
+};
+
+void code_unit(const Plan& P, const Precinct& pc, const ojphgpu_coded_block* cb, Unit& u)
 {
   const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
-  HeaderBits bb(hdr);
-  bool started = false; int skipped = 0;
-  body_bytes = 0;
-  for (int s = 0; s < 4; ++s) {
-    if (R.band[s] < 0) continue;
-    const Band& B = P.bands[(size_t)R.band[s]];
-    if (B.empty) continue;
-    const Rect& q = pc.cb[s];
-    if (q.w == 0 || q.h == 0) continue;
-    uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
-    TagTree inc, incf, mm, mmf;
-    inc.init(q.w, q.h, levels, 255); incf.init(q.w, q.h, levels, 0);
-    mm.init(q.w, q.h, levels, 255); mmf.init(q.w, q.h, levels, 0);
-    auto blk = [&](uint32_t x, uint32_t y) -> const ojphgpu_coded_block& {
-      return cb[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
-    };
+  const Band& B = P.bands[(size_t)R.band[u.band]];
+  const Rect& q = pc.cb[u.band];
+  const uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
+  static thread_local Pyramid inc, mm;
+  inc.shape(q.w, q.h, levels); mm.shape(q.w, q.h, levels);
+  const ojphgpu_coded_block* first = cb + B.first_block + (size_t)q.y0 * B.nbx + q.x0;
+  {
+    uint8_t* i0 = inc.level(0); uint8_t* m0 = mm.level(0);
     for (uint32_t y = 0; y < q.h; ++y)
       for (uint32_t x = 0; x < q.w; ++x) {
-        const ojphgpu_coded_block& k = blk(x, y);
-        inc.at(x, y, 0) = (k.len1 == 0) ? 1 : 0;
-        mm.at(x, y, 0) = (uint8_t)(k.len1 ? k.missing_msbs : 0);
-      }
-    for (uint32_t l = 1; l < levels; ++l) {
-      uint32_t hh = (q.h + (1u << l) - 1) >> l, ww = (q.w + (1u << l) - 1) >> l;
-      for (uint32_t y = 0; y < hh; ++y)
-        for (uint32_t x = 0; x < ww; ++x) {
-          uint8_t a = std::min(std::min(inc.at(2 * x, 2 * y, l - 1), inc.at(2 * x + 1, 2 * y, l - 1)),
-                               std::min(inc.at(2 * x, 2 * y + 1, l - 1), inc.at(2 * x + 1, 2 * y + 1, l - 1)));
-          uint8_t b = std::min(std::min(mm.at(2 * x, 2 * y, l - 1), mm.at(2 * x + 1, 2 * y, l - 1)),
-                               std::min(mm.at(2 * x, 2 * y + 1, l - 1), mm.at(2 * x + 1, 2 * y + 1, l - 1)));
-          inc.at(x, y, l) = a; mm.at(x, y, l) = b;
-        }
-    }
-    if (inc.at(0, 0, levels - 1) != 0) {           // no block of this band is coded
-      if (started) bb.bit(0); else ++skipped;
-      continue;
-    }
-    if (!started) { started = true; bb.bit(1); bb.zeros(skipped); skipped = 0; }
-    for (uint32_t y = 0; y < q.h; ++y)
-      for (uint32_t x = 0; x < q.w; ++x) {
-        const ojphgpu_coded_block& k = blk(x, y);
-        for (uint32_t cl = levels; cl > 0; --cl) {   // inclusion
-          uint32_t l = cl - 1;
-          if (incf.at(x >> l, y >> l, l) == 0) {
-            uint32_t sk = (uint32_t)inc.at(x >> l, y >> l, l) - (uint32_t)inc.at(x >> cl, y >> cl, cl);
-            bb.bit(1 - sk);
-            incf.at(x >> l, y >> l, l) = 1;
-          }
-          if (inc.at(x >> l, y >> l, l) > 0) break;
-        }
-        if (k.len1 == 0) continue;
-        for (uint32_t cl = levels; cl > 0; --cl) {   // missing MSBs
-          uint32_t l = cl - 1;
-          if (mmf.at(x >> l, y >> l, l) == 0) {
-            int nz = (int)mm.at(x >> l, y >> l, l) - (int)mm.at(x >> cl, y >> cl, cl);
-            bb.zeros(nz); bb.bit(1);
-            mmf.at(x >> l, y >> l, l) = 1;
-          }
-        }
-        uint32_t np = k.num_passes ? k.num_passes : 1;
-        if (np == 3) bb.bits(12, 4); else if (np == 2) bb.bits(2, 2); else bb.bits(0, 1);
-        int bits1 = bitlen(k.len1), extra = np > 2 ? 1 : 0, bits2 = np > 1 ? bitlen(k.len2) : 0;
-        int nb = std::max(std::max(bits1, bits2 - extra) - 3, 0);
-        bb.bits(0xFFFFFFFEu, nb + 1);
-        bb.bits(k.len1, nb + 3);
-        if (np > 1) bb.bits(k.len2, nb + 3 + extra);
-        body_bytes += (uint64_t)k.len1 + k.len2;
+        const ojphgpu_coded_block& k = first[(size_t)y * B.nbx + x];
+        i0[x + (size_t)y * q.w] = k.len1 == 0 ? 1 : 0;                      // single layer: included in it, or never
+        m0[x + (size_t)y * q.w] = (uint8_t)(k.len1 ? k.missing_msbs : 0);
       }
   }
-  if (started) bb.terminate();
-  return started;
+  inc.reduce(); mm.reduce();
+  u.any = inc.val[inc.node(0, 0, levels - 1)] == 0;
+  if (!u.any) return;
+  BitString& bs = u.bits;
+  bs.v.reserve((size_t)q.w * q.h * 4 + 16);
+  for (uint32_t y = 0; y < q.h; ++y)
+    for (uint32_t x = 0; x < q.w; ++x) {
+      const ojphgpu_coded_block& k = first[(size_t)y * B.nbx + x];
+      for (uint32_t cl = levels; cl > 0; --cl) {     // inclusion: from the root down, each node once
+        const size_t n = inc.node(x, y, cl - 1);
+        if (!inc.flag[n]) { bs.put(1u - ((uint32_t)inc.val[n] - (uint32_t)inc.val[inc.node(x, y, cl)]), 1); inc.flag[n] = 1; }
+        if (inc.val[n] > 0) break;
+      }
+      if (k.len1 == 0) continue;
+      for (uint32_t cl = levels; cl > 0; --cl) {     // missing MSBs: value above the parent's in unary
+        const size_t n = mm.node(x, y, cl - 1);
+        if (!mm.flag[n]) { bs.zeros((int)mm.val[n] - (int)mm.val[mm.node(x, y, cl)]); bs.put(1, 1); mm.flag[n] = 1; }
+      }
+      const uint32_t np = k.num_passes ? k.num_passes : 1;
+      if (np == 3) bs.put(12, 4); else if (np == 2) bs.put(2, 2); else bs.put(0, 1);
+      // pass lengths (ojph_precinct.cpp:250-265): Lblock = 3 + nb, announced by nb ones and a zero
+      const int bits1 = bitlen(k.len1), extra = np > 2 ? 1 : 0, bits2 = np > 1 ? bitlen(k.len2) : 0;
+      const int nb = std::max(std::max(bits1, bits2 - extra) - 3, 0);
+      bs.put(0xFFFFFFFEu, nb + 1);
+      bs.put(k.len1, nb + 3);
+      if (np > 1) bs.put(k.len2, nb + 3 + extra);
+      u.body += (uint64_t)k.len1 + k.len2;
+    }
+  bs.finish();
 }
 
-}  // namespace
+struct Packet {
+  const Precinct* pc;
+  uint32_t tile;                  // index relative to the first tile being written
+  uint32_t part;
+  uint32_t unit_first, unit_count;
+  std::vector<uint8_t> hdr;       // stuffed header bytes; empty = the packet is the single byte 0
+  uint64_t body = 0;
+};
 
-}  // namespace ojphgpu
-
-using namespace ojphgpu;
-
-namespace {
+void code_packet(Packet& k, std::vector<Unit>& units)
+{
+  bool any = false;
+  for (uint32_t i = 0; i < k.unit_count; ++i) any |= units[k.unit_first + i].any;
+  if (!any) return;
+  size_t bytes = 2;
+  for (uint32_t i = 0; i < k.unit_count; ++i) bytes += units[k.unit_first + i].bits.v.size() + 1;
+  k.hdr.reserve(bytes + bytes / 64 + 4);
+  StuffWriter sw(k.hdr);
+  bool started = false; int skipped = 0;
+  for (uint32_t i = 0; i < k.unit_count; ++i) {
+    Unit& u = units[k.unit_first + i];
+    if (!u.any) { if (started) sw.bit(0); else ++skipped; continue; }       // the band's inclusion root says "nothing here"
+    if (!started) { started = true; sw.bit(1); sw.zeros(skipped); }
+    sw.append(u.bits.v.data(), u.bits.nbits);
+    k.body += u.body;
+  }
+  sw.terminate();
+}
 
 // the tile-part a packet belongs to (tile::flush: TPsot = r, c, or c + r * num_comps)
 uint32_t part_of(const Plan& P, const Precinct& pc)
@@ -250,107 +328,167 @@ uint32_t part_of(const Plan& P, const Precinct& pc)
   }
 }
 
-// Tile-parts of tiles [t0, t1): SOT + SOD + packets (tile::flush, ojph_tile.cpp:584-774).  Tiles
-// are independent of each other, which is what lets ranks shard them.  len_out[(t - t0) *
-// parts_per_tile + k] receives Psot of tile-part k of tile t.  Returns 0 / OJPHGPU_E_OVERFLOW with
-// *out_len = bytes needed.
-int write_tile_parts(const Plan& P, const uint8_t* data, const ojphgpu_coded_block* cb, size_t t0, size_t t1,
-                     uint8_t* out, size_t cap, size_t* out_len, uint32_t* len_out)
+}  // namespace
+
+// Layout of the tile-parts of tiles [t0, t1): SOT + SOD + packets (tile::flush, ojph_tile.cpp:584-774).
+// Tiles are independent of each other, which is what lets ranks shard them.  len_out[(t - t0) *
+// parts_per_tile + k] receives Psot of tile-part k of tile t.  Positions count from the first SOT.
+int t2_layout_tiles(const Plan& P, const ojphgpu_coded_block* cb, size_t t0, size_t t1, T2Layout& L, uint32_t* len_out)
 {
-  // packet headers first (sizes are needed for Psot / TLM)
-  struct Pkt { std::vector<uint8_t> hdr; bool coded; };
+  L.blob.clear(); L.jobs.clear(); L.total = 0;
   const uint32_t ppt = P.parts_per_tile;
-  std::vector<std::vector<Pkt>> tile_pkts(t1 - t0);
-  std::vector<uint64_t> part_bytes((t1 - t0) * ppt, 0);
-  size_t total = 0;
+  std::vector<Packet> pkts;
+  std::vector<Unit> units;
   for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
-    tile_pkts[t - t0].resize(T.packets.size());
     uint32_t last_part = 0;
     for (size_t i = 0; i < T.packets.size(); ++i) {
-      Pkt& k = tile_pkts[t - t0][i]; uint64_t body = 0;
       const Precinct& pc = P.precincts[T.packets[i]];
-      k.coded = write_packet_header(P, pc, cb, k.hdr, body);
-      const uint32_t part = part_of(P, pc);
-      if (part < last_part || part >= ppt) return OJPHGPU_E_INVALID;       // a tile-part is a run of the packet sequence
-      last_part = part;
-      part_bytes[(t - t0) * ppt + part] += k.coded ? k.hdr.size() + body : 1;
+      Packet k; k.pc = &pc; k.tile = (uint32_t)(t - t0); k.part = part_of(P, pc);
+      if (k.part < last_part || k.part >= ppt) return OJPHGPU_E_INVALID;       // a tile-part is a run of the packet sequence
+      last_part = k.part;
+      k.unit_first = (uint32_t)units.size(); k.unit_count = 0;
+      const Resolution& R = P.ress[P.tcomps[T.comps[pc.comp]].res[pc.res]];
+      for (int s = 0; s < 4; ++s) {
+        if (R.band[s] < 0 || P.bands[(size_t)R.band[s]].empty) continue;
+        if (pc.cb[s].w == 0 || pc.cb[s].h == 0) continue;
+        Unit u; u.pkt = (uint32_t)pkts.size(); u.band = s;
+        units.push_back(std::move(u)); k.unit_count++;
+      }
+      pkts.push_back(std::move(k));
     }
+  }
+  // 1. units, 2. packets -- both embarrassingly parallel.  Nothing may throw on a pool thread.
+  std::atomic<int> failed{ 0 };
+  parallel_for(units.size(), [&](size_t i) {
+    try { code_unit(P, *pkts[units[i].pkt].pc, cb, units[i]); } catch (...) { failed = 1; }
+  });
+  if (failed) return OJPHGPU_E_NOMEM;
+  parallel_for(pkts.size(), [&](size_t i) {
+    try { code_packet(pkts[i], units); } catch (...) { failed = 1; }
+  });
+  if (failed) return OJPHGPU_E_NOMEM;
+  // 3. tile-part lengths
+  std::vector<uint64_t> part_bytes((t1 - t0) * ppt, 0);
+  for (const Packet& k : pkts) part_bytes[(size_t)k.tile * ppt + k.part] += k.hdr.empty() ? 1 : k.hdr.size() + k.body;
+  uint64_t total = 0; size_t blob_bytes = 0;
+  for (size_t t = t0; t < t1; ++t)
     for (uint32_t k = 0; k < ppt; ++k) {
       const uint64_t b = part_bytes[(t - t0) * ppt + k];
       if (b + 14 > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
       if (!P.part_exists(k)) { if (len_out) len_out[(t - t0) * ppt + k] = 0; continue; }   // length 0 = no such tile-part
       if (len_out) len_out[(t - t0) * ppt + k] = (uint32_t)b + 14;
-      total += 14 + b;
+      total += 14 + b; blob_bytes += 14;
     }
+  for (const Packet& k : pkts) blob_bytes += k.hdr.empty() ? 1 : k.hdr.size();
+  L.total = total;
+  // 4. the blob (everything that is not a code-block byte, in codestream order) and the placement jobs
+  L.blob.reserve(blob_bytes);
+  size_t njobs = 0;
+  for (size_t t = t0; t < t1; ++t) njobs += 2 * P.tiles[t].packets.size() + 2 * ppt;
+  uint64_t w = 0;                                    // write position in the output
+  size_t run_start = 0; uint64_t run_dst = 0;        // the blob bytes laid down since the last body
+  auto flush_run = [&]() {
+    if (L.blob.size() > run_start) L.jobs.push_back(T2Job{ run_dst, run_start, (uint32_t)(L.blob.size() - run_start), 1 });
+    run_start = L.blob.size(); run_dst = w;
+  };
+  auto b8 = [&](uint32_t x) { L.blob.push_back((uint8_t)x); ++w; };
+  auto b16 = [&](uint32_t x) { b8(x >> 8); b8(x); };
+  auto b32 = [&](uint32_t x) { b16(x >> 16); b16(x & 0xFFFF); };
+  size_t pi = 0;
+  {
+    size_t blocks = 0;
+    for (const Packet& k : pkts) for (uint32_t i = 0; i < k.unit_count; ++i) { const Rect& q = k.pc->cb[units[k.unit_first + i].band]; blocks += (size_t)q.w * q.h; }
+    L.jobs.reserve(njobs + blocks);
   }
-  *out_len = total;
-  if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
-
-  // markers and packet headers are laid down serially; the code-block bodies -- nearly all of the
-  // bytes -- are queued as copy jobs and moved by a few host threads (at GPU kernel speeds a
-  // single-threaded memcpy of the 90 MB of an 8K frame would dominate the whole encode)
-  struct Job { uint8_t* dst; const uint8_t* src; size_t n; };
-  std::vector<Job> jobs;
-  uint8_t* w = out;
-  auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
-  auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
   for (size_t t = t0; t < t1; ++t) {
     const Tile& T = P.tiles[t];
     uint32_t next_part = 0;                          // tile-parts are written in order, empty ones included
     auto open_parts_up_to = [&](uint32_t part) {
       for (; next_part <= part; ++next_part) {
         if (!P.part_exists(next_part)) continue;
-        u16(SOT); u16(10); u16(T.idx); u32((uint32_t)part_bytes[(t - t0) * ppt + next_part] + 14);
-        *w++ = (uint8_t)next_part; *w++ = (uint8_t)ppt;
-        u16(SOD);
+        b16(SOT); b16(10); b16(T.idx); b32((uint32_t)part_bytes[(t - t0) * ppt + next_part] + 14);
+        b8(next_part); b8(ppt);
+        b16(SOD);
       }
     };
-    for (size_t i = 0; i < T.packets.size(); ++i) {
-      const Pkt& k = tile_pkts[t - t0][i];
-      const Precinct& pc = P.precincts[T.packets[i]];
-      open_parts_up_to(part_of(P, pc));
-      if (!k.coded) { *w++ = 0; continue; }
-      memcpy(w, k.hdr.data(), k.hdr.size()); w += k.hdr.size();
-      const Resolution& R = P.ress[P.tcomps[T.comps[pc.comp]].res[pc.res]];
-      for (int s = 0; s < 4; ++s) {
-        if (R.band[s] < 0) continue;
-        const Band& B = P.bands[(size_t)R.band[s]];
-        if (B.empty) continue;
-        const Rect& q = pc.cb[s];
-        for (uint32_t y = 0; y < q.h; ++y)
+    for (size_t i = 0; i < T.packets.size(); ++i, ++pi) {
+      const Packet& k = pkts[pi];
+      open_parts_up_to(k.part);
+      if (k.hdr.empty()) { b8(0); continue; }
+      L.blob.insert(L.blob.end(), k.hdr.begin(), k.hdr.end()); w += k.hdr.size();
+      if (k.body == 0) continue;
+      flush_run();
+      const Resolution& R = P.ress[P.tcomps[T.comps[k.pc->comp]].res[k.pc->res]];
+      for (uint32_t ui = 0; ui < k.unit_count; ++ui) {
+        const Unit& u = units[k.unit_first + ui];
+        const Band& B = P.bands[(size_t)R.band[u.band]];
+        const Rect& q = k.pc->cb[u.band];
+        for (uint32_t y = 0; y < q.h; ++y) {
+          const ojphgpu_coded_block* row = cb + B.first_block + (size_t)(q.y0 + y) * B.nbx + q.x0;
           for (uint32_t x = 0; x < q.w; ++x) {
-            const ojphgpu_coded_block& b = cb[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
-            size_t n = (size_t)b.len1 + b.len2;
-            if (n) { jobs.push_back(Job{ w, data + b.offset, n }); w += n; }
+            const uint32_t n = row[x].len1 + row[x].len2;
+            if (n) { L.jobs.push_back(T2Job{ w, row[x].offset, n, 0 }); w += n; }
           }
+        }
       }
+      run_dst = w;
     }
     open_parts_up_to(ppt - 1);
   }
-  if ((size_t)(w - out) != total) return OJPHGPU_E_INVALID;
-  size_t body = 0;
-  for (const Job& j : jobs) body += j.n;
-  unsigned nthreads = std::thread::hardware_concurrency();
-  nthreads = std::min<unsigned>(nthreads ? nthreads : 1, 16);
-  if (body < (4u << 20) || jobs.size() < 64) nthreads = 1;
-  auto run = [&jobs](size_t a, size_t b) { for (size_t i = a; i < b; ++i) memcpy(jobs[i].dst, jobs[i].src, jobs[i].n); };
-  if (nthreads <= 1) run(0, jobs.size());
-  else {
-    std::vector<std::thread> th;
-    size_t start = 0, acc = 0; unsigned made = 0;
-    const size_t share = body / nthreads + 1;
-    for (size_t i = 0; i < jobs.size(); ++i) {
-      acc += jobs[i].n;
-      if (acc >= share && made + 1 < nthreads) { th.emplace_back(run, start, i + 1); start = i + 1; acc = 0; ++made; }
-    }
-    run(start, jobs.size());
-    for (std::thread& x : th) x.join();
-  }
+  flush_run();
+  if (w != total) return OJPHGPU_E_INVALID;
   return OJPHGPU_OK;
 }
 
-}  // namespace
+// Executes a layout on the host: dst = out + job.dst, source = the blob or the block data.  The
+// code-block bytes -- nearly all of the bytes -- are moved by the pool's threads.
+void t2_place_host(const T2Layout& L, const uint8_t* data, uint8_t* out)
+{
+  const size_t n = L.jobs.size();
+  if (L.total < (4u << 20) || n < 64) {
+    for (const T2Job& j : L.jobs) memcpy(out + j.dst, (j.blob ? L.blob.data() : data) + j.src, j.n);
+    return;
+  }
+  const size_t chunks = std::min<size_t>(n, (size_t)pool_threads() * 4);
+  std::vector<size_t> cut(chunks + 1, n);                 // equal shares of bytes, not of jobs
+  { uint64_t acc = 0; size_t c = 0; cut[0] = 0;
+    for (size_t i = 0; i < n && c + 1 < chunks; ++i) { acc += L.jobs[i].n; if (acc * chunks >= (uint64_t)(c + 1) * L.total) cut[++c] = i + 1; }
+    for (size_t k = c + 1; k < chunks; ++k) cut[k] = n; }
+  parallel_for(chunks, [&](size_t c) {
+    for (size_t i = cut[c]; i < cut[c + 1]; ++i) { const T2Job& j = L.jobs[i]; memcpy(out + j.dst, (j.blob ? L.blob.data() : data) + j.src, j.n); }
+  });
+}
+
+int t2_main_header(const Plan& P, const uint32_t* tile_part_len, std::vector<uint8_t>& out);
+
+// Layout of a whole codestream: main header | tile-parts | EOC
+int t2_layout_codestream(const Plan& P, const ojphgpu_coded_block* cb, T2Layout& L)
+{
+  const size_t nt = P.tiles.size();
+  std::vector<uint32_t> lens(nt * P.parts_per_tile, 0);
+  int rc = t2_layout_tiles(P, cb, 0, nt, L, lens.data());
+  if (rc) return rc;
+  std::vector<uint8_t> hdr;
+  rc = t2_main_header(P, lens.data(), hdr);
+  if (rc) return rc;
+  // the main header goes in front: shift every position by its length, prepend it to the blob
+  const uint64_t hl = hdr.size();
+  for (T2Job& j : L.jobs) { j.dst += hl; if (j.blob) j.src += hl; }
+  L.blob.insert(L.blob.begin(), hdr.begin(), hdr.end());
+  if (!L.jobs.empty() && L.jobs[0].blob && L.jobs[0].dst == hl) { L.jobs[0].dst = 0; L.jobs[0].src = 0; L.jobs[0].n += (uint32_t)hl; }
+  else L.jobs.insert(L.jobs.begin(), T2Job{ 0, 0, (uint32_t)hl, 1 });
+  const uint64_t end = hl + L.total;
+  const size_t eoc_at = L.blob.size();
+  L.blob.push_back((uint8_t)(EOC >> 8)); L.blob.push_back((uint8_t)EOC);
+  L.jobs.push_back(T2Job{ end, eoc_at, 2, 1 });
+  L.total = end + 2;
+  return OJPHGPU_OK;
+}
+
+}  // namespace ojphgpu
+
+using namespace ojphgpu;
 
 extern "C" int ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* data, const ojphgpu_coded_block* cb,
                                        uint32_t tile_first, uint32_t tile_count, uint8_t* out, size_t cap,
@@ -359,8 +497,39 @@ extern "C" int ojphgpu_t2_write_tiles(const ojphgpu_plan* plan, const uint8_t* d
   if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
   if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
-  return no_throw([&] { return write_tile_parts(P, data, cb, tile_first, (size_t)tile_first + tile_count, out, cap, out_len, tile_part_len); });
+  return no_throw([&]() -> int {
+    T2Layout L;
+    int rc = t2_layout_tiles(P, cb, tile_first, (size_t)tile_first + tile_count, L, tile_part_len);
+    if (rc) return rc;
+    *out_len = (size_t)L.total;
+    if (!out || cap < L.total) return OJPHGPU_E_OVERFLOW;
+    t2_place_host(L, data, out);
+    return OJPHGPU_OK;
+  });
 }
+
+namespace ojphgpu {
+
+// SOC .. last main-header marker (+ TLM when requested, which needs every tile-part's Psot)
+int t2_main_header(const Plan& P, const uint32_t* tile_part_len, std::vector<uint8_t>& out)
+{
+  ByteSink hdr;
+  write_main_header(P, hdr);
+  size_t per_tile = 0;
+  for (uint32_t k = 0; k < P.parts_per_tile; ++k) per_tile += P.part_exists(k) ? 1 : 0;
+  const size_t nparts = P.tiles.size() * per_tile;
+  if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
+    if (4 + 6 * nparts > 65535) return OJPHGPU_E_INVALID;
+    hdr.u16(TLM); hdr.u16(4 + 6 * (uint32_t)nparts); hdr.u8(0); hdr.u8(0x60);
+    for (size_t t = 0; t < P.tiles.size(); ++t)
+      for (uint32_t k = 0; k < P.parts_per_tile; ++k)
+        if (P.part_exists(k)) { hdr.u16((uint32_t)t); hdr.u32(tile_part_len ? tile_part_len[t * P.parts_per_tile + k] : 0); }
+  }
+  out.swap(hdr.v);
+  return OJPHGPU_OK;
+}
+
+}  // namespace ojphgpu
 
 extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile_part_len, uint8_t* out,
                                              size_t cap, size_t* out_len)
@@ -369,27 +538,13 @@ extern "C" int ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint
   const Plan& P = plan->plan;
   if (P.p.tlm && !tile_part_len) return OJPHGPU_E_INVALID;
   return no_throw([&]() -> int {
-  ByteSink hdr;
-  write_main_header(P, hdr);
-  size_t total = hdr.v.size();
-  size_t per_tile = 0;
-  for (uint32_t k = 0; k < P.parts_per_tile; ++k) per_tile += P.part_exists(k) ? 1 : 0;
-  const size_t nparts = P.tiles.size() * per_tile;
-  if (P.p.tlm && 4 + 6 * nparts > 65535) return OJPHGPU_E_INVALID;
-  if (P.p.tlm) total += 6 + 6 * nparts;
-  *out_len = total;
-  if (!out || cap < total) return OJPHGPU_E_OVERFLOW;
-  uint8_t* w = out;
-  memcpy(w, hdr.v.data(), hdr.v.size()); w += hdr.v.size();
-  auto u16 = [&](uint32_t x) { *w++ = (uint8_t)(x >> 8); *w++ = (uint8_t)x; };
-  auto u32 = [&](uint32_t x) { u16(x >> 16); u16(x & 0xFFFF); };
-  if (P.p.tlm) {                                     // ojph_params.cpp:2460-2519
-    u16(TLM); u16(4 + 6 * (uint32_t)nparts); *w++ = 0; *w++ = 0x60;
-    for (size_t t = 0; t < P.tiles.size(); ++t)
-      for (uint32_t k = 0; k < P.parts_per_tile; ++k)
-        if (P.part_exists(k)) { u16((uint32_t)t); u32(tile_part_len[t * P.parts_per_tile + k]); }
-  }
-  return OJPHGPU_OK;
+    std::vector<uint8_t> hdr;
+    int rc = t2_main_header(P, tile_part_len, hdr);
+    if (rc) return rc;
+    *out_len = hdr.size();
+    if (!out || cap < hdr.size()) return OJPHGPU_E_OVERFLOW;
+    memcpy(out, hdr.data(), hdr.size());
+    return OJPHGPU_OK;
   });
 }
 
@@ -399,20 +554,14 @@ extern "C" int ojphgpu_t2_write(const ojphgpu_plan* plan, const uint8_t* data,
 {
   if (!plan || !cb || !out_len) return OJPHGPU_E_INVALID;
   const Plan& P = plan->plan;
-  const size_t nt = P.tiles.size();
   return no_throw([&]() -> int {
-  std::vector<uint32_t> lens(nt * P.parts_per_tile, 0);
-  size_t hlen = 0, tlen = 0;
-  int rc = ojphgpu_t2_write_main_header(plan, lens.data(), nullptr, 0, &hlen);       // size only (independent of lens)
-  if (rc != OJPHGPU_E_OVERFLOW && rc != OJPHGPU_OK) return rc;
-  const bool room = out && cap > hlen + 2;
-  rc = write_tile_parts(P, data, cb, 0, nt, room ? out + hlen : nullptr, room ? cap - hlen - 2 : 0, &tlen, lens.data());
-  *out_len = hlen + tlen + 2;
-  if (rc) return rc;
-  rc = ojphgpu_t2_write_main_header(plan, lens.data(), out, hlen, &hlen);
-  if (rc) return rc;
-  out[hlen + tlen] = (uint8_t)(EOC >> 8); out[hlen + tlen + 1] = (uint8_t)EOC;
-  return OJPHGPU_OK;
+    T2Layout L;
+    int rc = t2_layout_codestream(P, cb, L);
+    if (rc) return rc;
+    *out_len = (size_t)L.total;
+    if (!out || cap < L.total) return OJPHGPU_E_OVERFLOW;
+    t2_place_host(L, data, out);
+    return OJPHGPU_OK;
   });
 }
 

@@ -706,9 +706,20 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
         Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
         Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||
         Q.p.color_transform != P.p.color_transform || Q.p.tile_w != P.p.tile_w || Q.p.tile_h != P.p.tile_h ||
-        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h || Q.p.qstep != P.p.qstep ||
-        memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
+        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h ||
+        Q.p.image_x0 != P.p.image_x0 || Q.p.image_y0 != P.p.image_y0 || Q.p.tile_x0 != P.p.tile_x0 || Q.p.tile_y0 != P.p.tile_y0 ||
+        memcmp(Q.p.comp_dx, P.p.comp_dx, sizeof(P.p.comp_dx)) != 0 || memcmp(Q.p.comp_dy, P.p.comp_dy, sizeof(P.p.comp_dy)) != 0 ||
+        memcmp(Q.p.comp_depth, P.p.comp_depth, sizeof(P.p.comp_depth)) != 0 || memcmp(Q.p.comp_sign, P.p.comp_sign, sizeof(P.p.comp_sign)) != 0 ||
+        Q.nlt3 != P.nlt3 || Q.bands.size() != P.bands.size() || memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
       return OJPHGPU_E_INVALID;
+    // the launches are laid out from frame 0's geometry: every block must sit where frame 0 has it (precinct
+    // sizes move the code-block grid).  Quantisation may differ: K_max / delta are taken per frame below.
+    for (size_t i = 0; f && i < P.blocks.size(); ++i) {
+      const Block& a = P.blocks[i]; const Block& b = Q.blocks[i];
+      if (a.band != b.band || a.r.x0 != b.r.x0 || a.r.y0 != b.r.y0 || a.r.w != b.r.w || a.r.h != b.r.h) return OJPHGPU_E_INVALID;
+    }
+    for (size_t i = 0; f && i < P.bands.size(); ++i)
+      if (P.bands[i].plane_off != Q.bands[i].plane_off || P.bands[i].pitch != Q.bands[i].pitch) return OJPHGPU_E_INVALID;
   }
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -756,11 +767,11 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   const Plan& Q = plans[f]->plan;
   uint64_t max_off = 0, min_off = ~0ull;
   for (size_t i = 0; i < ids.size(); ++i) {
-    const Block& k = P.blocks[ids[i]]; const Band& B = P.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];
+    const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
     ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i]; memset(&o, 0, sizeof(o));
     o.coef_off = (uint64_t)f * P.arena_elems + B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
-    o.reversible = (uint8_t)((P.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
+    o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) d->any_refine = true;
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;

@@ -411,6 +411,25 @@ def test_frame_batch_equals_frame_by_frame(kw):
         assert np.array_equal(out[f], want_dec), "frame %d" % f
 
 
+def test_frame_batch_with_different_quantisation():
+    """a batch decoder takes K_max / delta from each frame's own QCD (frames 1.. were
+    decoded with frame 0's step sizes); frames whose code-block grid differs are refused"""
+    from openjph_amd import capi, codec
+    from tests import cpu_pipeline as cp
+    frames = [synth_image(1, 150, 130, 12, seed=50 + f) for f in range(3)]
+    streams = [bytes(cp.encode(frames[f], bit_depth=12, reversible=False, qstep=q)[0]) for f, q in enumerate((0.002, 0.01, 0.0005))]
+    dec = codec.Decoder(streams)
+    out = dec.run_device().cpu().numpy()
+    assert dec.failed_blocks() == 0
+    for f in range(3):
+        want, _ = cp.decode(streams[f])
+        assert np.array_equal(out[f], want), "frame %d" % f
+    # guard bits / exponents of a reversible stream may differ too (different bit depth is a different frame format: refused)
+    other = bytes(cp.encode(frames[0], bit_depth=12, reversible=False, qstep=0.002, precinct=(64, 64))[0])
+    with pytest.raises(capi.OjphError):
+        codec.Decoder([streams[0], other])
+
+
 def test_multi_pass_codestream_decodes_like_the_oracle():
     """Foreign-style codestreams (blocks with SigProp / MagRef segments): GPU decode == oracle decode
     (the oracle is pinned to the reference on such streams by tests/test_cpu_parity.py)."""

@@ -30,7 +30,7 @@ def test_parser_fuzz_under_asan(tmp_path):
     exe = os.path.join(tmp, "t2_parse_fuzz")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            os.path.join(ROOT, "tests", "fuzz", "t2_parse_fuzz.cpp"), os.path.join(CSRC, "ojph_plan.cpp"),
-                           os.path.join(CSRC, "ojph_t2.cpp"), "-o", exe, "-pthread"])
+                           os.path.join(CSRC, "ojph_t2.cpp"), os.path.join(CSRC, "ojph_pool.cpp"), "-o", exe, "-pthread"])
     from tests import cpu_pipeline as cp
     from tests.test_cpu_parity import coc_case, nlt_case
     img = synth_image(3, 70, 90, 8, seed=1)
