@@ -34,6 +34,7 @@ extern "C" {
 #define OJPHGPU_E_CODESTREAM   -4   /* malformed codestream (== the reference's OJPH_ERROR)   */
 #define OJPHGPU_E_OVERFLOW     -5   /* output buffer too small; *out_len holds the need       */
 #define OJPHGPU_E_BLOCK        -6   /* a code-block failed to decode (non-resilient mode)     */
+#define OJPHGPU_E_AGAIN        -7   /* a frame pipeline has no free slot: collect a result first */
 
 /* ------------------------------------------------------------------------------------------ *
  * 1. Codestream parameters: what ojph::param_siz / param_cod / param_qcd setters carry
@@ -435,6 +436,55 @@ int  ojphgpu_encoder_ht_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, u
  * highest resolution first; decode: lowest first); *n = number of levels written */
 int  ojphgpu_encoder_level_timing(ojphgpu_encoder* enc, float* out, uint32_t cap, uint32_t* n);
 int  ojphgpu_decoder_level_timing(ojphgpu_decoder* dec, float* out, uint32_t cap, uint32_t* n);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 6. Frame pipelines: sequences of frames of one shape with PCIe copies, kernels and host Tier-2 of
+ *    consecutive frames overlapped (pinned staging, separate copy-in / compute / copy-out streams).
+ *    In the reference one codestream object is re-used across the frames of a sequence through
+ *    codestream::restart() (ojph_codestream.h:204, ojph_codestream_local.cpp:78-110): exchange() hands out
+ *    line buffers, flush() writes the file (:1148-1270); read_headers() / create() / pull() read one
+ *    (:769-1146, :1227-1270).  The pipe keeps that contract per frame -- the caller writes samples into
+ *    memory the library hands out and receives a finished codestream, or the other way round -- and
+ *    keeps `depth` (2..16) frames in flight.  One caller thread per pipe; results come back in
+ *    submission order.  container_bits = 16 | 32 (see ojphgpu_encoder_run_device16); host_threads =
+ *    threads that do a frame's host part (packet headers / parsing), 0 = 2.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ojphgpu_enc_pipe ojphgpu_enc_pipe;
+typedef struct ojphgpu_dec_pipe ojphgpu_dec_pipe;
+
+int  ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uint32_t depth, int container_bits,
+                             uint32_t host_threads, ojphgpu_enc_pipe** out);
+void ojphgpu_enc_pipe_destroy(ojphgpu_enc_pipe* pipe);
+/* pinned host memory for the next frame -- the frame layout of ojphgpu_plan_comp_info in container_bits-bit
+ * elements -- which the caller fills (what exchange() hands out line by line).  OJPHGPU_E_AGAIN when all
+ * `depth` slots are in flight: collect first. */
+int  ojphgpu_enc_pipe_acquire(ojphgpu_enc_pipe* pipe, void** h_frame, size_t* bytes);
+/* the acquired frame is complete (flush()): queues H2D -> kernels -> D2H of the block lengths -> packet
+ * headers (host threads) -> codestream assembly on the device -> D2H, and returns at once */
+int  ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* pipe);
+/* the oldest submitted frame's codestream (SOC .. EOC, byte-identical to ojphgpu_encode's); blocks until it
+ * is complete.  *h_codestream is pinned memory of the pipe, valid until the next _collect / _destroy. */
+int  ojphgpu_enc_pipe_collect(ojphgpu_enc_pipe* pipe, const uint8_t** h_codestream, size_t* len);
+/* out[0] frames completed, [1] mean host Tier-2 time per frame (ms), [2] mean submit -> codestream latency
+ * (ms), [3] host threads coding the packet headers of one frame */
+int  ojphgpu_enc_pipe_stats(ojphgpu_enc_pipe* pipe, double out[4]);
+
+/* the first codestream of the sequence fixes the frame geometry (it is only parsed, not decoded); every
+ * submitted codestream must describe the same frame format and code-block grid (quantisation may differ) */
+int  ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, int resilient, int device, uint32_t depth,
+                             int container_bits, uint32_t host_threads, ojphgpu_dec_pipe** out);
+void ojphgpu_dec_pipe_destroy(ojphgpu_dec_pipe* pipe);
+int  ojphgpu_dec_pipe_plan(ojphgpu_dec_pipe* pipe, const ojphgpu_plan** plan);   /* owned by the pipe */
+/* pinned host memory for the next codestream of `len` bytes (read the file straight into it) */
+int  ojphgpu_dec_pipe_acquire(ojphgpu_dec_pipe* pipe, size_t len, uint8_t** h_codestream);
+/* queues parse (host threads) -> H2D of the code-block bytes + descriptors -> kernels -> D2H of the frame */
+int  ojphgpu_dec_pipe_submit(ojphgpu_dec_pipe* pipe);
+/* the oldest submitted frame: container_bits-bit samples in the layout of ojphgpu_plan_comp_info, in
+ * pinned memory valid until the next _collect / _destroy.  OJPHGPU_E_BLOCK when code-blocks failed and the
+ * pipe is not resilient (the frame is still handed out, failed blocks zeroed, *failed_blocks counts them). */
+int  ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* pipe, const void** h_frame, size_t* bytes, uint32_t* failed_blocks);
+/* out[0] frames completed, [1] mean host parse time per frame (ms), [2] mean submit -> frame latency (ms), [3] host threads */
+int  ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* pipe, double out[4]);
 
 const char* ojphgpu_version(void);
 

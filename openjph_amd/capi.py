@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libojphgpu.so")
 
-OK, E_INVALID, E_NOMEM, E_HIP, E_CODESTREAM, E_OVERFLOW, E_BLOCK = 0, -1, -2, -3, -4, -5, -6
+OK, E_INVALID, E_NOMEM, E_HIP, E_CODESTREAM, E_OVERFLOW, E_BLOCK, E_AGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
 
 
@@ -199,6 +199,20 @@ SIGNATURES = {
     "ojphgpu_decoder_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_encoder_level_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "ojphgpu_decoder_level_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ojphgpu_enc_pipe_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ojphgpu_enc_pipe_destroy": (None, [C.c_void_p]),
+    "ojphgpu_enc_pipe_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ojphgpu_enc_pipe_submit": (C.c_int, [C.c_void_p]),
+    "ojphgpu_enc_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ojphgpu_enc_pipe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "ojphgpu_dec_pipe_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32,
+                                          C.POINTER(C.c_void_p)]),
+    "ojphgpu_dec_pipe_destroy": (None, [C.c_void_p]),
+    "ojphgpu_dec_pipe_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ojphgpu_dec_pipe_acquire": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ojphgpu_dec_pipe_submit": (C.c_int, [C.c_void_p]),
+    "ojphgpu_dec_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "ojphgpu_dec_pipe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "ojphgpu_version": (C.c_char_p, []),
 }
 
@@ -234,7 +248,8 @@ class OjphError(RuntimeError):
     def __init__(self, code, what=""):
         names = {E_INVALID: "invalid argument / unsupported parameters", E_NOMEM: "out of memory",
                  E_HIP: "HIP runtime error (no GPU?)", E_CODESTREAM: "malformed codestream",
-                 E_OVERFLOW: "output buffer too small", E_BLOCK: "error decoding a codeblock"}
+                 E_OVERFLOW: "output buffer too small", E_BLOCK: "error decoding a codeblock",
+                 E_AGAIN: "no free pipeline slot"}
         super().__init__("ojph error: %s (%d) %s" % (names.get(code, "?"), code, what))
         self.code = code
 

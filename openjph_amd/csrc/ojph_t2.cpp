@@ -41,23 +41,24 @@ struct ByteSink {
 inline uint32_t log2ceil(uint32_t x) { uint32_t t = 31 - (uint32_t)__builtin_clz(x); return t + ((x & (x - 1)) ? 1 : 0); }
 inline int bitlen(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
 
-// Tag tree storage of the PARSER, laid out like the reference's (ojph_precinct.cpp:58-84): level l is a
-// flat array addressed x + y * ceil(w / 2^l); lv[levels] is the virtual parent of the root (value 0).
-struct TagTree {
-  uint32_t w, h, levels;
-  std::vector<std::vector<uint8_t>> lv;
-  void init(uint32_t w_, uint32_t h_, uint32_t levels_, uint8_t fill) {
-    w = w_; h = h_; levels = levels_; lv.assign(levels + 1, std::vector<uint8_t>());
-    for (uint32_t l = 0; l < levels; ++l)
-      lv[l].assign((size_t)1 << ((levels - 1 - l) << 1), fill);
-    lv[levels].assign(1, 0);
+// Tag-tree node storage of the PARSER (precinct::parse, ojph_precinct.cpp:328-573): value and "already
+// decoded" flag per node, level l a flat array of ceil(w / 2^l) x ceil(h / 2^l) entries; node(x, y, levels)
+// is the virtual parent of the root (value 0).  One allocation, re-used from band to band.
+struct ParseTree {
+  std::vector<uint8_t> val, flag;
+  uint32_t levels = 0;
+  size_t off[34]; uint32_t W[34];
+  void shape(uint32_t w, uint32_t h, uint32_t levels_) {
+    levels = levels_;
+    size_t total = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+      W[l] = (w + (1u << l) - 1) >> l;
+      off[l] = total; total += (size_t)W[l] * ((h + (1u << l) - 1) >> l);
+    }
+    off[levels] = total; W[levels] = 1;
+    val.assign(total + 1, 0); flag.assign(total + 1, 0);
   }
-  uint8_t& at(uint32_t x, uint32_t y, uint32_t l) {
-    if (l >= levels) return lv[levels][0];
-    size_t i = x + (size_t)y * ((w + (1u << l) - 1) >> l);
-    if (i >= lv[l].size()) { static uint8_t pad; pad = 255; return pad; }
-    return lv[l][i];
-  }
+  size_t node(uint32_t x, uint32_t y, uint32_t l) const { return l >= levels ? off[levels] : off[l] + (x >> l) + (size_t)(y >> l) * W[l]; }
 };
 
 void write_main_header(const Plan& P, ByteSink& s)
@@ -657,37 +658,37 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
       if (b == 0) { bb.terminate(); pos = bb.pos; if (use_eph && pos + 2 <= end) pos += 2; return bb.threw ? OJPHGPU_E_CODESTREAM : 0; }
       empty_packet = false;
     }
-    uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
-    TagTree inc, incf, mm, mmf;
-    inc.init(q.w, q.h, levels, 0); incf.init(q.w, q.h, levels, 0);
-    mm.init(q.w, q.h, levels, 0); mmf.init(q.w, q.h, levels, 0);
+    const uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
+    if (levels > 32) return OJPHGPU_E_CODESTREAM;
+    static thread_local ParseTree inc, mm;
+    inc.shape(q.w, q.h, levels); mm.shape(q.w, q.h, levels);
     for (uint32_t y = 0; y < q.h; ++y)
       for (uint32_t x = 0; x < q.w; ++x) {
         CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
         bool empty_cb = false;
-        for (uint32_t cl = levels; cl > 0; --cl) {
-          uint32_t l = cl - 1;
-          empty_cb = inc.at(x >> l, y >> l, l) == 1;
+        for (uint32_t cl = levels; cl > 0; --cl) {     // inclusion, from the root down
+          const size_t n = inc.node(x, y, cl - 1);
+          empty_cb = inc.val[n] == 1;
           if (empty_cb) break;
-          if (incf.at(x >> l, y >> l, l) == 0) {
+          if (!inc.flag[n]) {
             uint32_t b; if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
             empty_cb = (b == 0);
-            inc.at(x >> l, y >> l, l) = (uint8_t)(1 - b);
-            incf.at(x >> l, y >> l, l) = 1;
+            inc.val[n] = (uint8_t)(1 - b);
+            inc.flag[n] = 1;
           }
           if (empty_cb) break;
         }
         if (empty_cb) continue;
         uint32_t mmsbs = 0;
-        for (uint32_t cl = levels; cl > 0; --cl) {
-          uint32_t l = cl - 1;
-          mmsbs = mm.at(x >> cl, y >> cl, cl);
-          if (mmf.at(x >> l, y >> l, l) == 0) {
+        for (uint32_t cl = levels; cl > 0; --cl) {     // missing MSBs: the parent's value plus a unary increment
+          const size_t n = mm.node(x, y, cl - 1);
+          mmsbs = mm.val[mm.node(x, y, cl)];
+          if (!mm.flag[n]) {
             uint32_t b = 0;
             while (b == 0) { if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM; mmsbs += 1 - b; }
-            mm.at(x >> l, y >> l, l) = (uint8_t)mmsbs;
-            mmf.at(x >> l, y >> l, l) = 1;
-          } else mmsbs = mm.at(x >> l, y >> l, l);
+            mm.val[n] = (uint8_t)mmsbs;
+            mm.flag[n] = 1;
+          } else mmsbs = mm.val[n];
         }
         if (mmsbs > B.K_max) return OJPHGPU_E_CODESTREAM;
         uint32_t b, np = 1;

@@ -48,264 +48,7 @@ int ensure_tables()
 
 }  // namespace ojphgpu
 
-namespace {
-
-#define HIPCHK(x) do { if ((x) != hipSuccess) return OJPHGPU_E_HIP; } while (0)
-
-struct DeviceBuf {
-  void* p = nullptr; size_t n = 0;
-  int alloc(size_t bytes) { n = bytes; return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
-  void release() { if (p) (void)hipFree(p); p = nullptr; }
-};
-
-// pinned host staging buffer (grows, never shrinks): D2H lands here at PCIe speed and without the
-// page-fault cost of a fresh pageable allocation
-struct HostBuf {
-  uint8_t* p = nullptr; size_t cap = 0; bool pinned = false; unsigned uses = 0;
-  // the first run of a codec object gets plain memory (pinning costs more than one pageable copy
-  // saves); an object that is run again is a long-lived one and gets a pinned buffer
-  int reserve(size_t bytes) {
-    const bool want_pin = ++uses >= 2;
-    if (bytes <= cap && (pinned || !want_pin)) return 0;
-    release();
-    void* q = nullptr;
-    if (want_pin && hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess) { p = (uint8_t*)q; pinned = true; }
-    else { (void)hipGetLastError(); p = (uint8_t*)malloc(bytes); pinned = false; }
-    cap = p ? bytes : 0;
-    return p ? 0 : -1;
-  }
-  void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
-};
-
-// One DWT launch: the levels `depth` steps below the top of their component, of the components with
-// the same wavelet.  Without COCs that is one batch per resolution; with them a component may have
-// fewer levels than another, or the other wavelet, and a depth splits in two.
-struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; };
-
-// DWT descriptors grouped so that one launch handles every tile-component
-struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
-
-template <typename F>
-void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, F f)
-{
-  for (const ojphgpu_level_info& lv : P.levels) {
-    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev) continue;
-    const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
-    if (L > depth && lv.res == L - depth) f(lv);
-  }
-}
-
-uint32_t max_recon_decomps(const Plan& P)
-{
-  uint32_t m = 0;
-  for (uint32_t c = 0; c < P.p.num_comps; ++c) m = std::max(m, P.recon_decomps(c));
-  return m;
-}
-
-void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
-{
-  descs.clear(); batches.clear();
-  const uint32_t depths = max_recon_decomps(P);
-  for (uint32_t depth = 0; depth < depths; ++depth)
-    for (int rev = 0; rev < 2; ++rev) {
-      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1 };
-      for_levels_of(P, tr, depth, rev != 0, [&](const ojphgpu_level_info& lv) {
-        ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
-        d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
-        d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
-        d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
-        descs.push_back(d);
-        b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
-      });
-      if (b.count) batches.push_back(b);
-    }
-}
-
-// Descriptors of the top DWT level of every component with the un-decomposed plane addressed inside
-// the image-sized component planes (for ojphgpu_dwt_forward_image / _inverse_image); batch.img_first
-// points at them.  None when the fused path does not apply (colour transform).
-void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches,
-                             std::vector<ojphgpu_dwt_desc>& out)
-{
-  out.clear();
-  if (P.p.color_transform || P.any_nlt3) return;          // those conversions live in the conversion kernels
-  for (LevelBatch& b : batches) {
-    if (b.depth != 0 || b.count == 0) continue;
-    b.img_first = (int)out.size();
-    size_t k = 0;
-    for_levels_of(P, tr, 0, b.rev, [&](const ojphgpu_level_info& lv) {
-      ojphgpu_dwt_desc d = descs[b.first + k++];
-      const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
-      const CompGeo& g = P.comps[lv.comp];
-      const Rect& rr = P.ress[tc.res[lv.res]].r;              // the tile-component at the reconstructed resolution
-      d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
-      d.src_pitch = g.w;
-      d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
-      out.push_back(d);
-    });
-  }
-}
-
-// One descriptor per tile and component, in that order; a component whose conversion is fused into
-// its top DWT level (no colour transform, at least one level) gets an empty one.  Returns whether
-// any component is left for the conversion kernels.
-bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
-{
-  descs.clear(); max_w = max_h = 0;
-  bool any = false;
-  for (const Tile& t : P.tiles) {
-    if (!tr.has(t.idx)) continue;
-    for (uint32_t c = 0; c < P.p.num_comps; ++c) {
-      const uint32_t L = P.recon_decomps(c);
-      const TileComp& tc = P.tcomps[t.comps[c]];
-      const Resolution& R = P.ress[tc.res[L]];
-      ojphgpu_convert_desc d; memset(&d, 0, sizeof(d));
-      if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
-      else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
-      const CompGeo& g = P.comps[c];
-      d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
-      d.img_pitch = g.w; d.img_off = g.frame_off;
-      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u);   // 0x200: bit 10 says which conversion
-      if (P.p.color_transform || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
-      descs.push_back(d);
-      max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
-    }
-  }
-  return any;
-}
-
-// Frame batches: the same plan applied to `nframes` independent frames in one set of launches
-// (config C5: a batch of independent 4K frames).  Frame f lives f * arena_elems further in the arena
-// and f * frame_elems further in the image buffer; descriptors are simply replicated, batch by batch.
-void replicate_levels(std::vector<ojphgpu_dwt_desc>& descs, std::vector<ojphgpu_dwt_desc>& img_descs, std::vector<LevelBatch>& batches,
-                      uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
-{
-  if (nframes <= 1) return;
-  std::vector<ojphgpu_dwt_desc> out, iout; std::vector<LevelBatch> nb;
-  for (const LevelBatch& b : batches) {
-    LevelBatch n = b;
-    n.first = (uint32_t)out.size(); n.count = b.count * nframes;
-    if (b.img_first >= 0) n.img_first = (int)iout.size();
-    for (uint32_t f = 0; f < nframes; ++f)
-      for (uint32_t i = 0; i < b.count; ++i) {
-        const uint64_t o = (uint64_t)f * arena_elems;
-        ojphgpu_dwt_desc d = descs[b.first + i];
-        d.src_off += o; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
-        out.push_back(d);
-        if (b.img_first >= 0) {
-          d = img_descs[(size_t)b.img_first + i];
-          d.src_off += (uint64_t)f * frame_elems; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
-          iout.push_back(d);
-        }
-      }
-    nb.push_back(n);
-  }
-  descs.swap(out); img_descs.swap(iout); batches.swap(nb);
-}
-
-void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
-{
-  if (nframes <= 1 || descs.empty()) return;
-  const size_t n = descs.size();
-  for (uint32_t f = 1; f < nframes; ++f)
-    for (size_t i = 0; i < n; ++i) {
-      ojphgpu_convert_desc d = descs[i];
-      d.plane_off += (uint64_t)f * arena_elems; d.img_off += (uint64_t)f * frame_elems;
-      descs.push_back(d);
-    }
-}
-
-// plan-order indices of the code-blocks that belong to the tile range
-std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
-{
-  std::vector<uint32_t> ids;
-  for (size_t i = 0; i < P.blocks.size(); ++i) {
-    const Band& B = P.bands[P.blocks[i].band];
-    if (tr.has(B.tile) && B.res <= P.top_read_res(B.comp)) ids.push_back((uint32_t)i);   // resolutions above are not decoded: their bands stay zero
-  }
-  return ids;
-}
-
-// Timing of one run_device: every launch (or group of launches) is bracketed by a pair of HIP events
-// on the stream it is issued on -- launches of one run may sit on two streams -- and tagged with a
-// kind; per-kind sums and the wall time of the whole run are read back afterwards.
-struct Spans {
-  struct Span { hipEvent_t a, b; int kind; };
-  std::vector<Span> pool;            // events are created once and reused
-  size_t used = 0;
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  bool ok = false;
-  bool detail = true;                // per-launch spans on; off = only the wall time of the run (two events)
-  int init() { ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess; return ok ? 0 : -1; }
-  void destroy() {
-    for (Span& x : pool) { (void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b); }
-    if (t0) (void)hipEventDestroy(t0);
-    if (t1) (void)hipEventDestroy(t1);
-    pool.clear();
-  }
-  void start(hipStream_t s) { used = 0; if (ok) (void)hipEventRecord(t0, s); }
-  void finish(hipStream_t s) { if (ok) (void)hipEventRecord(t1, s); }
-  int begin(int kind, hipStream_t s) {
-    if (!ok || !detail) return -1;
-    if (used == pool.size()) {
-      Span x{ nullptr, nullptr, kind };
-      if (hipEventCreate(&x.a) != hipSuccess || hipEventCreate(&x.b) != hipSuccess) { ok = false; return -1; }
-      pool.push_back(x);
-    }
-    pool[used].kind = kind;
-    (void)hipEventRecord(pool[used].a, s);
-    return (int)used++;
-  }
-  void end(int id, hipStream_t s) { if (ok && id >= 0) (void)hipEventRecord(pool[(size_t)id].b, s); }
-  // sum of the spans of `kind`; kind < 0: wall time of the run
-  int read(int kind, float* out) {
-    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
-    if (kind < 0) return hipEventElapsedTime(out, t0, t1) == hipSuccess ? 0 : -1;
-    float sum = 0;
-    for (size_t i = 0; i < used; ++i)
-      if (pool[i].kind == kind) { float ms = 0; if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) != hipSuccess) return -1; sum += ms; }
-    *out = sum;
-    return 0;
-  }
-  // the individual spans of `kind`, in issue order
-  int read_each(int kind, float* out, uint32_t cap) {
-    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
-    int n = 0;
-    for (size_t i = 0; i < used; ++i)
-      if (pool[i].kind == kind && (uint32_t)n < cap) { if (hipEventElapsedTime(&out[n], pool[i].a, pool[i].b) != hipSuccess) return -1; ++n; }
-    return n;
-  }
-};
-enum { SP_CONVERT = 0, SP_DWT = 1, SP_HT_ENC = 2, SP_PREP = 3, SP_STEP1 = 4, SP_STEP2 = 5, SP_REFINE = 6 };
-
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-struct ojphgpu_encoder {
-  const ojphgpu_plan* handle = nullptr;
-  const Plan* P = nullptr;
-  int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, scratch, out, results, counters;
-  bool need_convert = false;                       // some component is not converted inside its top DWT level
-  std::vector<LevelBatch> batches;
-  uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
-  TileRange tiles{ 0, 0 };
-  uint32_t nframes = 1;                            // frames coded per run_device (batch)
-  bool fetched = false;                            // results / bytes of the last run are on the host
-  uint64_t nbytes = 0;
-  std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes (per frame)
-  std::vector<ojphgpu_cb_result> h_results;
-  HostBuf h_out, h_res;
-  Spans timer;
-  bool ran = false;
-  // overlap of the block coder with the lower DWT levels: the blocks of the top resolution (3/4 of
-  // the samples) only need the first DWT level, so they are coded on a second stream while the
-  // small, latency-bound launches of levels 2..L run on the main one
-  uint32_t n_top = 0;                              // descriptors [0, n_top) = blocks of the top resolution
-  int widths_top = 0, widths_rest = 0;             // which block encoder kernels each range needs (bit 0 narrow, bit 1 wide)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-};
+#include "ojphgpu_objects.h"
 
 extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
 {
@@ -424,20 +167,23 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   return OJPHGPU_OK;
 }
 
-static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container);
+int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container);
 
-extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image) { return encoder_run(e, d_image, 32); }
-extern "C" int ojphgpu_encoder_run_device16(ojphgpu_encoder* e, const uint16_t* d_image) { return encoder_run(e, d_image, 16); }
+extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image) { return ojphgpu_encoder_run_container(e, d_image, 32); }
+extern "C" int ojphgpu_encoder_run_device16(ojphgpu_encoder* e, const uint16_t* d_image) { return ojphgpu_encoder_run_container(e, d_image, 16); }
 
 // container: 32 = int32 samples, 16 = 16-bit samples (int16 for signed components, else uint16)
-static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
+int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container)
 {
   if (!e || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
   if (container == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
   hipStream_t s = e->stream;
   Spans& T = e->timer;
-  HIPCHK(hipMemsetAsync(e->counters.p, 0, 16, s));
+  uint8_t* const d_out = (uint8_t*)(e->o_out ? e->o_out : e->out.p);          // a pipeline slot's buffers, or the object's own
+  ojphgpu_cb_result* const res = (ojphgpu_cb_result*)(e->o_results ? e->o_results : e->results.p);
+  uint32_t* const cnt = (uint32_t*)(e->o_counters ? e->o_counters : e->counters.p);
+  HIPCHK(hipMemsetAsync(cnt, 0, 16, s));
   T.start(s);
   int rc = OJPHGPU_OK;
   if (e->need_convert) {
@@ -451,15 +197,13 @@ static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
   }
   if (rc) return rc;
   const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)e->cb_descs.p;
-  ojphgpu_cb_result* res = (ojphgpu_cb_result*)e->results.p;
-  uint32_t* cnt = (uint32_t*)e->counters.p;
   bool forked = false;
   auto fork_top = [&]() -> int {                            // the top resolution's blocks are ready to be coded
     forked = true;
     HIPCHK(hipEventRecord(e->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     const int sh = T.begin(SP_HT_ENC, e->side);
-    int r2 = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, (uint8_t*)e->out.p,
+    int r2 = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, d_out,
                                        e->out_cap, res, cnt, cnt + 1, e->widths_top);
     if (r2) return r2;
     T.end(sh, e->side);
@@ -487,7 +231,7 @@ static int encoder_run(ojphgpu_encoder* e, const void* d_image, int container)
   const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
   const int sh = T.begin(SP_HT_ENC, s);
   rc = ojphgpu::ht_encode_launch(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p,
-                                 (uint8_t*)e->out.p, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest);
+                                 d_out, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest);
   if (rc) return rc;
   T.end(sh, s);
   if (e->n_top) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));     // join
@@ -589,7 +333,7 @@ static int encode_host(ojphgpu_encoder* e, const void* h_image, int container, u
   const size_t bytes = (size_t)P.frame_elems * 4 * e->nframes;          // sized for the wider container, used by both
   if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes / (container == 16 ? 2 : 1), hipMemcpyHostToDevice, e->stream));
-  int rc = encoder_run(e, e->image.p, container);
+  int rc = ojphgpu_encoder_run_container(e, e->image.p, container);
   if (rc) return rc;
   return ojphgpu_encoder_finish(e, h_out, cap, out_len);
 }
@@ -632,28 +376,6 @@ extern "C" int ojphgpu_encoder_level_timing(ojphgpu_encoder* e, float* out, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-struct ojphgpu_decoder {
-  const Plan* P = nullptr;
-  int device = 0; hipStream_t stream = nullptr;
-  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
-  // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
-  // levels with step 2, see decoder_create)
-  uint32_t n_low = 0;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool need_convert = false;                       // some component is not converted inside its top DWT level
-  TileRange tiles{ 0, 0 };
-  uint32_t nframes = 1;
-  bool any_refine = false;                         // some block carries SigProp / MagRef passes
-  std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
-  uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
-  std::vector<LevelBatch> batches;
-  uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
-  size_t data_first = 0, data_len = 0;              // byte range of the codestream holding this range's block data
-  Spans timer;
-  bool ran = false;
-};
-
 extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 {
   if (!d) return;
@@ -689,6 +411,67 @@ extern "C" int ojphgpu_decoder_create_batch(const ojphgpu_plan* const* plans, ui
   return no_throw([&] { return decoder_create(plans, num_frames, device, stream, 0, (uint32_t)plans[0]->plan.tiles.size(), out); });
 }
 
+// Two parsed codestreams describe frames one decoder object can take turns on: same frame format, same
+// place for every code-block.  Quantisation may differ (K_max / delta are per frame).
+int ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks)
+{
+  if (Q.coded.size() != Q.blocks.size()) return OJPHGPU_E_INVALID;    // plans must come from ojphgpu_t2_parse
+  if (Q.skip_read != P.skip_read || Q.skip_recon != P.skip_recon) return OJPHGPU_E_INVALID;
+  if (Q.blocks.size() != P.blocks.size() || Q.arena_elems != P.arena_elems || Q.p.width != P.p.width ||
+      Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
+      Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||
+      Q.p.color_transform != P.p.color_transform || Q.p.tile_w != P.p.tile_w || Q.p.tile_h != P.p.tile_h ||
+      Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h ||
+      Q.p.image_x0 != P.p.image_x0 || Q.p.image_y0 != P.p.image_y0 || Q.p.tile_x0 != P.p.tile_x0 || Q.p.tile_y0 != P.p.tile_y0 ||
+      memcmp(Q.p.comp_dx, P.p.comp_dx, sizeof(P.p.comp_dx)) != 0 || memcmp(Q.p.comp_dy, P.p.comp_dy, sizeof(P.p.comp_dy)) != 0 ||
+      memcmp(Q.p.comp_depth, P.p.comp_depth, sizeof(P.p.comp_depth)) != 0 || memcmp(Q.p.comp_sign, P.p.comp_sign, sizeof(P.p.comp_sign)) != 0 ||
+      Q.nlt3 != P.nlt3 || Q.bands.size() != P.bands.size() || memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
+    return OJPHGPU_E_INVALID;
+  if (!compare_blocks) return OJPHGPU_OK;
+  // the launches are laid out from the first frame's geometry: every block must sit where that frame has it
+  // (precinct sizes move the code-block grid)
+  for (size_t i = 0; i < P.blocks.size(); ++i) {
+    const Block& a = P.blocks[i]; const Block& b = Q.blocks[i];
+    if (a.band != b.band || a.r.x0 != b.r.x0 || a.r.y0 != b.r.y0 || a.r.w != b.r.w || a.r.h != b.r.h) return OJPHGPU_E_INVALID;
+  }
+  for (size_t i = 0; i < P.bands.size(); ++i)
+    if (P.bands[i].plane_off != Q.bands[i].plane_off || P.bands[i].pitch != Q.bands[i].pitch) return OJPHGPU_E_INVALID;
+  return OJPHGPU_OK;
+}
+
+// Block descriptors of one frame: geometry from P (the decoder's plan), what the packet headers and the
+// QCD / QCC of THIS frame's codestream say from Q.  arena_off = element offset of the frame's arena,
+// data_base = where the frame's byte range [fi.first, fi.first + fi.len) of the codestream will sit in the
+// device data buffer.  scratch_cap / reserved are left to ojphgpu_ht_decode_layout.
+void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
+                                uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi)
+{
+  uint64_t max_off = 0, min_off = ~0ull;
+  fi.any_refine = false; fi.max_len1 = 0;
+  for (size_t i = 0; i < ids.size(); ++i) {
+    const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
+    ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
+    o.coef_off = arena_off + P.bands[k.band].plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
+    o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
+    o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
+    o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
+    if (c.num_passes > 1 && c.len2 > 0) fi.any_refine = true;
+    o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
+    fi.max_len1 = std::max(fi.max_len1, c.len1);
+    if (c.len1 + c.len2) {
+      max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
+      min_off = std::min<uint64_t>(min_off, c.offset);
+    }
+  }
+  if (min_off > max_off) min_off = max_off = 0;
+  min_off &= ~(uint64_t)15;                                             // only this byte range of the codestream is uploaded
+  for (size_t i = 0; i < ids.size(); ++i) {
+    ojphgpu_cb_desc& o = bd[i];
+    if (o.len1 + o.len2) o.data_off = o.data_off - min_off + data_base; else o.data_off = 0;
+  }
+  fi.first = min_off; fi.len = max_off - min_off;
+}
+
 static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, int device, void* stream, uint32_t tile_first,
                           uint32_t tile_count, ojphgpu_decoder** out)
 {
@@ -699,27 +482,8 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   if ((uint64_t)tile_first + tile_count > P.tiles.size()) return OJPHGPU_E_INVALID;
   for (uint32_t f = 0; f < nframes; ++f) {                              // every frame of a batch has the same geometry
     if (!plans[f]) return OJPHGPU_E_INVALID;
-    const Plan& Q = plans[f]->plan;
-    if (Q.coded.size() != Q.blocks.size()) return OJPHGPU_E_INVALID;    // plans must come from ojphgpu_t2_parse
-    if (Q.skip_read != P.skip_read || Q.skip_recon != P.skip_recon) return OJPHGPU_E_INVALID;
-    if (Q.blocks.size() != P.blocks.size() || Q.arena_elems != P.arena_elems || Q.p.width != P.p.width ||
-        Q.p.height != P.p.height || Q.p.num_comps != P.p.num_comps || Q.p.bit_depth != P.p.bit_depth ||
-        Q.p.is_signed != P.p.is_signed || Q.p.reversible != P.p.reversible || Q.p.num_decomps != P.p.num_decomps ||
-        Q.p.color_transform != P.p.color_transform || Q.p.tile_w != P.p.tile_w || Q.p.tile_h != P.p.tile_h ||
-        Q.p.block_w != P.p.block_w || Q.p.block_h != P.p.block_h ||
-        Q.p.image_x0 != P.p.image_x0 || Q.p.image_y0 != P.p.image_y0 || Q.p.tile_x0 != P.p.tile_x0 || Q.p.tile_y0 != P.p.tile_y0 ||
-        memcmp(Q.p.comp_dx, P.p.comp_dx, sizeof(P.p.comp_dx)) != 0 || memcmp(Q.p.comp_dy, P.p.comp_dy, sizeof(P.p.comp_dy)) != 0 ||
-        memcmp(Q.p.comp_depth, P.p.comp_depth, sizeof(P.p.comp_depth)) != 0 || memcmp(Q.p.comp_sign, P.p.comp_sign, sizeof(P.p.comp_sign)) != 0 ||
-        Q.nlt3 != P.nlt3 || Q.bands.size() != P.bands.size() || memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
-      return OJPHGPU_E_INVALID;
-    // the launches are laid out from frame 0's geometry: every block must sit where frame 0 has it (precinct
-    // sizes move the code-block grid).  Quantisation may differ: K_max / delta are taken per frame below.
-    for (size_t i = 0; f && i < P.blocks.size(); ++i) {
-      const Block& a = P.blocks[i]; const Block& b = Q.blocks[i];
-      if (a.band != b.band || a.r.x0 != b.r.x0 || a.r.y0 != b.r.y0 || a.r.w != b.r.w || a.r.h != b.r.h) return OJPHGPU_E_INVALID;
-    }
-    for (size_t i = 0; f && i < P.bands.size(); ++i)
-      if (P.bands[i].plane_off != Q.bands[i].plane_off || P.bands[i].pitch != Q.bands[i].pitch) return OJPHGPU_E_INVALID;
+    const int rc = ojphgpu_same_frame_geometry(P, plans[f]->plan, f != 0);
+    if (rc) return rc;
   }
   HIPCHK(hipSetDevice(device));
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -759,36 +523,17 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
              hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
   }
+  d->block_ids = ids;
   d->nblocks = (uint32_t)(ids.size() * nframes);
   std::vector<ojphgpu_cb_desc> bd(ids.size() * nframes);
   uint64_t nquads = 0, naux = 0, data_total = 0;
   d->f_first.assign(nframes, 0); d->f_len.assign(nframes, 0); d->f_base.assign(nframes, 0);
   for (uint32_t f = 0; f < nframes; ++f) {
-  const Plan& Q = plans[f]->plan;
-  uint64_t max_off = 0, min_off = ~0ull;
-  for (size_t i = 0; i < ids.size(); ++i) {
-    const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
-    ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i]; memset(&o, 0, sizeof(o));
-    o.coef_off = (uint64_t)f * P.arena_elems + B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
-    o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
-    o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
-    o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
-    if (c.num_passes > 1 && c.len2 > 0) d->any_refine = true;
-    o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
-    d->max_len1 = std::max(d->max_len1, c.len1);
-    if (c.len1 + c.len2) {
-      max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
-      min_off = std::min<uint64_t>(min_off, c.offset);
-    }
-  }
-  if (min_off > max_off) min_off = max_off = 0;
-  min_off &= ~(uint64_t)15;                                             // only this byte range of the codestream is uploaded
-  for (size_t i = 0; i < ids.size(); ++i) {
-    ojphgpu_cb_desc& o = bd[(size_t)f * ids.size() + i];
-    if (o.len1 + o.len2) o.data_off = o.data_off - min_off + data_total; else o.data_off = 0;
-  }
-  d->f_first[f] = (size_t)min_off; d->f_len[f] = (size_t)(max_off - min_off); d->f_base[f] = (size_t)data_total;
-  data_total += ((max_off - min_off) + 63) & ~(uint64_t)63;
+    DecFrameInfo fi;
+    ojphgpu_decoder_fill_descs(P, plans[f]->plan, ids, (uint64_t)f * P.arena_elems, data_total, bd.data() + (size_t)f * ids.size(), fi);
+    d->any_refine |= fi.any_refine; d->max_len1 = std::max(d->max_len1, fi.max_len1);
+    d->f_first[f] = (size_t)fi.first; d->f_len[f] = (size_t)fi.len; d->f_base[f] = (size_t)data_total;
+    data_total += (fi.len + 63) & ~(uint64_t)63;
   }
   d->data_first = d->f_first[0];
   d->data_len = (size_t)data_total;
@@ -831,14 +576,15 @@ static int decode_chains(ojphgpu_decoder* d, hipStream_t s)
 {
   if (d->nblocks == 0) return OJPHGPU_OK;
   Spans& T = d->timer;
-  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p;
-  uint8_t* status = (uint8_t*)d->status.p;
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)(d->o_cb_descs ? d->o_cb_descs : d->cb_descs.p);
+  uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p);
+  const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
   int sp = T.begin(SP_PREP, s);
-  int rc = ojphgpu_ht_decode_prep(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (uint32_t*)d->aux.p);
+  int rc = ojphgpu_ht_decode_prep(s, cbd, d->nblocks, data, (uint32_t*)d->aux.p);
   if (rc) return rc;
   T.end(sp, s);
   sp = T.begin(SP_STEP1, s);
-  rc = ojphgpu_ht_decode_step1(s, cbd, d->nblocks, (const uint8_t*)d->data.p, (const uint32_t*)d->aux.p, (uint32_t*)d->quads.p, status);
+  rc = ojphgpu_ht_decode_step1(s, cbd, d->nblocks, data, (const uint32_t*)d->aux.p, (uint32_t*)d->quads.p, status);
   if (rc) return rc;
   T.end(sp, s);
   return OJPHGPU_OK;
@@ -849,28 +595,29 @@ static int decode_samples(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uin
 {
   if (count == 0) return OJPHGPU_OK;
   Spans& T = d->timer;
-  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)d->cb_descs.p + first;
-  uint8_t* status = (uint8_t*)d->status.p + first;
+  const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)(d->o_cb_descs ? d->o_cb_descs : d->cb_descs.p) + first;
+  uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p) + first;
+  const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
   int sp = T.begin(SP_STEP2, s);
-  int rc = ojphgpu_ht_decode_step2(s, cbd, count, (const uint8_t*)d->data.p, (const uint32_t*)d->quads.p, d->arena.p, status);
+  int rc = ojphgpu_ht_decode_step2(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status);
   if (rc) return rc;
   T.end(sp, s);
   if (d->any_refine) {
     sp = T.begin(SP_REFINE, s);
-    rc = ojphgpu_ht_decode_refine(s, cbd, count, (const uint8_t*)d->data.p, d->arena.p, status);
+    rc = ojphgpu_ht_decode_refine(s, cbd, count, data, d->arena.p, status);
     if (rc) return rc;
     T.end(sp, s);
   }
   return OJPHGPU_OK;
 }
 
-static int decoder_run(ojphgpu_decoder* d, void* d_image, int container);
+int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int container);
 static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t len, void* h_image, int container);
 
-extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image) { return decoder_run(d, d_image, 32); }
-extern "C" int ojphgpu_decoder_run_device16(ojphgpu_decoder* d, uint16_t* d_image) { return decoder_run(d, d_image, 16); }
+extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image) { return ojphgpu_decoder_run_container(d, d_image, 32); }
+extern "C" int ojphgpu_decoder_run_device16(ojphgpu_decoder* d, uint16_t* d_image) { return ojphgpu_decoder_run_container(d, d_image, 16); }
 
-static int decoder_run(ojphgpu_decoder* d, void* d_image, int container)
+int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int container)
 {
   if (!d || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
@@ -966,7 +713,7 @@ static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t l
   if (!d->image.p && d->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
   int rc = ojphgpu_decoder_upload(d, h_codestream, len);
   if (rc) return rc;
-  rc = decoder_run(d, d->image.p, container);
+  rc = ojphgpu_decoder_run_container(d, d->image.p, container);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (container == 16 ? 2 : 1), hipMemcpyDeviceToHost, d->stream));
   uint32_t failed = 0;

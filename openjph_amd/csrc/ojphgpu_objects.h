@@ -1,0 +1,313 @@
+// openjph_amd/csrc/ojphgpu_objects.h -- internals shared by the whole-frame codec objects
+// (ojphgpu_codec.cpp) and the frame pipelines built on them (ojphgpu_pipe.cpp): device / pinned host
+// buffers, launch batching, per-run event timing, and the encoder / decoder objects themselves.
+#ifndef OJPHGPU_OBJECTS_H
+#define OJPHGPU_OBJECTS_H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ht_tables.h"
+#include "ojph_plan.h"
+
+using namespace ojphgpu;
+
+namespace {
+
+#define HIPCHK(x) do { if ((x) != hipSuccess) return OJPHGPU_E_HIP; } while (0)
+
+struct DeviceBuf {
+  void* p = nullptr; size_t n = 0;
+  int alloc(size_t bytes) { n = bytes; return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+// pinned host staging buffer (grows, never shrinks): D2H lands here at PCIe speed and without the
+// page-fault cost of a fresh pageable allocation
+struct HostBuf {
+  uint8_t* p = nullptr; size_t cap = 0; bool pinned = false; unsigned uses = 0;
+  // the first run of a codec object gets plain memory (pinning costs more than one pageable copy
+  // saves); an object that is run again is a long-lived one and gets a pinned buffer
+  int reserve(size_t bytes) {
+    const bool want_pin = ++uses >= 2;
+    if (bytes <= cap && (pinned || !want_pin)) return 0;
+    release();
+    void* q = nullptr;
+    if (want_pin && hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess) { p = (uint8_t*)q; pinned = true; }
+    else { (void)hipGetLastError(); p = (uint8_t*)malloc(bytes); pinned = false; }
+    cap = p ? bytes : 0;
+    return p ? 0 : -1;
+  }
+  void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
+};
+
+// One DWT launch: the levels `depth` steps below the top of their component, of the components with
+// the same wavelet.  Without COCs that is one batch per resolution; with them a component may have
+// fewer levels than another, or the other wavelet, and a depth splits in two.
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; };
+
+// DWT descriptors grouped so that one launch handles every tile-component
+struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
+
+template <typename F>
+void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, F f)
+{
+  for (const ojphgpu_level_info& lv : P.levels) {
+    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev) continue;
+    const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
+    if (L > depth && lv.res == L - depth) f(lv);
+  }
+}
+
+uint32_t max_recon_decomps(const Plan& P)
+{
+  uint32_t m = 0;
+  for (uint32_t c = 0; c < P.p.num_comps; ++c) m = std::max(m, P.recon_decomps(c));
+  return m;
+}
+
+void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
+{
+  descs.clear(); batches.clear();
+  const uint32_t depths = max_recon_decomps(P);
+  for (uint32_t depth = 0; depth < depths; ++depth)
+    for (int rev = 0; rev < 2; ++rev) {
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1 };
+      for_levels_of(P, tr, depth, rev != 0, [&](const ojphgpu_level_info& lv) {
+        ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
+        d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
+        d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
+        d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
+        descs.push_back(d);
+        b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
+      });
+      if (b.count) batches.push_back(b);
+    }
+}
+
+// Descriptors of the top DWT level of every component with the un-decomposed plane addressed inside
+// the image-sized component planes (for ojphgpu_dwt_forward_image / _inverse_image); batch.img_first
+// points at them.  None when the fused path does not apply (colour transform).
+void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches,
+                             std::vector<ojphgpu_dwt_desc>& out)
+{
+  out.clear();
+  if (P.p.color_transform || P.any_nlt3) return;          // those conversions live in the conversion kernels
+  for (LevelBatch& b : batches) {
+    if (b.depth != 0 || b.count == 0) continue;
+    b.img_first = (int)out.size();
+    size_t k = 0;
+    for_levels_of(P, tr, 0, b.rev, [&](const ojphgpu_level_info& lv) {
+      ojphgpu_dwt_desc d = descs[b.first + k++];
+      const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
+      const CompGeo& g = P.comps[lv.comp];
+      const Rect& rr = P.ress[tc.res[lv.res]].r;              // the tile-component at the reconstructed resolution
+      d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
+      d.src_pitch = g.w;
+      d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
+      out.push_back(d);
+    });
+  }
+}
+
+// One descriptor per tile and component, in that order; a component whose conversion is fused into
+// its top DWT level (no colour transform, at least one level) gets an empty one.  Returns whether
+// any component is left for the conversion kernels.
+bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_convert_desc>& descs, uint32_t& max_w, uint32_t& max_h)
+{
+  descs.clear(); max_w = max_h = 0;
+  bool any = false;
+  for (const Tile& t : P.tiles) {
+    if (!tr.has(t.idx)) continue;
+    for (uint32_t c = 0; c < P.p.num_comps; ++c) {
+      const uint32_t L = P.recon_decomps(c);
+      const TileComp& tc = P.tcomps[t.comps[c]];
+      const Resolution& R = P.ress[tc.res[L]];
+      ojphgpu_convert_desc d; memset(&d, 0, sizeof(d));
+      if (L == 0) { const Band& B = P.bands[(size_t)R.band[0]]; d.plane_off = B.plane_off; d.pitch = B.pitch; }
+      else { d.plane_off = R.plane_off; d.pitch = R.pitch; }
+      const CompGeo& g = P.comps[c];
+      d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
+      d.img_pitch = g.w; d.img_off = g.frame_off;
+      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u);   // 0x200: bit 10 says which conversion
+      if (P.p.color_transform || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+      descs.push_back(d);
+      max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
+    }
+  }
+  return any;
+}
+
+// Frame batches: the same plan applied to `nframes` independent frames in one set of launches
+// (config C5: a batch of independent 4K frames).  Frame f lives f * arena_elems further in the arena
+// and f * frame_elems further in the image buffer; descriptors are simply replicated, batch by batch.
+void replicate_levels(std::vector<ojphgpu_dwt_desc>& descs, std::vector<ojphgpu_dwt_desc>& img_descs, std::vector<LevelBatch>& batches,
+                      uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
+{
+  if (nframes <= 1) return;
+  std::vector<ojphgpu_dwt_desc> out, iout; std::vector<LevelBatch> nb;
+  for (const LevelBatch& b : batches) {
+    LevelBatch n = b;
+    n.first = (uint32_t)out.size(); n.count = b.count * nframes;
+    if (b.img_first >= 0) n.img_first = (int)iout.size();
+    for (uint32_t f = 0; f < nframes; ++f)
+      for (uint32_t i = 0; i < b.count; ++i) {
+        const uint64_t o = (uint64_t)f * arena_elems;
+        ojphgpu_dwt_desc d = descs[b.first + i];
+        d.src_off += o; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
+        out.push_back(d);
+        if (b.img_first >= 0) {
+          d = img_descs[(size_t)b.img_first + i];
+          d.src_off += (uint64_t)f * frame_elems; d.ll_off += o; d.hl_off += o; d.lh_off += o; d.hh_off += o;
+          iout.push_back(d);
+        }
+      }
+    nb.push_back(n);
+  }
+  descs.swap(out); img_descs.swap(iout); batches.swap(nb);
+}
+
+void replicate_converts(std::vector<ojphgpu_convert_desc>& descs, uint32_t nframes, uint64_t arena_elems, uint64_t frame_elems)
+{
+  if (nframes <= 1 || descs.empty()) return;
+  const size_t n = descs.size();
+  for (uint32_t f = 1; f < nframes; ++f)
+    for (size_t i = 0; i < n; ++i) {
+      ojphgpu_convert_desc d = descs[i];
+      d.plane_off += (uint64_t)f * arena_elems; d.img_off += (uint64_t)f * frame_elems;
+      descs.push_back(d);
+    }
+}
+
+// plan-order indices of the code-blocks that belong to the tile range
+std::vector<uint32_t> blocks_of_tiles(const Plan& P, TileRange tr)
+{
+  std::vector<uint32_t> ids;
+  for (size_t i = 0; i < P.blocks.size(); ++i) {
+    const Band& B = P.bands[P.blocks[i].band];
+    if (tr.has(B.tile) && B.res <= P.top_read_res(B.comp)) ids.push_back((uint32_t)i);   // resolutions above are not decoded: their bands stay zero
+  }
+  return ids;
+}
+
+// Timing of one run_device: every launch (or group of launches) is bracketed by a pair of HIP events
+// on the stream it is issued on -- launches of one run may sit on two streams -- and tagged with a
+// kind; per-kind sums and the wall time of the whole run are read back afterwards.
+struct Spans {
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> pool;            // events are created once and reused
+  size_t used = 0;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool ok = false;
+  bool detail = true;                // per-launch spans on; off = only the wall time of the run (two events)
+  int init() { ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess; return ok ? 0 : -1; }
+  void destroy() {
+    for (Span& x : pool) { (void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b); }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    pool.clear();
+  }
+  void start(hipStream_t s) { used = 0; if (ok) (void)hipEventRecord(t0, s); }
+  void finish(hipStream_t s) { if (ok) (void)hipEventRecord(t1, s); }
+  int begin(int kind, hipStream_t s) {
+    if (!ok || !detail) return -1;
+    if (used == pool.size()) {
+      Span x{ nullptr, nullptr, kind };
+      if (hipEventCreate(&x.a) != hipSuccess || hipEventCreate(&x.b) != hipSuccess) { ok = false; return -1; }
+      pool.push_back(x);
+    }
+    pool[used].kind = kind;
+    (void)hipEventRecord(pool[used].a, s);
+    return (int)used++;
+  }
+  void end(int id, hipStream_t s) { if (ok && id >= 0) (void)hipEventRecord(pool[(size_t)id].b, s); }
+  // sum of the spans of `kind`; kind < 0: wall time of the run
+  int read(int kind, float* out) {
+    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
+    if (kind < 0) return hipEventElapsedTime(out, t0, t1) == hipSuccess ? 0 : -1;
+    float sum = 0;
+    for (size_t i = 0; i < used; ++i)
+      if (pool[i].kind == kind) { float ms = 0; if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) != hipSuccess) return -1; sum += ms; }
+    *out = sum;
+    return 0;
+  }
+  // the individual spans of `kind`, in issue order
+  int read_each(int kind, float* out, uint32_t cap) {
+    if (!ok || hipEventSynchronize(t1) != hipSuccess) return -1;
+    int n = 0;
+    for (size_t i = 0; i < used; ++i)
+      if (pool[i].kind == kind && (uint32_t)n < cap) { if (hipEventElapsedTime(&out[n], pool[i].a, pool[i].b) != hipSuccess) return -1; ++n; }
+    return n;
+  }
+};
+enum { SP_CONVERT = 0, SP_DWT = 1, SP_HT_ENC = 2, SP_PREP = 3, SP_STEP1 = 4, SP_STEP2 = 5, SP_REFINE = 6 };
+
+}  // namespace
+
+struct ojphgpu_encoder {
+  const ojphgpu_plan* handle = nullptr;
+  const Plan* P = nullptr;
+  int device = 0; hipStream_t stream = nullptr;
+  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, scratch, out, results, counters;
+  bool need_convert = false;                       // some component is not converted inside its top DWT level
+  std::vector<LevelBatch> batches;
+  uint32_t conv_max_w = 0, conv_max_h = 0, out_cap = 0;
+  TileRange tiles{ 0, 0 };
+  uint32_t nframes = 1;                            // frames coded per run_device (batch)
+  bool fetched = false;                            // results / bytes of the last run are on the host
+  uint64_t nbytes = 0;
+  std::vector<uint32_t> block_ids;                 // plan-order index of each block this encoder codes (per frame)
+  std::vector<ojphgpu_cb_result> h_results;
+  HostBuf h_out, h_res;
+  Spans timer;
+  bool ran = false;
+  // overlap of the block coder with the lower DWT levels: the blocks of the top resolution (3/4 of
+  // the samples) only need the first DWT level, so they are coded on a second stream while the
+  // small, latency-bound launches of levels 2..L run on the main one
+  uint32_t n_top = 0;                              // descriptors [0, n_top) = blocks of the top resolution
+  int widths_top = 0, widths_rest = 0;             // which block encoder kernels each range needs (bit 0 narrow, bit 1 wide)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // where a run writes its products: the object's own buffers (null), or -- for a frame pipeline that keeps
+  // several frames in flight -- the buffers of the frame's slot (ojphgpu_pipe.cpp)
+  void* o_out = nullptr; void* o_results = nullptr; void* o_counters = nullptr;
+};
+// the device part of an encode: d_image holds the frame in `container`-bit elements (32 / 16)
+int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container);
+
+struct ojphgpu_decoder {
+  const Plan* P = nullptr;
+  int device = 0; hipStream_t stream = nullptr;
+  DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
+  // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
+  // levels with step 2, see decoder_create)
+  uint32_t n_low = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool need_convert = false;                       // some component is not converted inside its top DWT level
+  TileRange tiles{ 0, 0 };
+  uint32_t nframes = 1;
+  bool any_refine = false;                         // some block carries SigProp / MagRef passes
+  std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
+  uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
+  std::vector<LevelBatch> batches;
+  uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
+  size_t data_first = 0, data_len = 0;              // byte range of the codestream holding this range's block data
+  Spans timer;
+  bool ran = false;
+  std::vector<uint32_t> block_ids;                 // plan-order index of each block descriptor (per frame)
+  // what a run reads: the object's own buffers (null), or those of a frame pipeline's slot
+  const void* o_cb_descs = nullptr; const void* o_data = nullptr; void* o_status = nullptr;
+};
+struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; };
+int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks);
+void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
+                                uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);
+int  ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int container);
+
+
+#endif

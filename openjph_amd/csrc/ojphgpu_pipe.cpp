@@ -1,0 +1,531 @@
+// openjph_amd/csrc/ojphgpu_pipe.cpp -- frame pipelines: what ojph::codestream's exchange() ... flush() /
+// read_headers() ... pull() contract (ojph_codestream_local.cpp:1148-1270, :912-1146) becomes when the hot
+// path runs on a GPU behind PCIe and frames follow each other (video, image sequences, a tiled image cut
+// into independent codestreams).
+//
+// One frame alone is bound by the PCIe copies either side of 0.6 ms of kernels; a SEQUENCE is not, if the
+// stages of consecutive frames overlap.  A pipe keeps `depth` frames in flight, each in a slot of its own:
+//
+//   encoder   caller fills slot n+1's pinned frame  |  H2D of n+1  |  kernels of n  |  D2H of n-1's block
+//             lengths -> packet headers on host threads -> placement kernel -> D2H of n-1's finished codestream
+//   decoder   host threads parse n+1's packet headers  |  H2D of n+1's bytes + descriptors  |  kernels of n  |
+//             D2H of n-1's frame into pinned memory the caller reads rows from
+//
+// on separate HIP streams (copy-in, compute, copy-out) with events between them.  The coded bytes never
+// pass through a host memcpy: the encoder's codestream is assembled in HBM (kernels_assemble.hip) from the
+// layout the host Tier-2 computes out of the block LENGTHS, and arrives in pinned memory ready to be
+// written to a file; the decoder uploads the codestream as it is and addresses the blocks inside it.
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "ojphgpu_objects.h"
+#include "ojph_pool.h"
+
+namespace ojphgpu {
+int assemble_launch(void* stream, const T2Job* d_jobs, uint32_t njobs, const uint8_t* d_blob, const uint8_t* d_data, uint8_t* d_out);
+}
+
+namespace {
+
+struct Pinned {
+  uint8_t* p = nullptr; size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    release();
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    p = (uint8_t*)q; cap = bytes;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Grow {                       // device buffer that grows (never shrinks)
+  DeviceBuf b; size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    b.release();
+    if (b.alloc(bytes + 64)) { cap = 0; return -1; }
+    cap = bytes;
+    return 0;
+  }
+};
+
+enum SlotState { FREE = 0, ACQUIRED, SUBMITTED, DONE, HELD };
+
+double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// =============================================================================================
+// encoder pipe
+// =============================================================================================
+struct EncSlot {
+  SlotState state = FREE;
+  Pinned h_in, h_res, h_lay, h_cs;
+  DeviceBuf image, out, results, counters;
+  Grow cs, lay;
+  hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_res = nullptr, ev_done = nullptr;
+  int rc = 0; size_t cs_len = 0;
+  double t_submit = 0, t_done = 0, t_t2 = 0;
+};
+
+struct ojphgpu_enc_pipe {
+  const ojphgpu_plan* handle = nullptr; const Plan* P = nullptr;
+  int device = 0, container = 16;
+  uint32_t depth = 0;
+  ojphgpu_encoder* enc = nullptr;
+  hipStream_t s_h2d = nullptr, s_comp = nullptr, s_res = nullptr, s_d2h = nullptr;
+  std::vector<EncSlot> slots;
+  size_t frame_bytes = 0, res_bytes = 0;
+  uint64_t n_acq = 0, n_sub = 0, n_col = 0;
+  std::mutex mu; std::condition_variable cv_work, cv_done;
+  std::deque<uint32_t> work; bool stop = false;
+  std::vector<std::thread> finishers;
+  double sum_t2 = 0, sum_latency = 0; uint64_t n_done = 0;
+};
+
+static void enc_finish_frame(ojphgpu_enc_pipe* p, EncSlot& s)
+{
+  const Plan& P = *p->P;
+  ojphgpu_encoder* e = p->enc;
+  auto fail = [&](int rc) { s.rc = rc; };
+  if (hipSetDevice(p->device) != hipSuccess) return fail(OJPHGPU_E_HIP);
+  if (hipEventSynchronize(s.ev_res) != hipSuccess) return fail(OJPHGPU_E_HIP);
+  const double t0 = now_ms();
+  const size_t nb = e->block_ids.size();
+  const ojphgpu_cb_result* res = (const ojphgpu_cb_result*)s.h_res.p;
+  const uint32_t* cnt = (const uint32_t*)(s.h_res.p + nb * sizeof(ojphgpu_cb_result));
+  if (cnt[1]) return fail(OJPHGPU_E_OVERFLOW);
+  int rc = no_throw([&]() -> int {
+    std::vector<ojphgpu_coded_block> cb(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
+    for (size_t i = 0; i < nb; ++i) {
+      const ojphgpu_cb_result& r = res[i];
+      ojphgpu_coded_block& c = cb[e->block_ids[i]];
+      c.offset = r.offset; c.len1 = r.length; c.len2 = 0;
+      c.missing_msbs = r.length ? P.bands[P.blocks[e->block_ids[i]].band].K_max - 1 : 0;      // ojph_codeblock.cpp:148
+      c.num_passes = r.length ? 1 : 0;
+    }
+    T2Layout L;
+    int r2 = t2_layout_codestream(P, cb.data(), L);
+    if (r2) return r2;
+    s.t_t2 = now_ms() - t0;
+    // layout -> device: jobs, then the blob (16-byte aligned), through the slot's pinned staging
+    const size_t jbytes = L.jobs.size() * sizeof(T2Job), boff = (jbytes + 63) & ~(size_t)63;
+    const size_t lbytes = boff + L.blob.size() + 16;
+    if (s.h_lay.reserve(lbytes + lbytes / 4) || s.lay.reserve(lbytes + lbytes / 4)) return OJPHGPU_E_NOMEM;
+    if (s.cs.reserve((size_t)L.total + (size_t)L.total / 8 + 64) || s.h_cs.reserve((size_t)L.total + (size_t)L.total / 8 + 64)) return OJPHGPU_E_NOMEM;
+    memcpy(s.h_lay.p, L.jobs.data(), jbytes);
+    memcpy(s.h_lay.p + boff, L.blob.data(), L.blob.size());
+    HIPCHK(hipMemcpyAsync(s.lay.b.p, s.h_lay.p, lbytes - 16, hipMemcpyHostToDevice, p->s_d2h));
+    r2 = assemble_launch(p->s_d2h, (const T2Job*)s.lay.b.p, (uint32_t)L.jobs.size(), (const uint8_t*)s.lay.b.p + boff,
+                         (const uint8_t*)s.out.p, (uint8_t*)s.cs.b.p);
+    if (r2) return r2;
+    HIPCHK(hipMemcpyAsync(s.h_cs.p, s.cs.b.p, (size_t)L.total, hipMemcpyDeviceToHost, p->s_d2h));
+    HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
+    HIPCHK(hipEventSynchronize(s.ev_done));
+    s.cs_len = (size_t)L.total;
+    return OJPHGPU_OK;
+  });
+  if (rc) fail(rc);
+}
+
+static void enc_finisher(ojphgpu_enc_pipe* p)
+{
+  for (;;) {
+    uint32_t si;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_work.wait(lk, [&] { return p->stop || !p->work.empty(); });
+      if (p->work.empty()) return;                   // stop requested and nothing left
+      si = p->work.front(); p->work.pop_front();
+    }
+    EncSlot& s = p->slots[si];
+    enc_finish_frame(p, s);
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      s.t_done = now_ms();
+      s.state = DONE;
+      p->sum_t2 += s.t_t2; p->sum_latency += s.t_done - s.t_submit; p->n_done++;
+    }
+    p->cv_done.notify_all();
+  }
+}
+
+extern "C" void ojphgpu_enc_pipe_destroy(ojphgpu_enc_pipe* p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+  p->cv_work.notify_all();
+  for (std::thread& t : p->finishers) t.join();
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_res, p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
+  if (p->enc) ojphgpu_encoder_destroy(p->enc);
+  for (EncSlot& s : p->slots) {
+    s.h_in.release(); s.h_res.release(); s.h_lay.release(); s.h_cs.release();
+    for (DeviceBuf* b : { &s.image, &s.out, &s.results, &s.counters, &s.cs.b, &s.lay.b }) b->release();
+    for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_res, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
+  }
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_res, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
+  delete p;
+}
+
+extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uint32_t depth, int container_bits,
+                                        uint32_t host_threads, ojphgpu_enc_pipe** out)
+{
+  if (!plan || !out || depth < 2 || depth > 16 || (container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  return no_throw([&]() -> int {
+    HIPCHK(hipSetDevice(device));
+    ojphgpu_enc_pipe* p = new (std::nothrow) ojphgpu_enc_pipe();
+    if (!p) return OJPHGPU_E_NOMEM;
+    struct Owner { ojphgpu_enc_pipe* p; ~Owner() { if (p) ojphgpu_enc_pipe_destroy(p); } } owner{ p };
+    const Plan& P = plan->plan;
+    p->handle = plan; p->P = &P; p->device = device; p->container = container_bits; p->depth = depth;
+    if (container_bits == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_res, &p->s_d2h })
+      HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    int rc = ojphgpu_encoder_create(plan, device, p->s_comp, &p->enc);
+    if (rc) return rc;
+    (void)ojphgpu_encoder_set_timing(p->enc, 0);
+    ojphgpu_encoder* e = p->enc;
+    const size_t nb = e->block_ids.size();
+    p->frame_bytes = (size_t)P.frame_elems * (size_t)(container_bits / 8);
+    p->res_bytes = nb * sizeof(ojphgpu_cb_result) + 16;
+    // the codestream of a frame: sized from the samples (1 byte each is generous for natural content), grown when a frame needs more
+    const size_t cs_guess = std::min<size_t>((size_t)e->out_cap, (size_t)P.frame_elems + (1u << 20));
+    p->slots.resize(depth);
+    for (EncSlot& s : p->slots) {
+      if (s.h_in.reserve(p->frame_bytes + 64) || s.h_res.reserve(p->res_bytes + 64) || s.h_cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
+      if (s.image.alloc(p->frame_bytes + 64) || s.out.alloc((size_t)e->out_cap + 64) || s.results.alloc(p->res_bytes) || s.counters.alloc(16) ||
+          s.cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
+      const size_t lay_guess = nb * sizeof(T2Job) + nb * 8 + (1u << 16);
+      if (s.h_lay.reserve(lay_guess) || s.lay.reserve(lay_guess)) return OJPHGPU_E_NOMEM;
+      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_res, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    const uint32_t nthreads = host_threads ? std::min<uint32_t>(host_threads, 16) : 2;
+    for (uint32_t i = 0; i < nthreads; ++i) p->finishers.emplace_back(enc_finisher, p);
+    owner.p = nullptr;
+    *out = p;
+    return OJPHGPU_OK;
+  });
+}
+
+extern "C" int ojphgpu_enc_pipe_acquire(ojphgpu_enc_pipe* p, void** h_frame, size_t* bytes)
+{
+  if (!p || !h_frame) return OJPHGPU_E_INVALID;
+  EncSlot& s = p->slots[p->n_acq % p->depth];
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (s.state == ACQUIRED) { *h_frame = s.h_in.p; if (bytes) *bytes = p->frame_bytes; return OJPHGPU_OK; }   // asked twice
+    if (s.state != FREE) return OJPHGPU_E_AGAIN;      // every slot is in flight: collect a codestream first
+    s.state = ACQUIRED;
+  }
+  *h_frame = s.h_in.p;
+  if (bytes) *bytes = p->frame_bytes;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
+{
+  if (!p) return OJPHGPU_E_INVALID;
+  const uint32_t si = (uint32_t)(p->n_acq % p->depth);
+  EncSlot& s = p->slots[si];
+  { std::lock_guard<std::mutex> lk(p->mu); if (s.state != ACQUIRED) return OJPHGPU_E_INVALID; }
+  HIPCHK(hipSetDevice(p->device));
+  ojphgpu_encoder* e = p->enc;
+  s.rc = 0; s.cs_len = 0; s.t_submit = now_ms();
+  HIPCHK(hipMemcpyAsync(s.image.p, s.h_in.p, p->frame_bytes, hipMemcpyHostToDevice, p->s_h2d));
+  HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
+  HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
+  e->o_out = s.out.p; e->o_results = s.results.p; e->o_counters = s.counters.p;
+  int rc = ojphgpu_encoder_run_container(e, s.image.p, p->container);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
+  // block lengths + byte counter to the host: all the packet-header coder needs
+  const size_t nb = e->block_ids.size();
+  HIPCHK(hipStreamWaitEvent(p->s_res, s.ev_kern, 0));
+  if (nb) HIPCHK(hipMemcpyAsync(s.h_res.p, s.results.p, nb * sizeof(ojphgpu_cb_result), hipMemcpyDeviceToHost, p->s_res));
+  HIPCHK(hipMemcpyAsync(s.h_res.p + nb * sizeof(ojphgpu_cb_result), s.counters.p, 8, hipMemcpyDeviceToHost, p->s_res));
+  HIPCHK(hipEventRecord(s.ev_res, p->s_res));
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    s.state = SUBMITTED;
+    p->work.push_back(si);
+    p->n_acq++; p->n_sub++;
+  }
+  p->cv_work.notify_one();
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_enc_pipe_collect(ojphgpu_enc_pipe* p, const uint8_t** h_codestream, size_t* len)
+{
+  if (!p || !h_codestream || !len) return OJPHGPU_E_INVALID;
+  std::unique_lock<std::mutex> lk(p->mu);
+  if (p->n_col >= p->n_sub) return OJPHGPU_E_INVALID;            // nothing in flight
+  if (p->n_col > 0) {                                              // the codestream handed out last time is released now
+    EncSlot& prev = p->slots[(p->n_col - 1) % p->depth];
+    if (prev.state == HELD) prev.state = FREE;
+  }
+  EncSlot& s = p->slots[p->n_col % p->depth];
+  p->cv_done.wait(lk, [&] { return s.state == DONE; });
+  p->n_col++;
+  if (s.rc) { s.state = FREE; return s.rc; }
+  s.state = HELD;
+  *h_codestream = s.h_cs.p; *len = s.cs_len;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_enc_pipe_stats(ojphgpu_enc_pipe* p, double out[4])
+{
+  if (!p || !out) return OJPHGPU_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->mu);
+  out[0] = (double)p->n_done;
+  out[1] = p->n_done ? p->sum_t2 / (double)p->n_done : 0.0;          // host Tier-2 (layout) per frame, ms
+  out[2] = p->n_done ? p->sum_latency / (double)p->n_done : 0.0;     // submit -> codestream in pinned memory, ms
+  out[3] = (double)pool_threads();
+  return OJPHGPU_OK;
+}
+
+// =============================================================================================
+// decoder pipe
+// =============================================================================================
+struct DecSlot {
+  SlotState state = FREE;
+  Pinned h_cs, h_descs, h_img, h_status;
+  Grow data;
+  DeviceBuf image, cb_descs, status;
+  hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_done = nullptr;
+  size_t cs_len = 0;
+  int rc = 0; uint32_t failed = 0;
+  double t_submit = 0, t_done = 0, t_parse = 0;
+};
+
+struct ojphgpu_dec_pipe {
+  ojphgpu_plan* first = nullptr;                     // parsed from the first codestream: the geometry of every frame
+  const Plan* P = nullptr;
+  int device = 0, container = 16, resilient = 0;
+  uint32_t depth = 0;
+  ojphgpu_decoder* dec = nullptr;
+  hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
+  std::vector<DecSlot> slots;
+  size_t frame_bytes = 0;
+  uint64_t n_acq = 0, n_sub = 0, n_col = 0;
+  std::mutex mu, enqueue_mu; std::condition_variable cv_work, cv_done;
+  std::deque<uint32_t> work; bool stop = false;
+  std::vector<std::thread> workers;
+  double sum_parse = 0, sum_latency = 0; uint64_t n_done = 0;
+};
+
+static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
+{
+  const Plan& P = *p->P;
+  ojphgpu_decoder* d = p->dec;
+  auto fail = [&](int rc) { s.rc = rc; };
+  if (hipSetDevice(p->device) != hipSuccess) return fail(OJPHGPU_E_HIP);
+  const double t0 = now_ms();
+  ojphgpu_plan* q = nullptr;
+  int rc = ojphgpu_t2_parse(s.h_cs.p, s.cs_len, p->resilient, &q);
+  if (rc) return fail(rc);
+  struct Hold { ojphgpu_plan* q; ~Hold() { ojphgpu_plan_destroy(q); } } hold{ q };
+  rc = no_throw([&]() -> int {
+    const Plan& Q = q->plan;
+    int r2 = ojphgpu_same_frame_geometry(P, Q, true);
+    if (r2) return r2;
+    const size_t nb = d->block_ids.size();
+    ojphgpu_cb_desc* bd = (ojphgpu_cb_desc*)s.h_descs.p;
+    DecFrameInfo fi;
+    ojphgpu_decoder_fill_descs(P, Q, d->block_ids, 0, 0, bd, fi);
+    uint64_t nquads = 0, naux = 0;
+    if (ojphgpu_ht_decode_layout(bd, (uint32_t)nb, &nquads, &naux) != OJPHGPU_OK) return OJPHGPU_E_INVALID;
+    if ((naux + 16) * 4 > d->aux.n || (nquads + 16) * 4 > d->quads.n) return OJPHGPU_E_INVALID;     // sized for the worst case at create
+    s.t_parse = now_ms() - t0;
+    if (fi.first + fi.len > s.cs_len) return OJPHGPU_E_CODESTREAM;
+    if (s.data.reserve((size_t)fi.len + (size_t)fi.len / 4 + 64)) return OJPHGPU_E_NOMEM;
+    if (fi.len) HIPCHK(hipMemcpyAsync(s.data.b.p, s.h_cs.p + fi.first, (size_t)fi.len, hipMemcpyHostToDevice, p->s_h2d));
+    if (nb) HIPCHK(hipMemcpyAsync(s.cb_descs.p, bd, nb * sizeof(ojphgpu_cb_desc), hipMemcpyHostToDevice, p->s_h2d));
+    HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
+    {
+      // the decoder object is shared by the frames in flight: what a run reads is set and enqueued under a lock
+      std::lock_guard<std::mutex> lk(p->enqueue_mu);
+      HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
+      d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
+      d->any_refine = fi.any_refine; d->max_len1 = fi.max_len1;
+      HIPCHK(hipMemsetAsync(s.status.p, 0, nb + 16, p->s_comp));
+      r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
+      if (r2) return r2;
+      HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
+    }
+    HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
+    HIPCHK(hipMemcpyAsync(s.h_img.p, s.image.p, p->frame_bytes, hipMemcpyDeviceToHost, p->s_d2h));
+    if (nb) HIPCHK(hipMemcpyAsync(s.h_status.p, s.status.p, nb, hipMemcpyDeviceToHost, p->s_d2h));
+    HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
+    HIPCHK(hipEventSynchronize(s.ev_done));
+    uint32_t failed = 0;
+    for (size_t i = 0; i < nb; ++i) failed += s.h_status.p[i] != 0;
+    s.failed = failed;
+    return OJPHGPU_OK;
+  });
+  if (rc) fail(rc);
+}
+
+static void dec_worker(ojphgpu_dec_pipe* p)
+{
+  for (;;) {
+    uint32_t si;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_work.wait(lk, [&] { return p->stop || !p->work.empty(); });
+      if (p->work.empty()) return;
+      si = p->work.front(); p->work.pop_front();
+    }
+    DecSlot& s = p->slots[si];
+    dec_process_frame(p, s);
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      s.t_done = now_ms();
+      s.state = DONE;
+      p->sum_parse += s.t_parse; p->sum_latency += s.t_done - s.t_submit; p->n_done++;
+    }
+    p->cv_done.notify_all();
+  }
+}
+
+extern "C" void ojphgpu_dec_pipe_destroy(ojphgpu_dec_pipe* p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+  p->cv_work.notify_all();
+  for (std::thread& t : p->workers) t.join();
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
+  if (p->dec) ojphgpu_decoder_destroy(p->dec);
+  for (DecSlot& s : p->slots) {
+    s.h_cs.release(); s.h_descs.release(); s.h_img.release(); s.h_status.release();
+    for (DeviceBuf* b : { &s.data.b, &s.image, &s.cb_descs, &s.status }) b->release();
+    for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
+  }
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
+  if (p->first) ojphgpu_plan_destroy(p->first);
+  delete p;
+}
+
+extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, int resilient, int device, uint32_t depth,
+                                        int container_bits, uint32_t host_threads, ojphgpu_dec_pipe** out)
+{
+  if (!h_codestream || !out || depth < 2 || depth > 16 || (container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  return no_throw([&]() -> int {
+    HIPCHK(hipSetDevice(device));
+    ojphgpu_dec_pipe* p = new (std::nothrow) ojphgpu_dec_pipe();
+    if (!p) return OJPHGPU_E_NOMEM;
+    struct Owner { ojphgpu_dec_pipe* p; ~Owner() { if (p) ojphgpu_dec_pipe_destroy(p); } } owner{ p };
+    int rc = ojphgpu_t2_parse(h_codestream, len, resilient, &p->first);
+    if (rc) return rc;
+    const Plan& P = p->first->plan;
+    p->P = &P; p->device = device; p->container = container_bits; p->depth = depth; p->resilient = resilient;
+    if (container_bits == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h }) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    rc = ojphgpu_decoder_create(p->first, device, p->s_comp, &p->dec);
+    if (rc) return rc;
+    (void)ojphgpu_decoder_set_timing(p->dec, 0);
+    ojphgpu_decoder* d = p->dec;
+    const size_t nb = d->block_ids.size();
+    // the flat VLC / MEL strings of any later frame fit: the worst case of every block (Lcup <= 4079 + slack)
+    {
+      const uint64_t worst = (uint64_t)nb * ojphgpu_ht_decode_aux_words(4079) + 64;
+      d->aux.release();
+      if (d->aux.alloc((size_t)worst * 4 + 64)) return OJPHGPU_E_NOMEM;
+    }
+    p->frame_bytes = (size_t)P.frame_elems * (size_t)(container_bits / 8);
+    p->slots.resize(depth);
+    for (DecSlot& s : p->slots) {
+      if (s.h_cs.reserve(len + len / 4 + (1u << 16)) || s.h_descs.reserve(nb * sizeof(ojphgpu_cb_desc) + 64) ||
+          s.h_img.reserve(p->frame_bytes + 64) || s.h_status.reserve(nb + 64)) return OJPHGPU_E_NOMEM;
+      if (s.data.reserve(len + len / 4 + 64) || s.image.alloc((size_t)P.frame_elems * 4 + 64) || s.cb_descs.alloc(nb * sizeof(ojphgpu_cb_desc) + 64) ||
+          s.status.alloc(nb + 64)) return OJPHGPU_E_NOMEM;
+      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    const uint32_t nthreads = host_threads ? std::min<uint32_t>(host_threads, 16) : 2;
+    for (uint32_t i = 0; i < nthreads; ++i) p->workers.emplace_back(dec_worker, p);
+    owner.p = nullptr;
+    *out = p;
+    return OJPHGPU_OK;
+  });
+}
+
+extern "C" int ojphgpu_dec_pipe_acquire(ojphgpu_dec_pipe* p, size_t len, uint8_t** h_codestream)
+{
+  if (!p || !h_codestream || len == 0) return OJPHGPU_E_INVALID;
+  DecSlot& s = p->slots[p->n_acq % p->depth];
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (s.state != FREE && s.state != ACQUIRED) return OJPHGPU_E_AGAIN;     // every slot is in flight: collect a frame first
+    s.state = ACQUIRED;
+  }
+  if (hipSetDevice(p->device) != hipSuccess) return OJPHGPU_E_HIP;
+  if (s.h_cs.reserve(len + len / 4 + 64)) { std::lock_guard<std::mutex> lk(p->mu); s.state = FREE; return OJPHGPU_E_NOMEM; }
+  s.cs_len = len;
+  *h_codestream = s.h_cs.p;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_submit(ojphgpu_dec_pipe* p)
+{
+  if (!p) return OJPHGPU_E_INVALID;
+  const uint32_t si = (uint32_t)(p->n_acq % p->depth);
+  DecSlot& s = p->slots[si];
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (s.state != ACQUIRED) return OJPHGPU_E_INVALID;
+  s.rc = 0; s.failed = 0; s.t_submit = now_ms();
+  s.state = SUBMITTED;
+  p->work.push_back(si);
+  p->n_acq++; p->n_sub++;
+  p->cv_work.notify_one();
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* p, const void** h_frame, size_t* bytes, uint32_t* failed_blocks)
+{
+  if (!p || !h_frame) return OJPHGPU_E_INVALID;
+  std::unique_lock<std::mutex> lk(p->mu);
+  if (p->n_col >= p->n_sub) return OJPHGPU_E_INVALID;
+  if (p->n_col > 0) {
+    DecSlot& prev = p->slots[(p->n_col - 1) % p->depth];
+    if (prev.state == HELD) prev.state = FREE;
+  }
+  DecSlot& s = p->slots[p->n_col % p->depth];
+  p->cv_done.wait(lk, [&] { return s.state == DONE; });
+  p->n_col++;
+  if (s.rc) { s.state = FREE; return s.rc; }
+  s.state = HELD;
+  *h_frame = s.h_img.p;
+  if (bytes) *bytes = p->frame_bytes;
+  if (failed_blocks) *failed_blocks = s.failed;
+  return (s.failed && !p->resilient) ? OJPHGPU_E_BLOCK : OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_plan(ojphgpu_dec_pipe* p, const ojphgpu_plan** plan)
+{
+  if (!p || !plan) return OJPHGPU_E_INVALID;
+  *plan = p->first;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* p, double out[4])
+{
+  if (!p || !out) return OJPHGPU_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->mu);
+  out[0] = (double)p->n_done;
+  out[1] = p->n_done ? p->sum_parse / (double)p->n_done : 0.0;       // host parse + descriptor fill per frame, ms
+  out[2] = p->n_done ? p->sum_latency / (double)p->n_done : 0.0;     // submit -> frame in pinned memory, ms
+  out[3] = (double)p->workers.size();
+  return OJPHGPU_OK;
+}

@@ -1,0 +1,137 @@
+"""Frame pipelines (C ABI section 6): sequences of same-shaped frames with the PCIe copies, the kernels
+and the host Tier-2 of consecutive frames overlapped.  Mirrors how one ojph::codestream object is re-used
+through restart() for the frames of a sequence (ojph_codestream.h:204): the caller writes samples into
+memory the library hands out and receives finished codestreams -- or the other way round -- `depth`
+frames in flight.  Plumbing only: ctypes views of the pipe's pinned host memory, no arithmetic here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check
+from .plan import Plan, make_params
+
+
+def _view(ptr, nbytes, dtype=np.uint8):
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+class EncoderPipe:
+    def __init__(self, plan: Plan = None, params=None, device=0, depth=4, container=16, host_threads=0, **kw):
+        from .codec import _torch
+        _torch()
+        self.plan = plan if plan is not None else Plan(params if params is not None else make_params(**kw))
+        self.container = int(container)
+        self.depth = int(depth)
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        check(self._lib.ojphgpu_enc_pipe_create(self.plan.handle, device, self.depth, self.container, host_threads,
+                                                C.byref(self._h)), "enc_pipe_create")
+        self.in_flight = 0
+
+    def close(self):
+        if self._h:
+            self._lib.ojphgpu_enc_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def acquire(self):
+        """-> writable numpy view ([C,H,W] uint16 / int32; flat when components differ in size) of the pinned
+        memory the next frame goes into, or None when every slot is in flight (collect first)"""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        rc = self._lib.ojphgpu_enc_pipe_acquire(self._h, C.byref(ptr), C.byref(n))
+        if rc == capi.E_AGAIN:
+            return None
+        check(rc, "enc_pipe_acquire")
+        return _view(ptr.value, n.value, np.uint16 if self.container == 16 else np.int32).reshape(self.plan.frame_shape)
+
+    def submit(self):
+        check(self._lib.ojphgpu_enc_pipe_submit(self._h), "enc_pipe_submit")
+        self.in_flight += 1
+
+    def collect(self, copy=True):
+        """the oldest frame's codestream; copy=False returns a view of pinned memory valid until the next collect"""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self.in_flight -= 1
+        check(self._lib.ojphgpu_enc_pipe_collect(self._h, C.byref(ptr), C.byref(n)), "enc_pipe_collect")
+        v = _view(ptr.value, n.value)
+        return v.tobytes() if copy else v
+
+    def stats(self):
+        out = (C.c_double * 4)()
+        check(self._lib.ojphgpu_enc_pipe_stats(self._h, out), "enc_pipe_stats")
+        return dict(frames=int(out[0]), host_tier2_ms=out[1], latency_ms=out[2], tier2_threads=int(out[3]))
+
+    def encode_sequence(self, frames):
+        """frames: iterable of [C,H,W] arrays -> generator of codestreams, in order"""
+        for f in frames:
+            buf = self.acquire()
+            while buf is None:
+                yield self.collect()
+                buf = self.acquire()
+            np.copyto(buf, np.asarray(f).astype(buf.dtype, copy=False).reshape(buf.shape), casting="unsafe")
+            self.submit()
+        while self.in_flight:
+            yield self.collect()
+
+
+class DecoderPipe:
+    def __init__(self, first_codestream: bytes, device=0, depth=4, container=16, host_threads=0, resilient=False):
+        from .codec import _torch
+        _torch()
+        self.container = int(container)
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        buf = np.frombuffer(first_codestream, dtype=np.uint8)
+        check(self._lib.ojphgpu_dec_pipe_create(buf.ctypes.data, len(first_codestream), int(resilient), device, depth,
+                                                self.container, host_threads, C.byref(self._h)), "dec_pipe_create")
+        h = C.c_void_p()
+        check(self._lib.ojphgpu_dec_pipe_plan(self._h, C.byref(h)), "dec_pipe_plan")
+        self.plan = Plan(handle=h, owned=False)
+        self.in_flight = 0
+
+    def close(self):
+        if self._h:
+            self._lib.ojphgpu_dec_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def acquire(self, nbytes):
+        """-> writable uint8 view of pinned memory for the next codestream, or None when every slot is in flight"""
+        ptr = C.c_void_p()
+        rc = self._lib.ojphgpu_dec_pipe_acquire(self._h, nbytes, C.byref(ptr))
+        if rc == capi.E_AGAIN:
+            return None
+        check(rc, "dec_pipe_acquire")
+        return _view(ptr.value, nbytes)
+
+    def submit(self):
+        check(self._lib.ojphgpu_dec_pipe_submit(self._h), "dec_pipe_submit")
+        self.in_flight += 1
+
+    def collect(self, copy=True):
+        ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        self.in_flight -= 1
+        check(self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed)), "dec_pipe_collect")
+        v = _view(ptr.value, n.value, np.uint16 if self.container == 16 else np.int32).reshape(self.plan.frame_shape)
+        return v.copy() if copy else v
+
+    def stats(self):
+        out = (C.c_double * 4)()
+        check(self._lib.ojphgpu_dec_pipe_stats(self._h, out), "dec_pipe_stats")
+        return dict(frames=int(out[0]), host_parse_ms=out[1], latency_ms=out[2], host_threads=int(out[3]))
+
+    def decode_sequence(self, codestreams):
+        for cs in codestreams:
+            buf = self.acquire(len(cs))
+            while buf is None:
+                yield self.collect()
+                buf = self.acquire(len(cs))
+            buf[:] = np.frombuffer(cs, dtype=np.uint8)
+            self.submit()
+        while self.in_flight:
+            yield self.collect()

@@ -93,8 +93,9 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
 class Plan:
     """Owns an ojphgpu_plan*. Tables are exposed as numpy structured arrays."""
 
-    def __init__(self, params=None, handle=None):
+    def __init__(self, params=None, handle=None, owned=True):
         self._lib = capi.lib()
+        self._owned = owned                # False: the handle belongs to another object (a decoder pipe)
         if handle is None:
             h = C.c_void_p()
             check(self._lib.ojphgpu_plan_create(C.byref(params), C.byref(h)), "plan_create")
@@ -122,9 +123,9 @@ class Plan:
 
     def __del__(self):
         try:
-            if self.handle:
+            if self.handle and self._owned:
                 self._lib.ojphgpu_plan_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 
