@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "ojph_plan.h"
 
 namespace {
@@ -60,9 +63,63 @@ __global__ __launch_bounds__(WAVES * 64) void assemble_codestream(const ojphgpu:
   if (lane < tail) dst[done + lane] = src[done + lane];
 }
 
+// Device -> pinned host memory by a kernel instead of hipMemcpyAsync: on this platform the runtime puts
+// host-to-device and device-to-host copies of different streams on the SAME SDMA engine, one after the
+// other (measured, profiles/r02_c_pipeline_timeline.txt: the next frame's 3.5 ms upload waited for the
+// previous frame's 1.3 ms download), which cost the encode pipeline a third of its frame rate (5.6 -> 3.95 ms
+// per 8K frame).  Stores from a kernel go over PCIe as posted writes beside the SDMA upload.  The grid is
+// small: the copy is PCIe-bound (55 GB/s alone, ~47 GB/s beside an upload) and 8 workgroups walking
+// contiguous segments were the fastest of 8 / 16 / 32 / 64 / 128 / 512 (profiles/r02_d_copy_modes.txt);
+// the CUs stay with the next frame's kernels.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void copy_to_host_kernel(v4u* __restrict__ dst, const v4u* __restrict__ src, size_t n16, size_t seg,
+                                                            uint8_t* __restrict__ dst_tail, const uint8_t* __restrict__ src_tail, uint32_t tail)
+{
+  // every workgroup walks ONE contiguous segment front to back, 16 KB (4 x 16 bytes per lane) per step: the
+  // host sees a few sequential write streams of full-size PCIe payloads
+  const size_t lo = (size_t)blockIdx.x * seg, hi = lo + seg < n16 ? lo + seg : n16;
+  size_t i = lo + threadIdx.x;
+  for (; i + 768 < hi; i += 1024) {
+    const v4u a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    __builtin_nontemporal_store(a, &dst[i]); __builtin_nontemporal_store(b, &dst[i + 256]);
+    __builtin_nontemporal_store(c, &dst[i + 512]); __builtin_nontemporal_store(d, &dst[i + 768]);
+  }
+  for (; i < hi; i += 256) { const v4u a = src[i]; __builtin_nontemporal_store(a, &dst[i]); }
+  if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+// byte counter + overflow flag of the block coder (device words) -> two words of pinned host memory
+__global__ void publish_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n)
+{
+  if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+
 }  // namespace
 
 namespace ojphgpu {
+
+// src: device memory, 16-byte aligned; d_dst: the DEVICE address of pinned host memory (hipHostGetDevicePointer), 16-byte aligned
+int copy_to_host_launch(void* stream, void* d_dst, const void* src, size_t bytes)
+{
+  if (bytes == 0) return OJPHGPU_OK;
+  if (!d_dst || !src || (((uintptr_t)d_dst | (uintptr_t)src) & 15u)) return OJPHGPU_E_INVALID;
+  const size_t n16 = bytes >> 4; const uint32_t tail = (uint32_t)(bytes & 15u);
+  static const unsigned max_blocks = [] { const char* e = getenv("OJPHGPU_COPY_WGS"); const long v = e ? atol(e) : 0; return v > 0 && v <= 4096 ? (unsigned)v : 8u; }();
+  size_t seg = (n16 + max_blocks - 1) / max_blocks;
+  seg = (seg + 1023) & ~(size_t)1023;                        // whole 16 KB steps
+  const unsigned blocks = (unsigned)std::max<size_t>(1, (n16 + seg - 1) / seg);
+  hipLaunchKernelGGL(copy_to_host_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (v4u*)d_dst, (const v4u*)src, n16, seg,
+                     (uint8_t*)d_dst + (n16 << 4), (const uint8_t*)src + (n16 << 4), tail);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+int publish_words_launch(void* stream, uint32_t* d_dst, const uint32_t* src, uint32_t n)
+{
+  if (!d_dst || !src || n > 64) return OJPHGPU_E_INVALID;
+  hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_dst, src, n);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
 
 int assemble_launch(void* stream, const T2Job* d_jobs, uint32_t njobs, const uint8_t* d_blob, const uint8_t* d_data, uint8_t* d_out)
 {

@@ -27,21 +27,27 @@
 
 namespace ojphgpu {
 int assemble_launch(void* stream, const T2Job* d_jobs, uint32_t njobs, const uint8_t* d_blob, const uint8_t* d_data, uint8_t* d_out);
+int copy_to_host_launch(void* stream, void* d_dst, const void* src, size_t bytes);
+int publish_words_launch(void* stream, uint32_t* d_dst, const uint32_t* src, uint32_t n);
 }
 
 namespace {
 
+// Pinned host memory, mapped into the device's address space and coherent: uploads from it go through
+// hipMemcpyAsync (SDMA); what comes BACK is written into it by kernels (`d` = its device address), see
+// kernels_assemble.hip for why.
 struct Pinned {
-  uint8_t* p = nullptr; size_t cap = 0;
+  uint8_t* p = nullptr; uint8_t* d = nullptr; size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return 0;
     release();
-    void* q = nullptr;
-    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    p = (uint8_t*)q; cap = bytes;
+    void* q = nullptr; void* dq = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (hipHostGetDevicePointer(&dq, q, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(q); return -1; }
+    p = (uint8_t*)q; d = (uint8_t*)dq; cap = bytes;
     return 0;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; d = nullptr; cap = 0; }
 };
 
 struct Grow {                       // device buffer that grows (never shrinks)
@@ -57,6 +63,33 @@ struct Grow {                       // device buffer that grows (never shrinks)
 
 enum SlotState { FREE = 0, ACQUIRED, SUBMITTED, DONE, HELD };
 
+// Which engine moves which direction (the two directions of one pipe must not share the SDMA engine, see
+// kernels_assemble.hip): 0 = upload by hipMemcpyAsync (SDMA), download by a copy kernel; 1 = upload by a copy
+// kernel reading the pinned memory, download by hipMemcpyAsync; 2 = both by hipMemcpyAsync (the runtime decides).
+int copy_mode(const char* name, int dflt)
+{
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : dflt;
+  return v >= 0 && v <= 2 ? v : dflt;
+}
+
+int upload(int mode, hipStream_t st, void* d_dst, const Pinned& src, size_t src_off, size_t bytes);
+int download(int mode, hipStream_t st, const Pinned& dst, const void* d_src, size_t bytes);
+
+int upload(int mode, hipStream_t st, void* d_dst, const Pinned& src, size_t src_off, size_t bytes)
+{
+  if (bytes == 0) return OJPHGPU_OK;
+  if (mode == 1 && ((src_off | (uintptr_t)d_dst) & 15u) == 0) return copy_to_host_launch(st, d_dst, src.d + src_off, bytes);   // the kernel copies either way
+  return hipMemcpyAsync(d_dst, src.p + src_off, bytes, hipMemcpyHostToDevice, st) == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+int download(int mode, hipStream_t st, const Pinned& dst, const void* d_src, size_t bytes)
+{
+  if (bytes == 0) return OJPHGPU_OK;
+  if (mode == 0) return copy_to_host_launch(st, dst.d, d_src, bytes);
+  return hipMemcpyAsync(dst.p, d_src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
 double now_ms()
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -70,9 +103,9 @@ double now_ms()
 struct EncSlot {
   SlotState state = FREE;
   Pinned h_in, h_res, h_lay, h_cs;
-  DeviceBuf image, out, results, counters;
-  Grow cs, lay;
-  hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_res = nullptr, ev_done = nullptr;
+  DeviceBuf image, out, counters;
+  Grow cs;
+  hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_done = nullptr;
   int rc = 0; size_t cs_len = 0;
   double t_submit = 0, t_done = 0, t_t2 = 0;
 };
@@ -80,9 +113,10 @@ struct EncSlot {
 struct ojphgpu_enc_pipe {
   const ojphgpu_plan* handle = nullptr; const Plan* P = nullptr;
   int device = 0, container = 16;
+  int mode = copy_mode("OJPHGPU_ENC_COPY_MODE", 0);
   uint32_t depth = 0;
   ojphgpu_encoder* enc = nullptr;
-  hipStream_t s_h2d = nullptr, s_comp = nullptr, s_res = nullptr, s_d2h = nullptr;
+  hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
   std::vector<EncSlot> slots;
   size_t frame_bytes = 0, res_bytes = 0;
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
@@ -98,7 +132,7 @@ static void enc_finish_frame(ojphgpu_enc_pipe* p, EncSlot& s)
   ojphgpu_encoder* e = p->enc;
   auto fail = [&](int rc) { s.rc = rc; };
   if (hipSetDevice(p->device) != hipSuccess) return fail(OJPHGPU_E_HIP);
-  if (hipEventSynchronize(s.ev_res) != hipSuccess) return fail(OJPHGPU_E_HIP);
+  if (hipEventSynchronize(s.ev_kern) != hipSuccess) return fail(OJPHGPU_E_HIP);
   const double t0 = now_ms();
   const size_t nb = e->block_ids.size();
   const ojphgpu_cb_result* res = (const ojphgpu_cb_result*)s.h_res.p;
@@ -117,18 +151,20 @@ static void enc_finish_frame(ojphgpu_enc_pipe* p, EncSlot& s)
     int r2 = t2_layout_codestream(P, cb.data(), L);
     if (r2) return r2;
     s.t_t2 = now_ms() - t0;
-    // layout -> device: jobs, then the blob (16-byte aligned), through the slot's pinned staging
+    // the layout goes into the slot's pinned staging -- jobs, then the blob (64-byte aligned) -- where the
+    // placement kernel reads it in place; the codestream is laid out in HBM and written to the slot's pinned
+    // output by a copy kernel
     const size_t jbytes = L.jobs.size() * sizeof(T2Job), boff = (jbytes + 63) & ~(size_t)63;
     const size_t lbytes = boff + L.blob.size() + 16;
-    if (s.h_lay.reserve(lbytes + lbytes / 4) || s.lay.reserve(lbytes + lbytes / 4)) return OJPHGPU_E_NOMEM;
+    if (s.h_lay.reserve(lbytes + lbytes / 4)) return OJPHGPU_E_NOMEM;
     if (s.cs.reserve((size_t)L.total + (size_t)L.total / 8 + 64) || s.h_cs.reserve((size_t)L.total + (size_t)L.total / 8 + 64)) return OJPHGPU_E_NOMEM;
     memcpy(s.h_lay.p, L.jobs.data(), jbytes);
     memcpy(s.h_lay.p + boff, L.blob.data(), L.blob.size());
-    HIPCHK(hipMemcpyAsync(s.lay.b.p, s.h_lay.p, lbytes - 16, hipMemcpyHostToDevice, p->s_d2h));
-    r2 = assemble_launch(p->s_d2h, (const T2Job*)s.lay.b.p, (uint32_t)L.jobs.size(), (const uint8_t*)s.lay.b.p + boff,
+    r2 = assemble_launch(p->s_d2h, (const T2Job*)s.h_lay.d, (uint32_t)L.jobs.size(), s.h_lay.d + boff,
                          (const uint8_t*)s.out.p, (uint8_t*)s.cs.b.p);
     if (r2) return r2;
-    HIPCHK(hipMemcpyAsync(s.h_cs.p, s.cs.b.p, (size_t)L.total, hipMemcpyDeviceToHost, p->s_d2h));
+    r2 = download(p->mode, p->s_d2h, s.h_cs, s.cs.b.p, (size_t)L.total);
+    if (r2) return r2;
     HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
     HIPCHK(hipEventSynchronize(s.ev_done));
     s.cs_len = (size_t)L.total;
@@ -166,14 +202,14 @@ extern "C" void ojphgpu_enc_pipe_destroy(ojphgpu_enc_pipe* p)
   { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
   p->cv_work.notify_all();
   for (std::thread& t : p->finishers) t.join();
-  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_res, p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
   if (p->enc) ojphgpu_encoder_destroy(p->enc);
   for (EncSlot& s : p->slots) {
     s.h_in.release(); s.h_res.release(); s.h_lay.release(); s.h_cs.release();
-    for (DeviceBuf* b : { &s.image, &s.out, &s.results, &s.counters, &s.cs.b, &s.lay.b }) b->release();
-    for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_res, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
+    for (DeviceBuf* b : { &s.image, &s.out, &s.counters, &s.cs.b }) b->release();
+    for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
   }
-  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_res, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
+  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
   delete p;
 }
 
@@ -190,7 +226,7 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     const Plan& P = plan->plan;
     p->handle = plan; p->P = &P; p->device = device; p->container = container_bits; p->depth = depth;
     if (container_bits == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
-    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_res, &p->s_d2h })
+    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h })
       HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     int rc = ojphgpu_encoder_create(plan, device, p->s_comp, &p->enc);
     if (rc) return rc;
@@ -204,11 +240,11 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     p->slots.resize(depth);
     for (EncSlot& s : p->slots) {
       if (s.h_in.reserve(p->frame_bytes + 64) || s.h_res.reserve(p->res_bytes + 64) || s.h_cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
-      if (s.image.alloc(p->frame_bytes + 64) || s.out.alloc((size_t)e->out_cap + 64) || s.results.alloc(p->res_bytes) || s.counters.alloc(16) ||
+      if (s.image.alloc(p->frame_bytes + 64) || s.out.alloc((size_t)e->out_cap + 64) || s.counters.alloc(16) ||
           s.cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
       const size_t lay_guess = nb * sizeof(T2Job) + nb * 8 + (1u << 16);
-      if (s.h_lay.reserve(lay_guess) || s.lay.reserve(lay_guess)) return OJPHGPU_E_NOMEM;
-      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_res, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+      if (s.h_lay.reserve(lay_guess)) return OJPHGPU_E_NOMEM;
+      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventReleaseToSystem));
     }
     const uint32_t nthreads = host_threads ? std::min<uint32_t>(host_threads, 16) : 2;
     for (uint32_t i = 0; i < nthreads; ++i) p->finishers.emplace_back(enc_finisher, p);
@@ -242,19 +278,18 @@ extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
   HIPCHK(hipSetDevice(p->device));
   ojphgpu_encoder* e = p->enc;
   s.rc = 0; s.cs_len = 0; s.t_submit = now_ms();
-  HIPCHK(hipMemcpyAsync(s.image.p, s.h_in.p, p->frame_bytes, hipMemcpyHostToDevice, p->s_h2d));
+  { const int r0 = upload(p->mode, p->s_h2d, s.image.p, s.h_in, 0, p->frame_bytes); if (r0) return r0; }
   HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
   HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
-  e->o_out = s.out.p; e->o_results = s.results.p; e->o_counters = s.counters.p;
+  // the block coder writes its per-block {offset, length} records straight into the slot's pinned memory
+  // (8 bytes per block, posted PCIe writes): all the host needs to code the packet headers
+  const size_t nb = e->block_ids.size();
+  e->o_out = s.out.p; e->o_results = s.h_res.d; e->o_counters = s.counters.p;
   int rc = ojphgpu_encoder_run_container(e, s.image.p, p->container);
   if (rc) return rc;
+  rc = publish_words_launch(p->s_comp, (uint32_t*)(s.h_res.d + nb * sizeof(ojphgpu_cb_result)), (const uint32_t*)s.counters.p, 2);
+  if (rc) return rc;
   HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
-  // block lengths + byte counter to the host: all the packet-header coder needs
-  const size_t nb = e->block_ids.size();
-  HIPCHK(hipStreamWaitEvent(p->s_res, s.ev_kern, 0));
-  if (nb) HIPCHK(hipMemcpyAsync(s.h_res.p, s.results.p, nb * sizeof(ojphgpu_cb_result), hipMemcpyDeviceToHost, p->s_res));
-  HIPCHK(hipMemcpyAsync(s.h_res.p + nb * sizeof(ojphgpu_cb_result), s.counters.p, 8, hipMemcpyDeviceToHost, p->s_res));
-  HIPCHK(hipEventRecord(s.ev_res, p->s_res));
   {
     std::lock_guard<std::mutex> lk(p->mu);
     s.state = SUBMITTED;
@@ -312,6 +347,7 @@ struct ojphgpu_dec_pipe {
   ojphgpu_plan* first = nullptr;                     // parsed from the first codestream: the geometry of every frame
   const Plan* P = nullptr;
   int device = 0, container = 16, resilient = 0;
+  int mode = copy_mode("OJPHGPU_DEC_COPY_MODE", 0);
   uint32_t depth = 0;
   ojphgpu_decoder* dec = nullptr;
   hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
@@ -349,8 +385,8 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     s.t_parse = now_ms() - t0;
     if (fi.first + fi.len > s.cs_len) return OJPHGPU_E_CODESTREAM;
     if (s.data.reserve((size_t)fi.len + (size_t)fi.len / 4 + 64)) return OJPHGPU_E_NOMEM;
-    if (fi.len) HIPCHK(hipMemcpyAsync(s.data.b.p, s.h_cs.p + fi.first, (size_t)fi.len, hipMemcpyHostToDevice, p->s_h2d));
-    if (nb) HIPCHK(hipMemcpyAsync(s.cb_descs.p, bd, nb * sizeof(ojphgpu_cb_desc), hipMemcpyHostToDevice, p->s_h2d));
+    if ((r2 = upload(p->mode, p->s_h2d, s.data.b.p, s.h_cs, (size_t)fi.first, (size_t)fi.len)) != 0) return r2;
+    if ((r2 = upload(p->mode, p->s_h2d, s.cb_descs.p, s.h_descs, 0, nb * sizeof(ojphgpu_cb_desc))) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
     {
       // the decoder object is shared by the frames in flight: what a run reads is set and enqueued under a lock
@@ -358,14 +394,13 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
       HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
       d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
       d->any_refine = fi.any_refine; d->max_len1 = fi.max_len1;
-      HIPCHK(hipMemsetAsync(s.status.p, 0, nb + 16, p->s_comp));
       r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
       if (r2) return r2;
       HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
     }
     HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
-    HIPCHK(hipMemcpyAsync(s.h_img.p, s.image.p, p->frame_bytes, hipMemcpyDeviceToHost, p->s_d2h));
-    if (nb) HIPCHK(hipMemcpyAsync(s.h_status.p, s.status.p, nb, hipMemcpyDeviceToHost, p->s_d2h));
+    if ((r2 = download(p->mode, p->s_d2h, s.h_img, s.image.p, p->frame_bytes)) != 0) return r2;       // beside the next frame's upload
+    if ((r2 = download(p->mode, p->s_d2h, s.h_status, s.status.p, nb)) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
     HIPCHK(hipEventSynchronize(s.ev_done));
     uint32_t failed = 0;
@@ -451,7 +486,7 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
           s.h_img.reserve(p->frame_bytes + 64) || s.h_status.reserve(nb + 64)) return OJPHGPU_E_NOMEM;
       if (s.data.reserve(len + len / 4 + 64) || s.image.alloc((size_t)P.frame_elems * 4 + 64) || s.cb_descs.alloc(nb * sizeof(ojphgpu_cb_desc) + 64) ||
           s.status.alloc(nb + 64)) return OJPHGPU_E_NOMEM;
-      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+      for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventReleaseToSystem));
     }
     const uint32_t nthreads = host_threads ? std::min<uint32_t>(host_threads, 16) : 2;
     for (uint32_t i = 0; i < nthreads; ++i) p->workers.emplace_back(dec_worker, p);
