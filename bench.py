@@ -71,8 +71,9 @@ def plan_is_tiled(tile):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=1500,
+                    help="timed steps (default 1500: about 2 s of GPU time on the 8K frame, long enough for an external sampler to see)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3_8k_444_12b_irv97", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -84,6 +85,8 @@ def main():
                          "exchanges line by line)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: the frame being encoded and the frame being decoded are issued on two HIP streams")
+    ap.add_argument("--e2e-frames", type=int, default=48,
+                    help="frames per frame-pipeline measurement (host memory -> codestream in host memory and back); 0 = skip")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch one elementwise kernel of known traffic (PMC unit calibration)")
     args = ap.parse_args()
@@ -95,7 +98,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         w_, h_, nc_, bd_, rev_, ct_, qstep_, _tile = WORKLOADS[args.workload]
         try:
-            cpu_all = cpu_baseline_all_cores(workload_image(args.workload)[:, :min(h_, 2048)], bd_, rev_, ct_, qstep_)
+            cpu_all = cpu_baseline_all_cores(workload_image(args.workload), bd_, rev_, ct_, qstep_, _tile)
         except Exception as e:                     # the single-thread figure stands on its own
             cpu_all = {"value": None, "error": str(e)[:200]}
     import torch
@@ -152,8 +155,9 @@ def main():
     t0 = time.perf_counter()
     if tiled:
         enc.run_device(d_img)
-        part, lens = enc.finish_tiles()
         cdev = dev if backend == "nccl" else None                # device tensors over RCCL, host tensors over gloo
+        # RCCL: the tile-parts are assembled in HBM and travel GPU -> GPU; gloo (CPU smoke runs): through the host
+        part, lens = enc.finish_tiles_device() if backend == "nccl" else enc.finish_tiles()
         all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, my_tiles[0], device=cdev, parts_per_tile=plan.parts_per_tile)
         parts, _ = shard.gather_bytes(part, device=cdev)         # RCCL: the final codestream gather
         cs = shard.assemble(plan.t2_main_header(all_lens), parts) if rank == 0 else None
@@ -207,10 +211,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank_ms = [round(elapsed * 1e3 / args.steps, 4)]
+    if world > 1:                                # every rank's own time travels: a straggler shows; value uses the maximum
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x) * 1e3 / args.steps, 4) for x in t.tolist()]
+        elapsed = float(t.max().item())
     ms_per_step = elapsed * 1e3 / args.steps
     if args.calibrate:                           # known traffic: reads 4 B/elem, writes 4 B/elem, 16 B per lane
         a = torch.zeros(64 * 1024 * 1024, dtype=torch.float32, device=dev)
@@ -317,14 +324,30 @@ def main():
         assert torch.equal(d_out2, d_out) or os.environ.get("OJPH_BENCH_NOCHECK"), "two-stream decode differs"
         del enc2, dec2, d_out2
 
+    # Frame pipelines: host memory -> codestream in host memory (and back) with PCIe and host Tier-2 inside the
+    # timed region, steady state over --e2e-frames frames: what a capture / playback process gets.
+    e2e = None
+    if args.e2e_frames > 0 and world == 1 and frames == 1 and not tiled:
+        try:
+            import gc
+            gc.collect(); torch.cuda.synchronize(dev)
+            e2e = e2e_pipelines(plan, img, cs, args.e2e_frames, args.container, torch)
+        except Exception as e:                   # reported, never fatal for the headline figure
+            e2e = {"error": str(e)[:300]}
+
     result = {
         "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
         "value": round(nsamples * (1 if tiled else world) / (ms_per_step * 1e-3) / 1e6, 2),
         "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "per_rank_ms_per_step": per_rank_ms,
         "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
         "dtype": "i32" if rev else "f32", "data": "synthetic",
+        "value_covers": "device-resident step: samples in HBM -> convert + DWT + quantise + HT block encode -> coded block bytes in HBM, "
+                        "then those bytes -> HT block decode + inverse DWT + convert -> samples in HBM; PCIe and host Tier-2 are "
+                        "outside (e2e_steady_Msamples_s has them inside)",
+        "e2e_steady_Msamples_s": ({k: v["Msamples_s"] for k, v in e2e.items() if isinstance(v, dict) and "Msamples_s" in v} if e2e and "error" not in e2e else None),
         "config": {"workload": args.workload, "width": w, "height": h, "components": nc, "bit_depth": bd,
                    "wavelet": "5/3 reversible" if rev else "9/7 irreversible", "qstep": qstep if not rev else None,
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
@@ -343,6 +366,11 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic},
         "kernels": kinfo,
     }
+    if e2e:
+        result["e2e"] = e2e
+    rv = roofline_valu(args.workload, kinfo)
+    if rv:
+        result["roofline_valu"] = rv
     if "dwt_forward(level 1)" in kernels and kernels["dwt_forward(level 1)"][1] > 0:
         # the HBM-bound kernel family of the path (north_star sets its roofline target on it); the
         # block coder launches above are bound by integer VALU issue, not by HBM.  Level 1 -- the two
@@ -373,6 +401,131 @@ def main():
         dist.destroy_process_group()
 
 
+def roofline_valu(workload, kinfo):
+    """The block coder is bound by VALU issue, not by HBM: its launches against THAT roof.  Wavefront
+    instructions come from the committed SQ counter pass (profiles/sq_counters.json, tools/sq_round.sh: SQ_INSTS_VALU
+    / SQ_INSTS_SALU summed over the launch); a SIMD issues one wave64 integer VALU instruction per 4 cycles
+    (measured), the chip has 1024 SIMDs at up to 2.4 GHz; the time comes from this run."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json"))).get(workload, {})
+    except Exception:
+        return None
+    out = {}
+    for k, v in kinfo.items():
+        base = k.split("(")[0].split("[")[0]
+        c = sq.get(k) or sq.get(base)
+        if not c or not v["ms"]:
+            continue
+        issue_ms = c["valu_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
+        out[k] = {"valu_wave_insts": c["valu_insts"], "salu_wave_insts": c.get("salu_insts"), "valu_issue_ms_at_peak": round(issue_ms, 4),
+                  "measured_ms": v["ms"], "frac": round(issue_ms / v["ms"], 3)}
+    if not out:
+        return None
+    return {"bound": "valu-issue", "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz", "kernels": out,
+            "source": "profiles/sq_counters.json"}
+
+
+def pcie_bandwidth(torch, nbytes=256 << 20, reps=4):
+    """one direction at a time, pinned memory, hipMemcpyAsync: the roof of the frame pipelines"""
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = {}
+    for name, (dst, src) in dict(h2d=(d, h), d2h=(h, d)).items():
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 1)
+    return out
+
+
+def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None):
+    """n frames through an encoder pipe in steady state; every slot is filled once (the frame a capture device would
+    have written there), later submissions send the slot again: each frame pays its H2D, kernels, Tier-2, D2H"""
+    from openjph_amd.pipeline import EncoderPipe
+    pipe = EncoderPipe(plan=plan, depth=depth, container=container, host_threads=threads)
+    k = 0
+    while k < depth:
+        buf = pipe.acquire()
+        if buf is None:
+            break
+        buf[:] = img.astype(buf.dtype)
+        pipe.submit(); k += 1
+    first = None
+    while pipe.in_flight:
+        c = pipe.collect()
+        first = c if first is None else first
+    if want is not None:
+        assert first == want, "pipeline codestream differs from the one-frame encoder's"
+    t0 = time.perf_counter()
+    sub = col = 0
+    nbytes = 0
+    while col < n:
+        while sub < n and pipe.acquire() is not None:
+            pipe.submit(); sub += 1
+        nbytes += len(pipe.collect(copy=False)); col += 1
+    dt = time.perf_counter() - t0
+    st = pipe.stats()
+    pipe.close()
+    assert nbytes == n * len(first)
+    return dt, st
+
+
+def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None):
+    from openjph_amd.pipeline import DecoderPipe
+    pipe = DecoderPipe(cs, depth=depth, container=container, host_threads=threads)
+    k = 0
+    while k < depth:
+        buf = pipe.acquire(len(cs))
+        if buf is None:
+            break
+        buf[:] = np.frombuffer(cs, np.uint8)
+        pipe.submit(); k += 1
+    first = None
+    while pipe.in_flight:
+        f = pipe.collect()
+        first = f if first is None else first
+    if want is not None:
+        assert np.array_equal(first.astype(np.int64), want.astype(np.int64)), "pipeline frame differs from the one-frame decoder's"
+    t0 = time.perf_counter()
+    sub = col = 0
+    while col < n:
+        while sub < n and pipe.acquire(len(cs)) is not None:      # the slot still holds the codestream
+            pipe.submit(); sub += 1
+        pipe.collect(copy=False); col += 1
+    dt = time.perf_counter() - t0
+    st = pipe.stats()
+    pipe.close()
+    return dt, st
+
+
+def e2e_pipelines(plan, img, cs, n, container, torch):
+    """steady-state Msamples/s of the encoder pipe, the decoder pipe, and both at once (a transcoder: every step one
+    frame goes in and one comes out in each direction)"""
+    import threading
+    nsamp = img.size
+    out = {"frames": n, "depth": 4, "sample_container_bits": container, "pcie_GBps_one_direction": pcie_bandwidth(torch)}
+    if isinstance(cs, (list, tuple)):
+        cs = cs[0]
+    dt, st = run_encoder_pipe(plan, img, n, container=container, want=cs)
+    out["encode"] = {"Msamples_s": round(nsamp * n / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
+                     "host_tier2_ms": round(st["host_tier2_ms"], 3), "latency_ms": round(st["latency_ms"], 2), "tier2_threads": st["tier2_threads"]}
+    dt, st = run_decoder_pipe(cs, n, container=container)
+    out["decode"] = {"Msamples_s": round(nsamp * n / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
+                     "host_parse_ms": round(st["host_parse_ms"], 3), "latency_ms": round(st["latency_ms"], 2)}
+    res = {}
+    te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, container=container)))
+    td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, container=container)))
+    t0 = time.perf_counter()
+    te.start(); td.start(); te.join(); td.join()
+    if "e" in res and "d" in res:
+        wall = max(res["e"][0], res["d"][0])               # both pipes code n frames; the slower one sets the step rate
+        out["encode+decode"] = {"Msamples_s": round(nsamp * n / wall / 1e6, 1), "ms_per_step": round(wall * 1e3 / n, 3),
+                                "encode_ms_per_frame": round(res["e"][0] * 1e3 / n, 3), "decode_ms_per_frame": round(res["d"][0] * 1e3 / n, 3)}
+    return out
+
+
 def cpu_baseline(img, bd, rev, ct, qstep, tile, reps):
     """The reference library (its own SIMD dispatch) on this host, one thread, same frame."""
     from oracle import refbind
@@ -398,43 +551,49 @@ def cpu_baseline(img, bd, rev, ct, qstep, tile, reps):
 
 
 def _cpu_worker(args):
-    """one process = one reference codestream object over its own tile-sized image (the library is
-    single-threaded; independent frames / tiles are how it scales on a host)"""
-    idx, rows, bd, rev, ct, qstep, rounds = args
-    tile = _CPU_BANDS[idx][:, :rows]                # inherited through fork: nothing is pickled
+    """one process = one reference codestream object coding WHOLE frames (the library is single-threaded;
+    independent frames are how it scales on a host)"""
+    bd, rev, ct, qstep, tile, rounds = args
     from oracle import refbind
     r = refbind.Ref()
+    img = _CPU_FRAME                                  # inherited through fork (copy-on-write: never written)
     t0 = time.perf_counter()
     for _ in range(rounds):
-        cs = r.encode(tile, bd, reversible=rev, color_transform=ct, qstep=qstep)
+        cs = r.encode(img, bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
         r.decode(cs)
     return time.perf_counter() - t0
 
 
-_CPU_BANDS = []
+_CPU_FRAME = None
 
 
-def cpu_baseline_all_cores(img, bd, rev, ct, qstep, rounds=2):
-    """aggregate encode+decode rate of P independent processes, P = min(host cpus, 64), each coding a
-    1024-row band of the frame `rounds` times: about 2 s of wall time"""
+def cpu_baseline_all_cores(img, bd, rev, ct, qstep, tile=(0, 0), rounds=1):
+    """aggregate encode+decode rate of P independent processes, each coding the whole frame `rounds` times.  P = all
+    of os.cpu_count(), lowered only if the host's free memory would not hold P decoded frames (a process needs the
+    decoded int32 frame + codestream + the library's line buffers: about 6 bytes per sample)"""
     import multiprocessing as mp
-    procs = max(1, min(os.cpu_count() or 1, 64))
-    h = img.shape[1]
-    band = min(1024, h)
-    tiles = [np.ascontiguousarray(img[:, (i * band) % max(h - band + 1, 1):][:, :band]) for i in range(procs)]
-    global _CPU_BANDS
-    _CPU_BANDS = tiles
+    global _CPU_FRAME
+    cpus = os.cpu_count() or 1
+    per_proc = img.size * 6 + (64 << 20)
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except Exception:
+        avail = 64 << 30
+    procs = max(1, min(cpus, int(avail * 0.4 // per_proc)))
+    _CPU_FRAME = img
     ctx = mp.get_context("fork")
+    small = (bd, rev, ct, qstep, tile, 0)
     with ctx.Pool(procs) as pool:
-        pool.map(_cpu_worker, [(i, 64, bd, rev, ct, qstep, 1) for i in range(procs)], chunksize=1)      # start the workers, load the library
+        pool.map(_cpu_worker, [small] * procs, chunksize=1)          # start the workers, load the library
         t0 = time.perf_counter()
-        pool.map(_cpu_worker, [(i, band, bd, rev, ct, qstep, rounds) for i in range(procs)], chunksize=1)
+        pool.map(_cpu_worker, [(bd, rev, ct, qstep, tile, rounds)] * procs, chunksize=1)
         wall = time.perf_counter() - t0
-    _CPU_BANDS = []
-    n = sum(t.size for t in tiles) * rounds
-    return {"value": round(n / wall / 1e6, 2), "unit": "Msamples/s", "cores": procs,
-            "sample": "%d processes, each encode+decode of a %dx%dx%d band x %d (%.2f s wall)"
-                      % (procs, tiles[0].shape[2], tiles[0].shape[1], tiles[0].shape[0], rounds, wall)}
+    _CPU_FRAME = None
+    n = img.size * rounds * procs
+    return {"value": round(n / wall / 1e6, 2), "unit": "Msamples/s", "cores": procs, "host_cpus": cpus,
+            "sample": "%d processes (host has %d cpus), each encode+decode of the whole %dx%dx%d frame x %d (%.2f s wall); "
+                      "includes the reference's Tier-2 and memory-file I/O, like the single-thread figure"
+                      % (procs, cpus, img.shape[2], img.shape[1], img.shape[0], rounds, wall)}
 
 
 if __name__ == "__main__":

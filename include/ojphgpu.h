@@ -371,6 +371,11 @@ int  ojphgpu_encoder_create_tiles(const ojphgpu_plan* plan, int device, void* st
 /* D2H + host Tier-2 of the range: its tile-parts only (see ojphgpu_t2_write_tiles) */
 int  ojphgpu_encoder_finish_tiles(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len,
                                   uint32_t* tile_part_len);
+/* the same with the tile-parts left in DEVICE memory (assembled there by a placement kernel; only the block
+ * lengths visit the host): d_out receives *out_len bytes.  What a rank hands to the final codestream gather
+ * of a multi-GPU encode (RCCL over xGMI) without a host round trip.  OJPHGPU_E_OVERFLOW + *out_len = need. */
+int  ojphgpu_encoder_finish_tiles_device(ojphgpu_encoder* enc, uint8_t* d_out, size_t cap, size_t* out_len,
+                                         uint32_t* tile_part_len);
 /* An encoder for a BATCH of num_frames independent frames of the plan's shape (video: BASELINE
  * config "512 independent 4K frames"): one set of launches codes all of them, which is what fills
  * the GPU when a single frame does not.  d_image / h_image then hold the frames back to back

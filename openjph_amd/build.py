@@ -21,11 +21,12 @@ def needs_build():
     deps.append(os.path.join(HERE, "..", "include", "ojphgpu.h"))
     deps.append(os.path.join(HERE, "..", "include", "ojph_gpu_codestream.h"))
     deps += [os.path.join(HERE, "apps", f) for f in os.listdir(os.path.join(HERE, "apps")) if f.endswith((".cpp", ".h"))]
-    check_src = os.path.join(HERE, "..", "tests", "facade", "coc_roundtrip.cpp")
-    if os.path.exists(check_src):
-        deps.append(check_src)
-    if not all(os.path.exists(x) for x in (os.path.join(HERE, "libopenjph_gpu.so"), os.path.join(HERE, "apps", "ojph_compress"),
-                                           os.path.join(HERE, "apps", "ojph_expand"), os.path.join(HERE, "apps", "facade_coc_roundtrip"))):
+    fdir = os.path.join(HERE, "..", "tests", "facade")
+    checks = sorted(f for f in os.listdir(fdir) if f.endswith(".cpp")) if os.path.isdir(fdir) else []
+    deps += [os.path.join(fdir, f) for f in checks]
+    outs = [os.path.join(HERE, "libopenjph_gpu.so"), os.path.join(HERE, "apps", "ojph_compress"), os.path.join(HERE, "apps", "ojph_expand")]
+    outs += [os.path.join(HERE, "apps", "facade_" + f[:-4]) for f in checks]
+    if not all(os.path.exists(x) for x in outs):
         return True
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -69,11 +70,12 @@ def build_facade(verbose=False):
     for app in ("ojph_compress", "ojph_expand"):
         cmds.append([HIPCC, "-O2", "-std=c++17", "-Wall", os.path.join(APPS, app + ".cpp"), "-o", os.path.join(APPS, app),
                      "-L" + HERE, "-lopenjph_gpu", "-lojphgpu", "-Wl,-rpath,$ORIGIN/.."])
-    # a facade scenario the tests run on the GPU box (tests/test_cli.py)
-    check_src = os.path.join(os.path.dirname(HERE), "tests", "facade", "coc_roundtrip.cpp")
-    if os.path.exists(check_src):
-        cmds.append([HIPCC, "-O2", "-std=c++17", "-Wall", check_src, "-o", os.path.join(APPS, "facade_coc_roundtrip"),
-                     "-L" + HERE, "-lopenjph_gpu", "-lojphgpu", "-Wl,-rpath,$ORIGIN/.."])
+    # facade scenarios the tests run on the GPU box (tests/test_cli.py)
+    fdir = os.path.join(os.path.dirname(HERE), "tests", "facade")
+    for f in sorted(os.listdir(fdir)) if os.path.isdir(fdir) else []:
+        if f.endswith(".cpp"):
+            cmds.append([HIPCC, "-O2", "-std=c++17", "-Wall", os.path.join(fdir, f), "-o", os.path.join(APPS, "facade_" + f[:-4]),
+                         "-L" + HERE, "-lopenjph_gpu", "-lojphgpu", "-Wl,-rpath,$ORIGIN/.."])
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd))

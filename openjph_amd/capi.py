@@ -175,6 +175,7 @@ SIGNATURES = {
     "ojphgpu_encoder_create_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p)]),
     "ojphgpu_encoder_finish_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
+    "ojphgpu_encoder_finish_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "ojphgpu_decoder_create_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p)]),
     "ojphgpu_encoder_create_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),

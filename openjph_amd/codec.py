@@ -117,6 +117,22 @@ class Encoder:
         check(rc, "encoder_finish_tiles")
         return out[:n.value].tobytes(), lens[:self.tiles[1] * self.plan.parts_per_tile].copy()
 
+    def finish_tiles_device(self):
+        """-> (tile-part bytes of this encoder's tile range as a uint8 torch tensor ON THE DEVICE, Psot per tile-part):
+        the bytes are assembled in HBM and never visit the host (input of shard.gather_bytes over RCCL)"""
+        torch = _torch()
+        cap = self.coded_bytes() + 64 * self.plan.num_blocks + 4096 * max(self.tiles[1], 1) + (1 << 16)
+        lens = np.zeros(max(self.tiles[1], 1) * self.plan.parts_per_tile, np.uint32)
+        n = C.c_size_t()
+        out = torch.empty(cap, dtype=torch.uint8, device="cuda:%d" % self.device)
+        rc = self._lib.ojphgpu_encoder_finish_tiles_device(self._h, C.c_void_p(out.data_ptr()), cap, C.byref(n), lens.ctypes.data)
+        if rc == capi.E_OVERFLOW and n.value > cap:
+            cap = int(n.value)
+            out = torch.empty(cap, dtype=torch.uint8, device="cuda:%d" % self.device)
+            rc = self._lib.ojphgpu_encoder_finish_tiles_device(self._h, C.c_void_p(out.data_ptr()), cap, C.byref(n), lens.ctypes.data)
+        check(rc, "encoder_finish_tiles_device")
+        return out[:n.value], lens[:self.tiles[1] * self.plan.parts_per_tile].copy()
+
     def encode(self, image):
         """image: numpy int32 [C,H,W] (host), a list of per-component 2-D arrays (sub-sampled
         components), or a torch int32 tensor on the device -> codestream bytes; for a batch encoder

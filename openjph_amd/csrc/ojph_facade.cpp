@@ -120,6 +120,16 @@ struct codestream_state {
   ojphgpu_plan* plan = nullptr;
   ojphgpu_encoder* enc = nullptr;
   ojphgpu_decoder* dec = nullptr;
+  // An object that is restart()ed codes a SEQUENCE of frames (ojph_codestream.h:204): from the second frame on it
+  // works through a frame pipeline (include/ojphgpu.h section 6) that outlives restart() -- pinned frame and
+  // codestream buffers, device arena, descriptor tables and streams are made once per frame format, the
+  // application's lines land directly in the pinned memory the upload reads.
+  bool sequence = false;              // restart() has been called
+  ojphgpu_enc_pipe* epipe = nullptr; ojphgpu_plan* epipe_plan = nullptr; ojphgpu_params epipe_params;
+  std::vector<std::vector<ui8>> epipe_comments;
+  ojphgpu_dec_pipe* dpipe = nullptr; bool dpipe_resilient = false;
+  bool frame_of_pipe = false;         // `frame` is memory of a pipe slot: not ours to free
+  bool restricted = false;            // restrict_input_resolution was called for this frame
   si32* frame = nullptr; bool frame_pinned = false; size_t frame_elems = 0;
   std::vector<ui32> cw, ch; std::vector<size_t> coff;   // component planes inside the frame (ojphgpu_plan_comp_info)
   std::vector<si32> spare;                              // a line nobody reads (interleaved exchange past a short component)
@@ -136,17 +146,25 @@ struct codestream_state {
     p.prog_order = 2; p.qstep = -1.0f;                                      // RPCL; qstep chosen from the bit depth
     comps.clear(); image_offset = point(0, 0); tile_offset = point(0, 0); skip_recon = 0;
   }
-  void release()
+  void release_pipes()
+  {
+    if (epipe) { ojphgpu_enc_pipe_destroy(epipe); epipe = nullptr; }
+    if (epipe_plan) { ojphgpu_plan_destroy(epipe_plan); epipe_plan = nullptr; }
+    if (dpipe) { ojphgpu_dec_pipe_destroy(dpipe); dpipe = nullptr; }
+  }
+  void release()                       // what one frame owned; the pipes stay (see `sequence`)
   {
     if (enc) { ojphgpu_encoder_destroy(enc); enc = nullptr; }
     if (dec) { ojphgpu_decoder_destroy(dec); dec = nullptr; }
-    if (plan) { ojphgpu_plan_destroy(plan); plan = nullptr; }
-    if (frame) { if (frame_pinned) (void)hipHostFree(frame); else free(frame); frame = nullptr; }
+    if (plan && plan != epipe_plan) ojphgpu_plan_destroy(plan);
+    plan = nullptr;
+    if (frame && !frame_of_pipe) { if (frame_pinned) (void)hipHostFree(frame); else free(frame); }
+    frame = nullptr; frame_of_pipe = false; restricted = false;
     frame_elems = 0; stream.clear(); lines.clear();
     headers_written = headers_read = decoded = false; exhausted = false; cur_comp = cur_line = 0;
     outfile = nullptr; infile = nullptr;
   }
-  void alloc_frame()
+  void alloc_frame(si32* pipe_frame = nullptr)
   {
     cw.assign(p.num_comps, 0); ch.assign(p.num_comps, 0); coff.assign(p.num_comps, 0);
     ui32 info[8], widest = 0;
@@ -162,7 +180,8 @@ struct codestream_state {
     // speed up (measured on the MI355X host: both ~57 GB/s), so the frame is plain memory; set
     // OJPH_GPU_PIN=1 for long-lived objects that restart() and reuse their buffers
     void* ptr = nullptr;
-    if (getenv("OJPH_GPU_PIN") && hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
+    if (pipe_frame) { frame = pipe_frame; frame_of_pipe = true; frame_pinned = true; }
+    else if (getenv("OJPH_GPU_PIN") && hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
     else { (void)hipGetLastError(); frame = (si32*)malloc(frame_elems * sizeof(si32)); frame_pinned = false; }
     if (!frame) ojph_error(0x00030F01, "cannot allocate the %zu-sample frame buffer", frame_elems);
     lines.assign(p.num_comps, line_buf());
@@ -414,8 +433,14 @@ static void warm_up_gpu_runtime()
 }
 
 codestream::codestream() : state(new codestream_state()) { warm_up_gpu_runtime(); }
-codestream::~codestream() { state->release(); delete state; }
-void codestream::restart() { state->release(); state->reset_params(); state->planar = -1; state->resilient = false; state->profile.clear(); }
+codestream::~codestream() { state->release(); state->release_pipes(); delete state; }
+// (ojph_codestream_local.cpp:78-110) the object forgets the frame it coded but keeps what a next frame of the
+// same format can use again
+void codestream::restart()
+{
+  state->release(); state->reset_params(); state->planar = -1; state->resilient = false; state->profile.clear();
+  state->sequence = true;
+}
 
 void codestream::set_planar(bool planar) { state->planar = planar ? 1 : 0; }
 bool codestream::is_planar() const { return state->planar == 1; }
@@ -549,9 +574,31 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
     if (ojphgpu_plan_set_comments(S.plan, d.data(), l.data(), r.data(), num_comments) != OJPHGPU_OK)
       ojph_error(0x00030F06, "COM marker segments rejected");
   }
-  rc = ojphgpu_encoder_create(S.plan, S.device, nullptr, &S.enc);
-  if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
-  S.alloc_frame();
+  std::vector<std::vector<ui8>> cmts;
+  for (ui32 i = 0; comments != nullptr && i < num_comments; ++i) {
+    std::vector<ui8> c((const ui8*)comments[i].data, (const ui8*)comments[i].data + comments[i].len);
+    c.push_back((ui8)comments[i].Rcom); c.push_back((ui8)(comments[i].Rcom >> 8));
+    cmts.push_back(c);
+  }
+  if (S.sequence) {                                                // a frame of a sequence: through the pipeline
+    if (S.epipe && (memcmp(&S.epipe_params, &p, sizeof(p)) != 0 || S.epipe_comments != cmts)) {   // another frame format
+      ojphgpu_enc_pipe_destroy(S.epipe); S.epipe = nullptr;
+      ojphgpu_plan_destroy(S.epipe_plan); S.epipe_plan = nullptr;
+    }
+    if (!S.epipe) {
+      rc = ojphgpu_enc_pipe_create(S.plan, S.device, 2, 32, 0, &S.epipe);
+      if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
+      S.epipe_plan = S.plan; S.epipe_params = p; S.epipe_comments = cmts;
+    } else { ojphgpu_plan_destroy(S.plan); S.plan = S.epipe_plan; }
+    void* slot = nullptr; size_t bytes = 0;
+    rc = ojphgpu_enc_pipe_acquire(S.epipe, &slot, &bytes);
+    if (rc) ojph_error(0x00030F08, "the frame pipeline has no free slot (status %d)", rc);
+    S.alloc_frame((si32*)slot);
+  } else {
+    rc = ojphgpu_encoder_create(S.plan, S.device, nullptr, &S.enc);
+    if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
+    S.alloc_frame();
+  }
   S.outfile = file;
   S.headers_written = true;
   S.cur_comp = 0; S.cur_line = 0; S.exhausted = false;
@@ -582,6 +629,14 @@ void codestream::flush()
 {
   codestream_state& S = *state;
   if (!S.headers_written) ojph_error(0x00030F0A, "flush called before write_headers");
+  if (S.epipe && S.frame_of_pipe) {            // the frame sits in the pipe's pinned slot already: upload, code, assemble, download
+    int rc = ojphgpu_enc_pipe_submit(S.epipe);
+    const ui8* cs = nullptr; size_t n = 0;
+    if (rc == OJPHGPU_OK) rc = ojphgpu_enc_pipe_collect(S.epipe, &cs, &n);
+    if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
+    if (S.outfile->write(cs, n) != n) ojph_error(0x00030071, "Error writing to file");               // :1163
+    return;
+  }
   size_t len = 0;
   int rc = ojphgpu_encode(S.enc, S.frame, nullptr, 0, &len);            // runs the GPU path; reports the codestream size
   if (rc != OJPHGPU_E_OVERFLOW && rc != OJPHGPU_OK) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
@@ -628,13 +683,36 @@ void codestream::restrict_input_resolution(ui32 skipped_res_for_data, ui32 skipp
                skipped_res_for_data, S.p.num_decomps);
   if (ojphgpu_plan_restrict_resolution(S.plan, skipped_res_for_data, skipped_res_for_recon) != OJPHGPU_OK)
     ojph_error(0x00030F0D, "the GPU path rejected the resolution restriction");
-  S.skip_recon = skipped_res_for_recon;
+  S.skip_recon = skipped_res_for_recon; S.restricted = true;
 }
 
 void codestream::create()
 {
   codestream_state& S = *state;
   if (!S.headers_read) ojph_error(0x00030F0E, "create called before read_headers");
+  if (S.sequence && !S.restricted) {            // a frame of a sequence: through the pipeline (whole-resolution decoding)
+    if (S.dpipe && S.dpipe_resilient != S.resilient) { ojphgpu_dec_pipe_destroy(S.dpipe); S.dpipe = nullptr; }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (!S.dpipe) {
+        int rc = ojphgpu_dec_pipe_create(S.stream.data(), S.stream.size(), S.resilient ? 1 : 0, S.device, 2, 32, 0, &S.dpipe);
+        if (rc) ojph_error(0x00030F0F, "cannot create the GPU decoder (status %d): no GPU?", rc);
+        S.dpipe_resilient = S.resilient;
+      }
+      ui8* slot = nullptr;
+      int rc = ojphgpu_dec_pipe_acquire(S.dpipe, S.stream.size(), &slot);
+      if (rc == OJPHGPU_OK) { memcpy(slot, S.stream.data(), S.stream.size()); rc = ojphgpu_dec_pipe_submit(S.dpipe); }
+      const void* frame = nullptr; size_t bytes = 0; ui32 failed = 0;
+      if (rc == OJPHGPU_OK) rc = ojphgpu_dec_pipe_collect(S.dpipe, &frame, &bytes, &failed);
+      if (rc == OJPHGPU_E_INVALID && attempt == 0) { ojphgpu_dec_pipe_destroy(S.dpipe); S.dpipe = nullptr; continue; }   // another frame format: a new pipe
+      if (rc == OJPHGPU_E_BLOCK) { if (!S.resilient) ojph_error(0x000300A1, "Error decoding a codeblock"); }
+      else if (rc) ojph_error(0x00030F12, "GPU decode failed (status %d)", rc);
+      S.alloc_frame((si32*)const_cast<void*>(frame));
+      S.decoded = true;
+      break;
+    }
+    S.cur_comp = 0; S.cur_line = 0; S.exhausted = false;
+    return;
+  }
   int rc = ojphgpu_decoder_create(S.plan, S.device, nullptr, &S.dec);
   if (rc) ojph_error(0x00030F0F, "cannot create the GPU decoder (status %d): no GPU?", rc);
   S.alloc_frame();
@@ -645,7 +723,7 @@ void codestream::create()
 line_buf* codestream::pull(ui32& comp_num)
 {
   codestream_state& S = *state;
-  if (!S.dec) ojph_error(0x00030F10, "pull called before create");
+  if (!S.dec && !S.decoded) ojph_error(0x00030F10, "pull called before create");
   if (!S.decoded) {
     int rc = ojphgpu_decode(S.dec, S.stream.data(), S.stream.size(), S.frame);
     if (rc == OJPHGPU_E_BLOCK) { if (!S.resilient) ojph_error(0x000300A1, "Error decoding a codeblock"); }   // ojph_codeblock.cpp:214-224

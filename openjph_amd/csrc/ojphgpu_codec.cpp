@@ -326,6 +326,53 @@ extern "C" int ojphgpu_encoder_finish_tiles(ojphgpu_encoder* e, uint8_t* h_out, 
   });
 }
 
+namespace ojphgpu {
+int assemble_launch(void* stream, const T2Job* d_jobs, uint32_t njobs, const uint8_t* d_blob, const uint8_t* d_data, uint8_t* d_out);
+}
+
+// The tile-parts of the range assembled in HBM (kernels_assemble.hip) instead of on the host: only the block
+// lengths come to the host, the layout goes back, and the bytes stay on the device -- where the final
+// codestream gather of a multi-GPU encode picks them up (RCCL send over xGMI, openjph_amd/shard.py).
+extern "C" int ojphgpu_encoder_finish_tiles_device(ojphgpu_encoder* e, uint8_t* d_out, size_t cap, size_t* out_len,
+                                                    uint32_t* tile_part_len)
+{
+  if (!e || !out_len || !e->ran) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
+    const Plan& P = *e->P;
+    uint64_t nbytes = 0;
+    int rc = ojphgpu_encoder_coded_bytes(e, &nbytes);
+    if (rc) return rc;
+    const size_t nb = e->block_ids.size();
+    const size_t rbytes = e->h_results.size() * sizeof(ojphgpu_cb_result);
+    if (rbytes) HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, rbytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<ojphgpu_coded_block> cb(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
+    for (size_t i = 0; i < nb; ++i) {
+      const ojphgpu_cb_result& r = e->h_results[i];
+      ojphgpu_coded_block& c = cb[e->block_ids[i]];
+      c.offset = r.offset; c.len1 = r.length; c.len2 = 0;
+      c.missing_msbs = r.length ? P.bands[P.blocks[e->block_ids[i]].band].K_max - 1 : 0;
+      c.num_passes = r.length ? 1 : 0;
+    }
+    T2Layout L;
+    rc = t2_layout_tiles(P, cb.data(), e->tiles.first, (size_t)e->tiles.first + e->tiles.count, L, tile_part_len);
+    if (rc) return rc;
+    *out_len = (size_t)L.total;
+    if (!d_out || cap < L.total) return OJPHGPU_E_OVERFLOW;
+    const size_t jbytes = L.jobs.size() * sizeof(T2Job), boff = (jbytes + 63) & ~(size_t)63;
+    DeviceBuf lay;
+    if (lay.alloc(boff + L.blob.size() + 64)) return OJPHGPU_E_NOMEM;
+    struct Free { DeviceBuf& b; ~Free() { b.release(); } } fr{ lay };
+    if (jbytes) HIPCHK(hipMemcpyAsync(lay.p, L.jobs.data(), jbytes, hipMemcpyHostToDevice, e->stream));
+    if (!L.blob.empty()) HIPCHK(hipMemcpyAsync((uint8_t*)lay.p + boff, L.blob.data(), L.blob.size(), hipMemcpyHostToDevice, e->stream));
+    rc = assemble_launch(e->stream, (const T2Job*)lay.p, (uint32_t)L.jobs.size(), (const uint8_t*)lay.p + boff,
+                         (const uint8_t*)(e->o_out ? e->o_out : e->out.p), d_out);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));            // the layout staging goes away with this call
+    return OJPHGPU_OK;
+  });
+}
+
 static int encode_host(ojphgpu_encoder* e, const void* h_image, int container, uint8_t* h_out, size_t cap, size_t* out_len)
 {
   if (!e || !h_image) return OJPHGPU_E_INVALID;

@@ -30,36 +30,39 @@ def assemble(main_header: bytes, tile_parts) -> bytes:
     return b"".join([main_header] + list(tile_parts) + [b"\xff\xd9"])
 
 
-def gather_bytes(payload: bytes, group=None, dst=0, device=None):
-    """Variable-length gather of one byte string per rank to `dst` (None elsewhere).
+def gather_bytes(payload, group=None, dst=0, device=None):
+    """Variable-length gather (gatherv) of one byte string per rank to `dst`: -> (list of per-rank byte strings
+    on `dst`, None elsewhere; the sizes, on every rank).
 
-    Two steps, as the path needs: an all-gather of the lengths (so that every rank knows the
-    prefix-sum offsets), then one gather of fixed-size padded buffers.  Works on gloo (CPU tensors)
-    and on nccl/RCCL (device tensors; pass device)."""
+    payload: bytes, or a uint8 torch tensor (on the device for nccl / RCCL: the tile-parts as
+    Encoder.finish_tiles_device leaves them, so that they travel GPU -> GPU over xGMI without a host round trip).
+    Two steps, as the path needs: an all-gather of the LENGTHS (every rank learns the prefix-sum offsets -- 8 bytes
+    per rank), then only the actual bytes travel, and only to `dst`: point-to-point sends matched by receives of
+    the exact sizes (gatherv to rank 0, not an all-gather of padded buffers)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = device if device is not None else "cpu"
-    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    if isinstance(payload, (bytes, bytearray, memoryview)):
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if len(payload) else torch.zeros(0, dtype=torch.uint8)
+    else:
+        t = payload
+    t = t.to(dev).contiguous()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    if dist.get_backend(group) == "nccl":
-        out = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.all_gather(out, buf, group=group)          # RCCL: all-gather is the robust primitive
-        if rank != dst:
-            return None, sizes
-    else:
-        out = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, out, dst=dst, group=group)
-        if rank != dst:
-            return None, sizes
-    return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)], sizes
+    if rank != dst:
+        if sizes[rank]:
+            dist.send(t, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        return None, sizes
+    bufs = [t if r == rank else torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(world)]
+    reqs = [dist.irecv(bufs[r], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+            for r in range(world) if r != rank and sizes[r]]
+    for q in reqs:
+        q.wait()
+    return [bytes(b.cpu().numpy().tobytes()) for b in bufs], sizes
 
 
 def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None, parts_per_tile=1):

@@ -116,6 +116,15 @@ def test_facade_component_coding_styles(tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_restart_codes_a_sequence():
+    """tests/facade/restart_sequence.cpp: one codestream object restart()ed from frame to frame works through
+    the frame pipelines and writes / reads what fresh objects do, across changes of the frame format"""
+    exe = os.path.join(ROOT, "openjph_amd", "apps", "facade_restart_sequence")
+    r = run([exe])
+    assert r.returncode == 0 and b"all checks passed" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
 def test_cli_raw_planar_12bit_irreversible(tmp_path):
     """the C3 family at a small size: planar .yuv, 12 bit, 9/7, qstep 0.001"""
     from tests import cpu_pipeline as cp

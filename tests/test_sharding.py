@@ -117,3 +117,40 @@ def test_tile_range_encoders_and_decoders_on_gpu(ci):
                 dec.run_device(out)
                 assert dec.failed_blocks() == 0
         assert np.array_equal(out.cpu().numpy(), codec.decode(whole))
+
+
+@pytest.mark.gpu
+def test_tile_parts_assembled_on_the_device_and_gathered_over_rccl():
+    """the RCCL branch on the one GPU of the box: a world_size-1 "nccl" group (RCCL refuses two ranks on one
+    device) runs the length all-gather on the device; the tile-parts assembled in HBM
+    (ojphgpu_encoder_finish_tiles_device) equal the host-assembled ones byte for byte"""
+    import torch
+    import torch.distributed as dist
+    from openjph_amd import codec, shard
+    from openjph_amd.plan import Plan, make_params
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    img = synth_image(1, 300, 500, 16, seed=3)
+    plan = Plan(make_params(500, 300, 1, bit_depth=16, tile=(128, 128), tlm=True))
+    want = codec.Encoder(plan=plan).encode(img)
+    d_img = torch.from_numpy(img).cuda()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        parts, lens = [], []
+        for r in range(3):                                     # three "ranks" share the GPU, one after the other
+            first, count = shard.tile_range(plan.num_tiles, r, 3)
+            e = codec.Encoder(plan=plan, tiles=(first, count))
+            e.run_device(d_img)
+            dpart, ln = e.finish_tiles_device()
+            hpart, ln2 = e.finish_tiles()
+            assert dpart.is_cuda and bytes(dpart.cpu().numpy().tobytes()) == hpart and np.array_equal(ln, ln2)
+            got, sizes = shard.gather_bytes(dpart, device=dev)  # all-gather of lengths over RCCL; no peer to send to
+            assert sizes == [len(hpart)] and got == [hpart]
+            all_l = shard.gather_tile_lengths(ln, plan.num_tiles, first, device=dev, parts_per_tile=plan.parts_per_tile)
+            parts.append(hpart); lens.append(all_l)
+        all_lens = np.sum(np.stack(lens), axis=0).astype(np.uint32)
+        assert shard.assemble(plan.t2_main_header(all_lens), parts) == want
+    finally:
+        dist.destroy_process_group()
