@@ -501,6 +501,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 //     the reference's single buffer) and leave the CU once, as aligned dwords, when the block's
 //     length is known; only blocks that outgrow the stage spill their MagSgn bytes to the HBM
 //     scratch slot.
+#ifndef ABL
+#define ABL 0                           // ablation bits for timing experiments (tools/enc_only.py); 0 in the product
+#endif
 constexpr uint32_t OUT_CAP = 5120;      // bytes of coded output staged in LDS per wavefront
 constexpr int PMS_WORDS = 576;          // 64 lanes * 8 samples * 31 bits + < 257 pending bytes (a window is 256 bytes)
 constexpr int PVLC_WORDS = 80;          // 64 pairs * 30 bits + < 65 pending bytes
@@ -529,14 +532,23 @@ __device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
   return pre | (pl << 8) | (suf << 16) | (sl << 24);
 }
 
+// REV: the quantise transfer of the blocks this instantiation codes (5/3 integer or 9/7 float coefficients) is a
+// compile-time property -- a launch over blocks of both kinds runs both instantiations, each skipping the other's
+template <bool REV>
 __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
     ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
 {
   __shared__ uint16_t s_vlc[2][2048];
+  __shared__ uint32_t s_uvlc[64];                   // U-VLC codewords of u = 0..63 (u <= 31 here), see uvlc_word
   __shared__ NarrowLds s_wave[WAVES];
   for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
+  if (threadIdx.x < 64) s_uvlc[threadIdx.x] = uvlc_word(threadIdx.x);
+#ifdef OCC_PROBE                                    // timing experiment: LDS ballast that lowers the workgroups per CU from 4 to 3
+  __shared__ uint32_t s_pad[3072];
+  if (n == 0xFFFFFFFFu) s_pad[threadIdx.x] = out_cap;
+#endif
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -545,12 +557,12 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
-  if (W > NARROW_MAX_W) return;                                           // ht_encode_wide_kernel's
+  if (W > NARROW_MAX_W || (d.reversible != 0) != REV) return;             // ht_encode_wide_kernel's, or the other instantiation's
   if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
   NarrowLds& L = s_wave[wave];
   uint8_t* outb = reinterpret_cast<uint8_t*>(L.out);
   const uint32_t K = d.K_max, p = 31u - K;      // missing_msbs = K_max - 1, p = 30 - missing_msbs
-  const bool rev = d.reversible != 0;
+  constexpr bool rev = REV;
   const float delta_inv = rev ? 0.0f : __fdiv_rn(1.0f, d.delta);         // ojph_codeblock.cpp:98
   const uint32_t* src = coef + d.coef_off;
   const uint32_t pitch = d.pitch;
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   wave_sync();
 
   // wave-uniform stream state
-  uint32_t ms_pend = 0, ms_k = 0, ms_ff = 0;            // pending bits in L.ms, bytes written, last byte was 0xFF
+  uint32_t ms_pend = 0, ms_base = 0, ms_k = 0, ms_ff = 0;   // pending bits in L.ms and where they start, bytes written, last byte was 0xFF
   uint32_t v_pend = 4, v_pos = 1, v_prev = 0xFF;        // pending bits in L.vlc, bytes "written" (incl. the head), last byte
   MelState mel = { 0, 0, 0, 0, 0, 0, 0 };
   uint32_t err = 0, any_sig = 0;
@@ -603,8 +615,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   // takes four consecutive bytes, speculating that none of the window's bytes is 0xFF; the window is cut
   // behind the first 0xFF (the byte after it carries 7 bits and shifts everything that follows) and the
   // next one starts there.  `flush` also emits the final partial window.  Returns the bit position reached.
-  auto ms_windows = [&](uint32_t T, bool flush) -> uint32_t {
-    uint32_t pos = 0;
+  auto ms_windows = [&](uint32_t base, uint32_t T, bool flush) -> uint32_t {
+    uint32_t pos = base;
     for (;;) {
       const uint32_t first_n = ms_ff ? 7u : 8u;
       if (!flush && pos + first_n + 8u * 255u > T) break;
@@ -703,16 +715,31 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
     const uint32_t qy = 4 * step + r;
     const bool active = pxok && qy < QH;
     const bool first_row = qy == 0;
-    uint32_t t[8];
+    // quantise transfer + 2*mu_p in one go (ojph_codestream_gen.cpp:59-121, ojph_block_encoder.cpp:592-595): the
+    // sign-magnitude word t = sign | magnitude of the reference is never formed, only what the coder takes from it --
+    // val = ((t + t) >> p) & ~1 and the sign t >> 31 -- with the same wrap-around when a magnitude overflows
+    uint32_t val[8], sgn[8], e[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // quad order: n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1)
-      t[2 * k] = to_sign_mag(ntop[k], rev, p, delta_inv);
-      t[2 * k + 1] = to_sign_mag(nbot[k], rev, p, delta_inv);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t raw = j ? nbot[k] : ntop[k];
+        uint32_t mag, sg;
+        if (rev) {
+          const int v = (int)raw;
+          mag = (uint32_t)(v >= 0 ? v : -v) << p;                              // :70-76
+          sg = (raw >> 31) | (mag >> 31);
+        } else {
+          const int tq = (int)__fmul_rn(__uint_as_float(raw), delta_inv);      // :113-118, C truncation
+          mag = (uint32_t)(tq >= 0 ? tq : -tq);
+          sg = (uint32_t)tq >> 31;
+        }
+        val[2 * k + j] = ((mag << 1) >> p) & ~1u; sgn[2 * k + j] = sg;
+      }
     }
     if (step + 1 < nsteps) load_rows(qy + 4, ntop, nbot);   // request the next step's samples now
-    uint32_t val[8], e[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { val[i] = ((t[i] + t[i]) >> p) & ~1u; e[i] = expo(val[i]); }   // 2*mu_p (:592-595)
+    for (int i = 0; i < 8; ++i) e[i] = expo(val[i]);
     // ---- the row above: exponents / significance of its samples, columns x0-1 .. x0+4 ----
     uint32_t botpack = 0;
 #pragma unroll
@@ -760,10 +787,10 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) {
         const int i = q * 4 + nn;
-        const uint32_t m = ((rho_q[q] >> nn) & 1u) ? U - ((tuple >> nn) & 1u) : 0u;          // :667-674
-        const uint32_t sv = val[i] - 2u + (t[i] >> 31);                                     // v_n = 2(mu-1)+sign (:601)
+        const uint32_t m = (U - ((tuple >> nn) & 1u)) & (0u - ((rho_q[q] >> nn) & 1u));      // :667-674; U <= 31
+        const uint32_t sv = val[i] - 2u + sgn[i];                                           // v_n = 2(mu-1)+sign (:601)
         msl[i] = m;
-        msv[i] = m ? (sv & ((m >= 32 ? 0u : (1u << m)) - 1u)) : 0u;
+        msv[i] = __builtin_amdgcn_ubfe(sv, 0u, m);                                          // the low m bits (none when m = 0)
       }
     }
     any_sig |= (__ballot((rho_q[0] | rho_q[1]) != 0) != 0ull) ? 1u : 0u;
@@ -779,8 +806,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
       const bool both_big = first_row && u0 > 2 && u1 > 2;                                   // :766-772
       const bool one_big = first_row && !both_big && u0 > 2 && u1 > 0;                       // :773-778
       ev2_valid = first_row && u0 > 0 && u1 > 0; ev2_bit = min(u0, u1) > 2;                   // :763-764
-      const uint32_t w0 = uvlc_word(both_big ? u0 - 2u : u0);
-      uint32_t w1 = uvlc_word(both_big ? u1 - 2u : u1);
+      const uint32_t w0 = s_uvlc[both_big ? u0 - 2u : u0];
+      uint32_t w1 = s_uvlc[both_big ? u1 - 2u : u1];
       if (one_big) w1 = (u1 - 1u) | (1u << 8);          // u1 in {1,2} is a single bit, no suffix
       vb |= (w0 & 0xFFu) << vl; vl += (w0 >> 8) & 0xFFu;                                     // prefix q0, prefix q1,
       vb |= (w1 & 0xFFu) << vl; vl += (w1 >> 8) & 0xFFu;                                     // suffix q0, suffix q1 (:779-785, :985-988)
@@ -789,8 +816,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
       if (!active) { vb = 0; vl = 0; ev2_valid = false; }
     }
 
+    if (ABL & 32) { any_sig |= (uint32_t)(__ballot((vb ^ msv[0] ^ msv[7] ^ msl[3] ^ cq[1]) == 0x12345u) != 0ull); continue; }
     // ---- MEL events of the pair, compacted in pair order, then run through the adaptive coder ----
-    {
+    if (!(ABL & 4)) {
       const bool ev0_valid = active && cq[0] == 0, ev1_valid = has_q1 && active && cq[1] == 0;
       const uint32_t ev0_bit = rho_q[0] != 0, ev1_bit = rho_q[1] != 0;
       const uint32_t cnt = (uint32_t)ev0_valid + (uint32_t)ev1_valid + (uint32_t)ev2_valid;
@@ -825,16 +853,29 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) tot += msl[i];
       const uint32_t incl = wave_incl_scan(tot, lane);
-      const uint32_t T = ms_pend + rdlane(incl, 63);
-      uint32_t at = ms_pend + incl - tot;
+      const uint32_t step_bits = rdlane(incl, 63);
+      // the pending bits live at [ms_base, ms_base + ms_pend) of the buffer; they only move to its front (and the
+      // buffer is cleared) when this step's bits would not fit behind them -- every third or fourth step on
+      // typical content instead of every step
+      if (ms_base + ms_pend + step_bits + 64u > 32u * (uint32_t)PMS_WORDS) {
+        ms_pend = compact(L.ms, ms_base, ms_base + ms_pend, PMS_WORDS);
+        ms_base = 0;
+      }
+      const uint32_t T = ms_base + ms_pend + step_bits;
+      uint32_t at = ms_base + ms_pend + incl - tot;
+      if (!(ABL & 1)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) { or_bits(L.ms, at, msv[i], msl[i]); at += msl[i]; }
+      }
       wave_sync();
-      const uint32_t pos = ms_windows(T, false);
-      ms_pend = compact(L.ms, pos, T, PMS_WORDS);
+      if (ABL & 2) { ms_base = 0; ms_pend = T & 7u; }
+      else {
+      const uint32_t pos = ms_windows(ms_base, T, false);
+      ms_base = pos; ms_pend = T - pos;
+      }
     }
     // ---- VLC ----
-    {
+    if (!(ABL & 8)) {
       const uint32_t incl = wave_incl_scan(vl, lane);
       const uint32_t T = v_pend + rdlane(incl, 63);
       or_bits(L.vlc, v_pend + incl - vl, vb, vl);
@@ -847,8 +888,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
   // ---- final flush of both bit buffers: what remains is < 8 bits each ----
   uint32_t ms_carry = 0, v_carry = 0;
   if (!err) {
-    uint32_t pos = ms_windows(ms_pend, true);
-    ms_carry = compact(L.ms, pos, ms_pend, PMS_WORDS);
+    uint32_t pos = ms_windows(ms_base, ms_base + ms_pend, true);
+    ms_carry = compact(L.ms, pos, ms_base + ms_pend, PMS_WORDS);
     pos = vlc_windows(v_pend, true);
     v_carry = compact(L.vlc, pos, v_pend, PVLC_WORDS);
   }
@@ -947,8 +988,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
 }  // namespace
 
 namespace ojphgpu {
-// `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones.  Every
-// kernel skips the blocks of the other kind, so a caller that does not know passes 3.
+// `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones; bit 2 = it holds
+// blocks of reversibly transformed components, bit 3 = of irreversibly transformed ones.  Every kernel skips the
+// blocks of the other kind, so a caller that does not know passes 3 (wavelet bits clear = both).
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
                      int widths)
@@ -957,8 +999,12 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
   dim3 grid((n + WAVES - 1) / WAVES);
-  if (widths & 1)
-    hipLaunchKernelGGL(ht_encode_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+  if ((widths & 12) == 0) widths |= 12;                   // the caller does not know the wavelets: both instantiations
+  if ((widths & 1) && (widths & 4))
+    hipLaunchKernelGGL(ht_encode_kernel<true>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+  if ((widths & 1) && (widths & 8))
+    hipLaunchKernelGGL(ht_encode_kernel<false>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
   if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,

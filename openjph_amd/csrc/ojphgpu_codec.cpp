@@ -133,7 +133,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     d.missing_msbs = (uint8_t)(B.K_max - 1); d.num_passes = 1; d.delta = B.delta;
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
-    (i < e->n_top ? e->widths_top : e->widths_rest) |= k.r.w > 64 ? 2 : 1;
+    (i < e->n_top ? e->widths_top : e->widths_rest) |= (k.r.w > 64 ? 2 : 1) | (d.reversible ? 4 : 8);   // which kernel variants the range needs
   }
   if (nframes > 1) {                                      // replicate the block descriptors, frame-major
     const size_t nb = bd.size();

@@ -269,7 +269,7 @@ struct ojphgpu_encoder {
   // the samples) only need the first DWT level, so they are coded on a second stream while the
   // small, latency-bound launches of levels 2..L run on the main one
   uint32_t n_top = 0;                              // descriptors [0, n_top) = blocks of the top resolution
-  int widths_top = 0, widths_rest = 0;             // which block encoder kernels each range needs (bit 0 narrow, bit 1 wide)
+  int widths_top = 0, widths_rest = 0;             // which block encoder kernels each range needs (bit 0 narrow, bit 1 wide, bit 2 reversible, bit 3 irreversible)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // where a run writes its products: the object's own buffers (null), or -- for a frame pipeline that keeps
