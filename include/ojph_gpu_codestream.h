@@ -13,12 +13,14 @@
 // first pull() (decode).  Errors are reported as the reference reports OJPH_ERROR:
 // std::runtime_error("ojph error") after the message went to stderr.
 //
-// Not every knob of the reference exists behind the GPU path: all
-// no per-component COD / step-size overrides (COC, set_irrev_quant(comp, ..)), no 64-bit samples,
-// no Part-2 wavelets.  Sub-sampling, components of different bit depth / signedness, image and
-// tile offsets, tile-part divisions, user COM markers, qfactor, the IMF / BROADCAST profile checks
-// and reduced-resolution decoding are supported.  What is not fails loudly in write_headers() /
-// read_headers() / the setter.
+// What the GPU path does not implement fails loudly in write_headers() /
+// read_headers() / the setter: the 64-bit sample path (bit depths above 26) and the Part-2 wavelets
+// (DFS / ATK).  Supported: per-component coding styles (COC: param_cod's comp_idx setters), per-component
+// quantisation (QCC: set_qfactor(comp, ..), set_irrev_quant(comp, ..)), NLT type 3, sub-sampling, components
+// of different bit depth / signedness, image and tile offsets, tile-part divisions, user COM markers,
+// qfactor, the IMF / BROADCAST profile checks, reduced-resolution and resilient decoding.
+// A restart()ed object codes a sequence of frames through a frame pipeline that outlives restart()
+// (pinned frame / codestream buffers, device objects made once per frame format).
 #ifndef OJPH_GPU_CODESTREAM_H
 #define OJPH_GPU_CODESTREAM_H
 

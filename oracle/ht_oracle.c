@@ -7,8 +7,10 @@
  * the quad pair -- not the image line -- is the unit of work, because that is the shape the
  * one-wavefront-per-code-block HIP kernels use.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function here against the
- * real reference compiled from /root/reference (oracle/_ref/libojph_ref*.so).
+ * Parity status: PINNED.  tests/test_cpu_parity.py checks every function here against the real
+ * reference compiled from /root/reference (oracle/_ref/libojph_ref*.so, oracle/Makefile) and against
+ * the golden vectors made from it (tests/golden/); tests/test_survey_ka.py pins the survey's
+ * whole-image known answers KA-3 / KA-4.
  */
 #include "ht_oracle.h"
 #include <stdlib.h>
