@@ -79,10 +79,10 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
                     help="independent frames coded per step as one batch (default 1; 8 for the c5 batch workload)")
-    ap.add_argument("--container", type=int, default=16, choices=(16, 32),
-                    help="bits of the sample containers of the frames in HBM: 16 = int16 / uint16 planes (how 8..16-bit frames "
-                         "exist in files and capture buffers; the default), 32 = int32 planes (what the reference's line_buf "
-                         "exchanges line by line)")
+    ap.add_argument("--container", type=int, default=16, choices=(8, 16, 32),
+                    help="bits of the sample containers of the frames in HBM: 16 = int16 / uint16 planes (how 9..16-bit frames "
+                         "exist in files and capture buffers; the default), 8 = int8 / uint8 planes (8-bit frames), 32 = int32 planes "
+                         "(what the reference's line_buf exchanges line by line)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: the frame being encoded and the frame being decoded are issued on two HIP streams")
     ap.add_argument("--e2e-frames", type=int, default=48,
@@ -128,7 +128,7 @@ def main():
     else:
         img = workload_image(args.workload, 0 if plan_is_tiled(tile) else rank)
     def to_dev(a):                               # the frame as it sits in HBM
-        return torch.from_numpy(a.astype(np.int16) if args.container == 16 else a).to(dev)
+        return torch.from_numpy(a.astype({8: np.int8, 16: np.int16}[args.container]) if args.container != 32 else a).to(dev)
     d_img = to_dev(img)
     params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
     from openjph_amd.plan import Plan
@@ -272,9 +272,9 @@ def main():
         del kernels["ht_encode"]
         kernels["ht_encode[top resolution, side stream]"] = (4.0 * area[top].sum() + coded[top].sum(), te["ht_launches_ms"][0])
         kernels["ht_encode[lower resolutions]"] = (4.0 * area[~top].sum() + coded[~top].sum(), te["ht_launches_ms"][1])
-    if ct or levels == 0:                        # otherwise the conversion is fused into the top DWT level
-        kernels["convert_forward"] = (8.0 * ns, te["convert_ms"])
-        kernels["convert_inverse"] = (8.0 * ns, td["convert_ms"])
+    if te["convert_ms"] > 0 or td["convert_ms"] > 0:   # otherwise the conversion (and the colour transform) is fused into the top DWT level
+        kernels["convert_forward"] = ((4.0 + args.container / 8.0) * ns, te["convert_ms"])
+        kernels["convert_inverse"] = ((4.0 + args.container / 8.0) * ns, td["convert_ms"])
     kinfo = {}
     for k, (b, ms) in kernels.items():
         kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}

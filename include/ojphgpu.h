@@ -241,6 +241,16 @@ int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_
 int ojphgpu_dwt_forward_image(void* stream, const ojphgpu_params* params,
                               const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w,
                               uint32_t max_h, const int32_t* d_image, void* d_base);
+/* the general form of the four calls around it: container_bits = 32 | 16 | 8 (two's complement for signed
+ * components, else the full unsigned range of the container; bit depths up to the container's width, 31 for
+ * 32).  colour != 0: the descriptors come in triples -- the planes of the three colour components of a tile,
+ * which share their geometry -- and the component transform (RCT for the 5/3, ICT for the 9/7:
+ * gen_rct_forward / _backward, gen_ict_forward / _backward, ojph_colour.cpp:443-571) is applied in the same
+ * loads / stores, so that a colour-transformed frame needs no conversion pass over HBM either. */
+int ojphgpu_dwt_forward_image_ex(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                                 uint32_t max_w, uint32_t max_h, const void* d_image, void* d_base, int container_bits, int colour);
+int ojphgpu_dwt_inverse_image_ex(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                                 uint32_t max_w, uint32_t max_h, void* d_image, void* d_base, int container_bits, int colour);
 /* the same with the image samples in 16-bit containers: int16 (two's complement) for signed
  * components, uint16 otherwise; bit depths up to 16.  Halves the HBM traffic of the image side of
  * the top level (and the PCIe traffic of whoever fills / drains the image buffer). */
@@ -346,6 +356,11 @@ int ojphgpu_convert_forward(void* stream, const ojphgpu_params* params,
 int ojphgpu_convert_inverse(void* stream, const ojphgpu_params* params,
                             const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
                             uint32_t max_w, uint32_t max_h, int32_t* d_image, const void* d_arena);
+/* container_bits = 32 | 16 | 8 */
+int ojphgpu_convert_forward_ex(void* stream, const ojphgpu_params* params, const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                               uint32_t max_w, uint32_t max_h, const void* d_image, void* d_arena, int container_bits);
+int ojphgpu_convert_inverse_ex(void* stream, const ojphgpu_params* params, const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
+                               uint32_t max_w, uint32_t max_h, void* d_image, const void* d_arena, int container_bits);
 /* 16-bit sample containers (see ojphgpu_dwt_forward_image16) */
 int ojphgpu_convert_forward16(void* stream, const ojphgpu_params* params,
                               const ojphgpu_convert_desc* d_descs, uint32_t n_tiles,
@@ -389,6 +404,9 @@ int  ojphgpu_encoder_run_device(ojphgpu_encoder* enc, const int32_t* d_image);
 /* the frame in 16-bit containers (same plane layout, 2-byte elements; int16 for signed components,
  * uint16 otherwise; every component at most 16 bits deep) */
 int  ojphgpu_encoder_run_device16(ojphgpu_encoder* enc, const uint16_t* d_image);
+/* 8-bit containers (int8 for signed components, uint8 otherwise; every component at most 8 bits deep): how 8-bit
+ * frames exist in files and capture buffers -- a quarter of the upload of int32 samples */
+int  ojphgpu_encoder_run_device8(ojphgpu_encoder* enc, const uint8_t* d_image);
 int  ojphgpu_encode16(ojphgpu_encoder* enc, const uint16_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len);
 /* D2H of block bytes + lengths, then host Tier-2 -> complete codestream */
 int  ojphgpu_encoder_finish(ojphgpu_encoder* enc, uint8_t* h_out, size_t cap, size_t* out_len);
@@ -416,6 +434,7 @@ int  ojphgpu_decoder_upload(ojphgpu_decoder* dec, const uint8_t* h_codestream, s
 /* device part only: coded bytes in HBM -> d_image (int32 planes) */
 int  ojphgpu_decoder_run_device(ojphgpu_decoder* dec, int32_t* d_image);
 int  ojphgpu_decoder_run_device16(ojphgpu_decoder* dec, uint16_t* d_image);     /* 16-bit containers */
+int  ojphgpu_decoder_run_device8(ojphgpu_decoder* dec, uint8_t* d_image);       /* 8-bit containers */
 int  ojphgpu_decode16(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len, uint16_t* h_image);
 /* number of code-blocks that failed to decode in the last run (synchronises) */
 int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
@@ -451,7 +470,7 @@ int  ojphgpu_decoder_level_timing(ojphgpu_decoder* dec, float* out, uint32_t cap
  *    (:769-1146, :1227-1270).  The pipe keeps that contract per frame -- the caller writes samples into
  *    memory the library hands out and receives a finished codestream, or the other way round -- and
  *    keeps `depth` (2..16) frames in flight.  One caller thread per pipe; results come back in
- *    submission order.  container_bits = 16 | 32 (see ojphgpu_encoder_run_device16); host_threads =
+ *    submission order.  container_bits = 8 | 16 | 32 (see ojphgpu_encoder_run_device16 / 8); host_threads =
  *    threads that do a frame's host part (packet headers / parsing), 0 = 2.
  * ------------------------------------------------------------------------------------------ */
 typedef struct ojphgpu_enc_pipe ojphgpu_enc_pipe;

@@ -126,6 +126,16 @@ SIGNATURES = {
     "ojphgpu_convert_inverse16": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p]),
     "ojphgpu_encoder_run_device16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ojphgpu_encoder_run_device8": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ojphgpu_decoder_run_device8": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ojphgpu_dwt_forward_image_ex": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "ojphgpu_dwt_inverse_image_ex": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "ojphgpu_convert_forward_ex": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_int]),
+    "ojphgpu_convert_inverse_ex": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_int]),
     "ojphgpu_encode16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ojphgpu_decoder_run_device16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_decode16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -79,6 +79,9 @@ class Encoder:
         if d_image.dtype in (torch.int16, torch.uint16):     # 16-bit containers: int16 for signed components, else uint16
             check(self._lib.ojphgpu_encoder_run_device16(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device16")
             return
+        if d_image.dtype in (torch.int8, torch.uint8):       # 8-bit containers
+            check(self._lib.ojphgpu_encoder_run_device8(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device8")
+            return
         assert d_image.dtype == torch.int32
         check(self._lib.ojphgpu_encoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "encoder_run_device")
 
@@ -143,6 +146,8 @@ class Encoder:
         if isinstance(image, np.ndarray):
             if image.dtype in (np.int16, np.uint16):         # stays 16 bits wide on its way to and in HBM
                 image = torch.from_numpy(np.ascontiguousarray(image).view(np.int16)).to("cuda:%d" % self.device)
+            elif image.dtype in (np.int8, np.uint8):         # ... or 8
+                image = torch.from_numpy(np.ascontiguousarray(image).view(np.int8)).to("cuda:%d" % self.device)
             else:
                 image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32)).to("cuda:%d" % self.device)
         self.run_device(image)
@@ -217,13 +222,15 @@ class Decoder:
         _torch().cuda.synchronize(self.device)   # the host buffer may go away after this call
 
     def run_device(self, d_image=None, dtype=None):
-        """dtype / d_image.dtype torch.int16 or torch.uint16: samples in 16-bit containers"""
+        """dtype / d_image.dtype torch.int16 / uint16 or torch.int8 / uint8: samples in 16- / 8-bit containers"""
         torch = _torch()
         if d_image is None:
             alloc = torch.empty if self.tiles == (0, self.plan.num_tiles) else torch.zeros
             d_image = alloc(self.shape, dtype=dtype or torch.int32, device="cuda:%d" % self.device)
         if d_image.dtype in (torch.int16, torch.uint16):
             check(self._lib.ojphgpu_decoder_run_device16(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device16")
+        elif d_image.dtype in (torch.int8, torch.uint8):
+            check(self._lib.ojphgpu_decoder_run_device8(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device8")
         else:
             check(self._lib.ojphgpu_decoder_run_device(self._h, C.c_void_p(d_image.data_ptr())), "decoder_run_device")
         return d_image

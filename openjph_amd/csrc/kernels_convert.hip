@@ -59,10 +59,11 @@ __device__ __forceinline__ int nlt3_map(int v, const ConvParams& p)
   return (p.nlt3 && v < 0) ? -v - (int)((1u << (p.bit_depth - 1)) + 1u) : v;
 }
 
-// S: container of the image samples -- int (32-bit) or short (16-bit: two's complement for signed
-// components, the full unsigned range otherwise)
+// S: container of the image samples -- int (32-bit), short (16-bit) or signed char (8-bit): two's complement for
+// signed components, the full unsigned range of the container otherwise
 template <typename S> __device__ __forceinline__ int sample_in(S v, const ConvParams&) { return (int)v; }
 template <> __device__ __forceinline__ int sample_in<short>(short v, const ConvParams& p) { return p.is_signed ? (int)v : (int)(unsigned short)v; }
+template <> __device__ __forceinline__ int sample_in<signed char>(signed char v, const ConvParams& p) { return p.is_signed ? (int)v : (int)(unsigned char)v; }
 
 template <typename S>
 __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
@@ -108,6 +109,13 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   }
 }
 
+// a narrower container saturates at its own range (see fit_container in kernels_dwt.hip)
+template <typename S> __device__ __forceinline__ S sample_out(int v, const ConvParams&) { return (S)v; }
+template <> __device__ __forceinline__ short sample_out<short>(int v, const ConvParams& p)
+{ return (short)(p.is_signed ? min(max(v, -32768), 32767) : min(max(v, 0), 65535)); }
+template <> __device__ __forceinline__ signed char sample_out<signed char>(int v, const ConvParams& p)
+{ return (signed char)(p.is_signed ? min(max(v, -128), 127) : min(max(v, 0), 255)); }
+
 template <typename S>
 __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, const ojphgpu_convert_desc* __restrict__ descs,
                                                               S* __restrict__ image, const uint32_t* __restrict__ arena)
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
-      image[at(d0)] = (S)nlt3_map(cr + g + shift, p); image[at(d1)] = (S)nlt3_map(g + shift, p); image[at(d2)] = (S)nlt3_map(cb + g + shift, p);
+      image[at(d0)] = sample_out<S>(nlt3_map(cr + g + shift, p), p); image[at(d1)] = sample_out<S>(nlt3_map(g + shift, p), p); image[at(d2)] = sample_out<S>(nlt3_map(cb + g + shift, p), p);
     } else {
       const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
       const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
       float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
-      image[at(d0)] = (S)nlt3_map(to_int(r, p), p); image[at(d1)] = (S)nlt3_map(to_int(g, p), p); image[at(d2)] = (S)nlt3_map(to_int(bb, p), p);
+      image[at(d0)] = sample_out<S>(nlt3_map(to_int(r, p), p), p); image[at(d1)] = sample_out<S>(nlt3_map(to_int(g, p), p), p); image[at(d2)] = sample_out<S>(nlt3_map(to_int(bb, p), p), p);
     }
   }
   for (uint32_t c = c_first; c < nc; ++c) {
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
     int v;
     if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
     else v = to_int(__uint_as_float(a), p);
-    image[at(d)] = (S)nlt3_map(v, p);
+    image[at(d)] = sample_out<S>(nlt3_map(v, p), p);
   }
 }
 
@@ -209,5 +217,34 @@ extern "C" int ojphgpu_convert_inverse16(void* stream, const ojphgpu_params* par
   dim3 grid((max_w + 255) / 256, max_h, n_tiles);
   hipLaunchKernelGGL(convert_inverse_kernel<short>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
                      (short*)d_image, (const uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+// the general form: container_bits = 32 | 16 | 8
+extern "C" int ojphgpu_convert_forward_ex(void* stream, const ojphgpu_params* params, const ojphgpu_convert_desc* d_descs,
+                                           uint32_t n_tiles, uint32_t max_w, uint32_t max_h, const void* d_image, void* d_arena,
+                                           int container_bits)
+{
+  if (container_bits == 32) return ojphgpu_convert_forward(stream, params, d_descs, n_tiles, max_w, max_h, (const int32_t*)d_image, d_arena);
+  if (container_bits == 16) return ojphgpu_convert_forward16(stream, params, d_descs, n_tiles, max_w, max_h, (const uint16_t*)d_image, d_arena);
+  if (container_bits != 8 || !params || !d_descs || !d_image || !d_arena || params->bit_depth > 8) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_forward_kernel<signed char>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     (const signed char*)d_image, (uint32_t*)d_arena);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+extern "C" int ojphgpu_convert_inverse_ex(void* stream, const ojphgpu_params* params, const ojphgpu_convert_desc* d_descs,
+                                           uint32_t n_tiles, uint32_t max_w, uint32_t max_h, void* d_image, const void* d_arena,
+                                           int container_bits)
+{
+  if (container_bits == 32) return ojphgpu_convert_inverse(stream, params, d_descs, n_tiles, max_w, max_h, (int32_t*)d_image, d_arena);
+  if (container_bits == 16) return ojphgpu_convert_inverse16(stream, params, d_descs, n_tiles, max_w, max_h, (uint16_t*)d_image, d_arena);
+  if (container_bits != 8 || !params || !d_descs || !d_image || !d_arena || params->bit_depth > 8) return OJPHGPU_E_INVALID;
+  if (n_tiles == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  dim3 grid((max_w + 255) / 256, max_h, n_tiles);
+  hipLaunchKernelGGL(convert_inverse_kernel<signed char>, grid, dim3(256), 0, (hipStream_t)stream, make(params), d_descs,
+                     (signed char*)d_image, (const uint32_t*)d_arena);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }

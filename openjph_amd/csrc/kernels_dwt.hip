@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <cstdlib>
 #include "../../include/ojphgpu.h"
 
 namespace {
@@ -192,10 +193,11 @@ template <> struct Cv<false> {
 template <typename E> struct Vec2 { typedef E type __attribute__((ext_vector_type(2), aligned(sizeof(E) < 4 ? sizeof(E) : 4))); };
 
 // element type of the plane a kernel variant reads / writes: IMG = 0 the arena (T), 32 an int32
-// image, 16 a 16-bit image (two's complement for signed components, else unsigned)
+// image, 16 / 8 a 16- / 8-bit image (two's complement for signed components, else unsigned)
 template <int IMG, typename T> struct ImgElem { typedef T type; };
 template <typename T> struct ImgElem<32, T> { typedef int type; };
 template <typename T> struct ImgElem<16, T> { typedef short type; };
+template <typename T> struct ImgElem<8, T> { typedef signed char type; };
 
 // Row loads are UNCONDITIONAL: every lane fetches two adjacent samples from a column clamped into
 // the row (and the callers clamp the row into the plane), and what a lane fetched is interpreted
@@ -213,18 +215,62 @@ __device__ __forceinline__ Raw<E> load_raw(const void* __restrict__ rowp, const 
   return r;
 }
 
-// IMG: the row came from an int32 image plane and is converted here
+// the integer sample a raw container element holds
+template <int IMG, typename E>
+__device__ __forceinline__ int sample_of(E v, const Conv& cv)
+{
+  if (IMG == 16) return cv.is_signed ? (int)v : (int)(unsigned short)v;     // unsigned components occupy the full container
+  if (IMG == 8) return cv.is_signed ? (int)v : (int)(unsigned char)v;
+  return (int)v;
+}
+
+// IMG: the row came from an image plane and is converted here
 template <bool REV, int IMG, typename E>
 __device__ __forceinline__ Pair<typename Wv<REV>::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
 {
   Pair<typename Wv<REV>::T> p;
   const auto a = g.from_y ? v.y : v.x, b = g.from_x ? v.x : v.y;
-  if (IMG == 16) {                               // unsigned components occupy the full 16 bits
-    const int ia = cv.is_signed ? (int)a : (int)(unsigned short)a, ib = cv.is_signed ? (int)b : (int)(unsigned short)b;
-    p.l = Cv<REV>::from_image(ia, cv); p.h = Cv<REV>::from_image(ib, cv);
-  } else if (IMG) { p.l = Cv<REV>::from_image((int)a, cv); p.h = Cv<REV>::from_image((int)b, cv); }
+  if (IMG) { p.l = Cv<REV>::from_image(sample_of<IMG>(a, cv), cv); p.h = Cv<REV>::from_image(sample_of<IMG>(b, cv), cv); }
   else { p.l = (typename Wv<REV>::T)a; p.h = (typename Wv<REV>::T)b; }
   return p;
+}
+
+// Forward / inverse component transform of one sample triple (ojph_colour.cpp:443-571: gen_rct_forward /
+// _backward, gen_ict_forward / _backward), on values that went through from_image / are about to go through
+// to_image -- the same operations in the same order as the stand-alone conversion kernels (kernels_convert.hip)
+constexpr float CT_ALPHA_RF = 0.299f, CT_ALPHA_GF = 0.587f, CT_ALPHA_BF = 0.114f;
+template <bool REV> struct Ct;
+template <> struct Ct<true> {
+  static __device__ __forceinline__ void fwd(int r, int g, int b, int& y, int& cb, int& cr) { y = (r + (g << 1) + b) >> 2; cb = b - g; cr = r - g; }
+  static __device__ __forceinline__ void inv(int y, int cb, int cr, int& r, int& g, int& b) { g = y - ((cb + cr) >> 2); r = cr + g; b = cb + g; }
+};
+template <> struct Ct<false> {
+  static __device__ __forceinline__ void fwd(float r, float g, float b, float& y, float& cb, float& cr) {
+    const float beta_cb = (float)(0.5 / (1 - (double)CT_ALPHA_BF)), beta_cr = (float)(0.5 / (1 - (double)CT_ALPHA_RF));
+    y = __fadd_rn(__fadd_rn(__fmul_rn(CT_ALPHA_RF, r), __fmul_rn(CT_ALPHA_GF, g)), __fmul_rn(CT_ALPHA_BF, b));
+    cb = __fmul_rn(beta_cb, __fsub_rn(b, y)); cr = __fmul_rn(beta_cr, __fsub_rn(r, y));
+  }
+  static __device__ __forceinline__ void inv(float y, float cb, float cr, float& r, float& g, float& b) {
+    const float g_cb2g = (float)(2.0 * (double)CT_ALPHA_BF * (1.0 - (double)CT_ALPHA_BF) / (double)CT_ALPHA_GF);
+    const float g_cr2g = (float)(2.0 * (double)CT_ALPHA_RF * (1.0 - (double)CT_ALPHA_RF) / (double)CT_ALPHA_GF);
+    const float g_cb2b = (float)(2.0 * (1.0 - (double)CT_ALPHA_BF)), g_cr2r = (float)(2.0 * (1.0 - (double)CT_ALPHA_RF));
+    g = __fsub_rn(__fsub_rn(y, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
+    r = __fadd_rn(y, __fmul_rn(g_cr2r, cr));
+    b = __fadd_rn(y, __fmul_rn(g_cb2b, cb));
+  }
+};
+
+// NC = 3: the rows of the three colour planes become the rows of Y, Cb, Cr
+template <bool REV, int IMG, int NC, typename E>
+__device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const Conv& cv, Pair<typename Wv<REV>::T>* out)
+{
+#pragma unroll
+  for (int k = 0; k < NC; ++k) out[k] = unpack<REV, IMG>(v[k], g, cv);
+  if (NC == 3) {
+    const Pair<typename Wv<REV>::T> r = out[0], gg = out[1], b = out[2];
+    Ct<REV>::fwd(r.l, gg.l, b.l, out[0].l, out[1].l, out[2].l);
+    Ct<REV>::fwd(r.h, gg.h, b.h, out[0].h, out[1].h, out[2].h);
+  }
 }
 
 // Memory order inside one iteration of the forward kernel: consume what the previous iteration fetched,
@@ -239,11 +285,19 @@ __device__ __forceinline__ void arrived(const A& a, const A& b, const A& c, cons
 {
   asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d));
 }
+__device__ __forceinline__ void arrived(const signed char& a, const signed char& b, const signed char& c, const signed char& d)
+{
+  asm volatile("" :: "v"((short)a), "v"((short)b), "v"((short)c), "v"((short)d));   // no 8-bit register class
+}
 
 // ---------------------------------------------------------------------------------------------
 // forward: plane (or image plane, IMG) -> LL, HL, LH, HH
 // ---------------------------------------------------------------------------------------------
-template <bool REV, int IMG>
+// NC = 1: one plane per wavefront strip.  NC = 3: the three colour planes of a tile at once -- the rows of R, G, B
+// are read once, turned into Y, Cb, Cr rows in registers (RCT / ICT) and run through three vertical pipelines, so a
+// colour-transformed frame needs no conversion pass over HBM (descs[3 z .. 3 z + 2] = the planes' descriptors, which
+// share their geometry).
+template <bool REV, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           typename Wv<REV>::T* __restrict__ base,
                                                           const void* __restrict__ image, Conv cv, int row_pairs)
@@ -255,7 +309,7 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
   // block-coder launch of the side stream, its wavefronts go first
   __builtin_amdgcn_s_setprio(2);
-  const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
   if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -268,18 +322,25 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   if (i0 >= npy) return;
   const int i1 = min(i0 + row_pairs, npy);
 
-  const char* src = IMG ? (const char*)image + d.src_off * sizeof(E) : (const char*)(base + d.src_off);
+  const char* src[NC]; T* ll[NC]; T* hl[NC]; T* lh[NC]; T* hh[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
+    src[k] = IMG ? (const char*)image + dk.src_off * sizeof(E) : (const char*)(base + dk.src_off);
+    ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
+  }
   const size_t sp = (size_t)d.src_pitch * sizeof(E);
-  T* ll = base + d.ll_off; T* hl = base + d.hl_off; T* lh = base + d.lh_off; T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  auto ldrow = [&](int y) {                                // image row y, clamped into the plane
-    return load_raw<E>(src + (size_t)min(max(y, 0), h - 1) * sp, g);
+  auto ldrow = [&](int y, RawRow* r) {                     // image row y of every plane, clamped into the plane
+    const size_t o = (size_t)min(max(y, 0), h - 1) * sp;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) r[k] = load_raw<E>(src[k] + o, g);
   };
-  auto put = [&](int t, bool low_row, T vl, T vh) {        // one transformed row -> its two sub-bands
+  auto put = [&](int k, int t, bool low_row, T vl, T vh) {   // one transformed row of plane k -> its two sub-bands
     if (!g.store) return;
-    T* lo = low_row ? ll : lh; T* hi = low_row ? hl : hh;
+    T* lo = low_row ? ll[k] : lh[k]; T* hi = low_row ? hl[k] : hh[k];
     const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
     const int r = low_row ? t - oy : t;                    // row index inside the sub-band
     if (g.eL) lo[(size_t)r * lop + (g.j - g.ox)] = vl;
@@ -288,76 +349,127 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 
   if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
     if (i0 > 0) return;
-    Pair<T> x = unpack<REV, IMG>(ldrow(0), g, cv);
-    if (oy != 0) { x.l = W::dbl(x.l); x.h = W::dbl(x.h); }
-    horz_analysis<REV>(x.l, x.h, g);
-    put(0, oy == 0, x.l, x.h);
+    RawRow r0[NC]; Pair<T> x[NC];
+    ldrow(0, r0);
+    unpack_all<REV, IMG, NC>(r0, g, cv, x);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (oy != 0) { x[k].l = W::dbl(x[k].l); x[k].h = W::dbl(x[k].h); }
+      horz_analysis<REV>(x[k].l, x[k].h, g);
+      put(k, 0, oy == 0, x[k].l, x[k].h);
+    }
     return;
   }
 
   // vertical software pipeline over row pairs t; see file header
   const int t0 = max(i0 - (REV ? 1 : 2), 0);
-  Pair<T> xl, xn, a, ap, b, bp, c, cp;   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
-  xl.l = xl.h = 0; a = ap = b = bp = c = cp = xl;
-  Pair<T> out_lo = xl, out_hi = xl;      // transformed rows of pair out_t, stored one iteration later
+  Pair<T> xl[NC], xn[NC], a[NC], ap[NC], b[NC], bp[NC], c[NC], cp[NC];   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
+  Pair<T> out_lo[NC], out_hi[NC];        // transformed rows of pair out_t, stored one iteration later
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { xl[k].l = xl[k].h = 0; a[k] = ap[k] = b[k] = bp[k] = c[k] = cp[k] = out_lo[k] = out_hi[k] = xl[k]; }
   int out_t = 0; bool has_lo = false, has_hi = false;
-  xl = unpack<REV, IMG>(ldrow(2 * t0 - oy), g, cv);
-  RawRow rh = ldrow(2 * t0 + 1 - oy), rn = ldrow(2 * t0 + 2 - oy);            // rows of iteration t0
+  RawRow rh[NC], rn[NC];
+  ldrow(2 * t0 - oy, rh);
+  unpack_all<REV, IMG, NC>(rh, g, cv, xl);
+  ldrow(2 * t0 + 1 - oy, rh); ldrow(2 * t0 + 2 - oy, rn);                     // rows of iteration t0
   for (int t = t0; t <= i1; ++t) {
-    arrived(rh.x, rh.y, rn.x, rn.y);
-    const Pair<T> xh = unpack<REV, IMG>(rh, g, cv);
-    xn = unpack<REV, IMG>(rn, g, cv);
-    if (has_lo) put(out_t, true, out_lo.l, out_lo.h);
-    if (has_hi) put(out_t, false, out_hi.l, out_hi.h);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) arrived(rh[k].x, rh[k].y, rn[k].x, rn[k].y);
+    Pair<T> xh[NC];
+    unpack_all<REV, IMG, NC>(rh, g, cv, xh);
+    unpack_all<REV, IMG, NC>(rn, g, cv, xn);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
+      if (has_hi) put(k, out_t, false, out_hi[k].l, out_hi[k].h);
+    }
     has_lo = has_hi = false;
     if (t < i1) {                                          // request the rows of iteration t+1 now
-      rh = ldrow(2 * t + 3 - oy);
-      rn = ldrow(2 * t + 4 - oy);
+      ldrow(2 * t + 3 - oy, rh);
+      ldrow(2 * t + 4 - oy, rn);
     }
     // interior of the plane (every row t-2 .. t+1 exists, no strip edge): the selects fold away
     auto lift = [&](auto chk) {
       constexpr bool CHK = decltype(chk)::value;
       const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
-      // a[t]
-      ap = a;
-      a.l = W::a0(xh.l, pick<CHK>(eLt, xl.l, xn.l), pick<CHK>(eLn, xn.l, xl.l));
-      a.h = W::a0(xh.h, pick<CHK>(eLt, xl.h, xn.h), pick<CHK>(eLn, xn.h, xl.h));
-      // b[t]
-      const bool eHp = exH(t - 1);
-      Pair<T> bo = b;                       // b[t-1]
-      b.l = W::a1(xl.l, pick<CHK>(eHp, ap.l, a.l), pick<CHK>(eHt, a.l, ap.l));
-      b.h = W::a1(xl.h, pick<CHK>(eHp, ap.h, a.h), pick<CHK>(eHt, a.h, ap.h));
-      bp = bo;
-      // c[t-1]
-      const bool eLp = exL(t - 1);
-      cp = c;
-      c.l = W::a2(ap.l, pick<CHK>(eLp, bp.l, b.l), pick<CHK>(eLt, b.l, bp.l));
-      c.h = W::a2(ap.h, pick<CHK>(eLp, bp.h, b.h), pick<CHK>(eLt, b.h, bp.h));
-      // d[t-1]
-      const bool eHpp = exH(t - 2);
-      T dl = W::a3(bp.l, pick<CHK>(eHpp, cp.l, c.l), pick<CHK>(eHp, c.l, cp.l));
-      T dh = W::a3(bp.h, pick<CHK>(eHpp, cp.h, c.h), pick<CHK>(eHp, c.h, cp.h));
-      if (t - 1 >= i0 && t - 1 < i1) {
-        out_t = t - 1;
-        if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
-          out_lo.l = W::mulKinv(dl); out_lo.h = W::mulKinv(dh);
-          horz_analysis<REV, CHK>(out_lo.l, out_lo.h, g); has_lo = true;
-        }
-        if (!CHK || eHp) {                                   // :663-664
-          out_hi.l = W::mulK(c.l); out_hi.h = W::mulK(c.h);
-          horz_analysis<REV, CHK>(out_hi.l, out_hi.h, g); has_hi = true;
+      const bool eHp = exH(t - 1), eLp = exL(t - 1), eHpp = exH(t - 2);
+      const bool emit = t - 1 >= i0 && t - 1 < i1;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        // a[t]
+        ap[k] = a[k];
+        a[k].l = W::a0(xh[k].l, pick<CHK>(eLt, xl[k].l, xn[k].l), pick<CHK>(eLn, xn[k].l, xl[k].l));
+        a[k].h = W::a0(xh[k].h, pick<CHK>(eLt, xl[k].h, xn[k].h), pick<CHK>(eLn, xn[k].h, xl[k].h));
+        // b[t]
+        const Pair<T> bo = b[k];                // b[t-1]
+        b[k].l = W::a1(xl[k].l, pick<CHK>(eHp, ap[k].l, a[k].l), pick<CHK>(eHt, a[k].l, ap[k].l));
+        b[k].h = W::a1(xl[k].h, pick<CHK>(eHp, ap[k].h, a[k].h), pick<CHK>(eHt, a[k].h, ap[k].h));
+        bp[k] = bo;
+        // c[t-1]
+        cp[k] = c[k];
+        c[k].l = W::a2(ap[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+        c[k].h = W::a2(ap[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+        // d[t-1]
+        const T dl = W::a3(bp[k].l, pick<CHK>(eHpp, cp[k].l, c[k].l), pick<CHK>(eHp, c[k].l, cp[k].l));
+        const T dh = W::a3(bp[k].h, pick<CHK>(eHpp, cp[k].h, c[k].h), pick<CHK>(eHp, c[k].h, cp[k].h));
+        if (emit) {
+          if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
+            out_lo[k].l = W::mulKinv(dl); out_lo[k].h = W::mulKinv(dh);
+            horz_analysis<REV, CHK>(out_lo[k].l, out_lo[k].h, g);
+          }
+          if (!CHK || eHp) {                                   // :663-664
+            out_hi[k].l = W::mulK(c[k].l); out_hi[k].h = W::mulK(c[k].h);
+            horz_analysis<REV, CHK>(out_hi[k].l, out_hi[k].h, g);
+          }
         }
       }
+      if (emit) { out_t = t - 1; has_lo = !CHK || eLp; has_hi = !CHK || eHp; }
     };
     if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * (t + 1) - oy < h) lift(std::false_type());
     else lift(std::true_type());
-    xl = xn;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) xl[k] = xn[k];
   }
-  if (has_lo) put(out_t, true, out_lo.l, out_lo.h);
-  if (has_hi) put(out_t, false, out_hi.l, out_hi.h);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
+    if (has_hi) put(k, out_t, false, out_hi[k].l, out_hi[k].h);
+  }
 }
 
 struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
+
+// one reconstructed row of a plane: a[0] = the lane's low (even-site) sample, a[1] the high one, as image integers
+// (IMG) or working values
+// A reconstructed sample may lie just outside its nominal range (the reference's float -> integer conversion
+// rounds 127.6 to 128 after its range test, ojph_colour.cpp:316-386: 256 for an 8-bit component).  In int32 samples
+// that value is handed over as it is, like the reference's line_buf; a narrower container SATURATES at its own
+// range instead of wrapping, as the reference's image writers do when they pack samples into 8 / 16 bits.
+template <int IMG>
+__device__ __forceinline__ int fit_container(int v, const Conv& cv)
+{
+  if (IMG == 32 || IMG == 0) return v;
+  const int hi = cv.is_signed ? (1 << (IMG - 1)) - 1 : (1 << IMG) - 1, lo = cv.is_signed ? -(1 << (IMG - 1)) : 0;
+  return min(max(v, lo), hi);
+}
+
+template <bool REV, int IMG>
+__device__ __forceinline__ void store_image_pair(void* __restrict__ rowp, const Geo& g, int a, int b, const Conv& cv)
+{
+  a = fit_container<IMG>(a, cv); b = fit_container<IMG>(b, cv);
+  const int xl = 2 * g.j - g.ox;
+  typedef typename ImgElem<IMG, int>::type E;
+  E* row = (E*)rowp;
+  if (IMG == 32) {
+    if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
+    else if (g.eL) row[xl] = (E)a;
+    else if (g.eH) row[xl + 1] = (E)b;
+  } else {
+    if (g.eL && g.eH) { typename Vec2<E>::type v; v.x = (E)a; v.y = (E)b; *reinterpret_cast<typename Vec2<E>::type*>(row + xl) = v; }
+    else if (g.eL) row[xl] = (E)a;
+    else if (g.eH) row[xl + 1] = (E)b;
+  }
+}
 
 template <bool REV, int IMG>
 __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
@@ -366,19 +478,8 @@ __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g
   typedef typename Wv<REV>::T T;
   if (!g.store) return;
   const int xl = 2 * g.j - g.ox;
-  if (IMG == 16) {
-    short* row = (short*)rowp;
-    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
-    if (g.eL && g.eH) { typename Vec2<short>::type v; v.x = (short)a; v.y = (short)b; *reinterpret_cast<typename Vec2<short>::type*>(row + xl) = v; }
-    else if (g.eL) row[xl] = (short)a;
-    else if (g.eH) row[xl + 1] = (short)b;
-  } else if (IMG) {
-    int* row = (int*)rowp;
-    const int a = Cv<REV>::to_image(l, cv), b = Cv<REV>::to_image(h, cv);
-    if (g.eL && g.eH) { I2 v; v.x = a; v.y = b; *reinterpret_cast<I2*>(row + xl) = v; }
-    else if (g.eL) row[xl] = a;
-    else if (g.eH) row[xl + 1] = b;
-  } else {
+  if (IMG) store_image_pair<REV, IMG>(rowp, g, Cv<REV>::to_image(l, cv), Cv<REV>::to_image(h, cv), cv);
+  else {
     T* row = (T*)rowp;
     if (g.ox == 0 && g.eL && g.eH) {
       typedef T V2 __attribute__((ext_vector_type(2)));
@@ -391,10 +492,29 @@ __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g
   }
 }
 
+// one reconstructed row of all NC planes; NC = 3: Y, Cb, Cr -> R, G, B on the way out
+template <bool REV, int IMG, int NC>
+__device__ __forceinline__ void store_rows(char* const* dst, size_t off, const Geo& g, const Pair<typename Wv<REV>::T>* v, const Conv& cv)
+{
+  typedef typename Wv<REV>::T T;
+  if (NC == 3) {
+    if (!g.store) return;
+    T rl, gl, bl, rh, gh, bh;
+    Ct<REV>::inv(v[0].l, v[1].l, v[2].l, rl, gl, bl);
+    Ct<REV>::inv(v[0].h, v[1].h, v[2].h, rh, gh, bh);
+    store_image_pair<REV, IMG>(dst[0] + off, g, Cv<REV>::to_image(rl, cv), Cv<REV>::to_image(rh, cv), cv);
+    store_image_pair<REV, IMG>(dst[1] + off, g, Cv<REV>::to_image(gl, cv), Cv<REV>::to_image(gh, cv), cv);
+    store_image_pair<REV, IMG>(dst[2] + off, g, Cv<REV>::to_image(bl, cv), Cv<REV>::to_image(bh, cv), cv);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) store_pair<REV, IMG>(dst[k] + off, g, v[k].l, v[k].h, cv);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
-// inverse: LL, HL, LH, HH -> plane (or image plane, IMG)
+// inverse: LL, HL, LH, HH -> plane (or image plane, IMG); NC as in the forward kernel
 // ---------------------------------------------------------------------------------------------
-template <bool REV, int IMG>
+template <bool REV, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           typename Wv<REV>::T* __restrict__ base,
                                                           void* __restrict__ image, Conv cv, int row_pairs)
@@ -404,7 +524,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
   // block-coder launch of the side stream, its wavefronts go first
   __builtin_amdgcn_s_setprio(2);
-  const ojphgpu_dwt_desc d = descs[blockIdx.z];
+  const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
   if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -418,70 +538,89 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const int i1 = min(i0 + row_pairs, npy);
 
   typedef typename ImgElem<IMG, T>::type E;                        // element type of the destination rows
-  char* dst = IMG ? (char*)image + d.src_off * sizeof(E) : (char*)(base + d.src_off);
+  char* dst[NC]; const T* ll[NC]; const T* hl[NC]; const T* lh[NC]; const T* hh[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
+    dst[k] = IMG ? (char*)image + dk.src_off * sizeof(E) : (char*)(base + dk.src_off);
+    ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
+  }
   const size_t dp = (size_t)d.src_pitch * sizeof(E);
-  const T* ll = base + d.ll_off; const T* hl = base + d.hl_off;
-  const T* lh = base + d.lh_off; const T* hh = base + d.hh_off;
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t
-  auto fetch = [&](int t, bool low_row, bool ex) {
-    Pair<T> p; p.l = p.h = 0;
-    if (!ex) return p;
-    const T* lo = low_row ? ll : lh; const T* hi = low_row ? hl : hh;
-    const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
-    const int r = low_row ? t - oy : t;
-    if (g.eL) p.l = lo[(size_t)r * lop + (g.j - g.ox)];
-    if (g.eH) p.h = hi[(size_t)r * hip + g.j];
-    return p;
+  // raw sub-band samples of the lane's column pair in the low (LL|HL) or high (LH|HH) row of pair t, every plane
+  auto fetch = [&](int t, bool low_row, bool ex, Pair<T>* p) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      p[k].l = p[k].h = 0;
+      if (!ex) continue;
+      const T* lo = low_row ? ll[k] : lh[k]; const T* hi = low_row ? hl[k] : hh[k];
+      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+      const int r = low_row ? t - oy : t;
+      if (g.eL) p[k].l = lo[(size_t)r * lop + (g.j - g.ox)];
+      if (g.eH) p[k].h = hi[(size_t)r * hip + g.j];
+    }
   };
-  auto horz = [&](Pair<T> p) { horz_synthesis<REV>(p.l, p.h, g); return p; };
 
   if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
     if (i0 > 0) return;
-    Pair<T> x = horz(fetch(0, oy == 0, true));
-    if (oy != 0) { x.l = W::halve(x.l); x.h = W::halve(x.h); }
-    store_pair<REV, IMG>(dst, g, x.l, x.h, cv);
+    Pair<T> x[NC];
+    fetch(0, oy == 0, true, x);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      horz_synthesis<REV>(x[k].l, x[k].h, g);
+      if (oy != 0) { x[k].l = W::halve(x[k].l); x[k].h = W::halve(x[k].h); }
+    }
+    store_rows<REV, IMG, NC>(dst, 0, g, x, cv);
     return;
   }
 
   const int t0 = max(i0 - (REV ? 1 : 2), 0);
   Pair<T> z; z.l = z.h = 0;
-  Pair<T> c = z, cp = z, b = z, bp = z, a = z, ap = z, xL = z, xLp = z;
+  Pair<T> c[NC], cp[NC], b[NC], bp[NC], a[NC], ap[NC], xL[NC], xLp[NC];
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
-  Pair<T> nlo = fetch(t0, true, exL(t0)), nhi = fetch(t0, false, exH(t0));       // sub-band rows of iteration t0
+#pragma unroll
+  for (int k = 0; k < NC; ++k) c[k] = cp[k] = b[k] = bp[k] = a[k] = ap[k] = xL[k] = xLp[k] = z;
+  Pair<T> nlo[NC], nhi[NC];
+  fetch(t0, true, exL(t0), nlo); fetch(t0, false, exH(t0), nhi);              // sub-band rows of iteration t0
   for (int t = t0; t <= i1 + 1; ++t) {
-    const Pair<T> in_lo = nlo, in_hi = nhi;
-    if (t <= i1) { nlo = fetch(t + 1, true, exL(t + 1)); nhi = fetch(t + 1, false, exH(t + 1)); }   // request t+1 now
+    Pair<T> in_lo[NC], in_hi[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { in_lo[k] = nlo[k]; in_hi[k] = nhi[k]; }
+    if (t <= i1) { fetch(t + 1, true, exL(t + 1), nlo); fetch(t + 1, false, exH(t + 1), nhi); }   // request t+1 now
     // interior of the plane (every row t-2 .. t exists, no strip edge): the selects fold away
     auto lift = [&](auto chk) {
       constexpr bool CHK = decltype(chk)::value;
       const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
       const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
-      Pair<T> dd = in_lo, cc = in_hi;
-      cp = c; c = z;
-      if (!CHK || eLt) { horz_synthesis<REV, CHK>(dd.l, dd.h, g); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;   // :855-856
-      if (!CHK || eHt) { horz_synthesis<REV, CHK>(cc.l, cc.h, g); c.l = W::mulKinv(cc.l); c.h = W::mulKinv(cc.h); }          // :871-872
-      // b[t]
-      bp = b;
-      b.l = W::s0(dd.l, pick<CHK>(eHp, cp.l, c.l), pick<CHK>(eHt, c.l, cp.l));
-      b.h = W::s0(dd.h, pick<CHK>(eHp, cp.h, c.h), pick<CHK>(eHt, c.h, cp.h));
-      // a[t-1]
-      ap = a;
-      a.l = W::s1(cp.l, pick<CHK>(eLp, bp.l, b.l), pick<CHK>(eLt, b.l, bp.l));
-      a.h = W::s1(cp.h, pick<CHK>(eLp, bp.h, b.h), pick<CHK>(eLt, b.h, bp.h));
-      // xL[t-1]
-      xLp = xL;
-      xL.l = W::s2(bp.l, pick<CHK>(eHpp, ap.l, a.l), pick<CHK>(eHp, a.l, ap.l));
-      xL.h = W::s2(bp.h, pick<CHK>(eHpp, ap.h, a.h), pick<CHK>(eHp, a.h, ap.h));
-      // xH[t-2]
-      T xhl = W::s3(ap.l, pick<CHK>(eLpp, xLp.l, xL.l), pick<CHK>(eLp, xL.l, xLp.l));
-      T xhh = W::s3(ap.h, pick<CHK>(eLpp, xLp.h, xL.h), pick<CHK>(eLp, xL.h, xLp.h));
+      Pair<T> xh[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        Pair<T> dd = in_lo[k], cc = in_hi[k];
+        cp[k] = c[k]; c[k] = z;
+        if (!CHK || eLt) { horz_synthesis<REV, CHK>(dd.l, dd.h, g); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;   // :855-856
+        if (!CHK || eHt) { horz_synthesis<REV, CHK>(cc.l, cc.h, g); c[k].l = W::mulKinv(cc.l); c[k].h = W::mulKinv(cc.h); }    // :871-872
+        // b[t]
+        bp[k] = b[k];
+        b[k].l = W::s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
+        b[k].h = W::s0(dd.h, pick<CHK>(eHp, cp[k].h, c[k].h), pick<CHK>(eHt, c[k].h, cp[k].h));
+        // a[t-1]
+        ap[k] = a[k];
+        a[k].l = W::s1(cp[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+        a[k].h = W::s1(cp[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+        // xL[t-1]
+        xLp[k] = xL[k];
+        xL[k].l = W::s2(bp[k].l, pick<CHK>(eHpp, ap[k].l, a[k].l), pick<CHK>(eHp, a[k].l, ap[k].l));
+        xL[k].h = W::s2(bp[k].h, pick<CHK>(eHpp, ap[k].h, a[k].h), pick<CHK>(eHp, a[k].h, ap[k].h));
+        // xH[t-2]
+        xh[k].l = W::s3(ap[k].l, pick<CHK>(eLpp, xLp[k].l, xL[k].l), pick<CHK>(eLp, xL[k].l, xLp[k].l));
+        xh[k].h = W::s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
+      }
       if (t - 2 >= i0 && t - 2 < i1 && (!CHK || eHpp))
-        store_pair<REV, IMG>(dst + (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xhl, xhh, cv);
+        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cv);
       if (t - 1 >= i0 && t - 1 < i1 && (!CHK || eLp))
-        store_pair<REV, IMG>(dst + (size_t)(2 * (t - 1) - oy) * dp, g, xL.l, xL.h, cv);
+        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cv);
     };
     if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * t + 1 - oy < h) lift(std::false_type());
     else lift(std::true_type());
@@ -516,22 +655,32 @@ dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h, int rp)
   return dim3((sx + 3) / 4, (npy + rp - 1) / rp, n);
 }
 
-// container: 0 = no image (arena planes only), 32 = int32 image samples, 16 = 16-bit image samples
+// container: 0 = no image (arena planes only), 32 = int32 image samples, 16 / 8 = 16- / 8-bit image samples;
+// nc = 3: the descriptors come in triples (the colour planes of a tile), see the kernels
 template <bool FWD>
 int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
-           void* d_base, void* d_image, Conv cv, int container = 32)
+           void* d_base, void* d_image, Conv cv, int container = 32, int nc = 1)
 {
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
-  if (!d_descs || !d_base) return OJPHGPU_E_INVALID;
-  const int rp = pick_row_pairs(n, max_w, max_h);
-  const dim3 grid = dwt_grid(n, max_w, max_h, rp);
+  if (!d_descs || !d_base || (nc != 1 && nc != 3) || n % (uint32_t)nc || (nc == 3 && !d_image)) return OJPHGPU_E_INVALID;
+  int rp = pick_row_pairs(n, max_w, max_h);
+  if (nc == 3) {
+    // a colour wavefront carries three pipelines: a third of the wavefronts of the plain kernel, each three times as
+    // long -- shorter vertical chunks bring the wavefront count back (the extra halo rows are cheap here: the
+    // image side is 1-2 bytes per sample)
+    static const int rp3 = [] { const char* e = getenv("OJPHGPU_DWT_RP_COLOUR"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 64 ? v : 8; }();
+    rp = rp3;
+  }
+  const dim3 grid = dwt_grid(n / (uint32_t)nc, max_w, max_h, rp);
   hipStream_t s = (hipStream_t)stream;
-#define OJPH_LAUNCH(K, REV, IMG, TP) hipLaunchKernelGGL((K<REV, IMG>), grid, dim3(256), 0, s, d_descs, (TP*)d_base, d_image, cv, rp)
-#define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, TP); else if (container == 16) OJPH_LAUNCH(K, REV, 16, TP); \
-                                         else OJPH_LAUNCH(K, REV, 32, TP); } while (0)
+#define OJPH_LAUNCH(K, REV, IMG, NC, TP) hipLaunchKernelGGL((K<REV, IMG, NC>), grid, dim3(256), 0, s, d_descs, (TP*)d_base, d_image, cv, rp)
+#define OJPH_LAUNCH_NC(K, REV, IMG, TP) do { if (nc == 3) OJPH_LAUNCH(K, REV, IMG, 3, TP); else OJPH_LAUNCH(K, REV, IMG, 1, TP); } while (0)
+#define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, 1, TP); else if (container == 16) OJPH_LAUNCH_NC(K, REV, 16, TP); \
+                                         else if (container == 8) OJPH_LAUNCH_NC(K, REV, 8, TP); else OJPH_LAUNCH_NC(K, REV, 32, TP); } while (0)
   if (FWD) { if (reversible) OJPH_LAUNCH_IMG(dwt_forward_kernel, true, int); else OJPH_LAUNCH_IMG(dwt_forward_kernel, false, float); }
   else { if (reversible) OJPH_LAUNCH_IMG(dwt_inverse_kernel, true, int); else OJPH_LAUNCH_IMG(dwt_inverse_kernel, false, float); }
 #undef OJPH_LAUNCH_IMG
+#undef OJPH_LAUNCH_NC
 #undef OJPH_LAUNCH
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
@@ -581,4 +730,27 @@ extern "C" int ojphgpu_dwt_inverse_image16(void* stream, const ojphgpu_params* p
   if (!params || !d_image || params->color_transform || params->bit_depth == 0 || params->bit_depth > 16) return OJPHGPU_E_INVALID;
   return launch<false>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, d_image,
                        Conv{ (int)params->bit_depth, (int)params->is_signed }, 16);
+}
+
+// the general form: container_bits = 32 | 16 | 8; colour != 0: the descriptors come in triples -- the three
+// colour planes of a tile -- and the component transform (RCT for the 5/3, ICT for the 9/7, ojph_colour.cpp:443-571)
+// is applied in the loads of the first analysis level / the stores of the last synthesis level
+extern "C" int ojphgpu_dwt_forward_image_ex(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                             uint32_t n, uint32_t max_w, uint32_t max_h, const void* d_image, void* d_base,
+                                             int container_bits, int colour)
+{
+  if (!params || !d_image || params->bit_depth == 0 || params->bit_depth > (uint32_t)(container_bits == 32 ? 31 : container_bits)) return OJPHGPU_E_INVALID;
+  if (container_bits != 32 && container_bits != 16 && container_bits != 8) return OJPHGPU_E_INVALID;
+  return launch<true>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, const_cast<void*>(d_image),
+                      Conv{ (int)params->bit_depth, (int)params->is_signed }, container_bits, colour ? 3 : 1);
+}
+
+extern "C" int ojphgpu_dwt_inverse_image_ex(void* stream, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                             uint32_t n, uint32_t max_w, uint32_t max_h, void* d_image, void* d_base,
+                                             int container_bits, int colour)
+{
+  if (!params || !d_image || params->bit_depth == 0 || params->bit_depth > (uint32_t)(container_bits == 32 ? 31 : container_bits)) return OJPHGPU_E_INVALID;
+  if (container_bits != 32 && container_bits != 16 && container_bits != 8) return OJPHGPU_E_INVALID;
+  return launch<false>(stream, (int)params->reversible, d_descs, n, max_w, max_h, d_base, d_image,
+                       Conv{ (int)params->bit_depth, (int)params->is_signed }, container_bits, colour ? 3 : 1);
 }

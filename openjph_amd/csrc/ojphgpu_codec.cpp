@@ -171,13 +171,15 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
 
 extern "C" int ojphgpu_encoder_run_device(ojphgpu_encoder* e, const int32_t* d_image) { return ojphgpu_encoder_run_container(e, d_image, 32); }
 extern "C" int ojphgpu_encoder_run_device16(ojphgpu_encoder* e, const uint16_t* d_image) { return ojphgpu_encoder_run_container(e, d_image, 16); }
+extern "C" int ojphgpu_encoder_run_device8(ojphgpu_encoder* e, const uint8_t* d_image) { return ojphgpu_encoder_run_container(e, d_image, 8); }
 
-// container: 32 = int32 samples, 16 = 16-bit samples (int16 for signed components, else uint16)
+// container: 32 = int32 samples, 16 / 8 = 16- / 8-bit samples (two's complement for signed components, else unsigned)
 int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container)
 {
   if (!e || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *e->P;
-  if (container == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+  if (container != 32 && container != 16 && container != 8) return OJPHGPU_E_INVALID;
+  if (container != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container) return OJPHGPU_E_INVALID;
   hipStream_t s = e->stream;
   Spans& T = e->timer;
   uint8_t* const d_out = (uint8_t*)(e->o_out ? e->o_out : e->out.p);          // a pipeline slot's buffers, or the object's own
@@ -188,11 +190,8 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
   int rc = OJPHGPU_OK;
   if (e->need_convert) {
     const int sp = T.begin(SP_CONVERT, s);
-    rc = container == 16
-       ? ojphgpu_convert_forward16(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
-                                   e->conv_max_w, e->conv_max_h, (const uint16_t*)d_image, e->arena.p)
-       : ojphgpu_convert_forward(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
-                                 e->conv_max_w, e->conv_max_h, (const int32_t*)d_image, e->arena.p);
+    rc = ojphgpu_convert_forward_ex(s, &P.p, (const ojphgpu_convert_desc*)e->conv_descs.p, e->tiles.count * e->nframes,
+                                    e->conv_max_w, e->conv_max_h, d_image, e->arena.p, container);
     T.end(sp, s);
   }
   if (rc) return rc;
@@ -216,9 +215,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
     if (b.img_first >= 0) {                                 // level shift / int->float applied in the loads
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)e->img_descs.p + b.img_first;
-      rc = container == 16
-         ? ojphgpu_dwt_forward_image16(s, &pp, idesc, b.count, b.max_w, b.max_h, (const uint16_t*)d_image, e->arena.p)
-         : ojphgpu_dwt_forward_image(s, &pp, idesc, b.count, b.max_w, b.max_h, (const int32_t*)d_image, e->arena.p);
+      rc = ojphgpu_dwt_forward_image_ex(s, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container, b.nc == 3);
     } else
       rc = ojphgpu_dwt_forward(s, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
@@ -379,7 +376,7 @@ static int encode_host(ojphgpu_encoder* e, const void* h_image, int container, u
   const Plan& P = *e->P;
   const size_t bytes = (size_t)P.frame_elems * 4 * e->nframes;          // sized for the wider container, used by both
   if (!e->image.p && e->image.alloc(bytes)) return OJPHGPU_E_NOMEM;
-  HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes / (container == 16 ? 2 : 1), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->image.p, h_image, bytes / (32 / container), hipMemcpyHostToDevice, e->stream));
   int rc = ojphgpu_encoder_run_container(e, e->image.p, container);
   if (rc) return rc;
   return ojphgpu_encoder_finish(e, h_out, cap, out_len);
@@ -663,12 +660,14 @@ static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t l
 
 extern "C" int ojphgpu_decoder_run_device(ojphgpu_decoder* d, int32_t* d_image) { return ojphgpu_decoder_run_container(d, d_image, 32); }
 extern "C" int ojphgpu_decoder_run_device16(ojphgpu_decoder* d, uint16_t* d_image) { return ojphgpu_decoder_run_container(d, d_image, 16); }
+extern "C" int ojphgpu_decoder_run_device8(ojphgpu_decoder* d, uint8_t* d_image) { return ojphgpu_decoder_run_container(d, d_image, 8); }
 
 int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int container)
 {
   if (!d || !d_image) return OJPHGPU_E_INVALID;
   const Plan& P = *d->P;
-  if (container == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+  if (container != 32 && container != 16 && container != 8) return OJPHGPU_E_INVALID;
+  if (container != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container) return OJPHGPU_E_INVALID;
   hipStream_t s = d->stream;
   Spans& T = d->timer;
   T.start(s);
@@ -697,9 +696,7 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     if (b.img_first >= 0) {                                 // float->int / level shift applied in the stores
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)d->img_descs.p + b.img_first;
-      rc = container == 16
-         ? ojphgpu_dwt_inverse_image16(ls, &pp, idesc, b.count, b.max_w, b.max_h, (uint16_t*)d_image, d->arena.p)
-         : ojphgpu_dwt_inverse_image(ls, &pp, idesc, b.count, b.max_w, b.max_h, (int32_t*)d_image, d->arena.p);
+      rc = ojphgpu_dwt_inverse_image_ex(ls, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container, b.nc == 3);
     } else
       rc = ojphgpu_dwt_inverse(ls, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
@@ -709,11 +706,8 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   if (d->n_low && !joined && (rc = finish_blocks()) != 0) return rc;
   if (d->need_convert) {
     const int sp = T.begin(SP_CONVERT, s);
-    rc = container == 16
-       ? ojphgpu_convert_inverse16(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
-                                   d->conv_max_w, d->conv_max_h, (uint16_t*)d_image, d->arena.p)
-       : ojphgpu_convert_inverse(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
-                                 d->conv_max_w, d->conv_max_h, (int32_t*)d_image, d->arena.p);
+    rc = ojphgpu_convert_inverse_ex(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,
+                                    d->conv_max_w, d->conv_max_h, d_image, d->arena.p, container);
     if (rc) return rc;
     T.end(sp, s);
   }
@@ -762,7 +756,7 @@ static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t l
   if (rc) return rc;
   rc = ojphgpu_decoder_run_container(d, d->image.p, container);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (container == 16 ? 2 : 1), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (32 / container), hipMemcpyDeviceToHost, d->stream));
   uint32_t failed = 0;
   rc = ojphgpu_decoder_failed_blocks(d, &failed);
   if (rc) return rc;

@@ -48,16 +48,31 @@ struct HostBuf {
 // One DWT launch: the levels `depth` steps below the top of their component, of the components with
 // the same wavelet.  Without COCs that is one batch per resolution; with them a component may have
 // fewer levels than another, or the other wavelet, and a depth splits in two.
-struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; };
+// nc = 3: the batch holds the top levels of the three colour components of every tile, as triples, and the
+// component transform is applied inside the DWT kernel (kernels_dwt.hip); group: 0 all components, 1 the colour
+// components (0..2), 2 the others -- how a depth is split when the colour transform is fused
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; };
 
 // DWT descriptors grouped so that one launch handles every tile-component
 struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
 
+inline bool in_group(uint32_t comp, int group) { return group == 0 || (group == 1) == (comp < 3); }
+
+// The component transform is applied inside the top DWT level of the three colour components (no conversion pass)
+// when every one of them has such a level and no non-linearity sits between the samples and the transform
+inline bool colour_fused(const Plan& P)
+{
+  if (!P.p.color_transform || P.any_nlt3 || P.p.num_comps < 3) return false;
+  for (uint32_t c = 0; c < 3; ++c) if (P.recon_decomps(c) == 0) return false;
+  const char* off = getenv("OJPHGPU_NO_COLOUR_FUSION");          // test switch: "1" keeps the stand-alone conversion kernels
+  return !(off && off[0] && off[0] != '0');
+}
+
 template <typename F>
-void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, F f)
+void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, int group, F f)
 {
   for (const ojphgpu_level_info& lv : P.levels) {
-    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev) continue;
+    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev || !in_group(lv.comp, group)) continue;
     const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
     if (L > depth && lv.res == L - depth) f(lv);
   }
@@ -74,10 +89,12 @@ void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_de
 {
   descs.clear(); batches.clear();
   const uint32_t depths = max_recon_decomps(P);
+  const bool fused = colour_fused(P);
   for (uint32_t depth = 0; depth < depths; ++depth)
-    for (int rev = 0; rev < 2; ++rev) {
-      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1 };
-      for_levels_of(P, tr, depth, rev != 0, [&](const ojphgpu_level_info& lv) {
+    for (int rev = 0; rev < 2; ++rev)
+    for (int group = (fused && depth == 0) ? 1 : 0; group <= ((fused && depth == 0) ? 2 : 0); ++group) {
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1, group == 1 ? 3 : 1, group };
+      for_levels_of(P, tr, depth, rev != 0, group, [&](const ojphgpu_level_info& lv) {
         ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
         d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
         d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
@@ -96,12 +113,12 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
                              std::vector<ojphgpu_dwt_desc>& out)
 {
   out.clear();
-  if (P.p.color_transform || P.any_nlt3) return;          // those conversions live in the conversion kernels
+  if (P.any_nlt3 || (P.p.color_transform && !colour_fused(P))) return;   // those conversions live in the conversion kernels
   for (LevelBatch& b : batches) {
     if (b.depth != 0 || b.count == 0) continue;
     b.img_first = (int)out.size();
     size_t k = 0;
-    for_levels_of(P, tr, 0, b.rev, [&](const ojphgpu_level_info& lv) {
+    for_levels_of(P, tr, 0, b.rev, b.group, [&](const ojphgpu_level_info& lv) {
       ojphgpu_dwt_desc d = descs[b.first + k++];
       const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
       const CompGeo& g = P.comps[lv.comp];
@@ -134,7 +151,7 @@ bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
       d.img_pitch = g.w; d.img_off = g.frame_off;
       d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u);   // 0x200: bit 10 says which conversion
-      if (P.p.color_transform || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }

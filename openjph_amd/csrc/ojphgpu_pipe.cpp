@@ -216,7 +216,7 @@ extern "C" void ojphgpu_enc_pipe_destroy(ojphgpu_enc_pipe* p)
 extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uint32_t depth, int container_bits,
                                         uint32_t host_threads, ojphgpu_enc_pipe** out)
 {
-  if (!plan || !out || depth < 2 || depth > 16 || (container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
+  if (!plan || !out || depth < 2 || depth > 16 || (container_bits != 8 && container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
   *out = nullptr;
   return no_throw([&]() -> int {
     HIPCHK(hipSetDevice(device));
@@ -225,7 +225,7 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     struct Owner { ojphgpu_enc_pipe* p; ~Owner() { if (p) ojphgpu_enc_pipe_destroy(p); } } owner{ p };
     const Plan& P = plan->plan;
     p->handle = plan; p->P = &P; p->device = device; p->container = container_bits; p->depth = depth;
-    if (container_bits == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+    if (container_bits != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container_bits) return OJPHGPU_E_INVALID;
     for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h })
       HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     int rc = ojphgpu_encoder_create(plan, device, p->s_comp, &p->enc);
@@ -455,7 +455,7 @@ extern "C" void ojphgpu_dec_pipe_destroy(ojphgpu_dec_pipe* p)
 extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, int resilient, int device, uint32_t depth,
                                         int container_bits, uint32_t host_threads, ojphgpu_dec_pipe** out)
 {
-  if (!h_codestream || !out || depth < 2 || depth > 16 || (container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
+  if (!h_codestream || !out || depth < 2 || depth > 16 || (container_bits != 8 && container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
   *out = nullptr;
   return no_throw([&]() -> int {
     HIPCHK(hipSetDevice(device));
@@ -466,7 +466,7 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
     if (rc) return rc;
     const Plan& P = p->first->plan;
     p->P = &P; p->device = device; p->container = container_bits; p->depth = depth; p->resilient = resilient;
-    if (container_bits == 16) for (const CompGeo& g : P.comps) if (g.bit_depth > 16) return OJPHGPU_E_INVALID;
+    if (container_bits != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container_bits) return OJPHGPU_E_INVALID;
     for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h }) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     rc = ojphgpu_decoder_create(p->first, device, p->s_comp, &p->dec);
     if (rc) return rc;

@@ -13,6 +13,9 @@ from .capi import check
 from .plan import Plan, make_params
 
 
+_CONTAINER = {8: np.uint8, 16: np.uint16, 32: np.int32}      # numpy view of a frame slot by container width
+
+
 def _view(ptr, nbytes, dtype=np.uint8):
     buf = (C.c_uint8 * nbytes).from_address(ptr)
     return np.frombuffer(buf, dtype=dtype)
@@ -46,7 +49,7 @@ class EncoderPipe:
         if rc == capi.E_AGAIN:
             return None
         check(rc, "enc_pipe_acquire")
-        return _view(ptr.value, n.value, np.uint16 if self.container == 16 else np.int32).reshape(self.plan.frame_shape)
+        return _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
 
     def submit(self):
         check(self._lib.ojphgpu_enc_pipe_submit(self._h), "enc_pipe_submit")
@@ -117,7 +120,7 @@ class DecoderPipe:
         ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
         self.in_flight -= 1
         check(self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed)), "dec_pipe_collect")
-        v = _view(ptr.value, n.value, np.uint16 if self.container == 16 else np.int32).reshape(self.plan.frame_shape)
+        v = _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
         return v.copy() if copy else v
 
     def stats(self):

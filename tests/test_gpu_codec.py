@@ -411,6 +411,62 @@ def test_frame_batch_equals_frame_by_frame(kw):
         assert np.array_equal(out[f], want_dec), "frame %d" % f
 
 
+@pytest.mark.parametrize("kw", [dict(nc=3, h=200, w=300, bd=8, color_transform=True),
+                                dict(nc=3, h=131, w=257, bd=8, reversible=False, color_transform=True, qstep=0.01),
+                                dict(nc=1, h=300, w=500, bd=8, tile=(128, 128)),
+                                dict(nc=3, h=100, w=150, bd=7, signed=True),
+                                dict(nc=4, h=120, w=160, bd=8, color_transform=True),
+                                dict(nc=1, h=64, w=1, bd=8), dict(nc=3, h=1, w=64, bd=8, color_transform=True)],
+                         ids=["rgb-rct", "rgb-ict", "tiled", "signed7", "rgba-rct", "w1", "h1-rct"])
+def test_sample_containers_8_16_32_agree(kw):
+    """the same frame handed over in int32, 16-bit and 8-bit containers gives the same codestream (the oracle's), and
+    decoding into the three container widths gives the same samples -- including the colour-transformed frames whose
+    RCT / ICT runs inside the top DWT level"""
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.plan import Plan, make_params
+    from tests import cpu_pipeline as cp
+    nc, h, w, bd, signed, c = _split(kw)
+    img = synth_image(nc, h, w, bd, seed=21, signed=signed)
+    plan = Plan(make_params(w, h, nc, bit_depth=bd, is_signed=signed, **c))
+    want, *_ = cp.encode(img, bit_depth=bd, is_signed=signed, **c)
+    enc = codec.Encoder(plan=plan)
+    for dt in (np.int32, np.int16, np.int8):
+        cs = enc.encode(img.astype(dt))                    # unsigned values wrap into the container: the bits are what counts
+        assert cs == want, "container %s: %d vs %d bytes" % (dt.__name__, len(cs), len(want))
+    want_dec, _ = cp.decode(want)
+    dec = codec.Decoder(want)
+    for tdt, bits in ((torch.int32, 32), (torch.int16, 16), (torch.int8, 8)):
+        out = dec.run_device(dtype=tdt).cpu().numpy().astype(np.int64)
+        ref = want_dec.astype(np.int64)
+        if bits < 32:                                      # a narrower container saturates at its own range (the reference's
+            if not signed:                                 # 9/7 decode can leave 2^B, e.g. 256 for 8 bits)
+                out &= (1 << bits) - 1
+            ref = np.clip(ref, -(1 << (bits - 1)) if signed else 0, (1 << (bits - 1)) - 1 if signed else (1 << bits) - 1)
+        assert np.array_equal(out, ref), "container %s" % tdt
+
+
+def test_unfused_colour_path_still_matches():
+    """OJPHGPU_NO_COLOUR_FUSION=1 sends colour-transformed frames through the stand-alone conversion kernels (the path
+    frames with an NLT or a colour component without decompositions take): same bytes, same samples"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "from openjph_amd import codec\nfrom tests import cpu_pipeline as cp\nfrom tests.synth import synth_image\n"
+        "for kw in (dict(bit_depth=8, color_transform=True), dict(bit_depth=10, color_transform=True, reversible=False, qstep=0.004)):\n"
+        "    img = synth_image(3, 150, 210, kw['bit_depth'], seed=9)\n"
+        "    want, *_ = cp.encode(img, **kw)\n"
+        "    assert codec.encode(img, **kw) == want\n"
+        "    assert np.array_equal(codec.decode(want), cp.decode(want)[0])\n"
+        "    assert codec.encode(img.astype(np.int16), **kw) == want\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OJPHGPU_NO_COLOUR_FUSION="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_frame_batch_with_different_quantisation():
     """a batch decoder takes K_max / delta from each frame's own QCD (frames 1.. were
     decoded with frame 0's step sizes); frames whose code-block grid differs are refused"""

@@ -24,12 +24,14 @@ def _kw(case):
 
 
 @pytest.mark.parametrize("case", SHAPES, ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("container", [16, 32])
+@pytest.mark.parametrize("container", [8, 16, 32])
 def test_encoder_pipe_matches_single_frame_encoder(case, container):
     from openjph_amd import codec
     from openjph_amd.pipeline import EncoderPipe
     from openjph_amd.plan import Plan, make_params
     nc, h, w, bd, kw = _kw(case)
+    if bd > container:
+        pytest.skip("samples do not fit the container")
     plan = Plan(make_params(w, h, nc, bit_depth=bd, **kw))
     frames = [synth_image(nc, h, w, bd, seed=100 + f) for f in range(9)]
     enc = codec.Encoder(plan=plan)
@@ -45,12 +47,14 @@ def test_encoder_pipe_matches_single_frame_encoder(case, container):
 
 
 @pytest.mark.parametrize("case", SHAPES, ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("container", [16, 32])
+@pytest.mark.parametrize("container", [8, 16, 32])
 def test_decoder_pipe_matches_single_frame_decoder(case, container):
     from openjph_amd import codec
     from openjph_amd.pipeline import DecoderPipe
     from openjph_amd.plan import Plan, make_params
     nc, h, w, bd, kw = _kw(case)
+    if bd > container:
+        pytest.skip("samples do not fit the container")
     frames = [synth_image(nc, h, w, bd, seed=200 + f) for f in range(7)]
     streams = []
     for f, img in enumerate(frames):
@@ -63,7 +67,8 @@ def test_decoder_pipe_matches_single_frame_decoder(case, container):
     got = list(pipe.decode_sequence(streams))
     assert len(got) == len(want)
     for f in range(len(frames)):
-        assert np.array_equal(got[f].astype(np.int64), want[f].astype(np.int64)), "frame %d" % f
+        ref = np.clip(want[f].astype(np.int64), 0, (1 << container) - 1) if container < 32 else want[f].astype(np.int64)   # narrow containers saturate
+        assert np.array_equal(got[f].astype(np.int64), ref), "frame %d" % f
     pipe.close()
 
 
