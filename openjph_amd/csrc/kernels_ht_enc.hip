@@ -30,6 +30,7 @@
 // model of exactly this formulation and is pinned against the reference).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "../../include/ojphgpu.h"
 #include "ht_tables.h"
 
@@ -504,7 +505,16 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 #ifndef ABL
 #define ABL 0                           // ablation bits for timing experiments (tools/enc_only.py); 0 in the product
 #endif
-constexpr uint32_t OUT_CAP = 5120;      // bytes of coded output staged in LDS per wavefront
+#ifndef NWAVES
+#define NWAVES 4                        // wavefronts (code-blocks) per workgroup of the narrow kernel
+#endif
+#ifndef NOUT_CAP
+#define NOUT_CAP 5120
+#endif
+#ifndef NWAVES_PER_EU
+#define NWAVES_PER_EU 4                 // register budget: wavefronts the kernel must fit per SIMD
+#endif
+constexpr uint32_t OUT_CAP = NOUT_CAP;  // bytes of coded output staged in LDS per wavefront
 constexpr int PMS_WORDS = 576;          // 64 lanes * 8 samples * 31 bits + < 257 pending bytes (a window is 256 bytes)
 constexpr int PVLC_WORDS = 80;          // 64 pairs * 30 bits + < 65 pending bytes
 
@@ -535,25 +545,21 @@ __device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
 // REV: the quantise transfer of the blocks this instantiation codes (5/3 integer or 9/7 float coefficients) is a
 // compile-time property -- a launch over blocks of both kinds runs both instantiations, each skipping the other's
 template <bool REV>
-__global__ __launch_bounds__(64 * WAVES) void ht_encode_kernel(
+__global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES_PER_EU, 8))) void ht_encode_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
     ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ uint32_t s_uvlc[64];                   // U-VLC codewords of u = 0..63 (u <= 31 here), see uvlc_word
-  __shared__ NarrowLds s_wave[WAVES];
+  __shared__ NarrowLds s_wave[NWAVES];
   for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
   if (threadIdx.x < 64) s_uvlc[threadIdx.x] = uvlc_word(threadIdx.x);
-#ifdef OCC_PROBE                                    // timing experiment: LDS ballast that lowers the workgroups per CU from 4 to 3
-  __shared__ uint32_t s_pad[3072];
-  if (n == 0xFFFFFFFFu) s_pad[threadIdx.x] = out_cap;
-#endif
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  const uint32_t bi = blockIdx.x * WAVES + wave;
+  const uint32_t bi = blockIdx.x * NWAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
@@ -1000,11 +1006,14 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
   dim3 grid((n + WAVES - 1) / WAVES);
   if ((widths & 12) == 0) widths |= 12;                   // the caller does not know the wavelets: both instantiations
+  // timing experiment: dynamic LDS nobody uses lowers the workgroups per CU (OJPHGPU_ENC_LDS_BALLAST bytes)
+  static const unsigned ballast = [] { const char* e = getenv("OJPHGPU_ENC_LDS_BALLAST"); const long v = e ? atol(e) : 0; return v > 0 && v < 100000 ? (unsigned)v : 0u; }();
+  const dim3 ngrid((n + NWAVES - 1) / NWAVES);
   if ((widths & 1) && (widths & 4))
-    hipLaunchKernelGGL(ht_encode_kernel<true>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+    hipLaunchKernelGGL(ht_encode_kernel<true>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
   if ((widths & 1) && (widths & 8))
-    hipLaunchKernelGGL(ht_encode_kernel<false>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+    hipLaunchKernelGGL(ht_encode_kernel<false>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
   if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,

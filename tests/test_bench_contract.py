@@ -35,7 +35,7 @@ def check_line(d, want_cpu_baseline):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_bench.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_bench.json")))
     assert files
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     check_line(d, want_cpu_baseline=True)
@@ -43,11 +43,19 @@ def test_committed_bench_line_keeps_the_contract():
     # the PMC traffic file carries the kernels the bench line names
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[d["config"]["workload"]]
     assert d["roofline"]["kernel"] in pmc
+    # round 2: a timed region an external sampler can see, the pipelines' end-to-end figures, every host cpu in the
+    # all-core baseline, the VALU roof of the block coder
+    assert d["steps"] >= 1000 and d["steps"] * d["ms_per_step"] >= 1500.0
+    e = d["e2e_steady_Msamples_s"]
+    assert e["encode"] > 10000 and e["decode"] > 10000 and d["e2e"]["frames"] >= 32
+    assert d["cpu_baseline"]["all_cores"]["cores"] == d["cpu_baseline"]["all_cores"]["host_cpus"]
+    assert "ht_encode[top resolution, side stream]" in d["roofline_valu"]["kernels"]
+    assert len(d["per_rank_ms_per_step"]) == d["n_gpus"] and "value_covers" in d
 
 
 @pytest.mark.gpu
 def test_live_bench_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--e2e-frames", "8"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -55,3 +63,4 @@ def test_live_bench_line():
     d = json.loads(lines[0])
     check_line(d, want_cpu_baseline=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["config"]["roundtrip_max_abs_err"] <= 8
+    assert d["e2e"]["frames"] == 8 and d["e2e_steady_Msamples_s"]["encode"] > 0 and d["e2e_steady_Msamples_s"]["encode+decode"] > 0

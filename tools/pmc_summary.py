@@ -73,10 +73,11 @@ def main():
         # template arguments: <reversible, image container bits (0 = arena planes only)>
         for d in ("forward", "inverse"):
             top = None
-            for rev in ("false", "true"):
-                for bits in ("16", "32"):
-                    top = top or pick("dwt_%s_kernel<%s, %s>" % (d, rev, bits))
-            low = pick("dwt_%s_kernel<false, 0>" % d) or pick("dwt_%s_kernel<true, 0>" % d)
+            for rev in ("false", "true"):                    # <reversible, container bits, planes per wavefront>
+                for bits in ("16", "32", "8"):
+                    for nc in ("1", "3"):
+                        top = top or pick("dwt_%s_kernel<%s, %s, %s>" % (d, rev, bits, nc))
+            low = pick("dwt_%s_kernel<false, 0, 1>" % d) or pick("dwt_%s_kernel<true, 0, 1>" % d)
             if top and low:
                 nl = len(fe.get(low, [])) // max(len(fe.get(top, [])), 1)
                 out["dwt_%s(all levels)" % d] = traffic(top) + nl * traffic(low)

@@ -6,16 +6,33 @@ rm -rf gpurun_out/sq1 gpurun_out/sq2
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d gpurun_out/sq1 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 > gpurun_out/sq1.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/sq2 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 > gpurun_out/sq2.log 2>&1
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, json
+out = {}
 for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:60]
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
-    for k, v in acc.items():
-        if "ojphgpu" in k or "anonymous" in k:
-            n = len(cnt[k])
-            print(k, " launches", n, " ".join("%s=%.3g" % (c, x / n) for c, x in sorted(v.items())))
+            k = r["Kernel_Name"]
+            per[k][r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, disp in per.items():
+        if "ojphgpu" not in k and "anonymous" not in k:
+            continue
+        n = len(disp)
+        tot = collections.defaultdict(float)
+        for dd in disp.values():
+            for c, x in dd.items(): tot[c] += x
+        print(k[:70], " launches", n, " ".join("%s=%.4g" % (c, x / n) for c, x in sorted(tot.items())))
+        if d.endswith("sq1") and "ht_encode_kernel" in k:
+            # per frame: the launches alternate top resolution (big) / lower resolutions (small)
+            v = sorted(dd.get("SQ_INSTS_VALU", 0.0) for dd in disp.values()); s_ = sorted(dd.get("SQ_INSTS_SALU", 0.0) for dd in disp.values())
+            h = len(v) // 2
+            out["ht_encode[top resolution, side stream]"] = {"valu_insts": sum(v[h:]) / max(len(v[h:]), 1), "salu_insts": sum(s_[h:]) / max(len(s_[h:]), 1)}
+            out["ht_encode[lower resolutions]"] = {"valu_insts": sum(v[:h]) / max(h, 1), "salu_insts": sum(s_[:h]) / max(h, 1)}
+        for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep")):
+            if d.endswith("sq1") and sub in k:
+                out[key] = {"valu_insts": tot["SQ_INSTS_VALU"] / n, "salu_insts": tot["SQ_INSTS_SALU"] / n}
+        if d.endswith("sq1") and "ht_dec_step2" in k:      # two launches per frame
+            out["ht_dec_step2"] = {"valu_insts": 2 * tot["SQ_INSTS_VALU"] / n, "salu_insts": 2 * tot["SQ_INSTS_SALU"] / n}
+json.dump({"c3_8k_444_12b_irv97": dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")}, open("gpurun_out/sq_counters.json", "w"), indent=1)
 PY
 find gpurun_out/sq1 gpurun_out/sq2 -type f -size +4M -delete
