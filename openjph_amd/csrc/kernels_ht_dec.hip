@@ -18,10 +18,16 @@
 //           codeword starts depends on every earlier codeword and on the neighbour context.  ONE
 //           LANE owns one code-block's chain and a wavefront advances 64 independent chains in
 //           lock step.  Everything that is not on the chain was moved off it: bits come from the
-//           flat strings (a 64-bit window + one prefetched word, no un-stuffing), the adaptive MEL
-//           run-length code is expanded ahead of time into a 64-entry event queue held in a
-//           register pair, the significance of the quad row above lives in two 64-bit masks, the
-//           decode tables in LDS.  Output: one 32-bit record per quad {t-word, u_q}.
+//           flat strings (VLC: two words + one prefetched word in registers, one v_alignbit per look,
+//           no branch; no un-stuffing), the adaptive MEL run-length code is expanded ahead of time into
+//           a 64-entry event queue held in a register pair, the significance of the quad row above
+//           lives in two 64-bit masks, the decode tables in LDS.  Output: one 32-bit record per quad
+//           {t-word, u_q}.  Tried and dropped in round 2 -- the MEL decoder taken out of this chain:
+//           (a) run by the prep kernel, one bit per MEL event for step 1: step 1 0.21 -> 0.18 ms, but
+//           the decoder is scalar code there (one wavefront per block), 300 M scalar instructions per 8K
+//           frame through one scalar unit per CU: prep 0.07 -> 1.0 ms; (b) a launch of its own, one lane
+//           per block beside prep: 0.24 ms for that launch (byte-wise un-stuffing and the symbol loop
+//           diverge between the 64 blocks of a wavefront), longer than what it saves.
 //   step 2  (ht_dec_step2_kernel)  ONE WAVEFRONT PER CODE-BLOCK, ONE LANE PER SAMPLE COLUMN.  A lane
 //           decodes the two samples of its column in the current quad row -- they are adjacent in
 //           the MagSgn bit string, so a wavefront prefix sum of the lanes' bit counts gives every
@@ -228,18 +234,25 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
 // Both readers take their bits from the flat strings of the prep kernel.  The word that will be
 // appended next is requested unconditionally once per quad pair -- outside any divergent branch, so
 // that the wait for it lands at its use one pair later and never on the chain.
-struct FlatLsb {            // VLC: LSB first; 64-bit window
-  const uint32_t* w; uint32_t idx, last, n, pre; uint64_t win;
+// Reader of the flat LSB-first VLC string: two consecutive words in registers, a bit position inside the lower one,
+// one more word in flight.  peek() is ONE v_alignbit_b32; advance(k) crosses at most one word boundary (k <= 32),
+// where the prefetched word moves in -- selects, no branch.  prefetch() is issued once per quad pair, after
+// advance(): the word it requests is only looked at one pair later.
+struct FlatRd {
+  const uint32_t* w; uint32_t idx, last, lo, hi, pre, bp;
   __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
     w = p; last = nwords - 1u;
-    win = (uint64_t)p[0] | ((uint64_t)p[last < 1u ? last : 1u] << 32); n = 64; idx = 2;
-    pre = p[last < 2u ? last : 2u];
+    lo = p[0]; hi = p[last < 1u ? last : 1u]; pre = p[last < 2u ? last : 2u];
+    idx = 2; bp = 0;
   }
-  __device__ __forceinline__ void refill() {          // afterwards n > 32
-    if (n <= 32u) { win |= (uint64_t)pre << n; n += 32u; ++idx; }
-    pre = w[idx < last ? idx : last];
+  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, bp); }   // 32 bits from the current position
+  __device__ __forceinline__ void advance(uint32_t k) {
+    bp += k;
+    const bool cross = bp >= 32u;
+    lo = cross ? hi : lo; hi = cross ? pre : hi;
+    bp = cross ? bp - 32u : bp; idx += cross ? 1u : 0u;
   }
-  __device__ __forceinline__ void skip(uint32_t k) { win >>= k; n -= k; }
+  __device__ __forceinline__ void prefetch() { pre = w[idx < last ? idx : last]; }
 };
 
 struct MelQueue {           // MEL: MSB first, decoded ahead into a queue of events (bit i of ev = i-th next event)
@@ -285,7 +298,7 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 
 // The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
 template <bool NARROW>
-__device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
+__device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
                                            const uint16_t* s_vlc, const uint16_t* s_uvlc0, const uint16_t* s_uvlc1)
 {
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
@@ -297,9 +310,8 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
   {
     uint32_t tleft = 0; uint64_t sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      vlc.refill();                       // > 32 bits: a pair consumes at most 2*7 + 7 + 10 of them
       mel.fill();                         // >= 5 events queued: a pair consumes at most 3
-      uint32_t v = (uint32_t)vlc.win, used = 0;
+      uint32_t v = vlc.peek(), used = 0;  // 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
       const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
       uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
       uint32_t t0 = s_vlc[c_q + (v & 0x7Fu)];
@@ -327,7 +339,7 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
-      vlc.skip(used); mel.drop(ecnt);
+      vlc.advance(used); vlc.prefetch(); mel.drop(ecnt);
       store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
@@ -340,9 +352,8 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
     auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
     uint32_t tleft = 0, carry = 0; uint64_t sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      vlc.refill();
       mel.fill();
-      uint32_t v = (uint32_t)vlc.win, used = 0;
+      uint32_t v = vlc.peek(), used = 0;
       const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
       // k0 / k1: what the sample row above contributes to the contexts of quad qx / qx+1 (:990-991,
       // :1024-1027): bit 7 = nw | n, bit 9 = ne | nf, over the columns 2qx-1 .. 2qx+4
@@ -388,7 +399,7 @@ __device__ __forceinline__ void step1_rows(FlatLsb& vlc, MelQueue& mel, uint32_t
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
       const uint32_t u1 = (entry >> 3) + (tmp >> len);
-      vlc.skip(used); mel.drop(ecnt);
+      vlc.advance(used); vlc.prefetch(); mel.drop(ecnt);
       store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(64) void ht_dec_step1_kernel(
   const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
   uint32_t* rec = quads + d.scratch_cap;          // pair p of this block: rec + 128 p (interleaved with the wavefront's other 63 blocks)
 
-  FlatLsb vlc; vlc.init(aux + d.reserved, vlc_words(scup));
+  FlatRd vlc; vlc.init(aux + d.reserved, vlc_words(scup));
   MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
