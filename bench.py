@@ -349,11 +349,12 @@ def main():
     # Frame pipelines: host memory -> codestream in host memory (and back) with PCIe and host Tier-2 inside the
     # timed region, steady state over --e2e-frames frames: what a capture / playback process gets.
     e2e = None
-    if args.e2e_frames > 0 and world == 1 and frames == 1 and not tiled:
+    if args.e2e_frames > 0 and world == 1 and not tiled:
         try:
             import gc
             gc.collect(); torch.cuda.synchronize(dev)
-            e2e = e2e_pipelines(plan, img, cs, args.e2e_frames, args.container, torch)
+            # (a batch workload goes through the pipes frame by frame: a pipe's slots are its batch)
+            e2e = e2e_pipelines(plan, img if frames == 1 else img[0], cs, args.e2e_frames, args.container, torch)
         except Exception as e:                   # reported, never fatal for the headline figure
             e2e = {"error": str(e)[:300]}
 

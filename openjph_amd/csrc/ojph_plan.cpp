@@ -423,6 +423,23 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   plan.ntx = div_ceil(X1 - p.tile_x0, p.tile_w);                                   // ojph_codestream_local.cpp:113-123
   plan.nty = div_ceil(Y1 - p.tile_y0, p.tile_h);
   if ((uint64_t)plan.ntx * plan.nty > 65535) return fail("the number of tiles cannot exceed 65535");
+  {
+    // Host resources are bounded BEFORE the tables are built (a 60-byte header can announce 2^36 samples in 4x4
+    // code-blocks): an upper estimate of the code-blocks -- every component's samples over its smallest possible
+    // block (a precinct of 2^PP halves it once more per axis), 4/3 for the pyramid, plus the partial blocks at the
+    // edges of every band of every tile-component -- must stay below 2^24 (about 1.5 GB of host tables).
+    double est = 0;
+    const double tiles = (double)plan.ntx * plan.nty;
+    for (uint32_t c = 0; c < p.num_comps; ++c) {
+      const CodStyle& st = plan.style(c);
+      uint32_t lbw = st.lbw, lbh = st.lbh;
+      for (uint32_t r = 0; r <= st.L && r < 36; ++r) { lbw = std::min(lbw, std::max(st.lpw(r), 1u) - (r ? 1u : 0u)); lbh = std::min(lbh, std::max(st.lph(r), 1u) - (r ? 1u : 0u)); }
+      const double area = (double)(1u << lbw) * (double)(1u << lbh);
+      est += (double)plan.comps[c].w * plan.comps[c].h / area * 1.34 + tiles * (3.0 * st.L + 1.0) * 4.0;
+      est += tiles * ((double)plan.comps[c].w / std::max(plan.ntx, 1u) / (1u << lbw) + (double)plan.comps[c].h / std::max(plan.nty, 1u) / (1u << lbh)) * 2.0 * (3.0 * st.L + 1.0);
+    }
+    if (est > (double)(1u << 24)) return fail("too many code-blocks for the host tables (more than 2^24)");
+  }
   uint64_t arena = 0;
   auto alloc = [&](uint32_t w, uint32_t h, uint32_t& pitch) {
     pitch = (std::max<uint32_t>(w, 1) + 63u) & ~63u;

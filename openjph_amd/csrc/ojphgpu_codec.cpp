@@ -146,7 +146,14 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
       }
     scratch_bytes *= nframes; samples *= nframes;
   }
-  uint64_t cap = std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
+  // The compacted output: scratch_bytes is a true upper bound of what the blocks can produce (K_max + 2 bits per
+  // sample plus stuffing); samples * 3 bytes covers every bit depth up to 20 on any content and keeps the buffer of
+  // the usual frames small -- deeper samples get the true bound, so that incompressible content cannot overflow.
+  // The byte cursor is 32 bits wide: a batch whose bound exceeds 4 GiB is clamped there and a frame batch that
+  // really produces more reports OJPHGPU_E_OVERFLOW (code fewer frames per batch).
+  uint32_t kmax_all = 0;
+  for (const Band& B : P.bands) kmax_all = std::max(kmax_all, B.K_max);
+  uint64_t cap = kmax_all > 20 ? scratch_bytes : std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
   cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
   e->out_cap = (uint32_t)cap;
 
