@@ -112,3 +112,33 @@ def test_pipes_report_back_pressure_and_errors():
     for i in (0, 2, 4):
         assert np.array_equal(results[i][0].astype(np.int32), img[0])
     dp.close()
+
+
+def test_pipes_can_be_destroyed_with_frames_in_flight_and_run_side_by_side():
+    """destroying a pipe drains what was submitted; an encoder pipe and a decoder pipe driven from two host threads
+    at once (a transcoder) give what they give alone"""
+    import threading
+    from openjph_amd import codec
+    from openjph_amd.pipeline import DecoderPipe, EncoderPipe
+    from openjph_amd.plan import Plan, make_params
+    plan = Plan(make_params(320, 240, 3, bit_depth=10, reversible=False, qstep=0.002))
+    frames = [synth_image(3, 240, 320, 10, seed=300 + f) for f in range(12)]
+    want = [codec.Encoder(plan=plan).encode(f) for f in frames[:3]]
+    pipe = EncoderPipe(plan=plan, depth=4)
+    for f in frames[:3]:
+        buf = pipe.acquire(); buf[:] = f.astype(buf.dtype); pipe.submit()
+    pipe.close()                                       # three frames in flight: must neither hang nor crash
+    dp = DecoderPipe(want[0], depth=4)
+    for cs in want:
+        buf = dp.acquire(len(cs)); buf[:] = np.frombuffer(cs, np.uint8); dp.submit()
+    dp.close()
+    # side by side
+    streams = [codec.Encoder(plan=plan).encode(f) for f in frames]
+    images = [codec.decode(cs) for cs in streams]
+    got = {}
+    te = threading.Thread(target=lambda: got.__setitem__("e", list(EncoderPipe(plan=plan, depth=3).encode_sequence(frames))))
+    td = threading.Thread(target=lambda: got.__setitem__("d", list(DecoderPipe(streams[0], depth=3).decode_sequence(streams))))
+    te.start(); td.start(); te.join(); td.join()
+    assert got["e"] == streams
+    for a, b in zip(got["d"], images):
+        assert np.array_equal(a.astype(np.int64), b.astype(np.int64))
