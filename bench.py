@@ -573,6 +573,8 @@ def cpu_baseline(img, bd, rev, ct, qstep, tile, reps):
         best_e = min(best_e, t1 - t0); best_d = min(best_d, t2 - t1)
     n = img.size
     out = {"value": round(n / (best_e + best_d) / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "covers": "the whole library call: sample conversion + DWT + block coder + its Tier-2 and memory-file I/O "
+                      "(compare with e2e_steady_Msamples_s; `value` is the device-resident step without Tier-2 / PCIe)",
             "sample": "the full %dx%dx%d frame, best of %d (encode %.3f s, decode %.3f s; simd level %d; host has %d cpus)"
                       % (img.shape[2], img.shape[1], img.shape[0], reps, best_e, best_d, r.simd_level(), os.cpu_count()),
             "encode_Msamples_s": round(n / best_e / 1e6, 2), "decode_Msamples_s": round(n / best_d / 1e6, 2)}

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t PW = (QW + 1) >> 1;
   auto rec_at = [&](uint32_t qy_, uint32_t qx_) { return rec[(size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u)]; };
   uint32_t ent_next = (uint32_t)lane < W ? rec_at(0, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
+  asm volatile("" : "+v"(ent_next));                  // the first record is awaited here, not inside the loop (see the note at the stores)
   for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
     const uint8_t* vexp = s_exp[wave][qy & 1];             // wide blocks: exponents of the sample row above (+1 offset)
     uint8_t* vnew = s_exp[wave][(qy & 1) ^ 1];
@@ -638,6 +639,10 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
       const uint32_t e_new = v1 ? 31u - (uint32_t)__clz((int)v1) : 0u;
       if (!wide) e_prev = e_new;
       else if (act) vnew[col + 1] = (uint8_t)e_new;
+      // The next step's record (requested at the top of this step) is taken into its register HERE, before this
+      // step's stores are issued: loads and stores share one in-order counter on gfx9, so a wait placed after the
+      // stores (where the compiler puts it: at the loop top) would also wait for the stores to reach L2.
+      asm volatile("" : "+v"(ent_next));
       if (act) {
         const uint32_t y = 2 * qy;
         uint32_t* o = dst + (size_t)y * pitch + col;

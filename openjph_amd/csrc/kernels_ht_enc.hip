@@ -594,29 +594,33 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   const uint32_t r = (uint32_t)lane >> 4, px = (uint32_t)lane & 15u;
   const bool pxok = px < PW;
   const uint32_t x0 = 4u * px;
-  const bool full4 = x0 + 3 < W;
   const bool has_q1 = pxok && x0 + 2 < W;
   uint32_t last_bot = 0;                                 // bottom-row pack of the previous step (all lanes)
 
-  // samples of one quad row of this lane's pair: top[0..3], bot[0..3]
+  // Samples of one quad row of this lane's pair: top[0..3], bot[0..3].  The loads are UNCONDITIONAL: rows and columns
+  // are clamped into the block, a lane / row / column that does not exist fetches something valid and is masked when
+  // the values are consumed, one step later.  (With a branch per case the two rows of the full-width case were
+  // separated by a wait for everything in flight -- the zero-initialisation of the registers the partial-width case
+  // loads into -- and the wavefront sat out a full memory latency in the middle of every step: SQ_WAIT_ANY 52 %.)
+  // Whether the block is a multiple of four columns wide is wave-uniform: the usual blocks take two 16-byte loads per
+  // lane, the others eight dword loads with clamped columns.
+  const bool w4 = (W & 3u) == 0;
   auto load_rows = [&](uint32_t qy, uint32_t* top, uint32_t* bot) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { top[k] = 0; bot[k] = 0; }
-    if (!pxok || qy >= QH) return;
-    const uint32_t y0 = 2 * qy;
-    const uint32_t* rp = src + (size_t)y0 * pitch + x0;
-    const bool two = y0 + 1 < H;
-    if (full4) {
-      const U4 a = *reinterpret_cast<const U4*>(rp);
+    const uint32_t qyc = min(qy, QH - 1u);
+    const uint32_t y0 = 2u * qyc, y1 = min(y0 + 1u, H - 1u);
+    const uint32_t* r0 = src + (size_t)y0 * pitch;
+    const uint32_t* r1 = src + (size_t)y1 * pitch;
+    if (w4) {
+      const uint32_t xc = min(x0, W - 4u);
+      const U4 a = *reinterpret_cast<const U4*>(r0 + xc);
+      const U4 c = *reinterpret_cast<const U4*>(r1 + xc);
       top[0] = a.x; top[1] = a.y; top[2] = a.z; top[3] = a.w;
-      if (two) { const U4 b = *reinterpret_cast<const U4*>(rp + pitch); bot[0] = b.x; bot[1] = b.y; bot[2] = b.z; bot[3] = b.w; }
+      bot[0] = c.x; bot[1] = c.y; bot[2] = c.z; bot[3] = c.w;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (x0 + k < W) { top[k] = rp[k]; if (two) bot[k] = rp[pitch + k]; }
+      for (int k = 0; k < 4; ++k) { const uint32_t xk = min(x0 + (uint32_t)k, W - 1u); top[k] = r0[xk]; bot[k] = r1[xk]; }
     }
   };
-
   // Stuffs whole 256-byte windows of the MagSgn bit buffer ("after 0xFF only 7 bits", :471-491): a lane
   // takes four consecutive bytes, speculating that none of the window's bytes is 0xFF; the window is cut
   // behind the first 0xFF (the byte after it carries 7 bits and shifts everything that follows) and the
@@ -729,7 +733,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     for (int k = 0; k < 4; ++k) {                       // quad order: n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const uint32_t raw = j ? nbot[k] : ntop[k];
+        // what the lane fetched for a sample that does not exist counts as zero
+        const bool exists = active && x0 + (uint32_t)k < W && (j == 0 || 2u * qy + 1u < H);
+        const uint32_t raw = exists ? (j ? nbot[k] : ntop[k]) : 0u;
         uint32_t mag, sg;
         if (rev) {
           const int v = (int)raw;
