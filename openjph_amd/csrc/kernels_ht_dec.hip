@@ -41,14 +41,15 @@
 // that the codec objects skip when no block of the frame has more than one pass.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <stdint.h>
 #include "../../include/ojphgpu.h"
 #include "ht_tables.h"
+#include "ht_uvlc.h"
 
 namespace ojphgpu {
 __device__ uint16_t g_dec_vlc[2][1024];
 __device__ uint16_t g_dec_uvlc0[320];
-__device__ uint16_t g_dec_uvlc1[256];
 }
 
 namespace {
@@ -255,32 +256,82 @@ struct FlatRd {
   __device__ __forceinline__ void prefetch() { pre = w[idx < last ? idx : last]; }
 };
 
-struct MelQueue {           // MEL: MSB first, decoded ahead into a queue of events (bit i of ev = i-th next event)
-  const uint32_t* w; uint32_t idx, last, n, pre, k, nev; uint64_t win, ev;
-  __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
-    w = p; last = nwords - 1u;
-    win = ((uint64_t)p[0] << 32) | (uint64_t)p[last < 1u ? last : 1u]; n = 64; idx = 2;
-    pre = p[last < 2u ? last : 2u];
-    k = 0; nev = 0; ev = 0;
-  }
-  // T.814 decodeMELSym, run by run (same runs as block_decoder32.cpp:170-269).  Afterwards at least
-  // 5 events are queued: the window holds > 32 bits after the refill, a codeword takes <= 6 of them
-  // and yields >= 1 event, and the loop only stops early with >= 32 events queued.
-  __device__ __forceinline__ void fill() {
-    if (n <= 32u) { win |= (uint64_t)pre << (32u - n); n += 32u; ++idx; }
-    pre = w[idx < last ? idx : last];
-    while (nev <= 31u && n >= 6u) {
-      const uint32_t e = mel_exp(k);
-      const uint32_t top = (uint32_t)(win >> 32);
-      if (top >> 31) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }     // 2^e zeros, no one
-      else {
-        const uint32_t run = (top >> (31u - e)) & ((1u << e) - 1u);                          // run zeros, then a one
-        ev |= 1ull << (nev + run); nev += run + 1u;
-        k = k > 0u ? k - 1u : 0u; win <<= (e + 1u); n -= (e + 1u);
+// MEL: the adaptive run-length code is decoded by a PARTNER WAVEFRONT (the second wavefront of the workgroup, on
+// another SIMD of the CU; most SIMDs are idle during this launch) into an event string in LDS -- bit i of the string
+// = the i-th MEL event of the lane's code-block -- so that the chain wavefront only reads event bits.  The events do
+// not depend on the VLC stream (only how many of them get consumed does), so the producer runs ahead freely; it
+// publishes how many 32-event words are complete and the chain polls that count in the rare case it catches up.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // pointers kept in structs must not decay to flat ones:
+                                                               // a flat load counts as a global one and drags vmcnt waits in
+constexpr uint32_t EV_WORDS = 44;          // <= 1024 quads + 256 initial-row pairs events = 40 words, + 2 of read-ahead
+__device__ __forceinline__ uint32_t ev_words_of(uint32_t QW, uint32_t QH)
+{
+  const uint32_t w = (QW * QH + ((QW + 1u) >> 1) + 31u) / 32u + 2u;
+  return w < EV_WORDS ? w : EV_WORDS;
+}
+
+// T.814 decodeMELSym, run by run (same runs as block_decoder32.cpp:170-269), MSB-first flat string of the prep kernel.
+// Demand driven: a lane stays at most EV_AHEAD words in front of what its chain has taken (s_cons), so that blocks
+// which hardly use the MEL stream (dense ones) do not pay for decoding all of it, and stops when the chain is done.
+constexpr uint32_t EV_AHEAD = 4;
+__device__ __forceinline__ void mel_producer(const uint32_t* __restrict__ w, uint32_t nwords, uint32_t out_words,
+                                             lds_u32* s_ev, volatile lds_u32* s_prog, const volatile lds_u32* s_cons,
+                                             const volatile lds_u32* s_done, uint32_t lane)
+{
+  const uint32_t last = nwords - 1u;
+  uint64_t win = ((uint64_t)w[0] << 32) | (uint64_t)w[last < 1u ? last : 1u];
+  uint32_t n = 64, idx = 2, k = 0, nev = 0, wr = 0;
+  uint32_t pre = w[last < 2u ? last : 2u];
+  uint64_t ev = 0;
+  while (wr < out_words && s_done[lane] == 0u) {
+    const bool go = wr < s_cons[lane] + EV_AHEAD;
+    if (go) {
+      if (n <= 32u) { win |= (uint64_t)pre << (32u - n); n += 32u; ++idx; pre = w[idx < last ? idx : last]; }
+      while (nev <= 31u && n >= 6u) {
+        const uint32_t e = mel_exp(k);
+        const uint32_t top = (uint32_t)(win >> 32);
+        if (top >> 31) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }     // 2^e zeros, no one
+        else {
+          const uint32_t run = (top >> (31u - e)) & ((1u << e) - 1u);                          // run zeros, then a one
+          ev |= 1ull << (nev + run); nev += run + 1u;
+          k = k > 0u ? k - 1u : 0u; win <<= (e + 1u); n -= (e + 1u);
+        }
+      }
+      if (nev >= 32u) {
+        s_ev[wr * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++wr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // LDS only: no wait on global memory
+        s_prog[lane] = wr;
       }
     }
+    if (__ballot(go) == 0ull) __builtin_amdgcn_s_sleep(16);     // every lane far enough ahead: leave the issue slots alone
   }
-  __device__ __forceinline__ void drop(uint32_t cnt) { ev >>= cnt; nev -= cnt; }
+}
+
+// chain side: 64 events in two registers + one word in flight, as FlatRd (LSB = next event)
+struct EvRd {
+  const lds_u32* ev; volatile lds_u32* prog; volatile lds_u32* cons; uint32_t idx, last, lo, hi, pre, bp, avail, lane; bool stuck;
+  __device__ __forceinline__ uint32_t fetch(uint32_t want) {
+    if (want >= avail) {                                     // rare: the producer is not that far yet
+      uint32_t spins = 0;
+      do { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; } while (want >= avail && ++spins < (1u << 22));
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      stuck = stuck || want >= avail;                        // cannot happen (the partner always progresses); never hang
+    }
+    return ev[want * 64u + lane];
+  }
+  __device__ __forceinline__ void init(const lds_u32* e, volatile lds_u32* p, volatile lds_u32* c, uint32_t nwords, uint32_t l) {
+    ev = e; prog = p; cons = c; last = nwords - 1u; lane = l; avail = 0; stuck = false;
+    lo = fetch(0); hi = fetch(last < 1u ? last : 1u); pre = fetch(last < 2u ? last : 2u);
+    idx = 2; bp = 0;
+  }
+  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, bp); }
+  __device__ __forceinline__ void advance(uint32_t k) {
+    bp += k;
+    const bool cross = bp >= 32u;
+    lo = cross ? hi : lo; hi = cross ? pre : hi;
+    bp = cross ? bp - 32u : bp; idx += cross ? 1u : 0u;
+  }
+  __device__ __forceinline__ void prefetch() { cons[lane] = idx; pre = fetch(idx < last ? idx : last); }   // idx: words taken so far
 };
 
 // Both records of a quad pair leave as ONE 8-byte store, also when the second quad does not exist
@@ -296,10 +347,15 @@ __device__ __forceinline__ void store_pair(uint32_t* p, uint32_t a, uint32_t b)
 
 constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad pairs of one block (64 blocks x 2 records)
 
+// The window moves of advance() must be done BEFORE the next word is requested (otherwise the compiler sinks them
+// below the poll branch of the event reader, keeps the old and the new prefetched word in two registers and copies
+// one into the other at the end of the step -- with a wait for the load that was only just issued)
+#define PIN_WINDOW(r) asm volatile("" : "+v"((r).lo), "+v"((r).hi))
+
 // The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
 template <bool NARROW>
-__device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
-                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0, const uint16_t* s_uvlc1)
+__device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
+                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0)
 {
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
   // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
@@ -310,9 +366,8 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t*
   {
     uint32_t tleft = 0; uint64_t sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      mel.fill();                         // >= 5 events queued: a pair consumes at most 3
       uint32_t v = vlc.peek(), used = 0;  // 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
-      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
+      const uint32_t evq = mel.peek(); uint32_t ecnt = 0;     // the next 32 MEL events: a pair consumes at most 3
       uint32_t c_q = ((tleft & 0x10u) << 3) | ((tleft & 0xE0u) << 2);                       // :903
       uint32_t t0 = s_vlc[c_q + (v & 0x7Fu)];
       if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }                      // :882-894
@@ -339,7 +394,7 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t*
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
-      vlc.advance(used); vlc.prefetch(); mel.drop(ecnt);
+      vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
@@ -352,9 +407,8 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t*
     auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
     uint32_t tleft = 0, carry = 0; uint64_t sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
-      mel.fill();
       uint32_t v = vlc.peek(), used = 0;
-      const uint32_t evq = (uint32_t)mel.ev; uint32_t ecnt = 0;
+      const uint32_t evq = mel.peek(); uint32_t ecnt = 0;
       // k0 / k1: what the sample row above contributes to the contexts of quad qx / qx+1 (:990-991,
       // :1024-1027): bit 7 = nw | n, bit 9 = ne | nf, over the columns 2qx-1 .. 2qx+4
       uint32_t k0, k1;
@@ -390,56 +444,68 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, MelQueue& mel, uint32_t*
         const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
         sig_cur |= (uint64_t)nib << (2u * qx);
       }
-      const uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
-      uint32_t entry = s_uvlc1[mode + (v & 0x3Fu)];
-      v >>= (entry & 7u); used += entry & 7u; entry >>= 3;
-      uint32_t len = entry & 0xFu;
-      const uint32_t tmp = v & ((1u << len) - 1u);
-      used += len; entry >>= 4;
-      len = entry & 7u; entry >>= 3;
-      const uint32_t u0 = (entry & 7u) + (tmp & ~(0xFFu << len));                           // :1082-1085
-      const uint32_t u1 = (entry >> 3) + (tmp >> len);
-      vlc.advance(used); vlc.prefetch(); mel.drop(ecnt);
+      // the pair's U-VLC by arithmetic instead of the uvlc_tbl1 look-up (:1065-1085): one LDS round trip less on the chain
+      uint32_t u0, u1;
+      used += ojphgpu::uvlc_pair_other_rows(v, t0 & 0x8u, t1 & 0x8u, u0, u1);
+      vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
   }
 }
 
-__global__ __launch_bounds__(64) void ht_dec_step1_kernel(
+template <int CH>                 // CH chain wavefronts + CH partner wavefronts per workgroup, 64 code-blocks per pair of them
+__global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ aux, uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
 {
   __shared__ uint16_t s_vlc[2048];
   __shared__ uint16_t s_uvlc0[320];
-  __shared__ uint16_t s_uvlc1[256];
-  // these few wavefronts are bound by the latency of their serial chains: when another launch shares
-  // the SIMDs (another stream, or the tail of the prep launch) they should win the issue arbitration
-  __builtin_amdgcn_s_setprio(3);
+  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
+  __shared__ uint32_t s_prog_all[CH][64];
+  __shared__ uint32_t s_done_all[CH][64];
+  __shared__ uint32_t s_cons_all[CH][64];
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
   for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_uvlc1[i] = ojphgpu::g_dec_uvlc1[i];
+  if (threadIdx.x < 64 * CH) { (&s_prog_all[0][0])[threadIdx.x] = 0; (&s_done_all[0][0])[threadIdx.x] = 0; (&s_cons_all[0][0])[threadIdx.x] = 0; }
   __syncthreads();
 
-  const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+  // wavefronts 0 .. CH-1: the chains of 64 code-blocks each; wavefronts CH .. 2CH-1: the MEL events of the same blocks
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool chain = wv < (uint32_t)CH;
+  const uint32_t set = chain ? wv : wv - (uint32_t)CH;
+  uint32_t* s_ev = s_ev_all[set];
+  uint32_t* s_prog = s_prog_all[set];
+  volatile lds_u32* s_done = (volatile lds_u32*)s_done_all[set];
+  volatile lds_u32* s_cons = (volatile lds_u32*)s_cons_all[set];
+  // the chain wavefronts are bound by the latency of their serial chains: when anything shares their SIMD
+  // (the partner, another stream, the tail of the prep launch) they should win the issue arbitration
+  if (chain) __builtin_amdgcn_s_setprio(3);
+  const uint32_t bi = (blockIdx.x * (uint32_t)CH + set) * 64u + lane;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
-  if (d.w == 0 || d.h == 0) { block_status[bi] = 0; return; }
-  if (d.len1 == 0 || d.num_passes == 0) { block_status[bi] = 0; return; }     // not coded: zero block
+  if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) { if (chain) block_status[bi] = 0; return; }   // not coded: zero block
   const uint8_t* cb = data + d.data_off;
   const uint32_t scup = check_block(d, cb);
-  if (scup == 0) { block_status[bi] = 1; return; }
-  block_status[bi] = 0;
+  if (scup == 0) { if (chain) block_status[bi] = 1; return; }
   const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
+  const uint32_t evw = ev_words_of(QW, QH);
+  if (!chain) {
+    mel_producer(aux + d.reserved + vlc_words(scup), mel_words(scup), evw, (lds_u32*)s_ev, (volatile lds_u32*)s_prog, s_cons, s_done, lane);
+    return;
+  }
   uint32_t* rec = quads + d.scratch_cap;          // pair p of this block: rec + 128 p (interleaved with the wavefront's other 63 blocks)
 
   FlatRd vlc; vlc.init(aux + d.reserved, vlc_words(scup));
-  MelQueue mel; mel.init(aux + d.reserved + vlc_words(scup), mel_words(scup));
+  EvRd mel; mel.init((const lds_u32*)s_ev, (volatile lds_u32*)s_prog, s_cons, evw, lane);
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
   // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
-  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, s_uvlc1);
-  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, s_uvlc1);
+  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  s_done[lane] = 1u;                               // the partner stops producing events for this block
+  block_status[bi] = mel.stuck ? 1 : 0;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -852,8 +918,11 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
   if (n == 0) return OJPHGPU_OK;
   if (ojphgpu::ensure_tables() != 0) return OJPHGPU_E_HIP;
   if (!d_blocks || !d_data || !d_aux || !d_quad_scratch || !d_block_status) return OJPHGPU_E_INVALID;
-  hipLaunchKernelGGL(ht_dec_step1_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_blocks, n, d_data,
-                     d_aux, d_quad_scratch, d_block_status);
+  static const int ch = [] { const char* e = getenv("OJPHGPU_S1_CH"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 4; }();
+  const uint32_t sets = (n + 63) / 64;
+  if (ch == 4) hipLaunchKernelGGL(ht_dec_step1_kernel<4>, dim3((sets + 3) / 4), dim3(512), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
+  else if (ch == 2) hipLaunchKernelGGL(ht_dec_step1_kernel<2>, dim3((sets + 1) / 2), dim3(256), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
+  else hipLaunchKernelGGL(ht_dec_step1_kernel<1>, dim3(sets), dim3(128), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
@@ -894,7 +963,6 @@ int upload_dec_tables(const HtTables& t)
 {
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_vlc), t.dec_vlc, sizeof(t.dec_vlc)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_uvlc0), t.dec_uvlc0, sizeof(t.dec_uvlc0)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_uvlc1), t.dec_uvlc1, sizeof(t.dec_uvlc1)) != hipSuccess) return -1;
   return 0;
 }
 }
