@@ -531,6 +531,11 @@ __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
   return d.num_passes > 1 && d.num_passes <= 3 && d.len2 > 0 && d.missing_msbs < 29;
 }
 
+// TX / WD: what the host knows about EVERY block of the launch (0 = nothing, decided per block at run time).
+// TX 1: reversible, no refinement passes; TX 2: irreversible, no refinement passes.  WD 1: no block wider than 64
+// samples.  The flags are wave-uniform either way; as template constants they take ~20 scalar tests and branches
+// out of every quad row.
+template <int TX, int WD>
 __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
@@ -550,9 +555,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   if (W == 0 || H == 0) return;
   uint32_t* dst = coef + d.coef_off;
-  const bool rev = (d.reversible & 1u) != 0;
+  const bool rev = TX == 1 ? true : TX == 2 ? false : (d.reversible & 1u) != 0;
   const uint32_t K = d.K_max;
-  const bool raw_out = needs_refinement(d);                  // SigProp / MagRef follow: keep sign-magnitude words
+  const bool raw_out = TX ? false : needs_refinement(d);     // SigProp / MagRef follow: keep sign-magnitude words
 
   auto zero_block = [&]() {                                  // mem_clear path, ojph_codeblock.cpp:247
     for (uint32_t y = 0; y < H; ++y)
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
   const uint32_t ms_len = lcup - scup;
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1;
-  const bool wide = W > 64;
+  const bool wide = WD == 1 ? false : W > 64;
 
   uint32_t* ring = s_ring[wave];
   for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
@@ -926,15 +931,31 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
+namespace ojphgpu {
+// kinds: what the caller knows about the blocks of the range (0 = nothing): bit 0 blocks of at most 64 columns occur,
+// bit 1 wider ones, bit 2 reversible ones, bit 3 irreversible ones, bit 4 blocks with SigProp / MagRef passes
+int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
+                           const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
+  const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
+  const int wd = (kinds & 3) == 1 ? 1 : 0;
+  const dim3 grid((n + WAVES - 1) / WAVES), wg(64 * WAVES);
+#define STEP2_LAUNCH(T, W) hipLaunchKernelGGL((ht_dec_step2_kernel<T, W>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, \
+                                              d_quad_scratch, (uint32_t*)d_coef, d_block_status)
+  if (wd) { if (tx == 1) STEP2_LAUNCH(1, 1); else if (tx == 2) STEP2_LAUNCH(2, 1); else STEP2_LAUNCH(0, 1); }
+  else    { if (tx == 1) STEP2_LAUNCH(1, 0); else if (tx == 2) STEP2_LAUNCH(2, 0); else STEP2_LAUNCH(0, 0); }
+#undef STEP2_LAUNCH
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+}  // namespace ojphgpu
+
 extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                         const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
                                         uint8_t* d_block_status)
 {
-  if (n == 0) return OJPHGPU_OK;
-  if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
-  hipLaunchKernelGGL(ht_dec_step2_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream,
-                     d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
-  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  return ojphgpu::ht_decode_step2_launch(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status, 0);
 }
 
 extern "C" int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,

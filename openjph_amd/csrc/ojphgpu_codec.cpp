@@ -498,7 +498,7 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi)
 {
   uint64_t max_off = 0, min_off = ~0ull;
-  fi.any_refine = false; fi.max_len1 = 0;
+  fi.any_refine = false; fi.max_len1 = 0; fi.kinds = 0;
   for (size_t i = 0; i < ids.size(); ++i) {
     const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
@@ -506,7 +506,8 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
     o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
-    if (c.num_passes > 1 && c.len2 > 0) fi.any_refine = true;
+    if (c.num_passes > 1 && c.len2 > 0) { fi.any_refine = true; fi.kinds |= 16; }
+    fi.kinds |= (k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8);
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     fi.max_len1 = std::max(fi.max_len1, c.len1);
     if (c.len1 + c.len2) {
@@ -582,7 +583,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   for (uint32_t f = 0; f < nframes; ++f) {
     DecFrameInfo fi;
     ojphgpu_decoder_fill_descs(P, plans[f]->plan, ids, (uint64_t)f * P.arena_elems, data_total, bd.data() + (size_t)f * ids.size(), fi);
-    d->any_refine |= fi.any_refine; d->max_len1 = std::max(d->max_len1, fi.max_len1);
+    d->any_refine |= fi.any_refine; d->kinds |= fi.kinds; d->max_len1 = std::max(d->max_len1, fi.max_len1);
     d->f_first[f] = (size_t)fi.first; d->f_len[f] = (size_t)fi.len; d->f_base[f] = (size_t)data_total;
     data_total += (fi.len + 63) & ~(uint64_t)63;
   }
@@ -650,7 +651,7 @@ static int decode_samples(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uin
   uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p) + first;
   const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
   int sp = T.begin(SP_STEP2, s);
-  int rc = ojphgpu_ht_decode_step2(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status);
+  int rc = ojphgpu::ht_decode_step2_launch(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status, d->kinds);
   if (rc) return rc;
   T.end(sp, s);
   if (d->any_refine) {

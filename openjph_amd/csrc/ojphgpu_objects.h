@@ -309,6 +309,7 @@ struct ojphgpu_decoder {
   TileRange tiles{ 0, 0 };
   uint32_t nframes = 1;
   bool any_refine = false;                         // some block carries SigProp / MagRef passes
+  int kinds = 0;                                   // block kinds of the frame(s), for ht_decode_step2_launch
   std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
   uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
   std::vector<LevelBatch> batches;
@@ -320,7 +321,7 @@ struct ojphgpu_decoder {
   // what a run reads: the object's own buffers (null), or those of a frame pipeline's slot
   const void* o_cb_descs = nullptr; const void* o_data = nullptr; void* o_status = nullptr;
 };
-struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; };
+struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0; };   // kinds: see ht_decode_step2_launch
 int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks);
 void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);

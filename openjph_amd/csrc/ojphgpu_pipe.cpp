@@ -393,7 +393,7 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
       std::lock_guard<std::mutex> lk(p->enqueue_mu);
       HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
       d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
-      d->any_refine = fi.any_refine; d->max_len1 = fi.max_len1;
+      d->any_refine = fi.any_refine; d->kinds = fi.kinds; d->max_len1 = fi.max_len1;
       r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
       if (r2) return r2;
       HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
