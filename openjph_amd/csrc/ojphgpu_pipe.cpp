@@ -66,6 +66,16 @@ enum SlotState { FREE = 0, ACQUIRED, SUBMITTED, DONE, HELD };
 // Which engine moves which direction (the two directions of one pipe must not share the SDMA engine, see
 // kernels_assemble.hip): 0 = upload by hipMemcpyAsync (SDMA), download by a copy kernel; 1 = upload by a copy
 // kernel reading the pinned memory, download by hipMemcpyAsync; 2 = both by hipMemcpyAsync (the runtime decides).
+// The stream of the device -> host copies: those are kernels (see kernels_assemble.hip) and must get their few
+// workgroups onto the chip while the block coder of the next frames keeps every CU full -- highest priority.
+hipError_t create_copy_out_stream(hipStream_t* s)
+{
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (getenv("OJPHGPU_COPY_PRIO_OFF")) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 int copy_mode(const char* name, int dflt)
 {
   const char* e = getenv(name);
@@ -226,8 +236,8 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     const Plan& P = plan->plan;
     p->handle = plan; p->P = &P; p->device = device; p->container = container_bits; p->depth = depth;
     if (container_bits != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container_bits) return OJPHGPU_E_INVALID;
-    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h })
-      HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (hipStream_t* s : { &p->s_h2d, &p->s_comp }) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    HIPCHK(create_copy_out_stream(&p->s_d2h));
     int rc = ojphgpu_encoder_create(plan, device, p->s_comp, &p->enc);
     if (rc) return rc;
     (void)ojphgpu_encoder_set_timing(p->enc, 0);
@@ -349,12 +359,21 @@ struct ojphgpu_dec_pipe {
   int device = 0, container = 16, resilient = 0;
   int mode = copy_mode("OJPHGPU_DEC_COPY_MODE", 0);
   uint32_t depth = 0;
-  ojphgpu_decoder* dec = nullptr;
-  hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
+  // Consecutive frames go to different decoder objects (own scratch, own compute stream): step 1 of the block decoder
+  // is a 0.2 ms chain that leaves most of the chip idle whatever the frame size, so for frames below ~8K one compute
+  // stream running frame after frame sets the pace (4K 8-bit: 0.82 ms per frame against 0.44 ms of PCIe); with two
+  // objects frame n+1's chains run beside frame n's step 2 and synthesis.  The objects run without their side
+  // stream (streams share 4 hardware queues; the frames overlap each other instead).
+  static constexpr uint32_t MAX_OBJECTS = 4;
+  uint32_t nobj = 0;
+  ojphgpu_decoder* decs[MAX_OBJECTS] = {};
+  hipStream_t s_comps[MAX_OBJECTS] = {};
+  std::mutex enqueue_mus[MAX_OBJECTS];
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
   std::vector<DecSlot> slots;
   size_t frame_bytes = 0;
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
-  std::mutex mu, enqueue_mu; std::condition_variable cv_work, cv_done;
+  std::mutex mu; std::condition_variable cv_work, cv_done;
   std::deque<uint32_t> work; bool stop = false;
   std::vector<std::thread> workers;
   double sum_parse = 0, sum_latency = 0; uint64_t n_done = 0;
@@ -363,7 +382,9 @@ struct ojphgpu_dec_pipe {
 static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
 {
   const Plan& P = *p->P;
-  ojphgpu_decoder* d = p->dec;
+  const uint32_t k = (uint32_t)(&s - p->slots.data()) % p->nobj;
+  ojphgpu_decoder* d = p->decs[k];
+  hipStream_t s_comp = p->s_comps[k];
   auto fail = [&](int rc) { s.rc = rc; };
   if (hipSetDevice(p->device) != hipSuccess) return fail(OJPHGPU_E_HIP);
   const double t0 = now_ms();
@@ -389,14 +410,14 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     if ((r2 = upload(p->mode, p->s_h2d, s.cb_descs.p, s.h_descs, 0, nb * sizeof(ojphgpu_cb_desc))) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
     {
-      // the decoder object is shared by the frames in flight: what a run reads is set and enqueued under a lock
-      std::lock_guard<std::mutex> lk(p->enqueue_mu);
-      HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
+      // a decoder object is shared by the frames in flight on it: what a run reads is set and enqueued under a lock
+      std::lock_guard<std::mutex> lk(p->enqueue_mus[k]);
+      HIPCHK(hipStreamWaitEvent(s_comp, s.ev_in, 0));
       d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
       d->any_refine = fi.any_refine; d->kinds = fi.kinds; d->max_len1 = fi.max_len1;
       r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
       if (r2) return r2;
-      HIPCHK(hipEventRecord(s.ev_kern, p->s_comp));
+      HIPCHK(hipEventRecord(s.ev_kern, s_comp));
     }
     HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
     if ((r2 = download(p->mode, p->s_d2h, s.h_img, s.image.p, p->frame_bytes)) != 0) return r2;       // beside the next frame's upload
@@ -440,14 +461,14 @@ extern "C" void ojphgpu_dec_pipe_destroy(ojphgpu_dec_pipe* p)
   { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
   p->cv_work.notify_all();
   for (std::thread& t : p->workers) t.join();
-  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
-  if (p->dec) ojphgpu_decoder_destroy(p->dec);
+  for (hipStream_t s : { p->s_h2d, p->s_comps[0], p->s_comps[1], p->s_comps[2], p->s_comps[3], p->s_d2h }) if (s) (void)hipStreamSynchronize(s);
+  for (ojphgpu_decoder* d : p->decs) if (d) ojphgpu_decoder_destroy(d);
   for (DecSlot& s : p->slots) {
     s.h_cs.release(); s.h_descs.release(); s.h_img.release(); s.h_status.release();
     for (DeviceBuf* b : { &s.data.b, &s.image, &s.cb_descs, &s.status }) b->release();
     for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
   }
-  for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
+  for (hipStream_t s : { p->s_h2d, p->s_comps[0], p->s_comps[1], p->s_comps[2], p->s_comps[3], p->s_d2h }) if (s) (void)hipStreamDestroy(s);
   if (p->first) ojphgpu_plan_destroy(p->first);
   delete p;
 }
@@ -467,18 +488,29 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
     const Plan& P = p->first->plan;
     p->P = &P; p->device = device; p->container = container_bits; p->depth = depth; p->resilient = resilient;
     if (container_bits != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container_bits) return OJPHGPU_E_INVALID;
-    for (hipStream_t* s : { &p->s_h2d, &p->s_comp, &p->s_d2h }) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    rc = ojphgpu_decoder_create(p->first, device, p->s_comp, &p->dec);
-    if (rc) return rc;
-    (void)ojphgpu_decoder_set_timing(p->dec, 0);
-    ojphgpu_decoder* d = p->dec;
-    const size_t nb = d->block_ids.size();
-    // the flat VLC / MEL strings of any later frame fit: the worst case of every block (Lcup <= 4079 + slack)
+    HIPCHK(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+    HIPCHK(create_copy_out_stream(&p->s_d2h));
     {
-      const uint64_t worst = (uint64_t)nb * ojphgpu_ht_decode_aux_words(4079) + 64;
-      d->aux.release();
-      if (d->aux.alloc((size_t)worst * 4 + 64)) return OJPHGPU_E_NOMEM;
+      const char* e = getenv("OJPHGPU_DEC_PIPE_OBJECTS"); const long v = e ? atol(e) : 0;
+      p->nobj = v >= 1 && v <= (long)ojphgpu_dec_pipe::MAX_OBJECTS ? (uint32_t)v : 2u;
+      p->nobj = std::min(p->nobj, depth);
     }
+    for (uint32_t k = 0; k < p->nobj; ++k) {
+      HIPCHK(hipStreamCreateWithFlags(&p->s_comps[k], hipStreamNonBlocking));
+      rc = ojphgpu_decoder_create(p->first, device, p->s_comps[k], &p->decs[k]);
+      if (rc) return rc;
+      ojphgpu_decoder* dk = p->decs[k];
+      (void)ojphgpu_decoder_set_timing(dk, 0);
+      if (p->nobj > 1 && dk->side) {                     // no fork inside a frame: the frames overlap each other
+        (void)hipStreamDestroy(dk->side); dk->side = nullptr; dk->n_low = 0;
+      }
+      // the flat VLC / MEL strings of any later frame fit: the worst case of every block (Lcup <= 4079 + slack)
+      const uint64_t worst = (uint64_t)dk->block_ids.size() * ojphgpu_ht_decode_aux_words(4079) + 64;
+      dk->aux.release();
+      if (dk->aux.alloc((size_t)worst * 4 + 64)) return OJPHGPU_E_NOMEM;
+    }
+    ojphgpu_decoder* d = p->decs[0];
+    const size_t nb = d->block_ids.size();
     p->frame_bytes = (size_t)P.frame_elems * (size_t)(container_bits / 8);
     p->slots.resize(depth);
     for (DecSlot& s : p->slots) {
