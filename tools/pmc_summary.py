@@ -43,18 +43,33 @@ def main():
             ks = [k for k in names if sub in k and (tmpl is None or tmpl in k)]
             return ks[0] if ks else None
 
+        def clusters(v):
+            """launch sizes of one kernel: values grouped where they differ by less than 15 %"""
+            out_ = []
+            for x in sorted(v):
+                if out_ and x <= 1.15 * (sum(out_[-1]) / len(out_[-1])) + 1.0:
+                    out_[-1].append(x)
+                else:
+                    out_.append([x])
+            return out_
+
+        def two_sizes(v):
+            """a stage that runs as two launches per frame (lower resolutions / top resolution): the two smallest launch
+            sizes; the bench's one-launch-over-all-blocks objects (the largest size, when there are three) are left out"""
+            c = clusters(v)
+            return (c[0], c[1]) if len(c) >= 2 else (c[0], c[0]) if c else ([], [])
+
         def traffic(k, sel=None):
             if k is None:
                 return None
             f, w = fe.get(k, []), wr.get(k, [])
-            if sel is not None:               # launches of one kernel that alternate between two sizes
-                big_f = sorted(f)[len(f) // 2:] if sel == "big" else sorted(f)[:len(f) // 2]
-                big_w = sorted(w)[len(w) // 2:] if sel == "big" else sorted(w)[:len(w) // 2]
-                f, w = big_f, big_w
+            if sel is not None:
+                f = two_sizes(f)[1 if sel == "big" else 0]
+                w = two_sizes(w)[1 if sel == "big" else 0]
             return int((2 * avg(f) + avg(w)) * 1024)
 
         enc = pick("ht_encode_kernel")
-        two = enc is not None and len(fe.get(enc, [])) >= 4 and max(fe[enc]) > 1.5 * min(fe[enc])
+        two = enc is not None and len(clusters(fe.get(enc, []))) >= 2
         out = {
             "_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from the PMC passes summarised next to this "
                      "file; x2 = gfx950 FETCH_SIZE correction (calibrated on an elementwise kernel of known traffic in "
@@ -63,8 +78,10 @@ def main():
         }
         s2 = pick("ht_dec_step2")                            # two launches per frame when the decoder overlaps the lower
         if s2 is not None:                                   # synthesis levels with the top resolution's blocks
-            per_frame = max(1, round(len(fe.get(s2, [])) / max(len(fe.get(pick("ht_dec_step1"), [])), 1)))
-            out["ht_dec_step2"] = traffic(s2) * per_frame
+            if len(clusters(fe.get(s2, []))) >= 2:
+                out["ht_dec_step2"] = traffic(s2, "big") + traffic(s2, "small")
+            else:
+                out["ht_dec_step2"] = traffic(s2)
         if two:
             out["ht_encode[top resolution, side stream]"] = traffic(enc, "big")
             out["ht_encode[lower resolutions]"] = traffic(enc, "small")

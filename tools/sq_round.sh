@@ -22,17 +22,22 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
         for dd in disp.values():
             for c, x in dd.items(): tot[c] += x
         print(k[:70], " launches", n, " ".join("%s=%.4g" % (c, x / n) for c, x in sorted(tot.items())))
-        if d.endswith("sq1") and "ht_encode_kernel" in k:
-            # per frame: the launches alternate top resolution (big) / lower resolutions (small)
-            v = sorted(dd.get("SQ_INSTS_VALU", 0.0) for dd in disp.values()); s_ = sorted(dd.get("SQ_INSTS_SALU", 0.0) for dd in disp.values())
-            h = len(v) // 2
-            out["ht_encode[top resolution, side stream]"] = {"valu_insts": sum(v[h:]) / max(len(v[h:]), 1), "salu_insts": sum(s_[h:]) / max(len(s_[h:]), 1)}
-            out["ht_encode[lower resolutions]"] = {"valu_insts": sum(v[:h]) / max(h, 1), "salu_insts": sum(s_[:h]) / max(h, 1)}
+        if d.endswith("sq1") and ("ht_encode_kernel" in k or "ht_dec_step2" in k):
+            # per frame these stages are two launches: the lower resolutions' blocks (fewer wavefronts) and the top
+            # resolution's; the bench's one-launch-over-all-blocks objects (most wavefronts) are left out
+            groups = collections.defaultdict(list)
+            for dd in disp.values(): groups[int(dd.get("SQ_WAVES", 0))].append(dd)
+            sizes = sorted(groups)
+            if len(sizes) >= 3: sizes = sizes[:2]
+            avg = lambda g, c: sum(dd.get(c, 0.0) for dd in groups[g]) / len(groups[g])
+            if "ht_encode_kernel" in k and len(sizes) == 2:
+                out["ht_encode[lower resolutions]"] = {"valu_insts": avg(sizes[0], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[0], "SQ_INSTS_SALU"), "wavefronts": sizes[0]}
+                out["ht_encode[top resolution, side stream]"] = {"valu_insts": avg(sizes[1], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[1], "SQ_INSTS_SALU"), "wavefronts": sizes[1]}
+            if "ht_dec_step2" in k:
+                out["ht_dec_step2"] = {"valu_insts": sum(avg(g, "SQ_INSTS_VALU") for g in sizes), "salu_insts": sum(avg(g, "SQ_INSTS_SALU") for g in sizes), "wavefronts": sum(sizes)}
         for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep")):
             if d.endswith("sq1") and sub in k:
                 out[key] = {"valu_insts": tot["SQ_INSTS_VALU"] / n, "salu_insts": tot["SQ_INSTS_SALU"] / n}
-        if d.endswith("sq1") and "ht_dec_step2" in k:      # two launches per frame
-            out["ht_dec_step2"] = {"valu_insts": 2 * tot["SQ_INSTS_VALU"] / n, "salu_insts": 2 * tot["SQ_INSTS_SALU"] / n}
 json.dump({"c3_8k_444_12b_irv97": dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")}, open("gpurun_out/sq_counters.json", "w"), indent=1)
 PY
 find gpurun_out/sq1 gpurun_out/sq2 -type f -size +4M -delete
