@@ -8,7 +8,7 @@
 // de-quantise transfer gen_rev/irv_tx_from_cb32 (src/core/codestream/ojph_codestream_gen.cpp:
 // 124-168); zero blocks / failures: codeblock::decode + pull_line (ojph_codeblock.cpp:190-266).
 //
-// Three launches per frame:
+// Three launches per frame (step 2 as two: lower resolutions, top resolution):
 //   prep    (ht_dec_prep_kernel)   ONE WAVEFRONT PER CODE-BLOCK.  Byte un-stuffing only looks at the
 //           previous raw byte, so the bit offset of every byte is a wavefront prefix sum (the idea
 //           of the reference's AVX2 decoder, ojph_block_decoder_avx2.cpp:277-386).  The backward
@@ -17,17 +17,23 @@
 //   step 1  (ht_dec_step1_kernel)  The MEL / VLC / U-VLC stage is a serial state machine: where a
 //           codeword starts depends on every earlier codeword and on the neighbour context.  ONE
 //           LANE owns one code-block's chain and a wavefront advances 64 independent chains in
-//           lock step.  Everything that is not on the chain was moved off it: bits come from the
-//           flat strings (VLC: two words + one prefetched word in registers, one v_alignbit per look,
-//           no branch; no un-stuffing), the adaptive MEL run-length code is expanded ahead of time into
-//           a 64-entry event queue held in a register pair, the significance of the quad row above
-//           lives in two 64-bit masks, the decode tables in LDS.  Output: one 32-bit record per quad
-//           {t-word, u_q}.  Tried and dropped in round 2 -- the MEL decoder taken out of this chain:
-//           (a) run by the prep kernel, one bit per MEL event for step 1: step 1 0.21 -> 0.18 ms, but
-//           the decoder is scalar code there (one wavefront per block), 300 M scalar instructions per 8K
-//           frame through one scalar unit per CU: prep 0.07 -> 1.0 ms; (b) a launch of its own, one lane
-//           per block beside prep: 0.24 ms for that launch (byte-wise un-stuffing and the symbol loop
-//           diverge between the 64 blocks of a wavefront), longer than what it saves.
+//           lock step.  Such a wavefront is alone on its SIMD and issues one instruction every ~6 cycles
+//           whatever it waits for: the launch time is instructions per quad pair x pairs x 6 cycles
+//           (measured: no change without the VLC word loads; slower when the LDS round trips were
+//           hidden by software pipelining at the price of 20 more instructions; slower with 32 or 16
+//           blocks per wavefront).  So everything that can leave the chain wavefront has left it:
+//           bits come from the flat strings (VLC: two words + one prefetched word in registers, one
+//           v_alignbit per look, no branch; no un-stuffing); the adaptive MEL run-length code is
+//           decoded by a PARTNER WAVEFRONT of the same workgroup (another SIMD; most are idle during
+//           this launch) into an event string in LDS that the chain reads one bit per event; the
+//           U-VLC of rows after the first is decoded by arithmetic (ht_uvlc.h) instead of a table in
+//           LDS; the significance of the quad row above lives in two 64-bit masks, the VLC tables in
+//           LDS.  Output: one 32-bit record per quad {t-word, u_q}.  Earlier attempts to take the MEL
+//           decoder out of the chain, dropped: (a) run by the prep kernel, one bit per MEL event for
+//           step 1: step 1 0.21 -> 0.18 ms, but the decoder is scalar code there (one wavefront per
+//           block), 300 M scalar instructions per 8K frame through one scalar unit per CU: prep 0.07 ->
+//           1.0 ms; (b) a launch of its own, one lane per block beside prep: 0.24 ms for that launch
+//           (byte-wise un-stuffing and the symbol loop diverge between the 64 blocks of a wavefront).
 //   step 2  (ht_dec_step2_kernel)  ONE WAVEFRONT PER CODE-BLOCK, ONE LANE PER SAMPLE COLUMN.  A lane
 //           decodes the two samples of its column in the current quad row -- they are adjacent in
 //           the MagSgn bit string, so a wavefront prefix sum of the lanes' bit counts gives every
