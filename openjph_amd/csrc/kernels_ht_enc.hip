@@ -150,10 +150,34 @@ __device__ __forceinline__ void mel_one(MelState& m, uint8_t* buf, int lane)
   m.run = 0; m.k = m.k > 0 ? m.k - 1 : 0;
 }
 
+// A slot of `bytes` (multiple of 4) in the compacted output for block bi; 0xFFFFFFFF when it does not fit.
+// One cursor for the whole output is ONE cache line that every block's atomic goes to: same-address device-scope
+// atomics complete at ~55 M/s on this part (they are resolved at the memory side, the XCDs' L2s are not coherent
+// with each other), 18 000 of them are 0.33 ms -- the top resolution's launch could not get below 0.39 ms, a quarter of
+// it waiting in that queue (measured with the allocation taken out).  With `nreg` regions (a power of two) block bi
+// allocates in region bi % nreg: regions[2r] = first byte, regions[2r + 1] = bytes, its cursor in a cache line of its
+// own at cursor[32 r].  nreg = 0: the single cursor of the C ABI entry point.
+__device__ __forceinline__ uint32_t claim_output(uint32_t* cursor, const uint32_t* regions, uint32_t nreg, uint32_t bi,
+                                                 uint32_t bytes, uint32_t out_cap, int lane)
+{
+  uint32_t base = 0, cap = out_cap;
+  uint32_t* cur = cursor;
+  if (nreg) {
+    const uint32_t r = bi & (nreg - 1u);
+    base = regions[2u * r]; cap = regions[2u * r + 1u];
+    cur = cursor + 32u * r;
+  }
+  uint32_t off = 0;
+  if (lane == 0) off = atomicAdd(cur, bytes);
+  off = rdfirst(off);
+  return (off > cap || bytes > cap - off) ? 0xFFFFFFFFu : base + off;
+}
+
 __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
-    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
+    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status,
+    const uint32_t* __restrict__ regions, uint32_t nreg)
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ WaveLds s_wave[WAVES];
@@ -459,9 +483,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
   uint32_t off = 0;
   if (err) total = 0;
   if (total) {                                            // slots are 4-byte aligned (ht_encode_kernel stores dwords)
-    if (lane == 0) off = atomicAdd(cursor, (total + 3u) & ~3u);
-    off = rdfirst(off);
-    if (off + ((total + 3u) & ~3u) > out_cap) { err = 1; total = 0; }
+    off = claim_output(cursor, regions, nreg, bi, (total + 3u) & ~3u, out_cap, lane);
+    if (off == 0xFFFFFFFFu) { err = 1; total = 0; off = 0; }
   }
   if (total) {
     const uint32_t scup = mel.pos + v_pos;
@@ -548,7 +571,8 @@ template <bool REV>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES_PER_EU, 8))) void ht_encode_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
-    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status)
+    ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status,
+    const uint32_t* __restrict__ regions, uint32_t nreg)
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ uint32_t s_uvlc[64];                   // U-VLC codewords of u = 0..63 (u <= 31 here), see uvlc_word
@@ -953,9 +977,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   uint32_t off = 0;
   if (err) total = 0;
   if (total) {
-    if (lane == 0) off = atomicAdd(cursor, (total + 3u) & ~3u);
-    off = rdfirst(off);
-    if (off + ((total + 3u) & ~3u) > out_cap) { err = 1; total = 0; }
+    off = claim_output(cursor, regions, nreg, bi, (total + 3u) & ~3u, out_cap, lane);
+    if (off == 0xFFFFFFFFu) { err = 1; total = 0; off = 0; }
   }
   if (total) {
     const uint32_t scup = mel.pos + v_pos;
@@ -1005,11 +1028,12 @@ namespace ojphgpu {
 // blocks of the other kind, so a caller that does not know passes 3 (wavelet bits clear = both).
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
-                     int widths)
+                     int widths, const uint32_t* d_regions, uint32_t nreg)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
   if (!d_blocks || !d_coef || !d_scratch || !d_out || !d_results || !d_cursor || !d_status) return OJPHGPU_E_INVALID;
+  if (nreg && (!d_regions || (nreg & (nreg - 1u)))) return OJPHGPU_E_INVALID;
   dim3 grid((n + WAVES - 1) / WAVES);
   if ((widths & 12) == 0) widths |= 12;                   // the caller does not know the wavelets: both instantiations
   // timing experiment: dynamic LDS nobody uses lowers the workgroups per CU (OJPHGPU_ENC_LDS_BALLAST bytes)
@@ -1017,13 +1041,13 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   const dim3 ngrid((n + NWAVES - 1) / NWAVES);
   if ((widths & 1) && (widths & 4))
     hipLaunchKernelGGL(ht_encode_kernel<true>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if ((widths & 1) && (widths & 8))
     hipLaunchKernelGGL(ht_encode_kernel<false>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 }  // namespace ojphgpu
@@ -1032,7 +1056,7 @@ extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, 
                                   const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
                                   ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status)
 {
-  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3);
+  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3, nullptr, 0);
 }
 
 namespace ojphgpu {

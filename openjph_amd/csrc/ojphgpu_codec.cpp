@@ -55,7 +55,7 @@ extern "C" void ojphgpu_encoder_destroy(ojphgpu_encoder* e)
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (DeviceBuf* b : { &e->arena, &e->image, &e->dwt_descs, &e->img_descs, &e->cb_descs, &e->conv_descs, &e->scratch, &e->out,
-                        &e->results, &e->counters }) b->release();
+                        &e->results, &e->counters, &e->regions }) b->release();
   e->h_out.release(); e->h_res.release();
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -155,13 +155,37 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   for (const Band& B : P.bands) kmax_all = std::max(kmax_all, B.K_max);
   uint64_t cap = kmax_all > 20 ? scratch_bytes : std::min<uint64_t>(scratch_bytes, samples * 3 + (1u << 20));
   cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
+  // ... split into regions (see ojphgpu_objects.h): a region holds the sum of its own blocks' shares of that bound
+  {
+    const char* ev = getenv("OJPHGPU_ENC_REGIONS"); const long v = ev ? atol(ev) : 16;
+    uint32_t R = (v >= 0 && v <= 64 && (v & (v - 1)) == 0) ? (uint32_t)v : 16u;
+    if (bd.size() < 4 * (size_t)R) R = 0;                   // a handful of blocks: one cursor
+    std::vector<uint64_t> rc(R ? R : 1, 0);
+    if (R) for (size_t i = 0; i < bd.size(); ++i) {
+      const uint64_t own = kmax_all > 20 ? bd[i].scratch_cap : std::min<uint64_t>(bd[i].scratch_cap, (uint64_t)bd[i].w * bd[i].h * 3 + 64);
+      rc[(i < e->n_top ? i : i - e->n_top) & (R - 1)] += own;   // the kernel sees the index inside its launch
+    }
+    uint64_t total = 0;
+    e->h_regions.assign(2 * (size_t)R, 0);
+    for (uint32_t r = 0; r < R; ++r) {
+      const uint64_t c = (rc[r] + (1u << 16) + 255) & ~(uint64_t)255;
+      if (total + c > 0xFFFFFF00ull) { R = 0; break; }      // the byte offsets are 32 bits wide: one clamped cursor, as before
+      e->h_regions[2 * r] = (uint32_t)total; e->h_regions[2 * r + 1] = (uint32_t)c;
+      total += c;
+    }
+    e->nreg = R;
+    if (R) cap = total; else e->h_regions.clear();
+    e->counters_bytes = R ? (size_t)R * 128 : 16;
+  }
   e->out_cap = (uint32_t)cap;
 
   if (e->arena.alloc(P.arena_elems * 4 * nframes) || e->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       e->img_descs.alloc(idd.size() * sizeof(dd[0])) || e->cb_descs.alloc(bd.size() * sizeof(bd[0])) || e->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       e->scratch.alloc(scratch_bytes) || e->out.alloc(cap) ||
-      e->results.alloc(bd.size() * sizeof(ojphgpu_cb_result)) || e->counters.alloc(16))
+      e->results.alloc(bd.size() * sizeof(ojphgpu_cb_result)) || e->counters.alloc(e->counters_bytes) ||
+      (e->nreg && e->regions.alloc(e->h_regions.size() * 4)))
     return bail(OJPHGPU_E_NOMEM);
+  if (e->nreg && hipMemcpy(e->regions.p, e->h_regions.data(), e->h_regions.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (hipMemset(e->arena.p, 0, P.arena_elems * 4 * nframes) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(e->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!idd.empty() && hipMemcpy(e->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
@@ -192,7 +216,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
   uint8_t* const d_out = (uint8_t*)(e->o_out ? e->o_out : e->out.p);          // a pipeline slot's buffers, or the object's own
   ojphgpu_cb_result* const res = (ojphgpu_cb_result*)(e->o_results ? e->o_results : e->results.p);
   uint32_t* const cnt = (uint32_t*)(e->o_counters ? e->o_counters : e->counters.p);
-  HIPCHK(hipMemsetAsync(cnt, 0, 16, s));
+  HIPCHK(hipMemsetAsync(cnt, 0, e->counters_bytes, s));
   T.start(s);
   int rc = OJPHGPU_OK;
   if (e->need_convert) {
@@ -210,7 +234,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
     HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     const int sh = T.begin(SP_HT_ENC, e->side);
     int r2 = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, d_out,
-                                       e->out_cap, res, cnt, cnt + 1, e->widths_top);
+                                       e->out_cap, res, cnt, cnt + 1, e->widths_top, (const uint32_t*)e->regions.p, e->nreg);
     if (r2) return r2;
     T.end(sh, e->side);
     HIPCHK(hipEventRecord(e->ev_join, e->side));
@@ -235,7 +259,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
   const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
   const int sh = T.begin(SP_HT_ENC, s);
   rc = ojphgpu::ht_encode_launch(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p,
-                                 d_out, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest);
+                                 d_out, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest, (const uint32_t*)e->regions.p, e->nreg);
   if (rc) return rc;
   T.end(sh, s);
   if (e->n_top) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));     // join
@@ -254,11 +278,13 @@ extern "C" int ojphgpu_encoder_set_timing(ojphgpu_encoder* e, int per_launch)
 extern "C" int ojphgpu_encoder_coded_bytes(ojphgpu_encoder* e, uint64_t* bytes)
 {
   if (!e || !bytes || !e->ran) return OJPHGPU_E_INVALID;
-  uint32_t c[2] = { 0, 0 };
-  HIPCHK(hipMemcpyAsync(c, e->counters.p, 8, hipMemcpyDeviceToHost, e->stream));
+  e->h_cursors.assign(e->counters_bytes / 4, 0);
+  HIPCHK(hipMemcpyAsync(e->h_cursors.data(), e->counters.p, e->counters_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  *bytes = c[0];
-  return c[1] ? OJPHGPU_E_OVERFLOW : OJPHGPU_OK;
+  uint64_t total = e->h_cursors[0];
+  for (uint32_t r = 1; r < e->nreg; ++r) total += e->h_cursors[32 * (size_t)r];
+  *bytes = total;
+  return e->h_cursors[1] ? OJPHGPU_E_OVERFLOW : OJPHGPU_OK;
 }
 
 // D2H of the block bytes + lengths of the last run (once per run); fills the plan-order coded-block
@@ -274,9 +300,24 @@ static int encoder_fetch(ojphgpu_encoder* e, uint32_t frame, std::vector<ojphgpu
     if (e->h_out.reserve(std::max<size_t>((size_t)e->nbytes + 16, (size_t)e->out_cap / 4)) || e->h_res.reserve(rbytes + 16))
       return OJPHGPU_E_NOMEM;
     if (rbytes) HIPCHK(hipMemcpyAsync(e->h_res.p, e->results.p, rbytes, hipMemcpyDeviceToHost, e->stream));
-    if (e->nbytes) HIPCHK(hipMemcpyAsync(e->h_out.p, e->out.p, (size_t)e->nbytes, hipMemcpyDeviceToHost, e->stream));
+    // the used part of every region goes to a compact host buffer; the blocks' offsets are moved along below
+    std::vector<uint64_t> hpos(e->nreg ? e->nreg : 1, 0);
+    if (e->nreg) {
+      uint64_t at = 0;
+      for (uint32_t r = 0; r < e->nreg; ++r) {
+        const uint32_t used = e->h_cursors[32 * (size_t)r];
+        hpos[r] = at;
+        if (used) HIPCHK(hipMemcpyAsync(e->h_out.p + at, (const uint8_t*)e->out.p + e->h_regions[2 * r], used, hipMemcpyDeviceToHost, e->stream));
+        at += used;
+      }
+    } else if (e->nbytes) HIPCHK(hipMemcpyAsync(e->h_out.p, e->out.p, (size_t)e->nbytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (rbytes) memcpy(e->h_results.data(), e->h_res.p, rbytes);
+    if (e->nreg)
+      for (size_t i = 0; i < e->h_results.size(); ++i) {
+        const uint32_t r = (uint32_t)(i < e->n_top ? i : i - e->n_top) & (e->nreg - 1);
+        if (e->h_results[i].length) e->h_results[i].offset = (uint32_t)(e->h_results[i].offset - e->h_regions[2 * r] + hpos[r]);
+      }
     e->fetched = true;
   }
   cb.assign(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
@@ -350,6 +391,7 @@ extern "C" int ojphgpu_encoder_finish_tiles_device(ojphgpu_encoder* e, uint8_t* 
     const size_t rbytes = e->h_results.size() * sizeof(ojphgpu_cb_result);
     if (rbytes) HIPCHK(hipMemcpyAsync(e->h_results.data(), e->results.p, rbytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    e->fetched = false;                                   // h_results holds device offsets again
     std::vector<ojphgpu_coded_block> cb(P.blocks.size(), ojphgpu_coded_block{ 0, 0, 0, 0, 0 });
     for (size_t i = 0; i < nb; ++i) {
       const ojphgpu_cb_result& r = e->h_results[i];

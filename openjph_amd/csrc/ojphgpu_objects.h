@@ -292,6 +292,13 @@ struct ojphgpu_encoder {
   // where a run writes its products: the object's own buffers (null), or -- for a frame pipeline that keeps
   // several frames in flight -- the buffers of the frame's slot (ojphgpu_pipe.cpp)
   void* o_out = nullptr; void* o_results = nullptr; void* o_counters = nullptr;
+  // The compacted output is split into nreg regions with a cursor each (block i allocates in region i % nreg), so
+  // that the blocks' allocation atomics do not all queue on one cache line (claim_output, kernels_ht_enc.hip).
+  // h_regions[2r] = first byte, [2r + 1] = capacity; counters: word 32 r = cursor of region r, word 1 = status.
+  uint32_t nreg = 0;
+  std::vector<uint32_t> h_regions, h_cursors;
+  DeviceBuf regions;
+  size_t counters_bytes = 16;
 };
 // the device part of an encode: d_image holds the frame in `container`-bit elements (32 / 16)
 int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container);

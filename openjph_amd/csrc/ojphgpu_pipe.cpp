@@ -250,7 +250,7 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     p->slots.resize(depth);
     for (EncSlot& s : p->slots) {
       if (s.h_in.reserve(p->frame_bytes + 64) || s.h_res.reserve(p->res_bytes + 64) || s.h_cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
-      if (s.image.alloc(p->frame_bytes + 64) || s.out.alloc((size_t)e->out_cap + 64) || s.counters.alloc(16) ||
+      if (s.image.alloc(p->frame_bytes + 64) || s.out.alloc((size_t)e->out_cap + 64) || s.counters.alloc(e->counters_bytes) ||
           s.cs.reserve(cs_guess)) return OJPHGPU_E_NOMEM;
       const size_t lay_guess = nb * sizeof(T2Job) + nb * 8 + (1u << 16);
       if (s.h_lay.reserve(lay_guess)) return OJPHGPU_E_NOMEM;
