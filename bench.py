@@ -534,18 +534,19 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
     frame goes in and one comes out in each direction)"""
     import threading
     nsamp = img.size
-    out = {"frames": n, "depth": 4, "sample_container_bits": container, "pcie_GBps_one_direction": pcie_bandwidth(torch)}
+    depth, threads = 6, 4                   # slots per pipe; host threads per pipe (finishers / parse workers)
+    out = {"frames": n, "depth": depth, "host_threads": threads, "sample_container_bits": container, "pcie_GBps_one_direction": pcie_bandwidth(torch)}
     if isinstance(cs, (list, tuple)):
         cs = cs[0]
-    dt, st = run_encoder_pipe(plan, img, n, container=container, want=cs)
+    dt, st = run_encoder_pipe(plan, img, n, depth, threads, container=container, want=cs)
     out["encode"] = {"Msamples_s": round(nsamp * n / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
                      "host_tier2_ms": round(st["host_tier2_ms"], 3), "latency_ms": round(st["latency_ms"], 2), "tier2_threads": st["tier2_threads"]}
-    dt, st = run_decoder_pipe(cs, n, container=container)
+    dt, st = run_decoder_pipe(cs, n, depth, threads, container=container)
     out["decode"] = {"Msamples_s": round(nsamp * n / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
                      "host_parse_ms": round(st["host_parse_ms"], 3), "latency_ms": round(st["latency_ms"], 2)}
     res = {}
-    te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, container=container)))
-    td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, container=container)))
+    te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container)))
+    td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container)))
     t0 = time.perf_counter()
     te.start(); td.start(); te.join(); td.join()
     if "e" in res and "d" in res:
