@@ -500,3 +500,31 @@ def test_multi_pass_codestream_decodes_like_the_oracle():
         want, _ = cp.decode(cs)
         got = codec.decode(cs)
         assert np.array_equal(got, want), "%d samples differ" % int((got != want).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regions", [0, 2, 8])
+def test_encoder_output_regions(regions, monkeypatch):
+    """the block encoder's compacted output split into regions with a cursor each (claim_output): same codestream
+    with one cursor, two and eight regions, on noise that fills the blocks' bounds; the host path (used parts of
+    the regions gathered, offsets moved along) and the device path (offsets as they are) can be mixed on one run"""
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.plan import Plan, make_params
+    from tests import cpu_pipeline as cp
+    monkeypatch.setenv("OJPHGPU_ENC_REGIONS", str(regions))
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 1 << 16, size=(1, 300, 500), dtype=np.int64).astype(np.int32)       # incompressible
+    c = dict(tile=(256, 256), block=(32, 32), tlm=True)
+    plan = Plan(make_params(500, 300, 1, bit_depth=16, **c))
+    want, *_ = cp.encode(img, bit_depth=16, **c)
+    enc = codec.Encoder(plan=plan)
+    enc.run_device(torch.from_numpy(img).cuda())
+    assert enc.finish() == want
+    dpart, lens = enc.finish_tiles_device()
+    hpart, lens2 = enc.finish_tiles()
+    assert bytes(dpart.cpu().numpy().tobytes()) == hpart and np.array_equal(lens, lens2)
+    assert enc.finish() == want
+    assert enc.coded_bytes() >= sum(int(x) for x in lens) - 64 * plan.num_tiles - 4096
+    out = codec.decode(want)
+    assert np.array_equal(out, img)
