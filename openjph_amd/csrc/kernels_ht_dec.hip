@@ -689,28 +689,24 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
         if (at >= dst_bits) win = ~0ull;
         else if (at + 64 > dst_bits) win |= ~0ull << (dst_bits - at);
       }
-      uint32_t out0, out1, v1 = 0;
+      // both samples without branches: m0 / m1 are 0 for an insignificant sample, its value is masked away at the end
+      uint32_t out0, out1, v1;
       {
-        uint32_t val = 0;
-        if (sel & 0x10u) {
-          const uint32_t ms_val = (uint32_t)win;
-          uint32_t v_n = ms_val & ((1u << m0) - 1u);                                    // :1127-1133
-          v_n |= ((sel >> 8) & 1u) << m0;
-          v_n |= 1u;
-          val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
-        }
+        const uint32_t ms_val = (uint32_t)win;
+        uint32_t v_n = ms_val & ((1u << m0) - 1u);                                      // :1127-1133
+        v_n |= ((sel >> 8) & 1u) << m0;
+        v_n |= 1u;
+        const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1))) & (uint32_t)(-(int32_t)((sel >> 4) & 1u));
         out0 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       {
-        uint32_t val = 0;
-        if (sel & 0x20u) {
-          const uint32_t ms_val = (uint32_t)(win >> m0);
-          uint32_t v_n = ms_val & ((1u << m1) - 1u);
-          v_n |= ((sel >> 9) & 1u) << m1;
-          v_n |= 1u;
-          val = (ms_val << 31) | ((v_n + 2u) << (p - 1));
-          v1 = v_n;
-        }
+        const uint32_t ms_val = (uint32_t)(win >> m0);
+        uint32_t v_n = ms_val & ((1u << m1) - 1u);
+        v_n |= ((sel >> 9) & 1u) << m1;
+        v_n |= 1u;
+        const uint32_t keep = (uint32_t)(-(int32_t)((sel >> 5) & 1u));
+        const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1))) & keep;
+        v1 = v_n & keep;
         out1 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       const uint32_t e_new = v1 ? 31u - (uint32_t)__clz((int)v1) : 0u;
