@@ -434,17 +434,21 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __r
         k0 = (((sg | (sg >> 1)) & 1u) << 7) | ((((sg >> 2) | (sg >> 3)) & 1u) << 9);
         k1 = ((((sg >> 2) | (sg >> 3)) & 1u) << 7) | ((((sg >> 4) | (sg >> 5)) & 1u) << 9);
       }
-      uint32_t c_q = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1) | k0;                  // :1022
-      uint32_t t0 = tbl[c_q + (v & 0x7Fu)];
-      if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t0 = 0; ecnt++; }
+      // both look-ups and their MEL corrections as selects, no branches (the second quad of an odd-width block's last
+      // pair does not exist: its look-up is made all the same and dropped)
+      const uint32_t c_q0 = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1) | k0;           // :1022
+      uint32_t t0 = tbl[c_q0 + (v & 0x7Fu)];
+      const bool z0 = c_q0 == 0;
+      t0 = (z0 & ((evq & 1u) == 0)) ? 0u : t0;
+      ecnt = z0 ? 1u : 0u;
       v >>= (t0 & 7u); used += t0 & 7u;
-      uint32_t t1 = 0;
-      if (qx + 1 < QW) {
-        c_q = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1) | k1;                               // :1059
-        t1 = tbl[c_q + (v & 0x7Fu)];
-        if (c_q == 0) { if (((evq >> ecnt) & 1u) == 0) t1 = 0; ecnt++; }
-        v >>= (t1 & 7u); used += t1 & 7u;
-      }
+      const bool ex1 = qx + 1 < QW;
+      const uint32_t c_q1 = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1) | k1;                 // :1059
+      uint32_t t1 = tbl[c_q1 + (v & 0x7Fu)];
+      const bool z1 = ex1 & (c_q1 == 0);
+      t1 = ((!ex1) | (z1 & (((evq >> ecnt) & 1u) == 0))) ? 0u : t1;
+      ecnt += z1 ? 1u : 0u;
+      v >>= (t1 & 7u); used += t1 & 7u;
       tleft = t1;
       if (NARROW) {
         const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
