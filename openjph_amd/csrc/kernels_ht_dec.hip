@@ -411,7 +411,9 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __r
     uint32_t* row = rec + (size_t)qy * PW * REC_STRIDE;                 // quad pair px of this row: row + px * REC_STRIDE
     const uint32_t* above = row - (size_t)PW * REC_STRIDE;
     auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
-    uint32_t tleft = 0, carry = 0; uint64_t sig_cur = 0;
+    uint32_t tleft = 0; uint64_t sig_cur = 0;
+    const uint64_t sig_or = sig_prev | (sig_prev >> 1);
+    uint32_t carry = ((uint32_t)sig_prev & 1u) << 7;              // "column -1 | column 0", as bit 7 of the first context
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       uint32_t v = vlc.peek(), used = 0;
       const uint32_t evq = mel.peek(); uint32_t ecnt = 0;
@@ -419,11 +421,12 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __r
       // :1024-1027): bit 7 = nw | n, bit 9 = ne | nf, over the columns 2qx-1 .. 2qx+4
       uint32_t k0, k1;
       if (NARROW) {
-        const uint32_t w = (uint32_t)(sig_prev >> (2u * qx));      // bit i: column 2qx + i
-        const uint32_t m = (w >> 1) | (w >> 2);                    // bit 0: columns 2qx+1|2qx+2, bit 2: 2qx+3|2qx+4
-        k0 = (((carry | w) & 1u) << 7) | ((m & 1u) << 9);
-        k1 = ((m & 1u) << 7) | ((m & 4u) << 7);
-        carry = (w >> 3) & 1u;                                     // column 2qx+3 = 2(qx+2)-1
+        // sig_or bit j = column j | column j+1 of the row above: the three pairs a context needs sit at bits 2qx-1
+        // (kept from the previous pair as `carry`, already in place), 2qx+1 and 2qx+3
+        const uint32_t w = (uint32_t)(sig_or >> (2u * qx));
+        k0 = carry | ((w & 2u) << 8);
+        k1 = (w & 0xAu) << 6;
+        carry = (w & 8u) << 4;
       } else {
         const uint32_t up0 = above_rec(qx);
         const uint32_t upl = qx ? above_rec(qx - 1) : 0u;
