@@ -613,7 +613,24 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   uint32_t v_pend = 4, v_pos = 1, v_prev = 0xFF;        // pending bits in L.vlc, bytes "written" (incl. the head), last byte
   MelState mel = { 0, 0, 0, 0, 0, 0, 0 };
   uint32_t err = 0, any_sig = 0;
-  bool spilled = false;
+  // The output stage in LDS holds the bytes [ms_out, ms_k) of the MagSgn stream (growing up from outb[0]) and the VLC
+  // bytes (growing down from the top).  Most blocks fit; when the two would meet (more than ~5 KB: deep samples at
+  // high rates, e.g. 16-bit lossless at 1.7 bytes per sample) the whole dwords of the MagSgn part are flushed to the
+  // block's 64-byte aligned scratch slot in HBM, the 0..3 bytes left over move to the front, and coding goes on in
+  // LDS -- so every byte that leaves for HBM leaves in aligned dwords, also at the end.
+  uint32_t ms_out = 0;
+  auto flush_stage = [&]() -> bool {
+    const uint32_t have = ms_k - ms_out, nwd = have >> 2;
+    if (ms_out + 4u * nwd > ms_cap) return false;
+    uint32_t* g = reinterpret_cast<uint32_t*>(ms_spill + ms_out);
+    for (uint32_t i = lane; i < nwd; i += 64) g[i] = L.out[i];
+    const uint32_t keep = L.out[nwd];                     // the bytes beyond the left-over ones are rewritten by what comes next
+    wave_sync();
+    if (lane == 0) L.out[0] = keep;
+    wave_sync();
+    ms_out += 4u * nwd;
+    return true;
+  };
 
   const uint32_t r = (uint32_t)lane >> 4, px = (uint32_t)lane & 15u;
   const bool pxok = px < PW;
@@ -674,13 +691,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       if (m_ff) { const uint32_t lf = (uint32_t)__builtin_ctzll(m_ff); f_ff = 4u * lf + ((uint32_t)__builtin_ctz(rdlane(ffm, (int)lf)) >> 3); }
       const uint32_t nc = min(n_ok, f_ff + 1u);
       if (nc == 0) break;
-      if (!spilled && ms_k + nc + v_pos + 72u > OUT_CAP) {          // the stage is full: MagSgn moves to HBM
-        if (ms_k > ms_cap) { err = 1; break; }
-        for (uint32_t i = lane; i < ms_k; i += 64) ms_spill[i] = outb[i];
-        spilled = true;
-      }
-      if (spilled && ms_k + nc > ms_cap) { err = 1; break; }
-      uint8_t* dstb = (spilled ? ms_spill : outb) + ms_k + 4u * (uint32_t)lane;
+      if (ms_k - ms_out + nc + v_pos + 72u > OUT_CAP && !flush_stage()) { err = 1; break; }   // the stage is full
+      uint8_t* dstb = outb + (ms_k - ms_out) + 4u * (uint32_t)lane;
       const uint32_t mine = nc > 4u * (uint32_t)lane ? min(4u, nc - 4u * (uint32_t)lane) : 0u;
       if (mine > 0) dstb[0] = (uint8_t)bytes;
       if (mine > 1) dstb[1] = (uint8_t)(bytes >> 8);
@@ -711,11 +723,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       const bool sp = fs < ft;
       if (n8 == 0 && !sp) break;
       if (v_pos + n8 + 1 >= (uint32_t)VLC_CAP) { err = 1; break; }
-      if (!spilled && ms_k + v_pos + n8 + 72u > OUT_CAP) {
-        if (ms_k > ms_cap) { err = 1; break; }
-        for (uint32_t i = lane; i < ms_k; i += 64) ms_spill[i] = outb[i];
-        spilled = true;
-      }
+      if (ms_k - ms_out + v_pos + n8 + 72u > OUT_CAP && !flush_stage()) { err = 1; break; }
       if ((uint32_t)lane < n8) outb[OUT_CAP - 1 - (v_pos + lane)] = (uint8_t)v8;
       if (sp && (uint32_t)lane == fs) outb[OUT_CAP - 1 - (v_pos + lane)] = 0x7F;
       const uint32_t last8 = n8 ? rdlane(v8, (int)(n8 - 1)) : v_prev;
@@ -939,8 +947,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       const uint32_t maxb = ms_ff ? 7u : 8u, tt = maxb - ms_carry;
       const uint32_t tmp = ms_tmp0 | ((0xFFu & ((1u << tt) - 1u)) << ms_carry);
       if (tmp != 0xFF) {
-        if (spilled) { if (ms_len >= ms_cap) err = 1; else if (lane == 0) ms_spill[ms_len] = (uint8_t)tmp; }
-        else if (lane == 0) outb[ms_len] = (uint8_t)tmp;
+        if (lane == 0) outb[ms_len - ms_out] = (uint8_t)tmp;
         ms_len++;
       }
     } else if (ms_ff) ms_len--;
@@ -983,8 +990,17 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   if (total) {
     const uint32_t scup = mel.pos + v_pos;
     const uint32_t tail = mel.pos + v_pos;
-    if (!spilled && total <= OUT_CAP) {
-      // close the gap: MEL and VLC bytes move down behind the MagSgn bytes (destination <= source)
+    const uint32_t gpart = min(ms_out, ms_len), local = ms_len - gpart;   // MagSgn bytes in the scratch slot / still in the stage
+    uint8_t* dst = out + off;
+    if (gpart) {                                          // (ms_out is a multiple of 4; ms_len < ms_out only when a final 0xFF was dropped)
+      const uint32_t nwd = gpart >> 2;
+      const uint32_t* s32 = reinterpret_cast<const uint32_t*>(ms_spill);
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+      for (uint32_t i = lane; i < nwd; i += 64) d32[i] = s32[i];
+      if ((uint32_t)lane < (gpart & 3u)) dst[4u * nwd + lane] = ms_spill[4u * nwd + lane];
+    }
+    if ((gpart & 3u) == 0 && local + tail <= OUT_CAP) {
+      // close the gap: MEL and VLC bytes move down behind the MagSgn bytes of the stage (destination <= source)
       for (uint32_t base = 0; base < tail; base += 64) {
         const uint32_t i = base + lane;
         uint32_t b = 0;
@@ -994,18 +1010,17 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
         if (i < tail) {
           if (i == tail - 1) b = scup >> 4;
           else if (i == tail - 2) b = (b & 0xF0u) | (scup & 0xFu);
-          outb[ms_len + i] = (uint8_t)b;
+          outb[local + i] = (uint8_t)b;
         }
         wave_sync();
       }
-      uint32_t* dst = reinterpret_cast<uint32_t*>(out + off);
-      const uint32_t nw = (total + 3u) >> 2;
-      for (uint32_t i = lane; i < nw; i += 64) dst[i] = L.out[i];
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + gpart);
+      const uint32_t nw = (local + tail + 3u) >> 2;
+      for (uint32_t i = lane; i < nw; i += 64) d32[i] = L.out[i];
     } else {
-      uint8_t* dst = out + off;
-      for (uint32_t i = lane; i < total; i += 64) {
+      for (uint32_t i = gpart + lane; i < total; i += 64) {
         uint32_t b;
-        if (i < ms_len) b = spilled ? ms_spill[i] : outb[i];
+        if (i < ms_len) b = outb[i - ms_out];
         else if (i < ms_len + mel.pos) b = L.mel[i - ms_len];
         else b = outb[OUT_CAP - v_pos + (i - ms_len - mel.pos)];
         if (i == total - 1) b = scup >> 4;
