@@ -278,7 +278,8 @@ def main():
     kinfo = {}
     for k, (b, ms) in kernels.items():
         kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}
-    dom = max((k for k in kernels if "level 1" not in k), key=lambda k: kernels[k][1])
+    # the dominant LAUNCH: the "(all levels)" entries are families of launches (roofline_dwt reports them)
+    dom = max((k for k in kernels if "(all levels)" not in k), key=lambda k: kernels[k][1])
     dom_b, dom_ms = kernels[dom]
     achieved = dom_b / 1e6 / dom_ms if dom_ms > 0 else 0.0
     traffic = None
