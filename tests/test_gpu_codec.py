@@ -528,3 +528,20 @@ def test_encoder_output_regions(regions, monkeypatch):
     assert enc.coded_bytes() >= sum(int(x) for x in lens) - 64 * plan.num_tiles - 4096
     out = codec.decode(want)
     assert np.array_equal(out, img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 256), (190, 250)], ids=["aligned", "ragged"])
+def test_blocks_larger_than_the_lds_output_stage(shape):
+    """incompressible 16-bit samples code ~2 bytes per sample: every 64x64 block overflows the block encoder's 5 KB
+    LDS stage and goes through its flush path (whole dwords to the block's scratch slot, coding goes on in LDS)"""
+    from openjph_amd import codec
+    from tests import cpu_pipeline as cp
+    h, w = shape
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 1 << 16, size=(1, h, w), dtype=np.int64).astype(np.int32)
+    want, *_ = cp.encode(img, bit_depth=16)
+    assert len(want) > 1.6 * h * w                      # the blocks are > 5 KB
+    got = codec.encode(img, bit_depth=16)
+    assert got == want
+    assert np.array_equal(codec.decode(got), img)
