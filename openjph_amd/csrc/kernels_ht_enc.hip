@@ -566,8 +566,11 @@ __device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
 }
 
 // REV: the quantise transfer of the blocks this instantiation codes (5/3 integer or 9/7 float coefficients) is a
-// compile-time property -- a launch over blocks of both kinds runs both instantiations, each skipping the other's
-template <bool REV>
+// compile-time property -- a launch over blocks of both kinds runs both instantiations, each skipping the other's.
+// LOGP: a step covers 2^LOGP quad pairs across (lane & (2^LOGP - 1)) by 64 / 2^LOGP quad rows down.  4 = the layout
+// described above (blocks up to 64 columns, 4 quad rows per step); 3 = blocks up to 32 columns (the 32 x 32 blocks of
+// the IMF profile), 8 quad rows per step -- with the 16-pair layout half of the lanes of such a block would idle.
+template <bool REV, int LOGP>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES_PER_EU, 8))) void ht_encode_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
@@ -587,7 +590,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
-  if (W > NARROW_MAX_W || (d.reversible != 0) != REV) return;             // ht_encode_wide_kernel's, or the other instantiation's
+  constexpr uint32_t PPR = 1u << LOGP, RPS = 64u >> LOGP;                 // quad pairs per row of a step, quad rows per step
+  if (W > NARROW_MAX_W || W > 4u * PPR || (d.reversible != 0) != REV) return;   // ht_encode_wide_kernel's, or another instantiation's
   if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
   NarrowLds& L = s_wave[wave];
   uint8_t* outb = reinterpret_cast<uint8_t*>(L.out);
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   uint8_t* ms_spill = scratch + d.data_off;                              // only used when the LDS stage overflows
   const uint32_t ms_cap = d.scratch_cap > (uint32_t)VLC_CAP ? d.scratch_cap - VLC_CAP : 0;
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1, PW = (QW + 1) >> 1;
-  const uint32_t nsteps = (QH + 3) >> 2;
+  const uint32_t nsteps = (QH + RPS - 1u) / RPS;
 
   for (int i = lane; i < PMS_WORDS; i += 64) L.ms[i] = 0;
   for (int i = lane; i < PVLC_WORDS; i += 64) L.vlc[i] = 0;
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     return true;
   };
 
-  const uint32_t r = (uint32_t)lane >> 4, px = (uint32_t)lane & 15u;
+  const uint32_t r = (uint32_t)lane >> LOGP, px = (uint32_t)lane & (PPR - 1u);
   const bool pxok = px < PW;
   const uint32_t x0 = 4u * px;
   const bool has_q1 = pxok && x0 + 2 < W;
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   uint32_t ntop[4], nbot[4];
   load_rows(r, ntop, nbot);
   for (uint32_t step = 0; step < nsteps && !err; ++step) {
-    const uint32_t qy = 4 * step + r;
+    const uint32_t qy = RPS * step + r;
     const bool active = pxok && qy < QH;
     const bool first_row = qy == 0;
     // quantise transfer + 2*mu_p in one go (ojph_codestream_gen.cpp:59-121, ojph_block_encoder.cpp:592-595): the
@@ -781,19 +785,19 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
         val[2 * k + j] = ((mag << 1) >> p) & ~1u; sgn[2 * k + j] = sg;
       }
     }
-    if (step + 1 < nsteps) load_rows(qy + 4, ntop, nbot);   // request the next step's samples now
+    if (step + 1 < nsteps) load_rows(qy + RPS, ntop, nbot); // request the next step's samples now
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = expo(val[i]);
     // ---- the row above: exponents / significance of its samples, columns x0-1 .. x0+4 ----
     uint32_t botpack = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) botpack |= (e[2 * k + 1] << (6 * k)) | ((val[2 * k + 1] ? 1u : 0u) << (24 + k));
-    const uint32_t give = lane >= 48 ? last_bot : botpack;
-    uint32_t above = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane - 16) & 63) << 2), (int)give);
+    const uint32_t give = (uint32_t)lane >= 64u - PPR ? last_bot : botpack;
+    uint32_t above = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane - (int)PPR) & 63) << 2), (int)give);
     if (first_row || !active) above = 0;
     uint32_t abl = dpp_prev(above), abr = dpp_next(above);
     if (px == 0) abl = 0;
-    if (px == 15) abr = 0;
+    if (px == PPR - 1u) abr = 0;
     last_bot = botpack;
     uint32_t Eab[6], Sab[6];
     Eab[0] = (abl >> 18) & 63u; Sab[0] = (abl >> 27) & 1u;
@@ -1039,7 +1043,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
 
 namespace ojphgpu {
 // `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones; bit 2 = it holds
-// blocks of reversibly transformed components, bit 3 = of irreversibly transformed ones.  Every kernel skips the
+// blocks of reversibly transformed components, bit 3 = of irreversibly transformed ones; bit 4 = none of its blocks of
+// up to 64 samples is wider than 32 (they take the 8-pairs-by-8-rows layout).  Every kernel skips the
 // blocks of the other kind, so a caller that does not know passes 3 (wavelet bits clear = both).
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
@@ -1054,11 +1059,17 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   // timing experiment: dynamic LDS nobody uses lowers the workgroups per CU (OJPHGPU_ENC_LDS_BALLAST bytes)
   static const unsigned ballast = [] { const char* e = getenv("OJPHGPU_ENC_LDS_BALLAST"); const long v = e ? atol(e) : 0; return v > 0 && v < 100000 ? (unsigned)v : 0u; }();
   const dim3 ngrid((n + NWAVES - 1) / NWAVES);
-  if ((widths & 1) && (widths & 4))
-    hipLaunchKernelGGL(ht_encode_kernel<true>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+  if ((widths & 1) && (widths & 4) && (widths & 16))
+    hipLaunchKernelGGL((ht_encode_kernel<true, 3>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
-  if ((widths & 1) && (widths & 8))
-    hipLaunchKernelGGL(ht_encode_kernel<false>, ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+  else if ((widths & 1) && (widths & 4))
+    hipLaunchKernelGGL((ht_encode_kernel<true, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
+  if ((widths & 1) && (widths & 8) && (widths & 16))
+    hipLaunchKernelGGL((ht_encode_kernel<false, 3>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
+  else if ((widths & 1) && (widths & 8))
+    hipLaunchKernelGGL((ht_encode_kernel<false, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
