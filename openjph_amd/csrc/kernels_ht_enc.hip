@@ -565,6 +565,72 @@ __device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
   return pre | (pl << 8) | (suf << 16) | (sl << 24);
 }
 
+// MEL coder of the narrow kernel (ojph_block_encoder.cpp:317-362): the adaptive run-length state machine is serial and
+// wave-uniform, i.e. scalar code, and it runs once per MEL event -- on content whose significance is scattered (a "1"
+// event every few quads: the usual lossy rates) it was a quarter of the whole encode.  So the serial part does the
+// minimum: it appends code bits to a 64-bit accumulator and stores a raw word every 32 bits; the byte stuffing
+// ("7 bits after an 0xFF") is done once per block by the whole wavefront (mel_stuff), the way the VLC bytes are made.
+struct MelFast {           // all wave-uniform
+  uint32_t k, run, nb, wpos, err; uint64_t acc;
+};
+constexpr uint32_t MEL_RAW_WORDS = MEL_CAP / 4;   // more raw bits than that cannot fit MEL_CAP bytes either
+
+__device__ __forceinline__ void melf_append(MelFast& m, uint32_t* raw, uint32_t code, uint32_t n, int lane)
+{
+  m.acc = (m.acc << n) | code; m.nb += n;
+  if (m.nb >= 32u) {
+    m.nb -= 32u;
+    if (m.wpos >= MEL_RAW_WORDS) m.err = 1;
+    else if (lane == 0) raw[m.wpos] = (uint32_t)(m.acc >> m.nb);       // MSB first: the first bit of the stream is bit 31 of word 0
+    m.wpos++;
+  }
+}
+
+__device__ __forceinline__ void melf_zero_run(MelFast& m, uint32_t* raw, uint32_t n, int lane)
+{
+  while (n > 0) {
+    const uint32_t need = (1u << mel_exp(m.k)) - m.run;
+    if (n >= need) { melf_append(m, raw, 1, 1, lane); n -= need; m.run = 0; m.k = m.k < 12 ? m.k + 1 : 12; }
+    else { m.run += n; n = 0; }
+  }
+}
+
+__device__ __forceinline__ void melf_one(MelFast& m, uint32_t* raw, int lane)
+{
+  melf_append(m, raw, m.run, mel_exp(m.k) + 1u, lane);      // a 0 followed by e bits of the run count
+  m.run = 0; m.k = m.k > 0 ? m.k - 1 : 0;
+}
+
+// raw bit string -> MEL bytes (mel_emit_bit / byte emission of :326-347): `raw` holds total_bits bits, MSB first, a
+// zero word behind them; bytes go to `out`.  Returns the state the termination code expects: bytes written, whether
+// the last one was 0xFF, and the bits (fewer than a byte) left over.
+__device__ __forceinline__ void mel_stuff(const uint32_t* raw, uint32_t total_bits, uint8_t* out, MelState& st, int lane)
+{
+  uint32_t pos = 0, bytes = 0, lastff = 0, err = 0;
+  for (;;) {
+    const uint32_t first = lastff ? 7u : 8u;
+    const uint32_t start = pos + (lane == 0 ? 0u : first + 8u * ((uint32_t)lane - 1u));
+    const uint32_t len = lane == 0 ? first : 8u;
+    const bool have = start + len <= total_bits;
+    const uint32_t w = start >> 5, sh = start & 31u;
+    const uint32_t x = have ? __funnelshift_l(raw[w + 1], raw[w], sh) >> (32u - len) : 0u;
+    const uint64_t m_have = __ballot(have), m_ff = __ballot(have && x == 0xFFu);
+    const uint32_t n_ok = m_have == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_have);
+    const uint32_t f_ff = m_ff ? (uint32_t)__builtin_ctzll(m_ff) : 64u;
+    const uint32_t nc = min(n_ok, f_ff + 1u);
+    if (nc == 0) break;
+    if (bytes + nc > (uint32_t)MEL_CAP) { err = 1; break; }
+    if ((uint32_t)lane < nc) out[bytes + lane] = (uint8_t)x;
+    bytes += nc;
+    pos += first + 8u * (nc - 1u);
+    lastff = f_ff < n_ok ? 1u : 0u;
+  }
+  const uint32_t left = total_bits - pos;                  // < 8
+  const uint32_t w = pos >> 5, sh = pos & 31u;
+  const uint32_t x = left ? rdfirst(__funnelshift_l(raw[w + 1], raw[w], sh)) >> (32u - left) : 0u;
+  st.k = 0; st.run = 0; st.acc = x; st.nb = left; st.pos = bytes; st.lastff = lastff; st.err = err;
+}
+
 // REV: the quantise transfer of the blocks this instantiation codes (5/3 integer or 9/7 float coefficients) is a
 // compile-time property -- a launch over blocks of both kinds runs both instantiations, each skipping the other's.
 // LOGP: a step covers 2^LOGP quad pairs across (lane & (2^LOGP - 1)) by 64 / 2^LOGP quad rows down.  4 = the layout
@@ -615,8 +681,11 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   // wave-uniform stream state
   uint32_t ms_pend = 0, ms_base = 0, ms_k = 0, ms_ff = 0;   // pending bits in L.ms and where they start, bytes written, last byte was 0xFF
   uint32_t v_pend = 4, v_pos = 1, v_prev = 0xFF;        // pending bits in L.vlc, bytes "written" (incl. the head), last byte
-  MelState mel = { 0, 0, 0, 0, 0, 0, 0 };
+  MelFast melf = { 0, 0, 0, 0, 0, 0 };
+  uint32_t* const mel_raw = reinterpret_cast<uint32_t*>(L.mel);       // raw MEL words until the block ends, then its bytes
   uint32_t err = 0, any_sig = 0;
+  bool prev_sig = false;                                 // the previous step had a significant sample
+
   // The output stage in LDS holds the bytes [ms_out, ms_k) of the MagSgn stream (growing up from outb[0]) and the VLC
   // bytes (growing down from the top).  Most blocks fit; when the two would meet (more than ~5 KB: deep samples at
   // high rates, e.g. 16-bit lossless at 1.7 bytes per sample) the whole dwords of the MagSgn part are flushed to the
@@ -786,6 +855,21 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       }
     }
     if (step + 1 < nsteps) load_rows(qy + RPS, ntop, nbot); // request the next step's samples now
+    // A step without a significant sample, below a step without one: every quad has context 0 and rho 0, i.e. one
+    // MEL "0" event and nothing else (no VLC codeword, no U-VLC, no MagSgn bits).  The events are all alike, so only
+    // their number matters.  (Smooth content at moderate rates is mostly such steps in the top resolution's sub-bands.)
+    {
+      const uint32_t nz = val[0] | val[1] | val[2] | val[3] | val[4] | val[5] | val[6] | val[7];
+      const bool step_sig = __ballot(nz != 0u) != 0ull;
+      const bool skip = !step_sig && !prev_sig;
+      prev_sig = step_sig;
+      if (skip) {
+        const uint32_t nq = (uint32_t)__popcll(__ballot(active)) + (uint32_t)__popcll(__ballot(has_q1 && active));
+        melf_zero_run(melf, mel_raw, nq, lane);
+        last_bot = 0;
+        continue;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = expo(val[i]);
     // ---- the row above: exponents / significance of its samples, columns x0-1 .. x0+4 ----
@@ -878,17 +962,23 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
         if (ev1_valid) { if (ev1_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
         if (ev2_valid) { if (ev2_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
         wave_sync();
+        // wave-uniform: whole zero runs at a time.  The step's event words are fetched from LDS ONCE (lane w holds
+        // word w) and walked in scalar registers -- with an LDS read per event, content whose significance is
+        // scattered (a "1" event every few quads) spent more time here than in everything else of the step
+        const uint32_t evw = L.ev[lane & 7];
         uint32_t done = 0;
-        while (done < nev) {                       // wave-uniform: whole zero runs at a time
-          const uint32_t w = done >> 5, sh = done & 31;
-          uint32_t word = rdfirst(L.ev[w]) >> sh;
-          const uint32_t avail = min(32u - sh, nev - done);
-          if (word == 0) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
-          const uint32_t z = (uint32_t)__builtin_ctz(word);
-          if (z >= avail) { mel_zero_run(mel, L.mel, avail, lane); done += avail; continue; }
-          mel_zero_run(mel, L.mel, z, lane);
-          mel_one(mel, L.mel, lane);
-          done += z + 1;
+        for (uint32_t w = 0; done < nev; ++w) {
+          uint32_t word = rdlane(evw, (int)w);
+          uint32_t left = min(32u, nev - done);
+          done += left;
+          while (left) {
+            const uint32_t z = word ? (uint32_t)__builtin_ctz(word) : 32u;
+            if (z >= left) { melf_zero_run(melf, mel_raw, left, lane); break; }
+            melf_zero_run(melf, mel_raw, z, lane);
+            melf_one(melf, mel_raw, lane);
+            word = z == 31u ? 0u : word >> (z + 1u);
+            left -= z + 1u;
+          }
         }
         wave_sync();
         if (lane < 8) L.ev[lane] = 0;
@@ -942,8 +1032,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     v_carry = compact(L.vlc, pos, v_pend, PVLC_WORDS);
   }
 
-  err |= mel.err;
+  err |= melf.err;
   uint32_t total = 0, ms_len = ms_k;
+  MelState mel = { 0, 0, 0, 0, 0, 0, 0 };                 // the byte-level state the termination works on (mel_stuff)
   if (!err && any_sig) {
     // ---- ms_terminate (:517-534) ----
     const uint32_t ms_tmp0 = rdfirst(L.ms[0]);
@@ -956,7 +1047,20 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       }
     } else if (ms_ff) ms_len--;
     // ---- terminate_mel_vlc (:412-441) ----
-    if (mel.run > 0) mel_put(mel, L.mel, 1, 1, lane);
+    if (melf.run > 0) melf_append(melf, mel_raw, 1, 1, lane);
+    err |= melf.err;
+    {
+      // the raw words move to the (now idle) MagSgn bit buffer, the bytes are written where the words were
+      uint32_t* rawc = L.ms + 128;
+      const uint32_t total_bits = 32u * melf.wpos + melf.nb;
+      wave_sync();
+      if ((uint32_t)lane < melf.wpos) rawc[lane] = mel_raw[lane];
+      if ((uint32_t)lane == melf.wpos) rawc[lane] = melf.nb ? (uint32_t)(melf.acc << (32u - melf.nb)) : 0u;
+      if ((uint32_t)lane == melf.wpos + 1u) rawc[lane] = 0;
+      wave_sync();
+      mel_stuff(rawc, err ? 0u : total_bits, L.mel, mel, lane);
+      wave_sync();
+    }
     const uint32_t need = mel.lastff ? 7u : 8u, remaining = need - mel.nb;
     const uint32_t mel_tmp = (mel.acc << remaining) & 0xFFu;
     const uint32_t mel_mask = (0xFFu << remaining) & 0xFFu;
