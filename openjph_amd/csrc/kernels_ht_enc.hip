@@ -23,9 +23,15 @@
 //     pass: every lane proposes one output byte assuming no stuffing event inside the 64-byte
 //     window, a ballot finds the first event, lanes up to it commit, and the window restarts;
 //   * MEL is an adaptive run-length coder and stays serial, but it runs on ballot-compacted
-//     event bits, whole zero-runs at a time, in wave-uniform (scalar) code;
-//   * stuffed bytes stream to a per-block scratch slot in HBM; when the three lengths are
-//     known the block takes its place in the compacted output with one atomicAdd.
+//     event bits, whole zero-runs at a time, in wave-uniform (scalar) code; in the narrow kernel
+//     the serial part only appends raw code bits, the bytes are made once per block by the whole
+//     wavefront (mel_stuff), and steps without a significant sample skip everything else;
+//   * the block's bytes are staged in LDS (MagSgn growing up, VLC growing down); a stage that
+//     fills up flushes its whole dwords to the block's scratch slot in HBM and goes on; when the
+//     three lengths are known the block takes its place in the compacted output with one
+//     atomicAdd -- on the cursor of one of 16 regions, not on one cursor for all (claim_output);
+//   * launches whose blocks are all at most 32 columns wide (the IMF profile's 32x32) use a layout
+//     of 8 quad pairs x 8 quad rows per step instead of 16 x 4 (template parameter LOGP).
 // The produced bytes are identical to the reference's (oracle/ht_oracle.c variant 1 is the CPU
 // model of exactly this formulation and is pinned against the reference).
 #include <hip/hip_runtime.h>
