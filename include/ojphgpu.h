@@ -493,6 +493,14 @@ int  ojphgpu_enc_pipe_collect(ojphgpu_enc_pipe* pipe, const uint8_t** h_codestre
  * (ms), [3] host threads coding the packet headers of one frame */
 int  ojphgpu_enc_pipe_stats(ojphgpu_enc_pipe* pipe, double out[4]);
 
+/* The frames of this pipe are handed over PIXEL-INTERLEAVED (R G B R G B ..., the order of .ppm files and of capture
+ * buffers; ppm_in::read, src/apps/others/ojph_img_io.cpp:338-375) instead of as planes: pixel_bits = 8 or 16 per
+ * sample, 16-bit samples big endian (as in the files) when big_endian != 0.  _acquire then hands out width * height *
+ * components * pixel_bits / 8 bytes, and a launch on the device turns them into the planar containers
+ * (ojphgpu_unpack_pixels).  Components must have one size and be unsigned, pixel_bits must hold the bit depth and
+ * must not exceed container_bits.  Call before the first _acquire; pixel_bits = 0 switches back to planes. */
+int  ojphgpu_enc_pipe_set_pixels(ojphgpu_enc_pipe* pipe, int pixel_bits, int big_endian);
+
 /* the first codestream of the sequence fixes the frame geometry (it is only parsed, not decoded); every
  * submitted codestream must describe the same frame format and code-block grid (quantisation may differ) */
 int  ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, int resilient, int device, uint32_t depth,
@@ -509,6 +517,22 @@ int  ojphgpu_dec_pipe_submit(ojphgpu_dec_pipe* pipe);
 int  ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* pipe, const void** h_frame, size_t* bytes, uint32_t* failed_blocks);
 /* out[0] frames completed, [1] mean host parse time per frame (ms), [2] mean submit -> frame latency (ms), [3] host threads */
 int  ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* pipe, double out[4]);
+/* decoded frames come back pixel-interleaved, clamped to [0, 2^depth - 1] (ppm_out::write and its converters,
+ * ojph_img_io.cpp:99-226, :539-556); same conditions as ojphgpu_enc_pipe_set_pixels; call before the first _submit */
+int  ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* pipe, int pixel_bits, int big_endian);
+
+/* ---------------------------------------------------------------------------------------------
+ * 7. Pixel-interleaved samples <-> planar containers on the device (kernels_pixels.hip)
+ * ------------------------------------------------------------------------------------------- */
+/* d_pixels: width * height pixels of num_comps samples each, pixel_bits = 8 or 16 bits per sample (16-bit samples
+ * byte-swapped when big_endian != 0); d_planes: num_comps planes of width * height samples in container_bits-bit
+ * elements (8, 16, 32; not narrower than pixel_bits).  Replaces the per-sample loops of the reference's image
+ * readers (ppm_in::read, ojph_img_io.cpp:338-375). */
+int  ojphgpu_unpack_pixels(void* stream, const void* d_pixels, void* d_planes, uint32_t width, uint32_t height,
+                           uint32_t num_comps, int pixel_bits, int big_endian, int container_bits);
+/* the way back, values clamped to [0, 2^bit_depth - 1] (gen_cvrt_32b*_to_*, ojph_img_io.cpp:99-226) */
+int  ojphgpu_pack_pixels(void* stream, const void* d_planes, void* d_pixels, uint32_t width, uint32_t height,
+                         uint32_t num_comps, int container_bits, int pixel_bits, int big_endian, uint32_t bit_depth);
 
 const char* ojphgpu_version(void);
 

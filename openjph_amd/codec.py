@@ -325,3 +325,35 @@ def ht_decode(descs: np.ndarray, data: np.ndarray, coef):
           "ht_decode")
     torch.cuda.synchronize(dev)
     return status.cpu().numpy()[:len(descs)]
+
+
+def unpack_pixels(pixels, num_comps=None, big_endian=False, dtype=None):
+    """pixel-interleaved samples on the device ([H,W,C] uint8 / uint16 tensor -- for big-endian 16-bit data the tensor
+    holds the file's bytes as they are) -> planes [C,H,W] in `dtype` (uint8 / int16 / uint16 / int32; default: as the
+    input).  ojphgpu_unpack_pixels: what the reference's image readers do sample by sample on the host."""
+    torch = _torch()
+    assert pixels.is_cuda and pixels.is_contiguous() and pixels.dim() == 3
+    h, w, c = pixels.shape
+    bits = pixels.element_size() * 8
+    assert bits in (8, 16)
+    out_dt = dtype if dtype is not None else (torch.uint8 if bits == 8 else torch.int16)
+    out = torch.empty((c, h, w), dtype=out_dt, device=pixels.device)
+    check(capi.lib().ojphgpu_unpack_pixels(_stream_ptr(torch, pixels.device.index or 0), C.c_void_p(pixels.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), w, h, c, bits, int(bool(big_endian)), out.element_size() * 8),
+          "unpack_pixels")
+    return out
+
+
+def pack_pixels(planes, bit_depth, pixel_bits=None, big_endian=False):
+    """planes [C,H,W] on the device -> pixel-interleaved [H,W,C] (uint8 for pixel_bits 8, else int16 holding the bytes
+    of uint16 samples, byte-swapped when big_endian), clamped to [0, 2^bit_depth - 1] as the reference's writers do."""
+    torch = _torch()
+    assert planes.is_cuda and planes.is_contiguous() and planes.dim() == 3
+    c, h, w = planes.shape
+    pb = int(pixel_bits) if pixel_bits else (8 if bit_depth <= 8 else 16)
+    out = torch.empty((h, w, c), dtype=torch.uint8 if pb == 8 else torch.int16, device=planes.device)
+    check(capi.lib().ojphgpu_pack_pixels(_stream_ptr(torch, planes.device.index or 0), C.c_void_p(planes.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), w, h, c, planes.element_size() * 8, pb, int(bool(big_endian)),
+                                         int(bit_depth)), "pack_pixels")
+    return out
+

@@ -113,7 +113,7 @@ double now_ms()
 struct EncSlot {
   SlotState state = FREE;
   Pinned h_in, h_res, h_lay, h_cs;
-  DeviceBuf image, out, counters;
+  DeviceBuf image, out, counters, pixels;           // pixels: the frame as it was handed over, when it comes pixel-interleaved
   Grow cs;
   hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_done = nullptr;
   int rc = 0; size_t cs_len = 0;
@@ -129,6 +129,8 @@ struct ojphgpu_enc_pipe {
   hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
   std::vector<EncSlot> slots;
   size_t frame_bytes = 0, res_bytes = 0;
+  int pixel_bits = 0, big_endian = 0;               // != 0: frames are handed over pixel-interleaved (ojphgpu_enc_pipe_set_pixels)
+  size_t in_bytes = 0;                              // what _acquire hands out: frame_bytes, or the interleaved frame
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
   std::mutex mu; std::condition_variable cv_work, cv_done;
   std::deque<uint32_t> work; bool stop = false;
@@ -216,7 +218,7 @@ extern "C" void ojphgpu_enc_pipe_destroy(ojphgpu_enc_pipe* p)
   if (p->enc) ojphgpu_encoder_destroy(p->enc);
   for (EncSlot& s : p->slots) {
     s.h_in.release(); s.h_res.release(); s.h_lay.release(); s.h_cs.release();
-    for (DeviceBuf* b : { &s.image, &s.out, &s.counters, &s.cs.b }) b->release();
+    for (DeviceBuf* b : { &s.image, &s.out, &s.counters, &s.cs.b, &s.pixels }) b->release();
     for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
   }
   for (hipStream_t s : { p->s_h2d, p->s_comp, p->s_d2h }) if (s) (void)hipStreamDestroy(s);
@@ -244,6 +246,7 @@ extern "C" int ojphgpu_enc_pipe_create(const ojphgpu_plan* plan, int device, uin
     ojphgpu_encoder* e = p->enc;
     const size_t nb = e->block_ids.size();
     p->frame_bytes = (size_t)P.frame_elems * (size_t)(container_bits / 8);
+    p->in_bytes = p->frame_bytes;
     p->res_bytes = nb * sizeof(ojphgpu_cb_result) + 16;
     // the codestream of a frame: sized from the samples (1 byte each is generous for natural content), grown when a frame needs more
     const size_t cs_guess = std::min<size_t>((size_t)e->out_cap, (size_t)P.frame_elems + (1u << 20));
@@ -270,13 +273,42 @@ extern "C" int ojphgpu_enc_pipe_acquire(ojphgpu_enc_pipe* p, void** h_frame, siz
   EncSlot& s = p->slots[p->n_acq % p->depth];
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    if (s.state == ACQUIRED) { *h_frame = s.h_in.p; if (bytes) *bytes = p->frame_bytes; return OJPHGPU_OK; }   // asked twice
+    if (s.state == ACQUIRED) { *h_frame = s.h_in.p; if (bytes) *bytes = p->in_bytes; return OJPHGPU_OK; }   // asked twice
     if (s.state != FREE) return OJPHGPU_E_AGAIN;      // every slot is in flight: collect a codestream first
     s.state = ACQUIRED;
   }
   *h_frame = s.h_in.p;
-  if (bytes) *bytes = p->frame_bytes;
+  if (bytes) *bytes = p->in_bytes;
   return OJPHGPU_OK;
+}
+
+// the conditions of the pixel-interleaved hand-over: one size for all components, unsigned, depths that fit
+static int pixels_fit(const Plan& P, int pixel_bits, int container_bits)
+{
+  if (pixel_bits != 8 && pixel_bits != 16) return OJPHGPU_E_INVALID;
+  if (pixel_bits > container_bits) return OJPHGPU_E_INVALID;
+  if (P.frame_elems != (uint64_t)P.p.width * P.p.height * P.p.num_comps) return OJPHGPU_E_INVALID;   // sub-sampled components
+  for (const CompGeo& g : P.comps) if (g.is_signed || g.bit_depth > (uint32_t)pixel_bits) return OJPHGPU_E_INVALID;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_enc_pipe_set_pixels(ojphgpu_enc_pipe* p, int pixel_bits, int big_endian)
+{
+  if (!p || p->n_acq != 0 || p->slots[0].state != FREE) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
+    if (pixel_bits == 0) { p->pixel_bits = 0; p->in_bytes = p->frame_bytes; return OJPHGPU_OK; }
+    const Plan& P = *p->P;
+    const int rc = pixels_fit(P, pixel_bits, p->container);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nbytes = (size_t)P.frame_elems * (size_t)(pixel_bits / 8);
+    for (EncSlot& s : p->slots) {
+      if (s.h_in.reserve(nbytes + 64)) return OJPHGPU_E_NOMEM;
+      if (!s.pixels.p && s.pixels.alloc(nbytes + 64)) return OJPHGPU_E_NOMEM;
+    }
+    p->pixel_bits = pixel_bits; p->big_endian = big_endian ? 1 : 0; p->in_bytes = nbytes;
+    return OJPHGPU_OK;
+  });
 }
 
 extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
@@ -288,9 +320,15 @@ extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
   HIPCHK(hipSetDevice(p->device));
   ojphgpu_encoder* e = p->enc;
   s.rc = 0; s.cs_len = 0; s.t_submit = now_ms();
-  { const int r0 = upload(p->mode, p->s_h2d, s.image.p, s.h_in, 0, p->frame_bytes); if (r0) return r0; }
+  { const int r0 = upload(p->mode, p->s_h2d, p->pixel_bits ? s.pixels.p : s.image.p, s.h_in, 0, p->in_bytes); if (r0) return r0; }
   HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
   HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
+  if (p->pixel_bits) {                               // the file's / capture buffer's bytes -> planes, on the device
+    const Plan& P = *p->P;
+    const int r0 = ojphgpu_unpack_pixels(p->s_comp, s.pixels.p, s.image.p, P.p.width, P.p.height, P.p.num_comps, p->pixel_bits,
+                                         p->big_endian, p->container);
+    if (r0) return r0;
+  }
   // the block coder writes its per-block {offset, length} records straight into the slot's pinned memory
   // (8 bytes per block, posted PCIe writes): all the host needs to code the packet headers
   const size_t nb = e->block_ids.size();
@@ -346,7 +384,7 @@ struct DecSlot {
   SlotState state = FREE;
   Pinned h_cs, h_descs, h_img, h_status;
   Grow data;
-  DeviceBuf image, cb_descs, status;
+  DeviceBuf image, cb_descs, status, pixels;
   hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_done = nullptr;
   size_t cs_len = 0;
   int rc = 0; uint32_t failed = 0;
@@ -372,6 +410,8 @@ struct ojphgpu_dec_pipe {
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
   std::vector<DecSlot> slots;
   size_t frame_bytes = 0;
+  int pixel_bits = 0, big_endian = 0;               // != 0: frames come back pixel-interleaved (ojphgpu_dec_pipe_set_pixels)
+  size_t out_bytes = 0;
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
   std::mutex mu; std::condition_variable cv_work, cv_done;
   std::deque<uint32_t> work; bool stop = false;
@@ -417,10 +457,17 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
       d->any_refine = fi.any_refine; d->kinds = fi.kinds; d->max_len1 = fi.max_len1;
       r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
       if (r2) return r2;
+      if (p->pixel_bits) {                           // planes -> the pixel order of the file / display buffer
+        uint32_t depth = 0;
+        for (const CompGeo& g : P.comps) depth = std::max(depth, g.bit_depth);
+        r2 = ojphgpu_pack_pixels(s_comp, s.image.p, s.pixels.p, P.p.width, P.p.height, P.p.num_comps, p->container, p->pixel_bits,
+                                 p->big_endian, depth);
+        if (r2) return r2;
+      }
       HIPCHK(hipEventRecord(s.ev_kern, s_comp));
     }
     HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
-    if ((r2 = download(p->mode, p->s_d2h, s.h_img, s.image.p, p->frame_bytes)) != 0) return r2;       // beside the next frame's upload
+    if ((r2 = download(p->mode, p->s_d2h, s.h_img, p->pixel_bits ? s.pixels.p : s.image.p, p->out_bytes)) != 0) return r2;       // beside the next frame's upload
     if ((r2 = download(p->mode, p->s_d2h, s.h_status, s.status.p, nb)) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
     HIPCHK(hipEventSynchronize(s.ev_done));
@@ -465,7 +512,7 @@ extern "C" void ojphgpu_dec_pipe_destroy(ojphgpu_dec_pipe* p)
   for (ojphgpu_decoder* d : p->decs) if (d) ojphgpu_decoder_destroy(d);
   for (DecSlot& s : p->slots) {
     s.h_cs.release(); s.h_descs.release(); s.h_img.release(); s.h_status.release();
-    for (DeviceBuf* b : { &s.data.b, &s.image, &s.cb_descs, &s.status }) b->release();
+    for (DeviceBuf* b : { &s.data.b, &s.image, &s.cb_descs, &s.status, &s.pixels }) b->release();
     for (hipEvent_t ev : { s.ev_in, s.ev_kern, s.ev_done }) if (ev) (void)hipEventDestroy(ev);
   }
   for (hipStream_t s : { p->s_h2d, p->s_comps[0], p->s_comps[1], p->s_comps[2], p->s_comps[3], p->s_d2h }) if (s) (void)hipStreamDestroy(s);
@@ -512,6 +559,7 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
     ojphgpu_decoder* d = p->decs[0];
     const size_t nb = d->block_ids.size();
     p->frame_bytes = (size_t)P.frame_elems * (size_t)(container_bits / 8);
+    p->out_bytes = p->frame_bytes;
     p->slots.resize(depth);
     for (DecSlot& s : p->slots) {
       if (s.h_cs.reserve(len + len / 4 + (1u << 16)) || s.h_descs.reserve(nb * sizeof(ojphgpu_cb_desc) + 64) ||
@@ -574,9 +622,28 @@ extern "C" int ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* p, const void** h_fram
   if (s.rc) { s.state = FREE; return s.rc; }
   s.state = HELD;
   *h_frame = s.h_img.p;
-  if (bytes) *bytes = p->frame_bytes;
+  if (bytes) *bytes = p->out_bytes;
   if (failed_blocks) *failed_blocks = s.failed;
   return (s.failed && !p->resilient) ? OJPHGPU_E_BLOCK : OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* p, int pixel_bits, int big_endian)
+{
+  if (!p || p->n_sub != 0) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
+    if (pixel_bits == 0) { p->pixel_bits = 0; p->out_bytes = p->frame_bytes; return OJPHGPU_OK; }
+    const Plan& P = *p->P;
+    const int rc = pixels_fit(P, pixel_bits, p->container);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nbytes = (size_t)P.frame_elems * (size_t)(pixel_bits / 8);
+    for (DecSlot& s : p->slots) {
+      if (s.h_img.reserve(nbytes + 64)) return OJPHGPU_E_NOMEM;
+      if (!s.pixels.p && s.pixels.alloc(nbytes + 64)) return OJPHGPU_E_NOMEM;
+    }
+    p->pixel_bits = pixel_bits; p->big_endian = big_endian ? 1 : 0; p->out_bytes = nbytes;
+    return OJPHGPU_OK;
+  });
 }
 
 extern "C" int ojphgpu_dec_pipe_plan(ojphgpu_dec_pipe* p, const ojphgpu_plan** plan)

@@ -22,7 +22,10 @@ def _view(ptr, nbytes, dtype=np.uint8):
 
 
 class EncoderPipe:
-    def __init__(self, plan: Plan = None, params=None, device=0, depth=4, container=16, host_threads=0, **kw):
+    def __init__(self, plan: Plan = None, params=None, device=0, depth=4, container=16, host_threads=0, pixels=None, **kw):
+        """pixels=(bits, big_endian): the frames are handed over pixel-interleaved ([H,W,C] of 8- or 16-bit samples, the
+        order of .ppm files / capture buffers; 16-bit samples byte-swapped when big_endian) and turned into planes on
+        the device"""
         from .codec import _torch
         _torch()
         self.plan = plan if plan is not None else Plan(params if params is not None else make_params(**kw))
@@ -32,6 +35,10 @@ class EncoderPipe:
         self._h = C.c_void_p()
         check(self._lib.ojphgpu_enc_pipe_create(self.plan.handle, device, self.depth, self.container, host_threads,
                                                 C.byref(self._h)), "enc_pipe_create")
+        self.pixels = None
+        if pixels is not None:
+            check(self._lib.ojphgpu_enc_pipe_set_pixels(self._h, int(pixels[0]), int(bool(pixels[1]))), "enc_pipe_set_pixels")
+            self.pixels = (int(pixels[0]), bool(pixels[1]))
         self.in_flight = 0
 
     def close(self):
@@ -49,6 +56,10 @@ class EncoderPipe:
         if rc == capi.E_AGAIN:
             return None
         check(rc, "enc_pipe_acquire")
+        if self.pixels is not None:                     # [H,W,C] in the file's sample type (big endian: the raw bytes)
+            c, h, w = self.plan.frame_shape
+            dt = np.uint8 if self.pixels[0] == 8 else np.dtype(">u2" if self.pixels[1] else "<u2")
+            return _view(ptr.value, n.value, np.uint8).view(dt).reshape(h, w, c)
         return _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
 
     def submit(self):
@@ -82,7 +93,8 @@ class EncoderPipe:
 
 
 class DecoderPipe:
-    def __init__(self, first_codestream: bytes, device=0, depth=4, container=16, host_threads=0, resilient=False):
+    def __init__(self, first_codestream: bytes, device=0, depth=4, container=16, host_threads=0, resilient=False, pixels=None):
+        """pixels=(bits, big_endian): decoded frames come back pixel-interleaved ([H,W,C]), clamped to the bit depth"""
         from .codec import _torch
         _torch()
         self.container = int(container)
@@ -94,6 +106,10 @@ class DecoderPipe:
         h = C.c_void_p()
         check(self._lib.ojphgpu_dec_pipe_plan(self._h, C.byref(h)), "dec_pipe_plan")
         self.plan = Plan(handle=h, owned=False)
+        self.pixels = None
+        if pixels is not None:
+            check(self._lib.ojphgpu_dec_pipe_set_pixels(self._h, int(pixels[0]), int(bool(pixels[1]))), "dec_pipe_set_pixels")
+            self.pixels = (int(pixels[0]), bool(pixels[1]))
         self.in_flight = 0
 
     def close(self):
@@ -120,7 +136,12 @@ class DecoderPipe:
         ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
         self.in_flight -= 1
         check(self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed)), "dec_pipe_collect")
-        v = _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
+        if self.pixels is not None:
+            c, h, w = self.plan.frame_shape
+            dt = np.uint8 if self.pixels[0] == 8 else np.dtype(">u2" if self.pixels[1] else "<u2")
+            v = _view(ptr.value, n.value, np.uint8).view(dt).reshape(h, w, c)
+        else:
+            v = _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
         return v.copy() if copy else v
 
     def stats(self):

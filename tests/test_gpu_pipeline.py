@@ -142,3 +142,48 @@ def test_pipes_can_be_destroyed_with_frames_in_flight_and_run_side_by_side():
     assert got["e"] == streams
     for a, b in zip(got["d"], images):
         assert np.array_equal(a.astype(np.int64), b.astype(np.int64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,big_endian,container", [(8, False, 8), (8, False, 16), (16, True, 16), (16, False, 32)],
+                         ids=["u8-c8", "u8-c16", "u16be-c16", "u16le-c32"])
+def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, container):
+    """ojphgpu_unpack_pixels / pack_pixels against numpy, and the pipes fed with / returning the bytes of .ppm files
+    ([H,W,C], 16-bit samples big endian): same codestream as from planes, decoded frames equal after the reference's
+    clamp"""
+    import torch
+    from openjph_amd import codec
+    from openjph_amd.pipeline import EncoderPipe, DecoderPipe
+    from openjph_amd.plan import Plan, make_params
+    h, w, c, bd = 70, 117, 3, (8 if bits == 8 else 12)
+    rng = np.random.default_rng(bits + container)
+    img = rng.integers(0, 1 << bd, size=(h, w, c), dtype=np.int64)
+    file_dt = np.uint8 if bits == 8 else np.dtype(">u2" if big_endian else "<u2")
+    raw = img.astype(file_dt)                                  # the bytes a .ppm file would hold
+    planes = np.ascontiguousarray(img.transpose(2, 0, 1))
+    tdt = {8: torch.uint8, 16: torch.int16, 32: torch.int32}[container]
+    d_raw = torch.from_numpy(raw.view(np.uint8 if bits == 8 else np.int16).copy()).cuda()
+    got = codec.unpack_pixels(d_raw, big_endian=big_endian, dtype=tdt)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64) & ((1 << container) - 1 if container < 32 else -1), planes)
+    back = codec.pack_pixels(got, bd, pixel_bits=bits, big_endian=big_endian).cpu().numpy()
+    assert back.tobytes() == raw.tobytes()
+    # clamp: values above the depth's range (what a lossy decode can leave) come out as 2^bd - 1
+    if container == 32:
+        over = torch.from_numpy((planes + (1 << bd)).astype(np.int32)).cuda()
+        cl = codec.pack_pixels(over, bd, pixel_bits=bits, big_endian=big_endian).cpu().numpy().tobytes()
+        assert cl == np.full((h, w, c), (1 << bd) - 1).astype(file_dt).tobytes()
+    # pipes
+    plan = Plan(make_params(w, h, c, bit_depth=bd, color_transform=True))
+    want = codec.Encoder(plan=plan).encode(planes.astype(np.int32))
+    pipe = EncoderPipe(plan=plan, depth=2, container=container, pixels=(bits, big_endian))
+    buf = pipe.acquire()
+    assert buf.shape == (h, w, c)
+    buf[:] = raw
+    pipe.submit()
+    assert pipe.collect() == want
+    pipe.close()
+    dp = DecoderPipe(want, depth=2, container=container, pixels=(bits, big_endian))
+    slot = dp.acquire(len(want)); slot[:] = np.frombuffer(want, np.uint8); dp.submit()
+    out = dp.collect()
+    assert out.shape == (h, w, c) and np.array_equal(out.astype(np.int64), img)
+    dp.close()
