@@ -470,17 +470,21 @@ def pcie_bandwidth(torch, nbytes=256 << 20, reps=4):
     return out
 
 
-def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None):
+def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None, packed=None):
     """n frames through an encoder pipe in steady state; every slot is filled once (the frame a capture device would
     have written there), later submissions send the slot again: each frame pays its H2D, kernels, Tier-2, D2H"""
     from openjph_amd.pipeline import EncoderPipe
-    pipe = EncoderPipe(plan=plan, depth=depth, container=container, host_threads=threads)
+    pipe = EncoderPipe(plan=plan, depth=depth, container=container, host_threads=threads, packed=packed)
     k = 0
+    filled = None
+    if packed:
+        from openjph_amd.pipeline import pack_bits
+        filled = pack_bits(img, packed)                # what a capture device delivering packed samples would have written
     while k < depth:
         buf = pipe.acquire()
         if buf is None:
             break
-        buf[:] = img.astype(buf.dtype)
+        buf[:] = filled if packed else img.astype(buf.dtype)
         pipe.submit(); k += 1
     first = None
     while pipe.in_flight:
@@ -502,9 +506,9 @@ def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None):
     return dt, st
 
 
-def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None):
+def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None, packed=None):
     from openjph_amd.pipeline import DecoderPipe
-    pipe = DecoderPipe(cs, depth=depth, container=container, host_threads=threads)
+    pipe = DecoderPipe(cs, depth=depth, container=container, host_threads=threads, packed=packed)
     k = 0
     while k < depth:
         buf = pipe.acquire(len(cs))
@@ -517,6 +521,10 @@ def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None):
         f = pipe.collect()
         first = f if first is None else first
     if want is not None:
+        if packed:
+            from openjph_amd.pipeline import unpack_bits
+            first = unpack_bits(first, packed, want.size).reshape(want.shape)
+            want = np.clip(want.astype(np.int64), 0, (1 << packed) - 1)      # packing clamps (a 9/7 decode can leave 2^B)
         assert np.array_equal(first.astype(np.int64), want.astype(np.int64)), "pipeline frame differs from the one-frame decoder's"
     t0 = time.perf_counter()
     sub = col = 0
@@ -554,6 +562,21 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
         wall = max(res["e"][0], res["d"][0])               # both pipes code n frames; the slower one sets the step rate
         out["encode+decode"] = {"Msamples_s": round(nsamp * n / wall / 1e6, 1), "ms_per_step": round(wall * 1e3 / n, 3),
                                 "encode_ms_per_frame": round(res["e"][0] * 1e3 / n, 3), "decode_ms_per_frame": round(res["d"][0] * 1e3 / n, 3)}
+    # the same pipes with the frames crossing PCIe as bit-packed planes (1.5 bytes per 12-bit sample instead of 2): the link
+    # is what bounds the figures above
+    try:
+        fmts = [plan.comp_format(c) for c in range(img.shape[0])]
+        bd = 0 if any(sg for _, sg in fmts) else max(b for b, _ in fmts)
+    except Exception:
+        bd = 0
+    if container == 16 and bd in (10, 12, 14) and img.ndim == 3:
+        try:
+            dt, _ = run_encoder_pipe(plan, img, n, depth, threads, container=container, packed=bd)
+            pe = round(nsamp * n / dt / 1e6, 1)
+            dt, _ = run_decoder_pipe(cs, n, depth, threads, container=container, packed=bd)
+            out["bit_packed"] = {"bits_per_sample_on_pcie": bd, "encode_Msamples_s": pe, "decode_Msamples_s": round(nsamp * n / dt / 1e6, 1)}
+        except Exception as e:
+            out["bit_packed"] = {"error": str(e)[:200]}
     return out
 
 

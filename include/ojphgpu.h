@@ -500,6 +500,10 @@ int  ojphgpu_enc_pipe_stats(ojphgpu_enc_pipe* pipe, double out[4]);
  * (ojphgpu_unpack_pixels).  Components must have one size and be unsigned, pixel_bits must hold the bit depth and
  * must not exceed container_bits.  Call before the first _acquire; pixel_bits = 0 switches back to planes. */
 int  ojphgpu_enc_pipe_set_pixels(ojphgpu_enc_pipe* pipe, int pixel_bits, int big_endian);
+/* ... or as planes of bit-packed samples (ojphgpu_unpack_bits: bits = 10, 12, 14; the whole frame one bit string in
+ * the plane order of the planar layout): _acquire hands out ceil(samples * bits / 8) bytes rounded up to whole groups
+ * of 32 samples.  Unsigned components whose depth fits `bits`, 16- or 32-bit containers.  bits = 0 switches back. */
+int  ojphgpu_enc_pipe_set_packed(ojphgpu_enc_pipe* pipe, int bits);
 
 /* the first codestream of the sequence fixes the frame geometry (it is only parsed, not decoded); every
  * submitted codestream must describe the same frame format and code-block grid (quantisation may differ) */
@@ -520,6 +524,7 @@ int  ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* pipe, double out[4]);
 /* decoded frames come back pixel-interleaved, clamped to [0, 2^depth - 1] (ppm_out::write and its converters,
  * ojph_img_io.cpp:99-226, :539-556); same conditions as ojphgpu_enc_pipe_set_pixels; call before the first _submit */
 int  ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* pipe, int pixel_bits, int big_endian);
+int  ojphgpu_dec_pipe_set_packed(ojphgpu_dec_pipe* pipe, int bits);     /* decoded frames come back bit-packed (clamped) */
 
 /* ---------------------------------------------------------------------------------------------
  * 7. Pixel-interleaved samples <-> planar containers on the device (kernels_pixels.hip)
@@ -533,6 +538,13 @@ int  ojphgpu_unpack_pixels(void* stream, const void* d_pixels, void* d_planes, u
 /* the way back, values clamped to [0, 2^bit_depth - 1] (gen_cvrt_32b*_to_*, ojph_img_io.cpp:99-226) */
 int  ojphgpu_pack_pixels(void* stream, const void* d_planes, void* d_pixels, uint32_t width, uint32_t height,
                          uint32_t num_comps, int container_bits, int pixel_bits, int big_endian, uint32_t bit_depth);
+/* Bit-packed samples: 10, 12 or 14 bits each, consecutive in one little-endian bit string (sample i = bits
+ * [i * bits, (i + 1) * bits)), the buffer padded to a multiple of 32 samples (4 * bits bytes, 4-byte aligned) <-> 16- or
+ * 32-bit containers.  A 12-bit frame crosses PCIe in 1.5 instead of 2 bytes per sample this way (the link is what
+ * bounds the frame pipelines).  Packing clamps to [0, 2^bits - 1].  No counterpart in the reference, whose files hold
+ * such samples in 16-bit words. */
+int  ojphgpu_unpack_bits(void* stream, const void* d_packed, void* d_samples, uint64_t num_samples, int bits, int container_bits);
+int  ojphgpu_pack_bits(void* stream, const void* d_samples, void* d_packed, uint64_t num_samples, int container_bits, int bits);
 
 const char* ojphgpu_version(void);
 

@@ -225,6 +225,10 @@ SIGNATURES = {
     "ojphgpu_dec_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "ojphgpu_dec_pipe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "ojphgpu_enc_pipe_set_pixels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ojphgpu_enc_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),
+    "ojphgpu_dec_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),
+    "ojphgpu_unpack_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
+    "ojphgpu_pack_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "ojphgpu_dec_pipe_set_pixels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ojphgpu_unpack_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
     "ojphgpu_pack_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32]),

@@ -118,6 +118,65 @@ int launch_pack(hipStream_t st, const void* src, void* dst, uint64_t npix, uint3
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
+// ---- bit-packed samples (10 / 12 / 14 bits each, consecutive in a little-endian bit string: sample i occupies bits
+// [i * BITS, (i + 1) * BITS)) <-> 16- or 32-bit containers.  A thread takes 32 samples = BITS dwords.
+template <int BITS, typename D>
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const uint32_t* __restrict__ src, D* __restrict__ dst, uint64_t n)
+{
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t s0 = 32ull * g;
+  if (s0 >= n) return;
+  uint32_t w[BITS + 1];
+#pragma unroll
+  for (int i = 0; i < BITS; ++i) w[i] = src[g * BITS + i];
+  w[BITS] = 0;
+  D o[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int pos = j * BITS, wi = pos >> 5, sh = pos & 31;
+    const uint32_t v = sh + BITS <= 32 ? w[wi] >> sh : __funnelshift_r(w[wi], w[wi + 1], sh);
+    o[j] = (D)(v & ((1u << BITS) - 1u));
+  }
+  if (s0 + 32 <= n) __builtin_memcpy(dst + s0, o, sizeof(o));
+  else for (int j = 0; j < 32; ++j) if (s0 + j < n) dst[s0 + j] = o[j];
+}
+
+template <int BITS, typename D>
+__global__ __launch_bounds__(256) void pack_bits_kernel(const D* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n)
+{
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t s0 = 32ull * g;
+  if (s0 >= n) return;
+  D in[32];
+  if (s0 + 32 <= n) __builtin_memcpy(in, src + s0, sizeof(in));
+  else for (int j = 0; j < 32; ++j) in[j] = s0 + j < n ? src[s0 + j] : (D)0;
+  uint32_t w[BITS + 1];
+#pragma unroll
+  for (int i = 0; i <= BITS; ++i) w[i] = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    int64_t x = (int64_t)in[j];
+    x = x < 0 ? 0 : (x > (int64_t)((1u << BITS) - 1u) ? (int64_t)((1u << BITS) - 1u) : x);     // clamp, as the reference's writers do
+    const uint32_t v = (uint32_t)x;
+    const int pos = j * BITS, wi = pos >> 5, sh = pos & 31;
+    w[wi] |= v << sh;
+    if (sh + BITS > 32) w[wi + 1] |= v >> (32 - sh);
+  }
+#pragma unroll
+  for (int i = 0; i < BITS; ++i) dst[g * BITS + i] = w[i];     // (the buffer is padded to whole groups of 32 samples)
+}
+
+template <typename D>
+int launch_bits(hipStream_t st, bool unpack, const void* src, void* dst, uint64_t n, int bits)
+{
+  const dim3 grid((unsigned)((n + 32ull * 256 - 1) / (32ull * 256))), wg(256);
+#define BITS_CASE(B) case B: if (unpack) hipLaunchKernelGGL((unpack_bits_kernel<B, D>), grid, wg, 0, st, (const uint32_t*)src, (D*)dst, n); \
+                             else hipLaunchKernelGGL((pack_bits_kernel<B, D>), grid, wg, 0, st, (const D*)src, (uint32_t*)dst, n); break;
+  switch (bits) { BITS_CASE(10) BITS_CASE(12) BITS_CASE(14) default: return OJPHGPU_E_INVALID; }
+#undef BITS_CASE
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
 bool bad_args(const void* a, const void* b, uint32_t w, uint32_t h, uint32_t nc, int pixel_bits, int container_bits)
 {
   return !a || !b || w == 0 || h == 0 || nc == 0 || nc > 16384 || (pixel_bits != 8 && pixel_bits != 16) ||
@@ -158,4 +217,22 @@ extern "C" int ojphgpu_pack_pixels(void* stream, const void* d_planes, void* d_p
   }
   if (container_bits == 16) return launch_pack<uint16_t, uint16_t>(st, d_planes, d_pixels, npix, num_comps, swap, maxv);
   return launch_pack<uint16_t, int32_t>(st, d_planes, d_pixels, npix, num_comps, swap, maxv);
+}
+
+// d_packed: num_samples samples of `bits` (10, 12, 14) bits each, one little-endian bit string, padded to a multiple of
+// 32 samples (4 * bits bytes); d_samples: 16- or 32-bit containers
+extern "C" int ojphgpu_unpack_bits(void* stream, const void* d_packed, void* d_samples, uint64_t num_samples, int bits, int container_bits)
+{
+  if (!d_packed || !d_samples || num_samples == 0 || ((uintptr_t)d_packed & 3u)) return OJPHGPU_E_INVALID;
+  if (container_bits == 16) return launch_bits<uint16_t>((hipStream_t)stream, true, d_packed, d_samples, num_samples, bits);
+  if (container_bits == 32) return launch_bits<int32_t>((hipStream_t)stream, true, d_packed, d_samples, num_samples, bits);
+  return OJPHGPU_E_INVALID;
+}
+
+extern "C" int ojphgpu_pack_bits(void* stream, const void* d_samples, void* d_packed, uint64_t num_samples, int container_bits, int bits)
+{
+  if (!d_packed || !d_samples || num_samples == 0 || ((uintptr_t)d_packed & 3u)) return OJPHGPU_E_INVALID;
+  if (container_bits == 16) return launch_bits<uint16_t>((hipStream_t)stream, false, d_samples, d_packed, num_samples, bits);
+  if (container_bits == 32) return launch_bits<int32_t>((hipStream_t)stream, false, d_samples, d_packed, num_samples, bits);
+  return OJPHGPU_E_INVALID;
 }

@@ -130,6 +130,7 @@ struct ojphgpu_enc_pipe {
   std::vector<EncSlot> slots;
   size_t frame_bytes = 0, res_bytes = 0;
   int pixel_bits = 0, big_endian = 0;               // != 0: frames are handed over pixel-interleaved (ojphgpu_enc_pipe_set_pixels)
+  int packed_bits = 0;                              // != 0: ... as bit-packed planes (ojphgpu_enc_pipe_set_packed)
   size_t in_bytes = 0;                              // what _acquire hands out: frame_bytes, or the interleaved frame
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
   std::mutex mu; std::condition_variable cv_work, cv_done;
@@ -294,7 +295,7 @@ static int pixels_fit(const Plan& P, int pixel_bits, int container_bits)
 
 extern "C" int ojphgpu_enc_pipe_set_pixels(ojphgpu_enc_pipe* p, int pixel_bits, int big_endian)
 {
-  if (!p || p->n_acq != 0 || p->slots[0].state != FREE) return OJPHGPU_E_INVALID;
+  if (!p || p->n_acq != 0 || p->slots[0].state != FREE || p->packed_bits) return OJPHGPU_E_INVALID;
   return no_throw([&]() -> int {
     if (pixel_bits == 0) { p->pixel_bits = 0; p->in_bytes = p->frame_bytes; return OJPHGPU_OK; }
     const Plan& P = *p->P;
@@ -311,6 +312,34 @@ extern "C" int ojphgpu_enc_pipe_set_pixels(ojphgpu_enc_pipe* p, int pixel_bits, 
   });
 }
 
+static size_t packed_bytes(uint64_t samples, int bits) { return (size_t)((samples + 31) / 32) * 4u * (size_t)bits; }
+
+static int packed_fit(const Plan& P, int bits, int container_bits)
+{
+  if ((bits != 10 && bits != 12 && bits != 14) || (container_bits != 16 && container_bits != 32)) return OJPHGPU_E_INVALID;
+  for (const CompGeo& g : P.comps) if (g.is_signed || g.bit_depth > (uint32_t)bits) return OJPHGPU_E_INVALID;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_enc_pipe_set_packed(ojphgpu_enc_pipe* p, int bits)
+{
+  if (!p || p->n_acq != 0 || p->slots[0].state != FREE || p->pixel_bits) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
+    if (bits == 0) { p->packed_bits = 0; p->in_bytes = p->frame_bytes; return OJPHGPU_OK; }
+    const Plan& P = *p->P;
+    const int rc = packed_fit(P, bits, p->container);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nbytes = packed_bytes(P.frame_elems, bits);
+    for (EncSlot& s : p->slots) {
+      if (s.h_in.reserve(nbytes + 64)) return OJPHGPU_E_NOMEM;
+      if (!s.pixels.p && s.pixels.alloc(nbytes + 64)) return OJPHGPU_E_NOMEM;
+    }
+    p->packed_bits = bits; p->in_bytes = nbytes;
+    return OJPHGPU_OK;
+  });
+}
+
 extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
 {
   if (!p) return OJPHGPU_E_INVALID;
@@ -320,13 +349,17 @@ extern "C" int ojphgpu_enc_pipe_submit(ojphgpu_enc_pipe* p)
   HIPCHK(hipSetDevice(p->device));
   ojphgpu_encoder* e = p->enc;
   s.rc = 0; s.cs_len = 0; s.t_submit = now_ms();
-  { const int r0 = upload(p->mode, p->s_h2d, p->pixel_bits ? s.pixels.p : s.image.p, s.h_in, 0, p->in_bytes); if (r0) return r0; }
+  { const int r0 = upload(p->mode, p->s_h2d, (p->pixel_bits || p->packed_bits) ? s.pixels.p : s.image.p, s.h_in, 0, p->in_bytes); if (r0) return r0; }
   HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
   HIPCHK(hipStreamWaitEvent(p->s_comp, s.ev_in, 0));
   if (p->pixel_bits) {                               // the file's / capture buffer's bytes -> planes, on the device
     const Plan& P = *p->P;
     const int r0 = ojphgpu_unpack_pixels(p->s_comp, s.pixels.p, s.image.p, P.p.width, P.p.height, P.p.num_comps, p->pixel_bits,
                                          p->big_endian, p->container);
+    if (r0) return r0;
+  }
+  if (p->packed_bits) {
+    const int r0 = ojphgpu_unpack_bits(p->s_comp, s.pixels.p, s.image.p, p->P->frame_elems, p->packed_bits, p->container);
     if (r0) return r0;
   }
   // the block coder writes its per-block {offset, length} records straight into the slot's pinned memory
@@ -411,6 +444,7 @@ struct ojphgpu_dec_pipe {
   std::vector<DecSlot> slots;
   size_t frame_bytes = 0;
   int pixel_bits = 0, big_endian = 0;               // != 0: frames come back pixel-interleaved (ojphgpu_dec_pipe_set_pixels)
+  int packed_bits = 0;                              // != 0: ... bit-packed (ojphgpu_dec_pipe_set_packed)
   size_t out_bytes = 0;
   uint64_t n_acq = 0, n_sub = 0, n_col = 0;
   std::mutex mu; std::condition_variable cv_work, cv_done;
@@ -464,10 +498,11 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
                                  p->big_endian, depth);
         if (r2) return r2;
       }
+      if (p->packed_bits && (r2 = ojphgpu_pack_bits(s_comp, s.image.p, s.pixels.p, P.frame_elems, p->container, p->packed_bits)) != 0) return r2;
       HIPCHK(hipEventRecord(s.ev_kern, s_comp));
     }
     HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
-    if ((r2 = download(p->mode, p->s_d2h, s.h_img, p->pixel_bits ? s.pixels.p : s.image.p, p->out_bytes)) != 0) return r2;       // beside the next frame's upload
+    if ((r2 = download(p->mode, p->s_d2h, s.h_img, (p->pixel_bits || p->packed_bits) ? s.pixels.p : s.image.p, p->out_bytes)) != 0) return r2;       // beside the next frame's upload
     if ((r2 = download(p->mode, p->s_d2h, s.h_status, s.status.p, nb)) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
     HIPCHK(hipEventSynchronize(s.ev_done));
@@ -629,7 +664,7 @@ extern "C" int ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* p, const void** h_fram
 
 extern "C" int ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* p, int pixel_bits, int big_endian)
 {
-  if (!p || p->n_sub != 0) return OJPHGPU_E_INVALID;
+  if (!p || p->n_sub != 0 || p->packed_bits) return OJPHGPU_E_INVALID;
   return no_throw([&]() -> int {
     if (pixel_bits == 0) { p->pixel_bits = 0; p->out_bytes = p->frame_bytes; return OJPHGPU_OK; }
     const Plan& P = *p->P;
@@ -642,6 +677,25 @@ extern "C" int ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* p, int pixel_bits, 
       if (!s.pixels.p && s.pixels.alloc(nbytes + 64)) return OJPHGPU_E_NOMEM;
     }
     p->pixel_bits = pixel_bits; p->big_endian = big_endian ? 1 : 0; p->out_bytes = nbytes;
+    return OJPHGPU_OK;
+  });
+}
+
+extern "C" int ojphgpu_dec_pipe_set_packed(ojphgpu_dec_pipe* p, int bits)
+{
+  if (!p || p->n_sub != 0 || p->pixel_bits) return OJPHGPU_E_INVALID;
+  return no_throw([&]() -> int {
+    if (bits == 0) { p->packed_bits = 0; p->out_bytes = p->frame_bytes; return OJPHGPU_OK; }
+    const Plan& P = *p->P;
+    const int rc = packed_fit(P, bits, p->container);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nbytes = packed_bytes(P.frame_elems, bits);
+    for (DecSlot& s : p->slots) {
+      if (s.h_img.reserve(nbytes + 64)) return OJPHGPU_E_NOMEM;
+      if (!s.pixels.p && s.pixels.alloc(nbytes + 64)) return OJPHGPU_E_NOMEM;
+    }
+    p->packed_bits = bits; p->out_bytes = nbytes;
     return OJPHGPU_OK;
   });
 }

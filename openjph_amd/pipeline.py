@@ -21,8 +21,33 @@ def _view(ptr, nbytes, dtype=np.uint8):
     return np.frombuffer(buf, dtype=dtype)
 
 
+def pack_bits(samples, bits):
+    """numpy: unsigned samples (any shape, flattened in C order) -> the little-endian bit string ojphgpu_unpack_bits
+    reads (sample i = bits [i * bits, (i + 1) * bits)), padded to a whole group of 32 samples"""
+    v = np.ascontiguousarray(samples).reshape(-1)
+    n = v.size
+    pad = (-n) % 32
+    if bits == 12:                                    # two samples in three bytes, without the bit matrix
+        a = np.zeros(n + pad, np.uint16); a[:n] = v
+        lo, hi = a[0::2], a[1::2]
+        out = np.empty((lo.size, 3), np.uint8)
+        out[:, 0] = lo & 0xFF; out[:, 1] = (lo >> 8) | ((hi & 0xF) << 4); out[:, 2] = hi >> 4
+        return out.reshape(-1)
+    v = v.astype(np.uint64)
+    if pad:
+        v = np.concatenate([v, np.zeros(pad, np.uint64)])
+    b = ((v[:, None] >> np.arange(bits, dtype=np.uint64)[None, :]) & 1).astype(np.uint8)       # LSB first
+    return np.packbits(b.reshape(-1), bitorder="little")
+
+
+def unpack_bits(packed, bits, n):
+    """numpy inverse of pack_bits: -> n samples (uint32)"""
+    b = np.unpackbits(np.ascontiguousarray(packed).view(np.uint8), bitorder="little")[: n * bits].reshape(n, bits).astype(np.uint32)
+    return (b << np.arange(bits, dtype=np.uint32)[None, :]).sum(axis=1).astype(np.uint32)
+
+
 class EncoderPipe:
-    def __init__(self, plan: Plan = None, params=None, device=0, depth=4, container=16, host_threads=0, pixels=None, **kw):
+    def __init__(self, plan: Plan = None, params=None, device=0, depth=4, container=16, host_threads=0, pixels=None, packed=None, **kw):
         """pixels=(bits, big_endian): the frames are handed over pixel-interleaved ([H,W,C] of 8- or 16-bit samples, the
         order of .ppm files / capture buffers; 16-bit samples byte-swapped when big_endian) and turned into planes on
         the device"""
@@ -39,6 +64,10 @@ class EncoderPipe:
         if pixels is not None:
             check(self._lib.ojphgpu_enc_pipe_set_pixels(self._h, int(pixels[0]), int(bool(pixels[1]))), "enc_pipe_set_pixels")
             self.pixels = (int(pixels[0]), bool(pixels[1]))
+        self.packed = None
+        if packed:                                        # planes of bit-packed samples (10 / 12 / 14 bits): acquire() -> uint8 view
+            check(self._lib.ojphgpu_enc_pipe_set_packed(self._h, int(packed)), "enc_pipe_set_packed")
+            self.packed = int(packed)
         self.in_flight = 0
 
     def close(self):
@@ -56,6 +85,8 @@ class EncoderPipe:
         if rc == capi.E_AGAIN:
             return None
         check(rc, "enc_pipe_acquire")
+        if self.packed:
+            return _view(ptr.value, n.value, np.uint8)
         if self.pixels is not None:                     # [H,W,C] in the file's sample type (big endian: the raw bytes)
             c, h, w = self.plan.frame_shape
             dt = np.uint8 if self.pixels[0] == 8 else np.dtype(">u2" if self.pixels[1] else "<u2")
@@ -93,7 +124,7 @@ class EncoderPipe:
 
 
 class DecoderPipe:
-    def __init__(self, first_codestream: bytes, device=0, depth=4, container=16, host_threads=0, resilient=False, pixels=None):
+    def __init__(self, first_codestream: bytes, device=0, depth=4, container=16, host_threads=0, resilient=False, pixels=None, packed=None):
         """pixels=(bits, big_endian): decoded frames come back pixel-interleaved ([H,W,C]), clamped to the bit depth"""
         from .codec import _torch
         _torch()
@@ -110,6 +141,10 @@ class DecoderPipe:
         if pixels is not None:
             check(self._lib.ojphgpu_dec_pipe_set_pixels(self._h, int(pixels[0]), int(bool(pixels[1]))), "dec_pipe_set_pixels")
             self.pixels = (int(pixels[0]), bool(pixels[1]))
+        self.packed = None
+        if packed:
+            check(self._lib.ojphgpu_dec_pipe_set_packed(self._h, int(packed)), "dec_pipe_set_packed")
+            self.packed = int(packed)
         self.in_flight = 0
 
     def close(self):
@@ -136,7 +171,9 @@ class DecoderPipe:
         ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
         self.in_flight -= 1
         check(self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed)), "dec_pipe_collect")
-        if self.pixels is not None:
+        if self.packed:
+            v = _view(ptr.value, n.value, np.uint8)
+        elif self.pixels is not None:
             c, h, w = self.plan.frame_shape
             dt = np.uint8 if self.pixels[0] == 8 else np.dtype(">u2" if self.pixels[1] else "<u2")
             v = _view(ptr.value, n.value, np.uint8).view(dt).reshape(h, w, c)

@@ -187,3 +187,33 @@ def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, conta
     out = dp.collect()
     assert out.shape == (h, w, c) and np.array_equal(out.astype(np.int64), img)
     dp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,container", [(12, 16), (10, 16), (14, 32)])
+def test_bit_packed_frames(bits, container):
+    """frames crossing PCIe as planes of bit-packed samples (1.5 bytes per 12-bit sample): same codestream as from
+    16-bit containers, decoded frames come back packed and equal"""
+    from openjph_amd import codec
+    from openjph_amd.pipeline import EncoderPipe, DecoderPipe, pack_bits, unpack_bits
+    from openjph_amd.plan import Plan, make_params
+    h, w, c = 53, 77, 3                                       # 12 243 samples: not a multiple of 32
+    rng = np.random.default_rng(bits)
+    img = rng.integers(0, 1 << bits, size=(c, h, w), dtype=np.int64).astype(np.int32)
+    assert np.array_equal(unpack_bits(pack_bits(img, bits), bits, img.size), img.reshape(-1))
+    plan = Plan(make_params(w, h, c, bit_depth=bits))
+    want = codec.Encoder(plan=plan).encode(img)
+    pipe = EncoderPipe(plan=plan, depth=2, container=container, packed=bits)
+    for _ in range(3):                                        # slots recycled
+        buf = pipe.acquire()
+        pk = pack_bits(img, bits)
+        assert buf.size == pk.size == (img.size + 31) // 32 * 4 * bits
+        buf[:] = pk
+        pipe.submit()
+        assert pipe.collect() == want
+    pipe.close()
+    dp = DecoderPipe(want, depth=2, container=container, packed=bits)
+    slot = dp.acquire(len(want)); slot[:] = np.frombuffer(want, np.uint8); dp.submit()
+    out = dp.collect()
+    assert np.array_equal(unpack_bits(out, bits, img.size), img.reshape(-1))
+    dp.close()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--container", type=int, default=16, help="bits per sample in host memory: 8, 16 or 32")
+    ap.add_argument("--packed", type=int, default=0, help="frames cross PCIe as bit-packed planes: 10, 12 or 14 bits per sample")
     args = ap.parse_args()
     import torch
     from bench import WORKLOADS, workload_image, pcie_bandwidth, run_encoder_pipe, run_decoder_pipe
@@ -34,13 +35,13 @@ def main():
     nsamp = img.size
     res = {"workload": name, "frames": args.frames, "depth": args.depth, "host_threads": args.threads, "pcie_GBps": pcie_bandwidth(torch)}
     want = codec.Encoder(plan=plan).encode(img)
-    dt, st = run_encoder_pipe(plan, img, args.frames, args.depth, args.threads, container=args.container, want=want)
+    dt, st = run_encoder_pipe(plan, img, args.frames, args.depth, args.threads, container=args.container, want=want, packed=args.packed or None)
     res["encode"] = {"Msamples_s": round(nsamp * args.frames / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / args.frames, 3), **st,
-                     "h2d_GBps": round(img.size * (args.container // 8) * args.frames / dt / 1e9, 1)}
+                     "h2d_GBps": round(img.size * ((args.packed or args.container) / 8) * args.frames / dt / 1e9, 1)}
     ref = codec.decode(want)
-    dt, st = run_decoder_pipe(want, args.frames, args.depth, args.threads, container=args.container, want=ref)
+    dt, st = run_decoder_pipe(want, args.frames, args.depth, args.threads, container=args.container, want=ref, packed=args.packed or None)
     res["decode"] = {"Msamples_s": round(nsamp * args.frames / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / args.frames, 3), **st,
-                     "d2h_GBps": round(img.size * (args.container // 8) * args.frames / dt / 1e9, 1)}
+                     "d2h_GBps": round(img.size * ((args.packed or args.container) / 8) * args.frames / dt / 1e9, 1)}
     print(json.dumps(res))
 
 
