@@ -217,3 +217,31 @@ def test_bit_packed_frames(bits, container):
     out = dp.collect()
     assert np.array_equal(unpack_bits(out, bits, img.size), img.reshape(-1))
     dp.close()
+
+
+@pytest.mark.gpu
+def test_frame_hand_over_options_are_checked():
+    """pixel-interleaved / bit-packed hand-over is refused where it cannot hold the frame: sub-sampled or signed
+    components, depths above the sample width, containers narrower than the samples, both options at once"""
+    from openjph_amd import capi
+    from openjph_amd.pipeline import EncoderPipe
+    from openjph_amd.plan import Plan, make_params
+
+    def refused(**kw):
+        plan_kw = kw.pop("plan")
+        try:
+            EncoderPipe(plan=Plan(make_params(64, 48, 3, **plan_kw)), depth=2, **kw).close()
+        except capi.OjphError:
+            return True
+        return False
+
+    assert refused(plan=dict(bit_depth=8, downsampling=[(1, 1), (2, 2), (2, 2)]), container=8, pixels=(8, False))
+    assert refused(plan=dict(bit_depth=8, is_signed=True), container=16, pixels=(8, False))
+    assert refused(plan=dict(bit_depth=12), container=16, pixels=(8, False))            # 12-bit samples in 8-bit pixels
+    assert refused(plan=dict(bit_depth=12), container=8, pixels=(16, True))             # (also: 12 bits in an 8-bit container)
+    assert refused(plan=dict(bit_depth=12), container=16, packed=10)
+    assert refused(plan=dict(bit_depth=10), container=16, packed=11)
+    assert refused(plan=dict(bit_depth=8), container=8, packed=10)                      # packed samples need 16- / 32-bit containers
+    assert refused(plan=dict(bit_depth=12), container=16, pixels=(16, False), packed=12)
+    assert not refused(plan=dict(bit_depth=12), container=16, packed=12)
+    assert not refused(plan=dict(bit_depth=12), container=32, pixels=(16, True))
