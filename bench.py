@@ -13,6 +13,12 @@ value = samples of all ranks / time; tiled frames (--workload c4_...) shard by c
 tiles of ONE frame, strong scaling, with the final tile-part gather over RCCL outside the timed
 region (it is host Tier-2 + PCIe work, like the single-GPU finish()).
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its N ranks itself (self_launch: the driver's own
+torch.distributed.run line on 127.0.0.1) and fails loudly when the node has fewer GPUs; under a launcher --gpus must equal
+WORLD_SIZE.  Every default run (any N) also carries `strong_scaling_c4`: the 16K x 16K frame in 256 tiles sharded over
+the ranks, with the RCCL gatherv of the tile-parts timed on its own -- one 1/2/4/8 sweep answers both the replica
+(weak) and the tile-sharded (strong) question of north_star.
+
 Prints ONE JSON line (rank 0).  Extra objects on that line:
   roofline     -- the dominant kernel of the step against the HBM roofline, from live HIP-event
                   timings on the codec's own stream (algorithmic bytes: SURVEY.md section 8(d))
@@ -68,9 +74,33 @@ def plan_is_tiled(tile):
     return tile[0] > 0
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: re-execute this script as N ranks (one process per GPU, the driver's own
+    launch line: torch.distributed.run, rendezvous on 127.0.0.1).  Rank 0's JSON line is the only thing on stdout.
+    Fails loudly when the node has fewer than N GPUs -- a smaller run must not pass for an N-GPU one."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("OJPH_BENCH_ONE_GPU"):
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node\n" % (n, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (one process per GPU).  Under a launcher (WORLD_SIZE in the environment) it must "
+                         "equal WORLD_SIZE; without one, N > 1 makes bench.py start its N ranks itself")
     ap.add_argument("--steps", type=int, default=1500,
                     help="timed steps (default 1500: about 2 s of GPU time on the 8K frame, long enough for an external sampler to see)")
     ap.add_argument("--warmup", type=int, default=5)
@@ -89,8 +119,20 @@ def main():
                     help="frames per frame-pipeline measurement (host memory -> codestream in host memory and back); 0 = skip")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch one elementwise kernel of known traffic (PMC unit calibration)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="skip the strong-scaling sub-measurement (the 16K x 16K frame in 256 tiles sharded over the ranks)")
+    ap.add_argument("--strong-steps", type=int, default=100)
     args = ap.parse_args()
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus is not None and args.gpus > 1:
+            sys.exit(self_launch(args.gpus))     # no launcher around us: become one (N ranks of this script, one per GPU)
+        args.gpus = 1
+    elif args.gpus is None:
+        args.gpus = int(env_world)
+    elif args.gpus != int(env_world):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the all-core CPU figure forks worker processes: done first, before this process owns a GPU context
@@ -359,6 +401,22 @@ def main():
         except Exception as e:                   # reported, never fatal for the headline figure
             e2e = {"error": str(e)[:300]}
 
+    # the strong-scaling question of north_star (one 16K frame, 256 tiles over the ranks) inside the same run
+    strong = None
+    if not args.no_strong and args.workload.startswith("c3") and frames == 1:
+        import gc
+        try:
+            del enc, dec
+        except NameError:
+            pass
+        gc.collect(); torch.cuda.synchronize(dev)
+        try:
+            strong = strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist)
+        except Exception as e:
+            if world > 1:
+                raise                                    # a rank that drops out would leave the others in a collective
+            strong = {"error": str(e)[:300]}
+
     result = {
         "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
         "value": round(nsamples * (1 if tiled else world) / (ms_per_step * 1e-3) / 1e6, 2),
@@ -392,6 +450,11 @@ def main():
     }
     if e2e:
         result["e2e"] = e2e
+    if strong:
+        result["strong_scaling_c4"] = strong
+    result["dist"] = {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                      "world_size": dist.get_world_size() if world > 1 else 1,
+                      "devices": torch.cuda.device_count(), "one_gpu_smoke": bool(os.environ.get("OJPH_BENCH_ONE_GPU"))}
     rv = roofline_valu(args.workload, kinfo)
     if rv:
         result["roofline_valu"] = rv
@@ -429,6 +492,115 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
+    """north_star's second scaling question, answered inside the same run as the replica figure: ONE 16384 x 16384 16-bit
+    frame in 256 tiles of 1024 x 1024 (BASELINE config 4), reversible 5/3, its tiles sharded over the ranks in contiguous
+    runs (strong scaling: the frame is fixed, a rank codes 256 / N tiles).  The timed step is encode + decode of the
+    rank's tiles, device resident, like `value`; the final codestream gather -- tile-parts assembled in HBM, an all-reduce
+    of the Psot lengths, a gatherv of the tile-part bytes to rank 0 over RCCL (point-to-point sends / receives of the exact
+    sizes) -- is timed separately.  Rank 0 checks the assembled codestream against the digest of the reference's own
+    (tests/golden/survey_ka.json, made by tests/golden/make_survey_ka.py); every rank checks its tiles decode losslessly.
+    Tile independence: ojph_codestream_local.cpp:113-180, ojph_tile.cpp:584-610."""
+    import hashlib
+    from openjph_amd import codec, shard
+    from openjph_amd.plan import Plan, make_params
+    from tests import synth
+    name = "c4_16k_gray_16b_rev53_tiled"
+    w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[name]
+    size = int(os.environ.get("OJPH_BENCH_STRONG_SIZE", "0")) or w            # (smaller frame: CPU-side smoke runs of this code path)
+    img = synth.survey_c4(size=size)
+    w = h = size
+    d_img = torch.from_numpy(img.astype(np.int16) if args.container == 16 else img).to(dev)
+    plan = Plan(make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile))
+    first, count = shard.tile_range(plan.num_tiles, rank, world)
+    assert count > 0, "more ranks than tiles"
+    enc = codec.Encoder(plan=plan, device=local_rank, tiles=(first, count))
+    enc.run_device(d_img)
+    torch.cuda.synchronize(dev)
+    cdev = dev if backend == "nccl" else None                 # device tensors over RCCL, host tensors over gloo
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    best = None
+    for _ in range(3):
+        sync()
+        t0 = time.perf_counter()
+        part, lens = enc.finish_tiles_device() if backend == "nccl" else enc.finish_tiles()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        if world > 1:
+            all_lens = shard.gather_tile_lengths(lens, plan.num_tiles, first, device=cdev, parts_per_tile=plan.parts_per_tile)
+            bufs, sizes = shard.gather_bytes(part, device=cdev, as_tensors=True)
+        else:
+            all_lens, bufs, sizes = np.asarray(lens, np.uint32), [part if hasattr(part, "cpu") else torch.frombuffer(bytearray(part), dtype=torch.uint8)], [len(part)]
+        sync()
+        t2 = time.perf_counter()
+        parts = [b.cpu().numpy().tobytes() for b in bufs] if rank == 0 else None
+        t3 = time.perf_counter()
+        cur = (t2 - t1, t1 - t0, t3 - t2)
+        best = cur if best is None or cur[0] < best[0] else best
+    cs = shard.assemble(plan.t2_main_header(all_lens), parts) if rank == 0 else None
+    digest_ok = None
+    if rank == 0 and size == WORKLOADS[name][0]:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_ka.json")))["c4"]
+        digest_ok = bool(len(cs) == gold["bytes"] and hashlib.sha256(cs).hexdigest() == gold["sha256"])
+    if world > 1:                                             # every rank decodes its tiles from the same codestream
+        n = torch.tensor([len(cs) if rank == 0 else 0], dtype=torch.int64, device=cdev or "cpu")
+        dist.broadcast(n, src=0)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=cdev or "cpu")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(cs), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        cs = cs if rank == 0 else buf.cpu().numpy().tobytes()
+        del buf
+    dec = codec.Decoder(cs, device=local_rank, tiles=(first, count))
+    d_out = torch.zeros_like(d_img)
+    dec.run_device(d_out)
+    torch.cuda.synchronize(dev)
+    assert dec.failed_blocks() == 0, "strong-scaling decode failed"
+    lossless = True
+    for t in range(first, first + count):
+        _, _, (x0, y0, tw, th) = plan.comp_plane(t, 0)
+        lossless = lossless and bool(torch.equal(d_out[:, y0:y0 + th, x0:x0 + tw], d_img[:, y0:y0 + th, x0:x0 + tw]))
+    assert lossless, "rank %d: its tiles of the reversible frame did not come back exactly" % rank
+    enc.set_timing(False); dec.set_timing(False)
+    steps = max(1, min(args.strong_steps, args.steps))
+    for _ in range(min(3, args.warmup)):
+        enc.run_device(d_img); dec.run_device(d_out)
+    sync(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enc.run_device(d_img); dec.run_device(d_out)
+    torch.cuda.synchronize(dev)
+    mine = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    per_rank = [mine]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=cdev or "cpu")
+        t[rank] = mine
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(x) for x in t.tolist()]
+    ms = max(per_rank) * 1e3 / steps
+    moved = int(sum(sizes)) - int(sizes[0])
+    del enc, dec, d_out, d_img
+    return {"workload": name, "scaling": "strong", "n_gpus": world, "width": w, "height": h, "tiles": int(plan.num_tiles),
+            "tiles_per_rank": [shard.tile_range(plan.num_tiles, r, world)[1] for r in range(world)],
+            "steps": steps, "ms_per_step": round(ms, 4), "per_rank_ms_per_step": [round(x * 1e3 / steps, 4) for x in per_rank],
+            "value": round(w * h * nc / ms / 1e3, 2), "unit": "Msamples/s",
+            "value_covers": "encode + decode of every rank's tiles, device resident (max over ranks); the gather below is outside",
+            "codestream_bytes": len(cs), "codestream_equals_reference_digest": digest_ok, "tiles_lossless_on_every_rank": True,
+            "gather": {"backend": "rccl" if backend == "nccl" else backend,
+                       "tile_parts_assembled_ms": round(best[1] * 1e3, 3),
+                       "lengths_allreduce_and_gatherv_ms": round(best[0] * 1e3, 3),
+                       "rank0_device_to_host_ms": round(best[2] * 1e3, 3),
+                       "bytes_received_by_rank0": moved,
+                       "gatherv_GBps": round(moved / best[0] / 1e9, 2) if moved and best[0] > 0 else None}}
 
 
 def roofline_valu(workload, kinfo):

@@ -30,7 +30,7 @@ def assemble(main_header: bytes, tile_parts) -> bytes:
     return b"".join([main_header] + list(tile_parts) + [b"\xff\xd9"])
 
 
-def gather_bytes(payload, group=None, dst=0, device=None):
+def gather_bytes(payload, group=None, dst=0, device=None, as_tensors=False):
     """Variable-length gather (gatherv) of one byte string per rank to `dst`: -> (list of per-rank byte strings
     on `dst`, None elsewhere; the sizes, on every rank).
 
@@ -38,7 +38,8 @@ def gather_bytes(payload, group=None, dst=0, device=None):
     Encoder.finish_tiles_device leaves them, so that they travel GPU -> GPU over xGMI without a host round trip).
     Two steps, as the path needs: an all-gather of the LENGTHS (every rank learns the prefix-sum offsets -- 8 bytes
     per rank), then only the actual bytes travel, and only to `dst`: point-to-point sends matched by receives of
-    the exact sizes (gatherv to rank 0, not an all-gather of padded buffers)."""
+    the exact sizes (gatherv to rank 0, not an all-gather of padded buffers).
+    as_tensors: `dst` gets the uint8 tensors as they arrived (on `device`) instead of host byte strings."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -62,6 +63,8 @@ def gather_bytes(payload, group=None, dst=0, device=None):
             for r in range(world) if r != rank and sizes[r]]
     for q in reqs:
         q.wait()
+    if as_tensors:
+        return bufs, sizes
     return [bytes(b.cpu().numpy().tobytes()) for b in bufs], sizes
 
 

@@ -62,14 +62,23 @@ def survey_c3(seed=1234, rows=4320):
 
 
 def survey_c4(seed=1234, size=16384):
-    """C4: 16384x16384x1 16-bit, 'the same family scaled to 16 bits' (C2's formula x 256)."""
+    """C4: 16384x16384x1 16-bit, 'the same family scaled to 16 bits' (C2's formula x 256).  Built slab by slab (the
+    float64 base and noise of the whole image would take 4 GB); the (x + y) term of a slab is a sliding window over its
+    1-D table -- the same values _family gives."""
     rng = np.random.default_rng(seed)
-    base = _family(size, size, 32768, 15360, 12800, 5120, 97, 61, 13)
+    x = np.arange(size, dtype=np.float64)
+    y = np.arange(size, dtype=np.float64)
+    s = np.arange(2 * size, dtype=np.float64)
+    row = 32768 + 15360 * np.sin(x / 97)
+    col = 12800 * np.cos(y / 61)
+    win = np.lib.stride_tricks.sliding_window_view(5120 * np.sin(s / 13), size)       # win[i, j] = t[i + j]
     out = np.empty((1, size, size), dtype=np.int32)
-    step = 2048                                          # in slabs: the float64 noise of the whole image would take 2 GB
+    step = 2048
     for r0 in range(0, size, step):
-        n = rng.normal(0, 1536, (min(step, size - r0), size))
-        out[0, r0:r0 + n.shape[0]] = np.clip(base[r0:r0 + n.shape[0]] + n, 0, 65535).astype(np.uint16)
+        r1 = min(r0 + step, size)
+        base = (row[None, :] + col[r0:r1, None]) + win[r0:r1]
+        n = rng.normal(0, 1536, (r1 - r0, size))
+        out[0, r0:r1] = np.clip(base + n, 0, 65535).astype(np.uint16)
     return out
 
 

@@ -64,3 +64,43 @@ def test_live_bench_line():
     check_line(d, want_cpu_baseline=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["config"]["roundtrip_max_abs_err"] <= 8
     assert d["e2e"]["frames"] == 8 and d["e2e_steady_Msamples_s"]["encode"] > 0 and d["e2e_steady_Msamples_s"]["encode+decode"] > 0
+
+
+def test_gpus_flag_without_enough_devices_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks -- and must refuse, not run a silent 1-GPU bench,
+    when the node does not have that many GPUs (this container has none)"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "OJPH_BENCH_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert b"--gpus 2" in r.stderr and b"visible" in r.stderr
+    # under a launcher the flag must agree with WORLD_SIZE
+    env["WORLD_SIZE"] = "4"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and b"WORLD_SIZE=4" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_self_launched_on_one_gpu():
+    """the N > 1 path of bench.py end to end on the one GPU of the test box: `--gpus 2` starts two ranks itself (both on
+    cuda:0, control and gather traffic over gloo), the line says n_gpus 2, and the tile-sharded 16K frame the two ranks
+    assemble is byte-identical to the reference's codestream (digest in tests/golden/survey_ka.json)"""
+    env = dict(os.environ, OJPH_BENCH_BACKEND="gloo", OJPH_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    check_line(d, want_cpu_baseline=False)
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["dist"]["world_size"] == 2
+    assert d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak"
+    s = d["strong_scaling_c4"]
+    assert s["n_gpus"] == 2 and s["tiles_per_rank"] == [128, 128] and len(s["per_rank_ms_per_step"]) == 2
+    assert s["codestream_equals_reference_digest"] is True and s["tiles_lossless_on_every_rank"] is True
+    assert s["gather"]["bytes_received_by_rank0"] > 100e6 and s["value"] > 0
