@@ -1,6 +1,8 @@
 """Case lists shared by tests/golden/make_golden.py (which runs the real reference once, in the
 build container) and tests/test_cpu_parity.py (which checks the oracle + host pipeline against the
 stored reference outputs anywhere)."""
+import numpy as np
+
 from tests.synth import synth_image
 
 # (w, h, K_max, density, amplitude, seed) -- single HT code-blocks (ojph_encode_codeblock32 inputs)
@@ -284,3 +286,27 @@ def refine_case(i):
     if i % 3 == 0:                       # runs of the bytes the stuffing rules care about
         tail = bytes((0xFF, 0x7F, 0x8F, 0x90, 0xFF, 0xFF)[j % 6] if (j // 7) % 2 else tail[j] for j in range(len2))
     return q, w, h, stride, kmax, npass, causal, tail
+
+
+def fuzz_seed_case(blob: bytes):
+    """An input of the reference's encoder fuzz target, decoded the way fuzzing/fuzz_targets/ojph_compress_fuzz_target.cpp
+    :46-124 reads it: 4 control bytes (width-1, height-1, components / depth selector / signed / reversible / colour
+    transform, decompositions / planar), then one sample per byte, wrapping around, pushed in exchange() order (planar:
+    component after component; otherwise row by row with the components of a row in turn).  -> (image [C,H,W] int32,
+    encoder keyword arguments)"""
+    d = np.frombuffer(blob, np.uint8)
+    w, h = int(d[0] & 0x7F) + 1, int(d[1] & 0x7F) + 1
+    nc = int(d[2] & 3) + 1
+    bd = (8, 10, 12, 16)[(int(d[2]) >> 2) & 3]
+    sg, rev, ct = bool((d[2] >> 4) & 1), bool((d[2] >> 5) & 1), bool((d[2] >> 6) & 1)
+    nd = min(int(d[3] & 7), 5)
+    planar = bool((d[3] >> 3) & 1)
+    if nc < 3:
+        ct = False
+    if ct:
+        planar = False
+    pix = d[4:].astype(np.int32)
+    seq = pix[np.arange(nc * h * w) % len(pix)] - (128 if sg else 0)
+    img = seq.reshape(nc, h, w) if planar else seq.reshape(h, nc, w).transpose(1, 0, 2)
+    return np.ascontiguousarray(img), dict(bit_depth=bd, is_signed=sg, reversible=rev, num_decomps=nd, color_transform=ct,
+                                           planar=planar, qstep=-1.0 if rev else 0.0005)

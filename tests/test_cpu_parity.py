@@ -171,18 +171,49 @@ def test_multi_pass_codestream_matches_live_reference(refgen):
         assert np.array_equal(got, want)
 
 
-def test_foreign_codestream_of_the_reference_tree(refgen):
-    """subprojects/js/html/test.j2c (a foreign encoder's stream: per-resolution precincts, ICT, 77
-    blocks with SigProp / MagRef passes) -- only where /root/reference exists."""
-    path = "/root/reference/subprojects/js/html/test.j2c"
-    if not os.path.exists(path):
-        pytest.skip("reference tree not present")
+def _foreign():
+    import hashlib, json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "foreign.json")))
+    rd = lambda e: open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", e["file"]), "rb").read()
+    sha = lambda a: hashlib.sha256(a if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a).tobytes()).hexdigest()
+    return g, rd, sha
+
+
+def test_foreign_codestream_of_the_reference_tree():
+    """tests/golden/foreign_test.j2c = the reference tree's subprojects/js/html/test.j2c (a foreign encoder's stream:
+    per-resolution precincts, ICT, 77 blocks with SigProp / MagRef passes): the oracle decodes what the reference's
+    generic build decodes (digest by tests/golden/make_foreign.py; the live library is asked too where it is built)."""
     from tests import cpu_pipeline as cp
-    cs = open(path, "rb").read()
-    want, _ = refgen.decode(cs)
+    from oracle import refbind
+    g, rd, sha = _foreign()
+    cs = rd(g["test_j2c"])
+    assert sha(cs) == g["test_j2c"]["sha256"]
     got, plan = cp.decode(cs)
-    assert int((plan.coded_blocks()["num_passes"] > 1).sum()) == 77
-    assert np.array_equal(got, want)
+    assert int((plan.coded_blocks()["num_passes"] > 1).sum()) == g["test_j2c"]["blocks_with_refinement_passes"] == 77
+    assert sha(got.astype(np.int32)) == g["test_j2c"]["decoded_sha256_generic"]
+    if refbind.available(generic=True):
+        want, _ = refbind.Ref(generic=True).decode(cs)
+        assert np.array_equal(got, want)
+    if os.path.exists("/root/reference/subprojects/js/html/test.j2c"):       # the fixture IS the tree's file
+        assert open("/root/reference/subprojects/js/html/test.j2c", "rb").read() == cs
+
+
+def test_encoder_fuzz_seed_of_the_reference_tree():
+    """tests/golden/fuzz_seed_*.bin = the seed of the reference's encoder fuzz target (128x128, 2 components, 12-bit
+    signed, 5/3, ONE decomposition, planar): the oracle pipeline writes the codestream the reference writes"""
+    from tests import cpu_pipeline as cp
+    from tests.golden_cases import fuzz_seed_case
+    from oracle import refbind
+    g, rd, sha = _foreign()
+    img, kw = fuzz_seed_case(rd(g["fuzz_seed"]))
+    assert kw == g["fuzz_seed"]["params"] and sha(img) == g["fuzz_seed"]["image_sha256"]
+    okw = {k: v for k, v in kw.items() if k != "planar"}
+    cs, *_ = cp.encode(img, **okw)
+    assert len(cs) == g["fuzz_seed"]["bytes"] and sha(cs) == g["fuzz_seed"]["sha256"]
+    dec, _ = cp.decode(cs)
+    assert np.array_equal(dec, img)
+    if refbind.available():
+        assert refbind.Ref().encode(img, kw["bit_depth"], is_signed=True, reversible=True, num_decomps=1, planar=True) == cs
 
 
 def test_decoder_rejects_what_the_reference_rejects(ref):

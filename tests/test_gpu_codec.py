@@ -2,6 +2,8 @@
 the emitted codestream must be byte-identical to the oracle-built one (which is pinned
 byte-for-byte against the real reference by tests/test_cpu_parity.py), and -- when
 oracle/_ref/*.so travelled to this box -- to the reference's own output."""
+import os
+
 import numpy as np
 import pytest
 
@@ -545,3 +547,46 @@ def test_blocks_larger_than_the_lds_output_stage(shape):
     got = codec.encode(img, bit_depth=16)
     assert got == want
     assert np.array_equal(codec.decode(got), img)
+
+
+@pytest.mark.gpu
+def test_foreign_codestream_through_the_hip_decoder():
+    """the only foreign-encoder codestream of the reference tree (tests/golden/foreign_test.j2c: 9/7 + ICT,
+    per-resolution precincts, 77 blocks with SigProp / MagRef passes) through ht_dec_refine_kernel and the rest of the HIP
+    decoder: sample for sample what the reference's generic build decodes (digest made by tests/golden/make_foreign.py,
+    ojph_block_decoder32.cpp:1318-1609), within 1 of its SIMD build; the frame pipeline gives the same frame"""
+    import hashlib, json
+    from openjph_amd import codec
+    from openjph_amd.pipeline import DecoderPipe
+    from oracle import refbind
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(gd, "foreign.json")))["test_j2c"]
+    cs = open(os.path.join(gd, g["file"]), "rb").read()
+    dec = codec.Decoder(cs)
+    assert int((dec.plan.coded_blocks()["num_passes"] > 1).sum()) == 77
+    out = dec.decode()
+    assert list(out.shape) == g["shape"]
+    assert hashlib.sha256(np.ascontiguousarray(out.astype(np.int32)).tobytes()).hexdigest() == g["decoded_sha256_generic"]
+    if refbind.available():                                    # the SIMD build's own tolerance: PAE <= 1
+        want, _ = refbind.Ref().decode(cs)
+        assert int(np.abs(out.astype(np.int64) - want).max()) <= g["max_abs_diff_generic_vs_simd"] <= 1
+    pipe = DecoderPipe(cs, depth=2, container=32)
+    slot = pipe.acquire(len(cs)); slot[:] = np.frombuffer(cs, np.uint8); pipe.submit()
+    assert np.array_equal(pipe.collect().astype(np.int64), out.astype(np.int64))
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_encoder_fuzz_seed_through_the_hip_encoder():
+    """the seed input of the reference's encoder fuzz target (signed 12-bit, two components, one decomposition): the HIP
+    path writes the reference's bytes (digest by tests/golden/make_foreign.py) and reads them back"""
+    import hashlib, json
+    from openjph_amd import codec
+    from tests.golden_cases import fuzz_seed_case
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(gd, "foreign.json")))["fuzz_seed"]
+    img, kw = fuzz_seed_case(open(os.path.join(gd, g["file"]), "rb").read())
+    kw.pop("planar")
+    cs = codec.encode(img, **kw)
+    assert len(cs) == g["bytes"] and hashlib.sha256(cs).hexdigest() == g["sha256"]
+    assert np.array_equal(codec.decode(cs), img)

@@ -147,10 +147,10 @@ def test_pipes_can_be_destroyed_with_frames_in_flight_and_run_side_by_side():
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits,big_endian,container", [(8, False, 8), (8, False, 16), (16, True, 16), (16, False, 32)],
                          ids=["u8-c8", "u8-c16", "u16be-c16", "u16le-c32"])
-def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, container):
+def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, container, refgen):
     """ojphgpu_unpack_pixels / pack_pixels against numpy, and the pipes fed with / returning the bytes of .ppm files
-    ([H,W,C], 16-bit samples big endian): same codestream as from planes, decoded frames equal after the reference's
-    clamp"""
+    ([H,W,C], 16-bit samples big endian): the codestream the REFERENCE writes for that .ppm-ordered frame (its
+    non-planar exchange order, colour transform on), decoded frames equal after the reference's clamp"""
     import torch
     from openjph_amd import codec
     from openjph_amd.pipeline import EncoderPipe, DecoderPipe
@@ -175,6 +175,7 @@ def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, conta
     # pipes
     plan = Plan(make_params(w, h, c, bit_depth=bd, color_transform=True))
     want = codec.Encoder(plan=plan).encode(planes.astype(np.int32))
+    assert want == refgen.encode(planes.astype(np.int32), bd, reversible=True, color_transform=True, planar=False)   # the reference leg
     pipe = EncoderPipe(plan=plan, depth=2, container=container, pixels=(bits, big_endian))
     buf = pipe.acquire()
     assert buf.shape == (h, w, c)
@@ -186,14 +187,15 @@ def test_pixel_interleaved_frames_unpacked_on_the_device(bits, big_endian, conta
     slot = dp.acquire(len(want)); slot[:] = np.frombuffer(want, np.uint8); dp.submit()
     out = dp.collect()
     assert out.shape == (h, w, c) and np.array_equal(out.astype(np.int64), img)
+    assert np.array_equal(refgen.decode(want)[0].transpose(1, 2, 0), out.astype(np.int64))
     dp.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits,container", [(12, 16), (10, 16), (14, 32)])
-def test_bit_packed_frames(bits, container):
-    """frames crossing PCIe as planes of bit-packed samples (1.5 bytes per 12-bit sample): same codestream as from
-    16-bit containers, decoded frames come back packed and equal"""
+def test_bit_packed_frames(bits, container, refgen):
+    """frames crossing PCIe as planes of bit-packed samples (1.5 bytes per 12-bit sample): the codestream the reference
+    writes for the frame, decoded frames come back packed and equal"""
     from openjph_amd import codec
     from openjph_amd.pipeline import EncoderPipe, DecoderPipe, pack_bits, unpack_bits
     from openjph_amd.plan import Plan, make_params
@@ -203,6 +205,7 @@ def test_bit_packed_frames(bits, container):
     assert np.array_equal(unpack_bits(pack_bits(img, bits), bits, img.size), img.reshape(-1))
     plan = Plan(make_params(w, h, c, bit_depth=bits))
     want = codec.Encoder(plan=plan).encode(img)
+    assert want == refgen.encode(img, bits, reversible=True, color_transform=False)      # the reference leg
     pipe = EncoderPipe(plan=plan, depth=2, container=container, packed=bits)
     for _ in range(3):                                        # slots recycled
         buf = pipe.acquire()
