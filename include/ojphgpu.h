@@ -521,10 +521,11 @@ int  ojphgpu_dec_pipe_submit(ojphgpu_dec_pipe* pipe);
 int  ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* pipe, const void** h_frame, size_t* bytes, uint32_t* failed_blocks);
 /* out[0] frames completed, [1] mean host parse time per frame (ms), [2] mean submit -> frame latency (ms), [3] host threads */
 int  ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* pipe, double out[4]);
-/* decoded frames come back pixel-interleaved, clamped to [0, 2^depth - 1] (ppm_out::write and its converters,
+/* decoded frames come back pixel-interleaved, clamped to [0, 2^depth - 1] -- ONE depth for the frame: the components
+ * must share their bit depth (a .ppm has one maxval), otherwise OJPHGPU_E_INVALID -- (ppm_out::write and its converters,
  * ojph_img_io.cpp:99-226, :539-556); same conditions as ojphgpu_enc_pipe_set_pixels; call before the first _submit */
 int  ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* pipe, int pixel_bits, int big_endian);
-int  ojphgpu_dec_pipe_set_packed(ojphgpu_dec_pipe* pipe, int bits);     /* decoded frames come back bit-packed (clamped) */
+int  ojphgpu_dec_pipe_set_packed(ojphgpu_dec_pipe* pipe, int bits);     /* decoded frames come back bit-packed, clamped to [0, 2^bits - 1] */
 
 /* ---------------------------------------------------------------------------------------------
  * 7. Pixel-interleaved samples <-> planar containers on the device (kernels_pixels.hip)

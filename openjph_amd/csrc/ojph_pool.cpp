@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -19,6 +20,7 @@ struct Batch {
   const std::function<void(size_t)>* fn;
   std::atomic<size_t> next{ 0 }, done{ 0 };
   std::mutex mu; std::condition_variable cv;
+  std::exception_ptr error;                              // the first exception a body threw (under mu)
 };
 
 class Pool {
@@ -39,7 +41,8 @@ public:
     cv_.notify_all();
     drain(*b);                                           // the caller works on its own batch
     std::unique_lock<std::mutex> lk(b->mu);
-    b->cv.wait(lk, [&] { return b->done.load() == n; });
+    b->cv.wait(lk, [&] { return b->done.load() == n; });   // every item is counted, also one whose body threw: `fn` outlives all calls
+    if (b->error) std::rethrow_exception(b->error);        // on the calling thread, after the last body has returned
   }
 
 private:
@@ -47,7 +50,8 @@ private:
     for (;;) {
       const size_t i = b.next.fetch_add(1);
       if (i >= b.n) return;
-      (*b.fn)(i);
+      try { (*b.fn)(i); }
+      catch (...) { std::lock_guard<std::mutex> lk(b.mu); if (!b.error) b.error = std::current_exception(); }
       if (b.done.fetch_add(1) + 1 == b.n) { std::lock_guard<std::mutex> lk(b.mu); b.cv.notify_all(); }
     }
   }

@@ -7,6 +7,8 @@
 // parallel_for(n, fn) runs fn(0) .. fn(n-1) on the pool's threads and on the caller; several callers
 // (the finisher threads of a frame pipeline) may be inside it at the same time.  OJPHGPU_T2_THREADS
 // sets the number of threads working on one call (default min(hardware threads, 8); 1 = caller only).
+// A body may throw: every item still runs (and is counted), and the first exception is rethrown from
+// parallel_for on the calling thread once the last body has returned -- never on a pool thread.
 #ifndef OJPH_POOL_H
 #define OJPH_POOL_H
 

@@ -679,6 +679,9 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
           if (empty_cb) break;
         }
         if (empty_cb) continue;
+        // (inner-node values are kept in 8 bits like the reference's `(ui8)mmsbs` store, ojph_precinct.cpp:425: a corrupt
+        // header with 256 or more increments at an inner node wraps there too, and only the leaf's 32-bit sum is tested
+        // against K_max, :430 -- the same streams are accepted and rejected)
         uint32_t mmsbs = 0;
         for (uint32_t cl = levels; cl > 0; --cl) {     // missing MSBs: the parent's value plus a unary increment
           const size_t n = mm.node(x, y, cl - 1);

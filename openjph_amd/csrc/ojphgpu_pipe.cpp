@@ -183,7 +183,12 @@ static void enc_finish_frame(ojphgpu_enc_pipe* p, EncSlot& s)
     s.cs_len = (size_t)L.total;
     return OJPHGPU_OK;
   });
-  if (rc) fail(rc);
+  if (rc) {
+    // uploads, kernels or the copy-out of this slot may already be enqueued: nothing of the slot may be rewritten or
+    // re-reserved (hipHostFree / hipFree in reserve()) by the next _acquire while they are in flight
+    hipStreamSynchronize(p->s_h2d); hipStreamSynchronize(p->s_comp); hipStreamSynchronize(p->s_d2h);
+    fail(rc);
+  }
 }
 
 static void enc_finisher(ojphgpu_enc_pipe* p)
@@ -511,7 +516,14 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     s.failed = failed;
     return OJPHGPU_OK;
   });
-  if (rc) fail(rc);
+  if (rc) {
+    // the slot goes DONE -> FREE next: whatever was enqueued for it must have finished before _acquire rewrites or
+    // re-reserves its buffers, and the shared decoder object must not keep pointing at them
+    hipStreamSynchronize(p->s_h2d); hipStreamSynchronize(s_comp); hipStreamSynchronize(p->s_d2h);
+    std::lock_guard<std::mutex> lk(p->enqueue_mus[k]);
+    if (d->o_cb_descs == s.cb_descs.p) { d->o_cb_descs = nullptr; d->o_data = nullptr; d->o_status = nullptr; }
+    fail(rc);
+  }
 }
 
 static void dec_worker(ojphgpu_dec_pipe* p)
@@ -670,6 +682,7 @@ extern "C" int ojphgpu_dec_pipe_set_pixels(ojphgpu_dec_pipe* p, int pixel_bits, 
     const Plan& P = *p->P;
     const int rc = pixels_fit(P, pixel_bits, p->container);
     if (rc) return rc;
+    for (const CompGeo& g : P.comps) if (g.bit_depth != P.comps[0].bit_depth) return OJPHGPU_E_INVALID;   // one clamp range per frame
     HIPCHK(hipSetDevice(p->device));
     const size_t nbytes = (size_t)P.frame_elems * (size_t)(pixel_bits / 8);
     for (DecSlot& s : p->slots) {

@@ -100,8 +100,10 @@ class EncoderPipe:
     def collect(self, copy=True):
         """the oldest frame's codestream; copy=False returns a view of pinned memory valid until the next collect"""
         ptr, n = C.c_void_p(), C.c_size_t()
-        self.in_flight -= 1
-        check(self._lib.ojphgpu_enc_pipe_collect(self._h, C.byref(ptr), C.byref(n)), "enc_pipe_collect")
+        rc = self._lib.ojphgpu_enc_pipe_collect(self._h, C.byref(ptr), C.byref(n))
+        if rc != capi.E_INVALID:             # E_INVALID: nothing was in flight, no slot consumed; any other outcome took the oldest frame
+            self.in_flight -= 1
+        check(rc, "enc_pipe_collect")
         v = _view(ptr.value, n.value)
         return v.tobytes() if copy else v
 
@@ -168,9 +170,15 @@ class DecoderPipe:
         self.in_flight += 1
 
     def collect(self, copy=True):
+        """the oldest frame.  When code-blocks failed on a non-resilient pipe the C ABI still hands the frame out
+        (failed blocks zeroed) with OJPHGPU_E_BLOCK: the exception raised here carries it as .frame and the count as
+        .failed_blocks (ojphgpu.h, ojphgpu_dec_pipe_collect)"""
         ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
-        self.in_flight -= 1
-        check(self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed)), "dec_pipe_collect")
+        rc = self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed))
+        if rc != capi.E_INVALID:             # E_INVALID: nothing was in flight, no slot consumed
+            self.in_flight -= 1
+        if rc != capi.E_BLOCK:
+            check(rc, "dec_pipe_collect")
         if self.packed:
             v = _view(ptr.value, n.value, np.uint8)
         elif self.pixels is not None:
@@ -179,6 +187,10 @@ class DecoderPipe:
             v = _view(ptr.value, n.value, np.uint8).view(dt).reshape(h, w, c)
         else:
             v = _view(ptr.value, n.value, _CONTAINER[self.container]).reshape(self.plan.frame_shape)
+        if rc == capi.E_BLOCK:
+            err = capi.OjphError(rc, "dec_pipe_collect: %d code-blocks" % failed.value)
+            err.frame, err.failed_blocks = v.copy(), int(failed.value)
+            raise err
         return v.copy() if copy else v
 
     def stats(self):
