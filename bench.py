@@ -119,10 +119,15 @@ def main():
                     help="frames per frame-pipeline measurement (host memory -> codestream in host memory and back); 0 = skip")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch one elementwise kernel of known traffic (PMC unit calibration)")
+    ap.add_argument("--plain", action="store_true",
+                    help="only the timed steps and their per-launch event timings (no two-stream / no-overlap objects, pipelines, "
+                         "strong-scaling part): what the rocprofv3 passes run, so that a trace holds ONE schedule of every launch")
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the strong-scaling sub-measurement (the 16K x 16K frame in 256 tiles sharded over the ranks)")
     ap.add_argument("--strong-steps", type=int, default=100)
     args = ap.parse_args()
+    if args.plain:
+        args.no_strong = True; args.e2e_frames = 0
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
@@ -325,11 +330,9 @@ def main():
     dom_b, dom_ms = kernels[dom]
     achieved = dom_b / 1e6 / dom_ms if dom_ms > 0 else 0.0
     traffic = None
-    try:                                         # HBM bytes per launch from the last committed PMC pass
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    pmc, pmc_state = committed_counters("pmc_traffic.json")       # HBM bytes per launch from the committed PMC pass ...
+    if pmc_state == "current":                                     # ... of exactly these kernel sources, or nothing
         traffic = pmc.get(args.workload, {}).get(dom.split("[")[0]) if "[" not in dom else pmc.get(args.workload, {}).get(dom)
-    except Exception:
-        pass
 
     # The same steps with the two independent jobs of a step -- encode this frame, decode that codestream
     # -- on two HIP streams (what a transcoder or a capture + playback node runs): reported next to
@@ -337,7 +340,7 @@ def main():
     # (HIP multiplexes streams onto 4 hardware queues: the one-stream codec objects and their side streams
     # are released first, or the two new streams would share queues and run one after the other)
     two_stream_ms = None
-    if args.streams == 1 and not tiled and world == 1:
+    if args.streams == 1 and not tiled and world == 1 and not args.plain:
         import gc
         del enc, dec
         gc.collect()
@@ -371,7 +374,7 @@ def main():
     # one stream, so the small lower levels are not stretched by the block coder that normally runs next to them
     # (their durations in `kernels` are; the schedule that makes the step fastest makes those spans longest)
     dwt_alone = None
-    if world == 1 and not tiled:
+    if world == 1 and not tiled and not args.plain:
         try:
             os.environ["OJPHGPU_NO_OVERLAP"] = "1"
             enc3 = codec.Encoder(plan=plan, device=local_rank, frames=frames)
@@ -445,7 +448,8 @@ def main():
                    "two_streams_ms_per_step": round(two_stream_ms, 4) if two_stream_ms else None,
                    "two_streams_Msamples_s": round(nsamples / two_stream_ms / 1e3, 2) if two_stream_ms else None},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic},
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/pmc_traffic.json (%s)" % pmc_state},
         "kernels": kinfo,
     }
     if e2e:
@@ -469,11 +473,9 @@ def main():
         ach = (bf + bi_) / 1e6 / (mf + mi)
         ach_all = (af + ai) / 1e6 / (amf + ami)
         tr = None
-        try:
+        if pmc_state == "current":
             w_ = pmc.get(args.workload, {})
             tr = w_.get("dwt_forward(level 1)", 0) + w_.get("dwt_inverse(level 1)", 0) or None
-        except Exception:
-            pass
         result["roofline_dwt"] = {"kernel": "dwt_forward + dwt_inverse (level 1, 2 launches)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr,
@@ -603,15 +605,31 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
                        "gatherv_GBps": round(moved / best[0] / 1e9, 2) if moved and best[0] > 0 else None}}
 
 
+def committed_counters(name):
+    """profiles/<name> -- counter passes are separate rocprofv3 runs (tools/pmc_round.sh, tools/sq_round.sh), their
+    results are committed.  They only describe THIS build if they were taken on the same kernel sources: the files carry
+    the digest of those sources (openjph_amd/build.py kernel_sources_digest) and a file with another digest, or none,
+    is refused: -> ({}, "stale: ...").  -> (contents, "current") otherwise."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}, "missing"
+    from openjph_amd.build import kernel_sources_digest
+    have, want = d.get("_kernels_sha256"), kernel_sources_digest()
+    if have != want:
+        return {}, "stale: taken on kernel sources %s, this build is %s" % ((have or "unstamped")[:12], want[:12])
+    return d, "current"
+
+
 def roofline_valu(workload, kinfo):
     """The block coder is bound by VALU issue, not by HBM: its launches against THAT roof.  Wavefront
     instructions come from the committed SQ counter pass (profiles/sq_counters.json, tools/sq_round.sh: SQ_INSTS_VALU
     / SQ_INSTS_SALU summed over the launch); a SIMD issues one wave64 integer VALU instruction per 4 cycles
     (measured), the chip has 1024 SIMDs at up to 2.4 GHz; the time comes from this run."""
-    try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json"))).get(workload, {})
-    except Exception:
-        return None
+    sq, state = committed_counters("sq_counters.json")
+    if state != "current":
+        return {"bound": "valu-issue", "kernels": {}, "source": "profiles/sq_counters.json (%s)" % state}
+    sq = sq.get(workload, {})
     out = {}
     for k, v in kinfo.items():
         base = k.split("(")[0].split("[")[0]
@@ -624,7 +642,8 @@ def roofline_valu(workload, kinfo):
     if not out:
         return None
     return {"bound": "valu-issue", "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz", "kernels": out,
-            "source": "profiles/sq_counters.json"}
+            "source": "profiles/sq_counters.json (current: same kernel sources, %s)" % json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["_kernels_sha256"][:12],
+            "issue_rate_probe": "tools/micro/valu_issue.hip, output in profiles/"}
 
 
 def pcie_bandwidth(torch, nbytes=256 << 20, reps=4):

@@ -13,6 +13,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-function"]
 
 
+def kernel_sources_digest():
+    """sha256 over the device code of the library (every .hip source and the headers / tables they include, in name
+    order): the identity of the kernels a counter pass was taken on.  tools/pmc_summary.py and tools/sq_round.sh stamp
+    their JSON with it; bench.py refuses counters whose stamp is not the digest of the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".inc")) or (f.endswith(".h") and f.startswith(("ht_", "kernels_"))):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

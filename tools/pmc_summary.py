@@ -99,8 +99,12 @@ def main():
                 nl = len(fe.get(low, [])) // max(len(fe.get(top, [])), 1)
                 out["dwt_%s(all levels)" % d] = traffic(top) + nl * traffic(low)
                 out["dwt_%s(level 1)" % d] = traffic(top)
-        # keyed by the bench workload (bench.py looks its kernels up under that name)
-        json.dump({sys.argv[4] if len(sys.argv) > 4 else "c3_8k_444_12b_irv97": out}, open(sys.argv[3], "w"), indent=1)
+        # keyed by the bench workload (bench.py looks its kernels up under that name); stamped with the digest of the
+        # kernel sources the pass ran on (bench.py refuses a file whose stamp is not the digest of the sources it runs)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from openjph_amd.build import kernel_sources_digest
+        json.dump({"_kernels_sha256": kernel_sources_digest(), sys.argv[4] if len(sys.argv) > 4 else "c3_8k_444_12b_irv97": out},
+                  open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ set -u
 R=gpurun_out/round; mkdir -p $R; export TMPDIR=/tmp
 ( timeout 900 python bench.py 2> $R/bench.err | tail -1 ) > $R/bench_c3.json
 rm -rf gpurun_out/prof
-( timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e-frames 0 2>&1 | tail -3 ) > $R/rocprof.log
+( timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline --plain 2>&1 | tail -3 ) > $R/rocprof.log
 DB=$(find gpurun_out/prof -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py "$DB" $R/kernel_stats.md > /dev/null; fi
 find gpurun_out/prof -name '*.db' -size +20M -delete

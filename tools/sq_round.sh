@@ -3,8 +3,8 @@
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf gpurun_out/sq1 gpurun_out/sq2
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d gpurun_out/sq1 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 > gpurun_out/sq1.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/sq2 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 > gpurun_out/sq2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d gpurun_out/sq1 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/sq2 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq2.log 2>&1
 python - <<'PY'
 import csv, glob, collections, json
 out = {}
@@ -38,6 +38,9 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
         for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep")):
             if d.endswith("sq1") and sub in k:
                 out[key] = {"valu_insts": tot["SQ_INSTS_VALU"] / n, "salu_insts": tot["SQ_INSTS_SALU"] / n}
-json.dump({"c3_8k_444_12b_irv97": dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")}, open("gpurun_out/sq_counters.json", "w"), indent=1)
+import os, sys
+sys.path.insert(0, os.getcwd())
+from openjph_amd.build import kernel_sources_digest
+json.dump({"_kernels_sha256": kernel_sources_digest(), "c3_8k_444_12b_irv97": dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")}, open("gpurun_out/sq_counters.json", "w"), indent=1)
 PY
 find gpurun_out/sq1 gpurun_out/sq2 -type f -size +4M -delete
