@@ -20,6 +20,8 @@ def kernel_sources_digest():
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
+        if f.startswith("_"):
+            continue                                      # scratch copies of experiments (never part of the library)
         if f.endswith((".hip", ".inc")) or (f.endswith(".h") and f.startswith(("ht_", "kernels_"))):
             h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()

@@ -531,6 +531,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 //     the reference's single buffer) and leave the CU once, as aligned dwords, when the block's
 //     length is known; only blocks that outgrow the stage spill their MagSgn bytes to the HBM
 //     scratch slot.
+#ifndef ABL
+#define ABL 0                           // ablation bits for timing experiments (tools/enc_only.py); 0 in the product
+#endif
 #ifndef NWAVES
 #define NWAVES 4                        // wavefronts (code-blocks) per workgroup of the narrow kernel
 #endif
@@ -542,15 +545,15 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 #endif
 constexpr uint32_t OUT_CAP = NOUT_CAP;  // bytes of coded output staged in LDS per wavefront
 constexpr int PMS_WORDS = 576;          // 64 lanes * 8 samples * 31 bits + < 257 pending bytes (a window is 256 bytes)
-constexpr int PVLC_WORDS = 112;         // 64 pairs * 30 bits of a step behind what earlier steps left pending (compacted on demand)
+constexpr int PVLC_WORDS = 80;          // 64 pairs * 30 bits + < 65 pending bytes
 
 struct NarrowLds {
   uint32_t out[OUT_CAP / 4];
   uint32_t ms[PMS_WORDS];
   uint32_t vlc[PVLC_WORDS];
+  uint32_t ev[8];                       // compacted MEL event bits of one step (<= 192)
   uint8_t  mel[MEL_CAP];
 };
-static_assert(2 * 2048 * 2 + 64 * 4 + NWAVES * sizeof(NarrowLds) <= 40960, "four workgroups of the narrow kernel must fit one CU's LDS");
 
 struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };
 
@@ -676,13 +679,14 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
 
   for (int i = lane; i < PMS_WORDS; i += 64) L.ms[i] = 0;
   for (int i = lane; i < PVLC_WORDS; i += 64) L.vlc[i] = 0;
+  if (lane < 8) L.ev[lane] = 0;
   wave_sync();
   if (lane == 0) { L.vlc[0] = 0xF; outb[OUT_CAP - 1] = 0xFF; }            // vlc_init: head byte, 4 bits already used (:365-375)
   wave_sync();
 
   // wave-uniform stream state
   uint32_t ms_pend = 0, ms_base = 0, ms_k = 0, ms_ff = 0;   // pending bits in L.ms and where they start, bytes written, last byte was 0xFF
-  uint32_t v_pend = 4, v_base = 0, v_pos = 1, v_prev = 0xFF;   // pending bits in L.vlc and where they start, bytes "written" (incl. the head), last byte
+  uint32_t v_pend = 4, v_pos = 1, v_prev = 0xFF;        // pending bits in L.vlc, bytes "written" (incl. the head), last byte
   MelFast melf = { 0, 0, 0, 0, 0, 0 };
   uint32_t* const mel_raw = reinterpret_cast<uint32_t*>(L.mel);       // raw MEL words until the block ends, then its bytes
   uint32_t err = 0, any_sig = 0;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   const bool pxok = px < PW;
   const uint32_t x0 = 4u * px;
   const bool has_q1 = pxok && x0 + 2 < W;
-  uint32_t last_S = 0;                                   // what the last quad row of the previous step hands to the first one of this step
+  uint32_t last_bot = 0;                                 // bottom-row pack of the previous step (all lanes)
 
   // Samples of one quad row of this lane's pair: top[0..3], bot[0..3].  The loads are UNCONDITIONAL: rows and columns
   // are clamped into the block, a lane / row / column that does not exist fetches something valid and is masked when
@@ -780,8 +784,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     return pos;
   };
   // same for the VLC buffer: bytes grow downwards, the rule looks at the byte above (:386-405)
-  auto vlc_windows = [&](uint32_t base, uint32_t T, bool flush) -> uint32_t {
-    uint32_t pos = base;
+  auto vlc_windows = [&](uint32_t T, bool flush) -> uint32_t {
+    uint32_t pos = 0;
     for (;;) {
       if (!flush && pos + 8u * 64u > T) break;
       const uint32_t start = pos + 8u * (uint32_t)lane;
@@ -826,73 +830,34 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     return rem;
   };
 
-  // ---- per-lane constants of the block ----
-  // The quantise transfer of a sample is ONE multiply (9/7) or ONE and (5/3) by a per-lane, per-column constant that is
-  // zero for the columns of this lane outside the block: what the clamped loads fetched there quantises to zero, so
-  // rho, exponents and MagSgn lengths of samples that do not exist come out as zero without a select per sample.
-  // 9/7: floor(|x| * (1/delta)) >> p == floor(|x| * ((1/delta) * 2^-p)) -- the scaling by a power of two is exact.
-  float colf[4]; uint32_t colm[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool in = pxok && x0 + (uint32_t)k < W;
-    colf[k] = in ? ldexpf(delta_inv, -(int)p) : 0.0f;
-    colm[k] = in ? (1u << (31u - p)) - 1u : 0u;                          // the magnitude bits the coder keeps: mu < 2^K_max
-  }
-  const bool ragged = (QH & (RPS - 1u)) != 0 || (H & 1u) != 0;           // the last step has quad rows / sample rows that do not exist
-
-  // one 32-bit value of at most 32 bits OR-ed into a bit buffer at bit position pos (no branch: the second word gets zeros
-  // when the value does not straddle)
-  auto or32 = [&](uint32_t* buf, uint32_t pos, uint32_t v) {
-    const uint32_t sh = pos & 31u;
-    uint32_t* wp = buf + (pos >> 5);
-    atomicOr(wp, v << sh);
-    atomicOr(wp + 1, (v >> 1) >> (sh ^ 31u));
-  };
-  // bytes of x that are not zero -> 0x80 in that byte (bytes < 0x80); 0x80-flags of four bytes -> bits 0..3
-  auto nz_flags = [](uint32_t x) -> uint32_t { return (x + 0x7F7F7F7Fu) & 0x80808080u; };
-  auto gather4 = [](uint32_t f) -> uint32_t { return ((f >> 7) * 0x10204080u) >> 28; };
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  auto pk_max = [](uint32_t a, uint32_t b2) -> uint32_t {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b2)));
-  };
-  // neighbour lanes of the same quad row (zero at the row's ends)
-  auto left_of = [&](uint32_t v) -> uint32_t {
-    if (LOGP == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
-    const uint32_t t = dpp_prev(v); return px == 0 ? 0u : t;
-  };
-  auto right_of = [&](uint32_t v) -> uint32_t {
-    if (LOGP == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, false);      // row_shl:1
-    const uint32_t t = dpp_next(v); return px == PPR - 1u ? 0u : t;
-  };
-
   uint32_t ntop[4], nbot[4];
   load_rows(r, ntop, nbot);
   for (uint32_t step = 0; step < nsteps && !err; ++step) {
     const uint32_t qy = RPS * step + r;
     const bool active = pxok && qy < QH;
-    // ---- quantise transfer + the coder's view of a sample (ojph_codestream_gen.cpp:59-121, ojph_block_encoder.cpp:592-601):
-    // mu = the magnitude above bit-plane p (the reference's val = 2 mu), the exponent e = bit length of 2 mu - 1, and
-    // sv = 2 (mu - 1) + sign, what MagSgn takes its bits from.  The sign-magnitude word of the reference is never formed.
-    if (ragged && step + 1 == nsteps) {                 // rows below the block: what was fetched for them counts as zero
-      const bool bot = active && 2u * qy + 1u < H;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { ntop[k] = active ? ntop[k] : 0u; nbot[k] = bot ? nbot[k] : 0u; }
-    }
-    uint32_t mu[8], sx[8];                              // sx: a word whose bit 31 is the sample's sign
+    const bool first_row = qy == 0;
+    // quantise transfer + 2*mu_p in one go (ojph_codestream_gen.cpp:59-121, ojph_block_encoder.cpp:592-595): the
+    // sign-magnitude word t = sign | magnitude of the reference is never formed, only what the coder takes from it --
+    // val = ((t + t) >> p) & ~1 and the sign t >> 31 -- with the same wrap-around when a magnitude overflows
+    uint32_t val[8], sgn[8], e[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // quad order: n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const uint32_t raw = j ? nbot[k] : ntop[k];
+        // what the lane fetched for a sample that does not exist counts as zero
+        const bool exists = active && x0 + (uint32_t)k < W && (j == 0 || 2u * qy + 1u < H);
+        const uint32_t raw = exists ? (j ? nbot[k] : ntop[k]) : 0u;
+        uint32_t mag, sg;
         if (rev) {
           const int v = (int)raw;
-          const uint32_t a = (uint32_t)(v >= 0 ? v : -v);
-          mu[2 * k + j] = a & colm[k];                                        // :70-76, with the same wrap-around when |v| >= 2^K_max:
-          sx[2 * k + j] = raw | (a << p);                                     // its top bit lands on the sign
+          mag = (uint32_t)(v >= 0 ? v : -v) << p;                              // :70-76
+          sg = (raw >> 31) | (mag >> 31);
         } else {
-          mu[2 * k + j] = (uint32_t)__fmul_rn(fabsf(__uint_as_float(raw)), colf[k]);   // :113-118, C truncation
-          sx[2 * k + j] = raw;
+          const int tq = (int)__fmul_rn(__uint_as_float(raw), delta_inv);      // :113-118, C truncation
+          mag = (uint32_t)(tq >= 0 ? tq : -tq);
+          sg = (uint32_t)tq >> 31;
         }
+        val[2 * k + j] = ((mag << 1) >> p) & ~1u; sgn[2 * k + j] = sg;
       }
     }
     if (step + 1 < nsteps) load_rows(qy + RPS, ntop, nbot); // request the next step's samples now
@@ -900,88 +865,82 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     // MEL "0" event and nothing else (no VLC codeword, no U-VLC, no MagSgn bits).  The events are all alike, so only
     // their number matters.  (Smooth content at moderate rates is mostly such steps in the top resolution's sub-bands.)
     {
-      const uint32_t nz = (mu[0] | mu[1]) | (mu[2] | mu[3]) | (mu[4] | mu[5]) | (mu[6] | mu[7]);
+      const uint32_t nz = val[0] | val[1] | val[2] | val[3] | val[4] | val[5] | val[6] | val[7];
       const bool step_sig = __ballot(nz != 0u) != 0ull;
       const bool skip = !step_sig && !prev_sig;
       prev_sig = step_sig;
       if (skip) {
         const uint32_t nq = (uint32_t)__popcll(__ballot(active)) + (uint32_t)__popcll(__ballot(has_q1 && active));
         melf_zero_run(melf, mel_raw, nq, lane);
-        last_S = 0;
+        last_bot = 0;
         continue;
       }
-      any_sig |= step_sig ? 1u : 0u;
     }
-    uint32_t e[8], sv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t m1 = mu[i] - 1u, w = m1 + mu[i];                         // 2 mu - 1 (all ones when mu = 0)
-      e[i] = (0u - (uint32_t)__builtin_clz(w)) & 31u;                         // 32 - clz(2 mu - 1), 0 for mu = 0 (w is never 0)
-      sv[i] = __builtin_amdgcn_alignbit(m1, sx[i], 31);                       // 2 (mu - 1) + sign (:601)
-    }
-    // exponents of a quad as four bytes; its significance pattern rho and, below, which samples reach the maximum
-    const uint32_t ep0 = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
-    const uint32_t ep1 = e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24);
-    const uint32_t sf0 = nz_flags(ep0), sf1 = nz_flags(ep1);
-    const uint32_t rho0 = gather4(sf0), rho1 = gather4(sf1);
-    const uint32_t emax0 = max(max(e[0], e[1]), max(e[2], e[3])), emax1 = max(max(e[4], e[5]), max(e[6], e[7]));
-
-    // ---- what the quad row below needs from this one, worked out HERE and handed down as one word per lane: for each
-    // of its two quads the largest exponent among the four bottom-row samples above it (columns x-1 .. x+2: kappa) in
-    // bits 0..4 of a 16-bit half, and whether the two left / the two right ones of them hold a significant sample
-    // (context bits "nw | n" and "ne | nf") in bits 5 / 7 -- :802, :862, :878, :950-:991.
-    uint32_t S;
-    {
-      const uint32_t b0 = e[1], b1 = e[3], b2 = e[5], b3 = e[7];             // bottom-row exponents of columns 0..3
-      const uint32_t m12 = max(b1, b2);
-      const uint32_t own = max(b0, m12) | (max(m12, b3) << 16);              // columns 0..2 (quad 0 below) | columns 1..3 (quad 1)
-      const uint32_t X = b3 | (b0 << 16), Y = b0 | (b3 << 16);
-      const uint32_t nb = (left_of(X) & 0xFFFFu) | (right_of(X) & 0xFFFF0000u);   // left lane's column 3 | right lane's column 0
-      const uint32_t mx = pk_max(own, nb);
-      const uint32_t F = (pk_max(nb, Y) + 0x007F001Fu) & 0x00800020u;        // quad 0: bit 5 = nw | n; quad 1: bit 7 = ne | nf
-      const uint32_t f12 = ((m12 + 31u) & 32u) * 0x10004u;                   // columns 1, 2: quad 0's ne | nf (bit 7), quad 1's nw | n (bit 5)
-      S = mx | F | f12;
-    }
-    const uint32_t give = (uint32_t)lane >= 64u - PPR ? last_S : S;
-    const uint32_t above = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane - (int)PPR) & 63) << 2), (int)give);
-    last_S = S;                                          // (the first quad row of the block gets the zero last_S starts with)
+    for (int i = 0; i < 8; ++i) e[i] = expo(val[i]);
+    // ---- the row above: exponents / significance of its samples, columns x0-1 .. x0+4 ----
+    uint32_t botpack = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) botpack |= (e[2 * k + 1] << (6 * k)) | ((val[2 * k + 1] ? 1u : 0u) << (24 + k));
+    const uint32_t give = (uint32_t)lane >= 64u - PPR ? last_bot : botpack;
+    uint32_t above = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane - (int)PPR) & 63) << 2), (int)give);
+    if (first_row || !active) above = 0;
+    uint32_t abl = dpp_prev(above), abr = dpp_next(above);
+    if (px == 0) abl = 0;
+    if (px == PPR - 1u) abr = 0;
+    last_bot = botpack;
+    uint32_t Eab[6], Sab[6];
+    Eab[0] = (abl >> 18) & 63u; Sab[0] = (abl >> 27) & 1u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Eab[1 + k] = (above >> (6 * k)) & 63u; Sab[1 + k] = (above >> (24 + k)) & 1u; }
+    Eab[5] = abr & 63u; Sab[5] = (abr >> 24) & 1u;
 
     // ---- per quad symbols ----
-    const uint32_t rho_left = left_of(rho1);            // rho of the quad to the left of quad 0
-    uint32_t uq[2], tup[2], Uq[2], chi[2];
+    uint32_t rho_q[2] = { 0, 0 }, emax[2] = { 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (val[i]) rho_q[i >> 2] |= 1u << (i & 3);
+      emax[i >> 2] = max(emax[i >> 2], e[i]);
+    }
+    uint32_t rho_prev = dpp_prev(rho_q[1]);             // rho of the quad to the left of q0
+    if (px == 0) rho_prev = 0;
+    uint32_t cq[2], uq[2], tup[2], msv[8], msl[8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const uint32_t rl = q == 0 ? rho_left : rho0, rho = q ? rho1 : rho0, emax = q ? emax1 : emax0, ep = q ? ep1 : ep0;
-      const uint32_t aq = q ? above >> 16 : above;
-      // context, kept as c << 5: rows below the first take nw / ne from above and "a quad to the left has a significant
-      // sample in its right column" (rho_left >= 4); the first row takes all three bits from the left quad (:731, :788)
-      uint32_t c5 = (aq & 0xA0u) | ((4u * rl + 48u) & 64u);
-      uint32_t tsel = 2048u;
-      if (step == 0) {
-        const bool fr = qy == 0;
-        c5 = fr ? ((rl >> 1) | (rl & 1u)) << 5 : c5;
-        tsel = fr ? 0u : 2048u;
+      const uint32_t rl = q == 0 ? rho_prev : rho_q[0];
+      uint32_t kappa = 1, c;
+      const uint32_t* E = Eab + 2 * q; const uint32_t* S = Sab + 2 * q;
+      const uint32_t me = max(max(E[0], E[1]), max(E[2], E[3]));
+      const uint32_t c_first = (rl >> 1) | (rl & 1u);                                       // :731,:788
+      const uint32_t c_other = (S[0] | S[1]) | ((S[2] | S[3]) << 2) | ((rl & 4u) >> 1) | ((rl & 8u) >> 2);   // :802,:878,:951,:967,:991
+      c = first_row ? c_first : c_other;
+      if (!first_row && (rho_q[q] & (rho_q[q] - 1u))) kappa = (uint32_t)max(1, (int)me - 1);  // :862,:950
+      const uint32_t U = max(emax[q], kappa), u = U - kappa;
+      uint32_t eps = 0;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) eps |= (uint32_t)(e[q * 4 + nn] == emax[q]) << nn;
+      if (u == 0) eps = 0;
+      const uint32_t tuple = s_vlc[first_row ? 0 : 1][(c << 8) + (rho_q[q] << 4) + eps];
+      cq[q] = c; uq[q] = u; tup[q] = tuple;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        const int i = q * 4 + nn;
+        const uint32_t m = (U - ((tuple >> nn) & 1u)) & (0u - ((rho_q[q] >> nn) & 1u));      // :667-674; U <= 31
+        const uint32_t sv = val[i] - 2u + sgn[i];                                           // v_n = 2(mu-1)+sign (:601)
+        msl[i] = m;
+        msv[i] = __builtin_amdgcn_ubfe(sv, 0u, m);                                          // the low m bits (none when m = 0)
       }
-      // kappa = max(1, max exponent above - 1) for a quad with more than one significant sample, else 1 (:862, :950)
-      const uint32_t multi = 0u - ((0xFEE8u >> rho) & 1u);
-      const uint32_t me = aq & 31u;
-      const uint32_t kappa = 1u + ((me > 2u ? me - 2u : 0u) & multi);
-      const uint32_t U = max(emax, kappa), u = U - kappa;
-      const uint32_t xe = ep ^ (emax * 0x01010101u);
-      uint32_t eps = gather4((nz_flags(xe) ^ 0x80808080u));               // samples whose exponent is the quad's maximum
-      eps = u ? eps : 0u;
-      tup[q] = (&s_vlc[0][0])[tsel + (c5 << 3) + (rho << 4) + eps];
-      uq[q] = u; Uq[q] = U; chi[q] = c5;
     }
+    any_sig |= (__ballot((rho_q[0] | rho_q[1]) != 0) != 0ull) ? 1u : 0u;
 
     // ---- VLC bits of the pair: cwd(q0) cwd(q1) then the interleaved U-VLC ----
     uint32_t vb = 0, vl = 0;
     bool ev2_valid = false; uint32_t ev2_bit = 0;
     {
       const uint32_t u0 = uq[0], u1 = has_q1 ? uq[1] : 0u;
-      vb = tup[0] >> 8; vl = (tup[0] >> 4) & 7u;
+      const uint32_t l0 = (tup[0] >> 4) & 7u;
+      vb = tup[0] >> 8; vl = l0;
       if (has_q1) { vb |= (tup[1] >> 8) << vl; vl += (tup[1] >> 4) & 7u; }
-      const bool first_row = qy == 0;
       const bool both_big = first_row && u0 > 2 && u1 > 2;                                   // :766-772
       const bool one_big = first_row && !both_big && u0 > 2 && u1 > 0;                       // :773-778
       ev2_valid = first_row && u0 > 0 && u1 > 0; ev2_bit = min(u0, u1) > 2;                   // :763-764
@@ -995,98 +954,78 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       if (!active) { vb = 0; vl = 0; ev2_valid = false; }
     }
 
-    // ---- MagSgn lengths: m_n = U - e_k bit for a significant sample, 0 otherwise (:667-674), four bytes per quad ----
-    uint32_t mp[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint32_t sf = q ? sf1 : sf0;
-      const uint32_t sig = (sf - (sf >> 7)) | sf;                             // 0xFF in the bytes of significant samples
-      const uint32_t ek = ((tup[q] & 15u) * 0x204081u) & 0x01010101u;         // the four e_k bits, one per byte
-      mp[q] = (Uq[q] * 0x01010101u - ek) & sig;
-    }
-    const uint32_t tot0 = __builtin_amdgcn_sad_u8(mp[0], 0u, 0u), tot = __builtin_amdgcn_sad_u8(mp[1], 0u, tot0);
-
-    // ---- stream positions of the lane's MagSgn and VLC bits: ONE wavefront prefix sum over both counts ----
-    const uint32_t incl = wave_incl_scan(tot | (vl << 16), lane);
-    const uint32_t sums = rdlane(incl, 63);
-    const uint32_t step_bits = sums & 0xFFFFu, step_vbits = sums >> 16;
-    // the pending bits of a buffer live at [base, base + pend); they only move to its front (and the buffer is
-    // cleared) when this step's bits would not fit behind them -- every third or fourth step on typical content
-    if (ms_base + ms_pend + step_bits + 64u > 32u * (uint32_t)PMS_WORDS) {
-      ms_pend = compact(L.ms, ms_base, ms_base + ms_pend, PMS_WORDS);
-      ms_base = 0;
-    }
-    if (v_base + v_pend + step_vbits + 64u > 32u * (uint32_t)PVLC_WORDS) {
-      v_pend = compact(L.vlc, v_base, v_base + v_pend, PVLC_WORDS);
-      v_base = 0;
-    }
-
-    // ---- MEL events of the step (quads with context 0, and in the first row the "both u > 0" event, :664, :763, :883):
-    // lane-major, within a lane quad 0, quad 1, then the u event.  The adaptive run-length coder is serial; it walks the
-    // "1" events only, in scalar code, taking the length of the zero run in front of each from population counts of the
-    // event masks (no compaction through LDS, no prefix sum).
-    {
-      const uint64_t V0 = __ballot(active && chi[0] == 0u), V1 = __ballot(active && has_q1 && chi[1] == 0u);
-      const uint64_t B0 = V0 & __ballot(rho0 != 0u), B1 = V1 & __ballot(rho1 != 0u);
-      uint64_t V2 = 0, B2 = 0;
-      if (step == 0) { V2 = __ballot(ev2_valid); B2 = V2 & __ballot(ev2_bit != 0u); }
-      uint64_t ones = B0 | B1 | B2;
-      uint32_t done = 0;                                                     // events already coded
-      while (ones) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(ones);
-        ones &= ones - 1ull;
-        const uint64_t below = (1ull << l) - 1ull;
-        uint32_t idx = (uint32_t)__popcll(V0 & below) + (uint32_t)__popcll(V1 & below) + (uint32_t)__popcll(V2 & below);
-        if ((V0 >> l) & 1ull) { if ((B0 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } idx++; }
-        if ((V1 >> l) & 1ull) { if ((B1 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } idx++; }
-        if ((V2 >> l) & 1ull) { if ((B2 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } }
-      }
-      const uint32_t nev = (uint32_t)__popcll(V0) + (uint32_t)__popcll(V1) + (uint32_t)__popcll(V2);
-      melf_zero_run(melf, mel_raw, nev - done, lane);
-    }
-
-    // ---- MagSgn and VLC bits into the flat, un-stuffed bit buffers ----
-    {
-      const uint32_t at = ms_base + ms_pend + (incl & 0xFFFFu) - tot;
-      const bool wide_bits = __ballot(max(Uq[0], Uq[1]) > 16u) != 0ull;      // wave-uniform: some sample of the step has more than 16 bits
-      if (!wide_bits) {
-        // two samples make at most 32 bits: the lane's eight values leave as four words
-        uint32_t pr[4], ln[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const uint32_t m = mp[q];
-          const uint32_t m0 = m & 0xFFu, m2 = (m >> 16) & 0xFFu;
-          const uint32_t v0 = __builtin_amdgcn_ubfe(sv[4 * q + 0], 0u, m0), v1 = __builtin_amdgcn_ubfe(sv[4 * q + 1], 0u, (m >> 8) & 0xFFu);
-          const uint32_t v2 = __builtin_amdgcn_ubfe(sv[4 * q + 2], 0u, m2), v3 = __builtin_amdgcn_ubfe(sv[4 * q + 3], 0u, m >> 24);
-          pr[2 * q] = v0 | (v1 << m0); pr[2 * q + 1] = v2 | (v3 << m2);
-          ln[q] = (m + (m >> 8)) & 0xFFu;                                     // bits of the quad's first two samples
+    if (ABL & 32) { any_sig |= (uint32_t)(__ballot((vb ^ msv[0] ^ msv[7] ^ msl[3] ^ cq[1]) == 0x12345u) != 0ull); continue; }
+    // ---- MEL events of the pair, compacted in pair order, then run through the adaptive coder ----
+    if (!(ABL & 4)) {
+      const bool ev0_valid = active && cq[0] == 0, ev1_valid = has_q1 && active && cq[1] == 0;
+      const uint32_t ev0_bit = rho_q[0] != 0, ev1_bit = rho_q[1] != 0;
+      const uint32_t cnt = (uint32_t)ev0_valid + (uint32_t)ev1_valid + (uint32_t)ev2_valid;
+      const uint32_t incl = wave_incl_scan(cnt, lane);
+      const uint32_t nev = rdlane(incl, 63);
+      if (nev) {
+        uint32_t at = incl - cnt;
+        if (ev0_valid) { if (ev0_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        if (ev1_valid) { if (ev1_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        if (ev2_valid) { if (ev2_bit) atomicOr(&L.ev[at >> 5], 1u << (at & 31)); at++; }
+        wave_sync();
+        // wave-uniform: whole zero runs at a time.  The step's event words are fetched from LDS ONCE (lane w holds
+        // word w) and walked in scalar registers -- with an LDS read per event, content whose significance is
+        // scattered (a "1" event every few quads) spent more time here than in everything else of the step
+        const uint32_t evw = L.ev[lane & 7];
+        uint32_t done = 0;
+        for (uint32_t w = 0; done < nev; ++w) {
+          uint32_t word = rdlane(evw, (int)w);
+          uint32_t left = min(32u, nev - done);
+          done += left;
+          while (left) {
+            const uint32_t z = word ? (uint32_t)__builtin_ctz(word) : 32u;
+            if (z >= left) { melf_zero_run(melf, mel_raw, left, lane); break; }
+            melf_zero_run(melf, mel_raw, z, lane);
+            melf_one(melf, mel_raw, lane);
+            word = z == 31u ? 0u : word >> (z + 1u);
+            left -= z + 1u;
+          }
         }
-        or32(L.ms, at, pr[0]);
-        or32(L.ms, at + ln[0], pr[1]);
-        or32(L.ms, at + tot0, pr[2]);
-        or32(L.ms, at + tot0 + ln[1], pr[3]);
-      } else {
-        uint32_t pos = at;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t m = (mp[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-          or_bits(L.ms, pos, __builtin_amdgcn_ubfe(sv[i], 0u, m), m);
-          pos += m;
-        }
+        wave_sync();
+        if (lane < 8) L.ev[lane] = 0;
       }
-      or32(L.vlc, v_base + v_pend + (incl >> 16) - vl, vb);
     }
-    wave_sync();
-    // ---- byte stuffing of the windows that are complete ----
+
+    // ---- MagSgn: OR the pair's bits into the flat buffer, stuff the full windows ----
     {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tot += msl[i];
+      const uint32_t incl = wave_incl_scan(tot, lane);
+      const uint32_t step_bits = rdlane(incl, 63);
+      // the pending bits live at [ms_base, ms_base + ms_pend) of the buffer; they only move to its front (and the
+      // buffer is cleared) when this step's bits would not fit behind them -- every third or fourth step on
+      // typical content instead of every step
+      if (ms_base + ms_pend + step_bits + 64u > 32u * (uint32_t)PMS_WORDS) {
+        ms_pend = compact(L.ms, ms_base, ms_base + ms_pend, PMS_WORDS);
+        ms_base = 0;
+      }
       const uint32_t T = ms_base + ms_pend + step_bits;
+      uint32_t at = ms_base + ms_pend + incl - tot;
+      if (!(ABL & 1)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { or_bits(L.ms, at, msv[i], msl[i]); at += msl[i]; }
+      }
+      wave_sync();
+      if (ABL & 2) { ms_base = 0; ms_pend = T & 7u; }
+      else {
       const uint32_t pos = ms_windows(ms_base, T, false);
       ms_base = pos; ms_pend = T - pos;
+      }
     }
-    {
-      const uint32_t T = v_base + v_pend + step_vbits;
-      const uint32_t pos = vlc_windows(v_base, T, false);
-      v_base = pos; v_pend = T - pos;
+    // ---- VLC ----
+    if (!(ABL & 8)) {
+      const uint32_t incl = wave_incl_scan(vl, lane);
+      const uint32_t T = v_pend + rdlane(incl, 63);
+      or_bits(L.vlc, v_pend + incl - vl, vb, vl);
+      wave_sync();
+      const uint32_t pos = vlc_windows(T, false);
+      v_pend = compact(L.vlc, pos, T, PVLC_WORDS);
     }
   }
 
@@ -1095,8 +1034,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   if (!err) {
     uint32_t pos = ms_windows(ms_base, ms_base + ms_pend, true);
     ms_carry = compact(L.ms, pos, ms_base + ms_pend, PMS_WORDS);
-    pos = vlc_windows(v_base, v_base + v_pend, true);
-    v_carry = compact(L.vlc, pos, v_base + v_pend, PVLC_WORDS);
+    pos = vlc_windows(v_pend, true);
+    v_carry = compact(L.vlc, pos, v_pend, PVLC_WORDS);
   }
 
   err |= melf.err;

@@ -3,7 +3,7 @@
 cp openjph_amd/libojphgpu.so /tmp/lib_orig.so
 for rep in 1 2; do
 for v in "$@"; do
-if [ $v = orig ]; then cp /tmp/lib_orig.so openjph_amd/libojphgpu.so; else cp openjph_amd/csrc/_build/lib_$v.so openjph_amd/libojphgpu.so; fi
+if [ $v = orig ]; then cp /tmp/lib_orig.so openjph_amd/libojphgpu.so; else cp openjph_amd/variants/lib_$v.so openjph_amd/libojphgpu.so; fi
 OJPH_BENCH_NOCHECK=1 timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --e2e-frames 0 2>/tmp/err.txt | tail -1 > /tmp/out.txt
 python -c "
 import json,sys; d=json.loads(open('/tmp/out.txt').read()); k=d['kernels']

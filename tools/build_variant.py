@@ -16,6 +16,6 @@ bdir = os.path.join(b.CSRC, "_build")
 obj = os.path.join(bdir, "%s.%s.o" % (src, name))
 subprocess.check_call([b.HIPCC, "-x", "hip"] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj])
 objs = [obj if s == src else os.path.join(bdir, s + ".o") for s in b.SOURCES]
-out = os.path.join(bdir, "lib_%s.so" % name)
+out = os.path.join(ROOT, "openjph_amd", "variants", "lib_%s.so" % name); os.makedirs(os.path.dirname(out), exist_ok=True)
 subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out] + objs)
 print(out)

@@ -37,7 +37,7 @@ shutil.copy(LIB, orig)
 try:
     for rep in range(2):
         for v in sys.argv[1:] or ["orig"]:
-            shutil.copy(orig if v == "orig" else os.path.join(ROOT, "openjph_amd", "csrc", "_build", "lib_%s.so" % v), LIB)
+            shutil.copy(orig if v == "orig" else os.path.join(ROOT, "openjph_amd", "variants", "lib_%s.so" % v), LIB)
             r = subprocess.run([sys.executable, "-c", CHILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             out = r.stdout.decode().strip().splitlines()
             print("%-12s total/dwt/ht... %s" % (v, out[-1] if out else r.stderr.decode()[-300:]), flush=True)
