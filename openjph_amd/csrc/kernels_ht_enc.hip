@@ -531,6 +531,10 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 //     the reference's single buffer) and leave the CU once, as aligned dwords, when the block's
 //     length is known; only blocks that outgrow the stage spill their MagSgn bytes to the HBM
 //     scratch slot.
+#ifndef ABL
+#define ABL 0                           // ablation bits for attribution experiments (tools/enc_only.py, tools/enc_counters.sh); 0 in the product:
+#endif                                  // 1 no MEL walk, 2 no MagSgn / VLC bits into LDS, 4 no byte stuffing windows, 8 symbols only,
+                                        // 16 sample loads + quantise transfer only, 32 (with any) samples read as if stored block by block
 #ifndef NWAVES
 #define NWAVES 4                        // wavefronts (code-blocks) per workgroup of the narrow kernel
 #endif
@@ -550,7 +554,10 @@ struct NarrowLds {
   uint32_t vlc[PVLC_WORDS];
   uint8_t  mel[MEL_CAP];
 };
-static_assert(2 * 2048 * 2 + 64 * 4 + NWAVES * sizeof(NarrowLds) <= 40960, "four workgroups of the narrow kernel must fit one CU's LDS");
+#ifndef NWG_PER_CU
+#define NWG_PER_CU 4                    // workgroups of the narrow kernel that must fit one CU's 160 KB of LDS
+#endif
+static_assert(NWG_PER_CU * (2 * 2048 * 2 + 64 * 4 + NWAVES * sizeof(NarrowLds)) <= 160 * 1024, "the narrow kernel's workgroups do not fit the LDS as planned");
 
 struct __attribute__((aligned(4))) U4 { uint32_t x, y, z, w; };
 
@@ -584,7 +591,7 @@ __device__ __forceinline__ void melf_append(MelFast& m, uint32_t* raw, uint32_t 
   if (m.nb >= 32u) {
     m.nb -= 32u;
     if (m.wpos >= MEL_RAW_WORDS) m.err = 1;
-    else if (lane == 0) raw[m.wpos] = (uint32_t)(m.acc >> m.nb);       // MSB first: the first bit of the stream is bit 31 of word 0
+    else raw[m.wpos] = (uint32_t)(m.acc >> m.nb);                      // MSB first: the first bit of the stream is bit 31 of word 0 (every lane stores the same word)
     m.wpos++;
   }
 }
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     const uint32_t y0 = 2u * qyc, y1 = min(y0 + 1u, H - 1u);
     const uint32_t* r0 = src + (size_t)y0 * pitch;
     const uint32_t* r1 = src + (size_t)y1 * pitch;
+    if (ABL & 32) { r0 = coef + (size_t)bi * 4096u + y0 * 64u; r1 = coef + (size_t)bi * 4096u + y1 * 64u; }   // timing experiment: block-contiguous samples
     if (w4) {
       const uint32_t xc = min(x0, W - 4u);
       const U4 a = *reinterpret_cast<const U4*>(r0 + xc);
@@ -779,7 +787,52 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     }
     return pos;
   };
+  // The same for the windows of a step, where every lane of a window has its four bytes by construction (the loop only
+  // runs while 256 whole bytes are pending): no per-lane byte counts, lane 0's 7-bit byte only when the previous window
+  // ended on an 0xFF, and the lane's four bytes leave as ONE (unaligned) dword store -- the lane at the cut writes up to
+  // three bytes too many, into space the next window overwrites (the capacity test keeps 72 bytes free above the cursor).
+  auto ms_windows_full = [&](uint32_t base, uint32_t T) -> uint32_t {
+    uint32_t pos = base;
+    for (;;) {
+      const uint32_t first_n = ms_ff ? 7u : 8u;
+      if (pos + first_n + 8u * 255u > T) break;
+      const uint32_t start = lane == 0 ? pos : pos + first_n - 8u + 32u * (uint32_t)lane;
+      const uint32_t w = start >> 5, sh = start & 31u;
+      uint32_t bytes = __funnelshift_r(L.ms[w], L.ms[w + 1], sh);
+      if (ms_ff) bytes = lane == 0 ? ((bytes & 0x7Fu) | ((bytes >> 7) << 8)) : bytes;
+      const uint32_t ffm = ((bytes & 0x7F7F7F7Fu) + 0x01010101u) & bytes & 0x80808080u;   // 0x80 in every byte that is 0xFF
+      const uint64_t m_ff = __ballot(ffm != 0u);
+      uint32_t nc = 256u, ff = 0u;
+      if (m_ff) { const uint32_t lf = (uint32_t)__builtin_ctzll(m_ff); nc = 4u * lf + ((uint32_t)__builtin_ctz(rdlane(ffm, (int)lf)) >> 3) + 1u; ff = 1u; }
+      if (ms_k - ms_out + nc + v_pos + 72u > OUT_CAP && !flush_stage()) { err = 1; break; }   // the stage is full
+      if (4u * (uint32_t)lane < nc) __builtin_memcpy(outb + (ms_k - ms_out) + 4u * (uint32_t)lane, &bytes, 4);
+      ms_k += nc;
+      pos += first_n + 8u * (nc - 1u);
+      ms_ff = ff;
+    }
+    return pos;
+  };
   // same for the VLC buffer: bytes grow downwards, the rule looks at the byte above (:386-405)
+  auto vlc_windows_full = [&](uint32_t base, uint32_t T) -> uint32_t {     // whole 64-byte windows only
+    uint32_t pos = base;
+    for (;;) {
+      if (pos + 8u * 64u > T) break;
+      const uint32_t v8 = get_bits(L.vlc, pos + 8u * (uint32_t)lane, 8);
+      uint32_t pv = dpp_prev(v8);
+      if (lane == 0) pv = v_prev;
+      const uint64_t m_sp = __ballot(pv > 0x8Fu && (v8 & 0x7Fu) == 0x7Fu);
+      uint32_t n8 = 64u, sp = 0u;
+      if (m_sp) { n8 = (uint32_t)__builtin_ctzll(m_sp); sp = 1u; }
+      if (v_pos + n8 + 1 >= (uint32_t)VLC_CAP) { err = 1; break; }
+      if (ms_k - ms_out + v_pos + n8 + 72u > OUT_CAP && !flush_stage()) { err = 1; break; }
+      if ((uint32_t)lane < n8 + sp) outb[OUT_CAP - 1 - (v_pos + lane)] = (uint8_t)((uint32_t)lane == n8 ? 0x7Fu : v8);
+      const uint32_t last8 = n8 ? rdlane(v8, (int)(n8 - 1)) : v_prev;
+      v_pos += n8 + sp;
+      pos += 8u * n8 + 7u * sp;
+      v_prev = sp ? 0x7Fu : last8;
+    }
+    return pos;
+  };
   auto vlc_windows = [&](uint32_t base, uint32_t T, bool flush) -> uint32_t {
     uint32_t pos = base;
     for (;;) {
@@ -896,6 +949,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       }
     }
     if (step + 1 < nsteps) load_rows(qy + RPS, ntop, nbot); // request the next step's samples now
+    if (ABL & 16) { any_sig |= (uint32_t)(__ballot((mu[0] ^ mu[1] ^ mu[2] ^ mu[3] ^ mu[4] ^ mu[5] ^ mu[6] ^ mu[7]) == 0x12345u) != 0ull); continue; }
     // A step without a significant sample, below a step without one: every quad has context 0 and rho 0, i.e. one
     // MEL "0" event and nothing else (no VLC codeword, no U-VLC, no MagSgn bits).  The events are all alike, so only
     // their number matters.  (Smooth content at moderate rates is mostly such steps in the top resolution's sub-bands.)
@@ -1025,28 +1079,39 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     // lane-major, within a lane quad 0, quad 1, then the u event.  The adaptive run-length coder is serial; it walks the
     // "1" events only, in scalar code, taking the length of the zero run in front of each from population counts of the
     // event masks (no compaction through LDS, no prefix sum).
-    {
+    if (ABL & 8) { any_sig |= (uint32_t)(__ballot((vb ^ mp[0] ^ mp[1] ^ sv[0] ^ sv[7] ^ chi[1] ^ incl) == 0x12345u) != 0ull); continue; }
+    if (!(ABL & 1)) {
       const uint64_t V0 = __ballot(active && chi[0] == 0u), V1 = __ballot(active && has_q1 && chi[1] == 0u);
       const uint64_t B0 = V0 & __ballot(rho0 != 0u), B1 = V1 & __ballot(rho1 != 0u);
       uint64_t V2 = 0, B2 = 0;
       if (step == 0) { V2 = __ballot(ev2_valid); B2 = V2 & __ballot(ev2_bit != 0u); }
+      if (V0 | V1 | V2) {                                                    // (dense content: most steps have no quad with context 0)
       uint64_t ones = B0 | B1 | B2;
       uint32_t done = 0;                                                     // events already coded
       while (ones) {
         const uint32_t l = (uint32_t)__builtin_ctzll(ones);
         ones &= ones - 1ull;
         const uint64_t below = (1ull << l) - 1ull;
-        uint32_t idx = (uint32_t)__popcll(V0 & below) + (uint32_t)__popcll(V1 & below) + (uint32_t)__popcll(V2 & below);
-        if ((V0 >> l) & 1ull) { if ((B0 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } idx++; }
-        if ((V1 >> l) & 1ull) { if ((B1 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } idx++; }
-        if ((V2 >> l) & 1ull) { if ((B2 >> l) & 1ull) { melf_zero_run(melf, mel_raw, idx - done, lane); melf_one(melf, mel_raw, lane); done = idx + 1u; } }
+        const uint32_t idx = (uint32_t)__popcll(V0 & below) + (uint32_t)__popcll(V1 & below) + (uint32_t)__popcll(V2 & below);
+        const uint32_t vl3 = (uint32_t)((V0 >> l) & 1ull) | ((uint32_t)((V1 >> l) & 1ull) << 1) | ((uint32_t)((V2 >> l) & 1ull) << 2);
+        uint32_t bl3 = (uint32_t)((B0 >> l) & 1ull) | ((uint32_t)((B1 >> l) & 1ull) << 1) | ((uint32_t)((B2 >> l) & 1ull) << 2);
+        while (bl3) {                                                        // the lane's "1" events, in order
+          const uint32_t j = (uint32_t)__builtin_ctz(bl3);
+          bl3 &= bl3 - 1u;
+          const uint32_t at = idx + (uint32_t)__popc(vl3 & ((1u << j) - 1u));
+          melf_zero_run(melf, mel_raw, at - done, lane);
+          melf_one(melf, mel_raw, lane);
+          done = at + 1u;
+        }
       }
       const uint32_t nev = (uint32_t)__popcll(V0) + (uint32_t)__popcll(V1) + (uint32_t)__popcll(V2);
       melf_zero_run(melf, mel_raw, nev - done, lane);
+      }
     }
 
     // ---- MagSgn and VLC bits into the flat, un-stuffed bit buffers ----
-    {
+    if (ABL & 2) { any_sig |= (uint32_t)(__ballot((vb ^ mp[0] ^ mp[1] ^ sv[0] ^ sv[3] ^ sv[5] ^ sv[7] ^ incl) == 0x12345u) != 0ull); }
+    else {
       const uint32_t at = ms_base + ms_pend + (incl & 0xFFFFu) - tot;
       const bool wide_bits = __ballot(max(Uq[0], Uq[1]) > 16u) != 0ull;      // wave-uniform: some sample of the step has more than 16 bits
       if (!wide_bits) {
@@ -1078,14 +1143,15 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     }
     wave_sync();
     // ---- byte stuffing of the windows that are complete ----
+    if (ABL & 4) { ms_base = 0; ms_pend = step_bits & 7u; v_base = 0; v_pend = step_vbits & 7u; continue; }
     {
       const uint32_t T = ms_base + ms_pend + step_bits;
-      const uint32_t pos = ms_windows(ms_base, T, false);
+      const uint32_t pos = ms_windows_full(ms_base, T);
       ms_base = pos; ms_pend = T - pos;
     }
     {
       const uint32_t T = v_base + v_pend + step_vbits;
-      const uint32_t pos = vlc_windows(v_base, T, false);
+      const uint32_t pos = vlc_windows_full(v_base, T);
       v_base = pos; v_pend = T - pos;
     }
   }
