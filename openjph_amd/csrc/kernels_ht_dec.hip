@@ -54,6 +54,9 @@
 #include "ht_uvlc.h"
 
 namespace ojphgpu {
+#ifdef S1_STATS
+__device__ unsigned long long g_s1_stats[8];     // experiment builds only: [0] slow VLC fetches, [1] their poll rounds, [2] slow MEL fetches, [3] pairs
+#endif
 __device__ uint16_t g_dec_vlc[2][1024];
 __device__ uint16_t g_dec_uvlc0[320];
 }
@@ -115,6 +118,11 @@ __device__ __forceinline__ uint32_t check_block(const ojphgpu_cb_desc& d, const 
   const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
   if (scup < 2 || scup > lcup || scup > 4079) return 0;
   return scup;
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
+{
+  uint32_t v; __builtin_memcpy(&v, p, 4); return v;
 }
 
 __device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v, uint32_t n)
@@ -260,6 +268,7 @@ struct FlatRd {
     bp = cross ? bp - 32u : bp; idx += cross ? 1u : 0u;
   }
   __device__ __forceinline__ void prefetch() { pre = w[idx < last ? idx : last]; }
+  __device__ __forceinline__ void settle() {}
 };
 
 // MEL: the adaptive run-length code is decoded by a PARTNER WAVEFRONT (the second wavefront of the workgroup, on
@@ -280,6 +289,21 @@ __device__ __forceinline__ uint32_t ev_words_of(uint32_t QW, uint32_t QH)
 // Demand driven: a lane stays at most EV_AHEAD words in front of what its chain has taken (s_cons), so that blocks
 // which hardly use the MEL stream (dense ones) do not pay for decoding all of it, and stops when the chain is done.
 constexpr uint32_t EV_AHEAD = 4;
+// one run of the adaptive MEL code (T.814 decodeMELSym, block_decoder32.cpp:170-269) from the MSB-first window, without a
+// branch: either 2^e "0" events (k up), or `run` < 2^e "0" events and a "1" (k down)
+__device__ __forceinline__ void mel_run(uint64_t& win, uint32_t& n, uint32_t& k, uint64_t& ev, uint32_t& nev)
+{
+  const uint32_t e = mel_exp(k);
+  const uint32_t top = (uint32_t)(win >> 32);
+  const bool zr = (top >> 31) != 0u;
+  const uint32_t run = (top >> (31u - e)) & ((1u << e) - 1u);
+  const uint32_t adv = zr ? 1u : e + 1u;
+  ev |= zr ? 0ull : 1ull << (nev + run);
+  nev += zr ? 1u << e : run + 1u;
+  k = zr ? (k < 12u ? k + 1u : 12u) : (k > 0u ? k - 1u : 0u);
+  win <<= adv; n -= adv;
+}
+
 __device__ __forceinline__ void mel_producer(const uint32_t* __restrict__ w, uint32_t nwords, uint32_t out_words,
                                              lds_u32* s_ev, volatile lds_u32* s_prog, const volatile lds_u32* s_cons,
                                              const volatile lds_u32* s_done, uint32_t lane)
@@ -293,16 +317,7 @@ __device__ __forceinline__ void mel_producer(const uint32_t* __restrict__ w, uin
     const bool go = wr < s_cons[lane] + EV_AHEAD;
     if (go) {
       if (n <= 32u) { win |= (uint64_t)pre << (32u - n); n += 32u; ++idx; pre = w[idx < last ? idx : last]; }
-      while (nev <= 31u && n >= 6u) {
-        const uint32_t e = mel_exp(k);
-        const uint32_t top = (uint32_t)(win >> 32);
-        if (top >> 31) { nev += 1u << e; k = k < 12u ? k + 1u : 12u; win <<= 1; n -= 1u; }     // 2^e zeros, no one
-        else {
-          const uint32_t run = (top >> (31u - e)) & ((1u << e) - 1u);                          // run zeros, then a one
-          ev |= 1ull << (nev + run); nev += run + 1u;
-          k = k > 0u ? k - 1u : 0u; win <<= (e + 1u); n -= (e + 1u);
-        }
-      }
+      while (nev <= 31u && n >= 6u) mel_run(win, n, k, ev, nev);
       if (nev >= 32u) {
         s_ev[wr * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++wr;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // LDS only: no wait on global memory
@@ -359,8 +374,8 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 #define PIN_WINDOW(r) asm volatile("" : "+v"((r).lo), "+v"((r).hi))
 
 // The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
-template <bool NARROW>
-__device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
+template <bool NARROW, class VlcRd>
+__device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
                                            const uint16_t* s_vlc, const uint16_t* s_uvlc0)
 {
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
@@ -400,7 +415,7 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __r
       len = entry & 7u; entry >>= 3;
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
-      vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
+      vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
@@ -460,11 +475,258 @@ __device__ __forceinline__ void step1_rows(FlatRd& vlc, EvRd& mel, uint32_t* __r
       // the pair's U-VLC by arithmetic instead of the uvlc_tbl1 look-up (:1065-1085): one LDS round trip less on the chain
       uint32_t u0, u1;
       used += ojphgpu::uvlc_pair_other_rows(v, t0 & 0x8u, t1 & 0x8u, u0, u1);
-      vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
+      vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
   }
+}
+
+// -------------------------------------------------------------------------------------------------
+// step 1 without a prep launch: the partner wavefront un-stuffs the block's VLC and MEL bytes itself
+// -------------------------------------------------------------------------------------------------
+// The flat bit strings the chain reads do not have to pass through HBM: the partner wavefront of a chain wavefront (one
+// lane per code-block, like the chain) reads the raw bytes of its block's cleanup segment -- the VLC part backwards from
+// the end, the MEL part forwards -- un-stuffs them with the rules flatten() applies, and hands the chain
+//   * the VLC bits as 32-bit words of the same flat LSB-first string, through a ring of VR_WORDS words per lane in LDS,
+//   * the MEL events decoded from the MEL bits, as before,
+// both demand driven: it stays a few words ahead of what the chain has taken.  Neither the chain nor anything else waits
+// for a prep launch (0.065 ms of an 8K frame's decode), the flat strings (two thirds of a byte per coded byte, written and
+// read once) never exist in memory, and the chain wavefront has no global load left in its loop: its record stores are the
+// only thing its vmcnt counts, so nothing on the chain ever waits for memory.
+constexpr uint32_t VR_WORDS = 16, VR_LOW = 6, EV_LOW = 2;    // high / low marks of the partner's bursts
+#ifndef MEL_RUNS_PER_PASS
+#define MEL_RUNS_PER_PASS 16
+#endif          // ring of flat VLC words per lane (the chain holds three more in registers)
+
+// chain side: the flat VLC string through the ring -- same window as FlatRd, words fetched from LDS
+struct RingRd {
+  const lds_u32* ring; volatile lds_u32* prog; volatile lds_u32* cons; uint32_t idx, lo, hi, pre, bp, av, pidx, lane; bool stuck;
+  __device__ __forceinline__ uint32_t fetch(uint32_t want) {      // blocking: waits until the partner has produced word `want`
+    uint32_t avail = prog[lane], spins = 0;
+    while (want >= avail && ++spins < (1u << 22)) { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; }
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    stuck = stuck || want >= avail;                          // cannot happen (the partner always progresses); never hang
+    return ring[(want & (VR_WORDS - 1u)) * 64u + lane];
+  }
+  __device__ __forceinline__ void init(const lds_u32* r, volatile lds_u32* p, volatile lds_u32* c, uint32_t l) {
+    ring = r; prog = p; cons = c; lane = l; stuck = false;
+    lo = fetch(0); hi = fetch(1); pre = fetch(2);
+    idx = 2; bp = 0; pidx = 0; av = 1;
+  }
+  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, bp); }
+  __device__ __forceinline__ void advance(uint32_t k) {
+    bp += k;
+    const bool cross = bp >= 32u;
+    lo = cross ? hi : lo; hi = cross ? pre : hi;
+    bp = cross ? bp - 32u : bp; idx += cross ? 1u : 0u;
+  }
+  // The word wanted next is read SPECULATIVELY together with the partner's progress count (progress first: LDS reads
+  // complete in order), both one quad pair before they are looked at; settle() -- called before the word can move into
+  // the window -- repeats the read in the rare case the partner had not got that far.  No lane polls in the steady
+  // state, so the 64 chains of the wavefront do not drag each other through a wait loop.
+  __device__ __forceinline__ void prefetch() { cons[lane] = idx; pidx = idx; av = prog[lane]; pre = ring[(idx & (VR_WORDS - 1u)) * 64u + lane]; }
+  __device__ __forceinline__ void settle() {
+    if (pidx >= av) {
+      pre = fetch(pidx); av = pidx + 1u;
+    }
+  }
+};
+
+// The partner's work for one lane's code-block.  VLC: flatten<false>'s string, word by word (rev_read :308-400: bytes from
+// cb[lcup - 3] downwards, 7 bits when the byte above is > 0x8F and the low 7 bits are ones, every raw byte OR-ed in with all
+// its bits, the 4 (3) initial bits from the high nibble of cb[lcup - 2], zeros beyond the segment).  MEL: mel_read :93-157
+// (forwards from cb[lcup - scup], 7 bits after an 0xFF, MSB first, the last byte's low nibble forced to ones, ones beyond
+// the segment) feeding the run-length decoder of mel_producer.
+struct __attribute__((aligned(4))) B16 { uint32_t d[4]; };
+__device__ __forceinline__ B16 load_b16_unaligned(const uint8_t* p) { B16 v; __builtin_memcpy(&v, p, 16); return v; }
+
+template <int ROLE>               // 1: the VLC words, 2: the MEL events (one partner wavefront each)
+__device__ __forceinline__ void raw_partner(const uint8_t* __restrict__ cb, uint32_t lcup, uint32_t scup, uint32_t room_below,
+                                            const B16& v0, const B16& v1, uint32_t ev_words,
+                                            lds_u32* s_ev, volatile lds_u32* s_eprog, const volatile lds_u32* s_econs,
+                                            lds_u32* s_vr, volatile lds_u32* s_vprog, const volatile lds_u32* s_vcons,
+                                            const volatile lds_u32* s_done, uint32_t lane)
+{
+  // Bytes come 16 at a time, one such chunk requested ahead of the one being worked on (a lane's loads are its own:
+  // nothing to coalesce, so what counts is round trips -- 4 bytes per trip kept the partner behind its chain).
+  // ---- VLC state ----
+  const uint32_t vreal = scup - 2u, vcount = vreal + 1u;     // real bytes; + the zero byte that keeps a stray bit of the last one
+  const uint32_t d0 = cb[lcup - 2];
+  uint64_t vacc = d0 >> 4;
+  uint32_t vnb = 4u - ((((d0 >> 4) & 7u) == 7u) ? 1u : 0u);
+  uint32_t vk = 0, vwr = 0, vp1 = d0 | 0xFu;
+  bool vp1_short = false;
+  // chunk c of the backward string = raw bytes 16c .. 16c+15: byte 16c in bits 31..24 of d[3], byte 16c+15 in bits 7..0 of d[0]
+  auto vload = [&](uint32_t k) -> B16 {
+    B16 z; z.d[0] = z.d[1] = z.d[2] = z.d[3] = 0u;
+    if (k >= vcount) return z;
+    const int off = (int)lcup - 18 - (int)k;                 // address of byte k+15
+    if (off >= -(int)room_below) return load_b16_unaligned(cb + off);   // (bytes below the segment do not count: masked by k+j < vreal)
+    for (int j = 0; j < 16; ++j) {                           // the first bytes of the buffer: never read below it
+      const int o = off + 15 - j;                            // address of byte k+j
+      if (o >= 0) z.d[3 - (j >> 2)] |= (uint32_t)cb[o] << (24 - 8 * (j & 3));
+    }
+    return z;
+  };
+  B16 vcur = v0, vnext = v1;
+  // ---- MEL state ----
+  const uint32_t mcount = scup - 1u, moff = lcup - scup;
+  auto mload = [&](uint32_t k) -> B16 {                      // raw bytes k .. k+15, byte k in bits 7..0 of d[0]
+    if (k < mcount) return load_b16_unaligned(cb + moff + k);
+    B16 z; z.d[0] = z.d[1] = z.d[2] = z.d[3] = 0xFFFFFFFFu; return z;
+  };
+  uint64_t win = 0;                                          // MSB first: the next bit is bit 63
+  uint32_t n = 0, mk = 0, mprev = 0, k = 0, nev = 0, ewr = 0;
+  B16 mcur, mnext;
+  if (ROLE == 2) { mcur = mload(0); mnext = mload(16); }
+  uint64_t ev = 0;
+  // The partner works in BURSTS: it wakes up when some lane's chain has come within the low mark of what was produced,
+  // fills every lane up to the high mark, and sleeps again.  A partner that tops up one word whenever one was taken runs all
+  // the time -- and it shares its SIMD with a chain wavefront, whose every instruction then queues behind a partner
+  // instruction that has just been issued.
+  bool burst = true;
+  for (;;) {
+    if (s_done[lane] != 0u) break;
+    if (!burst) {
+      const bool low = ROLE == 1 ? vwr < s_vcons[lane] + VR_LOW : (ewr < ev_words && ewr < s_econs[lane] + EV_LOW);
+      if (__ballot(low) == 0ull) { __builtin_amdgcn_s_sleep(32); continue; }
+      burst = true;
+    }
+    bool did = false;
+    if (ROLE == 1 && vwr < s_vcons[lane] + VR_WORDS) {       // ---- four more VLC bytes ----
+      did = true;
+      // the dword's four bytes at once (the byte-wise rule is in flatten<false>): W holds raw byte vk + j in byte j
+      uint32_t W = __builtin_bswap32(vcur.d[3]);
+      vcur.d[3] = vcur.d[2]; vcur.d[2] = vcur.d[1]; vcur.d[1] = vcur.d[0];
+      const uint32_t left = vk < vreal ? vreal - vk : 0u;                      // real bytes from vk on
+      W &= left >= 4u ? 0xFFFFFFFFu : (1u << (8u * left)) - 1u;               // beyond them: zeros
+      const uint32_t P = (W << 8) | vp1;                                       // byte j: the raw byte before byte j
+      const uint32_t G = ((P & 0x7F7F7F7Fu) + 0x70707070u) & P & 0x80808080u;  // ... is > 0x8F
+      const uint32_t L7 = ((W & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u;     // the low seven bits of byte j are ones
+      const uint32_t S = G & L7;                                               // byte j carries 7 bits
+      const uint32_t Sprev = (S << 8) | (vp1_short ? 0x80u : 0u);             // byte j-1 carried 7 bits ...
+      const uint32_t stray = ((Sprev & P) >> 7) & 0x01010101u;                 // ... and its MSB was set: OR-ed onto byte j's LSB
+      uint32_t x = (W | stray) & ~S;
+      x = (S & 0x00800000u) ? (x & 0x007FFFFFu) | ((x >> 1) & 0xFF800000u) : x;     // close the gaps above 7-bit bytes
+      x = (S & 0x00008000u) ? (x & 0x00007FFFu) | ((x >> 1) & 0xFFFF8000u) : x;
+      x = (S & 0x00000080u) ? (x & 0x0000007Fu) | ((x >> 1) & 0xFFFFFF80u) : x;
+      vacc |= (uint64_t)x << vnb;
+      vnb += 32u - (uint32_t)__popc(S);
+      vp1 = W >> 24; vp1_short = (S >> 31) != 0u;
+      vk += 4u;
+      if ((vk & 15u) == 0u) { vcur = vnext; vnext = vload(vk + 16u); }
+      if (vnb >= 32u) {
+        s_vr[(vwr & (VR_WORDS - 1u)) * 64u + lane] = (uint32_t)vacc; vacc >>= 32; vnb -= 32u; ++vwr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        s_vprog[lane] = vwr;
+      }
+    }
+    if (ROLE == 2 && ewr < ev_words && ewr < s_econs[lane] + EV_AHEAD) {  // ---- MEL: bytes in, events out ----
+      did = true;
+      if (n <= 32u) {
+        uint32_t w = mcur.d[0];
+        mcur.d[0] = mcur.d[1]; mcur.d[1] = mcur.d[2]; mcur.d[2] = mcur.d[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t b = w & 0xFFu; w >>= 8;
+          const uint32_t kk = mk + (uint32_t)j;
+          if (kk == mcount - 1u) b |= 0xFu;                  // the last MEL byte shares its low nibble with VLC (:116)
+          const uint32_t nbits = kk < mcount ? 8u - (mprev == 0xFFu ? 1u : 0u) : 8u;
+          const uint32_t val = kk < mcount ? b & ((1u << nbits) - 1u) : 0xFFu;
+          win |= (uint64_t)val << (64u - n - nbits);
+          n += nbits; mprev = kk < mcount ? b : 0u;
+        }
+        mk += 4u;
+        if ((mk & 15u) == 0u) { mcur = mnext; mnext = mload(mk + 16u); }
+      }
+      // (a bounded number of runs per pass: a lane that needs many events must not keep the other 63 lanes' VLC words waiting)
+      for (int it = 0; it < MEL_RUNS_PER_PASS && nev <= 31u && n >= 6u; ++it) mel_run(win, n, k, ev, nev);
+      if (nev >= 32u) {
+        s_ev[ewr * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++ewr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        s_eprog[lane] = ewr;
+      }
+    }
+    if (__ballot(did) == 0ull) burst = false;                // every lane is at the high mark
+  }
+}
+
+template <int CH>                 // CH chain wavefronts + 2 CH partner wavefronts per workgroup, 64 code-blocks per three of them
+__global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
+{
+  __shared__ uint16_t s_vlc[2048];
+  __shared__ uint16_t s_uvlc0[320];
+  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
+  __shared__ uint32_t s_vr_all[CH][VR_WORDS * 64];
+  __shared__ uint32_t s_ctl_all[CH][5][64];            // MEL words done / taken, VLC words done / wanted next, block done
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
+  for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
+  for (int i = threadIdx.x; i < CH * 5 * 64; i += blockDim.x) (&s_ctl_all[0][0][0])[i] = 0;
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool chain = wv < (uint32_t)CH;
+  const uint32_t set = wv % (uint32_t)CH;               // wavefronts CH .. 2CH-1: the VLC words, 2CH .. 3CH-1: the MEL events of the same blocks
+  lds_u32* s_ev = (lds_u32*)s_ev_all[set];
+  lds_u32* s_vr = (lds_u32*)s_vr_all[set];
+  volatile lds_u32* s_eprog = (volatile lds_u32*)s_ctl_all[set][0];
+  volatile lds_u32* s_econs = (volatile lds_u32*)s_ctl_all[set][1];
+  volatile lds_u32* s_vprog = (volatile lds_u32*)s_ctl_all[set][2];
+  volatile lds_u32* s_vcons = (volatile lds_u32*)s_ctl_all[set][3];
+  volatile lds_u32* s_done = (volatile lds_u32*)s_ctl_all[set][4];
+  if (chain) __builtin_amdgcn_s_setprio(3);
+  const uint32_t bi = (blockIdx.x * (uint32_t)CH + set) * 64u + lane;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) { if (chain) block_status[bi] = 0; return; }   // not coded: zero block
+  const uint8_t* cb = data + d.data_off;
+  const uint32_t room = d.data_off > 0xFFFFu ? 0xFFFFu : (uint32_t)d.data_off;
+  // The VLC partner asks for the first 32 bytes below the segment's end before anybody knows where the segment begins
+  // (scup sits in its last two bytes): they travel together with the two bytes check_block() reads, one round trip to
+  // memory instead of two in front of the first VLC word.  What lies below the VLC part is masked when it is used.
+  B16 v0, v1;
+  v0.d[0] = v0.d[1] = v0.d[2] = v0.d[3] = 0u; v1 = v0;
+  if (!chain && wv < 2u * (uint32_t)CH) {
+    const int o0 = (int)d.len1 - 18, o1 = o0 - 16;
+    if (o0 >= -(int)room) v0 = load_b16_unaligned(cb + o0);
+    else for (int j = 0; j < 16; ++j) { const int o = o0 + 15 - j; if (o >= 0) v0.d[3 - (j >> 2)] |= (uint32_t)cb[o] << (24 - 8 * (j & 3)); }
+    if (o1 >= -(int)room) v1 = load_b16_unaligned(cb + o1);
+    else for (int j = 0; j < 16; ++j) { const int o = o1 + 15 - j; if (o >= 0) v1.d[3 - (j >> 2)] |= (uint32_t)cb[o] << (24 - 8 * (j & 3)); }
+  }
+  const uint32_t scup = check_block(d, cb);
+  if (scup == 0) { if (chain) block_status[bi] = 1; return; }
+  const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
+  const uint32_t evw = ev_words_of(QW, QH);
+  if (!chain) {
+    if (wv < 2u * (uint32_t)CH) raw_partner<1>(cb, d.len1, scup, room, v0, v1, evw, s_ev, s_eprog, s_econs, s_vr, s_vprog, s_vcons, s_done, lane);
+    else raw_partner<2>(cb, d.len1, scup, room, v0, v1, evw, s_ev, s_eprog, s_econs, s_vr, s_vprog, s_vcons, s_done, lane);
+    return;
+  }
+  uint32_t* rec = quads + d.scratch_cap;
+#ifdef S1_STATS
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+  RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
+#ifdef S1_STATS
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
+#ifdef S1_STATS
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+#ifdef S1_STATS
+  if (lane == 0) { const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&ojphgpu::g_s1_stats[5], ts1 - ts0); atomicAdd(&ojphgpu::g_s1_stats[6], ts2 - ts1); atomicAdd(&ojphgpu::g_s1_stats[7], ts3 - ts2); atomicAdd(&ojphgpu::g_s1_stats[3], 1ull); }
+#endif
+  s_done[lane] = 1u;
+  block_status[bi] = (mel.stuck || vlc.stuck) ? 1 : 0;
 }
 
 template <int CH>                 // CH chain wavefronts + CH partner wavefronts per workgroup, 64 code-blocks per pair of them
@@ -510,13 +772,27 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
   }
   uint32_t* rec = quads + d.scratch_cap;          // pair p of this block: rec + 128 p (interleaved with the wavefront's other 63 blocks)
 
+#ifdef S1_STATS
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   FlatRd vlc; vlc.init(aux + d.reserved, vlc_words(scup));
+#ifdef S1_STATS
+  asm volatile("" : "+v"(vlc.pre));
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   EvRd mel; mel.init((const lds_u32*)s_ev, (volatile lds_u32*)s_prog, s_cons, evw, lane);
+#ifdef S1_STATS
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
   // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
   if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+#ifdef S1_STATS
+  if (lane == 0) { const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&ojphgpu::g_s1_stats[5], ts1 - ts0); atomicAdd(&ojphgpu::g_s1_stats[6], ts2 - ts1); atomicAdd(&ojphgpu::g_s1_stats[7], ts3 - ts2); atomicAdd(&ojphgpu::g_s1_stats[3], 1ull); }
+#endif
   s_done[lane] = 1u;                               // the partner stops producing events for this block
   block_status[bi] = mel.stuck ? 1 : 0;
 }
@@ -524,10 +800,6 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
 // -------------------------------------------------------------------------------------------------
 // step 2: one wavefront = one code-block, one lane = one sample column
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
-{
-  uint32_t v; __builtin_memcpy(&v, p, 4); return v;
-}
 
 // de-quantise transfer of one sign-magnitude word (ojph_codestream_gen.cpp:124-168)
 __device__ __forceinline__ uint32_t dequantise(uint32_t val, bool rev, uint32_t shift, float delta)
@@ -915,11 +1187,21 @@ extern "C" int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h, uint32_t n, uint64_t
   return OJPHGPU_OK;
 }
 
+namespace ojphgpu {
+// OJPHGPU_DEC_PREP=1: the two-launch form (prep writes the flat VLC / MEL strings, step 1 reads them) for A/B runs
+bool dec_uses_prep()
+{
+  static const bool v = [] { const char* e = getenv("OJPHGPU_DEC_PREP"); return e && atoi(e) != 0; }();
+  return v;
+}
+}
+
 extern "C" int ojphgpu_ht_decode_prep(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                        const uint8_t* d_data, uint32_t* d_aux)
 {
   if (n == 0) return OJPHGPU_OK;
   if (!d_blocks || !d_data || !d_aux) return OJPHGPU_E_INVALID;
+  if (!ojphgpu::dec_uses_prep()) return OJPHGPU_OK;            // step 1 reads the raw bytes itself
   hipLaunchKernelGGL(ht_dec_prep_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream,
                      d_blocks, n, d_data, d_aux);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
@@ -934,6 +1216,12 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
   if (!d_blocks || !d_data || !d_aux || !d_quad_scratch || !d_block_status) return OJPHGPU_E_INVALID;
   static const int ch = [] { const char* e = getenv("OJPHGPU_S1_CH"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 4; }();
   const uint32_t sets = (n + 63) / 64;
+  if (!ojphgpu::dec_uses_prep()) {
+    if (ch == 4) hipLaunchKernelGGL(ht_dec_step1_raw_kernel<4>, dim3((sets + 3) / 4), dim3(768), 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, d_block_status);
+    else if (ch == 2) hipLaunchKernelGGL(ht_dec_step1_raw_kernel<2>, dim3((sets + 1) / 2), dim3(384), 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, d_block_status);
+    else hipLaunchKernelGGL(ht_dec_step1_raw_kernel<1>, dim3(sets), dim3(192), 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, d_block_status);
+    return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  }
   if (ch == 4) hipLaunchKernelGGL(ht_dec_step1_kernel<4>, dim3((sets + 3) / 4), dim3(512), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   else if (ch == 2) hipLaunchKernelGGL(ht_dec_step1_kernel<2>, dim3((sets + 1) / 2), dim3(256), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   else hipLaunchKernelGGL(ht_dec_step1_kernel<1>, dim3(sets), dim3(128), 0, (hipStream_t)stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
@@ -987,6 +1275,15 @@ extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_refine(stream, d_blocks, n, d_data, d_coef, d_block_status);
   return rc;
 }
+
+#ifdef S1_STATS
+extern "C" int ojphgpu_debug_s1_stats(unsigned long long out[8], int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ojphgpu::g_s1_stats), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ojphgpu::g_s1_stats), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 namespace ojphgpu {
 int upload_dec_tables(const HtTables& t)
