@@ -305,6 +305,11 @@ def main():
         "ht_dec_step1": ((0.2 * c_rate + 1.0) * ns, td["ht_step1_ms"]),
         "ht_dec_step2": ((c_rate + 1.0 + 4.0) * ns, td["ht_step2_ms"]),
     }
+    if td["ht_step1_ms"] == 0.0 and td["ht_prep_ms"] < 0.02 and td["ht_step2_ms"] > 0:
+        # step 1 and step 2 ran as ONE launch (chains first, step-2 workers behind them slice by slice): one entry, the
+        # bytes of both -- the per-quad records still pass through memory once in each direction
+        b1, _ = kernels.pop("ht_dec_step1"); b2, _ = kernels.pop("ht_dec_step2"); kernels.pop("ht_dec_prep")
+        kernels["ht_dec_fused(step 1 + step 2)"] = (b1 + b2, td["ht_step2_ms"])
     if len(te["ht_launches_ms"]) == 2:
         # the encoder codes the top resolution's blocks on a side stream, concurrently with the lower
         # DWT levels and followed by the rest: two launches of the same kernel per frame, listed one

@@ -32,6 +32,11 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
                      int widths, const uint32_t* d_regions, uint32_t nreg);   // regions: see claim_output (kernels_ht_enc.hip)
 // ojphgpu_ht_decode_step2 with the caller's knowledge of the blocks of the range (kernels_ht_dec.hip)
+// step 1 + step 2 in one launch (kernels_ht_dec.hip, ht_dec_fused_kernel): chains first, step-2 workers behind them
+bool dec_fuses();
+uint64_t ht_decode_fused_state_words(uint32_t n);
+int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
+                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds);
 int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
                            const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds);
 

@@ -54,9 +54,6 @@
 #include "ht_uvlc.h"
 
 namespace ojphgpu {
-#ifdef S1_STATS
-__device__ unsigned long long g_s1_stats[8];     // experiment builds only: [0] slow VLC fetches, [1] their poll rounds, [2] slow MEL fetches, [3] pairs
-#endif
 __device__ uint16_t g_dec_vlc[2][1024];
 __device__ uint16_t g_dec_uvlc0[320];
 }
@@ -253,8 +250,13 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
 // one more word in flight.  peek() is ONE v_alignbit_b32; advance(k) crosses at most one word boundary (k <= 32),
 // where the prefetched word moves in -- selects, no branch.  prefetch() is issued once per quad pair, after
 // advance(): the word it requests is only looked at one pair later.
+// agent-scope accesses: what chains, workers of other slices and other XCDs (each with an L2 of its own) exchange inside
+// ONE launch of the fused kernel goes through memory, not through a cache that only its writer's XCD sees
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct FlatRd {
-  const uint32_t* w; uint32_t idx, last, lo, hi, pre, bp;
+  const uint32_t* w; uint32_t idx, last, lo, hi, pre, bp, lane = 0;
   __device__ __forceinline__ void init(const uint32_t* p, uint32_t nwords) {
     w = p; last = nwords - 1u;
     lo = p[0]; hi = p[last < 1u ? last : 1u]; pre = p[last < 2u ? last : 2u];
@@ -332,9 +334,9 @@ __device__ __forceinline__ void mel_producer(const uint32_t* __restrict__ w, uin
 struct EvRd {
   const lds_u32* ev; volatile lds_u32* prog; volatile lds_u32* cons; uint32_t idx, last, lo, hi, pre, bp, avail, lane; bool stuck;
   __device__ __forceinline__ uint32_t fetch(uint32_t want) {
-    if (want >= avail) {                                     // rare: the producer is not that far yet
+    if (want >= avail && !stuck) {                           // rare: the producer is not that far yet
       uint32_t spins = 0;
-      do { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; } while (want >= avail && ++spins < (1u << 22));
+      do { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; } while (want >= avail && ++spins < (1u << 17));
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       stuck = stuck || want >= avail;                        // cannot happen (the partner always progresses); never hang
     }
@@ -374,9 +376,27 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 #define PIN_WINDOW(r) asm volatile("" : "+v"((r).lo), "+v"((r).hi))
 
 // The quad rows of one code-block (one lane).  NARROW: QW <= 32 for every lane of the wavefront.
-template <bool NARROW, class VlcRd>
+// FUSED: the records are stored with agent scope and after every S2_ROWS quad rows the wavefront says so in `flag`
+// ((epoch << 16) | rows done), once its stores have completed: step-2 workers of the same launch are waiting for them.
+#ifndef S2_ROWS_N
+#define S2_ROWS_N 8
+#endif
+constexpr uint32_t S2_ROWS = S2_ROWS_N, S2_MAX_PER_WAVE = 8;
+template <bool FUSED>
+__device__ __forceinline__ void store_rec(uint32_t* p, uint32_t a, uint32_t b)
+{
+  if (FUSED) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)a | ((unsigned long long)b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else store_pair(p, a, b);
+}
+__device__ __forceinline__ void publish_rows(uint32_t* flag, uint32_t epoch, uint32_t rows, uint32_t lane)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the record stores of these rows have completed
+  if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) st_agent(flag, (epoch << 16) | rows);
+}
+
+template <bool NARROW, bool FUSED = false, class VlcRd>
 __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
-                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0)
+                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0)
 {
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
   // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
@@ -416,7 +436,7 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
       const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
-      store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
+      store_rec<FUSED>(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
   }
@@ -476,9 +496,10 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       uint32_t u0, u1;
       used += ojphgpu::uvlc_pair_other_rows(v, t0 & 0x8u, t1 & 0x8u, u0, u1);
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
-      store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
+      store_rec<FUSED>(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
     sig_prev = sig_cur;
+    if (FUSED && ((qy + 1u) & (S2_ROWS - 1u)) == 0u) publish_rows(flag, epoch, qy + 1u, vlc.lane);
   }
 }
 
@@ -503,8 +524,9 @@ constexpr uint32_t VR_WORDS = 16, VR_LOW = 6, EV_LOW = 2;    // high / low marks
 struct RingRd {
   const lds_u32* ring; volatile lds_u32* prog; volatile lds_u32* cons; uint32_t idx, lo, hi, pre, bp, av, pidx, lane; bool stuck;
   __device__ __forceinline__ uint32_t fetch(uint32_t want) {      // blocking: waits until the partner has produced word `want`
+    if (stuck) return 0u;                                    // (gave up on this block before: no second wait)
     uint32_t avail = prog[lane], spins = 0;
-    while (want >= avail && ++spins < (1u << 22)) { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; }
+    while (want >= avail && ++spins < (1u << 17)) { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; }
 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     stuck = stuck || want >= avail;                          // cannot happen (the partner always progresses); never hang
@@ -708,23 +730,10 @@ __global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
     return;
   }
   uint32_t* rec = quads + d.scratch_cap;
-#ifdef S1_STATS
-  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
   RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
-#ifdef S1_STATS
-  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-#endif
   EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
-#ifdef S1_STATS
-  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-#endif
   if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
-#ifdef S1_STATS
-  if (lane == 0) { const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&ojphgpu::g_s1_stats[5], ts1 - ts0); atomicAdd(&ojphgpu::g_s1_stats[6], ts2 - ts1); atomicAdd(&ojphgpu::g_s1_stats[7], ts3 - ts2); atomicAdd(&ojphgpu::g_s1_stats[3], 1ull); }
-#endif
   s_done[lane] = 1u;
   block_status[bi] = (mel.stuck || vlc.stuck) ? 1 : 0;
 }
@@ -772,27 +781,13 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
   }
   uint32_t* rec = quads + d.scratch_cap;          // pair p of this block: rec + 128 p (interleaved with the wavefront's other 63 blocks)
 
-#ifdef S1_STATS
-  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
   FlatRd vlc; vlc.init(aux + d.reserved, vlc_words(scup));
-#ifdef S1_STATS
-  asm volatile("" : "+v"(vlc.pre));
-  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-#endif
   EvRd mel; mel.init((const lds_u32*)s_ev, (volatile lds_u32*)s_prog, s_cons, evw, lane);
-#ifdef S1_STATS
-  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-#endif
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
   // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
   if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
-#ifdef S1_STATS
-  if (lane == 0) { const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&ojphgpu::g_s1_stats[5], ts1 - ts0); atomicAdd(&ojphgpu::g_s1_stats[6], ts2 - ts1); atomicAdd(&ojphgpu::g_s1_stats[7], ts3 - ts2); atomicAdd(&ojphgpu::g_s1_stats[3], 1ull); }
-#endif
   s_done[lane] = 1u;                               // the partner stops producing events for this block
   block_status[bi] = mel.stuck ? 1 : 0;
 }
@@ -820,23 +815,19 @@ __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
 // TX 1: reversible, no refinement passes; TX 2: irreversible, no refinement passes.  WD 1: no block wider than 64
 // samples.  The flags are wave-uniform either way; as template constants they take ~20 scalar tests and branches
 // out of every quad row.
-template <int TX, int WD>
-__global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
-    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
-    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
+// Per-block state a sliced step 2 keeps between two slices of a block (in LDS, 20 words per block): words 0..15 the
+// bottom-row exponents of the 64 columns (a byte each), 16 the MagSgn bits decoded so far, 17 a restart point of the
+// un-stuffer (bytes consumed, a multiple of 256), 18 the un-stuffed bits that point corresponds to, 19 != 0: the block failed.
+constexpr uint32_t S2_STATE_WORDS = 20;
+
+// Step 2 of ONE code-block by one wavefront: quad rows [qy_begin, qy_end) -- the whole block for the plain kernel;
+// SLICED: a slice of rows, state from / to `state`, per-quad records read with agent scope (the fused kernel).
+template <int TX, int WD, bool SLICED>
+__device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t bi, const uint8_t* __restrict__ data,
+                                            const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef,
+                                            uint8_t* __restrict__ block_status, uint32_t* ring, uint8_t* s_exp_w,
+                                            int lane, uint32_t qy_begin, uint32_t qy_end, uint32_t* state)
 {
-  __shared__ uint32_t s_ring[WAVES][RING_WORDS];
-  __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  // Workgroup k of a launch runs on XCD k % 8, each XCD with its own L2.  The per-quad records of 64
-  // consecutive blocks share their cache lines (pair-major interleave, see ojphgpu_ht_decode_layout), so
-  // consecutive blocks are given to ONE XCD: XCD x works through the x-th contiguous eighth of the blocks.
-  const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, xcd = blockIdx.x & 7u;
-  const uint32_t wg = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
-  const uint32_t bi = wg * WAVES + wave;
-  if (bi >= n) return;
-  const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   if (W == 0 || H == 0) return;
   uint32_t* dst = coef + d.coef_off;
@@ -848,7 +839,10 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     for (uint32_t y = 0; y < H; ++y)
       for (uint32_t x = lane; x < W; x += 64) dst[(size_t)y * pitch + x] = 0u;
   };
-  if (d.len1 == 0 || d.num_passes == 0 || block_status[bi] != 0) { zero_block(); return; }
+  if (d.len1 == 0 || d.num_passes == 0 || (SLICED ? __hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : block_status[bi]) != 0) {
+    if (!SLICED || qy_begin == 0) zero_block();
+    return;
+  }
   const uint32_t missing_msbs = d.missing_msbs;
   const uint32_t p = 30 - missing_msbs;
   const uint8_t* cb = data + d.data_off;
@@ -858,14 +852,19 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1;
   const bool wide = WD == 1 ? false : W > 64;
 
-  uint32_t* ring = s_ring[wave];
   for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
-  if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(&s_exp[wave][0][0])[i] = 0;
+  if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(s_exp_w)[i] = 0;
   wave_sync();
 
   // un-stuffs the next 256 MagSgn bytes into the ring ("after 0xFF only 7 bits", :609-653)
   uint32_t dst_bits = 0, src_pos = 0, mpos = 0;     // bits un-stuffed, bytes consumed, bits decoded (wave-uniform)
+  uint32_t hs[5] = { 0, 0, 0, 0, 0 }, hd[5] = { 0, 0, 0, 0, 0 };   // SLICED: the chunks un-stuffed last -- where they began (bytes, bits)
   auto unstuff_chunk = [&]() {
+    if (SLICED) {
+#pragma unroll
+      for (int i = 4; i > 0; --i) { hs[i] = hs[i - 1]; hd[i] = hd[i - 1]; }
+      hs[0] = src_pos; hd[0] = dst_bits;
+    }
     const uint32_t wb = (dst_bits + 31u) >> 5;               // words above the current partial word are stale
     ring[(wb + (uint32_t)lane) & RING_MASK] = 0;
     if (lane < 2) ring[(wb + 64u + (uint32_t)lane) & RING_MASK] = 0;
@@ -917,14 +916,27 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   bool bad = false;
   uint32_t e_prev = 0;                                   // exponent of this column's bottom sample, row above
   const uint32_t PW = (QW + 1) >> 1;
-  auto rec_at = [&](uint32_t qy_, uint32_t qx_) { return rec[(size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u)]; };
-  uint32_t ent_next = (uint32_t)lane < W ? rec_at(0, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
+  // (SLICED: agent-scope loads.  Plain loads were tried -- "the first touch of a line misses and fetches what the chain
+  // wrote" -- and returned stale data on the first run over a scratch area: an agent-scope store that has completed is
+  // visible to agent-scope loads, not necessarily to a plain load through another XCD's L2.)
+  auto rec_at = [&](uint32_t qy_, uint32_t qx_) -> uint32_t {
+    const uint32_t* q = rec + (size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u);
+    return SLICED ? ld_agent(q) : *q;
+  };
+  const uint32_t qy_last = qy_end < QH ? qy_end : QH;
+  if (SLICED && qy_begin > 0) {                          // take over where the previous slice's worker stopped
+    if (state[19] != 0u) return;
+    e_prev = (state[(uint32_t)lane >> 2] >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
+    mpos = state[16]; src_pos = state[17]; dst_bits = state[18];
+    hs[0] = src_pos; hd[0] = dst_bits;
+  }
+  uint32_t ent_next = (uint32_t)lane < W && qy_begin < qy_last ? rec_at(qy_begin, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
   asm volatile("" : "+v"(ent_next));                  // the first record is awaited here, not inside the loop (see the note at the stores)
-  for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
-    const uint8_t* vexp = s_exp[wave][qy & 1];             // wide blocks: exponents of the sample row above (+1 offset)
-    uint8_t* vnew = s_exp[wave][(qy & 1) ^ 1];
+  for (uint32_t qy = qy_begin; qy < qy_last && !bad; ++qy) {
+    const uint8_t* vexp = s_exp_w + (qy & 1) * EXP_BYTES;   // wide blocks: exponents of the sample row above (+1 offset)
+    uint8_t* vnew = s_exp_w + ((qy & 1) ^ 1) * EXP_BYTES;
     for (uint32_t c0 = 0; c0 < W; c0 += 64) {
-      while (src_pos < ms_len && dst_bits - mpos < ROW_BITS_MAX + 64u) unstuff_chunk();
+      while (src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)(ROW_BITS_MAX + 64u)) unstuff_chunk();   // (a resumed slice starts below mpos)
       const bool exhausted = src_pos >= ms_len;            // then bits at and beyond dst_bits read as 1 (:609-632)
       const uint32_t col = c0 + (uint32_t)lane;
       const bool act = col < W;
@@ -934,7 +946,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
         uint32_t nc0 = c0 + 64, nqy = qy;
         if (nc0 >= W) { nc0 = 0; nqy = qy + 1; }
         const uint32_t ncol = nc0 + (uint32_t)lane;
-        ent_next = (nqy < QH && ncol < W) ? rec_at(nqy, ncol >> 1) : 0u;
+        ent_next = (nqy < qy_last && ncol < W) ? rec_at(nqy, ncol >> 1) : 0u;      // (never beyond the slice: those records may not exist yet)
       }
       const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
       uint32_t U_q = ent >> 16;
@@ -1005,8 +1017,183 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     if (wide) wave_sync();
   }
   if (bad) { zero_block(); if (lane == 0) block_status[bi] = 1; }
+  if (SLICED && qy_last < QH) {                          // hand over to the next slice
+    if (bad) { if (lane == 0) state[19] = 1u; wave_sync(); return; }
+    // the un-stuffer restarts at the latest chunk that begins at or below the first bit still to be decoded
+    uint32_t rs = hs[4], rd = hd[4];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) if (hd[i] <= mpos) { rs = hs[i]; rd = hd[i]; }
+    const uint32_t e4 = e_prev | (from_next(e_prev) << 8);                    // four columns' exponents into one word
+    const uint32_t e8 = e4 | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e4, 0x102, 0xF, 0xF, false) << 16);   // row_shl:2
+    if (((uint32_t)lane & 3u) == 0) state[(uint32_t)lane >> 2] = e8;
+    if (lane == 0) { state[16] = mpos; state[17] = rs; state[18] = rd; state[19] = 0u; }
+    wave_sync();
+  }
 }
 
+template <int TX, int WD>
+__global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
+{
+  __shared__ uint32_t s_ring[WAVES][RING_WORDS];
+  __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
+  // Workgroup k of a launch runs on XCD k % 8, each XCD with its own L2.  The per-quad records of 64
+  // consecutive blocks share their cache lines (pair-major interleave, see ojphgpu_ht_decode_layout), so
+  // consecutive blocks are given to ONE XCD: XCD x works through the x-th contiguous eighth of the blocks.
+  const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, xcd = blockIdx.x & 7u;
+  const uint32_t wg = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+  const uint32_t bi = wg * WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  step2_block<TX, WD, false>(d, bi, data, quads, coef, block_status, s_ring[wave], &s_exp[wave][0][0], lane, 0u, 0xFFFFFFFFu, nullptr);
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// step 1 and step 2 in ONE launch: chains first, step-2 workers behind them, slice by slice
+// -------------------------------------------------------------------------------------------------
+// Step 1 is a latency floor: the serial chain of a code-block takes 0.2 ms however many blocks there are, and while the
+// 388 chain wavefronts of an 8K frame run, the rest of the chip has nothing to do -- step 2 of a block needs that block's
+// records.  But it needs them ROW BY ROW.  The fused kernel puts both into one launch:
+//   * workgroups 0 .. n1-1 are step 1 exactly as in ht_dec_step1_raw_kernel (chain + two partner wavefronts per 64
+//     blocks); a chain wavefront stores its records with agent scope and publishes, after every S2_ROWS quad rows, how many
+//     rows of its 64 blocks are complete (flag per chain wavefront; s_waitcnt vmcnt(0) first: the chain has no loads, its
+//     stores are all vmcnt counts);
+//   * the workgroups behind them are step-2 workers, slice after slice: worker (s, b) waits until the chain of block b
+//     has published S2_ROWS (s + 1) rows and until worker (s - 1, b) has handed over, decodes quad rows
+//     [S2_ROWS s, S2_ROWS (s + 1)) of block b with step2_block<SLICED> and leaves the 128 bytes of state the next slice
+//     needs (bottom-row exponents, MagSgn position, a restart point of the un-stuffer).
+// Workgroups are dispatched in index order, so every chain is resident before the first worker starts and every worker
+// of slice s - 1 before any of slice s: whoever is waited for is running or done -- no deadlock; all waits are bounded all
+// the same (a block whose wait runs out fails, the launch never hangs).  The XCDs' L2s are not coherent with each other:
+// everything exchanged inside the launch (records, flags, state, block status) is accessed with agent scope.  Flags and
+// hand-over counters carry the run's epoch, so nothing has to be cleared between runs.
+// Blocks wider than 64 samples and blocks with refinement passes keep the separate launches.
+__device__ __forceinline__ bool wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows)
+{
+  for (uint32_t spins = 0; spins < 60000u; ++spins) {
+    const uint32_t v = ld_agent(flag);
+    if ((v >> 16) == (epoch & 0xFFFFu) && (v & 0xFFFFu) >= rows) return true;
+    __builtin_amdgcn_s_sleep(12);
+  }
+  return false;
+}
+__device__ __forceinline__ bool wait_word(const uint32_t* p, uint32_t want)
+{
+  for (uint32_t spins = 0; spins < 60000u; ++spins) {
+    if (ld_agent(p) == want) return true;
+    __builtin_amdgcn_s_sleep(12);
+  }
+  return false;
+}
+
+template <int TX, int CH, int WGW>                    // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
+__global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
+    uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg)
+{
+  __shared__ uint16_t s_vlc[2048];
+  __shared__ uint16_t s_uvlc0[320];
+  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
+  __shared__ uint32_t s_vr_all[CH][VR_WORDS * 64];
+  __shared__ uint32_t s_ctl_all[CH][5][64];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+  if (blockIdx.x >= n1) {                                   // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
+    if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
+    // its LDS: the un-stuffing ring and the state of its blocks, in the (otherwise unused) event strings of the chain role
+    uint32_t* wlds = &s_ev_all[0][0] + wv * (RING_WORDS + S2_MAX_PER_WAVE * S2_STATE_WORDS);
+    uint32_t* ring = wlds;
+    const uint32_t wave_no = (blockIdx.x - n1) * (uint32_t)WGW + wv;
+    const uint32_t b0 = wave_no * per_wave;
+    if (b0 >= n) return;
+    const uint32_t nb = n - b0 < per_wave ? n - b0 : per_wave;
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+      const uint32_t q0 = sl * S2_ROWS;
+      for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t bi = b0 + k;
+        const ojphgpu_cb_desc d = blocks[bi];
+        if (d.w == 0 || d.h == 0) continue;
+        const uint32_t QH = ((uint32_t)d.h + 1) >> 1;
+        if (q0 >= QH) continue;
+        uint32_t* state = wlds + RING_WORDS + k * S2_STATE_WORDS;
+        if (d.len1 != 0 && d.num_passes != 0 && !wait_rows(fstate + (bi >> 6), epoch, q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH)) {
+          // cannot happen; a launch never hangs: the block fails
+          if (lane == 0) { __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); state[19] = 1u; }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wave_sync();
+        }
+        step2_block<TX, 1, true>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q0 + S2_ROWS, state);
+      }
+    }
+    return;
+  }
+
+  // ---- step 1: chains and their partners (ht_dec_step1_raw_kernel) ----
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
+  for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
+  for (int i = threadIdx.x; i < CH * 5 * 64; i += blockDim.x) (&s_ctl_all[0][0][0])[i] = 0;
+  __syncthreads();
+  if (wv >= 3u * (uint32_t)CH) return;                      // (wavefronts the step-1 role has no use for)
+  const bool chain = wv < (uint32_t)CH;
+  const uint32_t set = wv % (uint32_t)CH;
+  lds_u32* s_ev = (lds_u32*)s_ev_all[set];
+  lds_u32* s_vr = (lds_u32*)s_vr_all[set];
+  volatile lds_u32* s_eprog = (volatile lds_u32*)s_ctl_all[set][0];
+  volatile lds_u32* s_econs = (volatile lds_u32*)s_ctl_all[set][1];
+  volatile lds_u32* s_vprog = (volatile lds_u32*)s_ctl_all[set][2];
+  volatile lds_u32* s_vcons = (volatile lds_u32*)s_ctl_all[set][3];
+  volatile lds_u32* s_done = (volatile lds_u32*)s_ctl_all[set][4];
+  if (chain) __builtin_amdgcn_s_setprio(3);
+  const uint32_t cw = blockIdx.x * (uint32_t)CH + set;      // the chain wavefront's number = its blocks' number / 64
+  const uint32_t bi = cw * 64u + lane;
+  uint32_t* flag = fstate + cw;
+  // (no lane leaves early: the wavefront publishes "all rows done" at the end whatever its blocks are)
+  bool alive = bi < n;
+  ojphgpu_cb_desc d = blocks[alive ? bi : 0];
+  if (alive && (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0)) {      // not coded: zero block
+    if (chain) __hip_atomic_store(block_status + bi, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    alive = false;
+  }
+  const uint8_t* cb = data + d.data_off;
+  const uint32_t room = d.data_off > 0xFFFFu ? 0xFFFFu : (uint32_t)d.data_off;
+  B16 v0, v1;
+  v0.d[0] = v0.d[1] = v0.d[2] = v0.d[3] = 0u; v1 = v0;
+  if (alive && !chain && wv < 2u * (uint32_t)CH) {
+    const int o0 = (int)d.len1 - 18, o1 = o0 - 16;
+    if (o0 >= -(int)room) v0 = load_b16_unaligned(cb + o0);
+    else for (int jj = 0; jj < 16; ++jj) { const int o = o0 + 15 - jj; if (o >= 0) v0.d[3 - (jj >> 2)] |= (uint32_t)cb[o] << (24 - 8 * (jj & 3)); }
+    if (o1 >= -(int)room) v1 = load_b16_unaligned(cb + o1);
+    else for (int jj = 0; jj < 16; ++jj) { const int o = o1 + 15 - jj; if (o >= 0) v1.d[3 - (jj >> 2)] |= (uint32_t)cb[o] << (24 - 8 * (jj & 3)); }
+  }
+  uint32_t scup = 0;
+  if (alive) {
+    scup = check_block(d, cb);
+    if (scup == 0) { if (chain) __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); alive = false; }
+  }
+  if (alive) {
+    const uint32_t QW = ((uint32_t)d.w + 1) >> 1, QH = ((uint32_t)d.h + 1) >> 1;
+    const uint32_t evw = ev_words_of(QW, QH);
+    if (!chain) {
+      if (wv < 2u * (uint32_t)CH) raw_partner<1>(cb, d.len1, scup, room, v0, v1, evw, s_ev, s_eprog, s_econs, s_vr, s_vprog, s_vcons, s_done, lane);
+      else raw_partner<2>(cb, d.len1, scup, room, v0, v1, evw, s_ev, s_eprog, s_econs, s_vr, s_vprog, s_vcons, s_done, lane);
+    } else {
+      __hip_atomic_store(block_status + bi, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (what the last run left is not this run's)
+      uint32_t* rec = quads + d.scratch_cap;
+      RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
+      EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
+      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch);
+      s_done[lane] = 1u;
+      if (mel.stuck || vlc.stuck) __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (chain) publish_rows(flag, epoch, 0xFFFFu, lane);     // every row of every block of this wavefront is complete
+}
 
 // -------------------------------------------------------------------------------------------------
 // refinement: SigProp + MagRef passes (block_decoder32.cpp:1318-1609), one wavefront = one code-block
@@ -1248,6 +1435,51 @@ int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
 }
 }  // namespace ojphgpu
 
+namespace ojphgpu { bool dec_uses_prep(); }
+namespace ojphgpu {
+// words of the scratch the fused launch needs for n blocks (flags of the chain wavefronts, then the per-block state)
+uint64_t ht_decode_fused_state_words(uint32_t n) { return (uint64_t)(((n + 63u) / 64u + 8u + 63u) & ~63u) + 64u; }   // one flag per chain wavefront
+bool dec_fuses()
+{
+  static const bool v = [] { const char* e = getenv("OJPHGPU_DEC_FUSED"); return !(e && atoi(e) == 0); }();
+  return v && !dec_uses_prep();
+}
+// step 1 + step 2 of n blocks, all of them at most 64 samples wide, of one wavelet (kinds as in ht_decode_step2_launch)
+// and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch
+int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
+                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (ensure_tables() != 0) return OJPHGPU_E_HIP;
+  if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch || !d_state) return OJPHGPU_E_INVALID;
+  const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
+  if (tx == 0 || (kinds & 3) != 1 || max_h == 0) return OJPHGPU_E_INVALID;
+  const uint32_t nslices = (((max_h + 1u) >> 1) + S2_ROWS - 1u) / S2_ROWS;
+  // Every worker wavefront should be resident while the chains run: the blocks are dealt out `per_wave` consecutive ones to
+  // a wavefront, as few as the chip's wavefront slots allow.  (More blocks than the chip holds at S2_MAX_PER_WAVE: the
+  // surplus workgroups start when others end and find their rows complete -- slower, never stuck.)
+  // Shape: workgroups of 12 wavefronts, 4 chains (+ 8 partners) in the step-1 role, two per CU (OJPHGPU_FUSED_SHAPE=0:
+  // 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
+  // against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
+  static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
+  static const uint32_t cus = [] { int c = 256; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, 0); return (uint32_t)c; }();
+  const uint32_t ch = shape == 1 ? 4u : 2u, wgw = shape == 1 ? 12u : 8u, wg_slots = cus * (shape == 1 ? 2u : 4u);
+  const uint32_t n1 = (n + 64u * ch - 1u) / (64u * ch);
+  const uint32_t waves = (wg_slots > n1 ? wg_slots - n1 : 1u) * wgw;
+  uint32_t per_wave = (n + waves - 1u) / waves;
+  per_wave = per_wave < 1u ? 1u : per_wave > S2_MAX_PER_WAVE ? S2_MAX_PER_WAVE : per_wave;
+  const uint32_t wwgs = ((n + per_wave - 1u) / per_wave + wgw - 1u) / wgw;
+  static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
+  const dim3 grid(n1 + wwgs), wg(64 * wgw);
+#define FUSED_LAUNCH(T, C, W) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
+                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg)
+  if (shape == 1) { if (tx == 1) FUSED_LAUNCH(1, 4, 12); else FUSED_LAUNCH(2, 4, 12); }
+  else            { if (tx == 1) FUSED_LAUNCH(1, 2, 8); else FUSED_LAUNCH(2, 2, 8); }
+#undef FUSED_LAUNCH
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+}  // namespace ojphgpu
+
 extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                         const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
                                         uint8_t* d_block_status)
@@ -1276,14 +1508,6 @@ extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   return rc;
 }
 
-#ifdef S1_STATS
-extern "C" int ojphgpu_debug_s1_stats(unsigned long long out[8], int reset)
-{
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ojphgpu::g_s1_stats), 64) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ojphgpu::g_s1_stats), z, 64) != hipSuccess) return -1; }
-  return 0;
-}
-#endif
 
 namespace ojphgpu {
 int upload_dec_tables(const HtTables& t)

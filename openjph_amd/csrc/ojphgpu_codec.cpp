@@ -640,6 +640,12 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   if (ojphgpu_ht_decode_layout(bd.data(), (uint32_t)bd.size(), &nquads, &naux) != OJPHGPU_OK) return bail(OJPHGPU_E_INVALID);
   if (nquads >= 0xFFFFFFFFull || naux >= 0xFFFFFFFFull) return bail(OJPHGPU_E_INVALID);
   if (d->quads.alloc((size_t)nquads * 4 + 64) || d->aux.alloc((size_t)naux * 4 + 64)) return bail(OJPHGPU_E_NOMEM);
+  for (const ojphgpu_cb_desc& b : bd) d->max_block_h = std::max<uint32_t>(d->max_block_h, b.h);
+  if (ojphgpu::dec_fuses()) {                              // flags and per-block state of the fused step 1 + step 2 launch
+    const size_t fw = (size_t)ojphgpu::ht_decode_fused_state_words((uint32_t)bd.size());
+    if (d->fstate.alloc(fw * 4)) return bail(OJPHGPU_E_NOMEM);
+    if (hipMemset(d->fstate.p, 0, fw * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+  }
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
@@ -725,11 +731,28 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   hipStream_t s = d->stream;
   Spans& T = d->timer;
   T.start(s);
-  int rc = decode_chains(d, s);
-  if (rc) return rc;
-  rc = decode_samples(d, s, 0, d->n_low ? d->n_low : d->nblocks);
-  if (rc) return rc;
-  if (d->n_low) {                                           // fork: the lower synthesis levels on the side stream
+  // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
+  // every block is at most 64 samples wide, of one wavelet and without refinement passes; the synthesis levels follow on
+  // the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
+  const bool fused = d->fstate.p && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) && d->nblocks > 0;
+  const uint32_t n_low = fused ? 0u : d->n_low;
+  int rc;
+  if (fused) {
+    const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)(d->o_cb_descs ? d->o_cb_descs : d->cb_descs.p);
+    uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p);
+    const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
+    const int sp = T.begin(SP_STEP2, s);
+    rc = ojphgpu::ht_decode_fused_launch(s, cbd, d->nblocks, data, (uint32_t*)d->quads.p, d->arena.p, status, (uint32_t*)d->fstate.p,
+                                         ++d->fused_epoch, d->max_block_h, d->kinds);
+    if (rc) return rc;
+    T.end(sp, s);
+  } else {
+    rc = decode_chains(d, s);
+    if (rc) return rc;
+    rc = decode_samples(d, s, 0, n_low ? n_low : d->nblocks);
+    if (rc) return rc;
+  }
+  if (n_low) {                                              // fork: the lower synthesis levels on the side stream
     HIPCHK(hipEventRecord(d->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
   }
@@ -737,15 +760,15 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   auto finish_blocks = [&]() -> int {                       // meanwhile, on the main stream: the top resolution's blocks
     joined = true;
     HIPCHK(hipEventRecord(d->ev_join, d->side));
-    int r2 = decode_samples(d, s, d->n_low, d->nblocks - d->n_low);
+    int r2 = decode_samples(d, s, n_low, d->nblocks - n_low);
     if (r2) return r2;
     HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));           // join before the top synthesis level
     return OJPHGPU_OK;
   };
   for (const LevelBatch& b : d->batches) {
     const bool top = b.depth == 0;                          // the last level of its components (there may be two such launches)
-    hipStream_t ls = (d->n_low && !top) ? d->side : s;
-    if (top && d->n_low && !joined && (rc = finish_blocks()) != 0) return rc;
+    hipStream_t ls = (n_low && !top) ? d->side : s;
+    if (top && n_low && !joined && (rc = finish_blocks()) != 0) return rc;
     const int sp = T.begin(SP_DWT, ls);
     if (b.img_first >= 0) {                                 // float->int / level shift applied in the stores
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
@@ -757,7 +780,7 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     if (rc) return rc;
     T.end(sp, ls);
   }
-  if (d->n_low && !joined && (rc = finish_blocks()) != 0) return rc;
+  if (n_low && !joined && (rc = finish_blocks()) != 0) return rc;
   if (d->need_convert) {
     const int sp = T.begin(SP_CONVERT, s);
     rc = ojphgpu_convert_inverse_ex(s, &P.p, (const ojphgpu_convert_desc*)d->conv_descs.p, d->tiles.count * d->nframes,

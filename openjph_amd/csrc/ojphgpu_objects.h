@@ -307,6 +307,7 @@ struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
+  DeviceBuf fstate; uint32_t fused_epoch = 0, max_block_h = 0;     // the fused step 1 + step 2 launch: its flags / per-block state, run counter
   // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
   // levels with step 2, see decoder_create)
   uint32_t n_low = 0;

@@ -100,9 +100,10 @@ class EncoderPipe:
     def collect(self, copy=True):
         """the oldest frame's codestream; copy=False returns a view of pinned memory valid until the next collect"""
         ptr, n = C.c_void_p(), C.c_size_t()
+        if self.in_flight <= 0:              # nothing to collect: the counter stays where it is (the C call would say E_INVALID too)
+            raise capi.OjphError(capi.E_INVALID, "enc_pipe_collect: nothing in flight")
         rc = self._lib.ojphgpu_enc_pipe_collect(self._h, C.byref(ptr), C.byref(n))
-        if rc != capi.E_INVALID:             # E_INVALID: nothing was in flight, no slot consumed; any other outcome took the oldest frame
-            self.in_flight -= 1
+        self.in_flight -= 1                  # the oldest frame is taken whatever its outcome (a frame of its own may fail with E_INVALID)
         check(rc, "enc_pipe_collect")
         v = _view(ptr.value, n.value)
         return v.tobytes() if copy else v
@@ -174,9 +175,10 @@ class DecoderPipe:
         (failed blocks zeroed) with OJPHGPU_E_BLOCK: the exception raised here carries it as .frame and the count as
         .failed_blocks (ojphgpu.h, ojphgpu_dec_pipe_collect)"""
         ptr, n, failed = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        if self.in_flight <= 0:              # nothing to collect: the counter stays where it is
+            raise capi.OjphError(capi.E_INVALID, "dec_pipe_collect: nothing in flight")
         rc = self._lib.ojphgpu_dec_pipe_collect(self._h, C.byref(ptr), C.byref(n), C.byref(failed))
-        if rc != capi.E_INVALID:             # E_INVALID: nothing was in flight, no slot consumed
-            self.in_flight -= 1
+        self.in_flight -= 1                  # the oldest frame is taken whatever its outcome (a codestream of another geometry fails with E_INVALID)
         if rc != capi.E_BLOCK:
             check(rc, "dec_pipe_collect")
         if self.packed:

@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """a test that does not come back must not take the whole run (and a GPU box) with it: ten minutes each, where the
+    pytest-timeout plugin is installed"""
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
+
+
 def _ensure_built():
     """Builds the product library and the oracle when sources are newer (cheap no-op otherwise)."""
     import __graft_entry__ as g
