@@ -664,6 +664,15 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   if (!d_descs || !d_base || (nc != 1 && nc != 3) || n % (uint32_t)nc || (nc == 3 && !d_image)) return OJPHGPU_E_INVALID;
   int rp = pick_row_pairs(n, max_w, max_h);
+  {
+    // the synthesis re-reads two sub-band row pairs above and below each vertical chunk (the inverse top level moves 1.28 x
+    // its algorithmic bytes at 20 row pairs per chunk): longer chunks there trade that against the burstiness shorter
+    // chunks were introduced for -- OJPHGPU_DWT_RP_INV / OJPHGPU_DWT_RP_FWD override the cap of the large launches
+    static const int rp_inv = [] { const char* e = getenv("OJPHGPU_DWT_RP_INV"); const int v = e ? atoi(e) : 0; return v >= 4 && v <= 256 ? v : 0; }();
+    static const int rp_fwd = [] { const char* e = getenv("OJPHGPU_DWT_RP_FWD"); const int v = e ? atoi(e) : 0; return v >= 4 && v <= 256 ? v : 0; }();
+    const int cap = FWD ? rp_fwd : rp_inv;
+    if (cap && rp == MAX_ROW_PAIRS) rp = cap;
+  }
   if (nc == 3) {
     // a colour wavefront carries three pipelines: a third of the wavefronts of the plain kernel, each three times as
     // long -- shorter vertical chunks bring the wavefront count back (the extra halo rows are cheap here: the
