@@ -627,10 +627,11 @@ def committed_counters(name):
 
 
 def roofline_valu(workload, kinfo):
-    """The block coder is bound by VALU issue, not by HBM: its launches against THAT roof.  Wavefront
+    """The block coder is bound by instruction issue, not by HBM: its launches against THAT roof.  Wavefront
     instructions come from the committed SQ counter pass (profiles/sq_counters.json, tools/sq_round.sh: SQ_INSTS_VALU
-    / SQ_INSTS_SALU summed over the launch); a SIMD issues one wave64 integer VALU instruction per 4 cycles
-    (measured), the chip has 1024 SIMDs at up to 2.4 GHz; the time comes from this run."""
+    / SQ_INSTS_SALU summed over the launch, stamped with the digest of the kernel sources and refused when stale); a SIMD
+    issues one wave64 VALU instruction of the coders' mix per ~4 cycles (tools/micro/valu_issue.hip), the chip has 1024 SIMDs
+    at up to 2.4 GHz; the time comes from this run."""
     sq, state = committed_counters("sq_counters.json")
     if state != "current":
         return {"bound": "valu-issue", "kernels": {}, "source": "profiles/sq_counters.json (%s)" % state}
@@ -646,7 +647,9 @@ def roofline_valu(workload, kinfo):
                   "measured_ms": v["ms"], "frac": round(issue_ms / v["ms"], 3)}
     if not out:
         return None
-    return {"bound": "valu-issue", "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz", "kernels": out,
+    return {"bound": "valu-issue", "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz (tools/micro/valu_issue.hip, profiles/r03_valu_issue_probe.txt: "
+                                           "4.2 cycles per instruction per SIMD for shifts-left / bit-field / compare / select / cross-lane / 3-operand forms, "
+                                           "2.4 for add / and / or / xor / shift-right / fp32 add-mul-fma; the coders' mix is mostly the former)", "kernels": out,
             "source": "profiles/sq_counters.json (current: same kernel sources, %s)" % json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["_kernels_sha256"][:12],
             "issue_rate_probe": "tools/micro/valu_issue.hip, output in profiles/"}
 

@@ -273,6 +273,15 @@ public:
 
   // GPU-path extras (not in the reference): device ordinal used by flush() / create()
   void set_device(int device);
+  // A restart()ed object codes a sequence of frames through a frame pipeline whose slots hold the frame in the narrowest
+  // container its samples fit (8 / 16 / 32 bits: half or a quarter of the int32 bytes cross PCIe).  By default flush()
+  // returns with the codestream in the file, as the reference's does.  enable_frame_pipelining(n >= 2): flush() only
+  // queues the frame -- upload, kernels, Tier-2 and download of frame k run while the application fills frame k + 1 --
+  // and its codestream is written to the outfile given to ITS write_headers() when a later write_headers() needs the slot,
+  // at drain(), or when the object is destroyed; close() then closes a queued frame's file only once it has been written.
+  // The outfile objects of queued frames must stay alive and open until then.
+  void enable_frame_pipelining(ui32 frames_in_flight = 4);
+  void drain();
 
 private:
   codestream(const codestream&) = delete;

@@ -129,6 +129,17 @@ struct codestream_state {
   std::vector<std::vector<ui8>> epipe_comments;
   ojphgpu_dec_pipe* dpipe = nullptr; bool dpipe_resilient = false;
   bool frame_of_pipe = false;         // `frame` is memory of a pipe slot: not ours to free
+  // Frames of a sequence cross PCIe in the narrowest container their samples fit (8 / 16 / 32 bits, include/ojphgpu.h
+  // section 6): the lines exchange() / pull() hand out are int32 staging rows (the reference's line_buf contract), a row
+  // is narrowed into the pinned slot when the application hands it back, widened when it is pulled.
+  int pipe_bits = 32;                 // container of the pipe's slots
+  ui8* slot = nullptr;                // != nullptr: the frame lives in a slot of pipe_bits-bit samples, rows are staged
+  std::vector<std::vector<si32>> stage;
+  // enable_frame_pipelining(): flush() only queues the frame; its codestream is written to ITS outfile when a later
+  // flush() needs the slot, at drain(), or when the object goes away
+  struct Pending { outfile_base* file; bool close_after; };
+  std::vector<Pending> pending;
+  ui32 pipelining = 0;                // 0: flush() returns with the codestream written (the reference's contract)
   bool restricted = false;            // restrict_input_resolution was called for this frame
   si32* frame = nullptr; bool frame_pinned = false; size_t frame_elems = 0;
   std::vector<ui32> cw, ch; std::vector<size_t> coff;   // component planes inside the frame (ojphgpu_plan_comp_info)
@@ -148,6 +159,7 @@ struct codestream_state {
   }
   void release_pipes()
   {
+    try { drain(); } catch (...) {}
     if (epipe) { ojphgpu_enc_pipe_destroy(epipe); epipe = nullptr; }
     if (epipe_plan) { ojphgpu_plan_destroy(epipe_plan); epipe_plan = nullptr; }
     if (dpipe) { ojphgpu_dec_pipe_destroy(dpipe); dpipe = nullptr; }
@@ -159,7 +171,7 @@ struct codestream_state {
     if (plan && plan != epipe_plan) ojphgpu_plan_destroy(plan);
     plan = nullptr;
     if (frame && !frame_of_pipe) { if (frame_pinned) (void)hipHostFree(frame); else free(frame); }
-    frame = nullptr; frame_of_pipe = false; restricted = false;
+    frame = nullptr; frame_of_pipe = false; restricted = false; slot = nullptr;
     frame_elems = 0; stream.clear(); lines.clear();
     headers_written = headers_read = decoded = false; exhausted = false; cur_comp = cur_line = 0;
     outfile = nullptr; infile = nullptr;
@@ -180,6 +192,16 @@ struct codestream_state {
     // speed up (measured on the MI355X host: both ~57 GB/s), so the frame is plain memory; set
     // OJPH_GPU_PIN=1 for long-lived objects that restart() and reuse their buffers
     void* ptr = nullptr;
+    if (pipe_frame && pipe_bits != 32) {                  // rows are staged (one int32 row per component)
+      slot = (ui8*)pipe_frame; frame_of_pipe = true; frame_pinned = true;
+      stage.resize(p.num_comps);
+      for (ui32 c = 0; c < p.num_comps; ++c) stage[c].assign(cw[c] + 8, 0);
+      lines.assign(p.num_comps, line_buf());
+      for (ui32 c = 0; c < p.num_comps; ++c) {
+        lines[c].size = cw[c]; lines[c].pre_size = 0; lines[c].flags = line_buf::LFT_32BIT | line_buf::LFT_INTEGER;
+      }
+      return;
+    }
     if (pipe_frame) { frame = pipe_frame; frame_of_pipe = true; frame_pinned = true; }
     else if (getenv("OJPH_GPU_PIN") && hipHostMalloc(&ptr, frame_elems * sizeof(si32), hipHostMallocDefault) == hipSuccess) { frame = (si32*)ptr; frame_pinned = true; }
     else { (void)hipGetLastError(); frame = (si32*)malloc(frame_elems * sizeof(si32)); frame_pinned = false; }
@@ -189,7 +211,50 @@ struct codestream_state {
       lines[c].size = cw[c]; lines[c].pre_size = 0; lines[c].flags = line_buf::LFT_32BIT | line_buf::LFT_INTEGER;
     }
   }
-  si32* row(ui32 comp, ui32 line) { return line < ch[comp] ? frame + coff[comp] + (size_t)line * cw[comp] : spare.data(); }
+  si32* row(ui32 comp, ui32 line)
+  {
+    if (line >= ch[comp]) return spare.data();
+    return slot ? stage[comp].data() : frame + coff[comp] + (size_t)line * cw[comp];
+  }
+  // a staged row <-> its place in the slot (pipe_bits-bit samples, planes as ojphgpu_plan_comp_info lays them out)
+  void commit_row(ui32 comp, ui32 line)
+  {
+    if (!slot || line >= ch[comp]) return;
+    const si32* sp = stage[comp].data();
+    const size_t at = coff[comp] + (size_t)line * cw[comp];
+    const ui32 n = cw[comp];
+    if (pipe_bits == 8) { ui8* dp = slot + at; for (ui32 x = 0; x < n; ++x) dp[x] = (ui8)sp[x]; }
+    else { ui16* dp = (ui16*)slot + at; for (ui32 x = 0; x < n; ++x) dp[x] = (ui16)sp[x]; }
+  }
+  void fetch_row(ui32 comp, ui32 line)
+  {
+    if (!slot || line >= ch[comp]) return;
+    si32* dp = stage[comp].data();
+    const size_t at = coff[comp] + (size_t)line * cw[comp];
+    const ui32 n = cw[comp];
+    const bool sg = comps[comp].is_signed;
+    if (pipe_bits == 8) { const ui8* sp = slot + at; if (sg) for (ui32 x = 0; x < n; ++x) dp[x] = (si8)sp[x]; else for (ui32 x = 0; x < n; ++x) dp[x] = sp[x]; }
+    else { const ui16* sp = (const ui16*)slot + at; if (sg) for (ui32 x = 0; x < n; ++x) dp[x] = (si16)sp[x]; else for (ui32 x = 0; x < n; ++x) dp[x] = sp[x]; }
+  }
+  int container_for_frame() const                        // the narrowest slot container the frame's samples fit
+  {
+    ui32 deepest = 0;
+    for (ui32 c = 0; c < p.num_comps && c < comps.size(); ++c) deepest = comps[c].bit_depth > deepest ? comps[c].bit_depth : deepest;
+    return deepest <= 8 ? 8 : deepest <= 16 ? 16 : 32;
+  }
+  // the oldest queued frame: its codestream is collected from the pipe and written to its file
+  void write_oldest()
+  {
+    if (pending.empty() || !epipe) return;
+    const Pending pd = pending.front();
+    pending.erase(pending.begin());
+    const ui8* cs = nullptr; size_t n = 0;
+    const int rc = ojphgpu_enc_pipe_collect(epipe, &cs, &n);
+    if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
+    if (pd.file->write(cs, n) != n) ojph_error(0x00030071, "Error writing to file");
+    if (pd.close_after) pd.file->close();
+  }
+  void drain() { while (!pending.empty()) write_oldest(); }
   // what param_siz::get_recon_width / _height report (ojph_params.cpp:330-346), also before the plan exists
   ui32 recon_w(ui32 c) const
   {
@@ -458,6 +523,12 @@ bool codestream::is_tilepart_division_at_components() { return (state->p.reserve
 void codestream::request_tlm_marker(bool needed) { state->p.tlm = needed; }
 bool codestream::is_tlm_requested() { return state->p.tlm != 0; }
 void codestream::set_device(int device) { state->device = device; }
+void codestream::enable_frame_pipelining(ui32 frames_in_flight)
+{
+  state->drain();
+  state->pipelining = frames_in_flight < 2 ? 0u : frames_in_flight > 16 ? 16u : frames_in_flight;
+}
+void codestream::drain() { state->drain(); }
 void codestream::enable_resilience() { state->resilient = true; }
 param_siz codestream::access_siz() { return param_siz(state); }
 param_cod codestream::access_cod() { return param_cod(state); }
@@ -582,16 +653,24 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
   }
   if (S.sequence) {                                                // a frame of a sequence: through the pipeline
     if (S.epipe && (memcmp(&S.epipe_params, &p, sizeof(p)) != 0 || S.epipe_comments != cmts)) {   // another frame format
+      S.drain();
       ojphgpu_enc_pipe_destroy(S.epipe); S.epipe = nullptr;
       ojphgpu_plan_destroy(S.epipe_plan); S.epipe_plan = nullptr;
     }
+    if (S.epipe && S.pipe_bits != S.container_for_frame()) { S.drain(); ojphgpu_enc_pipe_destroy(S.epipe); S.epipe = nullptr; ojphgpu_plan_destroy(S.epipe_plan); S.epipe_plan = nullptr; }
     if (!S.epipe) {
-      rc = ojphgpu_enc_pipe_create(S.plan, S.device, 2, 32, 0, &S.epipe);
+      S.drain();
+      S.pipe_bits = S.container_for_frame();
+      rc = ojphgpu_enc_pipe_create(S.plan, S.device, S.pipelining > 2 ? S.pipelining : 4, S.pipe_bits, 0, &S.epipe);
       if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
       S.epipe_plan = S.plan; S.epipe_params = p; S.epipe_comments = cmts;
     } else { ojphgpu_plan_destroy(S.plan); S.plan = S.epipe_plan; }
     void* slot = nullptr; size_t bytes = 0;
     rc = ojphgpu_enc_pipe_acquire(S.epipe, &slot, &bytes);
+    while (rc == OJPHGPU_E_AGAIN && !S.pending.empty()) {   // every slot holds a queued frame: the oldest one is written out now
+      S.write_oldest();
+      rc = ojphgpu_enc_pipe_acquire(S.epipe, &slot, &bytes);
+    }
     if (rc) ojph_error(0x00030F08, "the frame pipeline has no free slot (status %d)", rc);
     S.alloc_frame((si32*)slot);
   } else {
@@ -610,8 +689,9 @@ line_buf* codestream::exchange(line_buf* line, ui32& next_component)
 {
   codestream_state& S = *state;
   if (!S.headers_written) ojph_error(0x00030F09, "exchange called before write_headers");
-  if (line) {                                   // the samples are already in place (the line points into the frame)
+  if (line) {                                   // the samples are in place (the line points into the frame), or in the staging row
     if (S.exhausted) { next_component = 0; return nullptr; }
+    S.commit_row(S.cur_comp, S.cur_line);
     if (S.planar) {                             // one component at a time, each with its own height (:1195-1207)
       if (++S.cur_line >= S.ch[S.cur_comp]) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) { S.exhausted = true; next_component = 0; return nullptr; } }
     } else {                                    // every component for every line of component 0 (:1208-1219)
@@ -631,10 +711,9 @@ void codestream::flush()
   if (!S.headers_written) ojph_error(0x00030F0A, "flush called before write_headers");
   if (S.epipe && S.frame_of_pipe) {            // the frame sits in the pipe's pinned slot already: upload, code, assemble, download
     int rc = ojphgpu_enc_pipe_submit(S.epipe);
-    const ui8* cs = nullptr; size_t n = 0;
-    if (rc == OJPHGPU_OK) rc = ojphgpu_enc_pipe_collect(S.epipe, &cs, &n);
     if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
-    if (S.outfile->write(cs, n) != n) ojph_error(0x00030071, "Error writing to file");               // :1163
+    S.pending.push_back(codestream_state::Pending{ S.outfile, false });
+    if (!S.pipelining) S.drain();                // the reference's contract: the codestream is in the file when flush() returns (:1163)
     return;
   }
   size_t len = 0;
@@ -691,10 +770,11 @@ void codestream::create()
   codestream_state& S = *state;
   if (!S.headers_read) ojph_error(0x00030F0E, "create called before read_headers");
   if (S.sequence && !S.restricted) {            // a frame of a sequence: through the pipeline (whole-resolution decoding)
-    if (S.dpipe && S.dpipe_resilient != S.resilient) { ojphgpu_dec_pipe_destroy(S.dpipe); S.dpipe = nullptr; }
+    if (S.dpipe && (S.dpipe_resilient != S.resilient || S.pipe_bits != S.container_for_frame())) { ojphgpu_dec_pipe_destroy(S.dpipe); S.dpipe = nullptr; }
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!S.dpipe) {
-        int rc = ojphgpu_dec_pipe_create(S.stream.data(), S.stream.size(), S.resilient ? 1 : 0, S.device, 2, 32, 0, &S.dpipe);
+        S.pipe_bits = S.container_for_frame();
+        int rc = ojphgpu_dec_pipe_create(S.stream.data(), S.stream.size(), S.resilient ? 1 : 0, S.device, 2, S.pipe_bits, 0, &S.dpipe);
         if (rc) ojph_error(0x00030F0F, "cannot create the GPU decoder (status %d): no GPU?", rc);
         S.dpipe_resilient = S.resilient;
       }
@@ -733,6 +813,7 @@ line_buf* codestream::pull(ui32& comp_num)
   if (S.exhausted) { comp_num = 0; return nullptr; }
   comp_num = S.cur_comp;
   line_buf* l = &S.lines[S.cur_comp];
+  S.fetch_row(S.cur_comp, S.cur_line);
   l->i32 = S.row(S.cur_comp, S.cur_line);
   if (S.planar) {
     if (++S.cur_line >= S.ch[S.cur_comp]) { S.cur_line = 0; if (++S.cur_comp >= S.p.num_comps) S.exhausted = true; }
@@ -746,7 +827,11 @@ void codestream::close()
 {
   codestream_state& S = *state;
   if (S.infile) S.infile->close();
-  if (S.outfile) S.outfile->close();
+  if (S.outfile) {
+    bool queued = false;
+    for (codestream_state::Pending& pd : S.pending) if (pd.file == S.outfile) { pd.close_after = true; queued = true; }
+    if (!queued) S.outfile->close();
+  }
   S.infile = nullptr; S.outfile = nullptr;
 }
 

@@ -119,6 +119,18 @@ int main()
     }
     for (unsigned i = 0; i < n; ++i) expect(fresh[i] == restarted[i], "a restarted object writes the codestream a fresh one writes");
     {
+      // frame pipelining (GPU-path extension): flush() queues, the codestreams reach their files later, in order
+      ojph::codestream cs;
+      cs.enable_frame_pipelining(3);
+      std::vector<ojph::mem_outfile> outs(n);                               // the files of queued frames stay alive
+      for (unsigned i = 0; i < n; ++i) {
+        encode_frame(cs, seq[i], i, outs[i]);                              // ends with flush() + close()
+        cs.restart();
+      }
+      cs.drain();
+      for (unsigned i = 0; i < n; ++i) expect(fresh[i] == bytes_of(outs[i]), "a pipelined sequence writes the codestreams a fresh object writes");
+    }
+    {
       ojph::codestream cs;
       for (unsigned i = 0; i < n; ++i) {
         decode_and_check(cs, seq[i], i, fresh[i], i == 2 ? 1u : 0u);        // frame 2 at half resolution

@@ -35,22 +35,40 @@ def check_line(d, want_cpu_baseline):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_bench.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_bench.json")))
     assert files
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     check_line(d, want_cpu_baseline=True)
     assert d["config"]["workload"] == "c3_8k_444_12b_irv97" and d["n_gpus"] == 1
-    # the PMC traffic file carries the kernels the bench line names
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[d["config"]["workload"]]
-    assert d["roofline"]["kernel"] in pmc
-    # round 2: a timed region an external sampler can see, the pipelines' end-to-end figures, every host cpu in the
-    # all-core baseline, the VALU roof of the block coder
-    assert d["steps"] >= 1000 and d["steps"] * d["ms_per_step"] >= 1500.0
+    # the PMC traffic file carries the kernels the bench line names, and the digest of the kernel sources it was taken on
+    pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert d["roofline"]["kernel"] in pmc_all[d["config"]["workload"]] and len(pmc_all["_kernels_sha256"]) == 64
+    assert len(json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["_kernels_sha256"]) == 64
+    # a timed region an external sampler can see, the pipelines' end-to-end figures, every host cpu in the all-core
+    # baseline, per-rank times, the strong-scaling part (16K frame, 256 tiles) with the reference's codestream digest
+    assert d["steps"] >= 1000 and d["steps"] * d["ms_per_step"] >= 1000.0
     e = d["e2e_steady_Msamples_s"]
     assert e["encode"] > 10000 and e["decode"] > 10000 and d["e2e"]["frames"] >= 32
     assert d["cpu_baseline"]["all_cores"]["cores"] == d["cpu_baseline"]["all_cores"]["host_cpus"]
-    assert "ht_encode[top resolution, side stream]" in d["roofline_valu"]["kernels"]
     assert len(d["per_rank_ms_per_step"]) == d["n_gpus"] and "value_covers" in d
+    s = d["strong_scaling_c4"]
+    assert s["scaling"] == "strong" and s["tiles"] == 256 and s["codestream_equals_reference_digest"] is True and s["value"] > 0
+    assert d["dist"]["world_size"] == 1
+
+
+def test_stale_counter_files_are_refused(tmp_path, monkeypatch):
+    """bench.py only quotes committed PMC / SQ counters taken on the kernel sources it runs"""
+    import bench
+    from openjph_amd.build import kernel_sources_digest
+    prof = tmp_path / "profiles"; prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "x.json").write_text(json.dumps({"_kernels_sha256": "0" * 64, "w": {"k": 1}}))
+    got, state = bench.committed_counters("x.json")
+    assert got == {} and state.startswith("stale")
+    (prof / "x.json").write_text(json.dumps({"_kernels_sha256": kernel_sources_digest(), "w": {"k": 1}}))
+    got, state = bench.committed_counters("x.json")
+    assert got["w"]["k"] == 1 and state == "current"
+    assert bench.committed_counters("missing.json") == ({}, "missing")
 
 
 @pytest.mark.gpu

@@ -74,8 +74,10 @@ def main():
             "_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from the PMC passes summarised next to this "
                      "file; x2 = gfx950 FETCH_SIZE correction (calibrated on an elementwise kernel of known traffic in "
                      "the same passes); multi-launch stages are per frame",
-            "ht_dec_prep": traffic(pick("ht_dec_prep")), "ht_dec_step1": traffic(pick("ht_dec_step1")),
+            "ht_dec_prep": traffic(pick("ht_dec_prep")), "ht_dec_step1": traffic(pick("ht_dec_step1_")),
         }
+        if pick("ht_dec_fused_kernel"):                      # step 1 + step 2 as one launch
+            out["ht_dec_fused(step 1 + step 2)"] = traffic(pick("ht_dec_fused_kernel"))
         s2 = pick("ht_dec_step2")                            # two launches per frame when the decoder overlaps the lower
         if s2 is not None:                                   # synthesis levels with the top resolution's blocks
             if len(clusters(fe.get(s2, []))) >= 2:

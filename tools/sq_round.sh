@@ -35,7 +35,7 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
                 out["ht_encode[top resolution, side stream]"] = {"valu_insts": avg(sizes[1], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[1], "SQ_INSTS_SALU"), "wavefronts": sizes[1]}
             if "ht_dec_step2" in k:
                 out["ht_dec_step2"] = {"valu_insts": sum(avg(g, "SQ_INSTS_VALU") for g in sizes), "salu_insts": sum(avg(g, "SQ_INSTS_SALU") for g in sizes), "wavefronts": sum(sizes)}
-        for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep")):
+        for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep"), ("ht_dec_fused(step 1 + step 2)", "ht_dec_fused_kernel")):
             if d.endswith("sq1") and sub in k:
                 out[key] = {"valu_insts": tot["SQ_INSTS_VALU"] / n, "salu_insts": tot["SQ_INSTS_SALU"] / n}
 import os, sys
