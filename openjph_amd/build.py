@@ -14,16 +14,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 def kernel_sources_digest():
-    """sha256 over the device code of the library (every .hip source and the headers / tables they include, in name
-    order): the identity of the kernels a counter pass was taken on.  tools/pmc_summary.py and tools/sq_round.sh stamp
-    their JSON with it; bench.py refuses counters whose stamp is not the digest of the sources it runs."""
+    """sha256 over the device code of the library as written (every .hip source and the headers / tables they include, in
+    name order; // comments, blank lines and indentation do not count): the identity of the kernels a counter pass was
+    taken on.  tools/pmc_summary.py and tools/sq_round.sh stamp their JSON with it; bench.py refuses counters whose stamp is
+    not the digest of the sources it runs."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         if f.startswith("_"):
             continue                                      # scratch copies of experiments (never part of the library)
         if f.endswith((".hip", ".inc")) or (f.endswith(".h") and f.startswith(("ht_", "kernels_"))):
-            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+            h.update(f.encode())
+            for line in open(os.path.join(CSRC, f), "r", errors="replace"):
+                line = re.sub(r"//.*$", "", line).strip()                 # (no string literal of these sources holds "//")
+                if line:
+                    h.update(re.sub(r"\s+", " ", line).encode()); h.update(b"\n")
     return h.hexdigest()
 
 
