@@ -8,7 +8,11 @@
 // de-quantise transfer gen_rev/irv_tx_from_cb32 (src/core/codestream/ojph_codestream_gen.cpp:
 // 124-168); zero blocks / failures: codeblock::decode + pull_line (ojph_codeblock.cpp:190-266).
 //
-// Three launches per frame (step 2 as two: lower resolutions, top resolution):
+// Round 3: ONE launch per frame in the common case -- ht_dec_fused_kernel, chain workgroups (step 1, reading the raw
+// cleanup segments through partner wavefronts: no prep launch, no flat strings in memory) followed by persistent step-2
+// worker wavefronts that take their blocks 8 quad rows at a time as the chains publish progress; see the comment above
+// that kernel.  The stages below are its parts, and remain launches of their own for blocks wider than 64 samples, mixed
+// wavelets, refinement passes (OJPHGPU_DEC_FUSED=0 / OJPHGPU_DEC_PREP=1 force the older forms):
 //   prep    (ht_dec_prep_kernel)   ONE WAVEFRONT PER CODE-BLOCK.  Byte un-stuffing only looks at the
 //           previous raw byte, so the bit offset of every byte is a wavefront prefix sum (the idea
 //           of the reference's AVX2 decoder, ojph_block_decoder_avx2.cpp:277-386).  The backward

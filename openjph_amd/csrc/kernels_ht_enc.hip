@@ -12,28 +12,30 @@
 // quantise transfer gen_rev/irv_tx_to_cb32 (src/core/codestream/ojph_codestream_gen.cpp:59-121);
 // "is there anything to code" test codeblock::encode (ojph_codeblock.cpp:142-175).
 //
-// The reference walks the block quad pair by quad pair with three serial bit writers.  Here
-//   * a lane owns one quad PAIR (8 samples) per step, the wave covers 64 consecutive pairs in
-//     raster order; everything a quad contributes (rho, exponents, context, kappa, u, VLC
-//     codeword, MagSgn bits) depends only on sample values, so it is computed in parallel --
-//     neighbour quads are read straight from the block (L1/L2 hits), not from line state;
-//   * MagSgn and VLC bits are OR-ed by all lanes into flat, un-stuffed LDS bit buffers at
-//     offsets given by a wavefront prefix sum;
-//   * byte stuffing (0xFF -> 7 bits forward; >0x8F,0x7F backward) is resolved by a speculative
-//     pass: every lane proposes one output byte assuming no stuffing event inside the 64-byte
-//     window, a ballot finds the first event, lanes up to it commit, and the window restarts;
-//   * MEL is an adaptive run-length coder and stays serial, but it runs on ballot-compacted
-//     event bits, whole zero-runs at a time, in wave-uniform (scalar) code; in the narrow kernel
-//     the serial part only appends raw code bits, the bytes are made once per block by the whole
-//     wavefront (mel_stuff), and steps without a significant sample skip everything else;
-//   * the block's bytes are staged in LDS (MagSgn growing up, VLC growing down); a stage that
-//     fills up flushes its whole dwords to the block's scratch slot in HBM and goes on; when the
-//     three lengths are known the block takes its place in the compacted output with one
-//     atomicAdd -- on the cursor of one of 16 regions, not on one cursor for all (claim_output);
-//   * launches whose blocks are all at most 32 columns wide (the IMF profile's 32x32) use a layout
-//     of 8 quad pairs x 8 quad rows per step instead of 16 x 4 (template parameter LOGP).
-// The produced bytes are identical to the reference's (oracle/ht_oracle.c variant 1 is the CPU
-// model of exactly this formulation and is pinned against the reference).
+// The reference walks the block quad pair by quad pair with three serial bit writers.  Here (narrow kernel; the wide
+// one keeps the first formulation, neighbours re-read from the block)
+//   * a lane owns one quad PAIR (8 samples) per step, the wave covers 64 consecutive pairs in raster order; everything a
+//     quad contributes (rho, exponents, context, kappa, u, VLC codeword, MagSgn bits) depends only on sample values, so it
+//     is computed in parallel, with instruction COST in mind (tools/micro/valu_issue.hip: add / and / or / xor / shift-right
+//     and fp32 add-mul issue at 2.4 cycles per wave64 instruction per SIMD, everything else -- shifts left, bit-field,
+//     compare, select, cross-lane, 3-operand forms -- at 4.2): the quantise transfer is one multiply / and by a per-column
+//     constant, a quad's exponents / rho / eps / MagSgn lengths are the bytes of one word, and what the row below needs
+//     from this row is worked out here and handed down as ONE packed word per lane;
+//   * MagSgn and VLC bits are OR-ed by all lanes into flat, un-stuffed LDS bit buffers at offsets given by ONE wavefront
+//     prefix sum (sample pairs of at most 32 bits when no sample of the step has more than 16);
+//   * byte stuffing (0xFF -> 7 bits forward; >0x8F,0x7F backward) is resolved by a speculative pass: every lane proposes
+//     its bytes assuming no stuffing event inside the window, a ballot finds the first event, lanes up to it commit, and
+//     the window restarts; lazily, only for whole windows;
+//   * MEL is an adaptive run-length coder and stays serial, but it only sees the "1" events: event masks are ballots, the
+//     zero run in front of a "1" is a population count; the serial part appends raw code bits, the bytes are made once
+//     per block by the whole wavefront (mel_stuff), and steps without a significant sample skip everything else;
+//   * the block's bytes are staged in LDS (MagSgn growing up, VLC growing down); a stage that fills up flushes its whole
+//     dwords to the block's scratch slot in HBM and goes on; when the three lengths are known the block takes its place in
+//     the compacted output with one atomicAdd -- on the cursor of one of 16 regions, not on one cursor for all (claim_output);
+//   * launches whose blocks are all at most 32 columns wide (the IMF profile's 32x32) use a layout of 8 quad pairs x 8
+//     quad rows per step instead of 16 x 4 (template parameter LOGP).
+// The produced bytes are identical to the reference's (oracle/ht_oracle.c is the CPU model and is pinned against the
+// reference; DESIGN.md section 4.2 has the instruction counts and the ablations).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
