@@ -590,3 +590,33 @@ def test_encoder_fuzz_seed_through_the_hip_encoder():
     cs = codec.encode(img, **kw)
     assert len(cs) == g["bytes"] and hashlib.sha256(cs).hexdigest() == g["sha256"]
     assert np.array_equal(codec.decode(cs), img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"OJPHGPU_DEC_FUSED": "0"}, {"OJPHGPU_DEC_PREP": "1"}, {"OJPHGPU_FUSED_SHAPE": "0"}],
+                         ids=["separate-launches", "prep-launch", "fused-8-wavefront-shape"])
+def test_the_other_decoder_schedules_decode_the_same(env, tmp_path):
+    """the block decoder's default is ONE launch for step 1 + step 2; the separate launches (also what blocks wider than 64
+    samples and refinement passes take), the round-2 form with a prep launch and the other workgroup shape of the fused
+    launch are chosen per process by environment switches: each decodes the oracle's samples -- ragged block heights (quad
+    rows not a multiple of a slice), tiles, a lossy and a lossless stream, twice in a row on the same decoder object"""
+    import subprocess, sys
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openjph_amd import codec
+from tests import cpu_pipeline as cp
+from tests.synth import synth_image
+for kw, shape in ((dict(bit_depth=8, num_decomps=3), (1, 333, 517)), (dict(bit_depth=12, reversible=False, qstep=0.002, tile=(256, 192)), (3, 401, 611)),
+                  (dict(bit_depth=10, block=(32, 32)), (1, 200, 300))):
+    img = synth_image(shape[0], shape[1], shape[2], kw["bit_depth"], seed=11)
+    cs = codec.encode(img, **kw)
+    want, _ = cp.decode(cs)
+    dec = codec.Decoder(cs)
+    for _ in range(2):
+        got = dec.run_device().cpu().numpy()
+        assert dec.failed_blocks() == 0 and np.array_equal(got, want), kw
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stderr[-2000:]
