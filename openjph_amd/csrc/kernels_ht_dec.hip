@@ -1466,7 +1466,7 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   // 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
   // against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
   static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
-  static const uint32_t cus = [] { int c = 256; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, 0); return (uint32_t)c; }();
+  static const uint32_t cus = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)(c > 0 ? c : 256); }();   // (one process drives one kind of GPU)
   const uint32_t ch = shape == 1 ? 4u : 2u, wgw = shape == 1 ? 12u : 8u, wg_slots = cus * (shape == 1 ? 2u : 4u);
   const uint32_t n1 = (n + 64u * ch - 1u) / (64u * ch);
   const uint32_t waves = (wg_slots > n1 ? wg_slots - n1 : 1u) * wgw;

@@ -118,9 +118,18 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     auto mid = std::stable_partition(e->block_ids.begin(), e->block_ids.end(), top);
     e->n_top = (uint32_t)(mid - e->block_ids.begin());
     if (e->n_top == 0 || e->n_top == e->block_ids.size()) e->n_top = 0;
-    else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-             hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
+    else {
+      // the side stream carries the long launch of the pair (the top resolution's blocks); the main stream's branch -- four
+      // small transform launches, then the other blocks -- is the one that ends last when both share the chip evenly:
+      // OJPHGPU_ENC_SIDE_PRIO=low lets the dispatcher prefer the main branch (high: the opposite; unset: equal)
+      int prio_lo = 0, prio_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      const char* pe = getenv("OJPHGPU_ENC_SIDE_PRIO");
+      const int prio = pe && pe[0] == 'l' ? prio_lo : pe && pe[0] == 'h' ? prio_hi : (prio_lo + prio_hi) / 2;
+      if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, pe ? prio : 0) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(OJPHGPU_E_HIP);
+    }
   }
   std::vector<ojphgpu_cb_desc> bd(e->block_ids.size());
   uint64_t scratch_bytes = 0, samples = 0;
