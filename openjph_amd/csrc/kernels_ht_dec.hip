@@ -386,6 +386,7 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 #define S2_ROWS_N 8
 #endif
 constexpr uint32_t S2_ROWS = S2_ROWS_N, S2_MAX_PER_WAVE = 8;
+constexpr int S2_RINGS = 5;                   // fused launch: worker wavefronts with at most this many blocks keep a ring per block
 template <bool FUSED>
 __device__ __forceinline__ void store_rec(uint32_t* p, uint32_t a, uint32_t b)
 {
@@ -826,7 +827,7 @@ constexpr uint32_t S2_STATE_WORDS = 20;
 
 // Step 2 of ONE code-block by one wavefront: quad rows [qy_begin, qy_end) -- the whole block for the plain kernel;
 // SLICED: a slice of rows, state from / to `state`, per-quad records read with agent scope (the fused kernel).
-template <int TX, int WD, bool SLICED>
+template <int TX, int WD, bool SLICED, bool KEEP = false>
 __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t bi, const uint8_t* __restrict__ data,
                                             const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef,
                                             uint8_t* __restrict__ block_status, uint32_t* ring, uint8_t* s_exp_w,
@@ -843,7 +844,8 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
     for (uint32_t y = 0; y < H; ++y)
       for (uint32_t x = lane; x < W; x += 64) dst[(size_t)y * pitch + x] = 0u;
   };
-  if (d.len1 == 0 || d.num_passes == 0 || (SLICED ? __hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : block_status[bi]) != 0) {
+  static_assert(!SLICED || WD == 1, "slices are for blocks of at most 64 columns");
+  if (d.len1 == 0 || d.num_passes == 0) {
     if (!SLICED || qy_begin == 0) zero_block();
     return;
   }
@@ -851,12 +853,38 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   const uint32_t p = 30 - missing_msbs;
   const uint8_t* cb = data + d.data_off;
   const uint32_t lcup = d.len1;
-  const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
-  const uint32_t ms_len = lcup - scup;
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1;
+  const uint32_t PW = (QW + 1) >> 1;
+  const uint32_t* rec = quads + d.scratch_cap;
+  const uint32_t qy_last = qy_end < QH ? qy_end : QH;
+  // (SLICED: agent-scope loads.  Plain loads were tried -- "the first touch of a line misses and fetches what the chain
+  // wrote" -- and returned stale data on the first run over a scratch area: an agent-scope store that has completed is
+  // visible to agent-scope loads, not necessarily to a plain load through another XCD's L2.)
+  auto rec_at = [&](uint32_t qy_, uint32_t qx_) -> uint32_t {
+    const uint32_t* q = rec + (size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u);
+    return SLICED ? ld_agent(q) : *q;
+  };
+  // SLICED: everything the slice needs from memory is requested at once -- the block's verdict, the length bytes and
+  // the records of ALL its quad rows (they are complete: the chain has published them) -- one round trip per slice where
+  // a record fetched one row ahead made it one per row (an agent-scope load takes longer than a row's arithmetic).
+  const uint32_t st = SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi];
+  const uint32_t len_b1 = cb[lcup - 1], len_b2 = cb[lcup >= 2u ? lcup - 2u : 0u];   // (a one-byte segment has failed in step 1; its bytes are not used)
+  uint32_t ents[SLICED ? S2_ROWS : 1u];
+  if (SLICED) {
+#pragma unroll
+    for (uint32_t i = 0; i < S2_ROWS; ++i)
+      ents[i] = ((uint32_t)lane < W && qy_begin + i < qy_last) ? rec_at(qy_begin + i, (uint32_t)lane >> 1) : 0u;
+  }
+  if (st != 0) {
+    if (!SLICED || qy_begin == 0) zero_block();
+    return;
+  }
+  const uint32_t scup = (len_b1 << 4) + (len_b2 & 0xFu);
+  const uint32_t ms_len = lcup - scup;
   const bool wide = WD == 1 ? false : W > 64;
 
-  for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
+  if (!KEEP || qy_begin == 0)
+    for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
   if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(s_exp_w)[i] = 0;
   wave_sync();
 
@@ -864,7 +892,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   uint32_t dst_bits = 0, src_pos = 0, mpos = 0;     // bits un-stuffed, bytes consumed, bits decoded (wave-uniform)
   uint32_t hs[5] = { 0, 0, 0, 0, 0 }, hd[5] = { 0, 0, 0, 0, 0 };   // SLICED: the chunks un-stuffed last -- where they began (bytes, bits)
   auto unstuff_chunk = [&]() {
-    if (SLICED) {
+    if (SLICED && !KEEP) {
 #pragma unroll
       for (int i = 4; i > 0; --i) { hs[i] = hs[i - 1]; hd[i] = hd[i - 1]; }
       hs[0] = src_pos; hd[0] = dst_bits;
@@ -912,30 +940,23 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
     wave_sync();
   };
 
-  const uint32_t* rec = quads + d.scratch_cap;
   const uint32_t mmsbp2 = missing_msbs + 2;
   const uint32_t shift = 31 - K;
   const float delta = d.delta;
   const uint32_t half = (uint32_t)lane & 1u;
   bool bad = false;
   uint32_t e_prev = 0;                                   // exponent of this column's bottom sample, row above
-  const uint32_t PW = (QW + 1) >> 1;
-  // (SLICED: agent-scope loads.  Plain loads were tried -- "the first touch of a line misses and fetches what the chain
-  // wrote" -- and returned stale data on the first run over a scratch area: an agent-scope store that has completed is
-  // visible to agent-scope loads, not necessarily to a plain load through another XCD's L2.)
-  auto rec_at = [&](uint32_t qy_, uint32_t qx_) -> uint32_t {
-    const uint32_t* q = rec + (size_t)(qy_ * PW + (qx_ >> 1)) * REC_STRIDE + (qx_ & 1u);
-    return SLICED ? ld_agent(q) : *q;
-  };
-  const uint32_t qy_last = qy_end < QH ? qy_end : QH;
   if (SLICED && qy_begin > 0) {                          // take over where the previous slice's worker stopped
     if (state[19] != 0u) return;
     e_prev = (state[(uint32_t)lane >> 2] >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
     mpos = state[16]; src_pos = state[17]; dst_bits = state[18];
     hs[0] = src_pos; hd[0] = dst_bits;
   }
-  uint32_t ent_next = (uint32_t)lane < W && qy_begin < qy_last ? rec_at(qy_begin, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
-  asm volatile("" : "+v"(ent_next));                  // the first record is awaited here, not inside the loop (see the note at the stores)
+  uint32_t ent_next = 0;
+  if (!SLICED) {
+    ent_next = (uint32_t)lane < W && qy_begin < qy_last ? rec_at(qy_begin, (uint32_t)lane >> 1) : 0u;      // records are fetched one step ahead
+    asm volatile("" : "+v"(ent_next));                // the first record is awaited here, not inside the loop (see the note at the stores)
+  }
   for (uint32_t qy = qy_begin; qy < qy_last && !bad; ++qy) {
     const uint8_t* vexp = s_exp_w + (qy & 1) * EXP_BYTES;   // wide blocks: exponents of the sample row above (+1 offset)
     uint8_t* vnew = s_exp_w + ((qy & 1) ^ 1) * EXP_BYTES;
@@ -945,8 +966,11 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       const uint32_t col = c0 + (uint32_t)lane;
       const bool act = col < W;
       const uint32_t qx = col >> 1;
-      const uint32_t ent = ent_next;
-      {
+      const uint32_t ent = SLICED ? ents[0] : ent_next;
+      if (SLICED) {
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < (SLICED ? S2_ROWS : 1u); ++i) ents[i] = ents[i + 1];
+      } else {
         uint32_t nc0 = c0 + 64, nqy = qy;
         if (nc0 >= W) { nc0 = 0; nqy = qy + 1; }
         const uint32_t ncol = nc0 + (uint32_t)lane;
@@ -1010,7 +1034,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       // The next step's record (requested at the top of this step) is taken into its register HERE, before this
       // step's stores are issued: loads and stores share one in-order counter on gfx9, so a wait placed after the
       // stores (where the compiler puts it: at the loop top) would also wait for the stores to reach L2.
-      asm volatile("" : "+v"(ent_next));
+      if (!SLICED) asm volatile("" : "+v"(ent_next));
       if (act) {
         const uint32_t y = 2 * qy;
         uint32_t* o = dst + (size_t)y * pitch + col;
@@ -1024,9 +1048,11 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   if (SLICED && qy_last < QH) {                          // hand over to the next slice
     if (bad) { if (lane == 0) state[19] = 1u; wave_sync(); return; }
     // the un-stuffer restarts at the latest chunk that begins at or below the first bit still to be decoded
+    // (KEEP: the block has a ring of its own, the next slice goes on exactly where this one stopped)
     uint32_t rs = hs[4], rd = hd[4];
 #pragma unroll
     for (int i = 3; i >= 0; --i) if (hd[i] <= mpos) { rs = hs[i]; rd = hd[i]; }
+    if (KEEP) { rs = src_pos; rd = dst_bits; }
     const uint32_t e4 = e_prev | (from_next(e_prev) << 8);                    // four columns' exponents into one word
     const uint32_t e8 = e4 | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e4, 0x102, 0xF, 0xF, false) << 16);   // row_shl:2
     if (((uint32_t)lane & 3u) == 0) state[(uint32_t)lane >> 2] = e8;
@@ -1094,25 +1120,29 @@ __device__ __forceinline__ bool wait_word(const uint32_t* p, uint32_t want)
   return false;
 }
 
-template <int TX, int CH, int WGW>                    // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
+// NR: un-stuffing rings per worker wavefront -- 1: one ring, every slice of a block re-un-stuffs from the latest chunk
+// boundary below its first bit; > 1: a ring per block (per_wave <= NR), a slice goes on where the one before stopped.
+template <int TX, int CH, int WGW, int NR>            // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
 __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
     uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg)
 {
-  __shared__ uint16_t s_vlc[2048];
-  __shared__ uint16_t s_uvlc0[320];
-  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
-  __shared__ uint32_t s_vr_all[CH][VR_WORDS * 64];
-  __shared__ uint32_t s_ctl_all[CH][5][64];
+  // one LDS area, carved per role: the step-1 role's tables, event strings, VLC rings and mailboxes -- or the workers'
+  // un-stuffing rings and block states
+  constexpr uint32_t EV_OFF = 1024 + 160, VR_OFF = EV_OFF + CH * EV_WORDS * 64, CTL_OFF = VR_OFF + CH * VR_WORDS * 64;
+  constexpr uint32_t CHAIN_WORDS = CTL_OFF + CH * 5 * 64;
+  constexpr uint32_t WORKER_WORDS = NR * RING_WORDS + S2_MAX_PER_WAVE * S2_STATE_WORDS;
+  constexpr uint32_t LDS_WORDS = CHAIN_WORDS > WGW * WORKER_WORDS ? CHAIN_WORDS : WGW * WORKER_WORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDS_WORDS];
+  uint16_t* const s_vlc = reinterpret_cast<uint16_t*>(s_mem);
+  uint16_t* const s_uvlc0 = reinterpret_cast<uint16_t*>(s_mem + 1024);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
   if (blockIdx.x >= n1) {                                   // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
     if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
-    // its LDS: the un-stuffing ring and the state of its blocks, in the (otherwise unused) event strings of the chain role
-    uint32_t* wlds = &s_ev_all[0][0] + wv * (RING_WORDS + S2_MAX_PER_WAVE * S2_STATE_WORDS);
-    uint32_t* ring = wlds;
+    uint32_t* wlds = s_mem + wv * WORKER_WORDS;
     const uint32_t wave_no = (blockIdx.x - n1) * (uint32_t)WGW + wv;
     const uint32_t b0 = wave_no * per_wave;
     if (b0 >= n) return;
@@ -1125,14 +1155,15 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         if (d.w == 0 || d.h == 0) continue;
         const uint32_t QH = ((uint32_t)d.h + 1) >> 1;
         if (q0 >= QH) continue;
-        uint32_t* state = wlds + RING_WORDS + k * S2_STATE_WORDS;
+        uint32_t* ring = wlds + (NR > 1 ? k : 0u) * RING_WORDS;
+        uint32_t* state = wlds + NR * RING_WORDS + k * S2_STATE_WORDS;
         if (d.len1 != 0 && d.num_passes != 0 && !wait_rows(fstate + (bi >> 6), epoch, q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH)) {
           // cannot happen; a launch never hangs: the block fails
           if (lane == 0) { __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); state[19] = 1u; }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           wave_sync();
         }
-        step2_block<TX, 1, true>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q0 + S2_ROWS, state);
+        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q0 + S2_ROWS, state);
       }
     }
     return;
@@ -1141,18 +1172,19 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   // ---- step 1: chains and their partners (ht_dec_step1_raw_kernel) ----
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
   for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
-  for (int i = threadIdx.x; i < CH * 5 * 64; i += blockDim.x) (&s_ctl_all[0][0][0])[i] = 0;
+  for (int i = threadIdx.x; i < CH * 5 * 64; i += blockDim.x) s_mem[CTL_OFF + i] = 0;
   __syncthreads();
   if (wv >= 3u * (uint32_t)CH) return;                      // (wavefronts the step-1 role has no use for)
   const bool chain = wv < (uint32_t)CH;
   const uint32_t set = wv % (uint32_t)CH;
-  lds_u32* s_ev = (lds_u32*)s_ev_all[set];
-  lds_u32* s_vr = (lds_u32*)s_vr_all[set];
-  volatile lds_u32* s_eprog = (volatile lds_u32*)s_ctl_all[set][0];
-  volatile lds_u32* s_econs = (volatile lds_u32*)s_ctl_all[set][1];
-  volatile lds_u32* s_vprog = (volatile lds_u32*)s_ctl_all[set][2];
-  volatile lds_u32* s_vcons = (volatile lds_u32*)s_ctl_all[set][3];
-  volatile lds_u32* s_done = (volatile lds_u32*)s_ctl_all[set][4];
+  lds_u32* s_ev = (lds_u32*)(s_mem + EV_OFF + set * EV_WORDS * 64);
+  lds_u32* s_vr = (lds_u32*)(s_mem + VR_OFF + set * VR_WORDS * 64);
+  uint32_t* const ctl = s_mem + CTL_OFF + set * 5 * 64;
+  volatile lds_u32* s_eprog = (volatile lds_u32*)(ctl);
+  volatile lds_u32* s_econs = (volatile lds_u32*)(ctl + 64);
+  volatile lds_u32* s_vprog = (volatile lds_u32*)(ctl + 128);
+  volatile lds_u32* s_vcons = (volatile lds_u32*)(ctl + 192);
+  volatile lds_u32* s_done = (volatile lds_u32*)(ctl + 256);
   if (chain) __builtin_amdgcn_s_setprio(3);
   const uint32_t cw = blockIdx.x * (uint32_t)CH + set;      // the chain wavefront's number = its blocks' number / 64
   const uint32_t bi = cw * 64u + lane;
@@ -1475,10 +1507,13 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   const uint32_t wwgs = ((n + per_wave - 1u) / per_wave + wgw - 1u) / wgw;
   static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
-#define FUSED_LAUNCH(T, C, W) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
+#define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
                                                  (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg)
-  if (shape == 1) { if (tx == 1) FUSED_LAUNCH(1, 4, 12); else FUSED_LAUNCH(2, 4, 12); }
-  else            { if (tx == 1) FUSED_LAUNCH(1, 2, 8); else FUSED_LAUNCH(2, 2, 8); }
+  // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
+  static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
+  if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }
+  else if (shape == 1) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, 1); else FUSED_LAUNCH(2, 4, 12, 1); }
+  else                 { if (tx == 1) FUSED_LAUNCH(1, 2, 8, 1); else FUSED_LAUNCH(2, 2, 8, 1); }
 #undef FUSED_LAUNCH
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
