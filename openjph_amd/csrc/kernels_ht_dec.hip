@@ -1102,14 +1102,16 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 // everything exchanged inside the launch (records, flags, state, block status) is accessed with agent scope.  Flags and
 // hand-over counters carry the run's epoch, so nothing has to be cleared between runs.
 // Blocks wider than 64 samples and blocks with refinement passes keep the separate launches.
-__device__ __forceinline__ bool wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows)
+// waits until the chain wavefront behind `flag` has published `rows` quad rows of this run; returns how many it has
+// published by then (0 = the wait ran out)
+__device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows)
 {
   for (uint32_t spins = 0; spins < 60000u; ++spins) {
     const uint32_t v = ld_agent(flag);
-    if ((v >> 16) == (epoch & 0xFFFFu) && (v & 0xFFFFu) >= rows) return true;
+    if ((v >> 16) == (epoch & 0xFFFFu) && (v & 0xFFFFu) >= rows) return v & 0xFFFFu;
     __builtin_amdgcn_s_sleep(12);
   }
-  return false;
+  return 0u;
 }
 __device__ __forceinline__ bool wait_word(const uint32_t* p, uint32_t want)
 {
@@ -1147,6 +1149,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const uint32_t b0 = wave_no * per_wave;
     if (b0 >= n) return;
     const uint32_t nb = n - b0 < per_wave ? n - b0 : per_wave;
+    uint32_t seen_cw = 0xFFFFFFFFu, seen_rows = 0;          // the last flag read: consecutive blocks mostly share a chain wavefront
     for (uint32_t sl = 0; sl < nslices; ++sl) {
       const uint32_t q0 = sl * S2_ROWS;
       for (uint32_t k = 0; k < nb; ++k) {
@@ -1157,7 +1160,14 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         if (q0 >= QH) continue;
         uint32_t* ring = wlds + (NR > 1 ? k : 0u) * RING_WORDS;
         uint32_t* state = wlds + NR * RING_WORDS + k * S2_STATE_WORDS;
-        if (d.len1 != 0 && d.num_passes != 0 && !wait_rows(fstate + (bi >> 6), epoch, q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH)) {
+        const uint32_t need = q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH;
+        bool there = true;
+        if (d.len1 != 0 && d.num_passes != 0 && !((bi >> 6) == seen_cw && seen_rows >= need)) {
+          seen_cw = bi >> 6;
+          seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + seen_cw, epoch, need));
+          there = seen_rows != 0u;
+        }
+        if (!there) {
           // cannot happen; a launch never hangs: the block fails
           if (lane == 0) { __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); state[19] = 1u; }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
