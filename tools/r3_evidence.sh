@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: the evidence of the final build in one box visit -> gpurun_out/r3ev/ (copied to profiles/r03_a_* afterwards)
+# round 3: the evidence of the final build in one box visit -> gpurun_out/r3ev/ (copied to profiles/r03_b_* afterwards)
 set -u
 R=gpurun_out/r3ev; mkdir -p $R; export TMPDIR=/tmp
 ( timeout 600 python bench.py 2> $R/bench.err | tail -1 ) > $R/bench_c3.json
