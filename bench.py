@@ -310,6 +310,10 @@ def main():
         # bytes of both -- the per-quad records still pass through memory once in each direction
         b1, _ = kernels.pop("ht_dec_step1"); b2, _ = kernels.pop("ht_dec_step2"); kernels.pop("ht_dec_prep")
         kernels["ht_dec_fused(step 1 + step 2)"] = (b1 + b2, td["ht_step2_ms"])
+    elif td["ht_prep_ms"] < 0.02:
+        # separate launches without the prep launch (step 1's partner wavefronts read the MEL / VLC bytes as they are):
+        # the prep span is empty
+        kernels.pop("ht_dec_prep")
     if len(te["ht_launches_ms"]) == 2:
         # the encoder codes the top resolution's blocks on a side stream, concurrently with the lower
         # DWT levels and followed by the rest: two launches of the same kernel per frame, listed one

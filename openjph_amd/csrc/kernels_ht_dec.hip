@@ -1485,10 +1485,48 @@ namespace ojphgpu { bool dec_uses_prep(); }
 namespace ojphgpu {
 // words of the scratch the fused launch needs for n blocks (flags of the chain wavefronts, then the per-block state)
 uint64_t ht_decode_fused_state_words(uint32_t n) { return (uint64_t)(((n + 63u) / 64u + 8u + 63u) & ~63u) + 64u; }   // one flag per chain wavefront
-bool dec_fuses()
+static int dec_fuse_mode()                                // OJPHGPU_DEC_FUSED: 0 never, 1 (default) where it pays, 2 wherever it can
 {
-  static const bool v = [] { const char* e = getenv("OJPHGPU_DEC_FUSED"); return !(e && atoi(e) == 0); }();
-  return v && !dec_uses_prep();
+  static const int v = [] { const char* e = getenv("OJPHGPU_DEC_FUSED"); return e ? atoi(e) : 1; }();
+  return dec_uses_prep() ? 0 : v;
+}
+bool dec_fuses() { return dec_fuse_mode() != 0; }
+
+// How the fused launch deals n blocks out: workgroups of `wgw` wavefronts, `ch` chains (+ 2 ch partners) in the step-1
+// role; every worker wavefront should be resident while the chains run, so the blocks go `per_wave` consecutive ones to
+// a wavefront, as few as the chip's wavefront slots allow.  (More blocks than the chip holds at S2_MAX_PER_WAVE: the
+// surplus workgroups start when others end and find their rows complete -- slower, never stuck.)
+// Shape: workgroups of 12 wavefronts, 4 chains (+ 8 partners) in the step-1 role, two per CU (OJPHGPU_FUSED_SHAPE=0:
+// 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
+// against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
+struct FusedShape { uint32_t shape, ch, wgw, n1, per_wave, wwgs; };
+static FusedShape fused_shape(uint32_t n)
+{
+  static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
+  static const uint32_t cus = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)(c > 0 ? c : 256); }();   // (one process drives one kind of GPU)
+  FusedShape f;
+  f.shape = shape;
+  f.ch = shape == 1 ? 4u : 2u; f.wgw = shape == 1 ? 12u : 8u;
+  const uint32_t wg_slots = cus * (shape == 1 ? 2u : 4u);
+  f.n1 = (n + 64u * f.ch - 1u) / (64u * f.ch);
+  const uint32_t waves = (wg_slots > f.n1 ? wg_slots - f.n1 : 1u) * f.wgw;
+  uint32_t per_wave = (n + waves - 1u) / waves;
+  f.per_wave = per_wave < 1u ? 1u : per_wave > S2_MAX_PER_WAVE ? S2_MAX_PER_WAVE : per_wave;
+  f.wwgs = ((n + f.per_wave - 1u) / f.per_wave + f.wgw - 1u) / f.wgw;
+  return f;
+}
+
+// Does ONE launch pay for these blocks?  Measured (profiles/r03_b_block_sizes*.txt, the C5 / C4 bench lines): it does
+// where step 1 is a long latency floor beside an idle chip -- blocks of 64 rows -- and every worker wavefront can be
+// resident with a ring per block (<= 5 blocks each: ~25 000 blocks on 256 CUs).  Blocks of 32 rows or fewer have chains
+// half as long, and more blocks than that make workers that start when others end: there the separate launches (raw
+// step 1, then step 2 beside the small synthesis levels) are faster -- 8K frame in 32x32 blocks 0.67 against 0.80 ms,
+// eight 4K frames per step 1.24 against 1.45 ms.  OJPHGPU_DEC_FUSED=2 fuses wherever the launch is able to.
+bool ht_decode_fused_pays(uint32_t n, uint32_t max_h)
+{
+  if (dec_fuse_mode() == 0) return false;
+  if (dec_fuse_mode() >= 2) return true;
+  return max_h > 32u && fused_shape(n).per_wave <= (uint32_t)S2_RINGS;
 }
 // step 1 + step 2 of n blocks, all of them at most 64 samples wide, of one wavelet (kinds as in ht_decode_step2_launch)
 // and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch
@@ -1501,20 +1539,8 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
   if (tx == 0 || (kinds & 3) != 1 || max_h == 0) return OJPHGPU_E_INVALID;
   const uint32_t nslices = (((max_h + 1u) >> 1) + S2_ROWS - 1u) / S2_ROWS;
-  // Every worker wavefront should be resident while the chains run: the blocks are dealt out `per_wave` consecutive ones to
-  // a wavefront, as few as the chip's wavefront slots allow.  (More blocks than the chip holds at S2_MAX_PER_WAVE: the
-  // surplus workgroups start when others end and find their rows complete -- slower, never stuck.)
-  // Shape: workgroups of 12 wavefronts, 4 chains (+ 8 partners) in the step-1 role, two per CU (OJPHGPU_FUSED_SHAPE=0:
-  // 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
-  // against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
-  static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
-  static const uint32_t cus = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)(c > 0 ? c : 256); }();   // (one process drives one kind of GPU)
-  const uint32_t ch = shape == 1 ? 4u : 2u, wgw = shape == 1 ? 12u : 8u, wg_slots = cus * (shape == 1 ? 2u : 4u);
-  const uint32_t n1 = (n + 64u * ch - 1u) / (64u * ch);
-  const uint32_t waves = (wg_slots > n1 ? wg_slots - n1 : 1u) * wgw;
-  uint32_t per_wave = (n + waves - 1u) / waves;
-  per_wave = per_wave < 1u ? 1u : per_wave > S2_MAX_PER_WAVE ? S2_MAX_PER_WAVE : per_wave;
-  const uint32_t wwgs = ((n + per_wave - 1u) / per_wave + wgw - 1u) / wgw;
+  const FusedShape f = fused_shape(n);
+  const uint32_t shape = f.shape, n1 = f.n1, per_wave = f.per_wave, wwgs = f.wwgs, wgw = f.wgw;
   static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
 #define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \

@@ -741,9 +741,10 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   Spans& T = d->timer;
   T.start(s);
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
-  // every block is at most 64 samples wide, of one wavelet and without refinement passes; the synthesis levels follow on
-  // the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
-  const bool fused = d->fstate.p && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) && d->nblocks > 0;
+  // every block is at most 64 samples wide, of one wavelet and without refinement passes -- and where it pays: blocks
+  // of 64 rows, few enough for resident workers (ht_decode_fused_pays); the synthesis levels follow on the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
+  const bool fused = d->fstate.p && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) && d->nblocks > 0 &&
+                     ojphgpu::ht_decode_fused_pays(d->nblocks, d->max_block_h);
   const uint32_t n_low = fused ? 0u : d->n_low;
   int rc;
   if (fused) {

@@ -593,10 +593,12 @@ def test_encoder_fuzz_seed_through_the_hip_encoder():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"OJPHGPU_DEC_FUSED": "0"}, {"OJPHGPU_DEC_PREP": "1"}, {"OJPHGPU_FUSED_SHAPE": "0"}, {"OJPHGPU_FUSED_RINGS": "1"}],
-                         ids=["separate-launches", "prep-launch", "fused-8-wavefront-shape", "fused-one-ring-per-wavefront"])
+@pytest.mark.parametrize("env", [{"OJPHGPU_DEC_FUSED": "0"}, {"OJPHGPU_DEC_PREP": "1"}, {"OJPHGPU_DEC_FUSED": "2"},
+                                 {"OJPHGPU_DEC_FUSED": "2", "OJPHGPU_FUSED_SHAPE": "0"}, {"OJPHGPU_DEC_FUSED": "2", "OJPHGPU_FUSED_RINGS": "1"}],
+                         ids=["separate-launches", "prep-launch", "fused-wherever-possible", "fused-8-wavefront-shape", "fused-one-ring-per-wavefront"])
 def test_the_other_decoder_schedules_decode_the_same(env, tmp_path):
-    """the block decoder's default is ONE launch for step 1 + step 2; the separate launches (also what blocks wider than 64
+    """the block decoder's default is ONE launch for step 1 + step 2 where that pays (blocks of 64 rows, few enough for
+    resident workers: the first stream below, not the 32x32 one); the separate launches (also what blocks wider than 64
     samples and refinement passes take), the round-2 form with a prep launch, the other workgroup shape of the fused
     launch and its workers with one un-stuffing ring per wavefront (what frames of more than ~25 000 blocks take) are chosen per process by environment switches: each decodes the oracle's samples -- ragged block heights (quad
     rows not a multiple of a slice), tiles, a lossy and a lossless stream, twice in a row on the same decoder object"""
