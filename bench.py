@@ -778,6 +778,15 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
             pe = round(nsamp * n / dt / 1e6, 1)
             dt, _ = run_decoder_pipe(cs, n, depth, threads, container=container, packed=bd)
             out["bit_packed"] = {"bits_per_sample_on_pcie": bd, "encode_Msamples_s": pe, "decode_Msamples_s": round(nsamp * n / dt / 1e6, 1)}
+            # ... and both directions at once (the transcoder case): the two directions share ~70 GB/s of link payload
+            res = {}
+            te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container, packed=bd)))
+            td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container, packed=bd)))
+            te.start(); td.start(); te.join(); td.join()
+            if "e" in res and "d" in res:
+                wall = max(res["e"][0], res["d"][0])
+                out["bit_packed"]["encode+decode_Msamples_s"] = round(nsamp * n / wall / 1e6, 1)
+                out["bit_packed"]["encode+decode_ms_per_step"] = round(wall * 1e3 / n, 3)
         except Exception as e:
             out["bit_packed"] = {"error": str(e)[:200]}
     return out
