@@ -1092,16 +1092,20 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 //     blocks); a chain wavefront stores its records with agent scope and publishes, after every S2_ROWS quad rows, how many
 //     rows of its 64 blocks are complete (flag per chain wavefront; s_waitcnt vmcnt(0) first: the chain has no loads, its
 //     stores are all vmcnt counts);
-//   * the workgroups behind them are step-2 workers, slice after slice: worker (s, b) waits until the chain of block b
-//     has published S2_ROWS (s + 1) rows and until worker (s - 1, b) has handed over, decodes quad rows
-//     [S2_ROWS s, S2_ROWS (s + 1)) of block b with step2_block<SLICED> and leaves the 128 bytes of state the next slice
-//     needs (bottom-row exponents, MagSgn position, a restart point of the un-stuffer).
-// Workgroups are dispatched in index order, so every chain is resident before the first worker starts and every worker
-// of slice s - 1 before any of slice s: whoever is waited for is running or done -- no deadlock; all waits are bounded all
-// the same (a block whose wait runs out fails, the launch never hangs).  The XCDs' L2s are not coherent with each other:
-// everything exchanged inside the launch (records, flags, state, block status) is accessed with agent scope.  Flags and
-// hand-over counters carry the run's epoch, so nothing has to be cleared between runs.
-// Blocks wider than 64 samples and blocks with refinement passes keep the separate launches.
+//   * the workgroups behind them are persistent step-2 worker wavefronts: a wavefront owns `per_wave` consecutive blocks
+//     (as few as the chip's wavefront slots allow: 5 at 8K) and takes them slice by slice -- slice 0 of each of its
+//     blocks, then slice 1, ... -- waiting (bounded) until the chain wavefront of a block has published the slice's rows.
+//     A slice is quad rows [S2_ROWS s, S2_ROWS (s + 1)) of a block, decoded by step2_block<SLICED>; what a block's next
+//     slice needs stays in the wavefront's LDS: 80 bytes of state (bottom-row exponents, MagSgn position, where the
+//     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits
+//     (otherwise one ring per wavefront and a restart of the un-stuffer at the latest 256-byte boundary per slice).
+// Workgroups are dispatched in index order, so every chain is resident before the first worker starts: whoever is waited
+// for is running or done -- no deadlock; all waits are bounded all the same (a block whose wait runs out fails, the
+// launch never hangs).  The XCDs' L2s are not coherent with each other: everything exchanged inside the launch
+// (records, flags, block status) is accessed with agent scope.  Flags carry the run's epoch, so nothing has to be
+// cleared between runs.  Blocks wider than 64 samples and blocks with refinement passes keep the separate launches,
+// and so do frames where the one launch does not pay (ht_decode_fused_pays).
+
 // waits until the chain wavefront behind `flag` has published `rows` quad rows of this run; returns how many it has
 // published by then (0 = the wait ran out)
 __device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows)
@@ -1112,14 +1116,6 @@ __device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epo
     __builtin_amdgcn_s_sleep(12);
   }
   return 0u;
-}
-__device__ __forceinline__ bool wait_word(const uint32_t* p, uint32_t want)
-{
-  for (uint32_t spins = 0; spins < 60000u; ++spins) {
-    if (ld_agent(p) == want) return true;
-    __builtin_amdgcn_s_sleep(12);
-  }
-  return false;
 }
 
 // NR: un-stuffing rings per worker wavefront -- 1: one ring, every slice of a block re-un-stuffs from the latest chunk
