@@ -142,7 +142,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the all-core CPU figure forks worker processes: done first, before this process owns a GPU context
     cpu_all = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # (the CPU figures belong to the N = 1 line)
         w_, h_, nc_, bd_, rev_, ct_, qstep_, _tile = WORKLOADS[args.workload]
         try:
             cpu_all = cpu_baseline_all_cores(workload_image(args.workload), bd_, rev_, ct_, qstep_, _tile)
@@ -496,7 +496,7 @@ def main():
                 "forward_ms": round(dwt_alone[0], 4), "inverse_ms": round(dwt_alone[1], 4), "achieved": round(a_alone, 1),
                 "frac": round(a_alone / HBM_PEAK_GBS, 4),
                 "forward_frac": round(af / 1e6 / dwt_alone[0] / HBM_PEAK_GBS, 4), "inverse_frac": round(ai / 1e6 / dwt_alone[1] / HBM_PEAK_GBS, 4)}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(img if frames == 1 else img[0], bd, rev, ct, qstep, tile, args.cpu_reps)
         result["cpu_baseline"]["all_cores"] = cpu_all
     if rank == 0:
