@@ -298,22 +298,26 @@ def main():
         "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels, args.container), td["dwt_ms"]),
         "dwt_inverse(level 1)": ((4.0 + args.container / 8.0) * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
         "ht_encode": ((4.0 + c_rate) * ns, te["ht_ms"]),            # all launches of the block encoder (sum)
-        # block decoder: prep reads the MEL/VLC share of the coded bytes and writes them flat; step 1
-        # reads that and writes one 4-byte record per quad (1 B/sample); step 2 reads the records and
-        # the MagSgn bytes and writes the 4-byte coefficients
-        "ht_dec_prep": (0.4 * c_rate * ns, td["ht_prep_ms"]),
-        "ht_dec_step1": ((0.2 * c_rate + 1.0) * ns, td["ht_step1_ms"]),
-        "ht_dec_step2": ((c_rate + 1.0 + 4.0) * ns, td["ht_step2_ms"]),
+        # block decoder, SURVEY.md section 8(d): it reads the c N coded bytes and writes the 4 N coefficient bytes -- (c + 4) N
+        # for the whole decoder.  Split by launch: step 1 reads the MEL / VLC share of the coded bytes (about a fifth), step 2
+        # the MagSgn share and writes the coefficients.  The per-quad records step 1 hands to step 2 (4 bytes per quad = 1 byte
+        # per sample, written once and read once) and the flat strings of the optional prep launch are INTERMEDIATE bytes:
+        # real traffic, not algorithmic -- reported next to the algorithmic figure, never inside it.
+        "ht_dec_prep": (0.0, td["ht_prep_ms"]),
+        "ht_dec_step1": (0.2 * c_rate * ns, td["ht_step1_ms"]),
+        "ht_dec_step2": ((0.8 * c_rate + 4.0) * ns, td["ht_step2_ms"]),
     }
+    intermediate = {"ht_dec_prep": 0.8 * c_rate * ns, "ht_dec_step1": 1.0 * ns, "ht_dec_step2": 1.0 * ns}
     if td["ht_step1_ms"] == 0.0 and td["ht_prep_ms"] < 0.02 and td["ht_step2_ms"] > 0:
-        # step 1 and step 2 ran as ONE launch (chains first, step-2 workers behind them slice by slice): one entry, the
-        # bytes of both -- the per-quad records still pass through memory once in each direction
+        # step 1 and step 2 ran as ONE launch (chains first, step-2 workers behind them slice by slice): one entry with the
+        # decoder's (c + 4) N; the records pass through memory once in each direction inside the launch (2 N intermediate)
         b1, _ = kernels.pop("ht_dec_step1"); b2, _ = kernels.pop("ht_dec_step2"); kernels.pop("ht_dec_prep")
         kernels["ht_dec_fused(step 1 + step 2)"] = (b1 + b2, td["ht_step2_ms"])
+        intermediate = {"ht_dec_fused(step 1 + step 2)": 2.0 * ns}
     elif td["ht_prep_ms"] < 0.02:
         # separate launches without the prep launch (step 1's partner wavefronts read the MEL / VLC bytes as they are):
         # the prep span is empty
-        kernels.pop("ht_dec_prep")
+        kernels.pop("ht_dec_prep"); intermediate.pop("ht_dec_prep")
     if len(te["ht_launches_ms"]) == 2:
         # the encoder codes the top resolution's blocks on a side stream, concurrently with the lower
         # DWT levels and followed by the rest: two launches of the same kernel per frame, listed one
@@ -334,6 +338,8 @@ def main():
     kinfo = {}
     for k, (b, ms) in kernels.items():
         kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}
+        if k in intermediate:
+            kinfo[k]["intermediate_GB"] = round(intermediate[k] / 1e9, 4)
     # the dominant LAUNCH: the "(all levels)" entries are families of launches (roofline_dwt reports them)
     dom = max((k for k in kernels if "(all levels)" not in k), key=lambda k: kernels[k][1])
     dom_b, dom_ms = kernels[dom]
@@ -456,8 +462,12 @@ def main():
                    "roundtrip_max_abs_err": int(err),
                    "two_streams_ms_per_step": round(two_stream_ms, 4) if two_stream_ms else None,
                    "two_streams_Msamples_s": round(nsamples / two_stream_ms / 1e3, 2) if two_stream_ms else None},
+        # achieved = SURVEY.md section 8(d)'s algorithmic bytes of the launch / its measured duration; what the launch moves
+        # beyond them (records handed from step 1 to step 2, halo re-reads) shows in `traffic` and `traffic_ratio`
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes": int(dom_b), "intermediate_bytes": int(intermediate.get(dom, 0)),
+                     "traffic_ratio": round(traffic / dom_b, 3) if traffic and dom_b else None,
                      "traffic_source": "profiles/pmc_traffic.json (%s)" % pmc_state},
         "kernels": kinfo,
     }
@@ -471,6 +481,13 @@ def main():
     rv = roofline_valu(args.workload, kinfo)
     if rv:
         result["roofline_valu"] = rv
+        # which roof the dominant launch is nearer to: the HBM fraction above, or the VALU-issue fraction of the same launch
+        fv = (rv.get("kernels") or {}).get(dom, {}).get("frac")
+        if fv is not None:
+            result["roofline"]["frac_valu_issue"] = fv
+            result["roofline"]["bound"] = "valu-issue" if fv > result["roofline"]["frac"] else "hbm"
+            result["roofline"]["bound_note"] = ("`bound` names the roof the launch sits closer to; achieved / peak / frac stay the HBM figures "
+                                                "(SURVEY 8(d) bytes over the HBM peak), frac_valu_issue is the same launch against the VALU-issue roof")
     if "dwt_forward(level 1)" in kernels and kernels["dwt_forward(level 1)"][1] > 0:
         # the HBM-bound kernel family of the path (north_star sets its roofline target on it); the
         # block coder launches above are bound by integer VALU issue, not by HBM.  Level 1 -- the two
@@ -659,17 +676,30 @@ def roofline_valu(workload, kinfo):
 
 
 def pcie_bandwidth(torch, nbytes=256 << 20, reps=4):
-    """one direction at a time, pinned memory, hipMemcpyAsync: the roof of the frame pipelines"""
-    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    out = {}
-    for name, (dst, src) in dict(h2d=(d, h), d2h=(h, d)).items():
-        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 1)
+    """hipMemcpyAsync between hipHostMalloc memory (what the pipes' slots are made of) and HBM, one direction at a time -- a
+    PROBE of the link as a plain copy sees it, not a roof: the encoder pipe's uploads reach the same or more, because several
+    copies are in flight.  (Round 3 timed torch's pin_memory() buffers here and got 33 GB/s host-to-device under a pipe that
+    moved 51 GB/s: that allocation is registered pageable memory, placed wherever the first touch put it.)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hptr, dptr = ctypes.c_void_p(), ctypes.c_void_p()
+    if hip.hipHostMalloc(ctypes.byref(hptr), ctypes.c_size_t(nbytes), ctypes.c_uint(0)) != 0:
+        return {"error": "hipHostMalloc failed"}
+    out = {"probe": "hipMemcpyAsync, hipHostMalloc <-> HBM, %d MiB x %d, one direction at a time (not a roof)" % (nbytes >> 20, reps)}
+    try:
+        if hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(nbytes)) != 0:
+            return {"error": "hipMalloc failed"}
+        ctypes.memset(hptr, 1, nbytes)                   # first touch by this thread
+        for name, (dst, src, kind) in dict(h2d=(dptr, hptr, 1), d2h=(hptr, dptr, 2)).items():
+            hip.hipMemcpyAsync(dst, src, ctypes.c_size_t(nbytes), ctypes.c_int(kind), None); hip.hipDeviceSynchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hip.hipMemcpyAsync(dst, src, ctypes.c_size_t(nbytes), ctypes.c_int(kind), None)
+            hip.hipDeviceSynchronize()
+            out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 1)
+    finally:
+        if dptr: hip.hipFree(dptr)
+        hip.hipHostFree(hptr)
     return out
 
 
@@ -747,7 +777,7 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
     import threading
     nsamp = img.size
     depth, threads = 6, 4                   # slots per pipe; host threads per pipe (finishers / parse workers)
-    out = {"frames": n, "depth": depth, "host_threads": threads, "sample_container_bits": container, "pcie_GBps_one_direction": pcie_bandwidth(torch)}
+    out = {"frames": n, "depth": depth, "host_threads": threads, "sample_container_bits": container, "memcpy_probe_GBps": pcie_bandwidth(torch)}
     if isinstance(cs, (list, tuple)):
         cs = cs[0]
     dt, st = run_encoder_pipe(plan, img, n, depth, threads, container=container, want=cs)

@@ -436,8 +436,14 @@ int  ojphgpu_decoder_run_device(ojphgpu_decoder* dec, int32_t* d_image);
 int  ojphgpu_decoder_run_device16(ojphgpu_decoder* dec, uint16_t* d_image);     /* 16-bit containers */
 int  ojphgpu_decoder_run_device8(ojphgpu_decoder* dec, uint8_t* d_image);       /* 8-bit containers */
 int  ojphgpu_decode16(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len, uint16_t* h_image);
-/* number of code-blocks that failed to decode in the last run (synchronises) */
+/* number of code-blocks that failed to decode in the last run (synchronises).  This call COLLECTS the run: when the
+ * one-launch block decoder of that run gave up waiting for its own step-1 part (a chip held up for seconds by other
+ * work; it marks the run instead of failing blocks), the frame is decoded again here through the separate launches,
+ * into the same d_image -- so read d_image after this call, not before.  The reference decides per block at
+ * codeblock::decode (ojph_codeblock.cpp:190-224); this is where its verdicts become visible. */
 int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
+/* how many runs of this decoder were repeated that way (0 in any normal process) */
+int  ojphgpu_decoder_fused_retries(ojphgpu_decoder* dec, uint32_t* count);
 int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len,
                     int32_t* h_image);
 
@@ -521,6 +527,8 @@ int  ojphgpu_dec_pipe_submit(ojphgpu_dec_pipe* pipe);
 int  ojphgpu_dec_pipe_collect(ojphgpu_dec_pipe* pipe, const void** h_frame, size_t* bytes, uint32_t* failed_blocks);
 /* out[0] frames completed, [1] mean host parse time per frame (ms), [2] mean submit -> frame latency (ms), [3] host threads */
 int  ojphgpu_dec_pipe_stats(ojphgpu_dec_pipe* pipe, double out[4]);
+/* frames this pipe decoded twice because the one-launch block decoder asked for it (ojphgpu_decoder_failed_blocks) */
+int  ojphgpu_dec_pipe_fused_retries(ojphgpu_dec_pipe* pipe, uint32_t* count);
 /* decoded frames come back pixel-interleaved, clamped to [0, 2^depth - 1] -- ONE depth for the frame: the components
  * must share their bit depth (a .ppm has one maxval), otherwise OJPHGPU_E_INVALID -- (ppm_out::write and its converters,
  * ojph_img_io.cpp:99-226, :539-556); same conditions as ojphgpu_enc_pipe_set_pixels; call before the first _submit */

@@ -202,6 +202,7 @@ SIGNATURES = {
     "ojphgpu_decoder_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ojphgpu_decoder_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_decoder_failed_blocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_decoder_fused_retries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "ojphgpu_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_encoder_ht_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_encoder_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -224,6 +225,7 @@ SIGNATURES = {
     "ojphgpu_dec_pipe_submit": (C.c_int, [C.c_void_p]),
     "ojphgpu_dec_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "ojphgpu_dec_pipe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "ojphgpu_dec_pipe_fused_retries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "ojphgpu_enc_pipe_set_pixels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ojphgpu_enc_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),
     "ojphgpu_dec_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),

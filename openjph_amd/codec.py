@@ -243,6 +243,12 @@ class Decoder:
         check(self._lib.ojphgpu_decoder_failed_blocks(self._h, C.byref(n)), "decoder_failed_blocks")
         return int(n.value)
 
+    def fused_retries(self):
+        """runs of this decoder that were repeated through the separate launches (see ojphgpu_decoder_failed_blocks)"""
+        n = C.c_uint32()
+        check(self._lib.ojphgpu_decoder_fused_retries(self._h, C.byref(n)), "decoder_fused_retries")
+        return int(n.value)
+
     def decode(self) -> np.ndarray:
         img = self.run_device()
         failed = self.failed_blocks()

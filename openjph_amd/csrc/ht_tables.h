@@ -35,9 +35,12 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
 // step 1 + step 2 in one launch (kernels_ht_dec.hip, ht_dec_fused_kernel): chains first, step-2 workers behind them
 bool dec_fuses();
 uint64_t ht_decode_fused_state_words(uint32_t n);
-bool ht_decode_fused_pays(uint32_t n, uint32_t max_h);   // one launch for step 1 + step 2, or the separate launches
+uint32_t device_cus(int device);                          // compute units of that device (256 when the query fails)
+bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus);   // one launch for step 1 + step 2, or the separate launches
+uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus);  // workgroups of that launch = what its ticket counter grows by per run
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
-                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds);
+                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
+                           uint32_t cus, uint32_t ticket_base);
 int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
                            const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds);
 

@@ -284,6 +284,9 @@ struct FlatRd {
 // publishes how many 32-event words are complete and the chain polls that count in the rare case it catches up.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;   // pointers kept in structs must not decay to flat ones:
                                                                // a flat load counts as a global one and drags vmcnt waits in
+// A chain that waits for its partner waits for a wavefront of its own workgroup: resident by construction, so the wait ends;
+// the bound (about a second of s_sleep(2) polls) only keeps a broken build from hanging the queue.
+constexpr uint32_t LDS_WAIT_SPINS = 1u << 23;
 constexpr uint32_t EV_WORDS = 44;          // <= 1024 quads + 256 initial-row pairs events = 40 words, + 2 of read-ahead
 __device__ __forceinline__ uint32_t ev_words_of(uint32_t QW, uint32_t QH)
 {
@@ -340,7 +343,7 @@ struct EvRd {
   __device__ __forceinline__ uint32_t fetch(uint32_t want) {
     if (want >= avail && !stuck) {                           // rare: the producer is not that far yet
       uint32_t spins = 0;
-      do { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; } while (want >= avail && ++spins < (1u << 17));
+      do { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; } while (want >= avail && ++spins < LDS_WAIT_SPINS);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       stuck = stuck || want >= avail;                        // cannot happen (the partner always progresses); never hang
     }
@@ -531,7 +534,7 @@ struct RingRd {
   __device__ __forceinline__ uint32_t fetch(uint32_t want) {      // blocking: waits until the partner has produced word `want`
     if (stuck) return 0u;                                    // (gave up on this block before: no second wait)
     uint32_t avail = prog[lane], spins = 0;
-    while (want >= avail && ++spins < (1u << 17)) { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; }
+    while (want >= avail && ++spins < LDS_WAIT_SPINS) { __builtin_amdgcn_s_sleep(2); avail = prog[lane]; }
 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     stuck = stuck || want >= avail;                          // cannot happen (the partner always progresses); never hang
@@ -1099,23 +1102,36 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 //     slice needs stays in the wavefront's LDS: 80 bytes of state (bottom-row exponents, MagSgn position, where the
 //     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits
 //     (otherwise one ring per wavefront and a restart of the un-stuffer at the latest 256-byte boundary per slice).
-// Workgroups are dispatched in index order, so every chain is resident before the first worker starts: whoever is waited
-// for is running or done -- no deadlock; all waits are bounded all the same (a block whose wait runs out fails, the
-// launch never hangs).  The XCDs' L2s are not coherent with each other: everything exchanged inside the launch
-// (records, flags, block status) is accessed with agent scope.  Flags carry the run's epoch, so nothing has to be
-// cleared between runs.  Blocks wider than 64 samples and blocks with refinement passes keep the separate launches,
-// and so do frames where the one launch does not pay (ht_decode_fused_pays).
+// Who plays which role is decided by a TICKET, not by blockIdx: every workgroup takes the next number from a counter when
+// it starts (one atomic per workgroup); numbers 0 .. n1-1 are the step-1 workgroups, the rest workers.  A worker therefore
+// only exists once every chain workgroup is RUNNING -- whatever order the eight XCDs' dispatchers hand workgroups out in, and
+// whatever else shares the chip (other streams' launches, a second decoder object's fused launch): whoever is waited for is
+// resident and makes progress, there is no deadlock and no dependence on dispatch order.  The waits are bounded all the
+// same, by TIME (s_memrealtime, 100 MHz; two seconds unless the host says otherwise): a wait that runs out does not fail its
+// block -- the worker writes the run's epoch into the RETRY word behind the block status array, and the host, when it
+// collects the verdicts of the run, decodes the frame again through the separate step 1 / step 2 launches
+// (ojphgpu_codec.cpp: fused_retry).  The same goes for a chain that gives up on its partner.  The counter never has to be
+// cleared: the host passes the value it had before the launch (it grows by the grid size per run).
+// The XCDs' L2s are not coherent with each other: everything exchanged inside the launch (records, flags, block status)
+// is accessed with agent scope.  Flags carry the run's epoch, so nothing has to be cleared between runs.  Blocks wider
+// than 64 samples and blocks with refinement passes keep the separate launches, and so do frames where the one launch
+// does not pay (ht_decode_fused_pays).
 
 // waits until the chain wavefront behind `flag` has published `rows` quad rows of this run; returns how many it has
-// published by then (0 = the wait ran out)
-__device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows)
+// published by then (0 = the wait ran out: `ticks` of the 100 MHz clock)
+__device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epoch, uint32_t rows, uint32_t ticks)
 {
-  for (uint32_t spins = 0; spins < 60000u; ++spins) {
+  uint64_t t0 = 0;
+  for (uint32_t spins = 0;; ++spins) {
     const uint32_t v = ld_agent(flag);
     if ((v >> 16) == (epoch & 0xFFFFu) && (v & 0xFFFFu) >= rows) return v & 0xFFFFu;
     __builtin_amdgcn_s_sleep(12);
+    if ((spins & 63u) == 63u) {                               // the clock is looked at every 64th poll
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > (uint64_t)ticks) return 0u;
+    }
   }
-  return 0u;
 }
 
 // NR: un-stuffing rings per worker wavefront -- 1: one ring, every slice of a block re-un-stuffs from the latest chunk
@@ -1124,7 +1140,8 @@ template <int TX, int CH, int WGW, int NR>            // WGW wavefronts per work
 __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
-    uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg)
+    uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg,
+    uint32_t ticket_off, uint32_t ticket_base, uint32_t wait_ticks)
 {
   // one LDS area, carved per role: the step-1 role's tables, event strings, VLC rings and mailboxes -- or the workers'
   // un-stuffing rings and block states
@@ -1137,11 +1154,17 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   uint16_t* const s_uvlc0 = reinterpret_cast<uint16_t*>(s_mem + 1024);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // the workgroup's number in START order (see above)
+  if (threadIdx.x == 0) s_mem[0] = __hip_atomic_fetch_add(fstate + ticket_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+  __syncthreads();
+  const uint32_t wgid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mem[0]);
+  __syncthreads();
+  uint32_t* const retry = reinterpret_cast<uint32_t*>(block_status + ((n + 3u) & ~3u));   // != the run's epoch: nothing to repeat
 
-  if (blockIdx.x >= n1) {                                   // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
+  if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
     if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
     uint32_t* wlds = s_mem + wv * WORKER_WORDS;
-    const uint32_t wave_no = (blockIdx.x - n1) * (uint32_t)WGW + wv;
+    const uint32_t wave_no = (wgid - n1) * (uint32_t)WGW + wv;
     const uint32_t b0 = wave_no * per_wave;
     if (b0 >= n) return;
     const uint32_t nb = n - b0 < per_wave ? n - b0 : per_wave;
@@ -1160,14 +1183,16 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         bool there = true;
         if (d.len1 != 0 && d.num_passes != 0 && !((bi >> 6) == seen_cw && seen_rows >= need)) {
           seen_cw = bi >> 6;
-          seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + seen_cw, epoch, need));
+          seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + seen_cw, epoch, need, wait_ticks));
           there = seen_rows != 0u;
         }
+        if ((dbg & 4u) && sl == 1u && bi % 61u == 7u) there = false;       // (test switch: this wait "ran out")
         if (!there) {
-          // cannot happen; a launch never hangs: the block fails
-          if (lane == 0) { __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); state[19] = 1u; }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          wave_sync();
+          // the chains are resident (tickets), so this is a chip held up for seconds by something else: the run is
+          // marked for a repeat through the separate launches and this wavefront stops (what it leaves undecoded is
+          // decoded by the repeat)
+          if (lane == 0) st_agent(retry, epoch);
+          return;
         }
         step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q0 + S2_ROWS, state);
       }
@@ -1192,7 +1217,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   volatile lds_u32* s_vcons = (volatile lds_u32*)(ctl + 192);
   volatile lds_u32* s_done = (volatile lds_u32*)(ctl + 256);
   if (chain) __builtin_amdgcn_s_setprio(3);
-  const uint32_t cw = blockIdx.x * (uint32_t)CH + set;      // the chain wavefront's number = its blocks' number / 64
+  const uint32_t cw = wgid * (uint32_t)CH + set;            // the chain wavefront's number = its blocks' number / 64
   const uint32_t bi = cw * 64u + lane;
   uint32_t* flag = fstate + cw;
   // (no lane leaves early: the wavefront publishes "all rows done" at the end whatever its blocks are)
@@ -1231,7 +1256,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
       step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch);
       s_done[lane] = 1u;
-      if (mel.stuck || vlc.stuck) __hip_atomic_store(block_status + bi, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mel.stuck || vlc.stuck) st_agent(retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
     }
   }
   if (chain) publish_rows(flag, epoch, 0xFFFFu, lane);     // every row of every block of this wavefront is complete
@@ -1496,10 +1521,10 @@ bool dec_fuses() { return dec_fuse_mode() != 0; }
 // 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
 // against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
 struct FusedShape { uint32_t shape, ch, wgw, n1, per_wave, wwgs; };
-static FusedShape fused_shape(uint32_t n)
+static FusedShape fused_shape(uint32_t n, uint32_t cus)
 {
   static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
-  static const uint32_t cus = [] { int dev = 0, c = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)(c > 0 ? c : 256); }();   // (one process drives one kind of GPU)
+  if (cus == 0) cus = 256;
   FusedShape f;
   f.shape = shape;
   f.ch = shape == 1 ? 4u : 2u; f.wgw = shape == 1 ? 12u : 8u;
@@ -1511,6 +1536,15 @@ static FusedShape fused_shape(uint32_t n)
   f.wwgs = ((n + f.per_wave - 1u) / f.per_wave + f.wgw - 1u) / f.wgw;
   return f;
 }
+// compute units of a device (the decoder objects ask once, for THEIR device, and hand the number to the calls below)
+uint32_t device_cus(int device)
+{
+  int c = 0;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c <= 0) { (void)hipGetLastError(); c = 256; }
+  return (uint32_t)c;
+}
+// workgroups of the fused launch over n blocks: the ticket counter of the scratch grows by this per run
+uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus) { const FusedShape f = fused_shape(n, cus); return f.n1 + f.wwgs; }
 
 // Does ONE launch pay for these blocks?  Measured (profiles/r03_b_block_sizes*.txt, the C5 / C4 bench lines): it does
 // where step 1 is a long latency floor beside an idle chip -- blocks of 64 rows -- and every worker wavefront can be
@@ -1518,16 +1552,20 @@ static FusedShape fused_shape(uint32_t n)
 // half as long, and more blocks than that make workers that start when others end: there the separate launches (raw
 // step 1, then step 2 beside the small synthesis levels) are faster -- 8K frame in 32x32 blocks 0.67 against 0.80 ms,
 // eight 4K frames per step 1.24 against 1.45 ms.  OJPHGPU_DEC_FUSED=2 fuses wherever the launch is able to.
-bool ht_decode_fused_pays(uint32_t n, uint32_t max_h)
+bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus)
 {
   if (dec_fuse_mode() == 0) return false;
   if (dec_fuse_mode() >= 2) return true;
-  return max_h > 32u && fused_shape(n).per_wave <= (uint32_t)S2_RINGS;
+  return max_h > 32u && fused_shape(n, cus).per_wave <= (uint32_t)S2_RINGS;
 }
 // step 1 + step 2 of n blocks, all of them at most 64 samples wide, of one wavelet (kinds as in ht_decode_step2_launch)
-// and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch
+// and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch;
+// d_state: ht_decode_fused_state_words(n) words, zeroed once; ticket_base: what the scratch's ticket counter holds before
+// this launch (0 at first, + ht_decode_fused_grid(n, cus) per launch); d_block_status: n bytes + the 4-byte RETRY word behind
+// them at the next multiple of 4 (== epoch after the run: a wait ran out, decode the blocks again by the separate launches)
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
-                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds)
+                           void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
+                           uint32_t cus, uint32_t ticket_base)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -1535,12 +1573,15 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
   if (tx == 0 || (kinds & 3) != 1 || max_h == 0) return OJPHGPU_E_INVALID;
   const uint32_t nslices = (((max_h + 1u) >> 1) + S2_ROWS - 1u) / S2_ROWS;
-  const FusedShape f = fused_shape(n);
+  const FusedShape f = fused_shape(n, cus);
   const uint32_t shape = f.shape, n1 = f.n1, per_wave = f.per_wave, wwgs = f.wwgs, wgw = f.wgw;
   static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
+  // how long a worker waits for a chain before it asks for the repeat (OJPHGPU_FUSED_WAIT_MS; ticks of the 100 MHz clock)
+  static const uint32_t wait_ticks = [] { const char* e = getenv("OJPHGPU_FUSED_WAIT_MS"); const long ms = e ? atol(e) : 2000; return (uint32_t)((ms < 1 ? 1 : ms > 40000 ? 40000 : ms) * 100000l); }();
+  const uint32_t ticket_off = (uint32_t)ht_decode_fused_state_words(n) - 64u;      // the last 64 words of the scratch: a cache line of its own
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
 #define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
-                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg)
+                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg, ticket_off, ticket_base, wait_ticks)
   // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
   static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
   if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }

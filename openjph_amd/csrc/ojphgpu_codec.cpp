@@ -598,6 +598,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   if (!d) return OJPHGPU_E_NOMEM;
   struct Owner { ojphgpu_decoder* p; ~Owner() { if (p) ojphgpu_decoder_destroy(p); } } owner{ d };   // also when a container throws
   d->P = &P; d->device = device; d->stream = (hipStream_t)stream;
+  d->cus = ojphgpu::device_cus(device);
   auto bail = [&](int rc) { return rc; };
 
   d->tiles = TileRange{ tile_first, tile_count };
@@ -659,6 +660,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
       d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
     return bail(OJPHGPU_E_NOMEM);
+  if (hipMemset(d->status.p, 0, bd.size() + 16) != hipSuccess) return bail(OJPHGPU_E_HIP);      // (the RETRY word behind the status bytes)
   if (hipMemset(d->arena.p, 0, P.arena_elems * 4 * nframes) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!dd.empty() && hipMemcpy(d->dwt_descs.p, dd.data(), dd.size() * sizeof(dd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
   if (!idd.empty() && hipMemcpy(d->img_descs.p, idd.data(), idd.size() * sizeof(idd[0]), hipMemcpyHostToDevice) != hipSuccess) return bail(OJPHGPU_E_HIP);
@@ -743,8 +745,9 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
   // every block is at most 64 samples wide, of one wavelet and without refinement passes -- and where it pays: blocks
   // of 64 rows, few enough for resident workers (ht_decode_fused_pays); the synthesis levels follow on the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
-  const bool fused = d->fstate.p && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) && d->nblocks > 0 &&
-                     ojphgpu::ht_decode_fused_pays(d->nblocks, d->max_block_h);
+  const bool fused = d->fstate.p && !d->force_separate && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) &&
+                     d->nblocks > 0 && ojphgpu::ht_decode_fused_pays(d->nblocks, d->max_block_h, d->cus);
+  d->last_fused = fused; d->last_image = d_image; d->last_container = container;
   const uint32_t n_low = fused ? 0u : d->n_low;
   int rc;
   if (fused) {
@@ -753,8 +756,9 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
     const int sp = T.begin(SP_STEP2, s);
     rc = ojphgpu::ht_decode_fused_launch(s, cbd, d->nblocks, data, (uint32_t*)d->quads.p, d->arena.p, status, (uint32_t*)d->fstate.p,
-                                         ++d->fused_epoch, d->max_block_h, d->kinds);
+                                         ++d->fused_epoch, d->max_block_h, d->kinds, d->cus, d->fused_tickets);
     if (rc) return rc;
+    d->fused_tickets += ojphgpu::ht_decode_fused_grid(d->nblocks, d->cus);
     T.end(sp, s);
   } else {
     rc = decode_chains(d, s);
@@ -810,15 +814,45 @@ extern "C" int ojphgpu_decoder_set_timing(ojphgpu_decoder* d, int per_launch)
   return OJPHGPU_OK;
 }
 
+// the run that has just been enqueued again, through the separate step 1 / step 2 launches (a fused launch asked for it)
+int ojphgpu_decoder_repeat_separate(ojphgpu_decoder* d)
+{
+  if (!d || !d->last_image) return OJPHGPU_E_INVALID;
+  d->force_separate = true;
+  const int rc = ojphgpu_decoder_run_container(d, d->last_image, d->last_container);
+  d->force_separate = false;
+  d->fused_retries++;
+  return rc;
+}
+
 extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count)
 {
   if (!d || !count || !d->ran) return OJPHGPU_E_INVALID;
-  std::vector<uint8_t> st(d->nblocks);
-  if (!st.empty()) HIPCHK(hipMemcpyAsync(st.data(), d->status.p, st.size(), hipMemcpyDeviceToHost, d->stream));
-  HIPCHK(hipStreamSynchronize(d->stream));
+  const size_t tail = ((size_t)d->nblocks + 3u) & ~(size_t)3u;
+  std::vector<uint8_t> st(tail + 4);
+  const uint8_t* status = (const uint8_t*)(d->o_status ? d->o_status : d->status.p);
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPCHK(hipMemcpyAsync(st.data(), status, st.size(), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    // a fused launch whose workers gave up waiting for their chains (the chip was held up for seconds by other work): its
+    // blocks have no verdict yet -- the frame is decoded again through the separate launches, into the same image
+    if (pass == 0 && d->last_fused && ojphgpu_fused_retry_wanted(st.data(), d->nblocks, d->fused_epoch)) {
+      const int rc = ojphgpu_decoder_repeat_separate(d);
+      if (rc) return rc;
+      continue;
+    }
+    break;
+  }
   uint32_t n = 0;
-  for (uint8_t v : st) n += v != 0;
+  for (uint32_t i = 0; i < d->nblocks; ++i) n += st[i] != 0;
   *count = n;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_fused_retries(ojphgpu_decoder* d, uint32_t* count)
+{
+  if (!d || !count) return OJPHGPU_E_INVALID;
+  *count = d->fused_retries;
   return OJPHGPU_OK;
 }
 
@@ -843,10 +877,11 @@ static int decode_host(ojphgpu_decoder* d, const uint8_t* h_codestream, size_t l
   if (rc) return rc;
   rc = ojphgpu_decoder_run_container(d, d->image.p, container);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (32 / container), hipMemcpyDeviceToHost, d->stream));
   uint32_t failed = 0;
-  rc = ojphgpu_decoder_failed_blocks(d, &failed);
+  rc = ojphgpu_decoder_failed_blocks(d, &failed);          // first: it may repeat the run (see there), and the image is read after that
   if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h_image, d->image.p, bytes / (32 / container), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
   return failed ? OJPHGPU_E_BLOCK : OJPHGPU_OK;
 }
 

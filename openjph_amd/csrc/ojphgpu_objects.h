@@ -308,6 +308,14 @@ struct ojphgpu_decoder {
   int device = 0; hipStream_t stream = nullptr;
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
   DeviceBuf fstate; uint32_t fused_epoch = 0, max_block_h = 0;     // the fused step 1 + step 2 launch: its flags / per-block state, run counter
+  uint32_t cus = 256;                               // compute units of `device` (the fused launch is shaped for them)
+  uint32_t fused_tickets = 0;                       // what the scratch's ticket counter holds (grows by the grid size per fused launch)
+  // A fused launch whose workers gave up waiting (a chip held up for seconds by other work) marks the run in the RETRY word
+  // behind the block status array; whoever collects the run's verdicts (ojphgpu_decoder_failed_blocks, the decoder pipe)
+  // then repeats the run through the separate launches: last_* is what that repeat needs.
+  bool last_fused = false, force_separate = false;
+  void* last_image = nullptr; int last_container = 0;
+  uint32_t fused_retries = 0;                       // runs repeated that way so far
   // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
   // levels with step 2, see decoder_create)
   uint32_t n_low = 0;
@@ -334,6 +342,13 @@ int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_bloc
 void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);
 int  ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int container);
+// after a run has completed, with the status bytes + the RETRY word behind them on the host (nblocks bytes, then the word at
+// the next multiple of 4): did the fused launch of that run (epoch) ask for a repeat?
+inline bool ojphgpu_fused_retry_wanted(const uint8_t* h_status, uint32_t nblocks, uint32_t epoch)
+{
+  uint32_t w; memcpy(&w, h_status + ((nblocks + 3u) & ~3u), 4);
+  return w == epoch;
+}
 
 
 #endif

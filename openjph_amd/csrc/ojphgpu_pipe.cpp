@@ -488,29 +488,44 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     if ((r2 = upload(p->mode, p->s_h2d, s.data.b.p, s.h_cs, (size_t)fi.first, (size_t)fi.len)) != 0) return r2;
     if ((r2 = upload(p->mode, p->s_h2d, s.cb_descs.p, s.h_descs, 0, nb * sizeof(ojphgpu_cb_desc))) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
-    {
-      // a decoder object is shared by the frames in flight on it: what a run reads is set and enqueued under a lock
-      std::lock_guard<std::mutex> lk(p->enqueue_mus[k]);
-      HIPCHK(hipStreamWaitEvent(s_comp, s.ev_in, 0));
-      d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
-      d->any_refine = fi.any_refine; d->kinds = fi.kinds; d->max_len1 = fi.max_len1;
-      r2 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
-      if (r2) return r2;
-      if (p->pixel_bits) {                           // planes -> the pixel order of the file / display buffer
-        uint32_t depth = 0;
-        for (const CompGeo& g : P.comps) depth = std::max(depth, g.bit_depth);
-        r2 = ojphgpu_pack_pixels(s_comp, s.image.p, s.pixels.p, P.p.width, P.p.height, P.p.num_comps, p->container, p->pixel_bits,
-                                 p->big_endian, depth);
-        if (r2) return r2;
+    // kernels of the frame on the object's compute stream, then the downloads; `separate`: the repeat a fused launch asked for
+    const size_t st_bytes = ((nb + 3) & ~(size_t)3) + 4;    // the status bytes + the RETRY word behind them
+    uint32_t epoch = 0; bool was_fused = false;
+    auto run_and_fetch = [&](bool separate) -> int {
+      int r3;
+      {
+        // a decoder object is shared by the frames in flight on it: what a run reads is set and enqueued under a lock
+        std::lock_guard<std::mutex> lk(p->enqueue_mus[k]);
+        HIPCHK(hipStreamWaitEvent(s_comp, s.ev_in, 0));
+        d->o_cb_descs = s.cb_descs.p; d->o_data = s.data.b.p; d->o_status = s.status.p;
+        d->any_refine = fi.any_refine; d->kinds = fi.kinds; d->max_len1 = fi.max_len1;
+        d->force_separate = separate;
+        r3 = ojphgpu_decoder_run_container(d, s.image.p, p->container);
+        d->force_separate = false;
+        if (r3) return r3;
+        epoch = d->fused_epoch; was_fused = d->last_fused;
+        if (separate) d->fused_retries++;
+        if (p->pixel_bits) {                           // planes -> the pixel order of the file / display buffer
+          uint32_t depth = 0;
+          for (const CompGeo& g : P.comps) depth = std::max(depth, g.bit_depth);
+          r3 = ojphgpu_pack_pixels(s_comp, s.image.p, s.pixels.p, P.p.width, P.p.height, P.p.num_comps, p->container, p->pixel_bits,
+                                   p->big_endian, depth);
+          if (r3) return r3;
+        }
+        if (p->packed_bits && (r3 = ojphgpu_pack_bits(s_comp, s.image.p, s.pixels.p, P.frame_elems, p->container, p->packed_bits)) != 0) return r3;
+        HIPCHK(hipEventRecord(s.ev_kern, s_comp));
       }
-      if (p->packed_bits && (r2 = ojphgpu_pack_bits(s_comp, s.image.p, s.pixels.p, P.frame_elems, p->container, p->packed_bits)) != 0) return r2;
-      HIPCHK(hipEventRecord(s.ev_kern, s_comp));
-    }
-    HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
-    if ((r2 = download(p->mode, p->s_d2h, s.h_img, (p->pixel_bits || p->packed_bits) ? s.pixels.p : s.image.p, p->out_bytes)) != 0) return r2;       // beside the next frame's upload
-    if ((r2 = download(p->mode, p->s_d2h, s.h_status, s.status.p, nb)) != 0) return r2;
-    HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
-    HIPCHK(hipEventSynchronize(s.ev_done));
+      HIPCHK(hipStreamWaitEvent(p->s_d2h, s.ev_kern, 0));
+      if ((r3 = download(p->mode, p->s_d2h, s.h_img, (p->pixel_bits || p->packed_bits) ? s.pixels.p : s.image.p, p->out_bytes)) != 0) return r3;       // beside the next frame's upload
+      if ((r3 = download(p->mode, p->s_d2h, s.h_status, s.status.p, st_bytes)) != 0) return r3;
+      HIPCHK(hipEventRecord(s.ev_done, p->s_d2h));
+      HIPCHK(hipEventSynchronize(s.ev_done));
+      return OJPHGPU_OK;
+    };
+    if ((r2 = run_and_fetch(false)) != 0) return r2;
+    // the fused block-decoder launch of this run gave up waiting (the chip was held up for seconds by other work) and marked
+    // the run instead of failing blocks: once more through the separate launches (see ojphgpu_decoder_failed_blocks)
+    if (was_fused && ojphgpu_fused_retry_wanted(s.h_status.p, (uint32_t)nb, epoch) && (r2 = run_and_fetch(true)) != 0) return r2;
     uint32_t failed = 0;
     for (size_t i = 0; i < nb; ++i) failed += s.h_status.p[i] != 0;
     s.failed = failed;
@@ -613,6 +628,7 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
           s.h_img.reserve(p->frame_bytes + 64) || s.h_status.reserve(nb + 64)) return OJPHGPU_E_NOMEM;
       if (s.data.reserve(len + len / 4 + 64) || s.image.alloc((size_t)P.frame_elems * 4 + 64) || s.cb_descs.alloc(nb * sizeof(ojphgpu_cb_desc) + 64) ||
           s.status.alloc(nb + 64)) return OJPHGPU_E_NOMEM;
+      HIPCHK(hipMemset(s.status.p, 0, nb + 64));
       for (hipEvent_t* ev : { &s.ev_in, &s.ev_kern, &s.ev_done }) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventReleaseToSystem));
     }
     const uint32_t nthreads = host_threads ? std::min<uint32_t>(host_threads, 16) : 2;
@@ -717,6 +733,18 @@ extern "C" int ojphgpu_dec_pipe_plan(ojphgpu_dec_pipe* p, const ojphgpu_plan** p
 {
   if (!p || !plan) return OJPHGPU_E_INVALID;
   *plan = p->first;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_dec_pipe_fused_retries(ojphgpu_dec_pipe* p, uint32_t* count)
+{
+  if (!p || !count) return OJPHGPU_E_INVALID;
+  uint32_t n = 0;
+  for (uint32_t k = 0; k < p->nobj; ++k) {
+    std::lock_guard<std::mutex> lk(p->enqueue_mus[k]);
+    n += p->decs[k]->fused_retries;
+  }
+  *count = n;
   return OJPHGPU_OK;
 }
 

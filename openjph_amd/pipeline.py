@@ -198,7 +198,9 @@ class DecoderPipe:
     def stats(self):
         out = (C.c_double * 4)()
         check(self._lib.ojphgpu_dec_pipe_stats(self._h, out), "dec_pipe_stats")
-        return dict(frames=int(out[0]), host_parse_ms=out[1], latency_ms=out[2], host_threads=int(out[3]))
+        n = C.c_uint32()
+        check(self._lib.ojphgpu_dec_pipe_fused_retries(self._h, C.byref(n)), "dec_pipe_fused_retries")
+        return dict(frames=int(out[0]), host_parse_ms=out[1], latency_ms=out[2], host_threads=int(out[3]), fused_retries=int(n.value))
 
     def decode_sequence(self, codestreams):
         for cs in codestreams:
