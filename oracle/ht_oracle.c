@@ -129,15 +129,20 @@ static void build_tables(void)
 
 static inline int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
 static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+static inline int clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
 
-/* UVLC encoder code of u (0..32) -> prefix / suffix (block_encoder.cpp:196-255) */
-static void uvlc_code(int u, int* pre, int* pre_len, int* suf, int* suf_len)
+/* UVLC encoder code of u -> prefix / suffix / extension (block_encoder.cpp:196-255): u <= 32 has no extension (all the
+ * 32-bit sample path ever produces); u >= 33 -- only the 64-bit sample path, :1269-1286 -- is coded as suffix 28 + (u - 33) % 4
+ * and a 4-bit extension (u - 33) / 4 */
+static void uvlc_code(int u, int* pre, int* pre_len, int* suf, int* suf_len, int* ext, int* ext_len)
 {
+  *ext = 0; *ext_len = 0;
   if (u == 0) { *pre = 0; *pre_len = 0; *suf = 0; *suf_len = 0; }
   else if (u == 1) { *pre = 1; *pre_len = 1; *suf = 0; *suf_len = 0; }
   else if (u == 2) { *pre = 2; *pre_len = 2; *suf = 0; *suf_len = 0; }
   else if (u <= 4) { *pre = 4; *pre_len = 3; *suf = u - 3; *suf_len = 1; }
-  else { *pre = 0; *pre_len = 3; *suf = u - 5; *suf_len = 5; }
+  else if (u <= 32) { *pre = 0; *pre_len = 3; *suf = u - 5; *suf_len = 5; }
+  else { *pre = 0; *pre_len = 3; *suf = 28 + (u - 33) % 4; *suf_len = 5; *ext = (u - 33) / 4; *ext_len = 4; }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -159,6 +164,11 @@ static int fb_put(flatbits* f, uint32_t v, int n)
   memcpy(f->b + byte, &w, 8);
   f->nbits += n;
   return 1;
+}
+static int fb_put64(flatbits* f, uint64_t v, int n)        /* n up to 64 */
+{
+  if (n > 32) { if (!fb_put(f, (uint32_t)v, 32)) return 0; return fb_put(f, (uint32_t)(v >> 32), n - 32); }
+  return fb_put(f, (uint32_t)v, n);
 }
 /* The reference's readers OR every raw byte into their window with all 8 bits and only then
  * advance by 7 or 8 (frwd_read :609-655, rev_read :308-359): after a stuffing event the byte's MSB
@@ -182,6 +192,12 @@ static uint32_t fb_get(const flatbits* f, long pos, int n)
   w >>= (pos & 7);
   if (n < 32) w &= (1ull << n) - 1;
   return (uint32_t)w;
+}
+static uint64_t fb_get64(const flatbits* f, long pos, int n)   /* n up to 64 */
+{
+  uint64_t lo = fb_get(f, pos, n < 32 ? n : 32);
+  if (n > 32) lo |= (uint64_t)fb_get(f, pos + 32, n - 32) << 32;
+  return lo;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -234,12 +250,12 @@ static int vlc_put(vlcw* v, int cwd, int len)
   }
   return 1;
 }
-static int ms_put(msw* m, uint32_t cwd, int len)
+static int ms_put(msw* m, uint64_t cwd, int len)          /* ms_encode / ms_encode64 (:471-512) */
 {
   while (len > 0) {
     if (m->pos >= m->size) return 0;
     int t = m->maxb - m->used; if (t > len) t = len;
-    m->tmp |= (cwd & ((1u << t) - 1)) << m->used;
+    m->tmp |= (uint32_t)(cwd & ((1ull << t) - 1)) << m->used;
     m->used += t; cwd >>= t; len -= t;
     if (m->used >= m->maxb) {
       m->buf[m->pos++] = (uint8_t)m->tmp;
@@ -252,32 +268,36 @@ static int ms_put(msw* m, uint32_t cwd, int len)
 /* ------------------------------------------------------------------------------------------ */
 /* HT cleanup encoder                                                                          */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { uint32_t val; uint32_t sign; } smp;
+/* The coder is written once, on 64-bit sign-magnitude samples (sign in bit 63, magnitude MSB aligned below it), which is
+ * ojph_encode_codeblock64 (block_encoder.cpp:1026-1520).  ojph_encode_codeblock32 (:542-1017) is the same algorithm on
+ * 32-bit words: with p32 = 30 - missing_msbs and p64 = 62 - missing_msbs = p32 + 32, a 32-bit word moved up by 32 bits
+ * gives the same 2*mu_p, hence the same symbols; it never reaches u > 32, so the U-VLC extension is never emitted. */
+typedef struct { uint64_t val; uint32_t sign; } smp;
 
-static inline smp get_smp(const uint32_t* buf, int w, int h, int stride, int x, int y, int p)
+static inline smp get_smp(const uint64_t* buf, int w, int h, int stride, int x, int y, int p)
 {
   smp s = { 0, 0 };
   if (x < 0 || y < 0 || x >= w || y >= h) return s;
-  uint32_t t = buf[(size_t)y * stride + x];
-  s.val = ((t + t) >> p) & ~1u;   /* 2*mu_p : block_encoder.cpp:592-595 */
-  s.sign = t >> 31;
+  uint64_t t = buf[(size_t)y * stride + x];
+  s.val = ((t + t) >> p) & ~1ull;   /* 2*mu_p : block_encoder.cpp:592-595, :1093-1096 */
+  s.sign = (uint32_t)(t >> 63);
   return s;
 }
-static inline int expo(uint32_t val) { return val ? 32 - clz32(val - 1) : 0; }
+static inline int expo(uint64_t val) { return val ? 64 - clz64(val - 1) : 0; }
 
 typedef struct {         /* everything one quad contributes, in stream order */
   int exists, rho, c_q, u, U, tuple;
-  uint32_t ms_val[4]; int ms_len[4];
+  uint64_t ms_val[4]; int ms_len[4];
   int mel_valid, mel_bit;
 } quadsym;
 
-static void quad_symbols(const uint32_t* buf, int w, int h, int stride, int p, int qx, int qy,
+static void quad_symbols(const uint64_t* buf, int w, int h, int stride, int p, int qx, int qy,
                          int rho_left, quadsym* q)
 {
   memset(q, 0, sizeof(*q));
   if (2 * qx >= w) return;
   q->exists = 1;
-  int e[4], emax = 0; uint32_t s[4];
+  int e[4], emax = 0; uint64_t s[4];
   for (int n = 0; n < 4; ++n) {
     smp a = get_smp(buf, w, h, stride, 2 * qx + (n >> 1), 2 * qy + (n & 1), p);
     e[n] = expo(a.val);
@@ -310,12 +330,12 @@ static void quad_symbols(const uint32_t* buf, int w, int h, int stride, int p, i
   for (int n = 0; n < 4; ++n) {
     int m = (q->rho >> n) & 1 ? q->U - ((q->tuple >> n) & 1) : 0;   /* :667-674 */
     q->ms_len[n] = m;
-    q->ms_val[n] = m ? (s[n] & ((m < 32 ? (1u << m) : 0u) - 1u)) : 0;
+    q->ms_val[n] = m ? (s[n] & ((m < 64 ? (1ull << m) : 0ull) - 1ull)) : 0;
   }
 }
 
 /* collects the (cwd,len) items of a pair for the VLC stream */
-typedef struct { int cwd[8], len[8], n; int mel_valid, mel_bit; } pairvlc;
+typedef struct { int cwd[12], len[12], n; int mel_valid, mel_bit; } pairvlc;
 static void pair_vlc(const quadsym* q0, const quadsym* q1, int first_row, pairvlc* o)
 {
   o->n = 0; o->mel_valid = 0; o->mel_bit = 0;
@@ -323,22 +343,23 @@ static void pair_vlc(const quadsym* q0, const quadsym* q1, int first_row, pairvl
   ADD(q0->tuple >> 8, (q0->tuple >> 4) & 7);
   if (q1->exists) ADD(q1->tuple >> 8, (q1->tuple >> 4) & 7);
   int u0 = q0->u, u1 = q1->exists ? q1->u : 0;
-  int p0, l0, s0, sl0, p1, l1, s1, sl1;
+  int p0, l0, s0, sl0, x0, xl0, p1, l1, s1, sl1, x1, xl1;
   if (first_row && u0 > 0 && u1 > 0) { o->mel_valid = 1; o->mel_bit = (u0 < u1 ? u0 : u1) > 2; }
-  if (first_row && u0 > 2 && u1 > 2) {                              /* :766-772 */
-    uvlc_code(u0 - 2, &p0, &l0, &s0, &sl0); uvlc_code(u1 - 2, &p1, &l1, &s1, &sl1);
-    ADD(p0, l0); ADD(p1, l1); ADD(s0, sl0); ADD(s1, sl1);
-  } else if (first_row && u0 > 2 && u1 > 0) {                       /* :773-778 */
-    uvlc_code(u0, &p0, &l0, &s0, &sl0);
-    ADD(p0, l0); ADD(u1 - 1, 1); ADD(s0, sl0);
-  } else {                                                          /* :779-785, :985-988 */
-    uvlc_code(u0, &p0, &l0, &s0, &sl0); uvlc_code(u1, &p1, &l1, &s1, &sl1);
-    ADD(p0, l0); ADD(p1, l1); ADD(s0, sl0); ADD(s1, sl1);
+  if (first_row && u0 > 2 && u1 > 2) {                              /* :766-772, :1269-1277 */
+    uvlc_code(u0 - 2, &p0, &l0, &s0, &sl0, &x0, &xl0); uvlc_code(u1 - 2, &p1, &l1, &s1, &sl1, &x1, &xl1);
+    ADD(p0, l0); ADD(p1, l1); ADD(s0, sl0); ADD(s1, sl1); ADD(x0, xl0); ADD(x1, xl1);
+  } else if (first_row && u0 > 2 && u1 > 0) {                       /* :773-778, :1278-1284 */
+    uvlc_code(u0, &p0, &l0, &s0, &sl0, &x0, &xl0);
+    ADD(p0, l0); ADD(u1 - 1, 1); ADD(s0, sl0); ADD(x0, xl0);
+  } else {                                                          /* :779-785, :985-988, :1285-1293, :1487-1492 */
+    uvlc_code(u0, &p0, &l0, &s0, &sl0, &x0, &xl0); uvlc_code(u1, &p1, &l1, &s1, &sl1, &x1, &xl1);
+    ADD(p0, l0); ADD(p1, l1); ADD(s0, sl0); ADD(s1, sl1); ADD(x0, xl0); ADD(x1, xl1);
   }
 #undef ADD
 }
 
-#define MS_CAP   ((16384 * 16 + 14) / 15)   /* block_encoder.cpp:550 */
+#define MS_CAP32 ((16384 * 16 + 14) / 15)   /* block_encoder.cpp:550 */
+#define MS_CAP64 ((22528 * 16 + 14) / 15)   /* :1041 */
 #define MEL_CAP  192
 #define VLC_CAP  (3072 - 192)
 
@@ -381,12 +402,13 @@ static int finish_block(uint8_t* out, int cap, const uint8_t* ms, int ms_len, me
   return total;
 }
 
-int ojo_ht_encode(const uint32_t* buf, int width, int height, int stride, int missing_msbs,
-                  uint8_t* out, int cap, int variant)
+static int ht_encode_core(const uint64_t* buf, int width, int height, int stride, int missing_msbs,
+                          uint8_t* out, int cap, int variant, int ms_cap)
 {
   build_tables();
-  int p = 30 - missing_msbs;
+  int p = 62 - missing_msbs;
   int QW = (width + 1) >> 1, QH = (height + 1) >> 1, PW = (QW + 1) >> 1;
+  const int MS_CAP = ms_cap;
 
   uint8_t* ms_buf = (uint8_t*)malloc(MS_CAP + 64);
   uint8_t mel_buf[MEL_CAP], vlc_buf[VLC_CAP];
@@ -416,10 +438,10 @@ int ojo_ht_encode(const uint32_t* buf, int width, int height, int stride, int mi
       for (int i = 0; i < pv.n; ++i)
         ok &= variant ? fb_put(&fvlc, (uint32_t)pv.cwd[i], pv.len[i]) : vlc_put(&vlc, pv.cwd[i], pv.len[i]);
       for (int n = 0; n < 4; ++n)
-        ok &= variant ? fb_put(&fms, q0.ms_val[n], q0.ms_len[n]) : ms_put(&ms, q0.ms_val[n], q0.ms_len[n]);
+        ok &= variant ? fb_put64(&fms, q0.ms_val[n], q0.ms_len[n]) : ms_put(&ms, q0.ms_val[n], q0.ms_len[n]);
       if (q1.exists)
         for (int n = 0; n < 4; ++n)
-          ok &= variant ? fb_put(&fms, q1.ms_val[n], q1.ms_len[n]) : ms_put(&ms, q1.ms_val[n], q1.ms_len[n]);
+          ok &= variant ? fb_put64(&fms, q1.ms_val[n], q1.ms_len[n]) : ms_put(&ms, q1.ms_val[n], q1.ms_len[n]);
     }
   }
   if (!ok) goto done;
@@ -486,6 +508,23 @@ done:
   return result;
 }
 
+int ojo_ht_encode64(const uint64_t* buf, int width, int height, int stride, int missing_msbs,
+                    uint8_t* out, int cap, int variant)
+{
+  return ht_encode_core(buf, width, height, stride, missing_msbs, out, cap, variant, MS_CAP64);
+}
+
+int ojo_ht_encode(const uint32_t* buf, int width, int height, int stride, int missing_msbs,
+                  uint8_t* out, int cap, int variant)
+{
+  uint64_t* wide = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)stride * (size_t)(height > 0 ? height : 1));
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) wide[(size_t)y * stride + x] = (uint64_t)buf[(size_t)y * stride + x] << 32;
+  const int r = ht_encode_core(wide, width, height, stride, missing_msbs, out, cap, variant, MS_CAP32);
+  free(wide);
+  return r;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* HT decoder                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -519,7 +558,7 @@ static uint32_t next_bit(const flatbits* f, long* pos)      /* exhausted streams
 }
 
 static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_passes, int p,
-                          int width, int height, int stride, uint32_t* out, int stripe_causal)
+                          int width, int height, int stride, uint64_t* out, int stripe_causal)
 {
   int ngroups = (width + 3) >> 2, nstripes = (height + 3) >> 2;
   int mstr = ngroups + 2;
@@ -580,7 +619,7 @@ static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_pass
           for (int r = 0; r < 4; ++r)
             if (new_sig & (1u << (4 * c + r))) {
               uint32_t sign = SPP_BIT();
-              out[(size_t)(y + r) * stride + x + c] = (sign << 31) | (3u << (p - 2));
+              out[(size_t)(y + r) * stride + x + c] = ((uint64_t)sign << 63) | (3ull << (p - 2));
             }
       }
       new_sig |= cs;
@@ -592,14 +631,14 @@ static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_pass
   }
   /* ---- magnitude refinement (:1561-1609): significant samples of the cleanup pass, column-major ---- */
   if (num_passes > 2) {
-    uint32_t half = 1u << (p - 2);
+    uint64_t half = 1ull << (p - 2);
     for (int y = 0; y < height; y += 4)
       for (int x = 0; x < width; ++x) {
         uint32_t nib = (sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
         for (int r = 0; r < 4; ++r)
           if (nib & (1u << r)) {
             uint32_t sym = MRP_BIT();
-            out[(size_t)(y + r) * stride + x] ^= ((1u - sym) << (p - 1)) | half;
+            out[(size_t)(y + r) * stride + x] ^= ((uint64_t)(1u - sym) << (p - 1)) | half;
           }
       }
   }
@@ -609,15 +648,27 @@ static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_pass
   free(sigma); free(prev_row);
 }
 
-int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int missing_msbs,
-                  int width, int height, int stride, uint32_t* out, int stripe_causal)
+/* The decoder is written once, with 64-bit samples out (sign in bit 63): ojph_decode_codeblock64
+ * (block_decoder64.cpp:766-1660).  ojph_decode_codeblock32 (block_decoder32.cpp:742-1613) is the same algorithm with
+ * p32 = 30 - missing_msbs where this uses p64 = 62 - missing_msbs = p32 + 32: its samples are these moved down by 32
+ * bits.  `wide` = the 64-bit function's own details:
+ *   * its VLC and MagSgn readers take ONE byte at a time and mask the bit a stuffed byte may not carry
+ *     (rev_read8 :305-327, frwd_read8 :626-640), where the 32-bit function's four-byte readers OR the whole byte in and
+ *     advance by 7 (see fb_put_byte): the same on conforming streams, different on corrupt ones;
+ *   * the U-VLC extension: a decoded u above 32 (before the initial row's bias) is followed by 4 more bits, u += 4 ext
+ *     (:997-1011, :1119-1133);
+ *   * no "32 bits are not enough" checks (:792-826 are commented out there). */
+static int ht_decode_core(const uint8_t* coded, int len1, int len2, int num_passes, int missing_msbs,
+                          int width, int height, int stride, uint64_t* out, int stripe_causal, int wide)
 {
   build_tables();
   if (num_passes > 1 && len2 == 0) num_passes = 1;
   if (num_passes > 3) return 0;
-  if (missing_msbs >= 30) return 0;                         /* block_decoder32.cpp:768-789 */
-  if (missing_msbs == 29 && num_passes > 1) num_passes = 1;
-  int p = 30 - missing_msbs;
+  if (!wide) {
+    if (missing_msbs >= 30) return 0;                       /* block_decoder32.cpp:768-789 */
+    if (missing_msbs == 29 && num_passes > 1) num_passes = 1;
+  } else if (missing_msbs > 60) return 0;                   /* (the reference shifts by a negative count there: nothing to match) */
+  int p = 62 - missing_msbs;
   if (len1 < 2) return 0;
   int lcup = len1;
   int scup = ((int)coded[lcup - 1] << 4) + (coded[lcup - 2] & 0xF);
@@ -627,7 +678,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
   int qstr = QW + 3;
   uint16_t* qinf = (uint16_t*)calloc((size_t)(QH + 1) * qstr, 2);
   uint16_t* quq  = (uint16_t*)calloc((size_t)(QH + 1) * qstr, 2);
-  uint32_t* vrow = (uint32_t*)calloc((size_t)2 * (2 * QW + 8), 4);
+  uint64_t* vrow = (uint64_t*)calloc((size_t)2 * (2 * QW + 8), 8);
   int ok = 1;
 
   /* ---- flat, destuffed streams ---- */
@@ -643,7 +694,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
       unstuff = (b == 0xFF);
     }
   }
-  { /* VLC: backward, LSB-first (:308-405) */
+  if (!wide) { /* VLC: backward, LSB-first (block_decoder32.cpp:308-405) */
     int d = coded[lcup - 2];
     int t = d >> 4;
     fb_put(&fvlc, (uint32_t)t, 4 - ((t & 7) == 7));
@@ -655,8 +706,30 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
       unstuff = b > 0x8F;
     }
     fb_put(&fvlc, 0, 32); fb_put(&fvlc, 0, 32);
+  } else {     /* rev_init8 / rev_read8 (block_decoder64.cpp:305-361): the byte is masked before it is used */
+    int val = coded[lcup - 2] >> 4;
+    int t = (val & 7) == 7;
+    val &= 0xF >> t;
+    fb_put(&fvlc, (uint32_t)val, 4 - t);
+    int unstuff = val > 0x8;
+    for (int i = lcup - 3; i >= lcup - scup; --i) {
+      int b = coded[i];
+      t = (unstuff && (b & 0x7F) == 0x7F) ? 1 : 0;
+      b &= 0xFF >> t;
+      fb_put(&fvlc, (uint32_t)b, 8 - t);
+      unstuff = b > 0x8F;
+    }
+    fb_put(&fvlc, 0, 32); fb_put(&fvlc, 0, 32); fb_put(&fvlc, 0, 32);
   }
-  destuff_forward(&fms, coded, lcup - scup, 0, 0xFF);
+  if (!wide) destuff_forward(&fms, coded, lcup - scup, 0, 0xFF);
+  else {       /* frwd_read8<0xFF> (:626-640) */
+    int unstuff = 0;
+    for (int i = 0; i < lcup - scup; ++i) {
+      int b = coded[i] & (0xFF >> unstuff);
+      fb_put(&fms, (uint32_t)b, 8 - unstuff);
+      unstuff = (b == 0xFF);
+    }
+  }
 
   /* ---- MEL symbol decoder (T.814 decodeMELSym; :170-269 keeps the same state as "runs") ---- */
   long melpos = 0; int mel_k = 0, mel_run = 0, mel_one = 0;
@@ -707,7 +780,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
       }
       /* UVLC */
       int mode = ((t[0] & 0x8) << 3) | ((t[1] & 0x8) << 4);
-      int entry;
+      int entry, bias0 = 0, bias1 = 0;         /* what the encoder took off u before coding it (uvlc_bias, block_common.cpp:255,290) */
       if (qy == 0) {
         if (mode == 0xC0) {
           int sym;
@@ -722,7 +795,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
             }
           }
           if (mel_run > 0) { mel_run--; sym = 0; } else { mel_one = 0; sym = 1; }
-          if (sym) mode += 0x40;
+          if (sym) { mode += 0x40; bias0 = bias1 = 2; }      /* (the one-bit second quad of mode 3 has a bias of 1, but is at most 2) */
         }
         entry = dec_uvlc0[mode + (int)VLC_PEEK(6)];
       } else
@@ -733,8 +806,14 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
       vpos += len; entry >>= 4;
       len = entry & 7; entry >>= 3;
       int kap = qy == 0 ? 1 : 0;   /* initial row stores U_q (kappa = 1), others u_q (:971-974,:1082-1085) */
-      urow[qx] = (uint16_t)(kap + (entry & 7) + (tmp & ~(0xFF << len)));
-      urow[qx + 1] = (uint16_t)(kap + (entry >> 3) + (tmp >> len));
+      int u0 = (entry & 7) + (tmp & ~(0xFF << len));
+      int u1 = (entry >> 3) + (tmp >> len);
+      if (wide) {                  /* the extension of a u above 32 (block_decoder64.cpp:997-1011, :1119-1133) */
+        if (u0 - bias0 > 32) { u0 += (int)VLC_PEEK(4) << 2; vpos += 4; }
+        if (u1 - bias1 > 32) { u1 += (int)VLC_PEEK(4) << 2; vpos += 4; }
+      }
+      urow[qx] = (uint16_t)(kap + u0);
+      urow[qx + 1] = (uint16_t)(kap + u1);
     }
   }
 
@@ -742,37 +821,37 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
   {
     long mpos = 0;
     int mmsbp2 = missing_msbs + 2;
-    uint32_t* vprev = vrow;                 /* v_n of the bottom sample row of the previous quad row */
-    uint32_t* vcur = vrow + 2 * QW + 8;
-    memset(vprev, 0, sizeof(uint32_t) * (size_t)(2 * QW + 8));
+    uint64_t* vprev = vrow;                 /* v_n of the bottom sample row of the previous quad row */
+    uint64_t* vcur = vrow + 2 * QW + 8;
+    memset(vprev, 0, sizeof(uint64_t) * (size_t)(2 * QW + 8));
     for (int qy = 0; qy < QH && ok; ++qy) {
-      memset(vcur, 0, sizeof(uint32_t) * (size_t)(2 * QW + 8));
+      memset(vcur, 0, sizeof(uint64_t) * (size_t)(2 * QW + 8));
       for (int qx = 0; qx < QW; ++qx) {
         int inf = qinf[(size_t)qy * qstr + qx];
         int U_q = quq[(size_t)qy * qstr + qx];
         if (qy > 0) {
           int gamma = inf & 0xF0; gamma &= gamma - 0x10;             /* :1218 */
           /* columns 2qx-1 .. 2qx+2 of the row above (vprev is offset by 1) */
-          uint32_t em = vprev[2 * qx] | vprev[2 * qx + 1] | vprev[2 * qx + 2] | vprev[2 * qx + 3];
-          int kappa = gamma ? 31 - clz32(em | 2) : 1;                /* :1219-1221 */
+          uint64_t em = vprev[2 * qx] | vprev[2 * qx + 1] | vprev[2 * qx + 2] | vprev[2 * qx + 3];
+          int kappa = gamma ? 63 - clz64(em | 2) : 1;                /* :1219-1221 */
           U_q += kappa;
         }
         if (U_q > mmsbp2) { ok = 0; break; }                         /* :1114,:1224 */
         for (int n = 0; n < 4; ++n) {
           int x = 2 * qx + (n >> 1), y = 2 * qy + (n & 1);
-          uint32_t val = 0, v_n = 0;
+          uint64_t val = 0, v_n = 0;
           if (inf & (1 << (4 + n))) {
             int m_n = U_q - ((inf >> (12 + n)) & 1);
             /* beyond the end the stream is all ones */
-            uint32_t ms_val = fb_get(&fms, mpos, 32);
-            if (mpos + 32 > fms.nbits) {
+            uint64_t ms_val = fb_get64(&fms, mpos, 64);
+            if (mpos + 64 > fms.nbits) {
               long valid = fms.nbits - mpos; if (valid < 0) valid = 0;
-              ms_val |= valid >= 32 ? 0u : (0xFFFFFFFFu << valid);
+              ms_val |= valid >= 64 ? 0ull : (~0ull << valid);
             }
             mpos += m_n;
-            val = ms_val << 31;
-            v_n = ms_val & ((1u << m_n) - 1);
-            v_n |= (uint32_t)((inf >> (8 + n)) & 1) << m_n;
+            val = ms_val << 63;
+            v_n = ms_val & ((m_n < 64 ? (1ull << m_n) : 0ull) - 1ull);
+            v_n |= (uint64_t)((inf >> (8 + n)) & 1) << m_n;
             v_n |= 1;
             val |= (v_n + 2) << (p - 1);                             /* :1127-1133 */
           }
@@ -780,7 +859,7 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
           if (n & 1) vcur[x + 1] = v_n;
         }
       }
-      uint32_t* t = vprev; vprev = vcur; vcur = t;
+      uint64_t* t = vprev; vprev = vcur; vcur = t;
     }
   }
 #undef VLC_PEEK
@@ -789,6 +868,24 @@ int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int 
     refine_passes(coded, lcup, len2, num_passes, p, width, height, stride, out, stripe_causal);
   fb_free(&fmel); fb_free(&fvlc); fb_free(&fms);
   free(qinf); free(quq); free(vrow);
+  return ok;
+}
+
+int ojo_ht_decode64(const uint8_t* coded, int len1, int len2, int num_passes, int missing_msbs,
+                    int width, int height, int stride, uint64_t* out, int stripe_causal)
+{
+  return ht_decode_core(coded, len1, len2, num_passes, missing_msbs, width, height, stride, out, stripe_causal, 1);
+}
+
+int ojo_ht_decode(const uint8_t* coded, int len1, int len2, int num_passes, int missing_msbs,
+                  int width, int height, int stride, uint32_t* out, int stripe_causal)
+{
+  uint64_t* wide = (uint64_t*)calloc((size_t)stride * (size_t)(height > 0 ? height : 1), sizeof(uint64_t));
+  const int ok = ht_decode_core(coded, len1, len2, num_passes, missing_msbs, width, height, stride, wide, stripe_causal, 0);
+  /* (what a failed decode leaves in the buffer is part of the behaviour the tests compare) */
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) out[(size_t)y * stride + x] = (uint32_t)(wide[(size_t)y * stride + x] >> 32);
+  free(wide);
   return ok;
 }
 
@@ -1009,6 +1106,155 @@ void ojo_dwt97_inv(float* dst, int dp, int w, int h, int x_even, int y_even,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* DWT, general form: any lifting kernel (ATK), one direction only (DFS), 32- / 64-bit integers or floats */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference runs every wavelet through the same code: a list of lifting steps in SYNTHESIS order (param_atk,
+ * ojph_params.cpp:2870-2896: 5/3 = { (a 1, b 2, e 2), (a -1, b 1, e 1) }, 9/7 = four float steps and K), applied
+ *   analysis : steps N-1 .. 0, the first one applied updates the HIGH-pass samples from their low-pass neighbours, the next
+ *              one the low-pass samples, and so on (gen_rev_horz_ana32 ojph_transform.cpp:336-412, gen_irv_horz_ana :715-783,
+ *              resolution::push_line ojph_resolution.cpp:571-583); reversible x += (b + a (l + r)) >> e, irreversible
+ *              x += a (l + r); then, irreversible only, K on one sub-sequence and 1 / K on the other;
+ *   synthesis: K first, then steps 0 .. N-1, step 0 updating the LOW-pass samples: x -= ... (gen_rev_horz_syn32 :514-590,
+ *              gen_irv_horz_syn :786-852, resolution::pull_line ojph_resolution.cpp:770-783).
+ * A missing neighbour at either end is replaced by the one that exists; a sequence of one sample is passed through when it
+ * sits at an even coordinate and doubled (analysis) / halved (synthesis) when at an odd one.  (a, b, e) with a = +-1 take
+ * special-case branches in the reference (:221-259) that compute the same value as the general formula.  With a DFS marker
+ * segment a level may transform one direction only (resolution::pull_line :725-949: HORZ_TRX / VERT_TRX); the other
+ * direction's samples are all "low".  Samples are worked on interleaved, in place -- same arithmetic as the reference's
+ * split lines.  The horizontal irreversible analysis scales "lp" by 1 / K after its pointers were swapped once per step
+ * (:765-777), i.e. the low-pass samples for an even number of steps and the high-pass ones for an odd number: kept. */
+#define OJO_GEN_LIFT(T, NAME, IS_FLOAT)                                                                                 \
+static void NAME(T* x, long st, int n, int even, const ojo_lift_step* steps, int nsteps, int synthesis)               \
+{                                                                                                                      \
+  if (n <= 1) return;                                                                                                  \
+  for (int k = 0; k < nsteps; ++k) {                                                                                   \
+    const int j = synthesis ? k : nsteps - 1 - k;            /* step index */                                          \
+    const int tgt_high = synthesis ? (k & 1) : !(k & 1);     /* which sub-sequence this step updates */                \
+    const int first = (tgt_high ? (even ? 1 : 0) : (even ? 0 : 1));                                                    \
+    for (int t = first; t < n; t += 2) {                                                                               \
+      int l = t - 1, r = t + 1;                                                                                        \
+      if (l < 0) l = r;                                                                                                \
+      if (r >= n) r = l;                                                                                               \
+      if (IS_FLOAT) {                                                                                                  \
+        const float a = steps[j].A;                                                                                    \
+        const float sum = (float)x[l * st] + (float)x[r * st];                                                         \
+        const float m = a * sum;                                                                                       \
+        x[t * st] = (T)(synthesis ? (float)x[t * st] - m : (float)x[t * st] + m);                                      \
+      } else {                                                                                                         \
+        const int64_t v = ((int64_t)steps[j].b + (int64_t)steps[j].a * ((int64_t)x[l * st] + (int64_t)x[r * st])) >> steps[j].e; \
+        x[t * st] = (T)(synthesis ? (int64_t)x[t * st] - v : (int64_t)x[t * st] + v);                                  \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }                                                                                                                    \
+}
+OJO_GEN_LIFT(int32_t, lift_gen_i32, 0)
+OJO_GEN_LIFT(int64_t, lift_gen_i64, 0)
+OJO_GEN_LIFT(float, lift_gen_f32, 1)
+
+#define OJO_GEN_LEVEL(T, SUF, IS_FLOAT)                                                                                 \
+static void dwt_fwd_gen_##SUF(const T* src, int sp, int w, int h, int x_even, int y_even, int horz, int vert,           \
+                              const ojo_lift_step* steps, int nsteps, float K,                                          \
+                              T* ll, int llp, T* hl, int hlp, T* lh, int lhp, T* hh, int hhp)                           \
+{                                                                                                                      \
+  T* wk = (T*)malloc(sizeof(T) * (size_t)w * (size_t)h);                                                               \
+  for (int y = 0; y < h; ++y) memcpy(wk + (size_t)y * w, src + (size_t)y * sp, sizeof(T) * (size_t)w);                  \
+  const float Kinv = 1.0f / K;                                                                                         \
+  if (vert) {                                                      /* vertical first (ojph_resolution.cpp:571-601) */  \
+    if (h > 1) {                                                                                                       \
+      for (int x = 0; x < w; ++x) lift_gen_##SUF(wk + x, w, h, y_even, steps, nsteps, 0);                               \
+      if (IS_FLOAT) for (int y = 0; y < h; ++y) {                                                                      \
+        const int high = ((y & 1) == 0) != (y_even != 0);                                                              \
+        for (int x = 0; x < w; ++x) wk[(size_t)y * w + x] = (T)((float)wk[(size_t)y * w + x] * (high ? K : Kinv));     \
+      }                                                                                                                \
+    } else if (!y_even) for (int x = 0; x < w; ++x) wk[x] = IS_FLOAT ? (T)((float)wk[x] * 2.0f) : (T)((int64_t)wk[x] * 2); \
+  }                                                                                                                    \
+  if (horz) for (int y = 0; y < h; ++y) {                                                                              \
+    T* row = wk + (size_t)y * w;                                                                                       \
+    if (w > 1) {                                                                                                       \
+      lift_gen_##SUF(row, 1, w, x_even, steps, nsteps, 0);                                                             \
+      if (IS_FLOAT) for (int x = 0; x < w; ++x) {                                                                      \
+        const int high = ((x & 1) == 0) != (x_even != 0);                                                              \
+        const int lp_is_high = nsteps & 1;                        /* the reference's swapped pointers (:765-777) */    \
+        row[x] = (T)((float)row[x] * ((high != lp_is_high) ? K : Kinv));                                               \
+      }                                                                                                                \
+    } else if (!x_even) row[0] = IS_FLOAT ? (T)((float)row[0] * 2.0f) : (T)((int64_t)row[0] * 2);                       \
+  }                                                                                                                    \
+  int ly = 0, hy = 0;                                                                                                  \
+  for (int y = 0; y < h; ++y) {                                                                                        \
+    const int yh = vert ? (((y & 1) == 0) != (y_even != 0)) : 0;                                                       \
+    T* lo_row = yh ? lh + (size_t)hy * lhp : ll + (size_t)ly * llp;                                                    \
+    T* hi_row = yh ? (hh ? hh + (size_t)hy * hhp : NULL) : (hl ? hl + (size_t)ly * hlp : NULL);                        \
+    int lx = 0, hx = 0;                                                                                                \
+    for (int x = 0; x < w; ++x) {                                                                                      \
+      const int xh = horz ? (((x & 1) == 0) != (x_even != 0)) : 0;                                                     \
+      if (xh) hi_row[hx++] = wk[(size_t)y * w + x]; else lo_row[lx++] = wk[(size_t)y * w + x];                         \
+    }                                                                                                                  \
+    if (yh) hy++; else ly++;                                                                                           \
+  }                                                                                                                    \
+  free(wk);                                                                                                            \
+}                                                                                                                      \
+static void dwt_inv_gen_##SUF(T* dst, int dp, int w, int h, int x_even, int y_even, int horz, int vert,                 \
+                              const ojo_lift_step* steps, int nsteps, float K,                                          \
+                              const T* ll, int llp, const T* hl, int hlp, const T* lh, int lhp, const T* hh, int hhp)   \
+{                                                                                                                      \
+  T* wk = (T*)malloc(sizeof(T) * (size_t)w * (size_t)h);                                                               \
+  const float Kinv = 1.0f / K;                                                                                         \
+  int ly = 0, hy = 0;                                                                                                  \
+  for (int y = 0; y < h; ++y) {                                                                                        \
+    const int yh = vert ? (((y & 1) == 0) != (y_even != 0)) : 0;                                                       \
+    const T* lo_row = yh ? lh + (size_t)hy * lhp : ll + (size_t)ly * llp;                                              \
+    const T* hi_row = yh ? (hh ? hh + (size_t)hy * hhp : NULL) : (hl ? hl + (size_t)ly * hlp : NULL);                  \
+    int lx = 0, hx = 0;                                                                                                \
+    for (int x = 0; x < w; ++x) {                                                                                      \
+      const int xh = horz ? (((x & 1) == 0) != (x_even != 0)) : 0;                                                     \
+      wk[(size_t)y * w + x] = xh ? hi_row[hx++] : lo_row[lx++];                                                        \
+    }                                                                                                                  \
+    if (yh) hy++; else ly++;                                                                                           \
+  }                                                                                                                    \
+  if (horz) for (int y = 0; y < h; ++y) {                          /* horizontal first (:740-766) */                   \
+    T* row = wk + (size_t)y * w;                                                                                       \
+    if (w > 1) {                                                                                                       \
+      if (IS_FLOAT) for (int x = 0; x < w; ++x) {                                                                      \
+        const int high = ((x & 1) == 0) != (x_even != 0);                                                              \
+        row[x] = (T)((float)row[x] * (high ? Kinv : K));                                                               \
+      }                                                                                                                \
+      lift_gen_##SUF(row, 1, w, x_even, steps, nsteps, 1);                                                             \
+    } else if (!x_even) row[0] = IS_FLOAT ? (T)((float)row[0] * 0.5f) : (T)((int64_t)row[0] >> 1);                      \
+  }                                                                                                                    \
+  if (vert) {                                                                                                          \
+    if (h > 1) {                                                                                                       \
+      if (IS_FLOAT) for (int y = 0; y < h; ++y) {                                                                      \
+        const int high = ((y & 1) == 0) != (y_even != 0);                                                              \
+        for (int x = 0; x < w; ++x) wk[(size_t)y * w + x] = (T)((float)wk[(size_t)y * w + x] * (high ? Kinv : K));     \
+      }                                                                                                                \
+      for (int x = 0; x < w; ++x) lift_gen_##SUF(wk + x, w, h, y_even, steps, nsteps, 1);                               \
+    } else if (!y_even) for (int x = 0; x < w; ++x) wk[x] = IS_FLOAT ? (T)((float)wk[x] * 0.5f) : (T)((int64_t)wk[x] >> 1); \
+  }                                                                                                                    \
+  for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * dp, wk + (size_t)y * w, sizeof(T) * (size_t)w);                  \
+  free(wk);                                                                                                            \
+}
+OJO_GEN_LEVEL(int32_t, i32, 0)
+OJO_GEN_LEVEL(int64_t, i64, 0)
+OJO_GEN_LEVEL(float, f32, 1)
+
+void ojo_dwt_fwd_gen(const void* src, int sp, int w, int h, int x_even, int y_even, int elem, int horz, int vert,
+                     const ojo_lift_step* steps, int nsteps, float K,
+                     void* ll, int llp, void* hl, int hlp, void* lh, int lhp, void* hh, int hhp)
+{
+  if (elem == 0) dwt_fwd_gen_i32((const int32_t*)src, sp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (int32_t*)ll, llp, (int32_t*)hl, hlp, (int32_t*)lh, lhp, (int32_t*)hh, hhp);
+  else if (elem == 1) dwt_fwd_gen_i64((const int64_t*)src, sp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (int64_t*)ll, llp, (int64_t*)hl, hlp, (int64_t*)lh, lhp, (int64_t*)hh, hhp);
+  else dwt_fwd_gen_f32((const float*)src, sp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (float*)ll, llp, (float*)hl, hlp, (float*)lh, lhp, (float*)hh, hhp);
+}
+void ojo_dwt_inv_gen(void* dst, int dp, int w, int h, int x_even, int y_even, int elem, int horz, int vert,
+                     const ojo_lift_step* steps, int nsteps, float K,
+                     const void* ll, int llp, const void* hl, int hlp, const void* lh, int lhp, const void* hh, int hhp)
+{
+  if (elem == 0) dwt_inv_gen_i32((int32_t*)dst, dp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (const int32_t*)ll, llp, (const int32_t*)hl, hlp, (const int32_t*)lh, lhp, (const int32_t*)hh, hhp);
+  else if (elem == 1) dwt_inv_gen_i64((int64_t*)dst, dp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (const int64_t*)ll, llp, (const int64_t*)hl, hlp, (const int64_t*)lh, lhp, (const int64_t*)hh, hhp);
+  else dwt_inv_gen_f32((float*)dst, dp, w, h, x_even, y_even, horz, vert, steps, nsteps, K, (const float*)ll, llp, (const float*)hl, hlp, (const float*)lh, lhp, (const float*)hh, hhp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* quantise transfer (ojph_codestream_gen.cpp:59-181)                                          */
 /* ------------------------------------------------------------------------------------------ */
 uint32_t ojo_quant_rev(const int32_t* src, uint32_t* dst, int count, int K_max)
@@ -1118,5 +1364,52 @@ void ojo_ict_inv(const float* y, const float* cb, const float* cr, float* r, flo
     float rr = y[i] + g_cr2r * cr[i];
     float bb = y[i] + g_cb2b * cb[i];
     r[i] = rr; g[i] = gg; b[i] = bb;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* 64-bit sample path (precision > 32 bits, ojph_params.cpp:1684-1706): transfers, conversion, RCT */
+/* ------------------------------------------------------------------------------------------ */
+uint64_t ojo_quant_rev64(const int64_t* src, uint64_t* dst, int count, int K_max)   /* gen_rev_tx_to_cb64, ojph_codestream_gen.cpp:81-100 */
+{
+  uint64_t mx = 0; const int shift = 63 - K_max;
+  for (int i = 0; i < count; ++i) {
+    const int64_t v = src[i];
+    const uint64_t val = (uint64_t)(v >= 0 ? v : -v) << shift;
+    dst[i] = (v >= 0 ? 0ull : 0x8000000000000000ull) | val;
+    mx |= val;
+  }
+  return mx;
+}
+void ojo_dequant_rev64(const uint64_t* src, int64_t* dst, int count, int K_max)     /* gen_rev_tx_from_cb64, :140-153 */
+{
+  const int shift = 63 - K_max;
+  for (int i = 0; i < count; ++i) {
+    const int64_t val = (int64_t)((src[i] & 0x7FFFFFFFFFFFFFFFull) >> shift);
+    dst[i] = (src[i] >> 63) ? -val : val;
+  }
+}
+/* gen_rev_convert, 32-bit image samples <-> 64-bit lines (ojph_colour.cpp:250-268); nlt3: gen_rev_convert_nlt_type3 (:288-311) */
+void ojo_rev_convert_to64(const int32_t* src, int64_t* dst, int count, int64_t shift, int nlt3)
+{
+  for (int i = 0; i < count; ++i) { const int64_t v = src[i]; dst[i] = nlt3 ? (v >= 0 ? v : -v - shift) : v + shift; }
+}
+void ojo_rev_convert_from64(const int64_t* src, int32_t* dst, int count, int64_t shift, int nlt3)
+{
+  for (int i = 0; i < count; ++i) { const int64_t v = src[i]; dst[i] = (int32_t)(nlt3 ? (v >= 0 ? v : -v - shift) : v + shift); }
+}
+/* gen_rct_forward / backward with 64-bit Y, Cb, Cr and 32-bit R, G, B (ojph_colour.cpp:467-489, :517-541) */
+void ojo_rct_fwd64(const int32_t* r, const int32_t* g, const int32_t* b, int64_t* y, int64_t* cb, int64_t* cr, int count)
+{
+  for (int i = 0; i < count; ++i) {
+    const int64_t rr = r[i], gg = g[i], bb = b[i];
+    y[i] = (rr + (gg << 1) + bb) >> 2; cb[i] = bb - gg; cr[i] = rr - gg;
+  }
+}
+void ojo_rct_inv64(const int64_t* y, const int64_t* cb, const int64_t* cr, int32_t* r, int32_t* g, int32_t* b, int count)
+{
+  for (int i = 0; i < count; ++i) {
+    const int64_t gg = y[i] - ((cb[i] + cr[i]) >> 2);
+    r[i] = (int32_t)(cr[i] + gg); g[i] = (int32_t)gg; b[i] = (int32_t)(cb[i] + gg);
   }
 }

@@ -21,6 +21,23 @@ def lib():
         L.ojo_ht_decode.restype = C.c_int
         L.ojo_ht_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_int]
+        L.ojo_ht_encode64.restype = C.c_int
+        L.ojo_ht_encode64.argtypes = L.ojo_ht_encode.argtypes
+        L.ojo_ht_decode64.restype = C.c_int
+        L.ojo_ht_decode64.argtypes = L.ojo_ht_decode.argtypes
+        for name in ("ojo_dwt_fwd_gen", "ojo_dwt_inv_gen"):
+            f = getattr(L, name); f.restype = None
+            f.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p, C.c_int] * 4
+        L.ojo_quant_rev64.restype = C.c_uint64
+        L.ojo_quant_rev64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ojo_dequant_rev64.restype = None
+        L.ojo_dequant_rev64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        for name in ("ojo_rev_convert_to64", "ojo_rev_convert_from64"):
+            f = getattr(L, name); f.restype = None
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
+        for name in ("ojo_rct_fwd64", "ojo_rct_inv64"):
+            f = getattr(L, name); f.restype = None
+            f.argtypes = [C.c_void_p] * 6 + [C.c_int]
         for name in ("ojo_dwt53_fwd", "ojo_dwt97_fwd"):
             f = getattr(L, name); f.restype = None
             f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p, C.c_int] * 4
@@ -63,6 +80,72 @@ def ht_decode(coded: bytes, width, height, stride, missing_msbs, len2=0, num_pas
     ok = lib().ojo_ht_decode(data.ctypes.data, len(coded) - len2, len2, num_passes, missing_msbs,
                              width, height, stride, out.ctypes.data, int(stripe_causal))
     return bool(ok), out
+
+
+def ht_encode64(buf, width, height, stride, missing_msbs, variant=0):
+    """uint64 sign-magnitude samples (sign in bit 63): the 64-bit sample path"""
+    buf = np.ascontiguousarray(buf, dtype=np.uint64)
+    out = np.empty(40960, dtype=np.uint8)
+    n = lib().ojo_ht_encode64(buf.ctypes.data, width, height, stride, missing_msbs, out.ctypes.data, out.size, variant)
+    return out[:n].tobytes()
+
+
+def ht_decode64(coded: bytes, width, height, stride, missing_msbs, len2=0, num_passes=1, stripe_causal=False):
+    data = np.frombuffer(coded, dtype=np.uint8)
+    out = np.zeros((height, stride), dtype=np.uint64)
+    ok = lib().ojo_ht_decode64(data.ctypes.data, len(coded) - len2, len2, num_passes, missing_msbs,
+                               width, height, stride, out.ctypes.data, int(stripe_causal))
+    return bool(ok), out
+
+
+class LiftStep(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("e", C.c_int32), ("A", C.c_float)]
+
+
+ELEM = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2}
+REV53 = [(1, 2, 2), (-1, 1, 1)]                                   # param_atk::init_rev53 (ojph_params.cpp:2883-2896), synthesis order
+IRV97 = [0.443506852043971, 0.882911075530934, -0.052980118572961, -1.586134342059924]
+K97 = 1.230174104914001
+
+
+def _steps(steps):
+    arr = (LiftStep * max(1, len(steps)))()
+    for i, st in enumerate(steps):
+        if isinstance(st, (tuple, list)):
+            arr[i].a, arr[i].b, arr[i].e = st
+        else:
+            arr[i].A = float(st)
+    return arr
+
+
+def dwt_fwd_gen(src, steps, K=1.0, horz=True, vert=True, x_even=True, y_even=True):
+    """one level in the general form; src int32 / int64 / float32 2-D; -> (ll, hl, lh, hh), absent bands empty"""
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    h, w = src.shape
+    lw, hw, lh_, hh_ = band_dims(w, h, x_even, y_even)
+    if not horz:
+        lw, hw = w, 0
+    if not vert:
+        lh_, hh_ = h, 0
+    mk = lambda r, c: np.zeros((max(r, 1), max(c, 1)), dt)
+    ll, hl, lh, hh = mk(lh_, lw), mk(lh_, hw), mk(hh_, lw), mk(hh_, hw)
+    lib().ojo_dwt_fwd_gen(src.ctypes.data, w, w, h, int(x_even), int(y_even), ELEM[dt], int(horz), int(vert),
+                          _steps(steps), len(steps), float(K), ll.ctypes.data, ll.shape[1], hl.ctypes.data, hl.shape[1],
+                          lh.ctypes.data, lh.shape[1], hh.ctypes.data, hh.shape[1])
+    return ll[:lh_, :lw], hl[:lh_, :hw], lh[:hh_, :lw], hh[:hh_, :hw]
+
+
+def dwt_inv_gen(ll, hl, lh, hh, w, h, steps, K=1.0, horz=True, vert=True, x_even=True, y_even=True):
+    dt = ll.dtype
+    bands = [np.ascontiguousarray(b, dtype=dt) if b.size else np.zeros((1, 1), dt) for b in (ll, hl, lh, hh)]
+    dst = np.zeros((h, w), dt)
+    args = []
+    for b in bands:
+        args += [b.ctypes.data, b.shape[1]]
+    lib().ojo_dwt_inv_gen(dst.ctypes.data, w, w, h, int(x_even), int(y_even), ELEM[dt], int(horz), int(vert),
+                          _steps(steps), len(steps), float(K), *args)
+    return dst
 
 
 def band_dims(w, h, x_even=True, y_even=True):

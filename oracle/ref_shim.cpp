@@ -298,4 +298,36 @@ int ref_decode_block32(int variant, const uint8_t* coded, uint32_t len1, uint32_
   return ok ? 0 : 1;
 }
 
+// the 64-bit sample path (ojph_block_encoder.cpp:1026, ojph_block_decoder64.cpp:766); generic C++ only in the reference
+long ref_encode_block64(uint64_t* buf, uint32_t missing_msbs, uint32_t width, uint32_t height, uint32_t stride,
+                        uint8_t* out, long out_cap)
+{
+  try {
+    static bool init = false;
+    if (!init) { ojph::local::initialize_block_encoder_tables(); init = true; }
+    ojph::mem_elastic_allocator elastic(1048576);
+    ojph::coded_lists* coded = NULL;
+    ojph::ui32 lengths[2] = { 0, 0 };
+    ojph::local::ojph_encode_codeblock64(buf, missing_msbs, 1, width, height, stride, lengths, &elastic, coded);
+    if ((long)lengths[0] > out_cap) return -(long)lengths[0];
+    memcpy(out, coded->buf, lengths[0]);
+    return (long)lengths[0];
+  } catch (const std::exception&) {
+    return 0;
+  }
+}
+
+int ref_decode_block64(const uint8_t* coded, uint32_t len1, uint32_t len2, uint32_t missing_msbs, uint32_t num_passes,
+                       uint32_t width, uint32_t height, uint32_t stride, uint64_t* out, int stripe_causal)
+{
+  std::vector<uint8_t> padded((size_t)len1 + len2 + 64, 0);
+  memcpy(padded.data() + 16, coded, (size_t)len1 + len2);
+  bool ok;
+  try {
+    ok = ojph::local::ojph_decode_codeblock64(padded.data() + 16, out, missing_msbs, num_passes, len1, len2, width, height,
+                                              stride, stripe_causal != 0);
+  } catch (const std::exception&) { return -1; }
+  return ok ? 0 : 1;
+}
+
 } // extern "C"

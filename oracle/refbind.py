@@ -83,6 +83,12 @@ class Ref:
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_int]
         L.ref_simd_level.restype = C.c_int
+        if hasattr(L, "ref_encode_block64"):              # (a prebuilt library of an earlier round may lack them)
+            L.ref_encode_block64.restype = C.c_long
+            L.ref_encode_block64.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_long]
+            L.ref_decode_block64.restype = C.c_int
+            L.ref_decode_block64.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_void_p, C.c_int]
 
     def simd_level(self):
         return self.lib.ref_simd_level()
@@ -193,4 +199,21 @@ class Ref:
         r = self.lib.ref_decode_block32(variant, data.ctypes.data, len1, len2, missing_msbs,
                                         num_passes, width, height, stride, out.ctypes.data,
                                         int(stripe_causal))
+        return r == 0, out[:height * stride].reshape(height, stride)
+
+    def encode_block64(self, buf, missing_msbs, width, height, stride):
+        """ojph_encode_codeblock64 on uint64 sign-magnitude samples"""
+        buf = np.ascontiguousarray(buf, dtype=np.uint64)
+        out = np.empty(65536 * 4, dtype=np.uint8)
+        n = self.lib.ref_encode_block64(buf.ctypes.data, missing_msbs, width, height, stride, out.ctypes.data, out.size)
+        if n <= 0:
+            raise RuntimeError("reference 64-bit block encode failed (%d)" % n)
+        return out[:n].tobytes()
+
+    def decode_block64(self, coded: bytes, missing_msbs, width, height, stride, len2=0, num_passes=1, stripe_causal=False):
+        data = np.frombuffer(coded, dtype=np.uint8)
+        out = np.zeros((height + 2) * stride, dtype=np.uint64)
+        len1 = len(coded) - len2
+        r = self.lib.ref_decode_block64(data.ctypes.data, len1, len2, missing_msbs, num_passes, width, height, stride,
+                                        out.ctypes.data, int(stripe_causal))
         return r == 0, out[:height * stride].reshape(height, stride)
