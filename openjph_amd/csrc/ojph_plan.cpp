@@ -282,6 +282,86 @@ uint32_t block_scratch_bytes(uint32_t w, uint32_t h, uint32_t K_max)
   return (uint32_t)((total + 63) & ~63ull);
 }
 
+// param_qcd::propose_precision (ojph_params.cpp:1684-1706): the largest K_max of the component's QCD / QCC -- of the three
+// colour components' when the colour transform is employed and this is one of them -- plus a sign bit plus one bit the
+// block coder wants; above 32 the reference takes its 64-bit sample path (ojph_resolution.cpp:209-229, ojph_subband.cpp:
+// 94-110, ojph_codeblock.cpp:57-99).  Only reversible components can take it here: the reference's encoder has no
+// irreversible 64-bit transfer (codeblock_fun::init sets tx_to_cb64 = NULL, ojph_codeblock_fun.cpp:174), and its decoder
+// scales such samples by a step size computed with a 32-bit shift (ojph_subband.cpp:159) -- nothing to be identical to.
+static uint32_t largest_Kmax(const QuantSet& q)                    // param_qcd::get_largest_Kmax (:1751-1775)
+{
+  uint32_t nb = 0;
+  if ((q.sqcd & 0x1F) == 0) for (uint8_t v : q.q8) { const uint32_t t = v >> 3; nb = std::max(nb, t == 0 ? 0u : t - 1u); }
+  else for (uint16_t v : q.q16) nb = std::max<uint32_t>(nb, (uint32_t)(v >> 11) - 1u);
+  return nb + q.guard_bits;
+}
+
+bool derive_precision(Plan& plan)
+{
+  const uint32_t nc = plan.p.num_comps;
+  plan.wide.assign(nc, 0); plan.any_wide = false;
+  for (uint32_t c = 0; c < nc; ++c) {
+    uint32_t precision = 0;
+    if (plan.p.color_transform && c < 3) for (uint32_t i = 0; i < 3; ++i) precision = std::max(precision, largest_Kmax(plan.quant(i)));
+    else precision = largest_Kmax(plan.quant(c));
+    precision += 2;
+    if (!plan.style(c).rev && plan.comps[c].bit_depth > 32) { plan.error = "irreversible coding of samples deeper than 32 bits: not supported"; return false; }   // (ojph_colour.cpp:331 asserts the same)
+    if (precision <= 32) continue;
+    if (!plan.style(c).rev) { plan.error = "an irreversibly transformed component needs more than 32 bits of precision: not supported"; return false; }
+    plan.wide[c] = 1; plan.any_wide = true;
+  }
+  return true;
+}
+
+// Places of the planes in the arena (32-bit elements): per tile-component, resolution by resolution, the raw plane of the
+// resolution (r > 0) and then its bands.  A component on the 64-bit sample path has 64-bit samples in all of them: two
+// elements per sample (pitch stays in samples; such planes start on even elements).  Then the DWT levels, which quote
+// those places.  Called by build_plan, and again by the parser once the codestream's own QCD / QCC are in place.
+void assign_planes(Plan& plan)
+{
+  uint64_t arena = 0;
+  auto alloc = [&](uint32_t w, uint32_t h, uint32_t& pitch, bool wide) {
+    pitch = (std::max<uint32_t>(w, 1) + 63u) & ~63u;
+    uint64_t off = arena;
+    arena += ((uint64_t)pitch * std::max<uint32_t>(h, 1) + 64) * (wide ? 2u : 1u);   // +64: kernels may over-read a row tail
+    arena = (arena + 63) & ~63ull;
+    return off;
+  };
+  plan.levels.clear();
+  for (const Tile& t : plan.tiles)
+    for (uint32_t ci : t.comps) {
+      const TileComp& tc = plan.tcomps[ci];
+      const uint32_t c = tc.comp, L = (uint32_t)tc.res.size() - 1;
+      const bool wide = c < plan.wide.size() && plan.wide[c] != 0;
+      for (uint32_t r = 0; r <= L; ++r) {
+        Resolution& R = plan.ress[tc.res[r]];
+        R.plane_off = 0; R.pitch = 0;
+        if (r > 0) R.plane_off = alloc(R.r.w, R.r.h, R.pitch, wide);
+        for (int b = 0; b < 4; ++b)
+          if (R.band[b] >= 0) { Band& B = plan.bands[(size_t)R.band[b]]; B.plane_off = alloc(B.r.w, B.r.h, B.pitch, wide); }
+      }
+      // DWT levels: res r -> res r-1 (or the LL band when r-1 == 0) + bands of res r
+      for (uint32_t r = L; r > 0; --r) {
+        const Resolution& R = plan.ress[tc.res[r]];
+        const Resolution& C = plan.ress[tc.res[r - 1]];
+        ojphgpu_level_info lv; memset(&lv, 0, sizeof(lv));
+        lv.tile = t.idx; lv.comp = c; lv.res = r;
+        lv.w = R.r.w; lv.h = R.r.h; lv.x_even = (R.r.x0 & 1) == 0; lv.y_even = (R.r.y0 & 1) == 0;
+        lv.src_off = R.plane_off; lv.src_pitch = R.pitch;
+        if (r - 1 == 0) { const Band& B = plan.bands[(size_t)C.band[0]]; lv.ll_off = B.plane_off; lv.ll_pitch = B.pitch; }
+        else { lv.ll_off = C.plane_off; lv.ll_pitch = C.pitch; }
+        const Band& HL = plan.bands[(size_t)R.band[1]];
+        const Band& LH = plan.bands[(size_t)R.band[2]];
+        const Band& HH = plan.bands[(size_t)R.band[3]];
+        lv.hl_off = HL.plane_off; lv.hl_pitch = HL.pitch;
+        lv.lh_off = LH.plane_off; lv.lh_pitch = LH.pitch;
+        lv.hh_off = HH.plane_off; lv.hh_pitch = HH.pitch;
+        plan.levels.push_back(lv);
+      }
+    }
+  plan.arena_elems = arena;
+}
+
 int build_plan(const ojphgpu_params& pin, Plan& plan)
 {
   plan = Plan();
@@ -289,7 +369,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   auto fail = [&](const char* m) { plan.error = m; return OJPHGPU_E_INVALID; };
   if (p.width == 0 || p.height == 0 || p.num_comps == 0) return fail("empty image");
   if (p.num_comps > 16384) return fail("too many components");
-  if (p.bit_depth < 1 || p.bit_depth > 26) return fail("bit depth unsupported (32-bit sample path only)");
+  if (p.bit_depth < 1 || p.bit_depth > 38) return fail("bit depth must be 1..38");            // Ssiz: 7 bits, T.800 allows up to 38
   if (p.num_decomps > 32) return fail("too many decompositions");
   if (p.block_w == 0) p.block_w = 64;
   if (p.block_h == 0) p.block_h = 64;
@@ -325,7 +405,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     plan.frame_elems += (uint64_t)g.w * g.h;
     g.bit_depth = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_depth[c] ? p.comp_depth[c] : p.bit_depth;
     g.is_signed = c < OJPHGPU_MAX_SUBSAMPLED_COMPS && p.comp_sign[c] ? p.comp_sign[c] == 2 : p.is_signed != 0;
-    if (g.bit_depth < 1 || g.bit_depth > 26) return fail("bit depth unsupported (32-bit sample path only)");
+    if (g.bit_depth < 1 || g.bit_depth > 38) return fail("bit depth must be 1..38");
   }
   // nothing beyond what a device could hold is planned: a frame of 2^36 samples is 256 GB of int32
   // coefficients, and block / band indices are 32 bits wide
@@ -440,15 +520,6 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     }
     if (est > (double)(1u << 24)) return fail("too many code-blocks for the host tables (more than 2^24)");
   }
-  uint64_t arena = 0;
-  auto alloc = [&](uint32_t w, uint32_t h, uint32_t& pitch) {
-    pitch = (std::max<uint32_t>(w, 1) + 63u) & ~63u;
-    uint64_t off = arena;
-    arena += (uint64_t)pitch * std::max<uint32_t>(h, 1) + 64;   // +64: kernels may over-read a row tail
-    arena = (arena + 63) & ~63ull;
-    return off;
-  };
-
   for (uint32_t ty = 0; ty < plan.nty; ++ty)
     for (uint32_t tx = 0; tx < plan.ntx; ++tx) {
       Tile t; t.idx = ty * plan.ntx + tx;
@@ -481,7 +552,8 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
           R.log_ppw = lpw; R.log_pph = lph;
           for (int i = 0; i < 4; ++i) R.band[i] = -1;
           R.plane_off = 0; R.pitch = 0;
-          if (r > 0) R.plane_off = alloc(R.r.w, R.r.h, R.pitch);   // raw plane; res 0 lives in its LL band
+          // (the raw plane of a resolution r > 0 -- res 0 lives in its LL band -- and the band planes get their place in
+          // the arena from assign_planes, once the sample width of the component is known)
           uint32_t trx0 = R.r.x0, try0 = R.r.y0, trx1 = R.r.x0 + R.r.w, try1 = R.r.y0 + R.r.h;
           uint32_t off = r > 0 ? 1 : 0;
           for (uint32_t b = (r ? 1 : 0); b < (r ? 4u : 1u); ++b) {
@@ -501,7 +573,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
             B.xcb = std::min(lbw, lpw - off); B.ycb = std::min(lbh, lph - off);
             B.empty = (B.r.w == 0 || B.r.h == 0);
             B.nbx = B.nby = 0; B.first_block = (uint32_t)plan.blocks.size();
-            B.plane_off = alloc(B.r.w, B.r.h, B.pitch);
+            B.plane_off = 0; B.pitch = 0;
             if (!B.empty) {
               uint32_t x1 = B.r.x0 + B.r.w, y1 = B.r.y0 + B.r.h;
               B.nbx = ((x1 + (1u << B.xcb) - 1) >> B.xcb) - (B.r.x0 >> B.xcb);
@@ -571,30 +643,13 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
           tc.res[r] = (uint32_t)plan.ress.size();
           plan.ress.push_back(R);
         }
-        // DWT levels: res r -> res r-1 (or the LL band when r-1 == 0) + bands of res r
-        for (uint32_t r = L; r > 0; --r) {
-          const Resolution& R = plan.ress[tc.res[r]];
-          const Resolution& C = plan.ress[tc.res[r - 1]];
-          ojphgpu_level_info lv; memset(&lv, 0, sizeof(lv));
-          lv.tile = t.idx; lv.comp = c; lv.res = r;
-          lv.w = R.r.w; lv.h = R.r.h; lv.x_even = (R.r.x0 & 1) == 0; lv.y_even = (R.r.y0 & 1) == 0;
-          lv.src_off = R.plane_off; lv.src_pitch = R.pitch;
-          if (r - 1 == 0) { const Band& B = plan.bands[(size_t)C.band[0]]; lv.ll_off = B.plane_off; lv.ll_pitch = B.pitch; }
-          else { lv.ll_off = C.plane_off; lv.ll_pitch = C.pitch; }
-          const Band& HL = plan.bands[(size_t)R.band[1]];
-          const Band& LH = plan.bands[(size_t)R.band[2]];
-          const Band& HH = plan.bands[(size_t)R.band[3]];
-          lv.hl_off = HL.plane_off; lv.hl_pitch = HL.pitch;
-          lv.lh_off = LH.plane_off; lv.lh_pitch = LH.pitch;
-          lv.hh_off = HH.plane_off; lv.hh_pitch = HH.pitch;
-          plan.levels.push_back(lv);
-        }
         t.comps.push_back((uint32_t)plan.tcomps.size());
         plan.tcomps.push_back(tc);
       }
       plan.tiles.push_back(t);
     }
-  plan.arena_elems = arena;
+  if (!derive_precision(plan)) return OJPHGPU_E_INVALID;
+  assign_planes(plan);
 
   // packet (precinct) order per tile (ojph_tile.cpp:604-772)
   for (Tile& t : plan.tiles) {
@@ -797,6 +852,7 @@ extern "C" int ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, 
   out[0] = st.L; out[1] = st.rev ? 1 : 0; out[2] = st.lbw; out[3] = st.lbh; out[4] = st.rank ? 1 : 0;
   out[5] = plan->plan.recon_decomps(comp);
   out[6] = plan->plan.nlt3[comp];
+  out[7] = comp < plan->plan.wide.size() ? plan->plan.wide[comp] : 0;      // the component takes the 64-bit sample path
   return OJPHGPU_OK;
 }
 

@@ -145,6 +145,9 @@ struct Plan {
   std::vector<ojphgpu_level_info> levels;   // DWT levels, highest resolution first per tile-comp
   std::vector<CodedBlock> coded;            // only after parse
   uint64_t arena_elems;
+  // components on the reference's 64-bit sample path (more than 32 bits of precision, param_qcd::propose_precision
+  // ojph_params.cpp:1684-1706): int64 planes, the 64-bit block coder
+  std::vector<uint8_t> wide; bool any_wide = false;
   uint32_t max_block_bytes;
   std::string error;
 };
@@ -157,6 +160,8 @@ bool derive_quant(Plan& plan);
 // param_nlt::check_validity / get_nonlinear_transform (ojph_params.cpp:2087-2208): the NLT segments to
 // write and the components the type 3 non-linearity applies to; parsed = the plan comes from a codestream
 bool derive_nlt(Plan& plan, bool parsed);
+bool derive_precision(Plan& plan);     // which components take the 64-bit sample path; false + plan.error: cannot be coded here
+void assign_planes(Plan& plan);        // arena places of the resolution / band planes, the DWT levels
 uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);
 float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band);   // get_irrev_delta (:1650)
 // worst-case coded size of a block of w*h samples with K_max magnitude bits

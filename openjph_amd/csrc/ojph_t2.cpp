@@ -924,13 +924,17 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
     // wraps below zero, and more than 31 magnitude bits is the reference's 64-bit sample path
     // (ojph_codeblock.cpp:74-99), which this library does not have -- neither may reach 31 - K_max
     if ((int32_t)B.K_max < 0) return OJPHGPU_E_CODESTREAM;
-    if (B.K_max > 31) return OJPHGPU_E_INVALID;
+    if (B.K_max > 61) return OJPHGPU_E_INVALID;                 // (the 64-bit block coder's own limit)
+    if (!P.style(B.comp).rev && B.K_max > 31) return OJPHGPU_E_INVALID;   // irreversible: the 32-bit path only (derive_precision)
     if (!P.style(B.comp).rev) {
       float dlt = band_delta(P, B.comp, B.res, B.band);
       dlt /= (float)(1u << (31 - B.K_max));
       B.delta = dlt; B.delta_inv = 1.0f / dlt;
     }
   }
+  // which components need the 64-bit sample path is a property of THESE marker segments; the planes are placed again
+  if (!derive_precision(P)) return OJPHGPU_E_INVALID;
+  assign_planes(P);
   P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
   std::vector<size_t> next_pkt(P.tiles.size(), 0);
   std::vector<uint32_t> next_part(P.tiles.size(), 0);

@@ -162,11 +162,12 @@ class Plan:
     def comp_style(self, comp):
         """coding style of component `comp` (its COC, else the COD): dict(num_decomps, reversible,
         log_block=(w, h), has_coc, recon_decomps = levels left after restrict_resolution, nlt3 = the type 3
-        non-linearity applies)"""
+        non-linearity applies, wide = the component takes the 64-bit sample path: int64 planes of two arena elements per
+        sample)"""
         out = (C.c_uint32 * 8)()
         check(self._lib.ojphgpu_plan_comp_style(self.handle, comp, out))
         return dict(num_decomps=int(out[0]), reversible=bool(out[1]), log_block=(int(out[2]), int(out[3])),
-                    has_coc=bool(out[4]), recon_decomps=int(out[5]), nlt3=bool(out[6]))
+                    has_coc=bool(out[4]), recon_decomps=int(out[5]), nlt3=bool(out[6]), wide=bool(out[7]))
 
     @property
     def frame_elems(self):

@@ -11,8 +11,19 @@ from oracle import oraclebind as ob
 
 
 def _view(arena, off, pitch, w, h, dtype):
+    """a plane of the arena (offsets in 32-bit elements, pitch in samples); int64: the 64-bit sample path"""
+    size = np.dtype(dtype).itemsize
     a = arena.view(dtype)
-    return np.lib.stride_tricks.as_strided(a[off:], shape=(h, w), strides=(pitch * 4, 4))
+    return np.lib.stride_tricks.as_strided(a[off * 4 // size:], shape=(h, w), strides=(pitch * size, size))
+
+
+def _wrap32(a):
+    """two's-complement wrap to 32 bits, as the reference's si32 arithmetic does"""
+    return a.astype(np.int64).astype(np.uint32).astype(np.int32) if a.dtype != np.int32 else a
+
+
+def _plane_dtype(rev, wide):
+    return (np.int64 if wide else np.int32) if rev else np.float32
 
 
 def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
@@ -23,6 +34,7 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
     comps = [plan.comp_info(c) for c in range(p.num_comps)]
     revs = [plan.comp_style(c)["reversible"] for c in range(p.num_comps)]      # per component (COC)
     nlt3 = [plan.comp_style(c)["nlt3"] for c in range(p.num_comps)]
+    wides = [plan.comp_style(c)["wide"] for c in range(p.num_comps)]
     arena = np.zeros(plan.arena_elems, np.uint32)
     lib = ob.lib()
     t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
@@ -33,33 +45,46 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]           # position inside the component's own plane
             src = np.ascontiguousarray(image[c][y0:y0 + h, x0:x0 + w], dtype=np.int32)
             bd, sg = plan.comp_format(c)
-            if nlt3[c]:                                          # gen_rev_convert_nlt_type3 (ojph_colour.cpp:273-311), irv :406-412
-                src = np.where(src >= 0, src, -src - ((1 << (bd - 1)) + 1)).astype(np.int32)
             if revs[c]:
+                # gen_rev_convert / _nlt_type3 (ojph_colour.cpp:238-311).  A component on the 64-bit sample path gets 64-bit
+                # lines -- unless it goes through the colour transform, whose input lines are always 32 bits wide
+                # (ojph_tile.cpp:312-322) and which widens itself (gen_rct_forward :467-489)
                 shift = 0 if sg else -(1 << (bd - 1))
-                dst = src + shift
+                s64 = src.astype(np.int64)
+                if nlt3[c]:
+                    dst = np.where(s64 >= 0, s64, -s64 - ((1 << (bd - 1)) + 1))
+                else:
+                    dst = s64 + shift
+                if not wides[c] or (p.color_transform and c < 3):
+                    dst = dst.astype(np.uint64).astype(np.uint32).astype(np.int32)      # 32-bit arithmetic wraps
             else:
+                if nlt3[c]:                                      # irv :406-412
+                    src = np.where(src >= 0, src, -src - ((1 << (bd - 1)) + 1)).astype(np.int32)
                 dst = np.empty(src.shape, np.float32)
                 lib.ojo_irv_to_float(src.ctypes.data, dst.ctypes.data, src.size, bd, int(sg))
             planes.append((off, pitch, w, h, dst))
         if p.color_transform:
             r, g, b = [np.ascontiguousarray(pl[4]) for pl in planes[:3]]
-            y = np.empty_like(r); cb = np.empty_like(r); cr = np.empty_like(r)
-            f = lib.ojo_rct_fwd if revs[0] else lib.ojo_ict_fwd
+            odt = np.int64 if (revs[0] and wides[0]) else r.dtype
+            y = np.empty(r.shape, odt); cb = np.empty(r.shape, odt); cr = np.empty(r.shape, odt)
+            f = (lib.ojo_rct_fwd64 if wides[0] else lib.ojo_rct_fwd) if revs[0] else lib.ojo_ict_fwd
             f(r.ctypes.data, g.ctypes.data, b.ctypes.data, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.size)
             for i, v in enumerate((y, cb, cr)):
                 planes[i] = planes[i][:4] + (v,)
         for c, (off, pitch, w, h, v) in enumerate(planes):
-            _view(arena, off, pitch, w, h, np.int32 if revs[c] else np.float32)[:] = v
+            _view(arena, off, pitch, w, h, _plane_dtype(revs[c], wides[c]))[:] = v
     for lv in plan.levels:
         w, h = int(lv["w"]), int(lv["h"])
         if w == 0 or h == 0 or not (t_first <= int(lv["tile"]) < t_first + t_count):
             continue
         rev = revs[int(lv["comp"])]
-        dt = np.int32 if rev else np.float32
+        dt = _plane_dtype(rev, wides[int(lv["comp"])])
         src = np.ascontiguousarray(_view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt))
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
-        ll, hl, lh, hh = (ob.dwt53_fwd if rev else ob.dwt97_fwd)(src, xe, ye)
+        if dt == np.int64:                                       # gen_rev_vert_step64 / horz_ana64 (ojph_transform.cpp:261,415)
+            ll, hl, lh, hh = ob.dwt_fwd_gen(src, ob.REV53, x_even=xe, y_even=ye)
+        else:
+            ll, hl, lh, hh = (ob.dwt53_fwd if rev else ob.dwt97_fwd)(src, xe, ye)
         for name, b in (("ll", ll), ("hl", hl), ("lh", lh), ("hh", hh)):
             if b.size:
                 _view(arena, int(lv[name + "_off"]), int(lv[name + "_pitch"]), b.shape[1], b.shape[0], dt)[:] = b
@@ -67,18 +92,29 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
 
 
 def quantise_block(plan, arena, k):
-    """Returns (sign-magnitude uint32 block [h, stride], stride) for block index k."""
+    """Returns (sign-magnitude block [h, stride] -- uint32, or uint64 on the 64-bit sample path --, OR of the magnitudes)
+    for block index k."""
     blk = plan.blocks[k]
     band = plan.bands[int(blk["band"])]
     w, h = int(blk["w"]), int(blk["h"])
-    off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
+    off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"]) * (2 if _is_wide(plan, band) else 1)
     rev = plan.comp_style(int(band["comp"]))["reversible"]
+    if _is_wide(plan, band):
+        raw = np.ascontiguousarray(_view(arena, int(band["plane_off"]), int(band["pitch"]), int(band["w"]), int(band["h"]), np.int64)
+                                   [int(blk["y0"]):int(blk["y0"]) + h, int(blk["x0"]):int(blk["x0"]) + w])
+        q = np.empty(raw.shape, np.uint64)
+        mx = ob.lib().ojo_quant_rev64(raw.ctypes.data, q.ctypes.data, raw.size, int(band["K_max"]))
+        return q, int(mx)
     raw = np.ascontiguousarray(_view(arena, off, int(band["pitch"]), w, h, np.int32 if rev else np.float32))
     if rev:
         q, mx = ob.quant_rev(raw, int(band["K_max"]))
     else:
         q, mx = ob.quant_irv(raw, float(band["delta_inv"]))
     return q, mx
+
+
+def _is_wide(plan, band):
+    return plan.comp_style(int(band["comp"]))["wide"]
 
 
 def encode_blocks(plan: Plan, arena, tiles=None):
@@ -89,13 +125,15 @@ def encode_blocks(plan: Plan, arena, tiles=None):
     t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
     for k in range(plan.num_blocks):
         blk = plan.blocks[k]
-        if not (t_first <= int(plan.bands[int(blk["band"])]["tile"]) < t_first + t_count):
+        band = plan.bands[int(blk["band"])]
+        if not (t_first <= int(band["tile"]) < t_first + t_count):
             continue
         K = int(blk["K_max"])
         q, mx = quantise_block(plan, arena, k)
-        if mx >= (1 << (31 - K)):                       # ojph_codeblock.cpp:146-158
+        wide = q.dtype == np.uint64
+        if mx >= (1 << ((63 if wide else 31) - K)):     # ojph_codeblock.cpp:146-175
             w, h = int(blk["w"]), int(blk["h"])
-            b = ob.ht_encode(q, w, h, w, K - 1)
+            b = (ob.ht_encode64 if wide else ob.ht_encode)(q, w, h, w, K - 1)
             assert len(b) > 0
             coded[k] = (pos, len(b), 0, K - 1, 1)
             chunks.append(b); pos += len(b)
@@ -169,15 +207,22 @@ def decode_blocks(plan: Plan, cs: bytes, resilient=False):
         rev = styles[int(band["comp"])]["reversible"]
         w, h = int(blk["w"]), int(blk["h"])
         o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
-        ok, sm = ob.ht_decode(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
-                              len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]),
-                              stripe_causal=bool(plan.params.reserved[0] & 1))
+        wide = styles[int(band["comp"])]["wide"]
+        ok, sm = (ob.ht_decode64 if wide else ob.ht_decode)(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
+                                                          len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]),
+                                                          stripe_causal=bool(plan.params.reserved[0] & 1))
         if not ok:
             if resilient:
                 continue
             raise RuntimeError("oracle failed to decode block %d" % k)
         off = int(band["plane_off"]) + int(blk["y0"]) * int(band["pitch"]) + int(blk["x0"])
-        if rev:
+        if wide:                                                 # gen_rev_tx_from_cb64 (ojph_codestream_gen.cpp:140-153)
+            sm = np.ascontiguousarray(sm)
+            dq = np.empty(sm.shape, np.int64)
+            ob.lib().ojo_dequant_rev64(sm.ctypes.data, dq.ctypes.data, sm.size, int(band["K_max"]))
+            _view(arena, int(band["plane_off"]), int(band["pitch"]), int(band["w"]), int(band["h"]), np.int64)[
+                int(blk["y0"]):int(blk["y0"]) + h, int(blk["x0"]):int(blk["x0"]) + w] = dq
+        elif rev:
             _view(arena, off, int(band["pitch"]), w, h, np.int32)[:] = ob.dequant_rev(sm, int(band["K_max"]))
         else:
             _view(arena, off, int(band["pitch"]), w, h, np.float32)[:] = ob.dequant_irv(sm, float(band["delta"]))
@@ -195,14 +240,17 @@ def inverse_stages(plan: Plan, arena):
         if w == 0 or h == 0 or int(lv["res"]) > styles[int(lv["comp"])]["recon_decomps"]:   # the resolution that is reconstructed
             continue
         rev = revs[int(lv["comp"])]
-        dt = np.int32 if rev else np.float32
+        dt = _plane_dtype(rev, styles[int(lv["comp"])]["wide"])
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
         lw, hw, lh_, hh_ = ob.band_dims(w, h, xe, ye)
         ll = _view(arena, int(lv["ll_off"]), int(lv["ll_pitch"]), lw, lh_, dt)
         hl = _view(arena, int(lv["hl_off"]), int(lv["hl_pitch"]), hw, lh_, dt)
         lh = _view(arena, int(lv["lh_off"]), int(lv["lh_pitch"]), lw, hh_, dt)
         hh = _view(arena, int(lv["hh_off"]), int(lv["hh_pitch"]), hw, hh_, dt)
-        dst = (ob.dwt53_inv if rev else ob.dwt97_inv)(ll, hl, lh, hh, w, h, xe, ye)
+        if dt == np.int64:
+            dst = ob.dwt_inv_gen(ll, hl, lh, hh, w, h, ob.REV53, x_even=xe, y_even=ye)
+        else:
+            dst = (ob.dwt53_inv if rev else ob.dwt97_inv)(ll, hl, lh, hh, w, h, xe, ye)
         _view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt)[:] = dst
     comps = [plan.comp_info(c) for c in range(p.num_comps)]
     image = [np.zeros((ci["h"], ci["w"]), np.int32) for ci in comps]
@@ -210,11 +258,12 @@ def inverse_stages(plan: Plan, arena):
         planes = []
         for c in range(p.num_comps):
             off, pitch, (x0, y0, w, h) = plan.comp_plane(t, c)
-            planes.append(np.ascontiguousarray(_view(arena, off, pitch, w, h, np.int32 if revs[c] else np.float32)))
+            planes.append(np.ascontiguousarray(_view(arena, off, pitch, w, h, _plane_dtype(revs[c], styles[c]["wide"]))))
         if p.color_transform:
             y, cb, cr = planes[:3]
-            r = np.empty_like(y); g = np.empty_like(y); b = np.empty_like(y)
-            f = lib.ojo_rct_inv if revs[0] else lib.ojo_ict_inv
+            odt = np.int32 if revs[0] else np.float32            # the colour transform's output lines are 32 bits wide
+            r = np.empty(y.shape, odt); g = np.empty(y.shape, odt); b = np.empty(y.shape, odt)
+            f = (lib.ojo_rct_inv64 if styles[0]["wide"] else lib.ojo_rct_inv) if revs[0] else lib.ojo_ict_inv
             f(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, r.ctypes.data, g.ctypes.data, b.ctypes.data, y.size)
             planes[:3] = [r, g, b]
         for c in range(p.num_comps):
@@ -222,12 +271,17 @@ def inverse_stages(plan: Plan, arena):
             v = planes[c]
             bd, sg = plan.comp_format(c)
             if revs[c]:
-                out = v + (0 if sg else (1 << (bd - 1)))
+                v64 = v.astype(np.int64)                         # gen_rev_convert / _nlt_type3 on the way out (ojph_tile.cpp:439-465)
+                if styles[c]["nlt3"]:
+                    out = np.where(v64 >= 0, v64, -v64 - ((1 << (bd - 1)) + 1))
+                else:
+                    out = v64 + (0 if sg else (1 << (bd - 1)))
+                out = out.astype(np.uint64).astype(np.uint32).astype(np.int32)          # (si32) / 32-bit arithmetic
             else:
                 out = np.empty(v.shape, np.int32)
                 lib.ojo_irv_to_int(v.ctypes.data, out.ctypes.data, v.size, bd, int(sg))
-            if styles[c]["nlt3"]:                               # the same mapping on the way out (ojph_tile.cpp:446-448)
-                out = np.where(out >= 0, out, -out - ((1 << (bd - 1)) + 1)).astype(np.int32)
+                if styles[c]["nlt3"]:                            # the same mapping on the way out (ojph_tile.cpp:446-448)
+                    out = np.where(out >= 0, out, -out - ((1 << (bd - 1)) + 1)).astype(np.int32)
             x0 -= comps[c]["x0"]; y0 -= comps[c]["y0"]
             image[c][y0:y0 + h, x0:x0 + w] = out
     return np.stack(image) if len(plan.frame_shape) == 3 else image
