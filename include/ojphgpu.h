@@ -232,6 +232,28 @@ int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_
 int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n,
                         uint32_t max_w, uint32_t max_h, void* d_base);
 
+/* The transform in its GENERAL form (kernels_lift.hip): any lifting kernel an ATK marker segment can describe
+ * (param_atk, ojph_params.cpp:2654-2896), levels that transform one direction only (DFS marker segment:
+ * resolution::pull_line's HORZ_TRX / VERT_TRX, ojph_resolution.cpp:290-300, :725-949), and 64-bit integer samples
+ * (gen_rev_vert_step64 / gen_rev_horz_ana64 / _syn64, ojph_transform.cpp:261,415,593 -- the reference's sample path
+ * for more than 32 bits of precision).  Steps are listed in synthesis order; a reversible step is
+ * x -+= (b + a (l + r)) >> e, an irreversible one x -+= A (l + r) with K scaling around the steps.
+ * elem: 0 = int32, 1 = int64 planes (an element offset of a descriptor still counts 32-bit elements, a pitch counts
+ * samples), 2 = float.  horz / vert = 0: the level leaves that direction alone -- all its samples are "low" there, only
+ * ll and hl (vert = 0) or ll and lh (horz = 0) are read / written.  The planes the descriptors name as src are
+ * transformed IN PLACE before they are split into the bands (forward) / after they are joined (inverse). */
+#define OJPHGPU_MAX_LIFT_STEPS 16
+typedef struct ojphgpu_lift_step { int32_t a, b, e; float A; } ojphgpu_lift_step;
+typedef struct ojphgpu_lift {
+  uint32_t num_steps, elem, horz, vert;
+  float    K;
+  ojphgpu_lift_step steps[OJPHGPU_MAX_LIFT_STEPS];
+} ojphgpu_lift;
+int ojphgpu_dwt_forward_general(void* stream, const ojphgpu_lift* kernel, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                                uint32_t max_w, uint32_t max_h, void* d_base);
+int ojphgpu_dwt_inverse_general(void* stream, const ojphgpu_lift* kernel, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                                uint32_t max_w, uint32_t max_h, void* d_base);
+
 /* The same transforms with the sample conversion of the adjacent stage fused in (no colour
  * transform): the first analysis level reads the int32 image planes directly -- level shift
  * (gen_rev_convert, ojph_colour.cpp:238) or int -> float (gen_irv_convert_to_float, :388) applied
@@ -269,7 +291,8 @@ typedef struct ojphgpu_cb_desc {     /* one code-block */
   uint32_t pitch;                    /* elements */
   uint16_t w, h;
   uint8_t  K_max, reversible, missing_msbs, num_passes;   /* last two: decode only; reversible bit 1
-                                        (decode): vertically causal code-block style */
+                                        (decode): vertically causal code-block style; bit 2: the block is on the
+                                        64-bit sample path (int64 samples at coef_off, the 64-bit block coder) */
   float    delta;                    /* irreversible: encode uses 1/delta, decode uses delta */
   uint32_t len1, len2;               /* decode: pass lengths */
   uint64_t data_off;                 /* decode: byte offset of the coded bytes in `d_data`;
@@ -342,7 +365,10 @@ typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint32_t fmt;                      /* bit depth | signed << 8 of the component; 0 = from params;
                                         | 0x200 when bit 10 says which conversion the component takes
                                         (1 = reversible level shift, 0 = to float): components with a COC;
-                                        | 0x800: NLT type 3 (negative v <-> -v - 2^(B-1) - 1, ojph_colour.cpp:273-311) */
+                                        | 0x800: NLT type 3 (negative v <-> -v - 2^(B-1) - 1, ojph_colour.cpp:273-311);
+                                        | 0x1000: the component is on the 64-bit sample path, its plane holds int64
+                                        samples (gen_rev_convert 32 <-> 64 bits, gen_rct_* with 64-bit Y Cb Cr,
+                                        ojph_colour.cpp:250-268, :467-489, :517-541) */
   uint32_t reserved;
 } ojphgpu_convert_desc;
 

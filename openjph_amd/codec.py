@@ -291,6 +291,34 @@ def dwt(direction, reversible, descs: np.ndarray, arena, max_w, max_h):
     torch.cuda.synchronize(dev)
 
 
+class _LiftStep(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("e", C.c_int32), ("A", C.c_float)]
+
+
+class _Lift(C.Structure):
+    _fields_ = [("num_steps", C.c_uint32), ("elem", C.c_uint32), ("horz", C.c_uint32), ("vert", C.c_uint32), ("K", C.c_float),
+                ("steps", _LiftStep * 16)]
+
+
+def dwt_general(direction, steps, elem, descs: np.ndarray, arena, max_w, max_h, K=1.0, horz=True, vert=True):
+    """ojphgpu_dwt_forward_general / _inverse_general: steps in synthesis order -- (a, b, e) tuples for a reversible
+    kernel, floats for an irreversible one; elem 0 = int32, 1 = int64, 2 = float planes in `arena`."""
+    torch = _torch()
+    dev = arena.device.index
+    d = to_device(descs, dev)
+    k = _Lift()
+    k.num_steps, k.elem, k.horz, k.vert, k.K = len(steps), int(elem), int(bool(horz)), int(bool(vert)), float(K)
+    for i, st in enumerate(steps):
+        if isinstance(st, (tuple, list)):
+            k.steps[i].a, k.steps[i].b, k.steps[i].e = st
+        else:
+            k.steps[i].A = float(st)
+    f = capi.lib().ojphgpu_dwt_forward_general if direction == "forward" else capi.lib().ojphgpu_dwt_inverse_general
+    check(f(_stream_ptr(torch, dev), C.byref(k), C.c_void_p(d.data_ptr()), len(descs), max_w, max_h, C.c_void_p(arena.data_ptr())),
+          "dwt_general_" + direction)
+    torch.cuda.synchronize(dev)
+
+
 def ht_encode(descs: np.ndarray, coef, scratch_bytes, out_cap):
     """Returns (results array, out bytes tensor (host numpy), status)."""
     torch = _torch()

@@ -18,6 +18,7 @@ namespace {
 struct ConvParams {
   uint32_t img_w, img_h, num_comps, bit_depth, is_signed, reversible, color;
   uint32_t nlt3;       // type 3 non-linearity of a signed component (gen_rev_convert_nlt_type3, ojph_colour.cpp:273-311)
+  uint32_t wide;       // the component is on the 64-bit sample path: its plane holds int64 samples (two arena elements each)
 };
 
 constexpr float ALPHA_RF = 0.299f, ALPHA_GF = 0.587f, ALPHA_BF = 0.114f;
@@ -49,7 +50,22 @@ __device__ __forceinline__ ConvParams with_fmt(ConvParams p, const ojphgpu_conve
   if (d.fmt) { p.bit_depth = d.fmt & 0xFFu; p.is_signed = (d.fmt >> 8) & 1u; }
   if (d.fmt & 0x200u) p.reversible = (d.fmt >> 10) & 1u;     // the component's own wavelet (COC)
   p.nlt3 = (d.fmt >> 11) & 1u;
+  p.wide = (d.fmt >> 12) & 1u;
   return p;
+}
+
+// 64-bit sample path (reversible only).  gen_rev_convert / gen_rev_convert_nlt_type3 with a 32-bit source and a 64-bit
+// destination line, and back (ojph_colour.cpp:250-268, :288-311): the level shift in 64-bit arithmetic, the way back
+// truncated to 32 bits.  Through the colour transform the reference's lines stay 32 bits wide on the image side
+// (ojph_tile.cpp:312-322: the level shift wraps like any si32 sum) and gen_rct_forward / _backward widen / narrow
+// themselves (:467-489, :517-541).
+__device__ __forceinline__ long long* plane64(uint32_t* arena, const ojphgpu_convert_desc& d) { return reinterpret_cast<long long*>(arena + d.plane_off); }
+__device__ __forceinline__ const long long* plane64(const uint32_t* arena, const ojphgpu_convert_desc& d) { return reinterpret_cast<const long long*>(arena + d.plane_off); }
+__device__ __forceinline__ long long half64(const ConvParams& p) { return 1ll << (p.bit_depth - 1); }
+__device__ __forceinline__ int level_shift32(const ConvParams& p) { return p.is_signed ? 0 : (int)(unsigned)(1ull << (p.bit_depth - 1)); }   // (wraps above 32 bits, like the (si32) cast)
+__device__ __forceinline__ int nlt3_map32(int v, const ConvParams& p)
+{
+  return (p.nlt3 && v < 0) ? (int)(0u - (unsigned)v - (unsigned)(half64(p) + 1)) : v;
 }
 
 // type 3 non-linearity: negative values v <-> -v - (2^(B-1) + 1); its own inverse, applied to the integer
@@ -80,7 +96,13 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
     p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
     int r = nlt3_map(sample_in<S>(image[at(d0)], p), p), g = nlt3_map(sample_in<S>(image[at(d1)], p), p), b = nlt3_map(sample_in<S>(image[at(d2)], p), p);
-    if (p.reversible) {
+    if (p.reversible && p.wide) {
+      const unsigned shift = 0u - (unsigned)level_shift32(p);
+      const long long rr = (int)((unsigned)r + shift), gg = (int)((unsigned)g + shift), bb = (int)((unsigned)b + shift);
+      plane64(arena, d0)[(size_t)y * d0.pitch + x] = (rr + (gg << 1) + bb) >> 2;
+      plane64(arena, d1)[(size_t)y * d1.pitch + x] = bb - gg;
+      plane64(arena, d2)[(size_t)y * d2.pitch + x] = rr - gg;
+    } else if (p.reversible) {
       const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
       r += shift; g += shift; b += shift;
       int yy = (r + (g << 1) + b) >> 2, cb = b - g, cr = r - g;
@@ -101,9 +123,14 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;           // sub-sampled components are smaller
     p = with_fmt(pc, d);
+    if (p.reversible && p.wide) {
+      const long long v = sample_in<S>(image[at(d)], p);
+      plane64(arena, d)[(size_t)y * d.pitch + x] = (p.nlt3 && p.is_signed) ? (v >= 0 ? v : -v - (half64(p) + 1)) : v - (p.is_signed ? 0 : half64(p));
+      continue;
+    }
     int v = nlt3_map(sample_in<S>(image[at(d)], p), p);
     uint32_t o;
-    if (p.reversible) o = (uint32_t)(v + (p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1))));
+    if (p.reversible) o = (uint32_t)v - (uint32_t)level_shift32(p);
     else o = __float_as_uint(to_float(v, p));
     arena[d.plane_off + (size_t)y * d.pitch + x] = o;
   }
@@ -130,10 +157,20 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
   if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
     p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
+    if (p.reversible && p.wide) {
+      const long long yy = plane64(arena, d0)[(size_t)y * d0.pitch + x], cb = plane64(arena, d1)[(size_t)y * d1.pitch + x],
+                      cr = plane64(arena, d2)[(size_t)y * d2.pitch + x];
+      const long long g = yy - ((cb + cr) >> 2);
+      const unsigned shift = (unsigned)level_shift32(p);
+      image[at(d0)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cr + g) + shift), p), p);
+      image[at(d1)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)g + shift), p), p);
+      image[at(d2)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cb + g) + shift), p), p);
+    }
     uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];
     uint32_t b = arena[d1.plane_off + (size_t)y * d1.pitch + x];
     uint32_t c = arena[d2.plane_off + (size_t)y * d2.pitch + x];
-    if (p.reversible) {
+    if (p.reversible && p.wide) {
+    } else if (p.reversible) {
       const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
@@ -154,9 +191,14 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
     const ojphgpu_convert_desc d = descs[tile * nc + c];
     if (x >= d.w || y >= d.h) continue;
     p = with_fmt(pc, d);
+    if (p.reversible && p.wide) {
+      const long long v = plane64(arena, d)[(size_t)y * d.pitch + x];
+      image[at(d)] = sample_out<S>((int)((p.nlt3 && p.is_signed) ? (v >= 0 ? v : -v - (half64(p) + 1)) : v + (p.is_signed ? 0 : half64(p))), p);
+      continue;
+    }
     uint32_t a = arena[d.plane_off + (size_t)y * d.pitch + x];
     int v;
-    if (p.reversible) v = (int)a + (p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1)));
+    if (p.reversible) v = (int)(a + (uint32_t)level_shift32(p));
     else v = to_int(__uint_as_float(a), p);
     image[at(d)] = sample_out<S>(nlt3_map(v, p), p);
   }
@@ -166,7 +208,7 @@ ConvParams make(const ojphgpu_params* q)
 {
   ConvParams p;
   p.img_w = q->width; p.img_h = q->height; p.num_comps = q->num_comps; p.bit_depth = q->bit_depth;
-  p.is_signed = q->is_signed; p.reversible = q->reversible; p.color = q->color_transform; p.nlt3 = 0;
+  p.is_signed = q->is_signed; p.reversible = q->reversible; p.color = q->color_transform; p.nlt3 = 0; p.wide = 0;
   return p;
 }
 

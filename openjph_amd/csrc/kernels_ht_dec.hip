@@ -114,7 +114,8 @@ __device__ __forceinline__ uint32_t mel_exp(uint32_t k)      // {0,0,0,1,1,1,2,2
 // returns scup or 0
 __device__ __forceinline__ uint32_t check_block(const ojphgpu_cb_desc& d, const uint8_t* cb)
 {
-  if (d.num_passes > 3 || d.missing_msbs >= 30 || d.len1 < 2) return 0;
+  // (32-bit path: block_decoder32.cpp:768-789; the 64-bit function has no such test, its p = 62 - missing_msbs must stay >= 2)
+  if (d.num_passes > 3 || d.missing_msbs >= ((d.reversible & 4u) ? 61u : 30u) || d.len1 < 2) return 0;
   const uint32_t lcup = d.len1;
   const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
   if (scup < 2 || scup > lcup || scup > 4079) return 0;
@@ -214,15 +215,16 @@ __device__ void flatten(const uint8_t* __restrict__ cb, uint32_t lcup, uint32_t 
     wave_sync();
     wpos += nfull; cursor = T & 31u;
   }
-  if (lane == 0) {
+  if (lane == 0 && cursor) {
     uint32_t w = lds[0];
-    if (cursor) {
-      if (MEL) w = __brev(w | (0xFFFFFFFFu << cursor));    // past the end the MEL segment continues with 1s (:98)
-      out[wpos++] = w;
-    }
-    out[wpos] = MEL ? 0xFFFFFFFFu : 0u;                   // ... and the VLC segment with 0s (:313-331)
-    out[wpos + 1] = MEL ? 0xFFFFFFFFu : 0u;
+    if (MEL) w = __brev(w | (0xFFFFFFFFu << cursor));      // past the end the MEL segment continues with 1s (:98)
+    out[wpos] = w;
   }
+  if (cursor) wpos++;
+  // ... and the VLC segment with 0s (:313-331): up to the nominal length of the string (un-stuffing made it shorter; a
+  // reader that runs past the segment -- corrupt streams do -- must find the fill value, not what the scratch held before)
+  const uint32_t nominal = MEL ? mel_words(scup) : vlc_words(scup);
+  for (uint32_t i = wpos + (uint32_t)lane; i < nominal; i += 64) out[i] = MEL ? 0xFFFFFFFFu : 0u;
   wave_sync();
 }
 
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_prep_kernel(
   const uint32_t bi = blockIdx.x * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
-  if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) return;
+  if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0 || (d.reversible & 4u)) return;   // (64-bit sample path: ht_dec64_prep_kernel)
   const uint8_t* cb = data + d.data_off;
   const uint32_t scup = check_block(d, cb);
   if (scup == 0) return;
@@ -402,7 +404,21 @@ __device__ __forceinline__ void publish_rows(uint32_t* flag, uint32_t epoch, uin
   if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) st_agent(flag, (epoch << 16) | rows);
 }
 
-template <bool NARROW, bool FUSED = false, class VlcRd>
+// W64: the block is on the 64-bit sample path (ojph_decode_codeblock64): a decoded u above 32 -- before the initial
+// row's bias of 2 when both quads have u > 2 -- is followed by a 4-bit extension, u += 4 ext (block_decoder64.cpp:
+// 997-1011, :1119-1133).  A pair can then take 38 bits: the window is advanced and refilled in between.
+template <class VlcRd>
+__device__ __forceinline__ void uvlc_extension(VlcRd& vlc, uint32_t& used, uint32_t& u0, uint32_t& u1, uint32_t b0, uint32_t b1)
+{
+  const bool c0 = u0 - b0 > 32u, c1 = u1 - b1 > 32u;
+  if (__ballot(c0 | c1) == 0ull) return;                  // (wave-uniform: no lane of the wavefront needs one)
+  vlc.settle(); vlc.advance(used); vlc.prefetch(); vlc.settle(); used = 0;
+  uint32_t v = vlc.peek();
+  if (c0) { u0 += (v & 0xFu) << 2; v >>= 4; used += 4u; }
+  if (c1) { u1 += (v & 0xFu) << 2; used += 4u; }
+}
+
+template <bool NARROW, bool FUSED = false, bool W64 = false, class VlcRd>
 __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
                                            const uint16_t* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0)
 {
@@ -441,8 +457,9 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       const uint32_t tmp = v & ((1u << len) - 1u);
       used += len; entry >>= 4;
       len = entry & 7u; entry >>= 3;
-      const uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                      // kappa = 1 (:971-974)
-      const uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
+      uint32_t u0 = 1u + (entry & 7u) + (tmp & ~(0xFFu << len));                            // kappa = 1 (:971-974)
+      uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
+      if (W64) { const uint32_t bias = mode == 0x100u ? 3u : 1u; uvlc_extension(vlc, used, u0, u1, bias, bias); }   // (kappa + what the encoder took off)
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_rec<FUSED>(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
@@ -503,6 +520,7 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       // the pair's U-VLC by arithmetic instead of the uvlc_tbl1 look-up (:1065-1085): one LDS round trip less on the chain
       uint32_t u0, u1;
       used += ojphgpu::uvlc_pair_other_rows(v, t0 & 0x8u, t1 & 0x8u, u0, u1);
+      if (W64) uvlc_extension(vlc, used, u0, u1, 0u, 0u);
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
       store_rec<FUSED>(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
     }
@@ -713,6 +731,7 @@ __global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
   const uint32_t bi = (blockIdx.x * (uint32_t)CH + set) * 64u + lane;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
+  if (d.reversible & 4u) return;                          // 64-bit sample path: ht_dec_step1_kernel<CH, true> on the prep strings
   if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) { if (chain) block_status[bi] = 0; return; }   // not coded: zero block
   const uint8_t* cb = data + d.data_off;
   const uint32_t room = d.data_off > 0xFFFFu ? 0xFFFFu : (uint32_t)d.data_off;
@@ -746,7 +765,7 @@ __global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
   block_status[bi] = (mel.stuck || vlc.stuck) ? 1 : 0;
 }
 
-template <int CH>                 // CH chain wavefronts + CH partner wavefronts per workgroup, 64 code-blocks per pair of them
+template <int CH, bool W64 = false>   // CH chain wavefronts + CH partner wavefronts per workgroup, 64 code-blocks per pair of them
 __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ aux, uint32_t* __restrict__ quads, uint8_t* __restrict__ block_status)
@@ -777,6 +796,7 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
   const uint32_t bi = (blockIdx.x * (uint32_t)CH + set) * 64u + lane;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
+  if (((d.reversible & 4u) != 0) != W64) return;           // the other instantiation's blocks (64-bit sample path or not)
   if (d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) { if (chain) block_status[bi] = 0; return; }   // not coded: zero block
   const uint8_t* cb = data + d.data_off;
   const uint32_t scup = check_block(d, cb);
@@ -794,8 +814,8 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
   // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
-  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
-  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  if (__all(QW <= 32)) step1_rows<true, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else step1_rows<false, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   s_done[lane] = 1u;                               // the partner stops producing events for this block
   block_status[bi] = mel.stuck ? 1 : 0;
 }
@@ -816,7 +836,7 @@ __device__ __forceinline__ uint32_t dequantise(uint32_t val, bool rev, uint32_t 
 // does the block carry SigProp / MagRef passes that will be decoded (block_decoder32.cpp:752-789)?
 __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
 {
-  return d.num_passes > 1 && d.num_passes <= 3 && d.len2 > 0 && d.missing_msbs < 29;
+  return d.num_passes > 1 && d.num_passes <= 3 && d.len2 > 0 && (d.missing_msbs < 29 || (d.reversible & 4u));   // (:783-789: 32-bit path only)
 }
 
 // TX / WD: what the host knows about EVERY block of the launch (0 = nothing, decided per block at run time).
@@ -1081,6 +1101,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
   const uint32_t bi = wg * WAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
+  if (d.reversible & 4u) return;                          // 64-bit sample path: ht_dec64_step2_kernel
   step2_block<TX, WD, false>(d, bi, data, quads, coef, block_status, s_ring[wave], &s_exp[wave][0][0], lane, 0u, 0xFFFFFFFFu, nullptr);
 }
 
@@ -1321,7 +1342,7 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
   const uint32_t bi = blockIdx.x * RWAVES + wave;
   if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
-  if (!needs_refinement(d) || d.w == 0 || d.h == 0 || d.len1 == 0 || block_status[bi] != 0) return;
+  if (!needs_refinement(d) || d.w == 0 || d.h == 0 || d.len1 == 0 || block_status[bi] != 0 || (d.reversible & 4u)) return;   // (64-bit: ht_dec64_refine_kernel)
   RefineLds& L = s_wave[wave];
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   uint32_t* plane = coef + d.coef_off;
@@ -1413,6 +1434,319 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
     for (uint32_t x = lane; x < W; x += 64) plane[(size_t)y * pitch + x] = dequantise(L.smp[y * W + x], rev, shift, delta);
 }
 
+// -------------------------------------------------------------------------------------------------
+// 64-bit sample path: ojph_decode_codeblock64 (block_decoder64.cpp:766-1660), transfer gen_rev_tx_from_cb64
+// (ojph_codestream_gen.cpp:140-153)
+// -------------------------------------------------------------------------------------------------
+// Components that need more than 32 bits of precision (param_qcd::propose_precision, ojph_params.cpp:1684-1706 -- samples
+// deeper than about 26 bits, reversible) are decoded by the reference's 64-bit function: the same algorithm with 64-bit
+// MagSgn values, a U-VLC extension for u > 32, and byte readers of its own -- its VLC and MagSgn readers take ONE byte at a
+// time and MASK the bit a stuffed byte may not carry (rev_read8 :305-327, frwd_read8 :626-640), where the 32-bit function's
+// four-byte readers OR the byte in whole; after a masked byte the "previous byte" the stuffing rule looks at is the masked
+// value.  The same on conforming streams, different on corrupt ones, so the un-stuffers below restate THOSE rules: whether
+// byte k carries 7 bits depends on the parity of the run of 0xFF bytes in front of it (a lane looks back over that run;
+// runs are short).  This path is rare by nature and built from the simple forms of the stages: a prep launch un-stuffs
+// all THREE segments of a block into flat bit strings in d_aux (VLC | MEL | MagSgn), step 1 is the lane-per-block chain
+// on those strings (ht_dec_step1_kernel<CH, true>: FlatRd + the MEL partner wavefront), step 2 reads the MagSgn bits
+// from the flat string -- one wavefront per block, one lane per column, any width, 64-bit samples out.
+__host__ __device__ __forceinline__ uint32_t ms_words64(uint32_t len1) { return (len1 * 8u + 31u) / 32u + 6u; }   // data + 5 words of ones
+
+// 256 bytes per round, 4 per lane, bits placed by a wavefront prefix sum: KIND 0 = the VLC segment backwards (rev_init8 /
+// rev_read8), 1 = the MagSgn segment forwards (frwd_read8<0xFF>); `out` gets the flat LSB-first string and pad words (VLC:
+// zeros, MagSgn: ones -- what the readers feed when the segment is exhausted)
+template <int KIND>
+__device__ uint32_t flatten64(const uint8_t* __restrict__ cb, uint32_t lcup, uint32_t scup, uint32_t* __restrict__ out, uint32_t nominal,
+                              uint32_t* lds, int lane)
+{
+  const uint32_t count = KIND == 0 ? scup - 2u : lcup - scup;
+  for (int i = lane; i < 68; i += 64) lds[i] = 0;
+  wave_sync();
+  uint32_t cursor = 0, wpos = 0;
+  bool unstuff0 = false;                                   // state in front of byte 0
+  if (KIND == 0) {                                         // rev_init8 (:343-361): the half byte, masked
+    uint32_t v = cb[lcup - 2] >> 4;
+    const uint32_t t = (v & 7u) == 7u ? 1u : 0u;
+    v &= 0xFu >> t;
+    if (lane == 0) lds[0] = v;
+    cursor = 4u - t; unstuff0 = v > 8u;
+    wave_sync();
+  }
+  auto raw = [&](uint32_t k) -> uint32_t { return KIND == 0 ? (uint32_t)cb[lcup - 3u - k] : (uint32_t)cb[k]; };
+  for (uint32_t base = 0; base < count; base += 256) {
+    const uint32_t k0 = base + 4u * (uint32_t)lane;
+    uint32_t val = 0, nb = 0;
+    if (k0 < count) {
+      // the state in front of byte k0, from the run of 0xFF bytes that ends at k0 - 1
+      uint32_t r = 0;
+      while (r < k0 && raw(k0 - 1u - r) == 0xFFu) ++r;
+      bool unstuff;
+      if (KIND == 0) {
+        // VLC: a byte is short when the (masked) byte before it is > 0x8F and its own low 7 bits are ones; a short 0xFF
+        // becomes 0x7F.  In front of the run: c = the byte before it (never 0xFF), or the half byte
+        const bool u_first = r == k0 ? unstuff0 : raw(k0 - 1u - r) > 0x8Fu;     // is the first 0xFF of the run short?
+        unstuff = r == 0 ? u_first : ((r & 1u) ? !u_first : u_first);            // after FF_r: not short -> 0xFF > 0x8F
+      } else
+        unstuff = (r & 1u) != 0u;                          // MagSgn: byte k is short when an odd number of 0xFF precede it
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t k = k0 + j;
+        if (k < count) {
+          uint32_t b = raw(k);
+          const uint32_t t = KIND == 0 ? ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u) : (unstuff ? 1u : 0u);
+          b &= 0xFFu >> t;
+          val |= b << nb; nb += 8u - t;
+          unstuff = KIND == 0 ? b > 0x8Fu : b == 0xFFu;
+        }
+      }
+    }
+    const uint32_t incl = wave_incl_scan(nb);
+    or_bits(lds, cursor + incl - nb, val, nb);
+    const uint32_t T = cursor + rdlane(incl, 63);
+    wave_sync();
+    const uint32_t nfull = T >> 5;
+    for (uint32_t i = lane; i < nfull; i += 64) out[wpos + i] = lds[i];
+    const uint32_t carry = lds[nfull];
+    wave_sync();
+    for (int i = lane; i < 68; i += 64) lds[i] = 0;
+    wave_sync();
+    if (lane == 0) lds[0] = carry;
+    wave_sync();
+    wpos += nfull; cursor = T & 31u;
+  }
+  const uint32_t total = wpos * 32u + cursor;
+  const uint32_t fill = KIND == 0 ? 0u : 0xFFFFFFFFu;
+  if (lane == 0 && cursor) { uint32_t w = lds[0]; if (KIND == 1) w |= 0xFFFFFFFFu << cursor; out[wpos] = w; }
+  if (cursor) wpos++;
+  for (uint32_t i = wpos + (uint32_t)lane; i < nominal; i += 64) out[i] = fill;      // (see flatten)
+  wave_sync();
+  return total;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void ht_dec64_prep_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data, uint32_t* __restrict__ aux)
+{
+  __shared__ uint32_t s_buf[WAVES][68];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t bi = blockIdx.x * WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (!(d.reversible & 4u) || d.w == 0 || d.h == 0 || d.len1 == 0 || d.num_passes == 0) return;
+  const uint8_t* cb = data + d.data_off;
+  const uint32_t scup = check_block(d, cb);
+  if (scup == 0) return;
+  uint32_t* out = aux + d.reserved;
+  flatten64<0>(cb, d.len1, scup, out, vlc_words(scup), s_buf[wave], lane);
+  flatten<true>(cb, d.len1, scup, out + vlc_words(scup), s_buf[wave], lane);      // (the MEL reader is the 32-bit function's, :93-157)
+  flatten64<1>(cb, d.len1, scup, out + vlc_words(scup) + mel_words(scup), ms_words64(d.len1), s_buf[wave], lane);
+}
+
+// step 2 of one block of 64-bit samples: the wavefront walks the quad rows, 64 columns at a time
+constexpr int W64_WAVES = 2;
+constexpr uint32_t W64_EXP = 1024 + 8;
+__global__ __launch_bounds__(64 * W64_WAVES) void ht_dec64_step2_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data, const uint32_t* __restrict__ aux,
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
+{
+  __shared__ uint8_t s_exp[W64_WAVES][2][W64_EXP];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t bi = blockIdx.x * W64_WAVES + wave;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (!(d.reversible & 4u)) return;
+  const uint32_t W = d.w, H = d.h, pitch = d.pitch;
+  if (W == 0 || H == 0) return;
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(coef + d.coef_off);
+  auto zero_block = [&]() {
+    for (uint32_t y = 0; y < H; ++y)
+      for (uint32_t x = lane; x < W; x += 64) dst[(size_t)y * pitch + x] = 0ull;
+  };
+  if (d.len1 == 0 || d.num_passes == 0 || block_status[bi] != 0) { zero_block(); return; }
+  const uint32_t missing_msbs = d.missing_msbs, p = 62u - missing_msbs, mmsbp2 = missing_msbs + 2u;
+  const uint8_t* cb = data + d.data_off;
+  const uint32_t lcup = d.len1;
+  const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
+  const uint32_t ms_len = lcup - scup;
+  const uint32_t* ms = aux + d.reserved + vlc_words(scup) + mel_words(scup);
+  const uint32_t ms_last = ms_words64(lcup) - 1u;          // (holds ones whatever the segment: flatten64 fills up to there)
+  (void)ms_len;
+  const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1, PW = (QW + 1) >> 1;
+  const uint32_t* rec = quads + d.scratch_cap;
+  const bool raw_out = needs_refinement(d);
+  const uint32_t shift = 63u - d.K_max;
+  uint8_t* ex = &s_exp[wave][0][0];
+  for (uint32_t i = lane; i < 2 * W64_EXP / 4; i += 64) reinterpret_cast<uint32_t*>(ex)[i] = 0;
+  wave_sync();
+  uint32_t mpos = 0;
+  bool bad = false;
+  for (uint32_t qy = 0; qy < QH && !bad; ++qy) {
+    const uint8_t* vexp = ex + (qy & 1) * W64_EXP;         // exponents of the sample row above (+1 offset)
+    uint8_t* vnew = ex + ((qy & 1) ^ 1) * W64_EXP;
+    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+      const uint32_t col = c0 + (uint32_t)lane;
+      const bool act = col < W;
+      const uint32_t qx = col >> 1, half = (uint32_t)lane & 1u;
+      const uint32_t ent = act ? rec[(size_t)(qy * PW + (qx >> 1)) * REC_STRIDE + (qx & 1u)] : 0u;
+      const uint32_t inf = ent & 0xFFFFu;
+      uint32_t U_q = ent >> 16;
+      if (qy > 0) {
+        uint32_t gamma = inf & 0xF0u; gamma &= gamma - 0x10u;                           // :1266
+        const uint32_t b = 2 * qx;
+        const uint32_t em = act ? max(max((uint32_t)vexp[b], (uint32_t)vexp[b + 1]), max((uint32_t)vexp[b + 2], (uint32_t)vexp[b + 3])) : 0u;
+        U_q += gamma ? max(em, 1u) : 1u;                                                // :1267-1270
+      }
+      if (__ballot(act && U_q > mmsbp2) != 0ull) { bad = true; break; }                 // :1162, :1271
+      const uint32_t sel = inf >> (2u * half);
+      const uint32_t m0 = (sel & 0x10u) ? U_q - ((sel >> 12) & 1u) : 0u;
+      const uint32_t m1 = (sel & 0x20u) ? U_q - ((sel >> 13) & 1u) : 0u;
+      const uint32_t tot = m0 + m1;
+      const uint32_t incl = wave_incl_scan(tot);
+      const uint32_t at = mpos + incl - tot;
+      mpos += rdlane(incl, 63);
+      // 128 bits from `at` (words beyond the string read as the all-ones pad)
+      const uint32_t wi = at >> 5, sh = at & 31u;
+      uint32_t w[5];
+#pragma unroll
+      for (uint32_t i = 0; i < 5; ++i) w[i] = ms[min(wi + i, ms_last)];
+      const uint64_t lo = (uint64_t)__funnelshift_r(w[0], w[1], sh) | ((uint64_t)__funnelshift_r(w[1], w[2], sh) << 32);
+      const uint64_t hi = (uint64_t)__funnelshift_r(w[2], w[3], sh) | ((uint64_t)__funnelshift_r(w[3], w[4], sh) << 32);
+      auto one = [&](uint64_t ms_val, uint32_t m, uint32_t e1, bool on, uint64_t& v_keep) -> uint64_t {   // :1166-1182
+        uint64_t v_n = ms_val & ((m < 64u ? (1ull << m) : 0ull) - 1ull);
+        v_n |= (uint64_t)e1 << (m & 63u);
+        v_n |= 1ull;
+        v_keep = on ? v_n : 0ull;
+        return on ? ((ms_val << 63) | ((v_n + 2ull) << (p - 1u))) : 0ull;
+      };
+      uint64_t v0k, v1k;
+      const uint64_t val0 = one(lo, m0, (sel >> 8) & 1u, (sel & 0x10u) != 0u, v0k);
+      const uint64_t ms1 = m0 == 0u ? lo : (m0 >= 64u ? hi : ((lo >> m0) | (hi << (64u - m0))));
+      const uint64_t val1 = one(ms1, m1, (sel >> 9) & 1u, (sel & 0x20u) != 0u, v1k);
+      (void)v0k;
+      if (act) vnew[col + 1] = (uint8_t)(v1k ? 63u - (uint32_t)__clzll((long long)v1k) : 0u);
+      if (act) {
+        auto xfer = [&](uint64_t v) -> unsigned long long {                              // gen_rev_tx_from_cb64
+          if (raw_out) return v;
+          const long long mag = (long long)((v & 0x7FFFFFFFFFFFFFFFull) >> shift);
+          return (unsigned long long)((v >> 63) ? -mag : mag);
+        };
+        const uint32_t y = 2 * qy;
+        dst[(size_t)y * pitch + col] = xfer(val0);
+        if (y + 1 < H) dst[(size_t)(y + 1) * pitch + col] = xfer(val1);
+      }
+    }
+    wave_sync();
+  }
+  if (bad) { zero_block(); if (lane == 0) block_status[bi] = 1; }
+}
+
+// SigProp + MagRef of a block of 64-bit samples (block_decoder64.cpp:1360-1657): ht_dec_refine_kernel with 64-bit words
+struct RefineLds64 {
+  uint64_t smp[4096];
+  uint16_t sigma[SIG_ENTRIES];
+  uint16_t prev_row[PREV_ENTRIES];
+  uint8_t  bytes[2048];
+};
+
+__global__ __launch_bounds__(64) void ht_dec64_refine_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
+{
+  __shared__ RefineLds64 L;
+  const int lane = threadIdx.x & 63;
+  const uint32_t bi = blockIdx.x;
+  if (bi >= n) return;
+  const ojphgpu_cb_desc d = blocks[bi];
+  if (!(d.reversible & 4u) || !needs_refinement(d) || d.w == 0 || d.h == 0 || d.len1 == 0 || block_status[bi] != 0) return;
+  const uint32_t W = d.w, H = d.h, pitch = d.pitch;
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(coef + d.coef_off);
+  const bool causal = (d.reversible & 2u) != 0;
+  const uint32_t p = 62u - d.missing_msbs;
+  const int ngroups = (int)((W + 3) >> 2), mstr = ngroups + 2;
+  for (uint32_t i = lane; i < SIG_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.sigma)[i] = 0;
+  for (uint32_t i = lane; i < PREV_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.prev_row)[i] = 0;
+  wave_sync();
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = lane; x < W; x += 64) {
+      const uint64_t v = plane[(size_t)y * pitch + x];
+      L.smp[y * W + x] = v;
+      if (v) {
+        const uint32_t e = (y >> 2) * (uint32_t)mstr + (x >> 2);
+        atomicOr(reinterpret_cast<uint32_t*>(L.sigma) + (e >> 1), (1u << (4 * (x & 3) + (y & 3))) << (16 * (e & 1)));
+      }
+    }
+  const uint8_t* seg = data + d.data_off + d.len1;
+  const int len2 = (int)d.len2;
+  for (int i = lane; i < len2 && i < 2048; i += 64) L.bytes[i] = seg[i];
+  wave_sync();
+  if (lane == 0) {
+    FwdBits spp; spp.init(L.bytes, len2 < 2048 ? len2 : 2048);
+    for (int y = 0; y < (int)H; y += 4) {
+      uint32_t pattern = 0xFFFFu;
+      if ((int)H - y < 4) { pattern = 0x7777u; if ((int)H - y < 3) { pattern = 0x3333u; if ((int)H - y < 2) pattern = 0x1111u; } }
+      uint32_t prev = 0;
+      const uint16_t* cur_sig = L.sigma + (y >> 2) * mstr;
+      const uint16_t* nxt_sig = cur_sig + mstr;
+      for (int x = 0, g = 0; x < (int)W; x += 4, ++g) {
+        int sft = x + 4 - (int)W; if (sft < 0) sft = 0;
+        pattern >>= sft * 4;
+        const uint32_t ps = L.prev_row[g] | ((uint32_t)L.prev_row[g + 1] << 16);
+        const uint32_t ns = nxt_sig[g] | ((uint32_t)nxt_sig[g + 1] << 16);
+        uint32_t u = (ps & 0x88888888u) >> 3;
+        if (!causal) u |= (ns & 0x11111111u) << 3;
+        const uint32_t cs = cur_sig[g] | ((uint32_t)cur_sig[g + 1] << 16);
+        uint32_t mbr = cs | ((cs & 0x77777777u) << 1) | ((cs & 0xEEEEEEEEu) >> 1) | u;
+        uint32_t t = mbr;
+        mbr |= (t << 4) | (t >> 4) | (prev >> 12);
+        mbr &= pattern; mbr &= ~cs;
+        uint32_t new_sig = mbr;
+        if (new_sig) {
+          const uint32_t inv_sig = ~cs & pattern;
+          for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t b = 1u << (4 * c + r);
+              if (!(new_sig & b)) continue;
+              new_sig &= ~b;
+              if (spp.bit()) {
+                const uint32_t grow = r == 0 ? 0x33u : (r == 1 ? 0x76u : (r == 2 ? 0xECu : 0xC8u));
+                new_sig |= (grow << (4 * c)) & inv_sig;
+              }
+            }
+          new_sig &= 0xFFFFu;
+          for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r)
+              if (new_sig & (1u << (4 * c + r)))
+                L.smp[(uint32_t)(y + r) * W + (uint32_t)(x + c)] = ((uint64_t)spp.bit() << 63) | (3ull << (p - 2));
+        }
+        new_sig |= cs;
+        L.prev_row[g] = (uint16_t)new_sig;
+        t = new_sig;
+        new_sig |= ((t & 0x7777u) << 1) | ((t & 0xEEEEu) >> 1);
+        prev = (new_sig | u) & 0xF000u;
+      }
+    }
+    if (d.num_passes > 2) {
+      BwdBits mrp; mrp.init(L.bytes, len2 < 2048 ? len2 : 2048);
+      const uint64_t half = 1ull << (p - 2);
+      for (int y = 0; y < (int)H; y += 4)
+        for (int x = 0; x < (int)W; ++x) {
+          const uint32_t nib = ((uint32_t)L.sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
+          for (int r = 0; r < 4; ++r)
+            if (nib & (1u << r))
+              L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((uint64_t)(1u - mrp.bit()) << (p - 1)) | half;
+        }
+    }
+  }
+  wave_sync();
+  const uint32_t shift = 63u - d.K_max;
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = lane; x < W; x += 64) {
+      const uint64_t v = L.smp[y * W + x];
+      const long long mag = (long long)((v & 0x7FFFFFFFFFFFFFFFull) >> shift);
+      plane[(size_t)y * pitch + x] = (unsigned long long)((v >> 63) ? -mag : mag);
+    }
+}
+
 }  // namespace
 
 extern "C" uint32_t ojphgpu_ht_decode_aux_words(uint32_t len1) { return aux_words(len1); }
@@ -1433,6 +1767,7 @@ extern "C" int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h, uint32_t n, uint64_t
       h[g + l].scratch_cap = (uint32_t)(q + 2 * l);
       h[g + l].reserved = (uint32_t)a;
       a += aux_words(h[g + l].len1);
+      if (h[g + l].reversible & 4u) a += ms_words64(h[g + l].len1);      // 64-bit sample path: the flat MagSgn string as well
     }
     q += (uint64_t)REC_STRIDE * pairs;
   }
@@ -1592,6 +1927,31 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
 }
 }  // namespace ojphgpu
 
+namespace ojphgpu {
+// words of d_aux a block of the 64-bit sample path needs beyond ojphgpu_ht_decode_aux_words(len1)
+uint32_t ht_decode64_extra_aux_words(uint32_t len1) { return ms_words64(len1); }
+
+// the blocks of [d_blocks, d_blocks + n) that are on the 64-bit sample path (cb_desc.reversible bit 2; the others are
+// skipped): prep (three flat strings per block in d_aux), step 1 on them, step 2, and -- refine != 0 -- SigProp / MagRef
+int ht_decode64_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_aux,
+                       uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int refine)
+{
+  if (n == 0) return OJPHGPU_OK;
+  if (ensure_tables() != 0) return OJPHGPU_E_HIP;
+  if (!d_blocks || !d_data || !d_aux || !d_quad_scratch || !d_coef || !d_block_status) return OJPHGPU_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ht_dec64_prep_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, s, d_blocks, n, d_data, d_aux);
+  const uint32_t sets = (n + 63) / 64;
+  hipLaunchKernelGGL((ht_dec_step1_kernel<4, true>), dim3((sets + 3) / 4), dim3(512), 0, s, d_blocks, n, d_data, (const uint32_t*)d_aux,
+                     d_quad_scratch, d_block_status);
+  hipLaunchKernelGGL(ht_dec64_step2_kernel, dim3((n + W64_WAVES - 1) / W64_WAVES), dim3(64 * W64_WAVES), 0, s, d_blocks, n, d_data,
+                     (const uint32_t*)d_aux, (const uint32_t*)d_quad_scratch, (uint32_t*)d_coef, d_block_status);
+  if (refine)
+    hipLaunchKernelGGL(ht_dec64_refine_kernel, dim3(n), dim3(64), 0, s, d_blocks, n, d_data, (uint32_t*)d_coef, (const uint8_t*)d_block_status);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+}  // namespace ojphgpu
+
 extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
                                         const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
                                         uint8_t* d_block_status)
@@ -1617,6 +1977,8 @@ extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step1(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step2(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_refine(stream, d_blocks, n, d_data, d_coef, d_block_status);
+  // blocks on the 64-bit sample path (descriptor flag; every launch above skipped them)
+  if (rc == OJPHGPU_OK) rc = ojphgpu::ht_decode64_launch(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_coef, d_block_status, 1);
   return rc;
 }
 

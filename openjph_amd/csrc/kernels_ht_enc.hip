@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/ojphgpu.h"
 #include "ht_tables.h"
 
@@ -55,9 +56,12 @@ constexpr int VLC_CAP = 3072 - MEL_CAP;   // :556
 constexpr int WAVES = 4;
 constexpr uint32_t NARROW_MAX_W = 64;   // blocks up to this width take the lane-per-column kernel
 
-struct WaveLds {
-  uint32_t ms[MS_WORDS];
-  uint32_t vlc[VLC_WORDS];
+constexpr int MS_WORDS64 = 1040;  // 64-bit samples: 64 lanes * 8 samples * 63 bits + carry
+constexpr int VLC_WORDS64 = 96;   //                 64 lanes * 38 bits + carry
+template <int MSW, int VLW>
+struct WaveLdsT {
+  uint32_t ms[MSW];
+  uint32_t vlc[VLW];
   uint32_t ev[8];                 // compacted MEL event bits of one step (<= 192)
   uint8_t  mel[MEL_CAP];
 };
@@ -114,6 +118,7 @@ __device__ __forceinline__ uint32_t to_sign_mag(uint32_t raw, bool reversible, u
 }
 
 __device__ __forceinline__ uint32_t expo(uint32_t val) { return val ? 32u - (uint32_t)__clz((int)(val - 1)) : 0u; }
+__device__ __forceinline__ uint32_t expo(uint64_t val) { return val ? 64u - (uint32_t)__clzll((long long)(val - 1)) : 0u; }
 
 // MEL exponents {0,0,0,1,1,1,2,2,2,3,3,4,5} packed 3 bits each (ojph_block_encoder.cpp:324)
 __device__ __forceinline__ uint32_t mel_exp(uint32_t k)
@@ -181,28 +186,36 @@ __device__ __forceinline__ uint32_t claim_output(uint32_t* cursor, const uint32_
   return (off > cap || bytes > cap - off) ? 0xFFFFFFFFu : base + off;
 }
 
+// S64: the blocks of components on the 64-bit sample path (ojph_encode_codeblock64, ojph_block_encoder.cpp:1026-1520; the
+// transfer gen_rev_tx_to_cb64, ojph_codestream_gen.cpp:81-100): int64 samples, exponents up to 63, MagSgn values of up to
+// 63 bits and the U-VLC extension for u > 32 (:245-253, :1269-1293, :1487-1492) -- the same symbols otherwise.
+template <bool S64>
 __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
     ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status,
     const uint32_t* __restrict__ regions, uint32_t nreg)
 {
+  using V = typename std::conditional<S64, uint64_t, uint32_t>::type;     // a sign-magnitude sample
+  constexpr uint32_t VBITS = S64 ? 64u : 32u;
+  constexpr int MSW = S64 ? MS_WORDS64 : MS_WORDS, VLW = S64 ? VLC_WORDS64 : VLC_WORDS;
   __shared__ uint16_t s_vlc[2][2048];
-  __shared__ WaveLds s_wave[WAVES];
+  __shared__ WaveLdsT<MSW, VLW> s_wave[WAVES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const uint32_t bi = blockIdx.x * WAVES + wave;
-  const bool mine = bi < n && blocks[bi].w > NARROW_MAX_W;               // narrow blocks belong to ht_encode_kernel
+  // narrow blocks of 32-bit samples belong to ht_encode_kernel; blocks of 64-bit samples, of any width, to the S64 instantiation
+  const bool mine = bi < n && (S64 ? (blocks[bi].reversible & 4u) != 0 : (blocks[bi].w > NARROW_MAX_W && (blocks[bi].reversible & 4u) == 0));
   if (!__syncthreads_or(mine ? 1 : 0)) return;
   for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
   __syncthreads();
   if (!mine) return;
   const ojphgpu_cb_desc d = blocks[bi];
-  WaveLds& L = s_wave[wave];
+  WaveLdsT<MSW, VLW>& L = s_wave[wave];
   const uint32_t W = d.w, H = d.h;
   if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
-  const uint32_t K = d.K_max, p = 31u - K;      // missing_msbs = K_max - 1, p = 30 - missing_msbs
-  const bool rev = d.reversible != 0;
+  const uint32_t K = d.K_max, p = VBITS - 1u - K;   // missing_msbs = K_max - 1, p = 30 (62) - missing_msbs
+  const bool rev = (d.reversible & 1u) != 0;
   const float delta_inv = rev ? 0.0f : __fdiv_rn(1.0f, d.delta);         // ojph_codeblock.cpp:98
   const uint32_t* src = coef + d.coef_off;
   const uint32_t pitch = d.pitch;
@@ -212,8 +225,8 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
 
   const uint32_t QW = (W + 1) >> 1, QH = (H + 1) >> 1, PW = (QW + 1) >> 1, NP = PW * QH;
 
-  for (int i = lane; i < MS_WORDS; i += 64) L.ms[i] = 0;
-  if (lane < VLC_WORDS) L.vlc[lane] = 0;
+  for (int i = lane; i < MSW; i += 64) L.ms[i] = 0;
+  for (int i = lane; i < VLW; i += 64) L.vlc[i] = 0;
   if (lane < 8) L.ev[lane] = 0;
   wave_sync();
   if (lane == 0) L.vlc[0] = 0xF;                                          // vlc_init: 4 bits already used (:365-375)
@@ -226,9 +239,13 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
   uint32_t err = 0, any_sig = 0;
   uint32_t carry_rho = 0;                               // rho of the last quad of the previous step
 
-  auto sample = [&](int x, int y) -> uint32_t {         // quantised sign-magnitude, 0 outside the block
-    if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return 0u;
-    return to_sign_mag(src[(size_t)y * pitch + x], rev, p, delta_inv);
+  auto sample = [&](int x, int y) -> V {                // quantised sign-magnitude, 0 outside the block
+    if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return (V)0;
+    if constexpr (S64) {                                // gen_rev_tx_to_cb64
+      const long long v = reinterpret_cast<const long long*>(src)[(size_t)y * pitch + x];
+      return (v >= 0 ? 0ull : 0x8000000000000000ull) | ((uint64_t)(v >= 0 ? v : -v) << p);
+    } else
+      return to_sign_mag(src[(size_t)y * pitch + x], rev, p, delta_inv);
   };
 
   for (uint32_t base = 0; base < NP; base += 64) {
@@ -240,26 +257,26 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     const bool first_row = qy == 0;
 
     // ---- samples of the pair: t[q*4+n], n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1) ----
-    uint32_t val[8], sgn[8];
+    V val[8]; uint32_t sgn[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int q = i >> 2, nn = i & 3;
-      uint32_t t = active ? sample(x0 + 2 * q + (nn >> 1), y0 + (nn & 1)) : 0u;
-      val[i] = ((t + t) >> p) & ~1u;                    // 2*mu_p        (:592-595)
-      sgn[i] = t >> 31;
+      V t = active ? sample(x0 + 2 * q + (nn >> 1), y0 + (nn & 1)) : (V)0;
+      val[i] = ((V)(t + t) >> p) & ~(V)1;               // 2*mu_p        (:592-595)
+      sgn[i] = (uint32_t)(t >> (VBITS - 1u));
     }
     // ---- bottom sample row of the quad row above: columns x0-1 .. x0+4 ----
     uint32_t Eab[6], Sab[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      uint32_t t = (active && !first_row) ? sample(x0 - 1 + i, y0 - 1) : 0u;
-      uint32_t v = ((t + t) >> p) & ~1u;
+      V t = (active && !first_row) ? sample(x0 - 1 + i, y0 - 1) : (V)0;
+      V v = ((V)(t + t) >> p) & ~(V)1;
       Eab[i] = expo(v); Sab[i] = v != 0;
     }
 
     // ---- per quad symbols ----
     uint32_t rho[2], cq[2], uq[2], Uq[2], tup[2];
-    uint32_t msv[8], msl[8];
+    V msv[8]; uint32_t msl[8];
     uint32_t rho_q[2] = { 0, 0 }, emax[2] = { 0, 0 }, e[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -297,9 +314,9 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
       for (int nn = 0; nn < 4; ++nn) {
         const int i = q * 4 + nn;
         const uint32_t m = ((rho_q[q] >> nn) & 1u) ? U - ((tuple >> nn) & 1u) : 0u;   // :667-674
-        const uint32_t s = val[i] ? val[i] - 2u + sgn[i] : 0u;                      // v_n = 2(mu-1)+sign (:601)
+        const V s = val[i] ? val[i] - 2u + sgn[i] : (V)0;                           // v_n = 2(mu-1)+sign (:601)
         msl[i] = m;
-        msv[i] = m ? (s & ((m >= 32 ? 0u : (1u << m)) - 1u)) : 0u;
+        msv[i] = m ? (s & ((m >= VBITS ? (V)0 : ((V)1 << m)) - (V)1)) : (V)0;
       }
     }
     const bool q0on = active, q1on = has_q1;
@@ -308,14 +325,17 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     any_sig |= (__ballot((rho[0] | rho[1]) != 0 && active) != 0ull) ? 1u : 0u;
 
     // ---- VLC bits of the pair: cwd(q0) cwd(q1) then the interleaved U-VLC ----
-    uint32_t vb = 0, vl = 0;
-    auto vadd = [&](uint32_t c, uint32_t len) { vb |= c << vl; vl += len; };
-    auto uvlc = [](uint32_t u, uint32_t& pre, uint32_t& pl, uint32_t& suf, uint32_t& sl) {   // :196-255
+    uint64_t vb = 0; uint32_t vl = 0;                   // (S64: up to 2 x 7 + 2 x (3 + 5 + 4) = 38 bits)
+    auto vadd = [&](uint32_t c, uint32_t len) { vb |= (uint64_t)c << vl; vl += len; };
+    uint32_t x0e = 0, xl0 = 0, x1e = 0, xl1 = 0;        // the extensions of the pair's two codewords (S64 only)
+    auto uvlc = [](uint32_t u, uint32_t& pre, uint32_t& pl, uint32_t& suf, uint32_t& sl, uint32_t& ext, uint32_t& el) {   // :196-255
+      ext = 0; el = 0;
       if (u == 0) { pre = 0; pl = 0; suf = 0; sl = 0; }
       else if (u == 1) { pre = 1; pl = 1; suf = 0; sl = 0; }
       else if (u == 2) { pre = 2; pl = 2; suf = 0; sl = 0; }
       else if (u <= 4) { pre = 4; pl = 3; suf = u - 3; sl = 1; }
-      else { pre = 0; pl = 3; suf = u - 5; sl = 5; }
+      else if (u <= 32 || !S64) { pre = 0; pl = 3; suf = u - 5; sl = 5; }
+      else { pre = 0; pl = 3; suf = 28u + ((u - 33u) & 3u); sl = 5; ext = (u - 33u) >> 2; el = 4; }   // :245-253
     };
     bool ev2_valid = false; uint32_t ev2_bit = 0;
     if (q0on) {
@@ -325,14 +345,14 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
       uint32_t p0, l0, s0, sl0, p1, l1, s1, sl1;
       if (first_row && u0 > 0 && u1 > 0) { ev2_valid = true; ev2_bit = min(u0, u1) > 2; }    // :763-764
       if (first_row && u0 > 2 && u1 > 2) {                                                    // :766-772
-        uvlc(u0 - 2, p0, l0, s0, sl0); uvlc(u1 - 2, p1, l1, s1, sl1);
-        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1);
+        uvlc(u0 - 2, p0, l0, s0, sl0, x0e, xl0); uvlc(u1 - 2, p1, l1, s1, sl1, x1e, xl1);
+        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1); vadd(x0e, xl0); vadd(x1e, xl1);
       } else if (first_row && u0 > 2 && u1 > 0) {                                             // :773-778
-        uvlc(u0, p0, l0, s0, sl0);
-        vadd(p0, l0); vadd(u1 - 1, 1); vadd(s0, sl0);
+        uvlc(u0, p0, l0, s0, sl0, x0e, xl0);
+        vadd(p0, l0); vadd(u1 - 1, 1); vadd(s0, sl0); vadd(x0e, xl0);
       } else {                                                                                // :779-785, :985-988
-        uvlc(u0, p0, l0, s0, sl0); uvlc(u1, p1, l1, s1, sl1);
-        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1);
+        uvlc(u0, p0, l0, s0, sl0, x0e, xl0); uvlc(u1, p1, l1, s1, sl1, x1e, xl1);
+        vadd(p0, l0); vadd(p1, l1); vadd(s0, sl0); vadd(s1, sl1); vadd(x0e, xl0); vadd(x1e, xl1);
       }
     }
 
@@ -373,7 +393,14 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
       const uint32_t T = ms_carry + rdlane(incl, 63);
       uint32_t at = ms_carry + incl - tot;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { or_bits(L.ms, at, msv[i], msl[i]); at += msl[i]; }
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (S64) {
+          const uint32_t lo = msl[i] < 32u ? msl[i] : 32u;
+          or_bits(L.ms, at, (uint32_t)msv[i], lo);
+          if (msl[i] > 32u) or_bits(L.ms, at + 32u, (uint32_t)(msv[i] >> 32), msl[i] - 32u);
+        } else or_bits(L.ms, at, (uint32_t)msv[i], msl[i]);
+        at += msl[i];
+      }
       wave_sync();
       uint32_t pos = 0;
       for (;;) {
@@ -397,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
       const uint32_t cv = rem ? get_bits(L.ms, pos, rem) : 0u;
       wave_sync();
       const uint32_t used = (T >> 5) + 2;
-      for (uint32_t i = lane; i < used && i < (uint32_t)MS_WORDS; i += 64) L.ms[i] = 0;
+      for (uint32_t i = lane; i < used && i < (uint32_t)MSW; i += 64) L.ms[i] = 0;
       wave_sync();
       if (lane == 0) L.ms[0] = cv;
       ms_carry = rem;
@@ -408,7 +435,11 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     {
       const uint32_t incl = wave_incl_scan(vl, lane);
       const uint32_t T = v_carry + rdlane(incl, 63);
-      or_bits(L.vlc, v_carry + incl - vl, vb, vl);
+      {
+        const uint32_t at = v_carry + incl - vl, lo = vl < 32u ? vl : 32u;
+        or_bits(L.vlc, at, (uint32_t)vb, lo);
+        if (vl > 32u) or_bits(L.vlc, at + 32u, (uint32_t)(vb >> 32), vl - 32u);
+      }
       wave_sync();
       uint32_t pos = 0;
       for (;;) {
@@ -436,7 +467,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
       const uint32_t rem = T - pos;
       const uint32_t cv = rem ? get_bits(L.vlc, pos, rem) : 0u;
       wave_sync();
-      if (lane < VLC_WORDS) L.vlc[lane] = 0;
+      for (int i = lane; i < VLW; i += 64) L.vlc[i] = 0;
       wave_sync();
       if (lane == 0) L.vlc[0] = cv;
       v_carry = rem;
@@ -669,7 +700,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
   constexpr uint32_t PPR = 1u << LOGP, RPS = 64u >> LOGP;                 // quad pairs per row of a step, quad rows per step
-  if (W > NARROW_MAX_W || W > 4u * PPR || (d.reversible != 0) != REV) return;   // ht_encode_wide_kernel's, or another instantiation's
+  if (W > NARROW_MAX_W || W > 4u * PPR || ((d.reversible & 1u) != 0) != REV || (d.reversible & 4u) != 0) return;   // ht_encode_wide_kernel's, or another instantiation's
   if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
   NarrowLds& L = s_wave[wave];
   uint8_t* outb = reinterpret_cast<uint8_t*>(L.out);
@@ -1283,8 +1314,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
 namespace ojphgpu {
 // `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones; bit 2 = it holds
 // blocks of reversibly transformed components, bit 3 = of irreversibly transformed ones; bit 4 = none of its blocks of
-// up to 64 samples is wider than 32 (they take the 8-pairs-by-8-rows layout).  Every kernel skips the
-// blocks of the other kind, so a caller that does not know passes 3 (wavelet bits clear = both).
+// up to 64 samples is wider than 32 (they take the 8-pairs-by-8-rows layout); bit 5 = it holds blocks of 64-bit samples
+// (cb_desc.reversible bit 2).  Every kernel skips the blocks of the other kind, so a caller that does not know passes
+// 3 | 32 (wavelet bits clear = both).
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
                      int widths, const uint32_t* d_regions, uint32_t nreg)
@@ -1311,7 +1343,10 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
     hipLaunchKernelGGL((ht_encode_kernel<false, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if (widths & 2)
-    hipLaunchKernelGGL(ht_encode_wide_kernel, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+    hipLaunchKernelGGL(ht_encode_wide_kernel<false>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
+  if (widths & 32)                                          // blocks of components on the 64-bit sample path
+    hipLaunchKernelGGL(ht_encode_wide_kernel<true>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
@@ -1321,7 +1356,7 @@ extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, 
                                   const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
                                   ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status)
 {
-  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3, nullptr, 0);
+  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3 | 32, nullptr, 0);
 }
 
 namespace ojphgpu {

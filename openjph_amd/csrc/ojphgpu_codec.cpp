@@ -138,13 +138,14 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     const Block& k = P.blocks[e->block_ids[i]]; const Band& B = P.bands[k.band];
     samples += (uint64_t)k.r.w * k.r.h;
     ojphgpu_cb_desc& d = bd[i]; memset(&d, 0, sizeof(d));
-    d.coef_off = B.plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; d.pitch = B.pitch;
-    d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)(P.style(B.comp).rev ? 1 : 0);
+    const bool wide = is_wide(P, B.comp);                  // 64-bit samples: two arena elements each
+    d.coef_off = B.plane_off + ((uint64_t)k.r.y0 * B.pitch + k.r.x0) * (wide ? 2u : 1u); d.pitch = B.pitch;
+    d.w = (uint16_t)k.r.w; d.h = (uint16_t)k.r.h; d.K_max = (uint8_t)B.K_max; d.reversible = (uint8_t)((P.style(B.comp).rev ? 1 : 0) | (wide ? 4 : 0));
     d.missing_msbs = (uint8_t)(B.K_max - 1); d.num_passes = 1; d.delta = B.delta;
     d.data_off = scratch_bytes; d.scratch_cap = block_scratch_bytes(k.r.w, k.r.h, B.K_max);
     scratch_bytes += d.scratch_cap;
-    (i < e->n_top ? e->widths_top : e->widths_rest) |= (k.r.w > 64 ? 2 : 1) | (d.reversible ? 4 : 8);   // which kernel variants the range needs
-    if (k.r.w > 32 && k.r.w <= 64) (i < e->n_top ? over32_top : over32_rest) = true;
+    (i < e->n_top ? e->widths_top : e->widths_rest) |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((d.reversible & 1) ? 4 : 8));   // which kernel variants the range needs
+    if (!wide && k.r.w > 32 && k.r.w <= 64) (i < e->n_top ? over32_top : over32_rest) = true;
   }
   if (!over32_top) e->widths_top |= 16;                    // every block of the range at most 32 samples wide (e.g. the IMF profile's 32 x 32)
   if (!over32_rest) e->widths_rest |= 16;
@@ -260,6 +261,9 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)e->img_descs.p + b.img_first;
       rc = ojphgpu_dwt_forward_image_ex(s, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container, b.nc == 3);
+    } else if (b.wide) {                                    // 64-bit sample path: the general lifting kernels
+      const ojphgpu_lift k53 = lift_rev53_64();
+      rc = ojphgpu_dwt_forward_general(s, &k53, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, e->arena.p);
     } else
       rc = ojphgpu_dwt_forward(s, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
@@ -531,7 +535,7 @@ int ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_block
       Q.p.image_x0 != P.p.image_x0 || Q.p.image_y0 != P.p.image_y0 || Q.p.tile_x0 != P.p.tile_x0 || Q.p.tile_y0 != P.p.tile_y0 ||
       memcmp(Q.p.comp_dx, P.p.comp_dx, sizeof(P.p.comp_dx)) != 0 || memcmp(Q.p.comp_dy, P.p.comp_dy, sizeof(P.p.comp_dy)) != 0 ||
       memcmp(Q.p.comp_depth, P.p.comp_depth, sizeof(P.p.comp_depth)) != 0 || memcmp(Q.p.comp_sign, P.p.comp_sign, sizeof(P.p.comp_sign)) != 0 ||
-      Q.nlt3 != P.nlt3 || Q.bands.size() != P.bands.size() || memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
+      Q.nlt3 != P.nlt3 || Q.wide != P.wide || Q.bands.size() != P.bands.size() || memcmp(Q.p.coc, P.p.coc, sizeof(P.p.coc)) != 0)
     return OJPHGPU_E_INVALID;
   if (!compare_blocks) return OJPHGPU_OK;
   // the launches are laid out from the first frame's geometry: every block must sit where that frame has it
@@ -557,12 +561,13 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
   for (size_t i = 0; i < ids.size(); ++i) {
     const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
-    o.coef_off = arena_off + P.bands[k.band].plane_off + (uint64_t)k.r.y0 * B.pitch + k.r.x0; o.pitch = B.pitch;
+    const bool wide = is_wide(Q, B.comp);                  // (same_frame_geometry: the same components as in P)
+    o.coef_off = arena_off + P.bands[k.band].plane_off + ((uint64_t)k.r.y0 * B.pitch + k.r.x0) * (wide ? 2u : 1u); o.pitch = B.pitch;
     o.w = (uint16_t)k.r.w; o.h = (uint16_t)k.r.h; o.K_max = (uint8_t)B.K_max;
-    o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u));   // bit 1: vertically causal
+    o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u) | (wide ? 4u : 0u));   // bit 1: vertically causal, bit 2: 64-bit samples
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) { fi.any_refine = true; fi.kinds |= 16; }
-    fi.kinds |= (k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8);
+    fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8));
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     fi.max_len1 = std::max(fi.max_len1, c.len1);
     if (c.len1 + c.len2) {
@@ -619,7 +624,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   // blocks (3/4 of the samples) on the main one.  Prep and step 1 stay single launches over all blocks:
   // step 1 costs one serial chain however few blocks it is given, splitting it would pay that twice
   // (measured: 0.96 vs 0.91 ms at 8K with every stage split in two).
-  if (nframes == 1 && max_recon_decomps(P) >= 2 && d->batches.size() >= 2 && d->batches.front().depth > 0 &&
+  if (nframes == 1 && max_recon_decomps(P) >= 2 && d->batches.size() >= 2 && d->batches.front().depth > 0 && !P.any_wide &&
       getenv("OJPHGPU_NO_OVERLAP") == nullptr) {
     auto low = [&](uint32_t id) { const Band& B = P.bands[P.blocks[id].band]; return B.res < P.recon_decomps(B.comp); };
     auto mid = std::stable_partition(ids.begin(), ids.end(), low);
@@ -689,7 +694,7 @@ extern "C" int ojphgpu_decoder_upload_frame(ojphgpu_decoder* d, uint32_t frame, 
 // prep + step 1 of every block (one launch each: step 1 costs one serial chain however few blocks it gets)
 static int decode_chains(ojphgpu_decoder* d, hipStream_t s)
 {
-  if (d->nblocks == 0) return OJPHGPU_OK;
+  if (d->nblocks == 0 || (d->kinds & 3) == 0) return OJPHGPU_OK;     // (nothing but blocks of the 64-bit sample path: decode_samples)
   Spans& T = d->timer;
   const ojphgpu_cb_desc* cbd = (const ojphgpu_cb_desc*)(d->o_cb_descs ? d->o_cb_descs : d->cb_descs.p);
   uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p);
@@ -714,10 +719,14 @@ static int decode_samples(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uin
   uint8_t* status = (uint8_t*)(d->o_status ? d->o_status : d->status.p) + first;
   const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
   int sp = T.begin(SP_STEP2, s);
-  int rc = ojphgpu::ht_decode_step2_launch(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status, d->kinds);
+  int rc = (d->kinds & 3) ? ojphgpu::ht_decode_step2_launch(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status, d->kinds & ~32) : OJPHGPU_OK;
   if (rc) return rc;
+  if (d->kinds & 32) {                                      // the blocks on the 64-bit sample path: all their launches (the others skip them)
+    rc = ojphgpu::ht_decode64_launch(s, cbd, count, data, (uint32_t*)d->aux.p, (uint32_t*)d->quads.p, d->arena.p, status, d->any_refine ? 1 : 0);
+    if (rc) return rc;
+  }
   T.end(sp, s);
-  if (d->any_refine) {
+  if (d->any_refine && (d->kinds & 3)) {
     sp = T.begin(SP_REFINE, s);
     rc = ojphgpu_ht_decode_refine(s, cbd, count, data, d->arena.p, status);
     if (rc) return rc;
@@ -745,7 +754,7 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
   // every block is at most 64 samples wide, of one wavelet and without refinement passes -- and where it pays: blocks
   // of 64 rows, few enough for resident workers (ht_decode_fused_pays); the synthesis levels follow on the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
-  const bool fused = d->fstate.p && !d->force_separate && !d->any_refine && (d->kinds & 3) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) &&
+  const bool fused = d->fstate.p && !d->force_separate && !d->any_refine && (d->kinds & (3 | 32)) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) &&
                      d->nblocks > 0 && ojphgpu::ht_decode_fused_pays(d->nblocks, d->max_block_h, d->cus);
   d->last_fused = fused; d->last_image = d_image; d->last_container = container;
   const uint32_t n_low = fused ? 0u : d->n_low;
@@ -788,6 +797,9 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)d->img_descs.p + b.img_first;
       rc = ojphgpu_dwt_inverse_image_ex(ls, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container, b.nc == 3);
+    } else if (b.wide) {
+      const ojphgpu_lift k53 = lift_rev53_64();
+      rc = ojphgpu_dwt_inverse_general(ls, &k53, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, d->arena.p);
     } else
       rc = ojphgpu_dwt_inverse(ls, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);

@@ -51,7 +51,8 @@ struct HostBuf {
 // nc = 3: the batch holds the top levels of the three colour components of every tile, as triples, and the
 // component transform is applied inside the DWT kernel (kernels_dwt.hip); group: 0 all components, 1 the colour
 // components (0..2), 2 the others -- how a depth is split when the colour transform is fused
-struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; };
+// wide: the levels of components on the 64-bit sample path (int64 planes: the general lifting kernels, kernels_lift.hip)
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool wide; };
 
 // DWT descriptors grouped so that one launch handles every tile-component
 struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
@@ -60,19 +61,24 @@ inline bool in_group(uint32_t comp, int group) { return group == 0 || (group == 
 
 // The component transform is applied inside the top DWT level of the three colour components (no conversion pass)
 // when every one of them has such a level and no non-linearity sits between the samples and the transform
+inline bool is_wide(const Plan& P, uint32_t comp) { return comp < P.wide.size() && P.wide[comp] != 0; }
+// samples deeper than 26 bits are converted by the conversion kernels, not inside the top DWT level (whose conversion
+// arithmetic was built and tested for the depths the 32-bit path had until round 4)
+inline bool deep(const Plan& P, uint32_t comp) { return P.comps[comp].bit_depth > 26 || is_wide(P, comp); }
+
 inline bool colour_fused(const Plan& P)
 {
   if (!P.p.color_transform || P.any_nlt3 || P.p.num_comps < 3) return false;
-  for (uint32_t c = 0; c < 3; ++c) if (P.recon_decomps(c) == 0) return false;
+  for (uint32_t c = 0; c < 3; ++c) if (P.recon_decomps(c) == 0 || deep(P, c)) return false;
   const char* off = getenv("OJPHGPU_NO_COLOUR_FUSION");          // test switch: "1" keeps the stand-alone conversion kernels
   return !(off && off[0] && off[0] != '0');
 }
 
 template <typename F>
-void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, int group, F f)
+void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, int group, bool wide, F f)
 {
   for (const ojphgpu_level_info& lv : P.levels) {
-    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev || !in_group(lv.comp, group)) continue;
+    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev || !in_group(lv.comp, group) || is_wide(P, lv.comp) != wide) continue;
     const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
     if (L > depth && lv.res == L - depth) f(lv);
   }
@@ -92,9 +98,10 @@ void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_de
   const bool fused = colour_fused(P);
   for (uint32_t depth = 0; depth < depths; ++depth)
     for (int rev = 0; rev < 2; ++rev)
+    for (int wide = 0; wide < (rev ? 2 : 1); ++wide)
     for (int group = (fused && depth == 0) ? 1 : 0; group <= ((fused && depth == 0) ? 2 : 0); ++group) {
-      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1, group == 1 ? 3 : 1, group };
-      for_levels_of(P, tr, depth, rev != 0, group, [&](const ojphgpu_level_info& lv) {
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1, group == 1 ? 3 : 1, group, wide != 0 };
+      for_levels_of(P, tr, depth, rev != 0, group, wide != 0, [&](const ojphgpu_level_info& lv) {
         ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
         d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
         d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
@@ -115,10 +122,13 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
   out.clear();
   if (P.any_nlt3 || (P.p.color_transform && !colour_fused(P))) return;   // those conversions live in the conversion kernels
   for (LevelBatch& b : batches) {
-    if (b.depth != 0 || b.count == 0) continue;
+    if (b.depth != 0 || b.count == 0 || b.wide) continue;
+    bool all_shallow = true;                                  // (a batch with a deep component keeps the conversion kernels)
+    for_levels_of(P, tr, 0, b.rev, b.group, false, [&](const ojphgpu_level_info& lv) { all_shallow = all_shallow && !deep(P, lv.comp); });
+    if (!all_shallow) continue;
     b.img_first = (int)out.size();
     size_t k = 0;
-    for_levels_of(P, tr, 0, b.rev, b.group, [&](const ojphgpu_level_info& lv) {
+    for_levels_of(P, tr, 0, b.rev, b.group, false, [&](const ojphgpu_level_info& lv) {
       ojphgpu_dwt_desc d = descs[b.first + k++];
       const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
       const CompGeo& g = P.comps[lv.comp];
@@ -150,8 +160,15 @@ bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       const CompGeo& g = P.comps[c];
       d.src_x0 = R.r.x0 - g.x0; d.src_y0 = R.r.y0 - g.y0;
       d.img_pitch = g.w; d.img_off = g.frame_off;
-      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u);   // 0x200: bit 10 says which conversion
-      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+      d.fmt = g.bit_depth | (g.is_signed ? 0x100u : 0u) | 0x200u | (P.style(c).rev ? 0x400u : 0u) | (P.nlt3[c] ? 0x800u : 0u) |   // 0x200: bit 10 says which conversion
+              (is_wide(P, c) ? 0x1000u : 0u);
+      // (a batch of the top DWT level converts its components itself only when none of them is deep: the batch of the
+      // component's wavelet, see build_image_level_descs)
+      bool batch_deep = false;
+      const int grp = colour_fused(P) ? (c < 3 ? 1 : 2) : 0;
+      for (uint32_t o = 0; o < P.p.num_comps; ++o)
+        batch_deep = batch_deep || (P.style(o).rev == P.style(c).rev && in_group(o, grp) && !is_wide(P, o) && deep(P, o) && P.recon_decomps(o) > 0);
+      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0 || is_wide(P, c) || batch_deep) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
@@ -337,7 +354,16 @@ struct ojphgpu_decoder {
   // what a run reads: the object's own buffers (null), or those of a frame pipeline's slot
   const void* o_cb_descs = nullptr; const void* o_data = nullptr; void* o_status = nullptr;
 };
-struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0; };   // kinds: see ht_decode_step2_launch
+struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0; };   // kinds: see ht_decode_step2_launch; bit 5: blocks on the 64-bit sample path
+// the general lifting kernel description of the reversible 5/3 on 64-bit samples (param_atk::init_rev53, ojph_params.cpp:2883-2896)
+inline ojphgpu_lift lift_rev53_64()
+{
+  ojphgpu_lift k; memset(&k, 0, sizeof(k));
+  k.num_steps = 2; k.elem = 1; k.horz = 1; k.vert = 1; k.K = 1.0f;
+  k.steps[0].a = 1; k.steps[0].b = 2; k.steps[0].e = 2;
+  k.steps[1].a = -1; k.steps[1].b = 1; k.steps[1].e = 1;
+  return k;
+}
 int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks);
 void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);

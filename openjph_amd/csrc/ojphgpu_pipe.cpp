@@ -614,7 +614,12 @@ extern "C" int ojphgpu_dec_pipe_create(const uint8_t* h_codestream, size_t len, 
         (void)hipStreamDestroy(dk->side); dk->side = nullptr; dk->n_low = 0;
       }
       // the flat VLC / MEL strings of any later frame fit: the worst case of every block (Lcup <= 4079 + slack)
-      const uint64_t worst = (uint64_t)dk->block_ids.size() * ojphgpu_ht_decode_aux_words(4079) + 64;
+      uint64_t worst = (uint64_t)dk->block_ids.size() * ojphgpu_ht_decode_aux_words(4079) + 64;
+      if (P.any_wide)                                      // 64-bit sample path: the flat MagSgn strings, bounded by what a block of that size can code
+        for (uint32_t id : dk->block_ids) {
+          const Block& k = P.blocks[id]; const Band& B = P.bands[k.band];
+          if (is_wide(P, B.comp)) worst += ojphgpu::ht_decode64_extra_aux_words(block_scratch_bytes(k.r.w, k.r.h, 62));
+        }
       dk->aux.release();
       if (dk->aux.alloc((size_t)worst * 4 + 64)) return OJPHGPU_E_NOMEM;
     }

@@ -1,0 +1,103 @@
+"""The 64-bit sample path and the general lifting form on the CPU side: the oracle's functions against the live reference
+(oracle/_ref, compiled from /root/reference by oracle/Makefile), and the oracle pipeline (oracle stages + this repo's plan
+and Tier-2) against the reference's whole codestreams for samples of 27..32 bits.
+
+Reference: ojph_encode_codeblock64 (ojph_block_encoder.cpp:1026-1520), ojph_decode_codeblock64
+(ojph_block_decoder64.cpp:766-1660), param_qcd::propose_precision (ojph_params.cpp:1684-1706), the 64-bit lines of
+resolution / subband / codeblock (ojph_resolution.cpp:209-229, ojph_subband.cpp:94-110, ojph_codeblock.cpp:57-266)."""
+import numpy as np
+import pytest
+
+from oracle import oraclebind as ob
+from tests.test_gpu_wide import SHAPES, WIDE_CASES, deep_image, wide_block
+
+
+def test_general_lifting_form_equals_the_53_and_97_oracles():
+    rng = np.random.default_rng(1)
+    for (h, w) in [(1, 1), (1, 7), (8, 1), (5, 7), (16, 16), (33, 18), (2, 2), (3, 2), (64, 65)]:
+        for xe in (True, False):
+            for ye in (True, False):
+                a = rng.integers(-1000, 1000, (h, w)).astype(np.int32)
+                g = ob.dwt_fwd_gen(a, ob.REV53, x_even=xe, y_even=ye)
+                assert all(np.array_equal(x, y) for x, y in zip(g, ob.dwt53_fwd(a, xe, ye)))
+                assert np.array_equal(ob.dwt_inv_gen(*g, w, h, ob.REV53, x_even=xe, y_even=ye), a)
+                a64 = a.astype(np.int64) * (1 << 20) + 12345
+                g = ob.dwt_fwd_gen(a64, ob.REV53, x_even=xe, y_even=ye)
+                assert np.array_equal(ob.dwt_inv_gen(*g, w, h, ob.REV53, x_even=xe, y_even=ye), a64)
+                f = rng.standard_normal((h, w)).astype(np.float32)
+                g = ob.dwt_fwd_gen(f, ob.IRV97, ob.K97, x_even=xe, y_even=ye)
+                s = ob.dwt97_fwd(f, xe, ye)
+                assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(g, s))
+                r1 = ob.dwt_inv_gen(*g, w, h, ob.IRV97, ob.K97, x_even=xe, y_even=ye)
+                assert np.array_equal(r1.view(np.uint32), ob.dwt97_inv(*s, w, h, xe, ye).view(np.uint32))
+
+
+def test_oracle_64bit_blocks_equal_the_reference(ref):
+    rng = np.random.default_rng(2)
+    for i in range(60):
+        w, h = SHAPES[i % len(SHAPES)]
+        kmax = int(rng.integers(31, 39))
+        sm, v = wide_block(rng, w, h, kmax, float(rng.choice([0.01, 0.2, 0.7, 1.0])), int(rng.choice([1, 3, 12, 30, kmax])))
+        if not np.any(v):
+            continue
+        want = ref.encode_block64(sm, kmax - 1, w, h, w)
+        assert ob.ht_encode64(sm, w, h, w, kmax - 1, 0) == want and ob.ht_encode64(sm, w, h, w, kmax - 1, 1) == want, (w, h, kmax)
+        ok1, d1 = ob.ht_decode64(want, w, h, w, kmax - 1)
+        ok2, d2 = ref.decode_block64(want, kmax - 1, w, h, w)
+        assert ok1 and ok2 and np.array_equal(d1, d2[:, :w])
+
+
+def test_oracle_64bit_decoder_on_corrupt_and_multi_pass_segments(ref):
+    """the 64-bit function has byte readers of its own (one byte at a time, stuffed bits masked): same verdict, same
+    samples on damaged segments; SigProp / MagRef bytes behind a cleanup segment"""
+    rng = np.random.default_rng(3)
+    w = h = 64; kmax = 34
+    sm, v = wide_block(rng, w, h, kmax, 0.6, 30)
+    good = ob.ht_encode64(sm, w, h, w, kmax - 1, 0)
+    trials = [good[:2], good[:len(good) // 2], good[:-1], b"\x00\x00", b"\xff\xff\xff\xff", good + b"\x00"]
+    for k in range(300):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 5))):
+            pos = int(rng.integers(0, len(b))) if k % 3 else len(b) - 1 - int(rng.integers(0, min(200, len(b))))
+            b[pos] = int(rng.choice([0xFF, 0x7F, 0x8F, 0x90, int(rng.integers(0, 256))]))
+        trials.append(bytes(b))
+    rejected = 0
+    for t in trials:
+        ok1, d1 = ob.ht_decode64(t, w, h, w, kmax - 1)
+        ok2, d2 = ref.decode_block64(t, kmax - 1, w, h, w)
+        assert ok1 == ok2
+        if ok1:
+            assert np.array_equal(d1, d2[:, :w])
+        rejected += not ok1
+    assert 0 < rejected < len(trials)
+    for k in range(60):
+        ww, hh = SHAPES[k % len(SHAPES)]
+        km = int(rng.integers(31, 38))
+        sm, v = wide_block(rng, ww, hh, km, 0.5, 20)
+        if not np.any(v):
+            continue
+        cup = ob.ht_encode64(sm, ww, hh, ww, km - 1, 0)
+        tail = bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8))
+        npass, causal = int(rng.integers(2, 4)), bool(k & 1)
+        ok1, d1 = ob.ht_decode64(cup + tail, ww, hh, ww, km - 1, len2=len(tail), num_passes=npass, stripe_causal=causal)
+        ok2, d2 = ref.decode_block64(cup + tail, km - 1, ww, hh, ww, len2=len(tail), num_passes=npass, stripe_causal=causal)
+        assert ok1 and ok2 and np.array_equal(d1, d2[:, :ww]), (ww, hh, km, npass, causal)
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_deep_sample_codestreams_equal_the_reference(case, ref, refgen):
+    from tests import cpu_pipeline as cp
+    c = dict(case)
+    nc, h, w, bd, signed = c.pop("nc"), c.pop("h"), c.pop("w"), c.pop("bd"), c.pop("signed")
+    img = deep_image(nc, h, w, bd, signed)
+    kw = dict(c, bit_depth=bd, is_signed=signed)
+    rkw = dict(kw); rkw.pop("bit_depth")
+    r = ref if kw.get("reversible", True) else refgen
+    want = r.encode(img, bd, **rkw)
+    got, plan, *_ = cp.encode(img, **kw)
+    assert got == want, "%d vs %d bytes" % (len(got), len(want))
+    dec, _ = cp.decode(want)
+    rdec, _ = r.decode(want)
+    assert np.array_equal(dec, rdec)
+    if kw.get("reversible", True):
+        assert np.array_equal(dec, img)
