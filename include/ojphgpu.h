@@ -42,6 +42,28 @@ extern "C" {
  * ------------------------------------------------------------------------------------------ */
 #define OJPHGPU_MAX_SUBSAMPLED_COMPS 16
 #define OJPHGPU_MAX_COC_COMPS 16
+/* Part 2 (ITU-T T.801) wavelets, as far as the reference reads them (it never writes them): an ATK marker segment = a
+ * lifting kernel (param_atk, ojph_params_local.h:1105-1230, read :2770-2866: whole-sample symmetric kernels with one
+ * coefficient per step, even-indexed first), a DFS marker segment = which directions every decomposition level
+ * transforms (param_dfs, :1030-1100, read ojph_params.cpp:2596-2644).  A lifting step, in synthesis order:
+ * reversible x -+= (b + a (l + r)) >> e, irreversible x -+= A (l + r). */
+#define OJPHGPU_MAX_LIFT_STEPS 16
+#define OJPHGPU_MAX_ATK 4
+#define OJPHGPU_MAX_DFS 4
+typedef struct ojphgpu_lift_step { int32_t a, b, e; float A; } ojphgpu_lift_step;
+typedef struct ojphgpu_atk {
+  uint8_t  index;                  /* Satk & 0xFF: 2..255 (0 and 1 name the Part-1 wavelets); 0 = entry unused       */
+  uint8_t  reversible, num_steps;
+  uint8_t  coeff_type;             /* how the coefficients are written: 0 8-bit, 1 16-bit integers, 2 float, 3 double */
+  float    K;                      /* irreversible: the scaling factor                                                */
+  ojphgpu_lift_step steps[OJPHGPU_MAX_LIFT_STEPS];
+} ojphgpu_atk;
+typedef struct ojphgpu_dfs {
+  uint8_t  used, index;            /* Sdfs: 0..15                                                                     */
+  uint8_t  num_levels, reserved;   /* Ids; levels beyond it repeat the last one (param_dfs::get_dwt_type :2539-2547)  */
+  uint8_t  types[32];              /* per decomposition level, 1 = the first one applied to the image:
+                                      0 none, 1 both directions, 2 horizontal only, 3 vertical only                   */
+} ojphgpu_dfs;
 /* A COC marker segment: what param_cod's comp_idx setters build (ojph_params.h:146-151,
  * ojph_params.cpp:255-282).  The reference starts a new COC from the SPcod defaults -- 5
  * decompositions, 64x64 blocks, wavelet_trans 0 (the 9/7), no precincts (ojph_params_local.h:344-353)
@@ -53,7 +75,12 @@ typedef struct ojphgpu_coc {
   uint8_t  num_decomps;            /* param_cod::set_num_decomposition(comp_idx, ..)                */
   uint8_t  log_block_w, log_block_h; /* param_cod::set_block_dims(comp_idx, ..), log2 (2..10)        */
   uint8_t  has_precincts;          /* param_cod::set_precinct_size(comp_idx, ..): precinct_exps[0..num_decomps] */
-  uint8_t  reserved[2];            /* are PPx | PPy << 4 per resolution; 0 = 32768 x 32768 everywhere */
+  uint8_t  reserved[2];            /* are PPx | PPy << 4 per resolution; 0 = 32768 x 32768 everywhere.
+                                      reserved[0]: bit 0 vertically causal (parser); bit 7: the decomposition is defined
+                                      by the DFS marker segment with the index in bits 1..4 -- the number of
+                                      decompositions is then the COD's (ojph_params_local.h:503-516, :613-618);
+                                      reserved[1]: the wavelet is the ATK marker segment with this index (2..255), 0 =
+                                      `reversible` names the Part-1 wavelet */
   uint8_t  precinct_exps[36];
 } ojphgpu_coc;
 typedef struct ojphgpu_params {
@@ -100,6 +127,11 @@ typedef struct ojphgpu_params {
      2 Cr) and its place in the creation order (QCCs are written in that order, then the ones the
      library adds, ojph_params.cpp:1822-1834) */
   uint8_t  qcc_qfactor[OJPHGPU_MAX_COC_COMPS], qcc_ctype[OJPHGPU_MAX_COC_COMPS], qcc_rank[OJPHGPU_MAX_COC_COMPS];
+  /* Part 2: the COD's wavelet when it is an ATK marker segment (its index, 2..255; 0 = `reversible` decides), and the
+     ATK / DFS marker segments of the main header (see ojphgpu_atk / ojphgpu_dfs) */
+  uint8_t  wavelet, part2_reserved[3];
+  ojphgpu_atk atk[OJPHGPU_MAX_ATK];
+  ojphgpu_dfs dfs[OJPHGPU_MAX_DFS];
 } ojphgpu_params;
 
 /* ------------------------------------------------------------------------------------------ *
@@ -135,6 +167,8 @@ typedef struct ojphgpu_level_info {  /* one DWT level of one tile-component: res
   uint64_t hl_off;  uint32_t hl_pitch;
   uint64_t lh_off;  uint32_t lh_pitch;
   uint64_t hh_off;  uint32_t hh_pitch;
+  uint32_t kind;                     /* 1 both directions (always, without a DFS marker segment), 2 horizontal only (ll +
+                                        hl), 3 vertical only (ll + lh), 0 no transform (ll = the plane) */
 } ojphgpu_level_info;
 
 typedef struct ojphgpu_coded_block { /* what the packet headers say about one code-block */
@@ -177,6 +211,12 @@ int  ojphgpu_plan_comp_format(const ojphgpu_plan* plan, uint32_t comp, uint32_t*
  * height, [4] 1 = the component has a COC, [5] decompositions left after restrict_resolution,
  * [6] 1 = the type 3 non-linearity applies to the component (NLT marker segment, signed component) */
 int  ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, uint32_t out[8]);
+/* the wavelet of decomposition level `level` (1 = the first one applied to the tile-component) of a component, as the
+ * general lifting kernels take it: the steps of its ATK marker segment (or of the Part-1 wavelet its COD / COC names),
+ * the directions its DFS marker segment has the level transform, elem by the component's sample path
+ * (cod.access_atk() + param_dfs::get_dwt_type as resolution::finalize_alloc combines them, ojph_resolution.cpp:264-300) */
+struct ojphgpu_lift;
+int  ojphgpu_plan_comp_lift(const ojphgpu_plan* plan, uint32_t comp, uint32_t level, struct ojphgpu_lift* out);
 
 /* ------------------------------------------------------------------------------------------ *
  * 3. Tier-2 on the host: marker segments + packet headers (tag trees, pass lengths) around the
@@ -242,8 +282,6 @@ int ojphgpu_dwt_inverse(void* stream, int reversible, const ojphgpu_dwt_desc* d_
  * samples), 2 = float.  horz / vert = 0: the level leaves that direction alone -- all its samples are "low" there, only
  * ll and hl (vert = 0) or ll and lh (horz = 0) are read / written.  The planes the descriptors name as src are
  * transformed IN PLACE before they are split into the bands (forward) / after they are joined (inverse). */
-#define OJPHGPU_MAX_LIFT_STEPS 16
-typedef struct ojphgpu_lift_step { int32_t a, b, e; float A; } ojphgpu_lift_step;
 typedef struct ojphgpu_lift {
   uint32_t num_steps, elem, horz, vert;
   float    K;

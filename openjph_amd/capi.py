@@ -23,6 +23,27 @@ class Coc(C.Structure):
     ]
 
 
+class LiftStep(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("e", C.c_int32), ("A", C.c_float)]
+
+
+class Atk(C.Structure):
+    """ojphgpu_atk: an ATK marker segment (a lifting kernel)"""
+    _fields_ = [("index", C.c_uint8), ("reversible", C.c_uint8), ("num_steps", C.c_uint8), ("coeff_type", C.c_uint8),
+                ("K", C.c_float), ("steps", LiftStep * 16)]
+
+
+class Dfs(C.Structure):
+    """ojphgpu_dfs: a DFS marker segment (which directions each decomposition level transforms)"""
+    _fields_ = [("used", C.c_uint8), ("index", C.c_uint8), ("num_levels", C.c_uint8), ("reserved", C.c_uint8), ("types", C.c_uint8 * 32)]
+
+
+class Lift(C.Structure):
+    """ojphgpu_lift: a lifting kernel as the general DWT kernels take it"""
+    _fields_ = [("num_steps", C.c_uint32), ("elem", C.c_uint32), ("horz", C.c_uint32), ("vert", C.c_uint32), ("K", C.c_float),
+                ("steps", LiftStep * 16)]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32), ("num_comps", C.c_uint32),
@@ -42,6 +63,7 @@ class Params(C.Structure):
         ("nlt_comp", C.c_uint8 * 16), ("nlt_rank", C.c_uint8 * 16), ("nlt_bd", C.c_uint8 * 16),
         ("nlt_reserved", C.c_uint8 * 2),
         ("qcc_qfactor", C.c_uint8 * 16), ("qcc_ctype", C.c_uint8 * 16), ("qcc_rank", C.c_uint8 * 16),
+        ("wavelet", C.c_uint8), ("part2_reserved", C.c_uint8 * 3), ("atk", Atk * 4), ("dfs", Dfs * 4),
     ]
 
 
@@ -68,7 +90,7 @@ class LevelInfo(C.Structure):
         ("ll_off", C.c_uint64), ("ll_pitch", C.c_uint32),
         ("hl_off", C.c_uint64), ("hl_pitch", C.c_uint32),
         ("lh_off", C.c_uint64), ("lh_pitch", C.c_uint32),
-        ("hh_off", C.c_uint64), ("hh_pitch", C.c_uint32),
+        ("hh_off", C.c_uint64), ("hh_pitch", C.c_uint32), ("kind", C.c_uint32),
     ]
 
 
@@ -142,6 +164,7 @@ SIGNATURES = {
     "ojphgpu_ht_decode_layout": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ojphgpu_plan_comp_format": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_comp_style": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ojphgpu_plan_comp_lift": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ojphgpu_plan_set_comments": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                             C.c_uint32]),
     "ojphgpu_plan_restrict_resolution": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -84,10 +84,14 @@ static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint
     uint32_t mx = B + X;
     for (uint32_t d = D; d > 0; --d) {
       double l = bibo53_l[d], h = bibo53_h[d - 1];
+      // (a DFS marker segment: the level has one sub-band, or none -- param_dfs::get_subband_idx; the reference never writes
+      // such a QCC, these are the exponents of the two-directional level, an upper bound)
+      const uint32_t kind = plan.level_kind(comp, d);
       X = (uint32_t)std::ceil(std::log(h * l) / M_LN2);
-      e.push_back(B + X); e.push_back(B + X); mx = std::max(mx, B + X);
+      if (kind == 1) { e.push_back(B + X); e.push_back(B + X); mx = std::max(mx, B + X); }
+      else if (kind == 2 || kind == 3) { e.push_back(B + X); mx = std::max(mx, B + X); }
       X = (uint32_t)std::ceil(std::log(h * h) / M_LN2);
-      e.push_back(B + X); mx = std::max(mx, B + X);
+      if (kind == 1) { e.push_back(B + X); mx = std::max(mx, B + X); }
     }
     if (mx > 38) { err = "bit depth, colour transform and wavelet need more than 38 bits"; return false; }   // :1520-1525
     int guard = std::max(1, (int)mx - 31);
@@ -138,9 +142,10 @@ static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint
   enc(delta_ref / (gl * gl * g_c * w_b));
   for (uint32_t d = D; d > 0; --d) {
     float l = energy97_l[d], h = energy97_h[d - 1];
-    w_b = std::pow(vw_get(weights, d, 1), power); enc(delta_ref / (h * l * g_c * w_b));
-    w_b = std::pow(vw_get(weights, d, 2), power); enc(delta_ref / (l * h * g_c * w_b));
-    w_b = std::pow(vw_get(weights, d, 3), power); enc(delta_ref / (h * h * g_c * w_b));
+    const uint32_t kind = plan.level_kind(comp, d);        // (DFS: see the reversible branch)
+    if (kind == 1 || kind == 2) { w_b = std::pow(vw_get(weights, d, 1), power); enc(delta_ref / (h * l * g_c * w_b)); }
+    if (kind == 1 || kind == 3) { w_b = std::pow(vw_get(weights, d, 2), power); enc(delta_ref / (l * h * g_c * w_b)); }
+    if (kind == 1) { w_b = std::pow(vw_get(weights, d, 3), power); enc(delta_ref / (h * h * g_c * w_b)); }
   }
   return true;
 }
@@ -176,7 +181,7 @@ bool derive_quant(Plan& plan)
     const bool own = c < OJPHGPU_MAX_COC_COMPS && p.qcc_qfactor[c] != 0;
     if (!plan.qcc[c].present) {
       if (st.L == plan.cod.L && st.rev == plan.cod.rev && plan.comps[c].bit_depth == plan.comps[qcd_comp].bit_depth &&
-          plan.comps[c].is_signed == plan.comps[qcd_comp].is_signed) continue;
+          plan.comps[c].is_signed == plan.comps[qcd_comp].is_signed && st.dfs < 0) continue;    // (DFS: another list of sub-bands)
       plan.qcc[c].present = true; plan.qcc_order.push_back(c);
       base = qcd_base;
     }
@@ -244,12 +249,25 @@ bool derive_nlt(Plan& plan, bool parsed)
   return true;
 }
 
-static inline uint32_t band_index(uint32_t res, uint32_t band) { return res ? (res - 1) * 3 + band : 0; }
+// index of a sub-band's entry in its QCD / QCC; with a DFS marker segment the levels below contribute 3, 1 or 0
+// sub-bands each (param_dfs::get_subband_idx, ojph_params.cpp:2550-2572)
+static inline uint32_t band_index(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)
+{
+  if (res == 0) return 0;
+  if (plan.style(comp).dfs < 0) return (res - 1) * 3 + band;
+  static const uint32_t ns[4] = { 0, 3, 1, 1 };
+  const uint32_t L = plan.style(comp).L;
+  uint32_t idx = 0;
+  for (uint32_t i = 1; i < res; ++i) idx += ns[plan.level_kind(comp, L - i + 1)];
+  idx += band;
+  if (plan.level_kind(comp, L - res + 1) == 3 && band == 2) --idx;
+  return idx;
+}
 
 uint32_t band_Kmax(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)   // ojph_params.cpp:1715-1749
 {
   const QuantSet& q = plan.quant(comp);
-  uint32_t idx = band_index(res, band);
+  uint32_t idx = band_index(plan, comp, res, band);
   if ((q.sqcd & 0x1F) == 0) {                            // the style of the marker segment decides, as in the reference
     idx = std::min<uint32_t>(idx, (uint32_t)q.q8.size() - 1);
     uint32_t nb = q.q8[idx] >> 3;
@@ -264,7 +282,7 @@ float band_delta(const Plan& plan, uint32_t comp, uint32_t res, uint32_t band)  
 {
   static const float arr[4] = { 1.0f, 2.0f, 2.0f, 4.0f };
   const QuantSet& q = plan.quant(comp);
-  uint32_t idx = std::min<uint32_t>(band_index(res, band), (uint32_t)q.q16.size() - 1);
+  uint32_t idx = std::min<uint32_t>(band_index(plan, comp, res, band), (uint32_t)q.q16.size() - 1);
   int eps = q.q16[idx] >> 11;
   float mantissa = (float)((q.q16[idx] & 0x7FF) | 0x800) * arr[band];
   mantissa /= (float)(1 << 11);
@@ -313,6 +331,29 @@ bool derive_precision(Plan& plan)
   return true;
 }
 
+ojphgpu_lift Plan::lift_of(uint32_t comp, uint32_t d) const
+{
+  ojphgpu_lift k; memset(&k, 0, sizeof(k));
+  const CodStyle& st = style(comp);
+  const uint32_t kind = level_kind(comp, d);
+  k.horz = kind == 1 || kind == 2; k.vert = kind == 1 || kind == 3;
+  k.elem = st.rev ? ((comp < wide.size() && wide[comp]) ? 1u : 0u) : 2u;
+  k.K = 1.0f;
+  if (const AtkDef* a = atk_of(comp)) {
+    k.num_steps = (uint32_t)a->steps.size(); k.K = a->K;
+    for (size_t i = 0; i < a->steps.size(); ++i) k.steps[i] = a->steps[i];
+  } else if (st.rev) {                                       // param_atk::init_rev53 (ojph_params.cpp:2883-2896)
+    k.num_steps = 2;
+    k.steps[0].a = 1; k.steps[0].b = 2; k.steps[0].e = 2;
+    k.steps[1].a = -1; k.steps[1].b = 1; k.steps[1].e = 1;
+  } else {                                                   // param_atk::init_irv97 (:2870-2881)
+    k.num_steps = 4; k.K = (float)1.230174104914001;
+    k.steps[0].A = (float)0.443506852043971; k.steps[1].A = (float)0.882911075530934;
+    k.steps[2].A = (float)-0.052980118572961; k.steps[3].A = (float)-1.586134342059924;
+  }
+  return k;
+}
+
 // Places of the planes in the arena (32-bit elements): per tile-component, resolution by resolution, the raw plane of the
 // resolution (r > 0) and then its bands.  A component on the 64-bit sample path has 64-bit samples in all of them: two
 // elements per sample (pitch stays in samples; such planes start on even elements).  Then the DWT levels, which quote
@@ -347,15 +388,12 @@ void assign_planes(Plan& plan)
         ojphgpu_level_info lv; memset(&lv, 0, sizeof(lv));
         lv.tile = t.idx; lv.comp = c; lv.res = r;
         lv.w = R.r.w; lv.h = R.r.h; lv.x_even = (R.r.x0 & 1) == 0; lv.y_even = (R.r.y0 & 1) == 0;
-        lv.src_off = R.plane_off; lv.src_pitch = R.pitch;
+        lv.src_off = R.plane_off; lv.src_pitch = R.pitch; lv.kind = R.kind;
         if (r - 1 == 0) { const Band& B = plan.bands[(size_t)C.band[0]]; lv.ll_off = B.plane_off; lv.ll_pitch = B.pitch; }
         else { lv.ll_off = C.plane_off; lv.ll_pitch = C.pitch; }
-        const Band& HL = plan.bands[(size_t)R.band[1]];
-        const Band& LH = plan.bands[(size_t)R.band[2]];
-        const Band& HH = plan.bands[(size_t)R.band[3]];
-        lv.hl_off = HL.plane_off; lv.hl_pitch = HL.pitch;
-        lv.lh_off = LH.plane_off; lv.lh_pitch = LH.pitch;
-        lv.hh_off = HH.plane_off; lv.hh_pitch = HH.pitch;
+        if (R.band[1] >= 0) { const Band& HL = plan.bands[(size_t)R.band[1]]; lv.hl_off = HL.plane_off; lv.hl_pitch = HL.pitch; }
+        if (R.band[2] >= 0) { const Band& LH = plan.bands[(size_t)R.band[2]]; lv.lh_off = LH.plane_off; lv.lh_pitch = LH.pitch; }
+        if (R.band[3] >= 0) { const Band& HH = plan.bands[(size_t)R.band[3]]; lv.hh_off = HH.plane_off; lv.hh_pitch = HH.pitch; }
         plan.levels.push_back(lv);
       }
     }
@@ -429,10 +467,51 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
           plan.comps[c].bit_depth != plan.comps[0].bit_depth || plan.comps[c].is_signed != plan.comps[0].is_signed)
         return fail("the colour transform needs the first three components to have the same sub-sampling, bit depth and signedness");   // ojph_params_local.h:455-490
   (void)subsampled;
+  // Part 2: the ATK / DFS marker segments (what the reference's reader accepts, ojph_params.cpp:2596-2644, :2770-2866)
+  plan.atks.clear(); plan.dfss.clear();
+  for (uint32_t i = 0; i < OJPHGPU_MAX_ATK; ++i) {
+    ojphgpu_atk& a = p.atk[i];
+    if (a.index == 0) { memset(&a, 0, sizeof(a)); continue; }
+    if (a.index < 2) return fail("an ATK marker segment's index must be 2..255");
+    for (const AtkDef& o : plan.atks) if (o.index == a.index) return fail("two ATK marker segments with one index");
+    if (a.num_steps == 0 || a.num_steps > OJPHGPU_MAX_LIFT_STEPS) return fail("an ATK marker segment with no or too many lifting steps");
+    a.reversible = a.reversible ? 1 : 0;
+    if (a.reversible ? a.coeff_type > 1 : (a.coeff_type < 2 || a.coeff_type > 3)) return fail("ATK coefficient type does not fit the kernel");
+    AtkDef d; d.index = a.index; d.rev = a.reversible != 0; d.coeff_type = a.coeff_type; d.K = a.reversible ? 1.0f : a.K;
+    for (uint32_t k = 0; k < a.num_steps; ++k) {
+      ojphgpu_lift_step st = a.steps[k];
+      if (d.rev) { st.A = 0.0f; if (st.e < 0 || st.e > 62) return fail("ATK lifting step with an impossible shift"); }
+      else { st.a = st.b = st.e = 0; }
+      a.steps[k] = st; d.steps.push_back(st);
+    }
+    for (uint32_t k = a.num_steps; k < OJPHGPU_MAX_LIFT_STEPS; ++k) memset(&a.steps[k], 0, sizeof(a.steps[k]));
+    if (!d.rev && !(d.K > 0.0f)) return fail("ATK scaling factor must be positive");
+    plan.atks.push_back(d);
+  }
+  for (uint32_t i = 0; i < OJPHGPU_MAX_DFS; ++i) {
+    ojphgpu_dfs& f = p.dfs[i];
+    if (!f.used) { memset(&f, 0, sizeof(f)); continue; }
+    f.used = 1; f.reserved = 0;
+    if (f.index > 15) return fail("a DFS marker segment's index must be 0..15");            // :2620-2622
+    if (f.num_levels == 0 || f.num_levels > 32) return fail("a DFS marker segment describes 1..32 levels");
+    for (const DfsDef& o : plan.dfss) if (o.index == f.index) return fail("two DFS marker segments with one index");
+    DfsDef d; d.index = f.index;
+    for (uint32_t k = 0; k < f.num_levels; ++k) { if (f.types[k] > 3) return fail("unknown DFS level type"); d.types.push_back(f.types[k]); }
+    for (uint32_t k = f.num_levels; k < 32; ++k) f.types[k] = 0;
+    plan.dfss.push_back(d);
+  }
+  auto find_atk = [&](uint32_t idx) -> const AtkDef* { for (const AtkDef& a : plan.atks) if (a.index == idx) return &a; return nullptr; };
   // the COD's style
   plan.cod = CodStyle();
   plan.cod.L = p.num_decomps; plan.cod.lbw = lbw; plan.cod.lbh = lbh; plan.cod.rev = p.reversible != 0;
   plan.cod.causal = (p.reserved[0] & 1u) != 0;
+  if (p.wavelet == 1) return fail("the wavelet byte names an ATK marker segment: 2..255");
+  plan.cod.wavelet = p.wavelet;
+  if (p.wavelet >= 2) {                                      // param_cod::update_atk (ojph_params.cpp:1279-1297)
+    const AtkDef* a = find_atk(p.wavelet);
+    if (!a) return fail("the COD names an ATK marker segment that is not there");
+    plan.cod.rev = a->rev; p.reversible = a->rev ? 1 : 0;
+  }
   {
     uint32_t lpw = 15, lph = 15;
     if (p.precinct_w && p.precinct_h) {
@@ -461,8 +540,23 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     if (c >= p.num_comps || k.rank == 0) { memset(&k, 0, sizeof(k)); continue; }   // canonical form
     CodStyle& st = plan.coc[c];
     st.rank = k.rank; st.L = k.num_decomps; st.lbw = k.log_block_w; st.lbh = k.log_block_h; st.rev = k.reversible != 0;
-    k.reversible = st.rev ? 1 : 0; k.reserved[0] &= 1; k.reserved[1] = 0;      // reserved[0] bit 0: vertically causal (parser)
-    st.causal = k.reserved[0] != 0;
+    k.reserved[0] &= 0x9Fu;                                                     // bit 0: vertically causal (parser); bit 7 + bits 1..4: DFS
+    st.causal = (k.reserved[0] & 1u) != 0;
+    if (k.reserved[0] & 0x80u) {                                                // the decomposition comes from a DFS marker segment,
+      st.dfs = (k.reserved[0] >> 1) & 0xF;                                      // the number of levels from the COD (ojph_params_local.h:503-516)
+      bool found = false;
+      for (const DfsDef& f : plan.dfss) found = found || (int)f.index == st.dfs;
+      if (!found) return fail("a COC names a DFS marker segment that is not there");   // ojph_resolution.cpp:276-287
+      st.L = p.num_decomps; k.num_decomps = (uint8_t)p.num_decomps;
+    } else k.reserved[0] &= 1u;
+    if (k.reserved[1] == 1) return fail("the wavelet byte names an ATK marker segment: 2..255");
+    st.wavelet = k.reserved[1];
+    if (st.wavelet >= 2) {
+      const AtkDef* a = find_atk(st.wavelet);
+      if (!a) return fail("a COC names an ATK marker segment that is not there");
+      st.rev = a->rev;
+    }
+    k.reversible = st.rev ? 1 : 0;
     if (st.L > 32) return fail("too many decompositions");
     if (!block_ok(st.lbw, st.lbh)) return fail("code-block dimensions must be powers of two, 4..1024, area <= 4096");
     st.has_prec = k.has_precincts != 0;
@@ -538,16 +632,23 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
         tc.r.w = div_ceil(t.r.x0 + t.r.w, cg.dx) - tc.r.x0; tc.r.h = div_ceil(t.r.y0 + t.r.h, cg.dy) - tc.r.y0;
         tc.res.assign(L + 1, 0);
         // resolution rectangles, top down (ojph_resolution.cpp:302-330 with band 0)
+        // (a DFS marker segment may have a level halve one direction only, or none: ojph_resolution.cpp:302-395)
         std::vector<Rect> rr(L + 1);
+        std::vector<uint32_t> kinds(L + 1, 1), dsx(L + 1, 1), dsy(L + 1, 1);   // kind of the level that splits r; down-sampling of r against the component
         rr[L] = tc.r;
         for (uint32_t r = L; r > 0; --r) {
-          Rect a = rr[r], b;
-          b.x0 = (a.x0 + 1) >> 1; b.y0 = (a.y0 + 1) >> 1;
-          b.w = ((a.x0 + a.w + 1) >> 1) - b.x0; b.h = ((a.y0 + a.h + 1) >> 1) - b.y0;
+          const uint32_t kind = plan.level_kind(c, L - r + 1);
+          const bool hx = kind == 1 || kind == 2, hy = kind == 1 || kind == 3;
+          kinds[r] = kind;
+          Rect a = rr[r], b = a;
+          if (hx) { b.x0 = (a.x0 + 1) >> 1; b.w = ((a.x0 + a.w + 1) >> 1) - b.x0; }
+          if (hy) { b.y0 = (a.y0 + 1) >> 1; b.h = ((a.y0 + a.h + 1) >> 1) - b.y0; }
           rr[r - 1] = b;
+          dsx[r - 1] = dsx[r] * (hx ? 2u : 1u); dsy[r - 1] = dsy[r] * (hy ? 2u : 1u);
         }
         for (uint32_t r = 0; r <= L; ++r) {
-          Resolution R; R.tile = t.idx; R.comp = c; R.res = r; R.r = rr[r];
+          Resolution R; R.tile = t.idx; R.comp = c; R.res = r; R.r = rr[r]; R.kind = r ? kinds[r] : 1;
+          const bool hx = R.kind == 1 || R.kind == 2, hy = R.kind == 1 || R.kind == 3;
           const uint32_t lpw = st.lpw(r), lph = st.lph(r);       // this resolution's precinct size
           R.log_ppw = lpw; R.log_pph = lph;
           for (int i = 0; i < 4; ++i) R.band[i] = -1;
@@ -555,13 +656,14 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
           // (the raw plane of a resolution r > 0 -- res 0 lives in its LL band -- and the band planes get their place in
           // the arena from assign_planes, once the sample width of the component is known)
           uint32_t trx0 = R.r.x0, try0 = R.r.y0, trx1 = R.r.x0 + R.r.w, try1 = R.r.y0 + R.r.h;
-          uint32_t off = r > 0 ? 1 : 0;
+          const uint32_t xoff = (r > 0 && hx) ? 1 : 0, yoff = (r > 0 && hy) ? 1 : 0;   // subband::finalize_alloc x_off / y_off (ojph_subband.cpp:134-138)
           for (uint32_t b = (r ? 1 : 0); b < (r ? 4u : 1u); ++b) {
+            if (r > 0 && !(R.kind == 1 || (R.kind == 2 && b == 1) || (R.kind == 3 && b == 2))) continue;   // the bands this kind of level has
             Band B; B.tile = t.idx; B.comp = c; B.res = r; B.band = b;
             if (r > 0) {
-              B.r.x0 = (trx0 - (b & 1) + 1) >> 1; B.r.y0 = (try0 - (b >> 1) + 1) >> 1;
-              B.r.w = ((trx1 - (b & 1) + 1) >> 1) - B.r.x0;
-              B.r.h = ((try1 - (b >> 1) + 1) >> 1) - B.r.y0;
+              B.r = R.r;
+              if (hx) { B.r.x0 = (trx0 - (b & 1) + 1) >> 1; B.r.w = ((trx1 - (b & 1) + 1) >> 1) - B.r.x0; }
+              if (hy) { B.r.y0 = (try0 - (b >> 1) + 1) >> 1; B.r.h = ((try1 - (b >> 1) + 1) >> 1) - B.r.y0; }
             } else B.r = R.r;
             B.K_max = band_Kmax(plan, c, r, b);
             B.delta = 0.0f; B.delta_inv = 0.0f;
@@ -570,7 +672,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
               d /= (float)(1u << (31 - B.K_max));
               B.delta = d; B.delta_inv = 1.0f / d;
             }
-            B.xcb = std::min(lbw, lpw - off); B.ycb = std::min(lbh, lph - off);
+            B.xcb = std::min(lbw, lpw - xoff); B.ycb = std::min(lbh, lph - yoff);
             B.empty = (B.r.w == 0 || B.r.h == 0);
             B.nbx = B.nby = 0; B.first_block = (uint32_t)plan.blocks.size();
             B.plane_off = 0; B.pitch = 0;
@@ -602,11 +704,10 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
             R.npw = ((trx1 + (1u << lpw) - 1) >> lpw) - (trx0 >> lpw);
             R.nph = ((try1 + (1u << lph) - 1) >> lph) - (try0 >> lph);
             uint32_t xlb = (trx0 >> lpw) << lpw, ylb = (try0 >> lph) << lph;
-            uint32_t ds = 1u << (L - r);
             for (uint32_t y = 0; y < R.nph; ++y)
               for (uint32_t x = 0; x < R.npw; ++x) {
                 Precinct P; P.tile = t.idx; P.comp = c; P.res = r;
-                uint64_t ix = (uint64_t)ds * cg.dx * (xlb + (x << lpw)), iy = (uint64_t)ds * cg.dy * (ylb + (y << lph));
+                uint64_t ix = (uint64_t)dsx[r] * cg.dx * (xlb + (x << lpw)), iy = (uint64_t)dsy[r] * cg.dy * (ylb + (y << lph));
                 P.img_x = (uint32_t)std::max<uint64_t>(ix, t.r.x0);
                 P.img_y = (uint32_t)std::max<uint64_t>(iy, t.r.y0);
                 for (int i = 0; i < 4; ++i) P.cb[i] = Rect{0, 0, 0, 0};
@@ -618,7 +719,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
               const Band& B = plan.bands[(size_t)R.band[b]];
               if (B.empty) continue;
               uint32_t pc_l = (trx0 >> lpw) << lpw, pc_t = (try0 >> lph) << lph;
-              uint32_t xs = off, ys = off, coly = 0;
+              uint32_t xs = xoff, ys = yoff, coly = 0;       // subband::get_cb_indices x_shift / y_shift (ojph_subband.cpp:240-241)
               for (uint32_t y = 0; y < R.nph; ++y) {
                 uint32_t pcy0 = std::max(try0, pc_t + (y << lph));
                 uint32_t pcy1 = std::min(try1, pc_t + ((y + 1) << lph));
@@ -852,7 +953,15 @@ extern "C" int ojphgpu_plan_comp_style(const ojphgpu_plan* plan, uint32_t comp, 
   out[0] = st.L; out[1] = st.rev ? 1 : 0; out[2] = st.lbw; out[3] = st.lbh; out[4] = st.rank ? 1 : 0;
   out[5] = plan->plan.recon_decomps(comp);
   out[6] = plan->plan.nlt3[comp];
-  out[7] = comp < plan->plan.wide.size() ? plan->plan.wide[comp] : 0;      // the component takes the 64-bit sample path
+  out[7] = ((comp < plan->plan.wide.size() && plan->plan.wide[comp]) ? 1u : 0u)   // bit 0: the component takes the 64-bit sample path
+         | (plan->plan.general(comp) ? 2u : 0u);                                  // bit 1: ... the general lifting kernels (that, or Part 2)
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_plan_comp_lift(const ojphgpu_plan* plan, uint32_t comp, uint32_t level, ojphgpu_lift* out)
+{
+  if (!plan || !out || comp >= plan->plan.p.num_comps || level == 0) return OJPHGPU_E_INVALID;
+  *out = plan->plan.lift_of(comp, level);
   return OJPHGPU_OK;
 }
 
@@ -869,8 +978,16 @@ extern "C" int ojphgpu_plan_restrict_resolution(ojphgpu_plan* plan, uint32_t ski
   // the reconstructed components: sub-sampling grows by 2^skip_recon (ojph_params.cpp:930-946)
   const uint64_t X1 = (uint64_t)P.p.image_x0 + P.p.width, Y1 = (uint64_t)P.p.image_y0 + P.p.height;
   P.frame_elems = 0;
+  uint32_t ci = 0;
   for (CompGeo& g : P.comps) {
-    const uint64_t fx = (uint64_t)g.dx << P.skip_recon, fy = (uint64_t)g.dy << P.skip_recon;
+    // (with a DFS marker segment a skipped level may halve one direction only: param_dfs::get_res_downsamp, :2575-2593)
+    uint64_t fx = g.dx, fy = g.dy;
+    for (uint32_t d = 1; d <= P.skip_recon; ++d) {
+      const uint32_t kind = P.level_kind(ci, d);
+      if (kind == 1 || kind == 2) fx *= 2;
+      if (kind == 1 || kind == 3) fy *= 2;
+    }
+    ++ci;
     g.x0 = (uint32_t)((P.p.image_x0 + fx - 1) / fx); g.y0 = (uint32_t)((P.p.image_y0 + fy - 1) / fy);
     g.w = (uint32_t)((X1 + fx - 1) / fx) - g.x0; g.h = (uint32_t)((Y1 + fy - 1) / fy) - g.y0;
     g.frame_off = P.frame_elems;

@@ -50,6 +50,8 @@ struct Precinct {
 
 struct Resolution {
   uint32_t tile, comp, res;
+  uint32_t kind = 1;            // r > 0: what the level that splits this resolution transforms -- 1 both directions, 2 horizontal
+                                // only (bands: HL), 3 vertical only (LH), 0 nothing (no bands): DFS marker segment
   Rect r;
   uint32_t log_ppw, log_pph;
   uint32_t npw, nph;            // precinct grid
@@ -88,6 +90,8 @@ struct CodStyle {                // the COD, or the COC of one component, resolv
   uint32_t lbw = 6, lbh = 6;    // log2 of the nominal code-block size
   bool rev = false;
   bool causal = false;          // vertically causal code-block style (foreign codestreams; set by the parser)
+  uint32_t wavelet = 0;         // >= 2: the ATK marker segment with this index is the wavelet (rev follows it); 0: the Part-1 one `rev` names
+  int dfs = -1;                 // >= 0 (COC only): the DFS marker segment with this index defines the decomposition; L is the COD's
   bool has_prec = false;        // Scod / Scoc bit 0: precinct sizes are listed
   uint8_t pexp[36] = { 0 };     // PPx | PPy << 4 per resolution when has_prec
   uint32_t rank = 0;            // COC: creation order (1..); 0 = this is the COD
@@ -101,6 +105,9 @@ struct QuantSet {               // contents of a QCD / QCC marker segment (ojph_
   std::vector<uint16_t> q16;    // irreversible: exponent << 11 | mantissa
   bool present = false;         // QCC: the component has its own marker segment
 };
+
+struct AtkDef { uint32_t index; bool rev; uint32_t coeff_type; float K; std::vector<ojphgpu_lift_step> steps; };   // an ATK marker segment
+struct DfsDef { uint32_t index; std::vector<uint8_t> types; };                // a DFS marker segment: types[d - 1] of decomposition level d
 
 struct NltSeg { uint16_t comp; uint8_t bd, type; };   // an NLT marker segment as written (Cnlt 65535 = all components)
 
@@ -124,6 +131,23 @@ struct Plan {
   CodStyle cod;                  // the main header's COD
   std::vector<CodStyle> coc;     // per component; .rank != 0 = the component has a COC of its own
   const CodStyle& style(uint32_t comp) const { return comp < coc.size() && coc[comp].rank ? coc[comp] : cod; }
+  std::vector<AtkDef> atks;      // Part 2: the main header's ATK / DFS marker segments
+  std::vector<DfsDef> dfss;
+  const AtkDef* atk_of(uint32_t comp) const {
+    const uint32_t w = style(comp).wavelet;
+    if (w >= 2) for (const AtkDef& a : atks) if (a.index == w) return &a;
+    return nullptr;
+  }
+  // what decomposition level d (1 = the first one applied to the tile-component) of a component transforms
+  // (param_dfs::get_dwt_type, ojph_params.cpp:2539-2547): 1 both directions, 2 horizontal, 3 vertical, 0 nothing
+  uint32_t level_kind(uint32_t comp, uint32_t d) const {
+    const int k = style(comp).dfs;
+    if (k < 0) return 1;
+    for (const DfsDef& f : dfss) if ((int)f.index == k && !f.types.empty()) return f.types[std::min<size_t>(d, f.types.size()) - 1];
+    return 1;
+  }
+  // the component needs the general lifting kernels (kernels_lift.hip): a Part-2 wavelet or decomposition, or 64-bit samples
+  bool general(uint32_t comp) const { return style(comp).wavelet >= 2 || style(comp).dfs >= 0 || (comp < wide.size() && wide[comp]); }
   uint32_t max_decomps = 0;      // over the components
   // decompositions of a component that are synthesised / the top resolution whose blocks are decoded
   uint32_t recon_decomps(uint32_t comp) const { return style(comp).L - skip_recon; }
@@ -148,6 +172,8 @@ struct Plan {
   // components on the reference's 64-bit sample path (more than 32 bits of precision, param_qcd::propose_precision
   // ojph_params.cpp:1684-1706): int64 planes, the 64-bit block coder
   std::vector<uint8_t> wide; bool any_wide = false;
+  // the lifting kernel of a component's decomposition level d as the general kernels take it (elem: int32 / int64 / float)
+  ojphgpu_lift lift_of(uint32_t comp, uint32_t d) const;
   uint32_t max_block_bytes;
   std::string error;
 };

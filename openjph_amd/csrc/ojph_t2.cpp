@@ -66,7 +66,10 @@ void write_main_header(const Plan& P, ByteSink& s)
   const ojphgpu_params& p = P.p;
   s.u16(SOC);
   // SIZ (ojph_params.cpp:805-851); Rsiz = 0x4000: HTJ2K codestream
-  s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000 | (P.nlt.empty() ? 0 : 0x8200));   // RSIZ_EXT | RSIZ_NLT with NLT segments (:2168-2170)
+  // (Part-2 wavelets -- the reference never writes them: the extension flag and the capability bits of T.801 Table A.2 for
+  // arbitrary decompositions and arbitrary kernels)
+  const uint32_t part2 = (P.dfss.empty() ? 0u : 0x8020u) | (P.atks.empty() ? 0u : 0x8080u);
+  s.u16(SIZ); s.u16(38 + 3 * p.num_comps); s.u16(0x4000 | (P.nlt.empty() ? 0 : 0x8200) | part2);   // RSIZ_EXT | RSIZ_NLT with NLT segments (:2168-2170)
   s.u32(p.image_x0 + p.width); s.u32(p.image_y0 + p.height); s.u32(p.image_x0); s.u32(p.image_y0);
   s.u32(p.tile_w); s.u32(p.tile_h); s.u32(p.tile_x0); s.u32(p.tile_y0);
   s.u16(p.num_comps);
@@ -93,7 +96,8 @@ void write_main_header(const Plan& P, ByteSink& s)
   s.u16(CAP); s.u16(8); s.u32(0x00020000); s.u16(Ccap);
   // COD (ojph_params.cpp:1035-1078)
   auto spcod = [&](const CodStyle& st) {
-    s.u8(st.L); s.u8(st.lbw - 2); s.u8(st.lbh - 2); s.u8(0x40); s.u8(st.rev ? 1 : 0);
+    s.u8(st.dfs >= 0 ? (0x80u | (uint32_t)st.dfs) : st.L);  // (COC: a DFS marker segment defines the decomposition, ojph_params_local.h:613-618)
+    s.u8(st.lbw - 2); s.u8(st.lbh - 2); s.u8(0x40 | (st.causal ? 0x08 : 0)); s.u8(st.wavelet >= 2 ? st.wavelet : (st.rev ? 1 : 0));
     if (st.has_prec) for (uint32_t i = 0; i <= st.L; ++i) s.u8(st.pexp[i]);
   };
   s.u16(COD); s.u16(12 + (P.cod.has_prec ? 1 + P.cod.L : 0));
@@ -128,6 +132,32 @@ void write_main_header(const Plan& P, ByteSink& s)
     s.u16(QCC); s.u16(3 + cw + qbytes(q));
     if (cw == 1) s.u8(c); else s.u16(c);
     spqcd(q);
+  }
+  // Part 2: DFS and ATK marker segments, in the form param_dfs::read / param_atk::read take them (ojph_params.cpp:2596-2644,
+  // :2770-2866; T.801 A.3.4, A.3.5)
+  for (const DfsDef& f : P.dfss) {
+    const uint32_t n = (uint32_t)f.types.size();
+    s.u16(DFS); s.u16(5 + (n + 3) / 4); s.u16(f.index); s.u8(n);
+    for (uint32_t i = 0; i < n; i += 4) {
+      uint32_t v = 0;
+      for (uint32_t j = 0; j < 4 && i + j < n; ++j) v |= (uint32_t)(f.types[i + j] & 3u) << (6 - 2 * j);
+      s.u8(v);
+    }
+  }
+  for (const AtkDef& a : P.atks) {
+    const uint32_t n = (uint32_t)a.steps.size();
+    const uint32_t ct = a.rev ? (a.coeff_type == 0 ? 0u : 1u) : 2u;       // integers as written, irreversible coefficients as floats
+    const uint32_t cbytes = ct == 0 ? 1 : ct == 1 ? 2 : 4;
+    const uint32_t len = 2 + 2 + (a.rev ? 0 : cbytes) + 1 + n * (a.rev ? 1 + 2 + 1 + cbytes : 1 + cbytes);
+    s.u16(ATK); s.u16(len);
+    s.u16(a.index | (ct << 8) | 0x800u | (a.rev ? 0x1000u : 0u) | 0x4000u);   // whole-sample symmetric, even-indexed first
+    auto f32 = [&](float v) { uint32_t u; memcpy(&u, &v, 4); s.u32(u); };
+    if (!a.rev) f32(a.K);
+    s.u8(n);
+    for (const ojphgpu_lift_step& st : a.steps) {
+      if (a.rev) { s.u8((uint32_t)st.e); s.u16((uint32_t)(uint16_t)(int16_t)st.b); s.u8(1); if (ct == 0) s.u8((uint32_t)(uint8_t)(int8_t)st.a); else s.u16((uint32_t)(uint16_t)(int16_t)st.a); }
+      else { s.u8(1); f32(st.A); }
+    }
   }
   // NLT segments: the ALL_COMPS entry first, then the components' in creation order (ojph_params.cpp:2210-2235)
   for (const NltSeg& n : P.nlt) { s.u16(NLT); s.u16(6); s.u16(n.comp); s.u8(n.bd); s.u8(n.type); }
@@ -816,7 +846,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       if (layers != 1) return OJPHGPU_E_INVALID;
       if ((style & 0x40) == 0) return OJPHGPU_E_CODESTREAM;       // not HT code-blocks
       if (style & ~0x48u) return OJPHGPU_E_INVALID;               // only HT (+ vertically causal) styles
-      if (wt > 1) return OJPHGPU_E_INVALID;                       // ATK wavelets: not supported
+      p.wavelet = wt > 1 ? (uint8_t)wt : 0;                       // an ATK marker segment is the wavelet (build_plan finds it)
       p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
       p.reserved[0] = (style & 0x08u) ? 1u : 0u;                  // vertically causal context (SigProp of foreign streams)
       use_sop = scod & 2; use_eph = scod & 4;
@@ -860,10 +890,13 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       const uint32_t cw = p.num_comps < 257 ? 1 : 2;
       if (L < 8 + cw) return OJPHGPU_E_CODESTREAM;
       const uint32_t comp = cw == 1 ? r.u8() : r.u16();
-      const uint32_t scoc = r.u8(), nd = r.u8(), xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
-      if (nd & 0x80) return OJPHGPU_E_INVALID;                     // DFS-defined decomposition: Part 2, not supported
+      const uint32_t scoc = r.u8(), nd_byte = r.u8(), xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
+      // bit 7 of the decompositions byte: the decomposition is defined by a DFS marker segment (index in the low
+      // bits) and has as many levels as the COD says (param_cod::get_num_decompositions, ojph_params_local.h:503-516)
+      const bool dfs_defined = (nd_byte & 0x80u) != 0;
+      if (dfs_defined && !have_cod) return OJPHGPU_E_INVALID;      // (needs the COD's count: a COC in front of the COD is not handled)
+      const uint32_t nd = dfs_defined ? p.num_decomps : nd_byte;
       if (nd > 32 || xcb > 8 || ycb > 8 || xcb + ycb > 8 || (style & 0x40) != 0x40 || (style & 0xB7) != 0) return OJPHGPU_E_CODESTREAM;   // :1240-1249
-      if (wt > 1) return OJPHGPU_E_INVALID;                        // ATK wavelets: not supported
       if (L != 8 + cw + ((scoc & 1) ? 1 + nd : 0)) return OJPHGPU_E_CODESTREAM;
       if (comp < p.num_comps) {                                    // one for a component that does not exist is only reported (:803-808)
         if (comp >= OJPHGPU_MAX_COC_COMPS) return OJPHGPU_E_INVALID;   // per-component styles: first 16 components
@@ -871,7 +904,8 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         if (k.rank) return OJPHGPU_E_CODESTREAM;                   // two COCs for one component (:809-812)
         k.rank = (uint8_t)++num_cocs; k.reversible = wt == 1; k.num_decomps = (uint8_t)nd;
         k.log_block_w = (uint8_t)(xcb + 2); k.log_block_h = (uint8_t)(ycb + 2);
-        k.has_precincts = scoc & 1; k.reserved[0] = (style & 0x08u) ? 1 : 0;
+        k.has_precincts = scoc & 1; k.reserved[0] = (uint8_t)(((style & 0x08u) ? 1u : 0u) | (dfs_defined ? 0x80u | ((nd_byte & 0xFu) << 1) : 0u));
+        k.reserved[1] = wt > 1 ? (uint8_t)wt : 0;
         if (scoc & 1)
           for (uint32_t i = 0; i <= nd; ++i) {
             k.precinct_exps[i] = (uint8_t)r.u8();
@@ -889,8 +923,64 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         if (p.nlt_comp[comp] == 0) p.nlt_rank[comp] = (uint8_t)++num_nlts;
         p.nlt_comp[comp] = (uint8_t)(type + 1); p.nlt_bd[comp] = (uint8_t)bd;
       }
-    } else if (m == RGN || m == POC || m == PPM || m == DFS || m == ATK) {
-      return OJPHGPU_E_INVALID;                                    // Part-2 / unsupported markers
+    } else if (m == DFS) {                                  // param_dfs::read (ojph_params.cpp:2596-2644)
+      if (L < 5) return OJPHGPU_E_CODESTREAM;
+      const uint32_t sdfs = r.u16(), ids = r.u8();
+      if (sdfs > 15 || ids == 0) return OJPHGPU_E_CODESTREAM;
+      if (L != 5 + (ids + 3) / 4) return OJPHGPU_E_CODESTREAM;
+      ojphgpu_dfs* f = nullptr;
+      for (ojphgpu_dfs& o : p.dfs) if (!o.used) { f = &o; break; }
+      if (!f) return OJPHGPU_E_INVALID;                            // more DFS marker segments than the tables hold
+      f->used = 1; f->index = (uint8_t)sdfs; f->num_levels = (uint8_t)std::min<uint32_t>(ids, 32);
+      for (uint32_t i = 0; i < ids; i += 4) {
+        const uint32_t v = r.u8();
+        for (uint32_t j = 0; j < 4 && i + j < 32 && i + j < ids; ++j) f->types[i + j] = (uint8_t)((v >> (6 - 2 * j)) & 3u);
+      }
+    } else if (m == ATK) {                                  // param_atk::read (ojph_params.cpp:2770-2866)
+      if (L < 5) return OJPHGPU_E_CODESTREAM;
+      const uint32_t satk = r.u16();
+      const uint32_t idx = satk & 0xFF, ctype = (satk >> 8) & 7;
+      const bool ws = (satk & 0x800) != 0, rev = (satk & 0x1000) != 0, m_init0 = (satk & 0x2000) == 0, ws_ext = (satk & 0x4000) != 0;
+      if (idx < 2) return OJPHGPU_E_CODESTREAM;                    // :2785-2791
+      if (!m_init0 || !ws || !ws_ext || (rev && ctype >= 2)) return OJPHGPU_E_INVALID;   // what the reference refuses, too (:2793-2805)
+      ojphgpu_atk* a = nullptr;
+      for (ojphgpu_atk& o : p.atk) { if (o.index == idx) return OJPHGPU_E_CODESTREAM; if (!o.index && !a) a = &o; }
+      if (!a) return OJPHGPU_E_INVALID;
+      auto coeff_f = [&](float& out) -> bool {                      // read_coefficient(float) :2687-2746
+        if (ctype == 0) { out = (float)r.u8(); return true; }
+        if (ctype == 1) { out = (float)r.u16(); return true; }
+        if (ctype == 2) { const uint32_t v = r.u32(); memcpy(&out, &v, 4); return true; }
+        if (ctype == 3) { const uint64_t hi = r.u32(); const uint64_t v = (hi << 32) | r.u32(); double dd; memcpy(&dd, &v, 8); out = (float)dd; return true; }
+        if (ctype == 4) {                                          // 128-bit float: sign, exponent and the top of the mantissa
+          const uint64_t hi = r.u32(); const uint64_t v = (hi << 32) | r.u32(); r.u32(); r.u32();
+          int32_t e = (int32_t)((v >> 48) & 0x7FFF); e -= 16383; e += 127; e &= 0xFF; e <<= 23;
+          uint32_t i = ((uint32_t)(v >> 32) & 0x80000000u) | (uint32_t)e | (uint32_t)((v >> 25) & 0x007FFFFFu);
+          memcpy(&out, &i, 4); return true;
+        }
+        return false;
+      };
+      a->index = (uint8_t)idx; a->reversible = rev ? 1 : 0; a->coeff_type = (uint8_t)ctype; a->K = 1.0f;
+      if (!rev && !coeff_f(a->K)) return OJPHGPU_E_INVALID;
+      const uint32_t natk = r.u8();
+      if (natk == 0 || natk > OJPHGPU_MAX_LIFT_STEPS) return OJPHGPU_E_INVALID;
+      a->num_steps = (uint8_t)natk;
+      for (uint32_t k = 0; k < natk; ++k) {
+        ojphgpu_lift_step& st = a->steps[k];
+        if (rev) {
+          st.e = (int32_t)r.u8(); st.b = (int32_t)(int16_t)r.u16();
+          const uint32_t lc = r.u8();
+          if (lc != 1) return lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID;   // :2834-2839: one coefficient per step
+          st.a = ctype == 0 ? (int32_t)(int8_t)r.u8() : (int32_t)(int16_t)r.u16();
+        } else {
+          const uint32_t lc = r.u8();
+          if (lc != 1) return lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID;
+          if (!coeff_f(st.A)) return OJPHGPU_E_INVALID;
+        }
+      }
+      if (a->coeff_type > 3) a->coeff_type = 2;                    // (written again as floats)
+      if (r.pos != next) return OJPHGPU_E_CODESTREAM;              // "The length of an ATK marker segment is not correct"
+    } else if (m == RGN || m == POC || m == PPM) {
+      return OJPHGPU_E_INVALID;                                    // unsupported markers
     }
     if (r.bad) return OJPHGPU_E_CODESTREAM;                        // a field ran past its segment
     r.pos = next; r.lim = r.n;

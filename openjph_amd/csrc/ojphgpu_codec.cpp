@@ -261,10 +261,9 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)e->img_descs.p + b.img_first;
       rc = ojphgpu_dwt_forward_image_ex(s, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container, b.nc == 3);
-    } else if (b.wide) {                                    // 64-bit sample path: the general lifting kernels
-      const ojphgpu_lift k53 = lift_rev53_64();
-      rc = ojphgpu_dwt_forward_general(s, &k53, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, e->arena.p);
-    } else
+    } else if (b.general)                                   // 64-bit samples, Part-2 wavelets / decompositions: the general lifting kernels
+      rc = ojphgpu_dwt_forward_general(s, &b.k, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, e->arena.p);
+    else
       rc = ojphgpu_dwt_forward(s, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, e->arena.p);
     if (rc) return rc;
@@ -797,10 +796,9 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)d->img_descs.p + b.img_first;
       rc = ojphgpu_dwt_inverse_image_ex(ls, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container, b.nc == 3);
-    } else if (b.wide) {
-      const ojphgpu_lift k53 = lift_rev53_64();
-      rc = ojphgpu_dwt_inverse_general(ls, &k53, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, d->arena.p);
-    } else
+    } else if (b.general)
+      rc = ojphgpu_dwt_inverse_general(ls, &b.k, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, d->arena.p);
+    else
       rc = ojphgpu_dwt_inverse(ls, b.rev ? 1 : 0, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count,
                                b.max_w, b.max_h, d->arena.p);
     if (rc) return rc;

@@ -51,8 +51,9 @@ struct HostBuf {
 // nc = 3: the batch holds the top levels of the three colour components of every tile, as triples, and the
 // component transform is applied inside the DWT kernel (kernels_dwt.hip); group: 0 all components, 1 the colour
 // components (0..2), 2 the others -- how a depth is split when the colour transform is fused
-// wide: the levels of components on the 64-bit sample path (int64 planes: the general lifting kernels, kernels_lift.hip)
-struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool wide; };
+// general: the levels of ONE component that needs the general lifting kernels (kernels_lift.hip: a Part-2 wavelet or
+// decomposition, or 64-bit samples) -- k describes the level
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool general; ojphgpu_lift k; };
 
 // DWT descriptors grouped so that one launch handles every tile-component
 struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
@@ -64,7 +65,7 @@ inline bool in_group(uint32_t comp, int group) { return group == 0 || (group == 
 inline bool is_wide(const Plan& P, uint32_t comp) { return comp < P.wide.size() && P.wide[comp] != 0; }
 // samples deeper than 26 bits are converted by the conversion kernels, not inside the top DWT level (whose conversion
 // arithmetic was built and tested for the depths the 32-bit path had until round 4)
-inline bool deep(const Plan& P, uint32_t comp) { return P.comps[comp].bit_depth > 26 || is_wide(P, comp); }
+inline bool deep(const Plan& P, uint32_t comp) { return P.comps[comp].bit_depth > 26 || P.general(comp); }
 
 inline bool colour_fused(const Plan& P)
 {
@@ -74,11 +75,13 @@ inline bool colour_fused(const Plan& P)
   return !(off && off[0] && off[0] != '0');
 }
 
+// gen_comp < 0: the levels of the components the two built-in wavelets' kernels transform; >= 0: of that component alone
 template <typename F>
-void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, int group, bool wide, F f)
+void for_levels_of(const Plan& P, TileRange tr, uint32_t depth, bool rev, int group, int gen_comp, F f)
 {
   for (const ojphgpu_level_info& lv : P.levels) {
-    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev || !in_group(lv.comp, group) || is_wide(P, lv.comp) != wide) continue;
+    if (!tr.has(lv.tile) || P.style(lv.comp).rev != rev || !in_group(lv.comp, group)) continue;
+    if (gen_comp < 0 ? P.general(lv.comp) : (int)lv.comp != gen_comp) continue;
     const uint32_t L = P.recon_decomps(lv.comp);            // reduced-resolution decoding stops below the top levels
     if (L > depth && lv.res == L - depth) f(lv);
   }
@@ -91,26 +94,39 @@ uint32_t max_recon_decomps(const Plan& P)
   return m;
 }
 
+inline void push_level_desc(const ojphgpu_level_info& lv, std::vector<ojphgpu_dwt_desc>& descs, LevelBatch& b)
+{
+  ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
+  d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
+  d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
+  d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
+  descs.push_back(d);
+  b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
+}
+
 void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_desc>& descs, std::vector<LevelBatch>& batches)
 {
   descs.clear(); batches.clear();
   const uint32_t depths = max_recon_decomps(P);
   const bool fused = colour_fused(P);
-  for (uint32_t depth = 0; depth < depths; ++depth)
+  ojphgpu_lift none; memset(&none, 0, sizeof(none));
+  for (uint32_t depth = 0; depth < depths; ++depth) {
     for (int rev = 0; rev < 2; ++rev)
-    for (int wide = 0; wide < (rev ? 2 : 1); ++wide)
     for (int group = (fused && depth == 0) ? 1 : 0; group <= ((fused && depth == 0) ? 2 : 0); ++group) {
-      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1, group == 1 ? 3 : 1, group, wide != 0 };
-      for_levels_of(P, tr, depth, rev != 0, group, wide != 0, [&](const ojphgpu_level_info& lv) {
-        ojphgpu_dwt_desc d; memset(&d, 0, sizeof(d));
-        d.src_off = lv.src_off; d.ll_off = lv.ll_off; d.hl_off = lv.hl_off; d.lh_off = lv.lh_off; d.hh_off = lv.hh_off;
-        d.src_pitch = lv.src_pitch; d.ll_pitch = lv.ll_pitch; d.hl_pitch = lv.hl_pitch; d.lh_pitch = lv.lh_pitch;
-        d.hh_pitch = lv.hh_pitch; d.w = lv.w; d.h = lv.h; d.x_even = lv.x_even; d.y_even = lv.y_even;
-        descs.push_back(d);
-        b.count++; b.max_w = std::max(b.max_w, lv.w); b.max_h = std::max(b.max_h, lv.h);
-      });
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, rev != 0, -1, group == 1 ? 3 : 1, group, false, none };
+      for_levels_of(P, tr, depth, rev != 0, group, -1, [&](const ojphgpu_level_info& lv) { push_level_desc(lv, descs, b); });
       if (b.count) batches.push_back(b);
     }
+    for (uint32_t c = 0; c < P.p.num_comps; ++c) {            // components of the general lifting kernels: a batch each
+      if (!P.general(c)) continue;
+      const uint32_t L = P.recon_decomps(c);
+      if (L <= depth) continue;
+      // the level `depth` steps below the component's reconstructed top is decomposition level (skipped + depth + 1)
+      LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, P.style(c).rev, -1, 1, 0, true, P.lift_of(c, P.skip_recon + depth + 1) };
+      for_levels_of(P, tr, depth, P.style(c).rev, 0, (int)c, [&](const ojphgpu_level_info& lv) { push_level_desc(lv, descs, b); });
+      if (b.count) batches.push_back(b);
+    }
+  }
 }
 
 // Descriptors of the top DWT level of every component with the un-decomposed plane addressed inside
@@ -122,13 +138,13 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
   out.clear();
   if (P.any_nlt3 || (P.p.color_transform && !colour_fused(P))) return;   // those conversions live in the conversion kernels
   for (LevelBatch& b : batches) {
-    if (b.depth != 0 || b.count == 0 || b.wide) continue;
+    if (b.depth != 0 || b.count == 0 || b.general) continue;
     bool all_shallow = true;                                  // (a batch with a deep component keeps the conversion kernels)
-    for_levels_of(P, tr, 0, b.rev, b.group, false, [&](const ojphgpu_level_info& lv) { all_shallow = all_shallow && !deep(P, lv.comp); });
+    for_levels_of(P, tr, 0, b.rev, b.group, -1, [&](const ojphgpu_level_info& lv) { all_shallow = all_shallow && !deep(P, lv.comp); });
     if (!all_shallow) continue;
     b.img_first = (int)out.size();
     size_t k = 0;
-    for_levels_of(P, tr, 0, b.rev, b.group, false, [&](const ojphgpu_level_info& lv) {
+    for_levels_of(P, tr, 0, b.rev, b.group, -1, [&](const ojphgpu_level_info& lv) {
       ojphgpu_dwt_desc d = descs[b.first + k++];
       const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
       const CompGeo& g = P.comps[lv.comp];
@@ -167,8 +183,8 @@ bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       bool batch_deep = false;
       const int grp = colour_fused(P) ? (c < 3 ? 1 : 2) : 0;
       for (uint32_t o = 0; o < P.p.num_comps; ++o)
-        batch_deep = batch_deep || (P.style(o).rev == P.style(c).rev && in_group(o, grp) && !is_wide(P, o) && deep(P, o) && P.recon_decomps(o) > 0);
-      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0 || is_wide(P, c) || batch_deep) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+        batch_deep = batch_deep || (P.style(o).rev == P.style(c).rev && in_group(o, grp) && !P.general(o) && deep(P, o) && P.recon_decomps(o) > 0);
+      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0 || P.general(c) || batch_deep) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
@@ -355,15 +371,6 @@ struct ojphgpu_decoder {
   const void* o_cb_descs = nullptr; const void* o_data = nullptr; void* o_status = nullptr;
 };
 struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0; };   // kinds: see ht_decode_step2_launch; bit 5: blocks on the 64-bit sample path
-// the general lifting kernel description of the reversible 5/3 on 64-bit samples (param_atk::init_rev53, ojph_params.cpp:2883-2896)
-inline ojphgpu_lift lift_rev53_64()
-{
-  ojphgpu_lift k; memset(&k, 0, sizeof(k));
-  k.num_steps = 2; k.elem = 1; k.horz = 1; k.vert = 1; k.K = 1.0f;
-  k.steps[0].a = 1; k.steps[0].b = 2; k.steps[0].e = 2;
-  k.steps[1].a = -1; k.steps[1].b = 1; k.steps[1].e = 1;
-  return k;
-}
 int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks);
 void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);

@@ -15,7 +15,7 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
                 num_decomps=5, block=(64, 64), color_transform=False, tile=(0, 0),
                 prog_order="RPCL", qstep=-1.0, precinct=(0, 0), tlm=False, precincts=None,
                 downsampling=None, image_offset=(0, 0), tile_offset=(0, 0), tileparts="", bit_depths=None, signs=None,
-                qfactor=0, coc=None, nlt=None, qfactors=None):
+                qfactor=0, coc=None, nlt=None, qfactors=None, atk=None, dfs=None, wavelet=0):
     """qfactors: {component: (ctype, qfactor)} with ctype "Y", "Cb" or "Cr" -- param_qcd::set_qfactor(comp_idx,
     ctype, qfactor) calls in the order of the dict (a QCC per named component).
     nlt: {component or "all": 0 or 3} -- param_nlt::set_nonlinear_transform calls in the order of the
@@ -23,6 +23,12 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
     coc: {component: dict(reversible=, num_decomps=, block=(w, h), precincts=[(w, h), ...])} -- COC
     marker segments in the order of the dict (param_cod's comp_idx setters); whatever a dict leaves
     out keeps the reference's COC defaults (9/7, 5 decompositions, 64x64, no precincts), NOT the COD's.
+    Part 2 (the reference only READS these; this library also writes them, which is where the test codestreams come
+    from): atk = {index 2..255: dict(steps=[(a, b, e), ...] for a reversible kernel or [A, ...] + K= for an irreversible
+    one, synthesis order)} -- ATK marker segments; dfs = {index 0..15: [kind per decomposition level, 1 = the first one
+    applied: 1 both directions, 2 horizontal, 3 vertical, 0 none]} -- DFS marker segments; wavelet = the ATK index the
+    COD names (0: `reversible` decides); a coc entry may carry wavelet= and dfs= (a DFS index; the number of
+    decompositions is then the COD's).
     width/height: the image SIZE (the reference's extent is offset + size); downsampling: list of
     (dx, dy) per component (param_siz::set_component), default 1,1; tileparts: "", "R", "C" or "RC"
     (codestream::set_tilepart_divisions); bit_depths / signs: per-component lists where they differ
@@ -50,6 +56,24 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
         p.comp_sign[c] = 2 if sg else 1
     p.image_x0, p.image_y0 = image_offset
     p.tile_x0, p.tile_y0 = tile_offset
+    p.wavelet = int(wavelet)
+    for i, (idx, a) in enumerate((atk or {}).items()):
+        k = p.atk[i]
+        steps = a["steps"]
+        k.index, k.num_steps = int(idx), len(steps)
+        k.reversible = int(isinstance(steps[0], (tuple, list)))
+        k.coeff_type = int(a.get("coeff_type", 1 if k.reversible else 2))
+        k.K = float(a.get("K", 1.0))
+        for j, st in enumerate(steps):
+            if k.reversible:
+                k.steps[j].a, k.steps[j].b, k.steps[j].e = [int(v) for v in st]
+            else:
+                k.steps[j].A = float(st)
+    for i, (idx, kinds) in enumerate((dfs or {}).items()):
+        f = p.dfs[i]
+        f.used, f.index, f.num_levels = 1, int(idx), len(kinds)
+        for j, kd in enumerate(kinds):
+            f.types[j] = int(kd)
     for rank, (c, st) in enumerate((coc or {}).items()):
         if not 0 <= int(c) < 16:
             raise ValueError("per-component coding styles can be given for the first 16 components")
@@ -57,6 +81,9 @@ def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, revers
         k.rank = rank + 1
         k.reversible = int(bool(st.get("reversible", False)))
         k.num_decomps = int(st.get("num_decomps", 5))
+        if st.get("dfs") is not None:
+            k.reserved[0] |= 0x80 | (int(st["dfs"]) << 1)
+        k.reserved[1] = int(st.get("wavelet", 0))
         bw, bh = st.get("block", (64, 64))
         k.log_block_w, k.log_block_h = int(bw).bit_length() - 1, int(bh).bit_length() - 1
         pl = st.get("precincts")
@@ -167,7 +194,17 @@ class Plan:
         out = (C.c_uint32 * 8)()
         check(self._lib.ojphgpu_plan_comp_style(self.handle, comp, out))
         return dict(num_decomps=int(out[0]), reversible=bool(out[1]), log_block=(int(out[2]), int(out[3])),
-                    has_coc=bool(out[4]), recon_decomps=int(out[5]), nlt3=bool(out[6]), wide=bool(out[7]))
+                    has_coc=bool(out[4]), recon_decomps=int(out[5]), nlt3=bool(out[6]), wide=bool(out[7] & 1),
+                    general=bool(out[7] & 2))
+
+    def comp_lift(self, comp, level):
+        """the wavelet of decomposition level `level` (1 = the first applied) of a component, for the general lifting
+        form: dict(steps=[(a, b, e) | A, ...] in synthesis order, K, elem (0 int32, 1 int64, 2 float), horz, vert)"""
+        k = capi.Lift()
+        check(self._lib.ojphgpu_plan_comp_lift(self.handle, comp, level, C.byref(k)))
+        rev = k.elem != 2
+        steps = [(k.steps[i].a, k.steps[i].b, k.steps[i].e) if rev else float(k.steps[i].A) for i in range(k.num_steps)]
+        return dict(steps=steps, K=float(k.K), elem=int(k.elem), horz=bool(k.horz), vert=bool(k.vert))
 
     @property
     def frame_elems(self):

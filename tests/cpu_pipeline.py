@@ -35,6 +35,7 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
     revs = [plan.comp_style(c)["reversible"] for c in range(p.num_comps)]      # per component (COC)
     nlt3 = [plan.comp_style(c)["nlt3"] for c in range(p.num_comps)]
     wides = [plan.comp_style(c)["wide"] for c in range(p.num_comps)]
+    gens = [plan.comp_style(c)["general"] for c in range(p.num_comps)]
     arena = np.zeros(plan.arena_elems, np.uint32)
     lib = ob.lib()
     t_first, t_count = (0, plan.num_tiles) if tiles is None else tiles
@@ -81,8 +82,9 @@ def forward_stages(plan: Plan, image: np.ndarray, tiles=None):
         dt = _plane_dtype(rev, wides[int(lv["comp"])])
         src = np.ascontiguousarray(_view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt))
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
-        if dt == np.int64:                                       # gen_rev_vert_step64 / horz_ana64 (ojph_transform.cpp:261,415)
-            ll, hl, lh, hh = ob.dwt_fwd_gen(src, ob.REV53, x_even=xe, y_even=ye)
+        if gens[int(lv["comp"])]:                                # 64-bit samples (gen_rev_vert_step64 / horz_ana64, ojph_transform.cpp:261,415),
+            k = plan.comp_lift(int(lv["comp"]), plan.comp_style(int(lv["comp"]))["num_decomps"] - int(lv["res"]) + 1)   # ATK kernels, DFS levels
+            ll, hl, lh, hh = ob.dwt_fwd_gen(src, k["steps"], k["K"], k["horz"], k["vert"], xe, ye)
         else:
             ll, hl, lh, hh = (ob.dwt53_fwd if rev else ob.dwt97_fwd)(src, xe, ye)
         for name, b in (("ll", ll), ("hl", hl), ("lh", lh), ("hh", hh)):
@@ -243,12 +245,18 @@ def inverse_stages(plan: Plan, arena):
         dt = _plane_dtype(rev, styles[int(lv["comp"])]["wide"])
         xe, ye = bool(lv["x_even"]), bool(lv["y_even"])
         lw, hw, lh_, hh_ = ob.band_dims(w, h, xe, ye)
+        kind = int(lv["kind"])                                   # DFS: a level may leave a direction alone
+        if kind in (0, 3):
+            lw, hw = w, 0
+        if kind in (0, 2):
+            lh_, hh_ = h, 0
         ll = _view(arena, int(lv["ll_off"]), int(lv["ll_pitch"]), lw, lh_, dt)
         hl = _view(arena, int(lv["hl_off"]), int(lv["hl_pitch"]), hw, lh_, dt)
         lh = _view(arena, int(lv["lh_off"]), int(lv["lh_pitch"]), lw, hh_, dt)
         hh = _view(arena, int(lv["hh_off"]), int(lv["hh_pitch"]), hw, hh_, dt)
-        if dt == np.int64:
-            dst = ob.dwt_inv_gen(ll, hl, lh, hh, w, h, ob.REV53, x_even=xe, y_even=ye)
+        if styles[int(lv["comp"])]["general"]:
+            k = plan.comp_lift(int(lv["comp"]), styles[int(lv["comp"])]["num_decomps"] - int(lv["res"]) + 1)
+            dst = ob.dwt_inv_gen(ll, hl, lh, hh, w, h, k["steps"], k["K"], k["horz"], k["vert"], xe, ye)
         else:
             dst = (ob.dwt53_inv if rev else ob.dwt97_inv)(ll, hl, lh, hh, w, h, xe, ye)
         _view(arena, int(lv["src_off"]), int(lv["src_pitch"]), w, h, dt)[:] = dst
