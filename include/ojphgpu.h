@@ -621,6 +621,33 @@ int  ojphgpu_pack_bits(void* stream, const void* d_samples, void* d_packed, uint
 
 const char* ojphgpu_version(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * 8. One frame over several GPUs of the node, from one process (ojphgpu_multi.cpp)
+ * ---------------------------------------------------------------------------------------------
+ * Tiles are independent (every tile has an object tree of its own in the reference, ojph_codestream_local.cpp:113-180, and
+ * codestream::flush writes them one after the other, ojph_tile.cpp:584-610): a tiled frame shards by contiguous runs of
+ * tiles, device k of n taking tiles [k * T / n ...) -- the first T % n runs one tile longer -- with one host thread and one
+ * codec object per device and NO exchange between the devices while they code.  The only meeting point is the caller's
+ * thread: main header from everybody's Psot lengths, a prefix sum of the runs' lengths, and every device copies its
+ * tile-parts straight to its place in the caller's buffer (encode) / its tiles' rectangles to the caller's image (decode).
+ * A frame of one tile uses the first device only.  h_image: the frame as int32 planes (ojphgpu_plan_comp_info); host
+ * buffers should be pinned for the copies to run at link speed.  The same device may be listed more than once. */
+typedef struct ojphgpu_multi_encoder ojphgpu_multi_encoder;
+typedef struct ojphgpu_multi_decoder ojphgpu_multi_decoder;
+int  ojphgpu_multi_encoder_create(const ojphgpu_plan* plan, const int* devices, uint32_t num_devices, ojphgpu_multi_encoder** out);
+void ojphgpu_multi_encoder_destroy(ojphgpu_multi_encoder* enc);
+/* whole codestream (SOC .. EOC) into h_out; OJPHGPU_E_OVERFLOW with *out_len = the bytes needed when cap is too small */
+int  ojphgpu_multi_encode(ojphgpu_multi_encoder* enc, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len);
+/* how the frame was dealt out: workers (<= num_devices, <= tiles) and the tiles of each */
+int  ojphgpu_multi_encoder_workers(const ojphgpu_multi_encoder* enc, uint32_t* num_workers, uint32_t* tiles_per_worker, uint32_t cap);
+/* parses the codestream once (codestream::read_headers + read, with restrict_input_resolution when the skips are not 0) */
+int  ojphgpu_multi_decoder_create(const uint8_t* h_codestream, size_t len, int resilient, uint32_t skipped_res_for_data,
+                                  uint32_t skipped_res_for_recon, const int* devices, uint32_t num_devices, ojphgpu_multi_decoder** out);
+void ojphgpu_multi_decoder_destroy(ojphgpu_multi_decoder* dec);
+int  ojphgpu_multi_decoder_plan(ojphgpu_multi_decoder* dec, const ojphgpu_plan** plan);      /* owned by the decoder */
+/* the codestream the decoder was created for -> h_image; OJPHGPU_E_BLOCK when blocks failed and the decoder is not resilient */
+int  ojphgpu_multi_decode(ojphgpu_multi_decoder* dec, const uint8_t* h_codestream, size_t len, int32_t* h_image, uint32_t* failed_blocks);
+
 #ifdef __cplusplus
 }
 #endif

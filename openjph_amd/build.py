@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libojphgpu.so")
-SOURCES = ["ojph_plan.cpp", "ojph_t2.cpp", "ojph_pool.cpp", "ht_tables.cpp", "ojphgpu_codec.cpp", "ojphgpu_pipe.cpp",
+SOURCES = ["ojph_plan.cpp", "ojph_t2.cpp", "ojph_pool.cpp", "ht_tables.cpp", "ojphgpu_codec.cpp", "ojphgpu_pipe.cpp", "ojphgpu_multi.cpp",
            "kernels_dwt.hip", "kernels_lift.hip", "kernels_convert.hip", "kernels_assemble.hip", "kernels_pixels.hip", "kernels_ht_enc.hip", "kernels_ht_dec.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

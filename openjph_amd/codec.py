@@ -267,6 +267,77 @@ class Decoder:
                     ht_prep_ms=ht[0], ht_step1_ms=ht[1], ht_step2_ms=ht[2])
 
 
+class MultiEncoder:
+    """One frame over several GPUs of this process (ojphgpu_multi_encoder: include/ojphgpu.h section 8): contiguous runs
+    of tiles, one host thread + one encoder object per device, tile-parts copied from every GPU straight to their place
+    in one pinned host buffer.  devices: list of device numbers (a number may repeat)."""
+
+    def __init__(self, params=None, plan=None, devices=(0,)):
+        torch = _torch()
+        self.plan = plan if plan is not None else Plan(params)
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(self._lib.ojphgpu_multi_encoder_create(self.plan.handle, devs, len(devices), C.byref(self._h)), "multi_encoder_create")
+        self._out = torch.empty(max(self.plan.frame_elems * 4, 1 << 20) + (1 << 20), dtype=torch.uint8).pin_memory()
+        n, per = C.c_uint32(), (C.c_uint32 * 64)()
+        check(self._lib.ojphgpu_multi_encoder_workers(self._h, C.byref(n), per, 64), "multi_encoder_workers")
+        self.tiles_per_worker = [int(per[i]) for i in range(n.value)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ojphgpu_multi_encoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def encode(self, image, copy=True):
+        """image: int32 numpy array / pinned torch tensor in the frame layout -> the codestream (bytes; copy=False: a view
+        of the encoder's pinned buffer, valid until the next call)"""
+        torch = _torch()
+        t = image if hasattr(image, "data_ptr") else torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32))
+        n = C.c_size_t()
+        check(self._lib.ojphgpu_multi_encode(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(self._out.data_ptr()), self._out.numel(),
+                                             C.byref(n)), "multi_encode")
+        v = self._out[:n.value].numpy()
+        return v.tobytes() if copy else v
+
+
+class MultiDecoder:
+    """The decoding mirror of MultiEncoder (ojphgpu_multi_decoder)."""
+
+    def __init__(self, codestream: bytes, devices=(0,), resilient=False, skip_res=None):
+        torch = _torch()
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        self._cs = np.frombuffer(codestream, np.uint8)
+        a, b = (0, 0) if not skip_res else ((skip_res, skip_res) if isinstance(skip_res, int) else skip_res)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(self._lib.ojphgpu_multi_decoder_create(self._cs.ctypes.data, len(codestream), int(resilient), a, b, devs, len(devices),
+                                                     C.byref(self._h)), "multi_decoder_create")
+        ph = C.c_void_p()
+        check(self._lib.ojphgpu_multi_decoder_plan(self._h, C.byref(ph)), "multi_decoder_plan")
+        self.plan = Plan(handle=ph, owned=False)
+        self.resilient = resilient
+        self._img = torch.zeros(self.plan.frame_shape, dtype=torch.int32).pin_memory()
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ojphgpu_multi_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def decode(self, copy=True):
+        failed = C.c_uint32()
+        check(self._lib.ojphgpu_multi_decode(self._h, self._cs.ctypes.data, len(self._cs), C.c_void_p(self._img.data_ptr()),
+                                             C.byref(failed)), "multi_decode")
+        v = self._img.numpy()
+        return v.copy() if copy else v
+
+
 def encode(image: np.ndarray, device=0, **kw) -> bytes:
     """One-shot helper: image int32 [C,H,W]; keyword args as in plan.make_params (minus sizes)."""
     nc, h, w = image.shape

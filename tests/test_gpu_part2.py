@@ -32,9 +32,8 @@ def test_part2_codestreams_on_the_gpu(case):
         assert np.array_equal(dec, rdec)
     L0 = min(plan.comp_style(c)["num_decomps"] for c in range(nc))
     if L0 >= 1:                                             # reduced resolution: a skipped level may halve one direction only
-        d1 = codec.Decoder(want, skip_res=(1, 1)).decode()
+        d = codec.Decoder(want, skip_res=(1, 1))
+        d1 = d.plan.unpack_frame(d.decode())                # (components may come out in different sizes)
         w1, _ = cp.decode(want, skip=(1, 1))
-        if isinstance(w1, list):
-            assert all(np.array_equal(a, b) for a, b in zip(d1, w1))
-        else:
-            assert np.array_equal(d1, w1)
+        for c in range(nc):
+            assert np.array_equal(d1[c], w1[c]), "reduced resolution: component %d differs" % c
