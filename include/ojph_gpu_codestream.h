@@ -273,13 +273,22 @@ public:
 
   // GPU-path extras (not in the reference): device ordinal used by flush() / create()
   void set_device(int device);
-  // A restart()ed object codes a sequence of frames through a frame pipeline whose slots hold the frame in the narrowest
-  // container its samples fit (8 / 16 / 32 bits: half or a quarter of the int32 bytes cross PCIe).  By default flush()
-  // returns with the codestream in the file, as the reference's does.  enable_frame_pipelining(n >= 2): flush() only
-  // queues the frame -- upload, kernels, Tier-2 and download of frame k run while the application fills frame k + 1 --
-  // and its codestream is written to the outfile given to ITS write_headers() when a later write_headers() needs the slot,
-  // at drain(), or when the object is destroyed; close() then closes a queued frame's file only once it has been written.
-  // The outfile objects of queued frames must stay alive and open until then.
+  // several GPUs of the node for ONE frame: a tiled frame's tiles are dealt out to them in contiguous runs, one host
+  // thread and codec object per device (include/ojphgpu.h section 8; tiles are independent in the reference too,
+  // ojph_codestream_local.cpp:113-180); frames of one tile use the first device
+  void set_devices(const int* devices, ui32 num_devices);
+  // restart()ed sequences keep their frames in pinned slots; by default these hold int32 samples like the reference's
+  // line_buf.  true: the narrowest container the bit depth fits (8 / 16 bits: half or a quarter of the PCIe traffic) --
+  // samples outside the bit depth's range handed to exchange() then saturate, and so do the values pull() returns
+  void set_narrow_sample_containers(bool narrow);
+  // A restart()ed object codes a sequence of frames through a frame pipeline (pinned slots, persistent device objects;
+  // int32 slots unless set_narrow_sample_containers).  By default flush() returns with the codestream in the file, as
+  // the reference's does.  enable_frame_pipelining(n >= 2): flush() only queues the frame -- upload, kernels, Tier-2 and
+  // download of frame k run while the application fills frame k + 1 -- and its codestream is written to the outfile
+  // given to ITS write_headers() when a later write_headers() needs the slot or names the same outfile object, at
+  // drain(), at close() of that outfile (a closed file holds its codestream: the object may be opened again for the next
+  // frame right away), or when the codestream object is destroyed.  To keep frames in flight across frames, give every
+  // frame an outfile object of its own and close() it after drain().
   void enable_frame_pipelining(ui32 frames_in_flight = 4);
   void drain();
 

@@ -12,7 +12,7 @@
 static void usage() {
   printf("ojph_compress (GPU path) -i in.{pgm,ppm,yuv,raw} -o out.j2c [-reversible true|false] [-qstep f | -qfactor 1..100]\n"
          "  [-num_decomps n] [-block_size {w,h}] [-precincts {w,h}] [-prog_order LRCP|RLCP|RPCL|PCRL|CPRL]\n"
-         "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n]\n"
+         "  [-colour_trans true|false] [-tile_size {w,h}] [-tlm_marker true|false] [-device n | -devices n,n,...]\n"
          "  [-image_offset {x,y}] [-tile_offset {x,y}] [-tileparts R|C|RC] [-profile IMF|BROADCAST] [-com \"text\"]\n"
          "  raw input: -dims {w,h} -num_comps n -bit_depth b [-signed true|false] [-downsamp {x,y},{x,y},...]\n");
 }
@@ -54,6 +54,11 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     ojph::codestream cs;
     if (a.get("-device")) cs.set_device(atoi(a.get("-device")));
+    if (a.get("-devices")) {                        // a tiled frame over several GPUs (contiguous runs of tiles)
+      std::vector<int> devs;
+      for (long v : Args::numbers(a.get("-devices"))) devs.push_back((int)v);
+      if (!devs.empty()) cs.set_devices(devs.data(), (ojph::ui32)devs.size());
+    }
     ojph::param_siz siz = cs.access_siz();
     auto io = Args::numbers(a.get("-image_offset")), to = Args::numbers(a.get("-tile_offset"));
     const ojph::point image_offset(io.size() == 2 ? (unsigned)io[0] : 0, io.size() == 2 ? (unsigned)io[1] : 0);

@@ -9,7 +9,7 @@
 int main(int argc, char** argv) {
   Args a(argc, argv);
   const char* in = a.get("-i"); const char* out = a.get("-o");
-  if (!in || !out) { printf("ojph_expand (GPU path) -i in.j2c -o out.{pgm,ppm,yuv,raw} [-skip_res n] [-resilient true] [-device n]\n"); return -1; }
+  if (!in || !out) { printf("ojph_expand (GPU path) -i in.j2c -o out.{pgm,ppm,yuv,raw} [-skip_res n] [-resilient true] [-device n | -devices n,n,...]\n"); return -1; }
   try {
     const auto t0 = std::chrono::steady_clock::now();
     const bool verbose = getenv("OJPH_APP_TIMING") != nullptr;       // phase times on stderr
@@ -18,6 +18,11 @@ int main(int argc, char** argv) {
     };
     ojph::codestream cs;
     if (a.get("-device")) cs.set_device(atoi(a.get("-device")));
+    if (a.get("-devices")) {
+      std::vector<int> devs;
+      for (long v : Args::numbers(a.get("-devices"))) devs.push_back((int)v);
+      if (!devs.empty()) cs.set_devices(devs.data(), (ojph::ui32)devs.size());
+    }
     if (Args::to_bool(a.get("-resilient"))) cs.enable_resilience();
     ojph::j2c_infile file;
     file.open(in);

@@ -115,6 +115,10 @@ struct codestream_state {
   bool headers_written = false, headers_read = false, decoded = false;
   std::string profile;
   int device = 0;
+  // more than one device: a tiled frame is coded by all of them, each a contiguous run of tiles (include/ojphgpu.h section 8)
+  std::vector<int> devices;
+  ojphgpu_multi_encoder* menc = nullptr; ojphgpu_multi_decoder* mdec = nullptr;
+  ui32 skip_data = 0;
   outfile_base* outfile = nullptr;
   infile_base* infile = nullptr;
   ojphgpu_plan* plan = nullptr;
@@ -168,6 +172,8 @@ struct codestream_state {
   {
     if (enc) { ojphgpu_encoder_destroy(enc); enc = nullptr; }
     if (dec) { ojphgpu_decoder_destroy(dec); dec = nullptr; }
+    if (menc) { ojphgpu_multi_encoder_destroy(menc); menc = nullptr; }
+    if (mdec) { ojphgpu_multi_decoder_destroy(mdec); mdec = nullptr; }
     if (plan && plan != epipe_plan) ojphgpu_plan_destroy(plan);
     plan = nullptr;
     if (frame && !frame_of_pipe) { if (frame_pinned) (void)hipHostFree(frame); else free(frame); }
@@ -223,8 +229,11 @@ struct codestream_state {
     const si32* sp = stage[comp].data();
     const size_t at = coff[comp] + (size_t)line * cw[comp];
     const ui32 n = cw[comp];
-    if (pipe_bits == 8) { ui8* dp = slot + at; for (ui32 x = 0; x < n; ++x) dp[x] = (ui8)sp[x]; }
-    else { ui16* dp = (ui16*)slot + at; for (ui32 x = 0; x < n; ++x) dp[x] = (ui16)sp[x]; }
+    // a sample outside the container's range saturates (it cannot be carried; the int32 slots of the default setting carry it)
+    const bool sg = comps[comp].is_signed;
+    const si32 lo = sg ? -(1 << (pipe_bits - 1)) : 0, hi = sg ? (1 << (pipe_bits - 1)) - 1 : (1 << pipe_bits) - 1;
+    if (pipe_bits == 8) { ui8* dp = slot + at; for (ui32 x = 0; x < n; ++x) { const si32 v = sp[x] < lo ? lo : (sp[x] > hi ? hi : sp[x]); dp[x] = (ui8)v; } }
+    else { ui16* dp = (ui16*)slot + at; for (ui32 x = 0; x < n; ++x) { const si32 v = sp[x] < lo ? lo : (sp[x] > hi ? hi : sp[x]); dp[x] = (ui16)v; } }
   }
   void fetch_row(ui32 comp, ui32 line)
   {
@@ -236,8 +245,13 @@ struct codestream_state {
     if (pipe_bits == 8) { const ui8* sp = slot + at; if (sg) for (ui32 x = 0; x < n; ++x) dp[x] = (si8)sp[x]; else for (ui32 x = 0; x < n; ++x) dp[x] = sp[x]; }
     else { const ui16* sp = (const ui16*)slot + at; if (sg) for (ui32 x = 0; x < n; ++x) dp[x] = (si16)sp[x]; else for (ui32 x = 0; x < n; ++x) dp[x] = sp[x]; }
   }
-  int container_for_frame() const                        // the narrowest slot container the frame's samples fit
+  // The slots of a sequence's pipes hold int32 samples unless the application asked for narrow ones
+  // (codestream::set_narrow_sample_containers): only int32 carries every value the reference's si32 line_buf does --
+  // an out-of-range sample handed to exchange(), the 256 a lossy decode of an 8-bit component can come back with.
+  bool narrow = false;
+  int container_for_frame() const                        // the slot container of the frame's samples
   {
+    if (!narrow) return 32;
     ui32 deepest = 0;
     for (ui32 c = 0; c < p.num_comps && c < comps.size(); ++c) deepest = comps[c].bit_depth > deepest ? comps[c].bit_depth : deepest;
     return deepest <= 8 ? 8 : deepest <= 16 ? 16 : 32;
@@ -522,7 +536,13 @@ bool codestream::is_tilepart_division_at_resolutions() { return (state->p.reserv
 bool codestream::is_tilepart_division_at_components() { return (state->p.reserved[1] & 2u) != 0; }
 void codestream::request_tlm_marker(bool needed) { state->p.tlm = needed; }
 bool codestream::is_tlm_requested() { return state->p.tlm != 0; }
-void codestream::set_device(int device) { state->device = device; }
+void codestream::set_device(int device) { state->device = device; state->devices.clear(); }
+void codestream::set_devices(const int* devices, ui32 num_devices)
+{
+  state->devices.assign(devices, devices + (devices ? num_devices : 0));
+  if (!state->devices.empty()) state->device = state->devices[0];
+}
+void codestream::set_narrow_sample_containers(bool narrow) { state->narrow = narrow; }
 void codestream::enable_frame_pipelining(ui32 frames_in_flight)
 {
   state->drain();
@@ -673,11 +693,18 @@ void codestream::write_headers(outfile_base* file, const comment_exchange* comme
     }
     if (rc) ojph_error(0x00030F08, "the frame pipeline has no free slot (status %d)", rc);
     S.alloc_frame((si32*)slot);
+  } else if (S.devices.size() > 1) {                               // a tiled frame over several GPUs
+    rc = ojphgpu_multi_encoder_create(S.plan, S.devices.data(), (uint32_t)S.devices.size(), &S.menc);
+    if (rc) ojph_error(0x00030F08, "cannot create the GPU encoders (status %d): fewer GPUs than asked for?", rc);
+    S.alloc_frame();
   } else {
     rc = ojphgpu_encoder_create(S.plan, S.device, nullptr, &S.enc);
     if (rc) ojph_error(0x00030F08, "cannot create the GPU encoder (status %d): no GPU?", rc);
     S.alloc_frame();
   }
+  // a frame still queued for this very file object (enable_frame_pipelining, and the application re-opened the object for
+  // the next frame): its codestream is written before the object is used again
+  for (const codestream_state::Pending& pd : S.pending) if (pd.file == file) { S.drain(); break; }
   S.outfile = file;
   S.headers_written = true;
   S.cur_comp = 0; S.cur_line = 0; S.exhausted = false;
@@ -715,6 +742,17 @@ void codestream::flush()
     S.pending.push_back(codestream_state::Pending{ S.outfile, false });
     if (!S.pipelining) S.drain();                // the reference's contract: the codestream is in the file when flush() returns (:1163)
     return;
+  }
+  if (S.menc) {
+    size_t cap = S.frame_elems * 5 + (1u << 20), len = 0;                // (more than 5 bytes per sample: the second round below)
+    for (int round = 0; round < 2; ++round) {
+      std::unique_ptr<ui8[]> out(new ui8[cap]);
+      const int rc = ojphgpu_multi_encode(S.menc, S.frame, out.get(), cap, &len);
+      if (rc == OJPHGPU_E_OVERFLOW && round == 0) { cap = len + 16; continue; }
+      if (rc) ojph_error(0x00030F0B, "GPU encode failed (status %d)", rc);
+      if (S.outfile->write(out.get(), len) != len) ojph_error(0x00030071, "Error writing to file");
+      return;
+    }
   }
   size_t len = 0;
   int rc = ojphgpu_encode(S.enc, S.frame, nullptr, 0, &len);            // runs the GPU path; reports the codestream size
@@ -762,7 +800,7 @@ void codestream::restrict_input_resolution(ui32 skipped_res_for_data, ui32 skipp
                skipped_res_for_data, S.p.num_decomps);
   if (ojphgpu_plan_restrict_resolution(S.plan, skipped_res_for_data, skipped_res_for_recon) != OJPHGPU_OK)
     ojph_error(0x00030F0D, "the GPU path rejected the resolution restriction");
-  S.skip_recon = skipped_res_for_recon; S.restricted = true;
+  S.skip_recon = skipped_res_for_recon; S.skip_data = skipped_res_for_data; S.restricted = true;
 }
 
 void codestream::create()
@@ -793,7 +831,12 @@ void codestream::create()
     S.cur_comp = 0; S.cur_line = 0; S.exhausted = false;
     return;
   }
-  int rc = ojphgpu_decoder_create(S.plan, S.device, nullptr, &S.dec);
+  int rc;
+  if (S.devices.size() > 1)
+    rc = ojphgpu_multi_decoder_create(S.stream.data(), S.stream.size(), S.resilient ? 1 : 0, S.restricted ? S.skip_data : 0,
+                                      S.restricted ? S.skip_recon : 0, S.devices.data(), (uint32_t)S.devices.size(), &S.mdec);
+  else
+    rc = ojphgpu_decoder_create(S.plan, S.device, nullptr, &S.dec);
   if (rc) ojph_error(0x00030F0F, "cannot create the GPU decoder (status %d): no GPU?", rc);
   S.alloc_frame();
   S.cur_comp = 0; S.cur_line = 0; S.exhausted = false; S.decoded = false;
@@ -803,9 +846,10 @@ void codestream::create()
 line_buf* codestream::pull(ui32& comp_num)
 {
   codestream_state& S = *state;
-  if (!S.dec && !S.decoded) ojph_error(0x00030F10, "pull called before create");
+  if (!S.dec && !S.mdec && !S.decoded) ojph_error(0x00030F10, "pull called before create");
   if (!S.decoded) {
-    int rc = ojphgpu_decode(S.dec, S.stream.data(), S.stream.size(), S.frame);
+    int rc = S.mdec ? ojphgpu_multi_decode(S.mdec, S.stream.data(), S.stream.size(), S.frame, nullptr)
+                    : ojphgpu_decode(S.dec, S.stream.data(), S.stream.size(), S.frame);
     if (rc == OJPHGPU_E_BLOCK) { if (!S.resilient) ojph_error(0x000300A1, "Error decoding a codeblock"); }   // ojph_codeblock.cpp:214-224
     else if (rc) ojph_error(0x00030F12, "GPU decode failed (status %d)", rc);
     S.decoded = true;
@@ -828,9 +872,10 @@ void codestream::close()
   codestream_state& S = *state;
   if (S.infile) S.infile->close();
   if (S.outfile) {
-    bool queued = false;
-    for (codestream_state::Pending& pd : S.pending) if (pd.file == S.outfile) { pd.close_after = true; queued = true; }
-    if (!queued) S.outfile->close();
+    // a frame still queued for this file (enable_frame_pipelining): the application may open the same file object for
+    // the next frame right after this call, so the queue is written out now -- the codestream is in the file that is closed
+    for (const codestream_state::Pending& pd : S.pending) if (pd.file == S.outfile) { S.drain(); break; }
+    S.outfile->close();
   }
   S.infile = nullptr; S.outfile = nullptr;
 }

@@ -131,9 +131,65 @@ int main()
       for (unsigned i = 0; i < n; ++i) expect(fresh[i] == bytes_of(outs[i]), "a pipelined sequence writes the codestreams a fresh object writes");
     }
     {
+      // the reference's idiom with ONE outfile object for every frame: open, write_headers, ..., flush, close, open again.
+      // A queued frame must be in the file that close() closes, not in the next one
+      ojph::codestream cs;
+      cs.enable_frame_pipelining(3);
+      ojph::mem_outfile out;
+      for (unsigned i = 0; i < n; ++i) {
+        encode_frame(cs, seq[i], i, out);                                  // opens `out`, ends with flush() + close()
+        expect(fresh[i] == bytes_of(out), "one outfile object reused from frame to frame holds every frame's own codestream");
+        cs.restart();
+      }
+    }
+    {
+      // narrow slots (opt-in): the same codestreams; and with the default int32 slots a sample outside the bit depth's range
+      // is coded as it was given (the reference's si32 line_buf carries it), which a fresh object's one-shot path does too
+      ojph::codestream cs;
+      cs.set_narrow_sample_containers(true);
+      for (unsigned i = 0; i < n; ++i) {
+        ojph::mem_outfile out;
+        encode_frame(cs, seq[i], i, out);
+        expect(fresh[i] == bytes_of(out), "narrow slots: the codestream a fresh object writes");
+        cs.restart();
+      }
+    }
+    {
+      const Format C{ 96, 64, 1, 8, true, false };
+      auto encode_out_of_range = [&](ojph::codestream& cs, ojph::mem_outfile& out) {
+        configure(cs, C);
+        out.open();
+        cs.write_headers(&out);
+        ojph::ui32 next = 0;
+        ojph::line_buf* line = cs.exchange(nullptr, next);
+        for (unsigned y = 0; y < C.h; ++y) {
+          for (unsigned x = 0; x < C.w; ++x) line->i32[x] = (int)((x * 5 + y * 3) % 300) - 20;    // beyond [0, 255] on both sides
+          line = cs.exchange(line, next);
+        }
+        cs.flush(); cs.close();
+      };
+      ojph::codestream one; ojph::mem_outfile ref_out;
+      encode_out_of_range(one, ref_out);
+      ojph::codestream cs;
+      for (int k = 0; k < 3; ++k) {
+        ojph::mem_outfile out;
+        encode_out_of_range(cs, out);
+        expect(bytes_of(ref_out) == bytes_of(out), "out-of-range samples are coded as given, also from the second frame of a sequence on");
+        cs.restart();
+      }
+    }
+    {
       ojph::codestream cs;
       for (unsigned i = 0; i < n; ++i) {
         decode_and_check(cs, seq[i], i, fresh[i], i == 2 ? 1u : 0u);        // frame 2 at half resolution
+        cs.restart();
+      }
+    }
+    {
+      ojph::codestream cs;
+      cs.set_narrow_sample_containers(true);
+      for (unsigned i = 0; i < n; ++i) {
+        decode_and_check(cs, seq[i], i, fresh[i], 0u);
         cs.restart();
       }
     }

@@ -125,6 +125,27 @@ def test_facade_restart_codes_a_sequence():
 
 
 @pytest.mark.gpu
+def test_facade_and_cli_over_several_devices(tmp_path):
+    """tests/facade/multi_device.cpp (codestream::set_devices) and `ojph_compress / ojph_expand -devices 0,0`: one tiled
+    frame over several workers -- the same GPU listed more than once on this one-GPU box -- writes the single-device
+    codestream and decodes losslessly"""
+    exe = os.path.join(ROOT, "openjph_amd", "apps", "facade_multi_device")
+    r = run([exe])
+    assert r.returncode == 0 and b"all checks passed" in r.stdout, (r.stdout, r.stderr)
+    img = synth_image(1, 300, 420, 12, seed=9)
+    src = tmp_path / "in.pgm"
+    write_pnm(src, img, 12)
+    args = ["-reversible", "true", "-tile_size", "{128,96}"]
+    assert run([COMPRESS, "-i", str(src), "-o", str(tmp_path / "a.j2c")] + args).returncode == 0
+    r = run([COMPRESS, "-i", str(src), "-o", str(tmp_path / "b.j2c"), "-devices", "0,0,0"] + args)
+    assert r.returncode == 0, r.stdout
+    assert open(tmp_path / "a.j2c", "rb").read() == open(tmp_path / "b.j2c", "rb").read()
+    r = run([EXPAND, "-i", str(tmp_path / "b.j2c"), "-o", str(tmp_path / "back.pgm"), "-devices", "0,0"])
+    assert r.returncode == 0, r.stdout
+    assert np.array_equal(read_pnm(tmp_path / "back.pgm"), img)
+
+
+@pytest.mark.gpu
 def test_cli_raw_planar_12bit_irreversible(tmp_path):
     """the C3 family at a small size: planar .yuv, 12 bit, 9/7, qstep 0.001"""
     from tests import cpu_pipeline as cp
