@@ -65,7 +65,33 @@ def gather_bytes(payload, group=None, dst=0, device=None, as_tensors=False):
         q.wait()
     if as_tensors:
         return bufs, sizes
-    return [bytes(b.cpu().numpy().tobytes()) for b in bufs], sizes
+    return [bytes(v.numpy().tobytes()) for v in to_host(bufs)], sizes
+
+
+_PINNED = {}
+
+
+def to_host(bufs):
+    """uint8 tensors (on a device, or already on the host) -> host views, in order, inside ONE pinned buffer that is kept
+    from call to call: the copies run at link speed (a pageable destination, what Tensor.cpu() gives, went at 3 GB/s for
+    the 450 MB of a 16K frame -- 150 ms against the 3 ms the frame takes to code)"""
+    import torch
+    total = sum(int(b.numel()) for b in bufs)
+    if not any(b.is_cuda for b in bufs):
+        return [b for b in bufs]
+    host = _PINNED.get("buf")
+    if host is None or host.numel() < total:
+        host = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
+        _PINNED["buf"] = host
+    out, at = [], 0
+    for b in bufs:
+        n = int(b.numel())
+        v = host[at:at + n]
+        if n:
+            v.copy_(b, non_blocking=True)
+        out.append(v); at += n
+    torch.cuda.synchronize()
+    return out
 
 
 def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None, parts_per_tile=1):
