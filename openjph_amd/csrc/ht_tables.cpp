@@ -52,6 +52,10 @@ void build_ht_tables(HtTables& t)
         if (r_cq(r) == c_q && r_cwd(r) == (cwd & ((1 << r_len(r)) - 1)))
           t.dec_vlc[k][i] = (uint16_t)((r_rho(r) << 4) | (r_uoff(r) << 3) | (r_ek(r) << 12) | (r_e1(r) << 8) | r_len(r));
       }
+      const unsigned e = t.dec_vlc[k][i], rho = (e >> 4) & 15u, e1 = (e >> 8) & 15u, ek = (e >> 12) & 15u;
+      unsigned packed = (rho & (rho - 1u)) ? 0x100u : 0u;
+      for (int s = 0; s < 4; ++s) packed |= (((rho >> s) & 1u) + ((ek >> s) & 1u) + ((e1 >> s) & 1u)) << (2 * s);
+      t.dec_vlc32[k][i] = e | (packed << 16);
     }
   }
   // U-VLC prefix (T.814 table 3), indexed by the next 3 stream bits:

@@ -13,6 +13,11 @@ namespace ojphgpu {
 struct HtTables {
   uint16_t enc_vlc[2][2048];   // [(c_q << 8) | (rho << 4) | eps] -> (cwd << 8) | (len << 4) | e_k
   uint16_t dec_vlc[2][1024];   // [(c_q << 7) | 7 bits] -> e_k<<12 | e_1<<8 | rho<<4 | u_off<<3 | len
+  // the same entries with, in the upper half, what step 2 needs of them in 9 bits (the fused launch's 16-bit records):
+  // bits 16 + 2i, 17 + 2i: sample i of the quad -- 0 insignificant, 1 significant, 2 significant with its e_k bit, 3 with
+  // e_k and e_1 (e_1 is a subset of e_k, e_k of rho in every row of the standard's tables); bit 24: more than one sample
+  // significant (gamma of T.814, block_decoder32.cpp:1218)
+  uint32_t dec_vlc32[2][1024];
   uint16_t dec_uvlc0[320];     // initial quad row
   uint16_t dec_uvlc1[256];     // other rows
 };
@@ -37,10 +42,10 @@ bool dec_fuses();
 uint64_t ht_decode_fused_state_words(uint32_t n);
 uint32_t device_cus(int device);                          // compute units of that device (256 when the query fails)
 bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus);   // one launch for step 1 + step 2, or the separate launches
-uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus);  // workgroups of that launch = what its ticket counter grows by per run
+uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus);  // workgroups of that launch
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
                            void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
-                           uint32_t cus, uint32_t ticket_base);
+                           uint32_t cus);
 // the blocks of a range that are on the 64-bit sample path (ojph_decode_codeblock64): all their launches
 uint32_t ht_decode64_extra_aux_words(uint32_t len1);
 int ht_decode64_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_aux,

@@ -59,6 +59,7 @@
 
 namespace ojphgpu {
 __device__ uint16_t g_dec_vlc[2][1024];
+__device__ uint32_t g_dec_vlc32[2][1024];    // the same + the 9 bits step 2 wants, for the fused launch's 16-bit records (ht_tables.h)
 __device__ uint16_t g_dec_uvlc0[320];
 }
 
@@ -290,6 +291,11 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;   // pointers kept i
 // the bound (about a second of s_sleep(2) polls) only keeps a broken build from hanging the queue.
 constexpr uint32_t LDS_WAIT_SPINS = 1u << 23;
 constexpr uint32_t EV_WORDS = 44;          // <= 1024 quads + 256 initial-row pairs events = 40 words, + 2 of read-ahead
+// The event string lives in a RING of EV_RING words per lane: the producer never writes word cons + EV_AHEAD or beyond, the
+// chain never reads below word cons (EvRd: the word it may still fetch again is word idx = cons), so a word is overwritten
+// only once it is EV_RING - EV_AHEAD words behind what the chain reads.  (The whole string, 44 words per lane, was 45 KB of
+// the fused launch's workgroup: with the rows of records staged in LDS as well, only one workgroup fitted a CU.)
+constexpr uint32_t EV_RING = 8;
 __device__ __forceinline__ uint32_t ev_words_of(uint32_t QW, uint32_t QH)
 {
   const uint32_t w = (QW * QH + ((QW + 1u) >> 1) + 31u) / 32u + 2u;
@@ -330,7 +336,7 @@ __device__ __forceinline__ void mel_producer(const uint32_t* __restrict__ w, uin
       if (n <= 32u) { win |= (uint64_t)pre << (32u - n); n += 32u; ++idx; pre = w[idx < last ? idx : last]; }
       while (nev <= 31u && n >= 6u) mel_run(win, n, k, ev, nev);
       if (nev >= 32u) {
-        s_ev[wr * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++wr;
+        s_ev[(wr & (EV_RING - 1u)) * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++wr;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // LDS only: no wait on global memory
         s_prog[lane] = wr;
       }
@@ -349,7 +355,7 @@ struct EvRd {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       stuck = stuck || want >= avail;                        // cannot happen (the partner always progresses); never hang
     }
-    return ev[want * 64u + lane];
+    return ev[(want & (EV_RING - 1u)) * 64u + lane];
   }
   __device__ __forceinline__ void init(const lds_u32* e, volatile lds_u32* p, volatile lds_u32* c, uint32_t nwords, uint32_t l) {
     ev = e; prog = p; cons = c; last = nwords - 1u; lane = l; avail = 0; stuck = false;
@@ -392,11 +398,33 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 #endif
 constexpr uint32_t S2_ROWS = S2_ROWS_N, S2_MAX_PER_WAVE = 8;
 constexpr int S2_RINGS = 5;                   // fused launch: worker wavefronts with at most this many blocks keep a ring per block
-template <bool FUSED>
-__device__ __forceinline__ void store_rec(uint32_t* p, uint32_t a, uint32_t b)
+// The fused launch's records.  The separate launches keep a 32-bit record per quad, pair-major over the 64 blocks of a
+// chain wavefront (a chain store = 512 contiguous bytes) -- but a step-2 wavefront then reads 16 pieces of 8 bytes, 512
+// bytes apart, per quad row, and an agent-scope load fetches a whole sector for each: the launch read SIX times the
+// records it used (PMC, round 3: 0.60 GB of its 0.67 GB of reads).  The fused launch therefore keeps
+//   * 16 bits per quad: step 2 needs 9 bits of the table entry (dec_vlc32: 2 bits per sample + gamma) and u < 64,
+//     record = packed9 | u << 9;
+//   * in 16-byte pieces -- a QUARTER of a quad row (8 quads) of one block -- laid out [row][quarter][block of the 64]:
+//     the chain (a lane per block) collects a row's pair words in LDS ([pair][lane]: conflict free both ways) and at the
+//     end of the row stores them with four 16-byte agent-scope stores, each 1 KB contiguous over the wavefront (a quarter
+//     of the store instructions, every line written whole); a worker's load of a row touches 4 pieces instead of 16.
+// (Block-major -- a block's row as 64 contiguous bytes, a worker's row ONE piece -- was built as well: the workers alone
+// are as fast, 0.200 ms against 0.232 with the 32-bit records, but every lane of the chain then writes 16 bytes into a line
+// of its own, and with the workers' stores beside them those partial writes cost the launch 0.04 ms, 0.38 against 0.34.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t REC16_ROW_WORDS = 16;                                  // 32 quads x 16 bits
+__device__ __forceinline__ void flush_row16(const lds_u32* s_rec, uint32_t lane, uint32_t* dst)
 {
-  if (FUSED) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)a | ((unsigned long long)b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else store_pair(p, a, b);
+  u32x4 q[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    q[j].x = s_rec[(4 * j + 0) * 64 + lane]; q[j].y = s_rec[(4 * j + 1) * 64 + lane];
+    q[j].z = s_rec[(4 * j + 2) * 64 + lane]; q[j].w = s_rec[(4 * j + 3) * 64 + lane];
+  }
+  // (one asm: the sixteen words are read with one wait; agent scope = write through, like the atomic stores)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
+               "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1"
+               :: "v"(dst), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]) : "memory");
 }
 __device__ __forceinline__ void publish_rows(uint32_t* flag, uint32_t epoch, uint32_t rows, uint32_t lane)
 {
@@ -418,10 +446,16 @@ __device__ __forceinline__ void uvlc_extension(VlcRd& vlc, uint32_t& used, uint3
   if (c1) { u1 += (v & 0xFu) << 2; used += 4u; }
 }
 
-template <bool NARROW, bool FUSED = false, bool W64 = false, class VlcRd>
+// FUSED: `rec` = the block's first 16 bytes of quad row 0 in the 16-bit layout, s_vlc = the dec_vlc32 entries,
+// s_rec = the wavefront's staging area for one row of pair words (16 x 64 words of LDS).
+template <bool NARROW, bool FUSED = false, bool W64 = false, class VlcRd, class TblT>
 __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
-                                           const uint16_t* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0)
+                                           const TblT* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0,
+                                           lds_u32* s_rec = nullptr)
 {
+  static_assert(!FUSED || NARROW, "the fused launch's records are for blocks of at most 64 columns");
+  // the first quarter of row qy of the block in the 16-bit layout (see flush_row16)
+  auto row16 = [&](uint32_t qy_) { return rec + (size_t)qy_ * (64u * REC16_ROW_WORDS); };
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
   // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
   uint64_t sig_prev = 0;
@@ -461,14 +495,16 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       uint32_t u1 = 1u + (entry >> 3) + (tmp >> len);
       if (W64) { const uint32_t bias = mode == 0x100u ? 3u : 1u; uvlc_extension(vlc, used, u0, u1, bias, bias); }   // (kappa + what the encoder took off)
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
-      store_rec<FUSED>(rec + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
+      if (FUSED) s_rec[(qx >> 1) * 64u + vlc.lane] = (t0 >> 16) | (u0 << 9) | (t1 & 0xFFFF0000u) | (u1 << 25);
+      else store_pair(rec + (size_t)(qx >> 1) * REC_STRIDE, (uint32_t)t0 | (u0 << 16), (uint32_t)t1 | (u1 << 16));
     }
+    if (FUSED) flush_row16(s_rec, vlc.lane, row16(0));
     sig_prev = sig_cur;
   }
   // ---- other quad rows (:977-1089) ----
-  const uint16_t* tbl = s_vlc + 1024;
+  const TblT* tbl = s_vlc + 1024;
   for (uint32_t qy = 1; qy < QH; ++qy) {
-    uint32_t* row = rec + (size_t)qy * PW * REC_STRIDE;                 // quad pair px of this row: row + px * REC_STRIDE
+    uint32_t* row = rec + (size_t)qy * PW * REC_STRIDE;                 // quad pair px of this row: row + px * REC_STRIDE (not FUSED)
     const uint32_t* above = row - (size_t)PW * REC_STRIDE;
     auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
     uint32_t tleft = 0; uint64_t sig_cur = 0;
@@ -522,8 +558,10 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       used += ojphgpu::uvlc_pair_other_rows(v, t0 & 0x8u, t1 & 0x8u, u0, u1);
       if (W64) uvlc_extension(vlc, used, u0, u1, 0u, 0u);
       vlc.settle(); vlc.advance(used); PIN_WINDOW(vlc); vlc.prefetch(); mel.advance(ecnt); mel.prefetch();
-      store_rec<FUSED>(row + (size_t)(qx >> 1) * REC_STRIDE, t0 | (u0 << 16), t1 | (u1 << 16));
+      if (FUSED) s_rec[(qx >> 1) * 64u + vlc.lane] = (t0 >> 16) | (u0 << 9) | (t1 & 0xFFFF0000u) | (u1 << 25);
+      else store_pair(row + (size_t)(qx >> 1) * REC_STRIDE, (uint32_t)t0 | (u0 << 16), (uint32_t)t1 | (u1 << 16));
     }
+    if (FUSED) flush_row16(s_rec, vlc.lane, row16(qy));
     sig_prev = sig_cur;
     if (FUSED && ((qy + 1u) & (S2_ROWS - 1u)) == 0u) publish_rows(flag, epoch, qy + 1u, vlc.lane);
   }
@@ -692,7 +730,7 @@ __device__ __forceinline__ void raw_partner(const uint8_t* __restrict__ cb, uint
       // (a bounded number of runs per pass: a lane that needs many events must not keep the other 63 lanes' VLC words waiting)
       for (int it = 0; it < MEL_RUNS_PER_PASS && nev <= 31u && n >= 6u; ++it) mel_run(win, n, k, ev, nev);
       if (nev >= 32u) {
-        s_ev[ewr * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++ewr;
+        s_ev[(ewr & (EV_RING - 1u)) * 64u + lane] = (uint32_t)ev; ev >>= 32; nev -= 32u; ++ewr;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         s_eprog[lane] = ewr;
       }
@@ -708,7 +746,7 @@ __global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
 {
   __shared__ uint16_t s_vlc[2048];
   __shared__ uint16_t s_uvlc0[320];
-  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
+  __shared__ uint32_t s_ev_all[CH][EV_RING * 64];
   __shared__ uint32_t s_vr_all[CH][VR_WORDS * 64];
   __shared__ uint32_t s_ctl_all[CH][5][64];            // MEL words done / taken, VLC words done / wanted next, block done
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
@@ -772,7 +810,7 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
 {
   __shared__ uint16_t s_vlc[2048];
   __shared__ uint16_t s_uvlc0[320];
-  __shared__ uint32_t s_ev_all[CH][EV_WORDS * 64];
+  __shared__ uint32_t s_ev_all[CH][EV_RING * 64];
   __shared__ uint32_t s_prog_all[CH][64];
   __shared__ uint32_t s_done_all[CH][64];
   __shared__ uint32_t s_cons_all[CH][64];
@@ -847,6 +885,17 @@ __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
 // bottom-row exponents of the 64 columns (a byte each), 16 the MagSgn bits decoded so far, 17 a restart point of the
 // un-stuffer (bytes consumed, a multiple of 256), 18 the un-stuffed bits that point corresponds to, 19 != 0: the block failed.
 constexpr uint32_t S2_STATE_WORDS = 20;
+constexpr uint32_t TICKET_STRIDE = 32;        // words between the fused launch's ticket counters: a cache line each
+constexpr uint32_t TICKET_CU_WORDS = 8 * 256; // a counter per compute unit: 8 XCDs x (SE_ID, SH_ID, CU_ID of HW_REG_HW_ID)
+constexpr uint32_t TICKET_WORDS = TICKET_CU_WORDS + 9 * TICKET_STRIDE;   // those + a 64-bit counter per XCD + the workers' counter
+
+// fused launch: where (in words of the record scratch) the 16-bit records of block `bi`, quad row 0, first quarter, are -- its group of
+// 64 blocks starts where the 32-bit layout's does (scratch_cap = that + 2 (bi % 64), ojphgpu_ht_decode_layout)
+__device__ __forceinline__ uint32_t rec16_base(const ojphgpu_cb_desc& d, uint32_t bi)
+{
+  const uint32_t l = bi & 63u;
+  return d.scratch_cap - 2u * l + l * 4u;
+}
 
 // Step 2 of ONE code-block by one wavefront: quad rows [qy_begin, qy_end) -- the whole block for the plain kernel;
 // SLICED: a slice of rows, state from / to `state`, per-quad records read with agent scope (the fused kernel).
@@ -893,10 +942,15 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   const uint32_t st = SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi];
   const uint32_t len_b1 = cb[lcup - 1], len_b2 = cb[lcup >= 2u ? lcup - 2u : 0u];   // (a one-byte segment has failed in step 1; its bytes are not used)
   uint32_t ents[SLICED ? S2_ROWS : 1u];
-  if (SLICED) {
+  if (SLICED) {                                              // 16-bit records, [row][quarter][block] (flush_row16)
+    const uint16_t* r16 = reinterpret_cast<const uint16_t*>(quads + rec16_base(d, bi) + (size_t)qy_begin * (64u * REC16_ROW_WORDS) + ((uint32_t)lane >> 4) * 256u)
+                          + (((uint32_t)lane >> 1) & 7u);
+    constexpr uint32_t row_step = 2u * 64u * REC16_ROW_WORDS;     // (in 16-bit units)
+    // (no conditions: the layout has the rows of the tallest block of the 64 rounded up to whole slices, and all 32 quads
+    // of every row; what an idle lane or a row beyond the block brings is not looked at -- eight loads in flight, one wait)
 #pragma unroll
     for (uint32_t i = 0; i < S2_ROWS; ++i)
-      ents[i] = ((uint32_t)lane < W && qy_begin + i < qy_last) ? rec_at(qy_begin + i, (uint32_t)lane >> 1) : 0u;
+      ents[i] = (uint32_t)__hip_atomic_load(r16 + i * row_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (st != 0) {
     if (!SLICED || qy_begin == 0) zero_block();
@@ -999,10 +1053,12 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
         const uint32_t ncol = nc0 + (uint32_t)lane;
         ent_next = (nqy < qy_last && ncol < W) ? rec_at(nqy, ncol >> 1) : 0u;      // (never beyond the slice: those records may not exist yet)
       }
+      // SLICED: ent = packed9 | u << 9 (ht_tables.h: dec_vlc32), 0 for an idle lane
       const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
-      uint32_t U_q = ent >> 16;
+      uint32_t U_q = SLICED ? inf >> 9 : ent >> 16;
       if (qy > 0) {
-        uint32_t gamma = inf & 0xF0u; gamma &= gamma - 0x10u;                           // :1218
+        uint32_t gamma = SLICED ? inf & 0x100u : inf & 0xF0u;
+        if (!SLICED) gamma &= gamma - 0x10u;                                            // :1218
         uint32_t em;                      // max exponent over columns 2qx-1 .. 2qx+2 of the sample row above
         if (!wide) {
           const uint32_t pm = max(e_prev, from_pair(e_prev));
@@ -1017,9 +1073,14 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       }
       if (__ballot(act && U_q > mmsbp2) != 0ull) { bad = true; break; }                 // :1114,:1224
       // this lane's samples: n0 = (col, 2qy), n1 = (col, 2qy+1); quad bits 2*half and 2*half+1
-      const uint32_t sel = inf >> (2u * half);
-      const uint32_t m0 = (sel & 0x10u) ? U_q - ((sel >> 12) & 1u) : 0u;
-      const uint32_t m1 = (sel & 0x20u) ? U_q - ((sel >> 13) & 1u) : 0u;
+      // sg*: the sample is significant, ek* / eb*: its e_k / e_1 bit
+      const uint32_t sel = SLICED ? inf >> (4u * half) : inf >> (2u * half);
+      const uint32_t st0 = sel & 3u, st1 = (sel >> 2) & 3u;                  // (SLICED: the samples' two-bit states)
+      const bool sg0 = SLICED ? st0 != 0u : (sel & 0x10u) != 0u, sg1 = SLICED ? st1 != 0u : (sel & 0x20u) != 0u;
+      const uint32_t ek0 = SLICED ? st0 >> 1 : (sel >> 12) & 1u, ek1 = SLICED ? st1 >> 1 : (sel >> 13) & 1u;
+      const uint32_t eb0 = SLICED ? st0 & (st0 >> 1) : (sel >> 8) & 1u, eb1 = SLICED ? st1 & (st1 >> 1) : (sel >> 9) & 1u;
+      const uint32_t m0 = sg0 ? U_q - ek0 : 0u;
+      const uint32_t m1 = sg1 ? U_q - ek1 : 0u;
       const uint32_t tot = m0 + m1;
       const uint32_t incl = wave_incl_scan(tot);
       const uint32_t at = mpos + incl - tot;
@@ -1036,17 +1097,17 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       {
         const uint32_t ms_val = (uint32_t)win;
         uint32_t v_n = ms_val & ((1u << m0) - 1u);                                      // :1127-1133
-        v_n |= ((sel >> 8) & 1u) << m0;
+        v_n |= eb0 << m0;
         v_n |= 1u;
-        const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1))) & (uint32_t)(-(int32_t)((sel >> 4) & 1u));
+        const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1))) & (sg0 ? 0xFFFFFFFFu : 0u);
         out0 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       {
         const uint32_t ms_val = (uint32_t)(win >> m0);
         uint32_t v_n = ms_val & ((1u << m1) - 1u);
-        v_n |= ((sel >> 9) & 1u) << m1;
+        v_n |= eb1 << m1;
         v_n |= 1u;
-        const uint32_t keep = (uint32_t)(-(int32_t)((sel >> 5) & 1u));
+        const uint32_t keep = sg1 ? 0xFFFFFFFFu : 0u;
         const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1))) & keep;
         v1 = v_n & keep;
         out1 = raw_out ? val : dequantise(val, rev, shift, delta);
@@ -1123,16 +1184,25 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 //     slice needs stays in the wavefront's LDS: 80 bytes of state (bottom-row exponents, MagSgn position, where the
 //     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits
 //     (otherwise one ring per wavefront and a restart of the un-stuffer at the latest 256-byte boundary per slice).
-// Who plays which role is decided by a TICKET, not by blockIdx: every workgroup takes the next number from a counter when
-// it starts (one atomic per workgroup); numbers 0 .. n1-1 are the step-1 workgroups, the rest workers.  A worker therefore
-// only exists once every chain workgroup is RUNNING -- whatever order the eight XCDs' dispatchers hand workgroups out in, and
-// whatever else shares the chip (other streams' launches, a second decoder object's fused launch): whoever is waited for is
-// resident and makes progress, there is no deadlock and no dependence on dispatch order.  The waits are bounded all the
-// same, by TIME (s_memrealtime, 100 MHz; two seconds unless the host says otherwise): a wait that runs out does not fail its
-// block -- the worker writes the run's epoch into the RETRY word behind the block status array, and the host, when it
-// collects the verdicts of the run, decodes the frame again through the separate step 1 / step 2 launches
-// (ojphgpu_codec.cpp: fused_retry).  The same goes for a chain that gives up on its partner.  The counter never has to be
-// cleared: the host passes the value it had before the launch (it grows by the grid size per run).
+// Who plays which role is decided by TICKETS, not by blockIdx.  A workgroup asks where it runs (HW_REG_XCC_ID, HW_REG_HW_ID)
+// and counts on its COMPUTE UNIT's counter.  The first workgroup of the run on a CU takes a number from its XCD's counter and,
+// while that is within the XCD's share of the step-1 workgroups (numbers x, x + 8, ... below n1 for XCD x), plays step 1;
+// everyone else is a worker and takes its number from a device-wide counter.  Step-1 numbers are therefore taken as CUs
+// receive their first workgroup, one chain workgroup to a CU, and a worker waits only for workgroups that a free CU of the
+// right XCD is enough to start -- whatever order the dispatchers hand workgroups out in and whatever else shares the chip
+// (other streams' launches, a second decoder object's fused launch): no deadlock, no dependence on dispatch order.
+// (Measured forms, chains alone / whole launch, 8K frame: roles by blockIdx 0.21 / 0.31 ms.  ONE device-wide counter, the
+// first form of the tickets: 0.29 / 0.36 -- whose atomic arrives first is decided by distance to the counter's memory channel,
+// the first 97 of 509 workgroups sat on four of the eight XCDs, 48 of them on one (tools/micro/xcc_probe.hip), two chain
+// workgroups to a CU.  A counter per XCD: still 0.29 / 0.36 -- an XCD's 64 workgroups start within microseconds of each
+// other and the first 13 to arrive are a random 13, so on about ten CUs two chain workgroups share the SIMDs, and the launch
+// ends with its slowest chain.  Per CU, as here: see DESIGN.md.)  Nothing is cleared between runs: the CU words hold the
+// epoch of the last run that came by, the counters (epoch << 32) | count -- epoch must GROW from run to run on a scratch.
+// The waits are bounded all the same, by TIME (s_memrealtime, 100 MHz; two seconds unless the host says otherwise): a wait
+// that runs out does not fail its block -- the worker writes the run's epoch into the RETRY word behind the block status
+// array, and the host, when it collects the verdicts of the run, decodes the frame again through the separate step 1 / step 2
+// launches (ojphgpu_codec.cpp: fused_retry).  The same goes for a chain that gives up on its partner, and it is what would
+// happen on a device whose XCDs do not each start their share of the workgroups (a step-1 number nobody takes).
 // The XCDs' L2s are not coherent with each other: everything exchanged inside the launch (records, flags, block status)
 // is accessed with agent scope.  Flags carry the run's epoch, so nothing has to be cleared between runs.  Blocks wider
 // than 64 samples and blocks with refinement passes keep the separate launches, and so do frames where the one launch
@@ -1162,24 +1232,50 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
     uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg,
-    uint32_t ticket_off, uint32_t ticket_base, uint32_t wait_ticks)
+    uint32_t ticket_off, uint32_t xcd_mask, uint32_t wait_ticks)
 {
   // one LDS area, carved per role: the step-1 role's tables, event strings, VLC rings and mailboxes -- or the workers'
   // un-stuffing rings and block states
-  constexpr uint32_t EV_OFF = 1024 + 160, VR_OFF = EV_OFF + CH * EV_WORDS * 64, CTL_OFF = VR_OFF + CH * VR_WORDS * 64;
-  constexpr uint32_t CHAIN_WORDS = CTL_OFF + CH * 5 * 64;
+  constexpr uint32_t EV_OFF = 2048 + 160, VR_OFF = EV_OFF + CH * EV_RING * 64, CTL_OFF = VR_OFF + CH * VR_WORDS * 64;
+  constexpr uint32_t REC_OFF = CTL_OFF + CH * 5 * 64;                       // a row of pair words per chain wavefront (flush_row16)
+  constexpr uint32_t CHAIN_WORDS = REC_OFF + CH * REC16_ROW_WORDS * 64;
   constexpr uint32_t WORKER_WORDS = NR * RING_WORDS + S2_MAX_PER_WAVE * S2_STATE_WORDS;
   constexpr uint32_t LDS_WORDS = CHAIN_WORDS > WGW * WORKER_WORDS ? CHAIN_WORDS : WGW * WORKER_WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDS_WORDS];
-  uint16_t* const s_vlc = reinterpret_cast<uint16_t*>(s_mem);
-  uint16_t* const s_uvlc0 = reinterpret_cast<uint16_t*>(s_mem + 1024);
+  uint32_t* const s_vlc = s_mem;                            // dec_vlc32: 2 x 1024 entries
+  uint16_t* const s_uvlc0 = reinterpret_cast<uint16_t*>(s_mem + 2048);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // the workgroup's number in START order (see above)
-  if (threadIdx.x == 0) s_mem[0] = __hip_atomic_fetch_add(fstate + ticket_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
-  __syncthreads();
-  const uint32_t wgid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mem[0]);
-  __syncthreads();
+  uint32_t wgid = blockIdx.x;
+  if (!(dbg & 8u)) {                                        // (dbg 8, timing experiment: roles by workgroup index)
+    if (threadIdx.x == 0) {
+      uint32_t xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      const uint32_t x = xcc & xcd_mask, nx = xcd_mask + 1u;
+      uint32_t* tk = fstate + ticket_off;
+      // the run's number on a counter that is never cleared: the counter holds (epoch << 32) | count -- raised to this
+      // run's epoch first (a no-op for all but the first to come), then counted on
+      auto take = [&](uint32_t* c) -> uint32_t {
+        unsigned long long* c64 = reinterpret_cast<unsigned long long*>(c);
+        (void)__hip_atomic_fetch_max(c64, (unsigned long long)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (uint32_t)__hip_atomic_fetch_add(c64, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      // the first workgroup of this run on its compute unit (CU_ID, SH_ID, SE_ID within the XCD) finds another run's epoch there
+      const bool first = __hip_atomic_exchange(tk + x * 256u + ((hw >> 8) & 0xFFu), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+      uint32_t role = 0xFFFFFFFFu;
+      if (first) {                                          // a step-1 workgroup, if its XCD still needs one
+        const uint32_t t = take(tk + TICKET_CU_WORDS + x * TICKET_STRIDE);
+        if (t * nx + x < n1) role = t * nx + x;             // the XCD's share: numbers x, x + nx, ... below n1
+      }
+      if (role == 0xFFFFFFFFu) role = n1 + take(tk + TICKET_CU_WORDS + 8u * TICKET_STRIDE);   // a worker: numbered over the whole device
+      s_mem[0] = role;
+    }
+    __syncthreads();
+    wgid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mem[0]);
+    __syncthreads();
+  }
   uint32_t* const retry = reinterpret_cast<uint32_t*>(block_status + ((n + 3u) & ~3u));   // != the run's epoch: nothing to repeat
 
   if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
@@ -1202,7 +1298,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         uint32_t* state = wlds + NR * RING_WORDS + k * S2_STATE_WORDS;
         const uint32_t need = q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH;
         bool there = true;
-        if (d.len1 != 0 && d.num_passes != 0 && !((bi >> 6) == seen_cw && seen_rows >= need)) {
+        if (!(dbg & 2u) && d.len1 != 0 && d.num_passes != 0 && !((bi >> 6) == seen_cw && seen_rows >= need)) {   // (dbg 2: the workers alone, over the records of the run before)
           seen_cw = bi >> 6;
           seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + seen_cw, epoch, need, wait_ticks));
           there = seen_rows != 0u;
@@ -1222,14 +1318,15 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   }
 
   // ---- step 1: chains and their partners (ht_dec_step1_raw_kernel) ----
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc[0][0])[i];
+  if (dbg & 2u) return;                                     // (timing experiment: the workers alone)
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_vlc[i] = (&ojphgpu::g_dec_vlc32[0][0])[i];
   for (int i = threadIdx.x; i < 320; i += blockDim.x) s_uvlc0[i] = ojphgpu::g_dec_uvlc0[i];
   for (int i = threadIdx.x; i < CH * 5 * 64; i += blockDim.x) s_mem[CTL_OFF + i] = 0;
   __syncthreads();
   if (wv >= 3u * (uint32_t)CH) return;                      // (wavefronts the step-1 role has no use for)
   const bool chain = wv < (uint32_t)CH;
   const uint32_t set = wv % (uint32_t)CH;
-  lds_u32* s_ev = (lds_u32*)(s_mem + EV_OFF + set * EV_WORDS * 64);
+  lds_u32* s_ev = (lds_u32*)(s_mem + EV_OFF + set * EV_RING * 64);
   lds_u32* s_vr = (lds_u32*)(s_mem + VR_OFF + set * VR_WORDS * 64);
   uint32_t* const ctl = s_mem + CTL_OFF + set * 5 * 64;
   volatile lds_u32* s_eprog = (volatile lds_u32*)(ctl);
@@ -1272,10 +1369,10 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       else raw_partner<2>(cb, d.len1, scup, room, v0, v1, evw, s_ev, s_eprog, s_econs, s_vr, s_vprog, s_vcons, s_done, lane);
     } else {
       __hip_atomic_store(block_status + bi, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (what the last run left is not this run's)
-      uint32_t* rec = quads + d.scratch_cap;
+      uint32_t* rec = quads + rec16_base(d, bi);
       RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
       EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
-      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch);
+      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64));
       s_done[lane] = 1u;
       if (mel.stuck || vlc.stuck) st_agent(retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
     }
@@ -1757,10 +1854,13 @@ extern "C" int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h, uint32_t n, uint64_t
   uint64_t q = 0, a = 0;
   for (uint32_t g = 0; g < n; g += 64) {                      // the 64 blocks one step-1 wavefront advances together
     const uint32_t m = n - g < 64u ? n - g : 64u;
-    uint64_t pairs = 1;
+    uint64_t pairs = 1, qh_max = 0;
+    bool narrow = true;
     for (uint32_t l = 0; l < m; ++l) {
       const uint64_t qw = ((uint64_t)h[g + l].w + 1) >> 1, qh = ((uint64_t)h[g + l].h + 1) >> 1;
       pairs = std::max<uint64_t>(pairs, ((qw + 1) >> 1) * qh);
+      qh_max = std::max(qh_max, qh);
+      narrow = narrow && h[g + l].w <= 64u;
     }
     for (uint32_t l = 0; l < m; ++l) {
       if (q + 2 * l > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
@@ -1769,7 +1869,10 @@ extern "C" int ojphgpu_ht_decode_layout(ojphgpu_cb_desc* h, uint32_t n, uint64_t
       a += aux_words(h[g + l].len1);
       if (h[g + l].reversible & 4u) a += ms_words64(h[g + l].len1);      // 64-bit sample path: the flat MagSgn string as well
     }
-    q += (uint64_t)REC_STRIDE * pairs;
+    // the fused launch's 16-bit records of the same group share the area (rec16_base): whole slices of S2_ROWS quad rows,
+    // 64 blocks, 64 bytes per block and row
+    const uint64_t slices = (qh_max + S2_ROWS - 1) / S2_ROWS;
+    q += std::max<uint64_t>((uint64_t)REC_STRIDE * pairs, narrow ? slices * 64u * S2_ROWS * REC16_ROW_WORDS : 0u);
   }
   if (q > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return OJPHGPU_E_INVALID;
   *quad_elems = q; *aux_elems = a;
@@ -1840,7 +1943,7 @@ int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
 namespace ojphgpu { bool dec_uses_prep(); }
 namespace ojphgpu {
 // words of the scratch the fused launch needs for n blocks (flags of the chain wavefronts, then the per-block state)
-uint64_t ht_decode_fused_state_words(uint32_t n) { return (uint64_t)(((n + 63u) / 64u + 8u + 63u) & ~63u) + 64u; }   // one flag per chain wavefront
+uint64_t ht_decode_fused_state_words(uint32_t n) { return (uint64_t)(((n + 63u) / 64u + 8u + 63u) & ~63u) + TICKET_WORDS; }   // one flag per chain wavefront + the ticket counters
 static int dec_fuse_mode()                                // OJPHGPU_DEC_FUSED: 0 never, 1 (default) where it pays, 2 wherever it can
 {
   static const int v = [] { const char* e = getenv("OJPHGPU_DEC_FUSED"); return e ? atoi(e) : 1; }();
@@ -1878,7 +1981,7 @@ uint32_t device_cus(int device)
   if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c <= 0) { (void)hipGetLastError(); c = 256; }
   return (uint32_t)c;
 }
-// workgroups of the fused launch over n blocks: the ticket counter of the scratch grows by this per run
+// workgroups of the fused launch over n blocks
 uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus) { const FusedShape f = fused_shape(n, cus); return f.n1 + f.wwgs; }
 
 // Does ONE launch pay for these blocks?  Measured (profiles/r03_b_block_sizes*.txt, the C5 / C4 bench lines): it does
@@ -1895,12 +1998,13 @@ bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus)
 }
 // step 1 + step 2 of n blocks, all of them at most 64 samples wide, of one wavelet (kinds as in ht_decode_step2_launch)
 // and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch;
-// d_state: ht_decode_fused_state_words(n) words, zeroed once; ticket_base: what the scratch's ticket counter holds before
-// this launch (0 at first, + ht_decode_fused_grid(n, cus) per launch); d_block_status: n bytes + the 4-byte RETRY word behind
+// d_state: ht_decode_fused_state_words(n) words, zeroed once, and epoch > 0 growing from launch to launch on it (the
+// ticket counters carry it); d_blocks: the array ojphgpu_ht_decode_layout laid out, from its first element (the
+// 16-bit records of a block are found from its position among the 64 of its chain wavefront); d_block_status: n bytes + the 4-byte RETRY word behind
 // them at the next multiple of 4 (== epoch after the run: a wait ran out, decode the blocks again by the separate launches)
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
                            void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
-                           uint32_t cus, uint32_t ticket_base)
+                           uint32_t cus)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -1913,10 +2017,13 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
   // how long a worker waits for a chain before it asks for the repeat (OJPHGPU_FUSED_WAIT_MS; ticks of the 100 MHz clock)
   static const uint32_t wait_ticks = [] { const char* e = getenv("OJPHGPU_FUSED_WAIT_MS"); const long ms = e ? atol(e) : 2000; return (uint32_t)((ms < 1 ? 1 : ms > 40000 ? 40000 : ms) * 100000l); }();
-  const uint32_t ticket_off = (uint32_t)ht_decode_fused_state_words(n) - 64u;      // the last 64 words of the scratch: a cache line of its own
+  const uint32_t ticket_off = (uint32_t)ht_decode_fused_state_words(n) - TICKET_WORDS;   // the ticket counters: behind the flags
+  // XCDs of the device (32 compute units each; a partitioned device has fewer): their ids, masked, pick the counter
+  const uint32_t nx = cus >= 256u ? 8u : cus >= 128u ? 4u : cus >= 64u ? 2u : 1u;
+  const uint32_t xcd_mask = nx - 1u;
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
 #define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
-                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg, ticket_off, ticket_base, wait_ticks)
+                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg, ticket_off, xcd_mask, wait_ticks)
   // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
   static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
   if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }
@@ -1987,6 +2094,7 @@ namespace ojphgpu {
 int upload_dec_tables(const HtTables& t)
 {
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_vlc), t.dec_vlc, sizeof(t.dec_vlc)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_vlc32), t.dec_vlc32, sizeof(t.dec_vlc32)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_uvlc0), t.dec_uvlc0, sizeof(t.dec_uvlc0)) != hipSuccess) return -1;
   return 0;
 }

@@ -764,9 +764,8 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
     const int sp = T.begin(SP_STEP2, s);
     rc = ojphgpu::ht_decode_fused_launch(s, cbd, d->nblocks, data, (uint32_t*)d->quads.p, d->arena.p, status, (uint32_t*)d->fstate.p,
-                                         ++d->fused_epoch, d->max_block_h, d->kinds, d->cus, d->fused_tickets);
+                                         ++d->fused_epoch, d->max_block_h, d->kinds, d->cus);
     if (rc) return rc;
-    d->fused_tickets += ojphgpu::ht_decode_fused_grid(d->nblocks, d->cus);
     T.end(sp, s);
   } else {
     rc = decode_chains(d, s);

@@ -342,7 +342,6 @@ struct ojphgpu_decoder {
   DeviceBuf arena, image, dwt_descs, img_descs, cb_descs, conv_descs, data, status, quads, aux;
   DeviceBuf fstate; uint32_t fused_epoch = 0, max_block_h = 0;     // the fused step 1 + step 2 launch: its flags / per-block state, run counter
   uint32_t cus = 256;                               // compute units of `device` (the fused launch is shaped for them)
-  uint32_t fused_tickets = 0;                       // what the scratch's ticket counter holds (grows by the grid size per fused launch)
   // A fused launch whose workers gave up waiting (a chip held up for seconds by other work) marks the run in the RETRY word
   // behind the block status array; whoever collects the run's verdicts (ojphgpu_decoder_failed_blocks, the decoder pipe)
   // then repeats the run through the separate launches: last_* is what that repeat needs.
