@@ -397,6 +397,32 @@ constexpr uint32_t REC_STRIDE = 128;      // elements between consecutive quad p
 #define S2_ROWS_N 8
 #endif
 constexpr uint32_t S2_ROWS = S2_ROWS_N, S2_MAX_PER_WAVE = 8;
+// The fused launch's slices of quad rows, the same for every block of a launch whose tallest block has `max_qh` quad rows:
+// S2_ROWS rows each -- but the LAST S2_ROWS-row slice is cut at max_qh - 4 and max_qh - 2: when the chains end, the workers
+// have the last slice still to decode, and how long the launch goes on after its chains is that slice's length (measured,
+// 8K frame: chains end at 0.245 ms, the launch with a last slice of 8 rows at 0.32 ms).  Slice `sl` = quad rows [lo, hi).
+struct SliceSched {
+  uint32_t tail, b1, b2, max_qh, n;        // the last full-size boundary; the two cuts (== tail / b1 when they fall away); slices in all
+  __host__ __device__ explicit SliceSched(uint32_t mq) {
+    max_qh = mq ? mq : 1u;
+    tail = ((max_qh - 1u) / S2_ROWS) * S2_ROWS;
+    b1 = max_qh > tail + 4u ? max_qh - 4u : tail;
+    b2 = max_qh > b1 + 2u ? max_qh - 2u : b1;
+    n = tail / S2_ROWS + 1u + (b1 > tail ? 1u : 0u) + (b2 > b1 ? 1u : 0u);
+  }
+  __host__ __device__ void bounds(uint32_t sl, uint32_t& lo, uint32_t& hi) const {
+    const uint32_t full = tail / S2_ROWS;
+    if (sl < full) { lo = sl * S2_ROWS; hi = lo + S2_ROWS; return; }
+    uint32_t j = sl - full;                // pieces of [tail, max_qh): [tail, b1) [b1, b2) [b2, max_qh), the empty ones left out
+    lo = tail;
+    if (b1 > tail) { if (j == 0u) { hi = b1; return; } --j; lo = b1; }
+    if (b2 > b1) { if (j == 0u) { hi = b2; return; } --j; lo = b2; }
+    hi = max_qh;
+  }
+  __host__ __device__ bool publishes_after(uint32_t rows) const {   // rows = quad rows complete; (the last rows are published by the wavefront's end)
+    return rows < max_qh && (rows % S2_ROWS == 0u || (rows == b1 && b1 > tail) || (rows == b2 && b2 > b1));
+  }
+};
 constexpr int S2_RINGS = 5;                   // fused launch: worker wavefronts with at most this many blocks keep a ring per block
 // The fused launch's records.  The separate launches keep a 32-bit record per quad, pair-major over the 64 blocks of a
 // chain wavefront (a chain store = 512 contiguous bytes) -- but a step-2 wavefront then reads 16 pieces of 8 bytes, 512
@@ -426,10 +452,23 @@ __device__ __forceinline__ void flush_row16(const lds_u32* s_rec, uint32_t lane,
                "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1"
                :: "v"(dst), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]) : "memory");
 }
+#ifdef FUSED_TIMELINE
+__device__ uint32_t g_tl_pub[1024 * 8];       // chain wavefront cw, publication k (8 quad rows each): when (s_memrealtime) -- before and after the wait for the stores
+__device__ uint32_t* g_tl_flags;
+#endif
 __device__ __forceinline__ void publish_rows(uint32_t* flag, uint32_t epoch, uint32_t rows, uint32_t lane)
 {
+#ifdef FUSED_TIMELINE
+  const uint32_t tl_a = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the record stores of these rows have completed
-  if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) st_agent(flag, (epoch << 16) | rows);
+  if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+    st_agent(flag, (epoch << 16) | rows);
+#ifdef FUSED_TIMELINE
+    const uint32_t k = rows == 0xFFFFu ? 7u : (rows >> 3) - 1u;
+    if (k < 8u) { g_tl_pub[((flag - g_tl_flags) & 1023u) * 8u + k] = (uint32_t)__builtin_amdgcn_s_memrealtime(); if (k < 4u) g_tl_pub[((flag - g_tl_flags) & 1023u) * 8u + 4u + k] = tl_a; }
+#endif
+  }
 }
 
 // W64: the block is on the 64-bit sample path (ojph_decode_codeblock64): a decoded u above 32 -- before the initial
@@ -451,7 +490,7 @@ __device__ __forceinline__ void uvlc_extension(VlcRd& vlc, uint32_t& used, uint3
 template <bool NARROW, bool FUSED = false, bool W64 = false, class VlcRd, class TblT>
 __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
                                            const TblT* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0,
-                                           lds_u32* s_rec = nullptr)
+                                           lds_u32* s_rec = nullptr, SliceSched sched = SliceSched(S2_ROWS))
 {
   static_assert(!FUSED || NARROW, "the fused launch's records are for blocks of at most 64 columns");
   // the first quarter of row qy of the block in the 16-bit layout (see flush_row16)
@@ -563,7 +602,7 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
     }
     if (FUSED) flush_row16(s_rec, vlc.lane, row16(qy));
     sig_prev = sig_cur;
-    if (FUSED && ((qy + 1u) & (S2_ROWS - 1u)) == 0u) publish_rows(flag, epoch, qy + 1u, vlc.lane);
+    if (FUSED && sched.publishes_after(qy + 1u)) publish_rows(flag, epoch, qy + 1u, vlc.lane);
   }
 }
 
@@ -885,9 +924,17 @@ __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
 // bottom-row exponents of the 64 columns (a byte each), 16 the MagSgn bits decoded so far, 17 a restart point of the
 // un-stuffer (bytes consumed, a multiple of 256), 18 the un-stuffed bits that point corresponds to, 19 != 0: the block failed.
 constexpr uint32_t S2_STATE_WORDS = 20;
+
+// -DFUSED_TIMELINE (tools/r4_timeline.py; never in the product build): every wavefront of the fused launch leaves, per
+// run, 12 words in g_tl -- role, where it ran, when it started / ended (s_memrealtime, 100 MHz), and for a worker how
+// long it waited for chains and when it finished each slice of its blocks
+#ifdef FUSED_TIMELINE
+__device__ uint32_t g_tl[8192 * 12];
+__device__ __forceinline__ uint32_t tl_now() { return (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+#endif
 constexpr uint32_t TICKET_STRIDE = 32;        // words between the fused launch's ticket counters: a cache line each
 constexpr uint32_t TICKET_CU_WORDS = 8 * 256; // a counter per compute unit: 8 XCDs x (SE_ID, SH_ID, CU_ID of HW_REG_HW_ID)
-constexpr uint32_t TICKET_WORDS = TICKET_CU_WORDS + 9 * TICKET_STRIDE;   // those + a 64-bit counter per XCD + the workers' counter
+constexpr uint32_t TICKET_WORDS = TICKET_CU_WORDS + 2 * TICKET_STRIDE;   // those + the 64-bit counters of the step-1 and the worker numbers
 
 // fused launch: where (in words of the record scratch) the 16-bit records of block `bi`, quad row 0, first quarter, are -- its group of
 // 64 blocks starts where the 32-bit layout's does (scratch_cap = that + 2 (bi % 64), ojphgpu_ht_decode_layout)
@@ -903,8 +950,11 @@ template <int TX, int WD, bool SLICED, bool KEEP = false>
 __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t bi, const uint8_t* __restrict__ data,
                                             const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef,
                                             uint8_t* __restrict__ block_status, uint32_t* ring, uint8_t* s_exp_w,
-                                            int lane, uint32_t qy_begin, uint32_t qy_end, uint32_t* state)
+                                            int lane, uint32_t qy_begin, uint32_t qy_end, uint32_t* state, bool prepare = false)
 {
+  // KEEP (a ring per block): the slices are preceded by ONE call with `prepare` set, made before the worker waits for
+  // anything -- the first MagSgn bytes do not depend on the chain, so the block's ring is cleared and filled and its state
+  // set up while the chains work on their first rows; every slice, the first included, then goes on from that state.
   const uint32_t W = d.w, H = d.h, pitch = d.pitch;
   if (W == 0 || H == 0) return;
   uint32_t* dst = coef + d.coef_off;
@@ -918,7 +968,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   };
   static_assert(!SLICED || WD == 1, "slices are for blocks of at most 64 columns");
   if (d.len1 == 0 || d.num_passes == 0) {
-    if (!SLICED || qy_begin == 0) zero_block();
+    if ((!SLICED || qy_begin == 0) && !prepare) zero_block();
     return;
   }
   const uint32_t missing_msbs = d.missing_msbs;
@@ -939,18 +989,20 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   // SLICED: everything the slice needs from memory is requested at once -- the block's verdict, the length bytes and
   // the records of ALL its quad rows (they are complete: the chain has published them) -- one round trip per slice where
   // a record fetched one row ahead made it one per row (an agent-scope load takes longer than a row's arithmetic).
-  const uint32_t st = SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi];
+  if (KEEP && prepare && check_block(d, cb) == 0u) return;    // (step 1 fails this block; its slices stop at the verdict)
+  const uint32_t st = (KEEP && prepare) ? 0u : SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi];
   const uint32_t len_b1 = cb[lcup - 1], len_b2 = cb[lcup >= 2u ? lcup - 2u : 0u];   // (a one-byte segment has failed in step 1; its bytes are not used)
   uint32_t ents[SLICED ? S2_ROWS : 1u];
-  if (SLICED) {                                              // 16-bit records, [row][quarter][block] (flush_row16)
+  if (SLICED && !(KEEP && prepare)) {                                              // 16-bit records, [row][quarter][block] (flush_row16)
     const uint16_t* r16 = reinterpret_cast<const uint16_t*>(quads + rec16_base(d, bi) + (size_t)qy_begin * (64u * REC16_ROW_WORDS) + ((uint32_t)lane >> 4) * 256u)
                           + (((uint32_t)lane >> 1) & 7u);
     constexpr uint32_t row_step = 2u * 64u * REC16_ROW_WORDS;     // (in 16-bit units)
-    // (no conditions: the layout has the rows of the tallest block of the 64 rounded up to whole slices, and all 32 quads
-    // of every row; what an idle lane or a row beyond the block brings is not looked at -- eight loads in flight, one wait)
+    // (no conditions: the layout has all 32 quads of every row; what an idle lane brings is not looked at -- eight loads
+    // in flight, one wait)
+    const uint32_t last = (qy_end < QH ? qy_end : QH) - qy_begin - 1u;      // (a short slice loads its last row again: never beyond what the chain has written)
 #pragma unroll
     for (uint32_t i = 0; i < S2_ROWS; ++i)
-      ents[i] = (uint32_t)__hip_atomic_load(r16 + i * row_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ents[i] = (uint32_t)__hip_atomic_load(r16 + (i < last ? i : last) * row_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (st != 0) {
     if (!SLICED || qy_begin == 0) zero_block();
@@ -960,7 +1012,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   const uint32_t ms_len = lcup - scup;
   const bool wide = WD == 1 ? false : W > 64;
 
-  if (!KEEP || qy_begin == 0)
+  if (!KEEP || prepare)
     for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
   if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(s_exp_w)[i] = 0;
   wave_sync();
@@ -1023,7 +1075,14 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   const uint32_t half = (uint32_t)lane & 1u;
   bool bad = false;
   uint32_t e_prev = 0;                                   // exponent of this column's bottom sample, row above
-  if (SLICED && qy_begin > 0) {                          // take over where the previous slice's worker stopped
+  if (KEEP && prepare) {                                 // fill the ring as the first row would, and leave the state of "nothing decoded yet"
+    while (src_pos < ms_len && dst_bits < ROW_BITS_MAX + 64u) unstuff_chunk();
+    if (lane < 16) state[lane] = 0u;
+    if (lane == 0) { state[16] = 0u; state[17] = src_pos; state[18] = dst_bits; state[19] = 0u; }
+    wave_sync();
+    return;
+  }
+  if (SLICED && (KEEP || qy_begin > 0)) {                // take over where the previous slice's worker stopped
     if (state[19] != 0u) return;
     e_prev = (state[(uint32_t)lane >> 2] >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
     mpos = state[16]; src_pos = state[17]; dst_bits = state[18];
@@ -1185,19 +1244,23 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 //     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits
 //     (otherwise one ring per wavefront and a restart of the un-stuffer at the latest 256-byte boundary per slice).
 // Who plays which role is decided by TICKETS, not by blockIdx.  A workgroup asks where it runs (HW_REG_XCC_ID, HW_REG_HW_ID)
-// and counts on its COMPUTE UNIT's counter.  The first workgroup of the run on a CU takes a number from its XCD's counter and,
-// while that is within the XCD's share of the step-1 workgroups (numbers x, x + 8, ... below n1 for XCD x), plays step 1;
-// everyone else is a worker and takes its number from a device-wide counter.  Step-1 numbers are therefore taken as CUs
-// receive their first workgroup, one chain workgroup to a CU, and a worker waits only for workgroups that a free CU of the
-// right XCD is enough to start -- whatever order the dispatchers hand workgroups out in and whatever else shares the chip
-// (other streams' launches, a second decoder object's fused launch): no deadlock, no dependence on dispatch order.
-// (Measured forms, chains alone / whole launch, 8K frame: roles by blockIdx 0.21 / 0.31 ms.  ONE device-wide counter, the
-// first form of the tickets: 0.29 / 0.36 -- whose atomic arrives first is decided by distance to the counter's memory channel,
-// the first 97 of 509 workgroups sat on four of the eight XCDs, 48 of them on one (tools/micro/xcc_probe.hip), two chain
-// workgroups to a CU.  A counter per XCD: still 0.29 / 0.36 -- an XCD's 64 workgroups start within microseconds of each
-// other and the first 13 to arrive are a random 13, so on about ten CUs two chain workgroups share the SIMDs, and the launch
-// ends with its slowest chain.  Per CU, as here: see DESIGN.md.)  Nothing is cleared between runs: the CU words hold the
-// epoch of the last run that came by, the counters (epoch << 32) | count -- epoch must GROW from run to run on a scratch.
+// and marks its COMPUTE UNIT with the run's epoch.  The first workgroup of the run on a CU takes a step-1 number while there
+// are any (n1 of them; the launch is not used with more step-1 workgroups than CUs); everyone else is a worker and takes its
+// number from the workers' counter.  Step-1 numbers are therefore taken as CUs receive their first workgroup -- one chain
+// workgroup to a CU -- and a worker can only be waiting for a workgroup that any CU the run has not touched yet is enough
+// to start, whatever order the dispatchers hand workgroups out in and whatever else shares the chip (other streams'
+// launches, a second decoder object's fused launch): no deadlock, no dependence on dispatch order or on which XCD a
+// workgroup lands on.
+// (Measured forms, chains alone / whole launch, 8K frame: roles by blockIdx 0.21 / 0.31 ms.  ONE counter and the first n1
+// to come play step 1, the first form of the tickets: 0.29 / 0.36 -- whose atomic arrives first is decided by distance to the
+// counter's memory channel, the first 97 of 509 workgroups sat on four of the eight XCDs, 48 of them on one
+// (tools/micro/xcc_probe.hip), two chain workgroups to a CU.  A counter per XCD with the XCD's share of the numbers: still
+// 0.29 / 0.36 -- an XCD's 64 workgroups start within microseconds of each other, the first 13 to arrive are a random 13, on
+// about ten CUs two chain workgroups share the SIMDs and the launch ends with its slowest chain; and a small launch whose
+// workgroups miss an XCD -- workgroup i is NOT always on XCD i % 8: after other streams had been busy the same five-workgroup
+// launch started elsewhere -- left that XCD's numbers untaken.  First on its CU, as here: 0.22 / 0.31.)
+// Nothing is cleared between runs: the CU words hold the epoch of the last run that came by, the two counters
+// (epoch << 32) | count -- epoch must GROW from run to run on a scratch.
 // The waits are bounded all the same, by TIME (s_memrealtime, 100 MHz; two seconds unless the host says otherwise): a wait
 // that runs out does not fail its block -- the worker writes the run's epoch into the RETRY word behind the block status
 // array, and the host, when it collects the verdicts of the run, decodes the frame again through the separate step 1 / step 2
@@ -1231,8 +1294,8 @@ template <int TX, int CH, int WGW, int NR>            // WGW wavefronts per work
 __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
-    uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t nslices, uint32_t epoch, uint32_t dbg,
-    uint32_t ticket_off, uint32_t xcd_mask, uint32_t wait_ticks)
+    uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t max_qh, uint32_t epoch, uint32_t dbg,
+    uint32_t ticket_off, uint32_t wait_ticks)
 {
   // one LDS area, carved per role: the step-1 role's tables, event strings, VLC rings and mailboxes -- or the workers'
   // un-stuffing rings and block states
@@ -1246,6 +1309,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   uint16_t* const s_uvlc0 = reinterpret_cast<uint16_t*>(s_mem + 2048);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const SliceSched sched(max_qh);
   // the workgroup's number in START order (see above)
   uint32_t wgid = blockIdx.x;
   if (!(dbg & 8u)) {                                        // (dbg 8, timing experiment: roles by workgroup index)
@@ -1253,7 +1317,6 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       uint32_t xcc, hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      const uint32_t x = xcc & xcd_mask, nx = xcd_mask + 1u;
       uint32_t* tk = fstate + ticket_off;
       // the run's number on a counter that is never cleared: the counter holds (epoch << 32) | count -- raised to this
       // run's epoch first (a no-op for all but the first to come), then counted on
@@ -1263,13 +1326,13 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         return (uint32_t)__hip_atomic_fetch_add(c64, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
       // the first workgroup of this run on its compute unit (CU_ID, SH_ID, SE_ID within the XCD) finds another run's epoch there
-      const bool first = __hip_atomic_exchange(tk + x * 256u + ((hw >> 8) & 0xFFu), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+      const bool first = __hip_atomic_exchange(tk + (xcc & 7u) * 256u + ((hw >> 8) & 0xFFu), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
       uint32_t role = 0xFFFFFFFFu;
-      if (first) {                                          // a step-1 workgroup, if its XCD still needs one
-        const uint32_t t = take(tk + TICKET_CU_WORDS + x * TICKET_STRIDE);
-        if (t * nx + x < n1) role = t * nx + x;             // the XCD's share: numbers x, x + nx, ... below n1
+      if (first) {                                          // a step-1 workgroup, while there are step-1 numbers left
+        const uint32_t t = take(tk + TICKET_CU_WORDS);
+        if (t < n1) role = t;
       }
-      if (role == 0xFFFFFFFFu) role = n1 + take(tk + TICKET_CU_WORDS + 8u * TICKET_STRIDE);   // a worker: numbered over the whole device
+      if (role == 0xFFFFFFFFu) role = n1 + take(tk + TICKET_CU_WORDS + TICKET_STRIDE);   // a worker
       s_mem[0] = role;
     }
     __syncthreads();
@@ -1277,30 +1340,70 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     __syncthreads();
   }
   uint32_t* const retry = reinterpret_cast<uint32_t*>(block_status + ((n + 3u) & ~3u));   // != the run's epoch: nothing to repeat
+#ifdef FUSED_TIMELINE
+  uint32_t tl_where;
+  {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    tl_where = (xcc << 16) | (hw & 0xFFFFu);
+  }
+  const uint32_t tl_t0 = tl_now();
+  if (threadIdx.x == 0) g_tl_flags = fstate;
+#endif
 
   if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
     if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
     uint32_t* wlds = s_mem + wv * WORKER_WORDS;
     const uint32_t wave_no = (wgid - n1) * (uint32_t)WGW + wv;
-    const uint32_t b0 = wave_no * per_wave;
-    if (b0 >= n) return;
-    const uint32_t nb = n - b0 < per_wave ? n - b0 : per_wave;
-    uint32_t seen_cw = 0xFFFFFFFFu, seen_rows = 0;          // the last flag read: consecutive blocks mostly share a chain wavefront
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-      const uint32_t q0 = sl * S2_ROWS;
+    // Its blocks are `nwaves` apart in the block order, not neighbours: the order goes resolution by resolution and band by
+    // band, and the bands differ in how much they code (8K frame: five consecutive blocks of the first half of the order keep
+    // a wavefront busy for 0.22 ms, five of the HH band of the top level for 0.16) -- every wavefront gets the same mix.
+    const uint32_t nwaves = (n + per_wave - 1u) / per_wave;
+    if (wave_no >= nwaves) return;
+    uint32_t nb = 0;
+    while (nb < per_wave && wave_no + nb * nwaves < n) ++nb;
+    if (NR > 1)                                             // what does not depend on the chains, before the first wait (step2_block)
       for (uint32_t k = 0; k < nb; ++k) {
-        const uint32_t bi = b0 + k;
+        const uint32_t bi = wave_no + k * nwaves;
+        const ojphgpu_cb_desc d = blocks[bi];
+        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, wlds + k * RING_WORDS, nullptr, (int)lane, 0u, 0u,
+                                           wlds + NR * RING_WORDS + k * S2_STATE_WORDS, true);
+      }
+#ifdef FUSED_TIMELINE
+    uint32_t* tl = g_tl + (size_t)((n1 * (uint32_t)WGW + wave_no) & 8191u) * 12u;
+    uint32_t tl_wait = 0;
+    if (lane == 0) { tl[0] = 2u; tl[1] = tl_where; tl[2] = tl_now(); }
+#endif
+#ifndef PRIO_PERIOD
+#define PRIO_PERIOD 6u
+#endif
+    uint32_t wave_slot, prio_it = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));     // WAVE_ID: the wavefront's slot on its SIMD = its age there
+    for (uint32_t sl = 0; sl < sched.n; ++sl) {
+      uint32_t q0, q1;
+      sched.bounds(sl, q0, q1);
+      // the progress flags of the blocks' chain wavefronts, one per lane: one round trip for all of them
+      const uint32_t flv = (lane < nb && !(dbg & 2u)) ? ld_agent(fstate + ((wave_no + lane * nwaves) >> 6)) : 0u;
+      for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t bi = wave_no + k * nwaves;
         const ojphgpu_cb_desc d = blocks[bi];
         if (d.w == 0 || d.h == 0) continue;
         const uint32_t QH = ((uint32_t)d.h + 1) >> 1;
         if (q0 >= QH) continue;
         uint32_t* ring = wlds + (NR > 1 ? k : 0u) * RING_WORDS;
         uint32_t* state = wlds + NR * RING_WORDS + k * S2_STATE_WORDS;
-        const uint32_t need = q0 + S2_ROWS < QH ? q0 + S2_ROWS : QH;
+        const uint32_t need = q1 < QH ? q1 : QH;
         bool there = true;
-        if (!(dbg & 2u) && d.len1 != 0 && d.num_passes != 0 && !((bi >> 6) == seen_cw && seen_rows >= need)) {   // (dbg 2: the workers alone, over the records of the run before)
-          seen_cw = bi >> 6;
-          seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + seen_cw, epoch, need, wait_ticks));
+        const uint32_t fl = rdlane(flv, (int)k);
+        if (!(dbg & 2u) && d.len1 != 0 && d.num_passes != 0 && !((fl >> 16) == (epoch & 0xFFFFu) && (fl & 0xFFFFu) >= need)) {   // (dbg 2: the workers alone, over the records of the run before)
+#ifdef FUSED_TIMELINE
+          const uint32_t tl_w0 = tl_now();
+#endif
+          const uint32_t seen_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + (bi >> 6), epoch, need, wait_ticks));
+#ifdef FUSED_TIMELINE
+          tl_wait += tl_now() - tl_w0;
+#endif
           there = seen_rows != 0u;
         }
         if ((dbg & 4u) && sl == 1u && bi % 61u == 7u) there = false;       // (test switch: this wait "ran out")
@@ -1311,9 +1414,19 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
           if (lane == 0) st_agent(retry, epoch);
           return;
         }
-        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q0 + S2_ROWS, state);
+        // The SIMD serves its wavefronts oldest first: of the six workers of a SIMD the one in slot 0 was through at 0.27 ms,
+        // the one in slot 5 at 0.33, alone on its SIMD for the last stretch.  Two priority levels below the partners', taken
+        // in turns -- the younger the wavefront, the larger its share of turns at the upper one -- even that out.
+        if ((prio_it++ % PRIO_PERIOD) < wave_slot) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, ring, nullptr, (int)lane, q0, q1, state);
       }
+#ifdef FUSED_TIMELINE
+      if (lane == 0 && sl < 7u) tl[4 + sl] = tl_now();
+#endif
     }
+#ifdef FUSED_TIMELINE
+    if (lane == 0) { tl[3] = tl_now(); tl[11] = tl_wait; }
+#endif
     return;
   }
 
@@ -1334,7 +1447,11 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   volatile lds_u32* s_vprog = (volatile lds_u32*)(ctl + 128);
   volatile lds_u32* s_vcons = (volatile lds_u32*)(ctl + 192);
   volatile lds_u32* s_done = (volatile lds_u32*)(ctl + 256);
+#ifndef PARTNER_PRIO
+#define PARTNER_PRIO 2
+#endif
   if (chain) __builtin_amdgcn_s_setprio(3);
+  else if (PARTNER_PRIO) __builtin_amdgcn_s_setprio(PARTNER_PRIO);
   const uint32_t cw = wgid * (uint32_t)CH + set;            // the chain wavefront's number = its blocks' number / 64
   const uint32_t bi = cw * 64u + lane;
   uint32_t* flag = fstate + cw;
@@ -1372,13 +1489,20 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       uint32_t* rec = quads + rec16_base(d, bi);
       RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
       EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
-      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64));
+      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64), sched);
       s_done[lane] = 1u;
       if (mel.stuck || vlc.stuck) st_agent(retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
     }
   }
   if (chain) publish_rows(flag, epoch, 0xFFFFu, lane);     // every row of every block of this wavefront is complete
+#ifdef FUSED_TIMELINE
+  if (lane == 0) {
+    uint32_t* tl = g_tl + (size_t)((wgid * (uint32_t)WGW + wv) & 8191u) * 12u;
+    tl[0] = chain ? 1u : 3u; tl[1] = tl_where; tl[2] = tl_t0; tl[3] = tl_now();
+  }
+#endif
 }
+
 
 // -------------------------------------------------------------------------------------------------
 // refinement: SigProp + MagRef passes (block_decoder32.cpp:1318-1609), one wavefront = one code-block
@@ -1993,6 +2117,7 @@ uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus) { const FusedShape f = f
 bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus)
 {
   if (dec_fuse_mode() == 0) return false;
+  if (fused_shape(n, cus).n1 > (cus ? cus : 256u)) return false;   // (a step-1 workgroup per CU at most: the tickets)
   if (dec_fuse_mode() >= 2) return true;
   return max_h > 32u && fused_shape(n, cus).per_wave <= (uint32_t)S2_RINGS;
 }
@@ -2011,19 +2136,16 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch || !d_state) return OJPHGPU_E_INVALID;
   const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
   if (tx == 0 || (kinds & 3) != 1 || max_h == 0) return OJPHGPU_E_INVALID;
-  const uint32_t nslices = (((max_h + 1u) >> 1) + S2_ROWS - 1u) / S2_ROWS;
+  const uint32_t max_qh = (max_h + 1u) >> 1;
   const FusedShape f = fused_shape(n, cus);
   const uint32_t shape = f.shape, n1 = f.n1, per_wave = f.per_wave, wwgs = f.wwgs, wgw = f.wgw;
   static const uint32_t dbg = [] { const char* e = getenv("OJPHGPU_FUSED_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
   // how long a worker waits for a chain before it asks for the repeat (OJPHGPU_FUSED_WAIT_MS; ticks of the 100 MHz clock)
   static const uint32_t wait_ticks = [] { const char* e = getenv("OJPHGPU_FUSED_WAIT_MS"); const long ms = e ? atol(e) : 2000; return (uint32_t)((ms < 1 ? 1 : ms > 40000 ? 40000 : ms) * 100000l); }();
   const uint32_t ticket_off = (uint32_t)ht_decode_fused_state_words(n) - TICKET_WORDS;   // the ticket counters: behind the flags
-  // XCDs of the device (32 compute units each; a partitioned device has fewer): their ids, masked, pick the counter
-  const uint32_t nx = cus >= 256u ? 8u : cus >= 128u ? 4u : cus >= 64u ? 2u : 1u;
-  const uint32_t xcd_mask = nx - 1u;
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
 #define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
-                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, nslices, epoch, dbg, ticket_off, xcd_mask, wait_ticks)
+                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, max_qh, epoch, dbg, ticket_off, wait_ticks)
   // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
   static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
   if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }
@@ -2099,3 +2221,15 @@ int upload_dec_tables(const HtTables& t)
   return 0;
 }
 }
+
+#ifdef FUSED_TIMELINE
+extern "C" int ojphgpu_debug_fused_timeline(uint32_t* out, uint32_t words, int clear)
+{
+  if (words > 8192u * 12u) words = 8192u * 12u;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), words * 4u) != hipSuccess) return -1;
+  if (out && words == 8192u * 12u && hipMemcpyFromSymbol(out + words, HIP_SYMBOL(g_tl_pub), sizeof(uint32_t) * 1024u * 8u) != hipSuccess) return -1;   // (a caller with room for them)
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tl)) != hipSuccess || hipMemset(p, 0, sizeof(uint32_t) * 8192u * 12u) != hipSuccess) return -1; }
+  return 0;
+}
+#endif

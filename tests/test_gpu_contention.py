@@ -74,6 +74,20 @@ def test_fused_launches_beside_each_other_and_under_a_held_chip():
         assert got["e"][i] == streams[i % 4], "frame %d: codestream differs under contention" % i
         assert np.array_equal(np.asarray(got["d"][i]).astype(np.int64), want[i % 4].astype(np.int64)), "frame %d differs" % i
     assert got["retries"] == 0
+    # and afterwards: small fused launches of fresh decoder objects (five workgroups) find their step-1 workgroup at once --
+    # after the streams above had been busy such a launch no longer started on the XCDs it starts on in a fresh process, and
+    # a form of the tickets that tied the step-1 numbers to XCDs waited two seconds per frame for a workgroup that never came
+    import time
+    small = synth_image(3, 100, 150, 7, seed=21, signed=True)
+    cs_small = codec.encode(small, bit_depth=7, is_signed=True)
+    want_small, _ = cp.decode(cs_small)
+    t0 = time.time()
+    for _ in range(10):
+        d = codec.Decoder(cs_small)
+        img = d.run_device()
+        assert d.failed_blocks() == 0 and d.fused_retries() == 0
+        assert np.array_equal(img.cpu().numpy().astype(np.int64), want_small.astype(np.int64))
+    assert time.time() - t0 < 5.0
 
 
 SCRIPT = r'''
