@@ -24,14 +24,15 @@ def main():
     ref_out = dec.run_device(dtype=torch.int16).clone()
     runs = checks = 0
     while time.time() < t_end:
-        for _ in range(40):
+        for _ in range(8):
             enc.run_device(d_img)
             out = dec.run_device(dtype=torch.int16)
             runs += 1
         assert torch.equal(out, ref_out), "decode differs after %d runs" % runs
         assert hashlib.sha256(enc.finish()).hexdigest() == ref_h, "codestream differs after %d runs" % runs
         checks += 1
-    print("8K frame: %d runs, %d checks, all identical" % (runs, checks))
+    assert dec.failed_blocks() == 0 and dec.fused_retries() == 0, "the fused launch asked for %d repeats" % dec.fused_retries()
+    print("8K frame: %d runs, %d checks, all identical, no fused launch repeated" % (runs, checks))
     # small frames of many shapes, fresh codec objects every time (allocation / table upload paths)
     rng = np.random.default_rng(0)
     n = 0
