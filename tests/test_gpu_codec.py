@@ -610,7 +610,10 @@ from openjph_amd import codec
 from tests import cpu_pipeline as cp
 from tests.synth import synth_image
 for kw, shape in ((dict(bit_depth=8, num_decomps=3), (1, 333, 517)), (dict(bit_depth=12, reversible=False, qstep=0.002, tile=(256, 192)), (3, 401, 611)),
-                  (dict(bit_depth=10, block=(32, 32)), (1, 200, 300))):
+                  (dict(bit_depth=10, block=(32, 32)), (1, 200, 300)),
+                  # tall blocks: many slices of quad rows, the last one cut (4 + 2 + 2 rows), heights that end inside every piece
+                  (dict(bit_depth=8, block=(16, 256), num_decomps=2), (1, 1021, 90)), (dict(bit_depth=9, block=(8, 512), num_decomps=1, reversible=False, qstep=0.01), (2, 1500, 40)),
+                  (dict(bit_depth=8, block=(64, 64), num_decomps=1), (1, 2 * 61, 70)), (dict(bit_depth=8, block=(64, 64), num_decomps=1), (1, 2 * 59, 70))):
     img = synth_image(shape[0], shape[1], shape[2], kw["bit_depth"], seed=11)
     cs = codec.encode(img, **kw)
     want, _ = cp.decode(cs)
