@@ -222,7 +222,12 @@ class Decoder:
         _torch().cuda.synchronize(self.device)   # the host buffer may go away after this call
 
     def run_device(self, d_image=None, dtype=None):
-        """dtype / d_image.dtype torch.int16 / uint16 or torch.int8 / uint8: samples in 16- / 8-bit containers"""
+        """dtype / d_image.dtype torch.int16 / uint16 or torch.int8 / uint8: samples in 16- / 8-bit containers.
+        Asynchronous: the launches are enqueued on the decoder's stream.  The run is COLLECTED by failed_blocks() (decode()
+        does it): that is where a block's verdict is read, and where a frame is decoded once more through the separate
+        launches if the one-launch block decoder ran out of patience on a chip held by others (fused_retries() counts; it
+        has not happened on an idle or a shared chip so far) -- a caller that reads d_image on the device without
+        collecting the run takes that frame as it is."""
         torch = _torch()
         if d_image is None:
             alloc = torch.empty if self.tiles == (0, self.plan.num_tiles) else torch.zeros

@@ -1232,17 +1232,23 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 // Step 1 is a latency floor: the serial chain of a code-block takes 0.2 ms however many blocks there are, and while the
 // 388 chain wavefronts of an 8K frame run, the rest of the chip has nothing to do -- step 2 of a block needs that block's
 // records.  But it needs them ROW BY ROW.  The fused kernel puts both into one launch:
-//   * workgroups 0 .. n1-1 are step 1 exactly as in ht_dec_step1_raw_kernel (chain + two partner wavefronts per 64
-//     blocks); a chain wavefront stores its records with agent scope and publishes, after every S2_ROWS quad rows, how many
-//     rows of its 64 blocks are complete (flag per chain wavefront; s_waitcnt vmcnt(0) first: the chain has no loads, its
-//     stores are all vmcnt counts);
-//   * the workgroups behind them are persistent step-2 worker wavefronts: a wavefront owns `per_wave` consecutive blocks
-//     (as few as the chip's wavefront slots allow: 5 at 8K) and takes them slice by slice -- slice 0 of each of its
-//     blocks, then slice 1, ... -- waiting (bounded) until the chain wavefront of a block has published the slice's rows.
-//     A slice is quad rows [S2_ROWS s, S2_ROWS (s + 1)) of a block, decoded by step2_block<SLICED>; what a block's next
-//     slice needs stays in the wavefront's LDS: 80 bytes of state (bottom-row exponents, MagSgn position, where the
-//     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits
-//     (otherwise one ring per wavefront and a restart of the un-stuffer at the latest 256-byte boundary per slice).
+//   * n1 workgroups are step 1 as in ht_dec_step1_raw_kernel (chain + two partner wavefronts per 64 blocks); a chain
+//     wavefront stores its records with agent scope (16 bits per quad, a row's worth staged in LDS: flush_row16) and
+//     publishes, at the end of every slice of quad rows, how many rows of its 64 blocks are complete (flag per chain
+//     wavefront; s_waitcnt vmcnt(0) first: the chain has no loads, its stores are all vmcnt counts).  The chain wavefronts
+//     run at priority 3, their partners at 2: a SIMD serves its wavefronts oldest first, and a partner behind three older
+//     worker wavefronts kept its chain waiting for VLC words (the workgroups that happened to come second on their CU ran a
+//     third slower than the rest, and the launch ends with its slowest chain);
+//   * the other workgroups are persistent step-2 worker wavefronts: a wavefront owns `per_wave` blocks (as few as the
+//     chip's wavefront slots allow: 5 at 8K), `nwaves` apart in the block order so that every wavefront gets the same mix
+//     of bands, and takes them slice by slice -- slice 0 of each of its blocks, then slice 1, ... -- waiting (bounded)
+//     until the chain wavefront of a block has published the slice's rows.  A slice is S2_ROWS quad rows of a block, the
+//     last S2_ROWS rows of the tallest block as 4 + 2 + 2 (SliceSched), decoded by step2_block<SLICED>; what a block's
+//     next slice needs stays in the wavefront's LDS: 80 bytes of state (bottom-row exponents, MagSgn position, where the
+//     un-stuffer stands) and, with at most S2_RINGS blocks per wavefront, the block's own ring of un-stuffed MagSgn bits,
+//     cleared and filled BEFORE the first wait (otherwise one ring per wavefront and a restart of the un-stuffer at the
+//     latest 256-byte boundary per slice).  The workers take priorities 0 and 1 in turns, the younger the wavefront the
+//     larger its share of turns at 1: left to the oldest-first rule, slot 0 of a SIMD was through 0.06 ms before slot 5.
 // Who plays which role is decided by TICKETS, not by blockIdx.  A workgroup asks where it runs (HW_REG_XCC_ID, HW_REG_HW_ID)
 // and marks its COMPUTE UNIT with the run's epoch.  The first workgroup of the run on a CU takes a step-1 number while there
 // are any (n1 of them; the launch is not used with more step-1 workgroups than CUs); everyone else is a worker and takes its
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   if (threadIdx.x == 0) g_tl_flags = fstate;
 #endif
 
-  if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` consecutive blocks, slice by slice ----
+  if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` blocks, slice by slice ----
     if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
     uint32_t* wlds = s_mem + wv * WORKER_WORDS;
     const uint32_t wave_no = (wgid - n1) * (uint32_t)WGW + wv;
