@@ -753,7 +753,7 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
   // every block is at most 64 samples wide, of one wavelet and without refinement passes -- and where it pays: blocks
   // of 64 rows, few enough for resident workers (ht_decode_fused_pays); the synthesis levels follow on the same stream.  Otherwise: the separate launches, with the lower synthesis levels beside step 2 of the top resolution.
-  const bool fused = d->fstate.p && !d->force_separate && !d->any_refine && (d->kinds & (3 | 32)) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) &&
+  const bool fused = d->fstate.p && !d->force_separate && !d->fused_off && !d->any_refine && (d->kinds & (3 | 32)) == 1 && ((d->kinds & 12) == 4 || (d->kinds & 12) == 8) &&
                      d->nblocks > 0 && ojphgpu::ht_decode_fused_pays(d->nblocks, d->max_block_h, d->cus);
   d->last_fused = fused; d->last_image = d_image; d->last_container = container;
   const uint32_t n_low = fused ? 0u : d->n_low;
@@ -845,10 +845,14 @@ extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count
     HIPCHK(hipStreamSynchronize(d->stream));
     // a fused launch whose workers gave up waiting for their chains (the chip was held up for seconds by other work): its
     // blocks have no verdict yet -- the frame is decoded again through the separate launches, into the same image
-    if (pass == 0 && d->last_fused && ojphgpu_fused_retry_wanted(st.data(), d->nblocks, d->fused_epoch)) {
-      const int rc = ojphgpu_decoder_repeat_separate(d);
-      if (rc) return rc;
-      continue;
+    if (pass == 0 && d->last_fused) {
+      const bool again = ojphgpu_fused_retry_wanted(st.data(), d->nblocks, d->fused_epoch);
+      d->fused_outcome(again);
+      if (again) {
+        const int rc = ojphgpu_decoder_repeat_separate(d);
+        if (rc) return rc;
+        continue;
+      }
     }
     break;
   }

@@ -348,6 +348,10 @@ struct ojphgpu_decoder {
   bool last_fused = false, force_separate = false;
   void* last_image = nullptr; int last_container = 0;
   uint32_t fused_retries = 0;                       // runs repeated that way so far
+  // eight repeats in a row and the object stops using the one launch: a wait that runs out costs seconds, and a chip (or a
+  // device layout) on which it keeps running out is better served by the separate launches than by trying again
+  uint32_t fused_strikes = 0; bool fused_off = false;
+  void fused_outcome(bool repeated) { if (!repeated) fused_strikes = 0; else if (++fused_strikes >= 8u) fused_off = true; }
   // descriptors [0, n_low) = blocks below the top resolution (0 = no overlap of the lower synthesis
   // levels with step 2, see decoder_create)
   uint32_t n_low = 0;

@@ -525,7 +525,11 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     if ((r2 = run_and_fetch(false)) != 0) return r2;
     // the fused block-decoder launch of this run gave up waiting (the chip was held up for seconds by other work) and marked
     // the run instead of failing blocks: once more through the separate launches (see ojphgpu_decoder_failed_blocks)
-    if (was_fused && ojphgpu_fused_retry_wanted(s.h_status.p, (uint32_t)nb, epoch) && (r2 = run_and_fetch(true)) != 0) return r2;
+    if (was_fused) {
+      const bool again = ojphgpu_fused_retry_wanted(s.h_status.p, (uint32_t)nb, epoch);
+      { std::lock_guard<std::mutex> lk(p->enqueue_mus[k]); d->fused_outcome(again); }
+      if (again && (r2 = run_and_fetch(true)) != 0) return r2;
+    }
     uint32_t failed = 0;
     for (size_t i = 0; i < nb; ++i) failed += s.h_status.p[i] != 0;
     s.failed = failed;

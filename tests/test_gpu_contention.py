@@ -113,6 +113,12 @@ for kw, shape in ((dict(bit_depth=8, num_decomps=2), (1, 700, 900)), (dict(bit_d
     assert st["fused_retries"] == 5, st
     for f in frames:
         assert np.array_equal(np.asarray(f).astype(np.int64), want.astype(np.int64))
+    # eight repeats in a row and a decoder object stops using the one launch
+    dec = codec.Decoder(cs)
+    for run in range(11):
+        d_img = dec.run_device()
+        assert dec.failed_blocks() == 0 and np.array_equal(d_img.cpu().numpy(), want), run
+    assert dec.fused_retries() == 8, dec.fused_retries()
 print("OK")
 ''' % ROOT
 
@@ -120,7 +126,8 @@ print("OK")
 def test_a_wait_that_runs_out_repeats_the_run_through_the_separate_launches():
     """OJPHGPU_FUSED_DBG=4 makes one worker wavefront of every fused launch behave as if its wait for the chains had run
     out in the second slice: the run is marked, the decoder object / the pipe decode the frame again through the
-    separate step 1 / step 2 launches when they collect it, and the caller sees the oracle's samples and no failed block"""
+    separate step 1 / step 2 launches when they collect it, and the caller sees the oracle's samples and no failed block;
+    after eight repeats in a row a decoder object keeps to the separate launches"""
     env = dict(os.environ, OJPHGPU_FUSED_DBG="4", OJPHGPU_DEC_FUSED="2")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"OK" in r.stdout, r.stderr[-3000:]
