@@ -1,10 +1,13 @@
 #!/bin/bash
 # SQ counters (instruction mix + stall composition), one pass of 8 SQ counters, --pmc + --kernel-trace only.
+#   tools/sq_round.sh [workload [container bits]]    (default: the 8K bench frame in 16-bit containers)
+# The result is MERGED into gpurun_out/sq_counters.json under the workload's name (same kernel digest only).
 set -u
+WL=${1:-c3_8k_444_12b_irv97}; CT=${2:-16}; export WL
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf gpurun_out/sq1 gpurun_out/sq2
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d gpurun_out/sq1 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq1.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/sq2 -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d gpurun_out/sq1 -o sq -- env OJPH_BENCH_NOCHECK=1 python bench.py --workload $WL --container $CT --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/sq2 -o sq -- env OJPH_BENCH_NOCHECK=1 python bench.py --workload $WL --container $CT --steps 2 --warmup 1 --no-cpu-baseline --plain > gpurun_out/sq2.log 2>&1
 python - <<'PY'
 import csv, glob, collections, json
 out = {}
@@ -33,6 +36,8 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
             if "ht_encode_kernel" in k and len(sizes) == 2:
                 out["ht_encode[lower resolutions]"] = {"valu_insts": avg(sizes[0], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[0], "SQ_INSTS_SALU"), "wavefronts": sizes[0]}
                 out["ht_encode[top resolution, side stream]"] = {"valu_insts": avg(sizes[1], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[1], "SQ_INSTS_SALU"), "wavefronts": sizes[1]}
+            if "ht_encode_kernel" in k and len(sizes) == 1:   # (frame batches: one launch over all blocks)
+                out["ht_encode"] = {"valu_insts": avg(sizes[0], "SQ_INSTS_VALU"), "salu_insts": avg(sizes[0], "SQ_INSTS_SALU"), "wavefronts": sizes[0]}
             if "ht_dec_step2" in k:
                 out["ht_dec_step2"] = {"valu_insts": sum(avg(g, "SQ_INSTS_VALU") for g in sizes), "salu_insts": sum(avg(g, "SQ_INSTS_SALU") for g in sizes), "wavefronts": sum(sizes)}
         for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep"), ("ht_dec_fused(step 1 + step 2)", "ht_dec_fused_kernel")):
@@ -41,6 +46,14 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
 import os, sys
 sys.path.insert(0, os.getcwd())
 from openjph_amd.build import kernel_sources_digest
-json.dump({"_kernels_sha256": kernel_sources_digest(), "c3_8k_444_12b_irv97": dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")}, open("gpurun_out/sq_counters.json", "w"), indent=1)
+dig = kernel_sources_digest()
+try:
+    allw = json.load(open("gpurun_out/sq_counters.json"))
+    if allw.get("_kernels_sha256") != dig: allw = {}
+except Exception:
+    allw = {}
+allw["_kernels_sha256"] = dig
+allw[os.environ["WL"]] = dict(out, _note="wavefront instructions per launch (per frame for multi-launch stages), SQ_INSTS_VALU / SQ_INSTS_SALU summed over the dispatch, rocprofv3 --pmc pass of tools/sq_round.sh")
+json.dump(allw, open("gpurun_out/sq_counters.json", "w"), indent=1)
 PY
 find gpurun_out/sq1 gpurun_out/sq2 -type f -size +4M -delete
