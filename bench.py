@@ -663,7 +663,7 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
         try:
             del enc
             me = codec.MultiEncoder(plan=plan, devices=[local_rank])
-            h32 = torch.from_numpy(img.astype(np.int32)).pin_memory()
+            h32 = torch.from_numpy(img.astype(np.int16) if args.container == 16 else img.astype(np.int32)).pin_memory()
             bt = None
             for _ in range(4):
                 t0 = time.perf_counter()
@@ -672,8 +672,8 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
                 bt = dt if bt is None or dt < bt else bt
             inproc = {"ms": round(bt * 1e3, 3), "Msamples_s": round(w * h * nc / bt / 1e6, 1), "devices": 1,
                       "bytes_equal_reference": bool(size != WORKLOADS[name][0] or hashlib.sha256(out.tobytes()).hexdigest() == gold["sha256"]),
-                      "covers": "ojphgpu_multi_encode: int32 frame in pinned host memory -> codestream in pinned host memory (uploads, kernels, "
-                                "Tier-2 layout, placement in HBM, download)"}
+                      "covers": "ojphgpu_multi_encode_container: the frame in %d-bit containers in pinned host memory -> codestream in pinned host "
+                                "memory (uploads, kernels, Tier-2 layout, placement in HBM, download)" % (16 if args.container == 16 else 32)}
             del me, h32
             enc = None
         except Exception as e:

@@ -638,6 +638,10 @@ int  ojphgpu_multi_encoder_create(const ojphgpu_plan* plan, const int* devices, 
 void ojphgpu_multi_encoder_destroy(ojphgpu_multi_encoder* enc);
 /* whole codestream (SOC .. EOC) into h_out; OJPHGPU_E_OVERFLOW with *out_len = the bytes needed when cap is too small */
 int  ojphgpu_multi_encode(ojphgpu_multi_encoder* enc, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len);
+/* the same with the frame's samples in container_bits-bit containers (32 | 16 | 8, as ojphgpu_encoder_run_device16 / 8):
+ * half / a quarter of the bytes over every device's link */
+int  ojphgpu_multi_encode_container(ojphgpu_multi_encoder* enc, const void* h_image, int container_bits, uint8_t* h_out, size_t cap,
+                                    size_t* out_len);
 /* how the frame was dealt out: workers (<= num_devices, <= tiles) and the tiles of each */
 int  ojphgpu_multi_encoder_workers(const ojphgpu_multi_encoder* enc, uint32_t* num_workers, uint32_t* tiles_per_worker, uint32_t cap);
 /* parses the codestream once (codestream::read_headers + read, with restrict_input_resolution when the skips are not 0) */
@@ -647,6 +651,8 @@ void ojphgpu_multi_decoder_destroy(ojphgpu_multi_decoder* dec);
 int  ojphgpu_multi_decoder_plan(ojphgpu_multi_decoder* dec, const ojphgpu_plan** plan);      /* owned by the decoder */
 /* the codestream the decoder was created for -> h_image; OJPHGPU_E_BLOCK when blocks failed and the decoder is not resilient */
 int  ojphgpu_multi_decode(ojphgpu_multi_decoder* dec, const uint8_t* h_codestream, size_t len, int32_t* h_image, uint32_t* failed_blocks);
+int  ojphgpu_multi_decode_container(ojphgpu_multi_decoder* dec, const uint8_t* h_codestream, size_t len, void* h_image, int container_bits,
+                                    uint32_t* failed_blocks);
 
 #ifdef __cplusplus
 }

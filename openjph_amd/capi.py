@@ -254,12 +254,14 @@ SIGNATURES = {
     "ojphgpu_multi_encoder_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
     "ojphgpu_multi_encoder_destroy": (None, [C.c_void_p]),
     "ojphgpu_multi_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ojphgpu_multi_encode_container": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ojphgpu_multi_encoder_workers": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
     "ojphgpu_multi_decoder_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_uint32,
                                               C.POINTER(C.c_void_p)]),
     "ojphgpu_multi_decoder_destroy": (None, [C.c_void_p]),
     "ojphgpu_multi_decoder_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ojphgpu_multi_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_multi_decode_container": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "ojphgpu_enc_pipe_set_pixels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ojphgpu_enc_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),
     "ojphgpu_dec_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),

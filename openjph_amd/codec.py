@@ -298,13 +298,19 @@ class MultiEncoder:
             pass
 
     def encode(self, image, copy=True):
-        """image: int32 numpy array / pinned torch tensor in the frame layout -> the codestream (bytes; copy=False: a view
-        of the encoder's pinned buffer, valid until the next call)"""
+        """image: numpy array / pinned torch tensor in the frame layout, int32 or in 16- / 8-bit containers (the dtype says
+        which: half / a quarter of the bytes over every device's link) -> the codestream (bytes; copy=False: a view of the
+        encoder's pinned buffer, valid until the next call)"""
         torch = _torch()
-        t = image if hasattr(image, "data_ptr") else torch.from_numpy(np.ascontiguousarray(image, dtype=np.int32))
+        if hasattr(image, "data_ptr"):
+            t = image
+        else:
+            a = np.ascontiguousarray(image)
+            t = torch.from_numpy(a if a.dtype.itemsize in (1, 2) and a.dtype.kind in "iu" else a.astype(np.int32))
+        bits = 8 * t.element_size()
         n = C.c_size_t()
-        check(self._lib.ojphgpu_multi_encode(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(self._out.data_ptr()), self._out.numel(),
-                                             C.byref(n)), "multi_encode")
+        check(self._lib.ojphgpu_multi_encode_container(self._h, C.c_void_p(t.data_ptr()), bits, C.c_void_p(self._out.data_ptr()),
+                                                       self._out.numel(), C.byref(n)), "multi_encode")
         v = self._out[:n.value].numpy()
         return v.tobytes() if copy else v
 
@@ -335,11 +341,21 @@ class MultiDecoder:
         except Exception:
             pass
 
-    def decode(self, copy=True):
+    def decode(self, copy=True, dtype=None):
+        """dtype np.int16 / np.uint16 / np.int8 / np.uint8: the samples come down in 16- / 8-bit containers"""
+        torch = _torch()
+        dt = np.dtype(dtype or np.int32)
+        if dt.itemsize != 4:
+            key = "_img%d" % dt.itemsize
+            if not hasattr(self, key):
+                setattr(self, key, torch.zeros(self.plan.frame_shape, dtype=torch.int16 if dt.itemsize == 2 else torch.int8).pin_memory())
+            img = getattr(self, key)
+        else:
+            img = self._img
         failed = C.c_uint32()
-        check(self._lib.ojphgpu_multi_decode(self._h, self._cs.ctypes.data, len(self._cs), C.c_void_p(self._img.data_ptr()),
-                                             C.byref(failed)), "multi_decode")
-        v = self._img.numpy()
+        check(self._lib.ojphgpu_multi_decode_container(self._h, self._cs.ctypes.data, len(self._cs), C.c_void_p(img.data_ptr()),
+                                                       8 * dt.itemsize, C.byref(failed)), "multi_decode")
+        v = img.numpy().view(dt) if dt.itemsize != 4 else img.numpy()
         return v.copy() if copy else v
 
 

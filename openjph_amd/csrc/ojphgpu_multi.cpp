@@ -54,6 +54,45 @@ Piece piece_of(const Plan& P, uint32_t t, uint32_t c)
   return Piece{ g.frame_off + (uint64_t)(R.r.y0 - g.y0) * g.w + (R.r.x0 - g.x0), g.w, R.r.w, R.r.h };
 }
 
+// The rectangles of component c that a run of tiles covers, merged: tiles of one tile row side by side into one rectangle,
+// rectangles of equal extent below each other into one -- a run of whole tile rows is ONE rectangle (and, spanning the
+// plane's width, one contiguous copy) where tile by tile it was thousands of 4 KB rows.
+struct Rect2 { uint64_t off; uint32_t x, y, w, h; };
+std::vector<Rect2> rects_of(const Plan& P, Range tiles, uint32_t c)
+{
+  std::vector<Rect2> r;
+  const CompGeo& g = P.comps[c];
+  for (uint32_t t = tiles.first; t < tiles.first + tiles.count; ++t) {
+    const Piece q = piece_of(P, t, c);
+    if (q.w == 0 || q.h == 0) continue;
+    const uint64_t rel = q.off - g.frame_off;
+    Rect2 n{ q.off, (uint32_t)(rel % g.w), (uint32_t)(rel / g.w), q.w, q.h };
+    if (!r.empty() && r.back().y == n.y && r.back().h == n.h && r.back().x + r.back().w == n.x) r.back().w += n.w;   // next tile of the row
+    else r.push_back(n);
+  }
+  std::vector<Rect2> m;
+  for (const Rect2& n : r) {
+    if (!m.empty() && m.back().x == n.x && m.back().w == n.w && m.back().y + m.back().h == n.y) m.back().h += n.h;    // next tile row
+    else m.push_back(n);
+  }
+  return m;
+}
+
+// host <-> device copy of those rectangles (esz bytes per sample); to_device: host -> device
+int copy_rects(const Plan& P, Range tiles, uint32_t nc, uint8_t* dev, uint8_t* host, uint32_t esz, bool to_device, hipStream_t s)
+{
+  for (uint32_t c = 0; c < nc; ++c) {
+    const size_t pitch = (size_t)P.comps[c].w * esz;
+    for (const Rect2& q : rects_of(P, tiles, c)) {
+      uint8_t* d = dev + q.off * esz; uint8_t* h = host + q.off * esz;
+      const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+      if ((size_t)q.w * esz == pitch) HIPCHK(hipMemcpyAsync(to_device ? d : h, to_device ? h : d, pitch * q.h, kind, s));
+      else HIPCHK(hipMemcpy2DAsync(to_device ? d : h, pitch, to_device ? h : d, pitch, (size_t)q.w * esz, q.h, kind, s));
+    }
+  }
+  return OJPHGPU_OK;
+}
+
 template <typename F>
 int run_workers(size_t n, F f)
 {
@@ -136,21 +175,24 @@ extern "C" int ojphgpu_multi_encoder_create(const ojphgpu_plan* plan, const int*
 
 extern "C" int ojphgpu_multi_encode(ojphgpu_multi_encoder* m, const int32_t* h_image, uint8_t* h_out, size_t cap, size_t* out_len)
 {
-  if (!m || !h_image || !out_len) return OJPHGPU_E_INVALID;
+  return ojphgpu_multi_encode_container(m, h_image, 32, h_out, cap, out_len);
+}
+
+extern "C" int ojphgpu_multi_encode_container(ojphgpu_multi_encoder* m, const void* h_image, int container_bits, uint8_t* h_out, size_t cap,
+                                               size_t* out_len)
+{
+  if (!m || !h_image || !out_len || (container_bits != 32 && container_bits != 16 && container_bits != 8)) return OJPHGPU_E_INVALID;
   const Plan& P = m->plan->plan;
+  const uint32_t esz = (uint32_t)container_bits / 8u;
   const uint32_t ppt = P.parts_per_tile, nc = P.p.num_comps;
   // 1. every device: its tiles in, kernels, tile-parts laid out in its HBM
   int rc = run_workers(m->w.size(), [&](size_t k) -> int {
     auto& W = m->w[k];
     HIPCHK(hipSetDevice(W.device));
-    for (uint32_t t = W.tiles.first; t < W.tiles.first + W.tiles.count; ++t)
-      for (uint32_t c = 0; c < nc; ++c) {
-        const Piece q = piece_of(P, t, c);
-        if (q.w == 0 || q.h == 0) continue;
-        HIPCHK(hipMemcpy2DAsync((int32_t*)W.d_image + q.off, (size_t)q.pitch * 4, h_image + q.off, (size_t)q.pitch * 4, (size_t)q.w * 4, q.h,
-                                hipMemcpyHostToDevice, W.stream));
-      }
-    int r = ojphgpu_encoder_run_device(W.enc, (const int32_t*)W.d_image);
+    int r = copy_rects(P, W.tiles, nc, (uint8_t*)W.d_image, (uint8_t*)const_cast<void*>(h_image), esz, true, W.stream);
+    if (r) return r;
+    r = container_bits == 16 ? ojphgpu_encoder_run_device16(W.enc, (const uint16_t*)W.d_image)
+      : container_bits == 8 ? ojphgpu_encoder_run_device8(W.enc, (const uint8_t*)W.d_image) : ojphgpu_encoder_run_device(W.enc, (const int32_t*)W.d_image);
     if (r) return r;
     return ojphgpu_encoder_finish_tiles_device(W.enc, (uint8_t*)W.d_out, W.out_cap, &W.len, m->psot.data() + (size_t)W.tiles.first * ppt);
   });
@@ -261,25 +303,28 @@ extern "C" int ojphgpu_multi_decoder_plan(ojphgpu_multi_decoder* m, const ojphgp
 // h_codestream: the codestream the decoder was created for (its block data is uploaded from here, each device its range)
 extern "C" int ojphgpu_multi_decode(ojphgpu_multi_decoder* m, const uint8_t* h_codestream, size_t len, int32_t* h_image, uint32_t* failed_blocks)
 {
-  if (!m || !h_codestream || !h_image) return OJPHGPU_E_INVALID;
+  return ojphgpu_multi_decode_container(m, h_codestream, len, h_image, 32, failed_blocks);
+}
+
+extern "C" int ojphgpu_multi_decode_container(ojphgpu_multi_decoder* m, const uint8_t* h_codestream, size_t len, void* h_image, int container_bits,
+                                               uint32_t* failed_blocks)
+{
+  if (!m || !h_codestream || !h_image || (container_bits != 32 && container_bits != 16 && container_bits != 8)) return OJPHGPU_E_INVALID;
   const Plan& P = m->plan->plan;
+  const uint32_t esz = (uint32_t)container_bits / 8u;
   const uint32_t nc = P.p.num_comps;
   int rc = run_workers(m->w.size(), [&](size_t k) -> int {
     auto& W = m->w[k];
     HIPCHK(hipSetDevice(W.device));
     int r = ojphgpu_decoder_upload(W.dec, h_codestream, len);
     if (r) return r;
-    r = ojphgpu_decoder_run_device(W.dec, (int32_t*)W.d_image);
+    r = container_bits == 16 ? ojphgpu_decoder_run_device16(W.dec, (uint16_t*)W.d_image)
+      : container_bits == 8 ? ojphgpu_decoder_run_device8(W.dec, (uint8_t*)W.d_image) : ojphgpu_decoder_run_device(W.dec, (int32_t*)W.d_image);
     if (r) return r;
     r = ojphgpu_decoder_failed_blocks(W.dec, &W.failed);            // collects the run (see its comment): before the image is read
     if (r) return r;
-    for (uint32_t t = W.tiles.first; t < W.tiles.first + W.tiles.count; ++t)
-      for (uint32_t c = 0; c < nc; ++c) {
-        const Piece q = piece_of(P, t, c);
-        if (q.w == 0 || q.h == 0) continue;
-        HIPCHK(hipMemcpy2DAsync(h_image + q.off, (size_t)q.pitch * 4, (const int32_t*)W.d_image + q.off, (size_t)q.pitch * 4, (size_t)q.w * 4, q.h,
-                                hipMemcpyDeviceToHost, W.stream));
-      }
+    r = copy_rects(P, W.tiles, nc, (uint8_t*)W.d_image, (uint8_t*)h_image, esz, false, W.stream);
+    if (r) return r;
     HIPCHK(hipStreamSynchronize(W.stream));
     return OJPHGPU_OK;
   });

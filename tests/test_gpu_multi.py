@@ -42,6 +42,11 @@ def test_multi_device_codec_equals_the_single_device_one(case, devices):
     for _ in range(2):
         got = md.decode()
         assert np.array_equal(got.reshape(-1), np.asarray(want_dec).reshape(-1))
+    if bd <= 16 and "downsampling" not in c:                # the same frame in 16-bit (8-bit) containers: same bytes, same samples
+        dt = (np.uint8 if bd <= 8 else np.uint16)
+        assert me.encode(np.asarray(img).astype(dt)) == want
+        got = md.decode(dtype=dt)
+        assert np.array_equal(got.reshape(-1).astype(np.int64), np.asarray(want_dec).reshape(-1).astype(np.int64))
     if plan.num_tiles > 1 and "downsampling" not in c:      # reduced resolution through the same path
         md = codec.MultiDecoder(want, devices=devices, skip_res=1)
         assert np.array_equal(md.decode().reshape(-1), np.asarray(codec.Decoder(want, skip_res=1).decode()).reshape(-1))
