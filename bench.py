@@ -656,6 +656,44 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
         t = torch.tensor([e2e_best], dtype=torch.float64, device=cdev or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e_best = float(t.item())
+    # ... and with the node's shared-memory gather instead of the gatherv (shard.HostGather): every rank copies its tile-parts over
+    # its OWN link straight to their place in one host segment; no rank receives anything, nothing crosses xGMI
+    host_gather = None
+    try:
+        hg = shard.HostGather(int(len(cs)) + (1 << 20) if rank == 0 else 0, register=True) if world == 1 else None
+        if world > 1:
+            cap = torch.tensor([int(len(cs)) + (1 << 20) if rank == 0 else 0], dtype=torch.int64, device=cdev or "cpu")
+            dist.broadcast(cap, src=0)
+            hg = shard.HostGather(int(cap.item()), register=True)
+        ppt = plan.parts_per_tile
+        hg_best, hg_ok = None, None
+        for _ in range(5):
+            sync()
+            t0 = time.perf_counter()
+            d_img[:, r0:r1].copy_(h_img[:, r0:r1], non_blocking=True)
+            enc.run_device(d_img)
+            part, lens = enc.finish_tiles_device() if (backend == "nccl" or world == 1) else enc.finish_tiles()
+            all_lens = (shard.gather_tile_lengths(lens, plan.num_tiles, first, device=cdev, parts_per_tile=ppt) if world > 1
+                        else np.asarray(lens, np.uint32))
+            sizes = [int(np.asarray(all_lens[shard.tile_range(plan.num_tiles, r, world)[0] * ppt:
+                                             sum(shard.tile_range(plan.num_tiles, r, world)) * ppt], dtype=np.uint64).sum()) for r in range(world)]
+            n_out = hg.place(part, sizes, plan.t2_main_header(all_lens) if rank == 0 else None)
+            sync()
+            dt = time.perf_counter() - t0
+            if rank == 0 and hg_ok is None and size == WORKLOADS[name][0]:
+                hg_ok = bool(n_out == gold["bytes"] and hashlib.sha256(bytes(hg.view[:n_out])).hexdigest() == gold["sha256"])
+            hg_best = dt if hg_best is None or dt < hg_best else hg_best
+        if world > 1:
+            t = torch.tensor([hg_best], dtype=torch.float64, device=cdev or "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hg_best = float(t.item())
+        host_gather = {"ms": round(hg_best * 1e3, 3), "Msamples_s": round(w * h * nc / hg_best / 1e6, 1), "codestream_equals_reference_digest": hg_ok,
+                       "registered_with_hip": bool(hg._registered),
+                       "covers": "the same job with the tile-parts placed by every rank itself in ONE shared host segment (POSIX shared memory, "
+                                 "hipHostRegister): N links at once, no receiving GPU"}
+        hg.close()
+    except Exception as e:                                    # (the figure above stands; this one says why it is missing)
+        host_gather = {"error": str(e)[:300]}
     # the same end-to-end job through the ONE-process form of the sharding (C ABI section 8: a host thread + encoder per device,
     # tile-parts copied from every GPU straight to their place in one pinned buffer) -- measured on rank 0's GPU at N = 1
     inproc = None
@@ -690,6 +728,7 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
                            "covers": "frame in pinned host memory -> .j2c bytes in pinned host memory on rank 0: every rank's upload of its "
                                      "tiles' rows, kernels, tile-parts laid out in HBM, all-reduce of the Psot lengths, gatherv of the "
                                      "tile-parts to rank 0, rank 0's copies behind the main header; max over ranks, best of 5",
+                           "shared_host_segment": host_gather,
                            "one_process_multi_device": inproc},
             "codestream_bytes": len(cs), "codestream_equals_reference_digest": digest_ok, "tiles_lossless_on_every_rank": True,
             "gather": {"backend": "rccl" if backend == "nccl" else backend,

@@ -651,6 +651,12 @@ void ojphgpu_multi_decoder_destroy(ojphgpu_multi_decoder* dec);
 int  ojphgpu_multi_decoder_plan(ojphgpu_multi_decoder* dec, const ojphgpu_plan** plan);      /* owned by the decoder */
 /* the codestream the decoder was created for -> h_image; OJPHGPU_E_BLOCK when blocks failed and the decoder is not resilient */
 int  ojphgpu_multi_decode(ojphgpu_multi_decoder* dec, const uint8_t* h_codestream, size_t len, int32_t* h_image, uint32_t* failed_blocks);
+/* Host memory the caller got elsewhere (a shared-memory segment several processes write one codestream into, a file
+ * mapping) made known to the HIP runtime this library runs on, so that copies from / to it run at link speed
+ * (hipHostRegister / hipHostUnregister).  openjph_amd/shard.py HostGather: every rank of a node copies its tile-parts over
+ * its own GPU's link straight to their place in ONE segment -- the gather of SURVEY 8(e) without a receiving GPU. */
+int  ojphgpu_host_register(void* h_ptr, size_t bytes);
+int  ojphgpu_host_unregister(void* h_ptr);
 int  ojphgpu_multi_decode_container(ojphgpu_multi_decoder* dec, const uint8_t* h_codestream, size_t len, void* h_image, int container_bits,
                                     uint32_t* failed_blocks);
 

@@ -261,6 +261,8 @@ SIGNATURES = {
     "ojphgpu_multi_decoder_destroy": (None, [C.c_void_p]),
     "ojphgpu_multi_decoder_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ojphgpu_multi_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ojphgpu_host_unregister": (C.c_int, [C.c_void_p]),
     "ojphgpu_multi_decode_container": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "ojphgpu_enc_pipe_set_pixels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ojphgpu_enc_pipe_set_packed": (C.c_int, [C.c_void_p, C.c_int]),

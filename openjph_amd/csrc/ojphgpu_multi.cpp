@@ -334,3 +334,17 @@ extern "C" int ojphgpu_multi_decode_container(ojphgpu_multi_decoder* m, const ui
   if (failed_blocks) *failed_blocks = failed;
   return (failed && !m->resilient) ? OJPHGPU_E_BLOCK : OJPHGPU_OK;
 }
+
+extern "C" int ojphgpu_host_register(void* h_ptr, size_t bytes)
+{
+  if (!h_ptr || !bytes) return OJPHGPU_E_INVALID;
+  if (hipHostRegister(h_ptr, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return OJPHGPU_E_HIP; }
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_host_unregister(void* h_ptr)
+{
+  if (!h_ptr) return OJPHGPU_E_INVALID;
+  if (hipHostUnregister(h_ptr) != hipSuccess) { (void)hipGetLastError(); return OJPHGPU_E_HIP; }
+  return OJPHGPU_OK;
+}

@@ -94,6 +94,92 @@ def to_host(bufs):
     return out
 
 
+class HostGather:
+    """The final gather of a node WITHOUT a receiving GPU: one shared-memory segment for the codestream, every rank copies its
+    tile-parts from its own GPU over its own link straight to their place in it (the offsets are a prefix sum of the lengths
+    every rank already exchanges for the main header).  Where the RCCL gatherv funnels the whole codestream through rank 0's
+    GPU and then through rank 0's one link to the host, here N links work at once and nothing crosses xGMI.  Ranks of ONE node
+    only (POSIX shared memory).  Collective: every rank of the group constructs it, calls place() per frame, and close().
+
+    capacity: bytes of the segment (a bound of the codestream's size).  register: make the segment known to the HIP runtime
+    (pinned, link-speed copies) -- off for host-only runs (the gloo tests)."""
+
+    def __init__(self, capacity: int, group=None, register=True):
+        import torch.distributed as dist
+        from multiprocessing import shared_memory
+        self._dist = dist.is_available() and dist.is_initialized()       # (a single process: the same calls, nobody to meet)
+        self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if self._dist else (0, 1)
+        self.group = group
+        name = [None]
+        if self.rank == 0:
+            self._shm = shared_memory.SharedMemory(create=True, size=int(capacity))
+            name[0] = self._shm.name
+        if self._dist:
+            dist.broadcast_object_list(name, src=0, group=group)
+        if self.rank != 0:
+            self._shm = shared_memory.SharedMemory(name=name[0])
+            try:                                              # (Python < 3.13 lets every attaching process's tracker unlink the
+                from multiprocessing import resource_tracker  #  segment at exit: it is rank 0's to remove)
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        self.capacity = int(capacity)
+        self.view = np.frombuffer(self._shm.buf, dtype=np.uint8, count=self.capacity)
+        self._registered = False
+        if register:
+            from . import capi
+            rc = capi.lib().ojphgpu_host_register(self.view.ctypes.data, self.capacity)
+            self._registered = rc == 0
+        if self._dist:
+            dist.barrier(group=group)
+
+    def place(self, part, lengths_of_all_ranks, header: bytes = None):
+        """part: this rank's tile-parts (uint8 tensor on its device, or on the host, or bytes); lengths_of_all_ranks: the
+        byte counts of every rank's part, in rank order; header: the main header (rank 0 passes it).  Returns the total
+        length once every rank's bytes are in place (a barrier closes the call); rank 0 appends EOC."""
+        import torch
+        import torch.distributed as dist
+        hlen = torch.tensor([len(header) if (self.rank == 0 and header is not None) else 0], dtype=torch.int64)
+        if self._dist:
+            if torch.cuda.is_available() and dist.get_backend(self.group) == "nccl":
+                hlen = hlen.cuda(); dist.broadcast(hlen, src=0, group=self.group); hlen = hlen.cpu()
+            else:
+                dist.broadcast(hlen, src=0, group=self.group)
+        at = int(hlen.item()) + int(sum(int(x) for x in lengths_of_all_ranks[:self.rank]))
+        total = int(hlen.item()) + int(sum(int(x) for x in lengths_of_all_ranks)) + 2
+        if total > self.capacity:
+            raise ValueError("codestream of %d bytes does not fit the segment (%d)" % (total, self.capacity))
+        n = int(lengths_of_all_ranks[self.rank])
+        dst = torch.from_numpy(self.view[at:at + n])
+        if hasattr(part, "is_cuda"):
+            if n:
+                dst.copy_(part[:n], non_blocking=True)
+            if part.is_cuda:
+                torch.cuda.synchronize(part.device)
+        elif n:
+            self.view[at:at + n] = np.frombuffer(part, dtype=np.uint8, count=n)
+        if self.rank == 0:
+            if header is not None:
+                self.view[:len(header)] = np.frombuffer(header, dtype=np.uint8)
+            self.view[total - 2] = 0xFF; self.view[total - 1] = 0xD9
+        if self._dist:
+            dist.barrier(group=self.group)
+        return total
+
+    def close(self):
+        import torch.distributed as dist
+        if self._dist:
+            dist.barrier(group=self.group)
+        if self._registered:
+            from . import capi
+            capi.lib().ojphgpu_host_unregister(self.view.ctypes.data)
+            self._registered = False
+        self.view = None
+        self._shm.close()
+        if self.rank == 0:
+            self._shm.unlink()
+
+
 def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None, device=None, parts_per_tile=1):
     """All ranks learn Psot of every tile-part (needed by the TLM marker and for file offsets);
     lens holds parts_per_tile entries per tile of this rank's run."""
@@ -121,3 +207,22 @@ def encode_sharded(encode_tiles, plan, group=None, device=None):
     if rank != 0:
         return None
     return assemble(plan.t2_main_header(all_lens), parts)
+
+
+def encode_sharded_to_host(encode_tiles, plan, gather: HostGather, group=None, device=None):
+    """encode_sharded with the node's HostGather instead of the gatherv to rank 0: every rank places its tile-parts itself.
+    encode_tiles(first, count) -> (tile-part bytes / uint8 tensor on the rank's device, Psot array).  Returns the length of
+    the codestream (it lies at the start of gather.view on every rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    first, count = tile_range(plan.num_tiles, rank, world)
+    part, lens = encode_tiles(first, count) if count else (b"", np.zeros(0, np.uint32))
+    all_lens = gather_tile_lengths(lens, plan.num_tiles, first, group, device, plan.parts_per_tile)
+    ppt = plan.parts_per_tile
+    sizes = [int(np.asarray(all_lens[tile_range(plan.num_tiles, r, world)[0] * ppt:
+                                     (tile_range(plan.num_tiles, r, world)[0] + tile_range(plan.num_tiles, r, world)[1]) * ppt], dtype=np.uint64).sum())
+             for r in range(world)]
+    header = plan.t2_main_header(all_lens) if rank == 0 else None
+    return gather.place(part, sizes, header)

@@ -44,8 +44,15 @@ def _worker(rank, world, port, case, q):
         kw = dict(case["kw"], bit_depth=case["bd"])
         plan = Plan(make_params(case["w"], case["h"], case["nc"], **kw))
         cs = shard.encode_sharded(lambda first, count: cp.encode_tiles(plan, img, first, count), plan)
+        # the same frame through the node's shared-memory gather (every rank places its own tile-parts; no receiving rank)
+        cap = [len(cs) + 4096 if rank == 0 else 0]
+        dist.broadcast_object_list(cap, src=0)
+        hg = shard.HostGather(cap[0], register=False)
+        n = shard.encode_sharded_to_host(lambda first, count: cp.encode_tiles(plan, img, first, count), plan, hg)
+        same = bytes(hg.view[:n]) == (cs if rank == 0 else bytes(hg.view[:n]))
         if rank == 0:
-            q.put(cs)
+            q.put(cs if same and n == len(cs) else b"host gather differs")
+        hg.close()
         dist.barrier()
     finally:
         dist.destroy_process_group()
