@@ -34,3 +34,12 @@ def test_reference_decodes_part2_codestreams_like_the_oracle(case, ref, refgen):
             assert all(np.array_equal(a, b) for a, b in zip(d1, w1))
         else:
             assert np.array_equal(d1, w1)
+
+
+def test_random_part2_configurations_decode_like_the_reference(ref, refgen):
+    """a few seconds of tools/fuzz_part2_cpu.py (random ATK kernels, DFS level kinds, component styles, tiles, offsets): the live
+    reference decodes what this repository writes to the oracle pipeline's samples (profiles/r04_a_part2_fuzz.txt: 25 000 cases)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_part2_cpu
+    assert fuzz_part2_cpu.main(seconds=6.0, seed=5) == 0
