@@ -65,6 +65,47 @@ static float vw_get(const float* v, uint32_t level, uint32_t band)      // visua
   return v[(level - 1) * 3 + (3 - band)];
 }
 
+// BIBO gains of a lifting kernel an ATK marker segment describes: the largest factor by which one analysis level can
+// raise a low-pass (gl) / a high-pass (gh) sample over the samples it is made from -- the L1 norm of the level's analysis
+// filters, found by running the steps (analysis order: N-1 .. 0, the first one on the high-pass samples, K on the high and
+// 1 / K on the low ones) over the unit impulses of a 64-sample line.  The reference only READS such kernels and takes the
+// magnitude bits of their sub-bands from the QCD / QCC it is given; the writer here has to choose them, and the 5/3 and 9/7
+// tables it uses for the Part-1 wavelets say nothing about a kernel with other gains: coefficients past K_max bits would be
+// coded with their top bits cut off.
+static void atk_bibo_gains(const AtkDef& a, double& gl, double& gh, double* dc_low = nullptr)
+{
+  const int N = 64;
+  std::vector<std::vector<double>> m(N, std::vector<double>(N, 0.0));
+  for (int i = 0; i < N; ++i) m[i][i] = 1.0;
+  const int ns = (int)a.steps.size();
+  for (int k = 0; k < ns; ++k) {
+    const ojphgpu_lift_step& st = a.steps[(size_t)(ns - 1 - k)];
+    const double c = a.rev ? (double)st.a / std::ldexp(1.0, (int)st.e) : (double)st.A;
+    const int first = (k & 1) ? 0 : 1;                       // k = 0 updates the high-pass (odd) samples of a line that starts even
+    std::vector<std::vector<double>> nm = m;
+    for (int t = first; t < N; t += 2) {
+      const int l = t == 0 ? 1 : t - 1, r = t + 1 >= N ? t - 1 : t + 1;
+      for (int j = 0; j < N; ++j) nm[t][j] = m[t][j] + c * (m[l][j] + m[r][j]);
+    }
+    m.swap(nm);
+  }
+  gl = gh = 0.0;
+  if (dc_low) *dc_low = 0.0;
+  for (int t = N / 4; t < 3 * N / 4; ++t) {                  // (samples away from the borders: the extension only repeats taps)
+    double n1 = 0.0, dc = 0.0;
+    for (int j = 0; j < N; ++j) { n1 += std::fabs(m[t][j]); dc += m[t][j]; }
+    // (K: the low-pass samples are scaled by 1 / K, the high-pass ones by K -- the other way round in the reference's horizontal
+    //  analysis after an odd number of steps, so then the larger of the two)
+    const double k_lo = a.rev ? 1.0 : (ns & 1) ? std::max((double)a.K, 1.0 / (double)a.K) : 1.0 / (double)a.K;
+    const double k_hi = a.rev ? 1.0 : (ns & 1) ? std::max((double)a.K, 1.0 / (double)a.K) : (double)a.K;
+    if (dc_low && !(t & 1)) *dc_low = std::max(*dc_low, std::fabs(dc) * k_lo);   // what a level makes of a constant
+    n1 *= (t & 1) ? k_hi : k_lo;
+    (t & 1 ? gh : gl) = std::max(t & 1 ? gh : gl, n1);
+  }
+  if (a.rev) { gl += 0.5 * ns; gh += 0.5 * ns; }            // every step rounds: half a unit each, against small samples
+  gl = std::max(gl, 1.0); gh = std::max(gh, 1.0);
+}
+
 // One QCD / QCC: param_qcd::make_quant_steps for component `comp` (ojph_params.cpp:1434-1460) with
 // set_rev_quant (:1495-1540) or set_irrev_quant (:1542-1599).  ctype 0 Y, 1 Cb, 2 Cr; qfactor 0 = unset.
 // `st` = the COD (for the QCD) or the component's own coding style; `base` = the base step handed down
@@ -75,15 +116,22 @@ static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint
   const ojphgpu_params& p = plan.p;
   const uint32_t D = st.L, depth = plan.comps[comp].bit_depth;
   q.q8.clear(); q.q16.clear();
+  // an ATK kernel: cumulative gains from its own filters -- low-pass after d levels gl^d, high-pass of level d gl^(d-1) gh
+  // (upper bounds: the product of the levels' norms) -- in place of the 5/3 table
+  const AtkDef* atk = plan.atk_of(comp);
+  double agl = 1.0, agh = 1.0;
+  if (atk) atk_bibo_gains(*atk, agl, agh);
+  auto bibo_l = [&](uint32_t d) { return atk ? std::pow(agl, (double)d) : (double)bibo53_l[d]; };
+  auto bibo_h = [&](uint32_t d) { return atk ? std::pow(agl, (double)d) * agh : (double)bibo53_h[d]; };
   if (st.rev) {
     uint32_t B = depth + ((comp < 3 && p.color_transform) ? 1 : 0);
     std::vector<uint32_t> e;
-    double bl = bibo53_l[D];
+    double bl = bibo_l(D);
     uint32_t X = (uint32_t)std::ceil(std::log(bl * bl) / M_LN2);
     e.push_back(B + X);
     uint32_t mx = B + X;
     for (uint32_t d = D; d > 0; --d) {
-      double l = bibo53_l[d], h = bibo53_h[d - 1];
+      double l = bibo_l(d), h = bibo_h(d - 1);
       // (a DFS marker segment: the level has one sub-band, or none -- param_dfs::get_subband_idx; the reference never writes
       // such a QCC, these are the exponents of the two-directional level, an upper bound)
       const uint32_t kind = plan.level_kind(comp, d);
@@ -101,7 +149,21 @@ static bool make_quant(const Plan& plan, const CodStyle& st, uint32_t comp, uint
     return true;
   }
   q.guard_bits = 1;
-  q.sqcd = (uint8_t)((1 << 5) | 0x2);
+  if (atk) {
+    // The normalised samples lie in [-1/2, 1/2).  What decides whether the quantised magnitudes fit is, as for the 9/7 (which
+    // the reference codes with ONE guard bit: its low-pass filter passes a constant unchanged, and natural images stay far
+    // below the BIBO bound of the high-pass filters), what the kernel makes of SMOOTH content over the levels -- the DC gain
+    // of its low-pass filter, which an arbitrary kernel does not normalise to 1 -- times what one high-pass filter can add.
+    double dcl = 1.0, l1, h1;
+    atk_bibo_gains(*atk, l1, h1, &dcl);
+    dcl = std::max(1.0, dcl);
+    const double dm1 = (double)(D ? D - 1 : 0);
+    const double g1 = std::pow(dcl, dm1) * std::max(dcl, h1);
+    int gb = 1 + (int)std::ceil(std::log(std::max(1.0, g1 * g1 * 0.5)) / M_LN2 - 1e-9);
+    if (gb > 7) { err = "the wavelet kernel's gain over these decompositions needs more guard bits than a QCD / QCC can signal"; return false; }
+    q.guard_bits = (uint32_t)std::max(1, gb);
+  }
+  q.sqcd = (uint8_t)((q.guard_bits << 5) | 0x2);
   if (!(base > 0.0f)) {                                  // :1451-1455
     uint32_t t = std::min<uint32_t>(16, depth);
     base = 1.0f / (float)(1 << t);

@@ -45,7 +45,8 @@ def rand_case(rng):
                 steps.append((a, int(rng.integers(0, 1 << e)) if e else 0, e))
             atk[idx] = dict(steps=steps)
         else:
-            atk[idx] = dict(steps=[float(np.round(rng.uniform(-1.6, 0.9), 6)) or 0.25 for _ in range(n)], K=float(np.round(rng.uniform(0.8, 1.4), 6)))
+            g = float(os.environ.get("FUZZ_GAIN", "1.0"))     # (large coefficients over many steps and levels take the quantised magnitudes past 31 bits too)
+            atk[idx] = dict(steps=[float(np.round(rng.uniform(-1.6 * g, 0.9 * g), 6)) or 0.25 for _ in range(n)], K=float(np.round(rng.uniform(0.8, 1.4), 6)))
         return idx
 
     def new_dfs(levels):
