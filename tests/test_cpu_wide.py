@@ -101,3 +101,13 @@ def test_deep_sample_codestreams_equal_the_reference(case, ref, refgen):
     assert np.array_equal(dec, rdec)
     if kw.get("reversible", True):
         assert np.array_equal(dec, img)
+
+
+def test_random_deep_frames_equal_the_reference(ref):
+    """a few seconds of tools/fuzz_wide_cpu.py: random 25..32-bit frames (components, signedness, colour transform, tiles, block
+    sizes, progression orders) -- the reference's encoder writes the oracle pipeline's bytes and both decode them alike
+    (profiles/r04_a_wide_fuzz.txt: 23 000 frames)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_wide_cpu
+    assert fuzz_wide_cpu.main(seconds=5.0, seed=9) == 0
