@@ -806,9 +806,10 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   bool use_sop = false, use_eph = false;
   uint32_t num_cocs = 0, num_nlts = 0;
   for (;;) {
-    if (!r.ok(4)) return OJPHGPU_E_CODESTREAM;
+    if (!r.ok(2)) return OJPHGPU_E_CODESTREAM;
     uint32_t m = r.u16();
-    if (m == SOT) { r.pos -= 2; break; }
+    if (m == SOT) { r.pos -= 2; break; }            // (the marker alone ends the main header: a file cut inside the SOT segment is the tile-part loop's case)
+    if (!r.ok(2)) return OJPHGPU_E_CODESTREAM;
     uint32_t L = r.u16();
     if (L < 2 || !r.ok(L - 2)) return OJPHGPU_E_CODESTREAM;
     size_t next = r.pos + L - 2;

@@ -370,7 +370,9 @@ def test_truncated_codestreams_behave_like_the_reference(k, ref):
     img = _truncation_image()
     kw = dict(dict(num_decomps=5), **TRUNC_PARAMS[k])
     cs = ref.encode(img, 8, reversible=True, **kw)
-    cuts = sorted(set([len(cs) * c // 16 for c in range(1, 16)] + list(range(2, 330, 9)) + [len(cs) - 1, len(cs) - 2, len(cs) - 3]))
+    sot = cs.find(b"\xff\x90")                                 # every byte of the first SOT segment and its neighbourhood as well
+    cuts = sorted(set([len(cs) * c // 16 for c in range(1, 16)] + list(range(2, 330, 9)) + list(range(sot - 2, sot + 16)) +
+                      [len(cs) - 1, len(cs) - 2, len(cs) - 3]))
     detected = 0
     for n in cuts:
         part = cs[:n]

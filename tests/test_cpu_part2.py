@@ -43,3 +43,34 @@ def test_random_part2_configurations_decode_like_the_reference(ref, refgen):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_part2_cpu
     assert fuzz_part2_cpu.main(seconds=6.0, seed=5) == 0
+
+
+def test_cut_part2_codestreams_behave_like_the_reference(ref, refgen):
+    """Part-2 codestreams cut at every byte of the main header (ATK / DFS segments included) and of the first tile-part header,
+    and at a dozen points of the data: the parser raises exactly when the reference raises, with and without resilience, and
+    otherwise reconstructs the same image (tools/fuzz_trunc_part2_cpu.py runs every case; this test three of them)"""
+    from openjph_amd import capi
+    from openjph_amd.plan import parse_codestream
+    from tests import cpu_pipeline as cp
+    for case in (CASES[2], CASES[5], CASES[8]):
+        nc, h, w, bd, kw = split(case)
+        cs, plan, *_ = cp.encode(image(nc, h, w, bd), **kw)
+        r = ref if all(plan.comp_style(i)["reversible"] for i in range(nc)) else refgen
+        sot = cs.find(b"\xff\x90")
+        raised = 0
+        for k in list(range(2, sot + 14)) + [len(cs) * c // 12 for c in range(1, 12)] + [len(cs) - 1, len(cs) - 2]:
+            for resilient in (False, True):
+                try:
+                    want, _ = r.decode(cs[:k], resilient=resilient)
+                except RuntimeError:
+                    want = None
+                try:
+                    pl = parse_codestream(cs[:k], resilient=resilient)
+                    got = cp.inverse_stages(pl, cp.decode_blocks(pl, cs[:k]))
+                except capi.OjphError:
+                    got = None
+                assert (want is None) == (got is None), "cut at %d of %d (main header %d), resilient=%s" % (k, len(cs), sot, resilient)
+                if want is not None:
+                    assert all(np.array_equal(a, b) for a, b in zip(got, want)) if isinstance(want, list) else np.array_equal(got, want)
+                raised += want is None
+        assert raised > 0
