@@ -558,16 +558,26 @@ static uint32_t next_bit(const flatbits* f, long* pos)      /* exhausted streams
 }
 
 static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_passes, int p,
-                          int width, int height, int stride, uint64_t* out, int stripe_causal)
+                          int width, int height, int stride, uint64_t* out, int stripe_causal,
+                          const uint16_t* qinf, int qstr)
 {
   int ngroups = (width + 3) >> 2, nstripes = (height + 3) >> 2;
   int mstr = ngroups + 2;
   uint16_t* sigma = (uint16_t*)calloc((size_t)(nstripes + 1) * mstr, 2);
   uint16_t* prev_row = (uint16_t*)calloc((size_t)mstr, 2);
-  for (int y = 0; y < height; ++y)
-    for (int x = 0; x < width; ++x)
-      if (out[(size_t)y * stride + x] != 0)
-        sigma[(y >> 2) * mstr + (x >> 2)] |= (uint16_t)(1u << (4 * (x & 3) + (y & 3)));
+  /* sigma is the quads' rho bits re-arranged (:1331-1351), NOT "the sample is non-zero": a damaged VLC segment may call
+   * the samples of a quad's second column / second row significant where the block is one column / row short, and those
+   * bits count as neighbours in SigProp and take a bit each in MagRef (their samples are never written here) */
+  int QW = (width + 1) >> 1, QH = (height + 1) >> 1;
+  for (int qy = 0; qy < QH; ++qy)
+    for (int qx = 0; qx < QW; ++qx) {
+      const uint32_t rho = ((uint32_t)qinf[(size_t)qy * qstr + qx] >> 4) & 0xFu;
+      for (int n = 0; n < 4; ++n)
+        if (rho & (1u << n)) {
+          const int x = 2 * qx + (n >> 1), y = 2 * qy + (n & 1);
+          sigma[(y >> 2) * mstr + (x >> 2)] |= (uint16_t)(1u << (4 * (x & 3) + (y & 3)));
+        }
+    }
 
   flatbits fspp, fmrp;
   fb_init(&fspp, len2 + 64); fb_init(&fmrp, len2 + 64);
@@ -633,12 +643,12 @@ static void refine_passes(const uint8_t* coded, int lcup, int len2, int num_pass
   if (num_passes > 2) {
     uint64_t half = 1ull << (p - 2);
     for (int y = 0; y < height; y += 4)
-      for (int x = 0; x < width; ++x) {
+      for (int x = 0; x < 4 * ngroups; ++x) {
         uint32_t nib = (sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
         for (int r = 0; r < 4; ++r)
           if (nib & (1u << r)) {
-            uint32_t sym = MRP_BIT();
-            out[(size_t)(y + r) * stride + x] ^= ((uint64_t)(1u - sym) << (p - 1)) | half;
+            uint32_t sym = MRP_BIT();              /* (a bit is taken for a flagged sample outside the block, too: :1583-1606) */
+            if (x < width && y + r < height) out[(size_t)(y + r) * stride + x] ^= ((uint64_t)(1u - sym) << (p - 1)) | half;
           }
       }
   }
@@ -697,7 +707,8 @@ static int ht_decode_core(const uint8_t* coded, int len1, int len2, int num_pass
   if (!wide) { /* VLC: backward, LSB-first (block_decoder32.cpp:308-405) */
     int d = coded[lcup - 2];
     int t = d >> 4;
-    fb_put(&fvlc, (uint32_t)t, 4 - ((t & 7) == 7));
+    fb_put_byte(&fvlc, (uint32_t)t, 4 - ((t & 7) == 7));   /* rev_init :373-375: all four bits stay in the window, bit 3 of an
+                                                              0xF nibble ends up OR-ed with the next byte's LSB */
     int unstuff = (d | 0xF) > 0x8F;
     for (int i = lcup - 3; i >= lcup - scup; --i) {
       int b = coded[i];
@@ -840,6 +851,8 @@ static int ht_decode_core(const uint8_t* coded, int len1, int len2, int num_pass
         for (int n = 0; n < 4; ++n) {
           int x = 2 * qx + (n >> 1), y = 2 * qy + (n & 1);
           uint64_t val = 0, v_n = 0;
+          if (x >= width) break;            /* the second column of an odd-width block's last quad is not read at all, whatever
+                                               a damaged VLC segment says about its samples (:1159, :1269; decoder64 :1207, :1316) */
           if (inf & (1 << (4 + n))) {
             int m_n = U_q - ((inf >> (12 + n)) & 1);
             /* beyond the end the stream is all ones */
@@ -865,7 +878,7 @@ static int ht_decode_core(const uint8_t* coded, int len1, int len2, int num_pass
 #undef VLC_PEEK
 
   if (ok && num_passes > 1)
-    refine_passes(coded, lcup, len2, num_passes, p, width, height, stride, out, stripe_causal);
+    refine_passes(coded, lcup, len2, num_passes, p, width, height, stride, out, stripe_causal, qinf, qstr);
   fb_free(&fmel); fb_free(&fvlc); fb_free(&fms);
   free(qinf); free(quq); free(vrow);
   return ok;

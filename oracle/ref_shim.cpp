@@ -330,4 +330,7 @@ int ref_decode_block64(const uint8_t* coded, uint32_t len1, uint32_t len2, uint3
   return ok ? 0 : 1;
 }
 
+// 0: the library's messages are swallowed (the block-level entry points do not set a level of their own)
+void ref_set_verbose(int on) { ojph::set_message_level(on ? ojph::OJPH_MSG_ALL_MSG : ojph::OJPH_MSG_NO_MSG); }
+
 } // extern "C"

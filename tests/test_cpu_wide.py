@@ -111,3 +111,14 @@ def test_random_deep_frames_equal_the_reference(ref):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_wide_cpu
     assert fuzz_wide_cpu.main(seconds=5.0, seed=9) == 0
+
+
+def test_damaged_blocks_decode_like_the_reference(refgen):
+    """a few seconds of tools/fuzz_blocks_cpu.py: damaged cleanup segments (changed bytes, Scup, stuffing runs, cut and random
+    segments; any block shape, odd widths and heights; any missing_msbs; SigProp / MagRef bytes behind them) through the oracle's
+    32- and 64-bit block decoders and the live reference's generic ones: same verdict, same samples
+    (profiles/r04_b_block_fuzz.txt)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_blocks_cpu
+    assert fuzz_blocks_cpu.main(seconds=6.0, seed=700000) == 0
