@@ -246,6 +246,14 @@ int  ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile
 int  ojphgpu_t2_parse(const uint8_t* h_codestream, size_t len, int resilient, ojphgpu_plan** out);
 /* after ojphgpu_t2_parse: per-block coded info (offsets are into the parsed codestream) */
 int  ojphgpu_plan_coded_blocks(const ojphgpu_plan* plan, ojphgpu_coded_block* out, size_t n);
+/* after ojphgpu_t2_parse of a DAMAGED codestream: the blocks the reference would decode from bytes the codestream does not
+ * hold -- a packet header promising more bytes than its tile-part has left makes bb_read_chunk (ojph_bitbuffer_read.h:134-150)
+ * pad the block with zeros.  hdr = what the packet header said, got = how many of hdr.len1 + hdr.len2 bytes exist at
+ * hdr.offset.  ojphgpu_plan_coded_blocks reports these blocks as not coded and the device decoder leaves them zero (what the
+ * reference does with them when its block decoder refuses the padded bytes; the cases it does not are listed here).
+ * *count receives how many there are (out == NULL: only that); OJPHGPU_E_OVERFLOW when cap is too small. */
+typedef struct ojphgpu_padded_block { uint32_t block, got; ojphgpu_coded_block hdr; } ojphgpu_padded_block;
+int  ojphgpu_plan_padded_blocks(const ojphgpu_plan* plan, ojphgpu_padded_block* out, size_t cap, size_t* count);
 /* codestream::restrict_input_resolution (ojph_codestream_local.cpp:883-900) on a parsed plan, before
  * a decoder is created from it: the top `skipped_res_for_data` resolutions are not decoded and the
  * top `skipped_res_for_recon` (<= the former) are not synthesised.  The frame of the decoder -- and

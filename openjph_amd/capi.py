@@ -99,6 +99,11 @@ class CodedBlock(C.Structure):
                 ("missing_msbs", C.c_uint32), ("num_passes", C.c_uint32)]
 
 
+class PaddedBlock(C.Structure):            # ojphgpu_padded_block
+    _fields_ = [("block", C.c_uint32), ("got", C.c_uint32), ("offset", C.c_uint64), ("len1", C.c_uint32), ("len2", C.c_uint32),
+                ("missing_msbs", C.c_uint32), ("num_passes", C.c_uint32)]
+
+
 class DwtDesc(C.Structure):
     _fields_ = [
         ("src_off", C.c_uint64), ("ll_off", C.c_uint64), ("hl_off", C.c_uint64),
@@ -174,6 +179,7 @@ SIGNATURES = {
     "ojphgpu_plan_comp_plane": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_coded_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ojphgpu_plan_padded_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_t2_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_size_t)]),
     "ojphgpu_t2_write_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

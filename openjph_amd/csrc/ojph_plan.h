@@ -122,6 +122,11 @@ struct Plan {
   // resolutions are not decoded (their blocks count as empty), the top skip_recon are not
   // synthesised; comps / frame_elems then describe the smaller reconstructed frame
   uint32_t skip_read = 0, skip_recon = 0;
+  // parser: blocks the reference keeps although their tile-part did not hold all their bytes -- it pads them with zeros
+  // (bb_read_chunk, ojph_bitbuffer_read.h:134-150).  Their bytes are not in the codestream: in `coded` they are not coded,
+  // here is what the packet header said (block = plan order index, got = bytes the codestream does hold at offset)
+  struct PaddedBlock { uint32_t block, got; CodedBlock hdr; };
+  std::vector<PaddedBlock> padded;
   // tile-part divisions after the progression order had its say (ojph_codestream_local.cpp:582-620):
   // bit 0 = a tile-part per resolution, bit 1 = per component
   uint32_t tilepart_div = 0, parts_per_tile = 1;

@@ -613,15 +613,48 @@ struct Reader {
   uint32_t u32() { uint32_t v = u16(); return (v << 16) | u16(); }
 };
 
-struct HeaderReader {      // ojph_bitbuffer_read.h:66-176
-  const uint8_t* d; size_t pos, end;
-  bool phys;                 // `end` is the end of the file, short of what Psot announced
-  uint32_t tmp = 0; int avail = 0; bool unstuff = false; bool exhausted = false;
-  bool threw = false;        // bb_read found the FILE short: the reference throws there, wherever the bit was wanted (:82-83)
-  bool fill() {
-    if (pos < end) { uint8_t t = d[pos++]; tmp = t; avail = 8 - (unstuff ? 1 : 0); unstuff = (t == 0xFF); return true; }
-    if (phys) threw = true;
-    tmp = 0; avail = 8 - (unstuff ? 1 : 0); unstuff = false; exhausted = true; return false;
+// The reference reads the tile-parts through a FILE object and its behaviour on damaged codestreams is the behaviour of
+// that object: mem_infile (ojph_file.cpp:345-390) -- a read past the end returns the bytes that are there, a seek outside
+// [0, size] FAILS and leaves the position where it was (nobody checks).  Everything from the first SOT on is read through
+// this model of it.
+struct RefFile {
+  const uint8_t* d; size_t n, pos;
+  bool eof() const { return pos >= n; }
+  size_t avail() const { return n - pos; }
+  bool get(uint8_t& b) { if (pos >= n) return false; b = d[pos++]; return true; }
+  size_t skip(size_t k) { k = std::min(k, n - pos); pos += k; return k; }       // a read whose bytes are not looked at
+  bool seek_cur(int64_t off) { const int64_t t = (int64_t)pos + off; if (t < 0 || (uint64_t)t > n) return false; pos = (size_t)t; return true; }
+  bool seek_set(uint64_t off) { if (off > n) return false; pos = (size_t)off; return true; }
+};
+
+// find_marker (ojph_codestream_local.cpp:706-730): byte by byte; after an 0xFF the NEXT byte is taken, too, and compared with the
+// low bytes of the markers looked for -- if it is none of them it is gone (0xFF 0xFF 0x90 is not an SOT).
+int find_marker(RefFile& f, const uint8_t* low, int count)
+{
+  uint8_t c;
+  while (!f.eof()) {
+    if (!f.get(c)) return -1;
+    if (c != 0xFF) continue;
+    if (!f.get(c)) return -1;
+    for (int i = 0; i < count; ++i) if (c == low[i]) return i;
+  }
+  return -1;
+}
+
+struct PacketThrow { const char* what; };   // the reference's `throw "..."` inside precinct::parse / bb_read (caught in tile::parse_tile_header)
+
+struct BitBuf {            // bit_read_buf (ojph_bitbuffer_read.h:56-130): at most bytes_left bytes are taken from the file
+  RefFile* f; uint32_t bytes_left;
+  uint32_t tmp = 0; int avail = 0; bool unstuff = false;
+  bool fill() {                                             // bb_read :78-100
+    if (bytes_left > 0) {
+      uint8_t t;
+      if (!f->get(t)) throw PacketThrow{ "error reading from file" };
+      tmp = t; avail = 8 - (unstuff ? 1 : 0); unstuff = (t == 0xFF); --bytes_left;
+      return true;
+    }
+    tmp = 0; avail = 8 - (unstuff ? 1 : 0); unstuff = false;
+    return false;
   }
   bool bit(uint32_t& b) { bool r = true; if (avail == 0) r = fill(); b = (tmp >> --avail) & 1; return r; }
   bool bits(int n, uint32_t& v) {
@@ -633,48 +666,59 @@ struct HeaderReader {      // ojph_bitbuffer_read.h:66-176
     }
     return r;
   }
-  void terminate() { if (unstuff) fill(); tmp = 0; avail = 0; }
+  void skip_sop() {                                         // bb_skip_sop :183-221
+    if (bytes_left < 2) return;
+    uint8_t m0 = 0, m1 = 0;
+    if (!f->get(m0) || !f->get(m1)) throw PacketThrow{ "error reading from file" };
+    if (m0 == 0xFF && m1 == 0x91) {
+      bytes_left -= 2;
+      if (bytes_left < 4) throw PacketThrow{ "precinct truncated early" };
+      uint8_t l0 = 0, l1 = 0;
+      if (!f->get(l0) || !f->get(l1)) throw PacketThrow{ "error reading from file" };
+      if (l0 != 0 || l1 != 4) throw PacketThrow{ "something is wrong with SOP length" };
+      if (!f->seek_cur(2)) throw PacketThrow{ "error seeking file" };
+      bytes_left -= 4;
+    } else if (!f->seek_cur(-2)) throw PacketThrow{ "error seeking file" };
+  }
+  void terminate(bool uses_eph) {                            // bb_terminate :168-180, bb_skip_eph :153-165
+    if (unstuff) fill();
+    if (uses_eph && bytes_left >= 2) {
+      uint8_t m0 = 0, m1 = 0;
+      if (!f->get(m0) || !f->get(m1)) throw PacketThrow{ "error reading from file" };
+      bytes_left -= 2;
+      if (m0 != 0xFF || m1 != 0x92) throw PacketThrow{ "should find EPH, but found something else" };
+    }
+    tmp = 0; avail = 0;
+  }
 };
 
 }  // namespace
 
-// Parses one packet starting at d[pos]; fills coded[] for the blocks of the precinct.
-// Returns 0, OJPHGPU_E_CODESTREAM when the packet HEADER cannot be read (precinct::parse throws,
-// ojph_precinct.cpp:380-500: an error unless the codestream is read resiliently), or
-// PACKET_DATA_ENDED when the code-block BYTES run out (:545-556: no error in either mode -- the
-// broken block and everything after it in the tile-part count as not coded).
-enum { PACKET_DATA_ENDED = 1 };
+// One packet, as precinct::parse (ojph_precinct.cpp:326-573) reads it: from the file's position, with at most `data_left`
+// bytes of this tile-part; fills coded[] for the blocks of the precinct and leaves in data_left what the tile-part still
+// has.  Throws PacketThrow where the reference throws (the header cannot be read, a length is out of range, missing MSBs
+// beyond K_max, the file is shorter than the tile-part claims while a header bit is wanted, an SOP / EPH is not what it should be).
+// Code-block BYTES (:526-569): a chunk takes min(its length, what the tile-part has left) bytes from the file; only when
+// the FILE has fewer, the block -- and every block after it -- counts as not coded (no error in either mode).  When the
+// tile-part has fewer than the header says but the file delivers them, the reference keeps the block with the missing
+// bytes as ZEROS: `padded` counts those (see t2_parse).
+struct PaddedBlock { uint32_t id, got; };       // block id, bytes the file delivered
 
-static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
-                             bool use_sop, bool use_eph);
+// A precinct whose header threw is read AGAIN from the next tile-part of its tile (resolution::parse_one_precinct,
+// ojph_resolution.cpp:1020-1035: the position moves on only after precinct::parse has returned).  What the failed attempt
+// wrote into its blocks' headers STAYS (coded_cb_header: lengths, passes, missing MSBs; no bytes -- next_coded is still NULL):
+// a block the next attempt does not find included keeps those lengths and takes that many bytes in the body phase
+// (:526-569 goes by pass_length alone).  `has_data` is next_coded != NULL; blocks without it are emptied at the end of t2_parse.
+static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data_left, bool use_sop, bool use_eph,
+                         std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data);
 
-static int parse_packet(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
-                        bool use_sop, bool use_eph)
-{
-  const int rc = parse_packet_impl(P, pc, d, pos, end, phys, use_sop, use_eph);
-  if (rc == OJPHGPU_E_CODESTREAM) {              // blocks that got lengths from the broken header never get bytes
-    const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
-    for (int s = 0; s < 4; ++s) {
-      if (R.band[s] < 0) continue;
-      const Band& B = P.bands[(size_t)R.band[s]];
-      if (B.empty) continue;
-      const Rect& q = pc.cb[s];
-      for (uint32_t y = 0; y < q.h; ++y)
-        for (uint32_t x = 0; x < q.w; ++x) {
-          CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
-          k.len1 = k.len2 = 0; k.num_passes = 0;
-        }
-    }
-  }
-  return rc;
-}
-
-static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size_t& pos, size_t end, bool phys,
-                             bool use_sop, bool use_eph)
+static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data_left, bool use_sop, bool use_eph,
+                         std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data)
 {
   const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
-  if (use_sop && pos + 6 <= end && d[pos] == 0xFF && d[pos + 1] == 0x91) pos += 6;
-  HeaderReader bb{ d, pos, end, phys };
+  BitBuf bb{ &f, data_left };
+  if (use_sop) bb.skip_sop();
+  auto lost = [&](const char* what) -> PacketThrow { data_left = 0; return PacketThrow{ what }; };   // { data_left = 0; throw "..."; }
   bool empty_packet = true;
   for (int s = 0; s < 4; ++s) {
     if (R.band[s] < 0) continue;
@@ -684,12 +728,11 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
     if (q.w == 0 || q.h == 0) continue;
     if (empty_packet) {
       uint32_t b; bb.bit(b);
-      if (bb.threw) return OJPHGPU_E_CODESTREAM;
-      if (b == 0) { bb.terminate(); pos = bb.pos; if (use_eph && pos + 2 <= end) pos += 2; return bb.threw ? OJPHGPU_E_CODESTREAM : 0; }
+      if (b == 0) { bb.terminate(use_eph); data_left = bb.bytes_left; return; }
       empty_packet = false;
     }
     const uint32_t levels = 1 + std::max(log2ceil(q.w), log2ceil(q.h));
-    if (levels > 32) return OJPHGPU_E_CODESTREAM;
+    if (levels > 32) throw PacketThrow{ "tag tree too deep" };
     static thread_local ParseTree inc, mm;
     inc.shape(q.w, q.h, levels); mm.shape(q.w, q.h, levels);
     for (uint32_t y = 0; y < q.h; ++y)
@@ -701,7 +744,7 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
           empty_cb = inc.val[n] == 1;
           if (empty_cb) break;
           if (!inc.flag[n]) {
-            uint32_t b; if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+            uint32_t b; if (!bb.bit(b)) throw lost("error reading from file p1");
             empty_cb = (b == 0);
             inc.val[n] = (uint8_t)(1 - b);
             inc.flag[n] = 1;
@@ -718,23 +761,23 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
           mmsbs = mm.val[mm.node(x, y, cl)];
           if (!mm.flag[n]) {
             uint32_t b = 0;
-            while (b == 0) { if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM; mmsbs += 1 - b; }
+            while (b == 0) { if (!bb.bit(b)) throw lost("error reading from file p2"); mmsbs += 1 - b; }
             mm.val[n] = (uint8_t)mmsbs;
             mm.flag[n] = 1;
           } else mmsbs = mm.val[n];
         }
-        if (mmsbs > B.K_max) return OJPHGPU_E_CODESTREAM;
+        if (mmsbs > B.K_max) throw PacketThrow{ "missing msbs are larger or equal to Kmax" };
         uint32_t b, np = 1;
-        if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+        if (!bb.bit(b)) throw lost("p3");
         if (b) {
-          np = 2; if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM;
+          np = 2; if (!bb.bit(b)) throw lost("p4");
           if (b) {
-            if (!bb.bits(2, b)) return OJPHGPU_E_CODESTREAM;
+            if (!bb.bits(2, b)) throw lost("p5");
             np = 3 + b;
             if (b == 3) {
-              if (!bb.bits(5, b)) return OJPHGPU_E_CODESTREAM;
+              if (!bb.bits(5, b)) throw lost("p6");
               np = 6 + b;
-              if (b == 31) { if (!bb.bits(7, b)) return OJPHGPU_E_CODESTREAM; np = 37 + b; }
+              if (b == 31) { if (!bb.bits(7, b)) throw lost("p7"); np = 37 + b; }
             }
           }
         }
@@ -742,27 +785,24 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
         k.missing_msbs = mmsbs + phld;
         phld *= 3;
         k.num_passes = np - phld;
+        k.len1 = k.len2 = 0;
         int Lblock = 3; b = 1;
-        while (b) { if (!bb.bit(b)) return OJPHGPU_E_CODESTREAM; Lblock += (int)b; }
+        while (b) { if (!bb.bit(b)) throw lost("p8"); Lblock += (int)b; }
         int nbits = Lblock + 31 - __builtin_clz(phld + 1);
-        if (!bb.bits(nbits, b)) return OJPHGPU_E_CODESTREAM;
-        if (b < 2 || b >= 65535) return OJPHGPU_E_CODESTREAM;
-        k.len1 = b; k.len2 = 0;
+        if (!bb.bits(nbits, b)) throw lost("p9");
+        if (b < 2 || b >= 65535) throw PacketThrow{ "cleanup segment length" };
+        k.len1 = b;
         if (k.num_passes > 1) {
           nbits = Lblock + (k.num_passes > 2 ? 1 : 0);
-          if (!bb.bits(nbits, b)) return OJPHGPU_E_CODESTREAM;
-          if (b >= 2047) return OJPHGPU_E_CODESTREAM;
+          if (!bb.bits(nbits, b)) throw lost("p10");
+          if (b >= 2047) throw PacketThrow{ "refinement segment length" };
           k.len2 = b;
         }
       }
   }
   if (empty_packet) { uint32_t b; bb.bit(b); }
-  bb.terminate();
-  if (bb.threw) return OJPHGPU_E_CODESTREAM;
-  pos = bb.pos;
-  if (use_eph && pos + 2 <= end && d[pos] == 0xFF && d[pos + 1] == 0x92) pos += 2;
+  bb.terminate(use_eph);
   // body
-  bool ended = false;
   for (int s = 0; s < 4; ++s) {
     if (R.band[s] < 0) continue;
     const Band& B = P.bands[(size_t)R.band[s]];
@@ -770,17 +810,40 @@ static int parse_packet_impl(Plan& P, const Precinct& pc, const uint8_t* d, size
     const Rect& q = pc.cb[s];
     for (uint32_t y = 0; y < q.h; ++y)
       for (uint32_t x = 0; x < q.w; ++x) {
-        CodedBlock& k = P.coded[B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x)];
-        size_t nbytes = (size_t)k.len1 + k.len2;
+        const size_t id = B.first_block + (q.y0 + y) * B.nbx + (q.x0 + x);
+        CodedBlock& k = P.coded[id];
+        const uint32_t nbytes = k.len1 + k.len2;
         if (!nbytes) continue;
-        if (ended || pos + nbytes > end) { k.len1 = k.len2 = 0; k.num_passes = 0; pos = end; ended = true; continue; }
-        k.offset = pos; pos += nbytes;
+        if (!data_left) { k.len1 = k.len2 = 0; continue; }
+        const uint32_t want = std::min(nbytes, bb.bytes_left);         // bb_read_chunk (ojph_bitbuffer_read.h:134-150)
+        k.offset = f.pos;
+        const uint32_t got = (uint32_t)f.skip(want);
+        bb.bytes_left -= got;
+        has_data[id] = 1;                                               // (get_buffer comes first, whatever the read delivers)
+        if (got != want) { k.len1 = k.len2 = 0; data_left = 0; }        // "no need to decode a broken codeblock"
+        else if (want < nbytes) padded.push_back(PaddedBlock{ (uint32_t)id, want });   // kept, its last nbytes - want bytes are zeros
       }
   }
-  return ended ? PACKET_DATA_ENDED : 0;
+  data_left = bb.bytes_left;
 }
 
 static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out);
+
+extern "C" int ojphgpu_plan_padded_blocks(const ojphgpu_plan* plan, ojphgpu_padded_block* out, size_t cap, size_t* count)
+{
+  if (!plan || !count) return OJPHGPU_E_INVALID;
+  const Plan& P = plan->plan;
+  *count = P.padded.size();
+  if (!out) return OJPHGPU_OK;                                       // (the count alone)
+  if (cap < P.padded.size()) return OJPHGPU_E_OVERFLOW;
+  for (size_t i = 0; i < P.padded.size(); ++i) {
+    const Plan::PaddedBlock& b = P.padded[i];
+    out[i].block = b.block; out[i].got = b.got;
+    out[i].hdr.offset = b.hdr.offset; out[i].hdr.len1 = b.hdr.len1; out[i].hdr.len2 = b.hdr.len2;
+    out[i].hdr.missing_msbs = b.hdr.missing_msbs; out[i].hdr.num_passes = b.hdr.num_passes;
+  }
+  return OJPHGPU_OK;
+}
 
 extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
 {
@@ -1027,52 +1090,109 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   if (!derive_precision(P)) return OJPHGPU_E_INVALID;
   assign_planes(P);
   P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
+  // ---- tile-parts: codestream::read (ojph_codestream_local.cpp:912-1113) ----
+  // Markers are SEARCHED for (find_marker), not expected: whatever lies between the end of one tile-part and the next 0xFF90 /
+  // 0xFFD9 is passed over, and so is anything between the SOT segment and the first marker a tile-part header may hold.  What a
+  // damaged or truncated file means follows from where each step leaves the file position; in resilient mode every failure is
+  // only reported and reading goes on with the search for the next SOT.
   std::vector<size_t> next_pkt(P.tiles.size(), 0);
   std::vector<uint32_t> next_part(P.tiles.size(), 0);
-  int status = OJPHGPU_OK;
-  // tile-parts
-  // What a truncated file means follows codestream::read (ojph_codestream_local.cpp:912-1113): the
-  // file ending where the next SOT / EOC is expected is only reported ("File terminated early",
-  // :1104-1108), and so is a tile-part shorter than its Psot whose packets end inside code-block
-  // bytes; a cut inside an SOT, a tile-part header or a packet header is an error unless resilient.
+  std::vector<PaddedBlock> padded;
+  std::vector<uint8_t> has_data(P.blocks.size(), 0);
+  RefFile f{ d, len, std::min(r.pos + 2, len) };                       // read_headers has taken the first SOT marker
+  static const uint8_t first_part_markers[11] = { 0x52, 0x53, 0x5C, 0x5D, 0x5E, 0x5F, 0x61, 0x58, 0x64, 0x76, 0x93 };   // COD COC QCD QCC RGN POC PPT PLT COM NLT SOD
+  static const uint8_t next_markers[2] = { 0x90, 0xD9 };                // SOT, EOC
   for (;;) {
-    if (!r.ok(2)) break;                                                // :1103-1108
-    size_t sot_pos = r.pos;
-    uint32_t m = r.u16();
-    if (m == EOC) break;
-    if (m != SOT || !r.ok(10)) { status = OJPHGPU_E_CODESTREAM; break; }
-    uint32_t lsot = r.u16(), isot = r.u16(), psot = r.u32(); const uint32_t tpsot = r.u8(); r.u8();
-    if (lsot != 10 || isot >= P.tiles.size()) { status = OJPHGPU_E_CODESTREAM; break; }
-    if (tpsot != next_part[isot]++ && !resilient) { status = OJPHGPU_E_CODESTREAM; break; }   // "wrong tile part index" (ojph_tile.cpp:780-787)
-    const size_t tp_nominal = psot ? sot_pos + psot : (len >= 2 ? len - 2 : len);   // where Psot says the tile-part ends
-    const size_t tp_end = std::min(tp_nominal, len);
-    bool bad = false;
-    for (;;) {                                   // tile-part header markers up to SOD
-      if (!r.ok(2)) { bad = true; break; }
-      uint32_t mk = r.u16();
-      if (mk == SOD) break;
-      if (!r.ok(2)) { bad = true; break; }
-      uint32_t L = r.u16();
-      if (L < 2 || !r.ok(L - 2)) { bad = true; break; }
-      if (mk != PLT && mk != COM) { return OJPHGPU_E_INVALID; }
-      r.pos += L - 2;
+    // param_sot::read (ojph_params.cpp:2390-2461)
+    bool sot_ok = true;
+    uint32_t isot = 0, psot = 0, tpsot = 0, tnsot = 0;
+    {
+      uint8_t h[10]; size_t got = 0;
+      auto need = [&](size_t k) { while (got < k) { if (!f.get(h[got])) return false; ++got; } return true; };
+      if (!need(2)) sot_ok = false;
+      else if (((uint32_t)h[0] << 8 | h[1]) != 10) sot_ok = false;
+      else if (!need(4)) sot_ok = false;
+      else if ((isot = (uint32_t)h[2] << 8 | h[3]) == 0xFFFF) sot_ok = false;
+      else if (!need(8)) sot_ok = false;
+      else if (!need(9)) sot_ok = false;
+      else if (!need(10)) sot_ok = false;
+      if (sot_ok) { psot = (uint32_t)h[4] << 24 | (uint32_t)h[5] << 16 | (uint32_t)h[6] << 8 | h[7]; tpsot = h[8]; tnsot = h[9]; }
+      else if (!resilient) return OJPHGPU_E_CODESTREAM;
     }
-    if (bad) { status = OJPHGPU_E_CODESTREAM; break; }
-    const Tile& T = P.tiles[isot];
-    size_t pos = r.pos;
-    // packets are parsed while Psot promises more bytes (tile::parse_tile_header, ojph_tile.cpp:792-905);
-    // when the file ends first, a packet whose code-block bytes are cut is tolerated, and the next
-    // packet -- if the tile has one -- fails on its first header bit
-    while (pos < tp_nominal && next_pkt[isot] < T.packets.size()) {
-      int prc = parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], d, pos, tp_end, tp_nominal > len, use_sop, use_eph);
-      next_pkt[isot]++;
-      if (prc == PACKET_DATA_ENDED) continue;
-      if (prc != 0) { status = prc; break; }
+    if (sot_ok) {
+      const uint64_t tile_start = f.pos;
+      bool skip_tile = false;
+      if (isot >= P.tiles.size()) {                                     // "wrong tile index" :925-933
+        if (!resilient) return OJPHGPU_E_CODESTREAM;
+        skip_tile = true;
+      }
+      if (!skip_tile) {
+        if (tpsot && tnsot && tpsot >= tnsot && !resilient) return OJPHGPU_E_CODESTREAM;      // :939-950
+        // tile-part header: the first tile-part of a tile may hold COD COC QCD QCC RGN, every one POC PPT PLT COM NLT; all
+        // of them are passed over ("... in a tile is not supported yet" is a warning), up to the SOD (:952-1093)
+        const uint8_t* list = tpsot ? first_part_markers + 5 : first_part_markers;
+        const int nlist = tpsot ? 6 : 11;
+        bool sod_found = false;
+        for (;;) {
+          const int idx = find_marker(f, list, nlist);
+          if (idx == nlist - 1) { sod_found = true; break; }
+          if (idx < 0) { if (!resilient) return OJPHGPU_E_CODESTREAM; break; }   // "File terminated early before start of data is found"
+          uint8_t l0 = 0, l1 = 0;                                         // skip_marker :734-766
+          if (!f.get(l0) || !f.get(l1)) { if (!resilient) return OJPHGPU_E_CODESTREAM; break; }   // (a lone byte stays taken)
+          f.seek_cur((int64_t)((uint32_t)l0 << 8 | l1) - 2);              // (a length below 2 steps backwards; out of the file: no move)
+        }
+        if (sod_found) {
+          // tile::parse_tile_header (ojph_tile.cpp:777-935)
+          if (tpsot != (next_part[isot] & 0xFFFFFFFFu) && !resilient) return OJPHGPU_E_CODESTREAM;   // "wrong tile part index"
+          ++next_part[isot];
+          const uint32_t payload = psot > 0 ? psot - 12u : 0u;            // (param_sot::get_payload_length; 32-bit arithmetic throughout)
+          const uint64_t tile_end = tile_start + payload;
+          uint32_t data_left = payload - (uint32_t)(f.pos - tile_start);
+          if (data_left != 0) {
+            const Tile& T = P.tiles[isot];
+            try {
+              while (data_left > 0 && next_pkt[isot] < T.packets.size()) {
+                parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], f, data_left, use_sop, use_eph, padded, has_data);
+                ++next_pkt[isot];
+              }
+            } catch (const PacketThrow&) {
+              if (!resilient) return OJPHGPU_E_CODESTREAM;
+            }
+            f.seek_set(tile_end);                                         // (beyond the file: the position stays where parsing stopped)
+          }
+        }
+      }
     }
-    r.pos = tp_end;                                                     // tile::parse_tile_header ends with a seek to here
-    if (status != OJPHGPU_OK && !resilient) break;
+    const int idx = find_marker(f, next_markers, 2);                      // :1101-1111
+    if (idx != 0) break;                                                  // EOC, or "File terminated early" (reported only)
   }
-  if (status != OJPHGPU_OK && !resilient) { return status; }
+  // Blocks the reference keeps although the tile-part did not hold all their bytes (bb_read_chunk pads them with zeros): their
+  // bytes do not exist in the codestream, so they cannot be handed to the block decoder by offset.
+  //   * The padding reaches the last two bytes of the cleanup segment: Scup reads 0 (or, with one byte of padding, the low
+  //     nibble of the byte before it); below 2 or above the segment length the block is refused (block_decoder32.cpp:817-819)
+  //     -- an error unless the codestream is read resiliently (ojph_codeblock.cpp:214-222), a zero block if it is.
+  //   * The cleanup segment is whole and there is one refinement pass (SigProp reads forwards, zeros when exhausted): the
+  //     same as a refinement segment that ends where the bytes end.
+  //   * Anything else (MagRef reads backwards, out of the padding; one byte of padding under a plausible Scup) needs the
+  //     padded bytes: the block is listed in P.padded (ojphgpu_plan_padded_blocks) and is NOT coded as far as `coded` and the
+  //     device decoder are concerned -- an open item.
+  for (size_t i = 0; i < P.coded.size(); ++i)                             // codeblock::decode (ojph_codeblock.cpp:192-194): lengths, passes AND bytes
+    if (!has_data[i] || P.coded[i].len1 == 0 || P.coded[i].num_passes == 0) { P.coded[i].len1 = P.coded[i].len2 = 0; P.coded[i].num_passes = 0; }
+  for (const PaddedBlock& pb : padded) {
+    CodedBlock& k = P.coded[pb.id];
+    if (k.len1 == 0) continue;
+    bool refused = false, listed = false;
+    if (pb.got + 2 <= k.len1) refused = true;
+    else if (pb.got + 1 == k.len1) {
+      const uint32_t scup = d[k.offset + k.len1 - 2] & 0xFu;
+      refused = scup < 2 || scup > k.len1;
+      listed = !refused;
+    } else if (k.num_passes == 2) { k.len2 = pb.got - k.len1; continue; }
+    else listed = true;
+    if (refused && !resilient) return OJPHGPU_E_CODESTREAM;
+    if (listed) P.padded.push_back(Plan::PaddedBlock{ pb.id, pb.got, k });
+    k.len1 = k.len2 = 0; k.num_passes = 0;
+  }
   *out = hold.release();
   return OJPHGPU_OK;
 }

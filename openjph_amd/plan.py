@@ -3,12 +3,13 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import Params, BandInfo, BlockInfo, LevelInfo, CodedBlock, check, PROG_ORDERS
+from .capi import Params, BandInfo, BlockInfo, LevelInfo, CodedBlock, PaddedBlock, check, PROG_ORDERS
 
 band_dtype = np.dtype(BandInfo)
 block_dtype = np.dtype(BlockInfo)
 level_dtype = np.dtype(LevelInfo)
 coded_dtype = np.dtype(CodedBlock)
+padded_dtype = np.dtype(PaddedBlock)
 
 
 def make_params(width, height, num_comps=1, bit_depth=8, is_signed=False, reversible=True,
@@ -248,6 +249,16 @@ class Plan:
     def coded_blocks(self):
         out = np.zeros(self.num_blocks, coded_dtype)
         check(self._lib.ojphgpu_plan_coded_blocks(self.handle, out.ctypes.data, self.num_blocks))
+        return out
+
+    def padded_blocks(self):
+        """ojphgpu_plan_padded_blocks: (block, got, offset, len1, len2, missing_msbs, num_passes) of the blocks a damaged
+        codestream's packet headers promise more bytes for than their tile-part holds"""
+        n = C.c_size_t()
+        check(self._lib.ojphgpu_plan_padded_blocks(self.handle, None, 0, C.byref(n)))
+        out = np.zeros(int(n.value), padded_dtype)
+        if n.value:
+            check(self._lib.ojphgpu_plan_padded_blocks(self.handle, out.ctypes.data, int(n.value), C.byref(n)))
         return out
 
     def t2_write(self, block_data: np.ndarray, coded: np.ndarray) -> bytes:

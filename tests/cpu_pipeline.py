@@ -198,8 +198,14 @@ def decode_blocks(plan: Plan, cs: bytes, resilient=False):
     top_read = [st["num_decomps"] - plan.skip[0] for st in styles]
     arena = np.zeros(plan.arena_elems, np.uint32)
     buf = np.frombuffer(cs, dtype=np.uint8)
+    # blocks whose tile-part ran out of bytes: the reference decodes what there is, padded with zeros
+    # (ojphgpu_plan_padded_blocks; bb_read_chunk, ojph_bitbuffer_read.h:134-150)
+    padded = {int(q["block"]): q for q in plan.padded_blocks()}
     for k in range(plan.num_blocks):
         cbk = coded[k]
+        pad = 0
+        if k in padded:
+            cbk = padded[k]; pad = int(cbk["len1"]) + int(cbk["len2"]) - int(cbk["got"])
         if cbk["len1"] == 0:
             continue
         blk = plan.blocks[k]
@@ -210,7 +216,7 @@ def decode_blocks(plan: Plan, cs: bytes, resilient=False):
         w, h = int(blk["w"]), int(blk["h"])
         o = int(cbk["offset"]); n = int(cbk["len1"]) + int(cbk["len2"])
         wide = styles[int(band["comp"])]["wide"]
-        ok, sm = (ob.ht_decode64 if wide else ob.ht_decode)(buf[o:o + n].tobytes(), w, h, w, int(cbk["missing_msbs"]),
+        ok, sm = (ob.ht_decode64 if wide else ob.ht_decode)(buf[o:o + n - pad].tobytes() + bytes(pad), w, h, w, int(cbk["missing_msbs"]),
                                                           len2=int(cbk["len2"]), num_passes=int(cbk["num_passes"]),
                                                           stripe_causal=bool(plan.params.reserved[0] & 1))
         if not ok:

@@ -15,7 +15,7 @@ from oracle import refbind
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 600000
 rng = np.random.default_rng(seed)
-refs = {True: refbind.Ref(generic=False), False: refbind.Ref(generic=True)}
+refs = {True: refbind.Ref(generic=True), False: refbind.Ref(generic=True)}   # (the generic C++ block decoder: the AVX2 one decodes DAMAGED blocks differently from it)
 n = bad = streams = raised = 0
 while time.time() < t_end:
     planes, kw, size = random_case(seed); seed += 1
