@@ -464,7 +464,7 @@ void assign_planes(Plan& plan)
 
 int build_plan(const ojphgpu_params& pin, Plan& plan)
 {
-  plan = Plan();
+  { const bool parsed = plan.parsed, no_packets = plan.no_packets; plan = Plan(); plan.parsed = parsed; plan.no_packets = no_packets; }
   ojphgpu_params p = pin;
   auto fail = [&](const char* m) { plan.error = m; return OJPHGPU_E_INVALID; };
   if (p.width == 0 || p.height == 0 || p.num_comps == 0) return fail("empty image");
@@ -519,7 +519,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     p.comp_dx[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dx : 0;
     p.comp_dy[c] = c < p.num_comps ? (uint8_t)plan.comps[c].dy : 0;
   }
-  if (p.prog_order == 2 || p.prog_order == 3)                                      // ojph_params_local.h:488-499
+  if (!plan.parsed && (p.prog_order == 2 || p.prog_order == 3))                    // ojph_params_local.h:488-499 (the writer's check)
     for (const CompGeo& g : plan.comps)
       if ((g.dx & (g.dx - 1)) || (g.dy & (g.dy - 1)))
         return fail("For RPCL and PCRL progression orders, component downsampling factors have to be powers of 2");

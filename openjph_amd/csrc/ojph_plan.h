@@ -122,6 +122,10 @@ struct Plan {
   // resolutions are not decoded (their blocks count as empty), the top skip_recon are not
   // synthesised; comps / frame_elems then describe the smaller reconstructed frame
   uint32_t skip_read = 0, skip_recon = 0;
+  // set by the codestream parser before build_plan: what only the reference's WRITER checks (param_cod::check_validity and
+  // friends, called from codestream::write_headers alone, ojph_codestream_local.cpp:571-576) does not stop a codestream from being read
+  bool parsed = false;
+  bool no_packets = false;      // parser: a progression order byte above 4 -- tile::parse_tile_header reads no packet at all (ojph_tile.cpp:900-901)
   // parser: blocks the reference keeps although their tile-part did not hold all their bytes -- it pads them with zeros
   // (bb_read_chunk, ojph_bitbuffer_read.h:134-150).  Their bytes are not in the codestream: in `coded` they are not coded,
   // here is what the packet header said (block = plan order index, got = bytes the codestream does hold at offset)

@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -856,11 +858,16 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   return OJPHGPU_OK;
 }
 
+// OJPHGPU_T2_DEBUG=1 in the environment: where the parser gave up (stderr)
+static int t2_refused(int rc, int line)
+{
+  if (getenv("OJPHGPU_T2_DEBUG")) fprintf(stderr, "ojphgpu_t2_parse: %d at ojph_t2.cpp:%d\n", rc, line);
+  return rc;
+}
+
 static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
 {
   *out = nullptr;
-  Reader r(d, len, 0);
-  if (!r.ok(2) || r.u16() != SOC) return OJPHGPU_E_CODESTREAM;
   ojphgpu_params p; memset(&p, 0, sizeof(p));
   bool have_siz = false, have_cod = false, have_qcd = false;
   uint8_t scod = 0, sqcd = 0; std::vector<uint8_t> q8; std::vector<uint16_t> q16;
@@ -868,59 +875,85 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   std::vector<Qcc> qccs;
   bool use_sop = false, use_eph = false;
   uint32_t num_cocs = 0, num_nlts = 0;
-  for (;;) {
-    if (!r.ok(2)) return OJPHGPU_E_CODESTREAM;
-    uint32_t m = r.u16();
-    if (m == SOT) { r.pos -= 2; break; }            // (the marker alone ends the main header: a file cut inside the SOT segment is the tile-part loop's case)
-    if (!r.ok(2)) return OJPHGPU_E_CODESTREAM;
+  // Main header: codestream::read_headers (ojph_codestream_local.cpp:768-881).  Markers are SEARCHED for (find_marker): SOC,
+  // then SIZ, then any of the 18 the reference knows up to the first SOT; bytes in between -- and marker segments it does
+  // not know -- are passed over byte by byte.  Nothing here is subject to the resilience setting.
+  static const uint8_t hdr_markers[18] = { 0x50, 0x56, 0x59, 0x52, 0x53, 0x5C, 0x5D, 0x5E, 0x5F, 0x60, 0x55, 0x57, 0x63, 0x64,
+                                           0x72, 0x79, 0x76, 0x90 };   // CAP PRF CPF COD COC QCD QCC RGN POC PPM TLM PLM CRG COM DFS ATK NLT SOT
+  RefFile hf{ d, len, 0 };
+  { const uint8_t soc = 0x4F, siz = 0x51; find_marker(hf, &soc, 1); find_marker(hf, &siz, 1); }
+  Reader r(d, len, hf.pos);
+  for (bool first = true;; first = false) {
+    uint32_t m = SIZ;
+    if (!first) {
+      const int idx = find_marker(hf, hdr_markers, 18);
+      if (idx < 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                        // "File ended before finding a tile segment"
+      m = 0xFF00u | hdr_markers[idx];
+      if (m == SOT) break;
+    }
+    r.pos = hf.pos; r.lim = r.n; r.bad = false;
+    if (!r.ok(2)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
     uint32_t L = r.u16();
-    if (L < 2 || !r.ok(L - 2)) return OJPHGPU_E_CODESTREAM;
+    if (m == 0xFF56 || m == 0xFF59 || m == RGN || m == POC || m == PPM || m == TLM || m == PLM || m == CRG || m == COM) {
+      // skip_marker (:734-766): a seek the file refuses leaves the position behind the length field
+      if (m == TLM) p.tlm = 1;
+      hf.pos = r.pos; hf.seek_cur((int64_t)L - 2);
+      continue;
+    }
+    if (L < 2 || !r.ok(L - 2)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
     size_t next = r.pos + L - 2;
     r.lim = next;                                                  // no field of this segment lies beyond it
     // shortest legal segment per marker (T.800 A.5 / A.6): checked before any field is read
-    if ((m == SIZ && L < 41) || (m == COD && L < 12) || (m == QCD && L < 4)) return OJPHGPU_E_CODESTREAM;
-    if (m == SIZ) {
+    if ((m == SIZ && L < 41) || (m == COD && L < 12) || (m == QCD && L < 4)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+    if (m == CAP) {                                                // param_cap::read (ojph_params.cpp:992-1013)
+      const uint32_t pcap = r.u32();
+      if (pcap != 0x00020000u) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);       // only Part 15, and Part 15 it must be
+      r.u16();                                                     // Ccap15
+      if (L != 8) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+    } else if (m == SIZ) {
       uint32_t rsiz = r.u16();
-      if ((rsiz & 0x4000) == 0) return OJPHGPU_E_CODESTREAM;      // not an HTJ2K codestream
+      if ((rsiz & 0x4000) == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);      // not an HTJ2K codestream
       const uint32_t xs = r.u32(), ys = r.u32();                   // image extent
       p.image_x0 = r.u32(); p.image_y0 = r.u32();
       p.tile_w = r.u32(); p.tile_h = r.u32();
       p.tile_x0 = r.u32(); p.tile_y0 = r.u32();
-      if (xs <= p.image_x0 || ys <= p.image_y0 || p.tile_w == 0 || p.tile_h == 0) return OJPHGPU_E_CODESTREAM;   // ojph_params_local.h:235-249
+      if (xs <= p.image_x0 || ys <= p.image_y0 || p.tile_w == 0 || p.tile_h == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // ojph_params_local.h:235-249
       p.width = xs - p.image_x0; p.height = ys - p.image_y0;
       p.num_comps = r.u16();
-      if (L != 38 + 3 * p.num_comps || p.num_comps == 0) return OJPHGPU_E_CODESTREAM;
+      if (L != 38 + 3 * p.num_comps || p.num_comps == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       for (uint32_t c = 0; c < p.num_comps; ++c) {
         uint32_t ss = r.u8(), xr = r.u8(), yr = r.u8();
         uint32_t bd = (ss & 0x7F) + 1, sg = ss >> 7;
-        if (xr == 0 || yr == 0) return OJPHGPU_E_CODESTREAM;
-        if ((xr != 1 || yr != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return OJPHGPU_E_INVALID;
+        if (xr == 0 || yr == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+        if ((xr != 1 || yr != 1) && c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
         if (c < OJPHGPU_MAX_SUBSAMPLED_COMPS) { p.comp_dx[c] = (uint8_t)xr; p.comp_dy[c] = (uint8_t)yr; }
         if (c == 0) { p.bit_depth = bd; p.is_signed = sg; }
         else if (bd != p.bit_depth || sg != p.is_signed) {
-          if (c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return OJPHGPU_E_INVALID;      // per-component formats: first 16 components
+          if (c >= OJPHGPU_MAX_SUBSAMPLED_COMPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);      // per-component formats: first 16 components
           p.comp_depth[c] = (uint8_t)bd; p.comp_sign[c] = sg ? 2 : 1;
         }
       }
       have_siz = true;
     } else if (m == COD) {
       scod = (uint8_t)r.u8(); p.prog_order = r.u8();
-      uint32_t layers = r.u16(); p.color_transform = r.u8();
+      uint32_t layers = r.u16(); p.color_transform = r.u8() == 1 ? 1 : 0;   // (is_employing_color_transform: SGCod.mc_trans == 1, ojph_params_local.h:537-543)
       p.num_decomps = r.u8(); uint32_t xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
-      if (layers != 1) return OJPHGPU_E_INVALID;
-      if ((style & 0x40) == 0) return OJPHGPU_E_CODESTREAM;       // not HT code-blocks
-      if (style & ~0x48u) return OJPHGPU_E_INVALID;               // only HT (+ vertically causal) styles
+      if (layers != 1) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
+      if (p.num_decomps > 32 || xcb > 8 || ycb > 8 || xcb + ycb > 8) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // "wrong settings in a COD-SPcod parameter" (ojph_params.cpp:1174-1180)
+      if ((style & 0x40) == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);       // not HT code-blocks
+      if (style & ~0x48u) return t2_refused(OJPHGPU_E_INVALID, __LINE__);               // only HT (+ vertically causal) styles
       p.wavelet = wt > 1 ? (uint8_t)wt : 0;                       // an ATK marker segment is the wavelet (build_plan finds it)
       p.reversible = wt == 1; p.block_w = 1u << ((xcb & 0xF) + 2); p.block_h = 1u << ((ycb & 0xF) + 2);
       p.reserved[0] = (style & 0x08u) ? 1u : 0u;                  // vertically causal context (SigProp of foreign streams)
       use_sop = scod & 2; use_eph = scod & 4;
-      if (L != 12 + ((scod & 1) ? 1 + p.num_decomps : 0)) return OJPHGPU_E_CODESTREAM;   // ojph_params.cpp:1201-1202
+      if (L != 12 + ((scod & 1) ? 1 + p.num_decomps : 0)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // ojph_params.cpp:1201-1202
       if (scod & 1) {
         uint32_t pw = 0, ph = 0; bool uniform = true;
-        if (p.num_decomps >= 36) return OJPHGPU_E_INVALID;
+        if (p.num_decomps >= 36) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
         for (uint32_t i = 0; i <= p.num_decomps; ++i) {
           uint32_t v = r.u8();
           p.precinct_exps[i] = (uint8_t)v;
+          if (i && ((v & 0xF) == 0 || (v >> 4) == 0)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // :1190-1198
           if (i == 0) { pw = v & 0xF; ph = v >> 4; }
           else if ((v & 0xF) != pw || (v >> 4) != ph) uniform = false;
         }
@@ -928,44 +961,45 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         if (uniform) memset(p.precinct_exps, 0, sizeof(p.precinct_exps));
       }
       have_cod = true;
-    } else if (m == QCD) {
+    } else if (m == QCD) {                                         // param_qcd::read (ojph_params.cpp:1903-1947); a later one replaces an earlier one
       sqcd = (uint8_t)r.u8();
-      uint32_t n = L - 3;
-      if ((sqcd & 0x1F) == 0) for (uint32_t i = 0; i < n; ++i) q8.push_back((uint8_t)r.u8());
-      else if ((sqcd & 0x1F) == 2) for (uint32_t i = 0; i < n / 2; ++i) q16.push_back((uint16_t)r.u16());
-      else return OJPHGPU_E_INVALID;                              // scalar derived: not supported
+      q8.clear(); q16.clear();
+      const uint32_t kind = sqcd & 0x1F, n = kind == 0 ? L - 3 : (L - 3) / 2;
+      if (kind == 1) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                   // scalar derived: "not supported yet"
+      if (kind > 2 || n == 0 || n > 97 || L != 3 + (kind == 0 ? n : 2 * n)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+      if (kind == 0) for (uint32_t i = 0; i < n; ++i) q8.push_back((uint8_t)r.u8());
+      else for (uint32_t i = 0; i < n; ++i) q16.push_back((uint16_t)r.u16());
       have_qcd = true;
     } else if (m == QCC) {                                         // ojph_params.cpp:1950-2018
-      if (!have_siz) return OJPHGPU_E_CODESTREAM;
+      if (!have_siz) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t cw = p.num_comps < 257 ? 1 : 2;
-      if (L < 3 + cw) return OJPHGPU_E_CODESTREAM;
+      if (L < 3 + cw) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       Qcc k; k.comp = cw == 1 ? r.u8() : r.u16();
       k.q.sqcd = (uint8_t)r.u8(); k.q.guard_bits = k.q.sqcd >> 5; k.q.present = true;
-      uint32_t n = L - 3 - cw;
-      if ((k.q.sqcd & 0x1F) == 0) for (uint32_t i = 0; i < n; ++i) k.q.q8.push_back((uint8_t)r.u8());
-      else if ((k.q.sqcd & 0x1F) == 2) for (uint32_t i = 0; i < n / 2; ++i) k.q.q16.push_back((uint16_t)r.u16());
-      else return OJPHGPU_E_INVALID;
-      if (n == 0 || k.comp >= p.num_comps) return OJPHGPU_E_CODESTREAM;
+      const uint32_t kind = k.q.sqcd & 0x1F, n = kind == 0 ? L - 3 - cw : (L - 3 - cw) / 2;
+      if (kind == 1) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                   // scalar derived: "not supported yet"
+      if (kind > 2 || n == 0 || n > 97 || L != 3 + cw + (kind == 0 ? n : 2 * n)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // :1971-2008
+      if (kind == 0) for (uint32_t i = 0; i < n; ++i) k.q.q8.push_back((uint8_t)r.u8());
+      else for (uint32_t i = 0; i < n; ++i) k.q.q16.push_back((uint16_t)r.u16());
+      if (k.comp >= p.num_comps) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       qccs.push_back(k);
-    } else if (m == TLM) {
-      p.tlm = 1;
     } else if (m == COC) {                                         // param_cod::read_coc (ojph_params.cpp:1206-1276)
-      if (!have_siz) return OJPHGPU_E_CODESTREAM;
+      if (!have_siz) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t cw = p.num_comps < 257 ? 1 : 2;
-      if (L < 8 + cw) return OJPHGPU_E_CODESTREAM;
+      if (L < 8 + cw) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t comp = cw == 1 ? r.u8() : r.u16();
       const uint32_t scoc = r.u8(), nd_byte = r.u8(), xcb = r.u8(), ycb = r.u8(), style = r.u8(), wt = r.u8();
       // bit 7 of the decompositions byte: the decomposition is defined by a DFS marker segment (index in the low
       // bits) and has as many levels as the COD says (param_cod::get_num_decompositions, ojph_params_local.h:503-516)
       const bool dfs_defined = (nd_byte & 0x80u) != 0;
-      if (dfs_defined && !have_cod) return OJPHGPU_E_INVALID;      // (needs the COD's count: a COC in front of the COD is not handled)
+      if (dfs_defined && !have_cod) return t2_refused(OJPHGPU_E_INVALID, __LINE__);      // (needs the COD's count: a COC in front of the COD is not handled)
       const uint32_t nd = dfs_defined ? p.num_decomps : nd_byte;
-      if (nd > 32 || xcb > 8 || ycb > 8 || xcb + ycb > 8 || (style & 0x40) != 0x40 || (style & 0xB7) != 0) return OJPHGPU_E_CODESTREAM;   // :1240-1249
-      if (L != 8 + cw + ((scoc & 1) ? 1 + nd : 0)) return OJPHGPU_E_CODESTREAM;
+      if (nd > 32 || xcb > 8 || ycb > 8 || xcb + ycb > 8 || (style & 0x40) != 0x40 || (style & 0xB7) != 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // :1240-1249
+      if (L != 8 + cw + ((scoc & 1) ? 1 + nd : 0)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       if (comp < p.num_comps) {                                    // one for a component that does not exist is only reported (:803-808)
-        if (comp >= OJPHGPU_MAX_COC_COMPS) return OJPHGPU_E_INVALID;   // per-component styles: first 16 components
+        if (comp >= OJPHGPU_MAX_COC_COMPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);   // per-component styles: first 16 components
         ojphgpu_coc& k = p.coc[comp];
-        if (k.rank) return OJPHGPU_E_CODESTREAM;                   // two COCs for one component (:809-812)
+        if (k.rank) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                   // two COCs for one component (:809-812)
         k.rank = (uint8_t)++num_cocs; k.reversible = wt == 1; k.num_decomps = (uint8_t)nd;
         k.log_block_w = (uint8_t)(xcb + 2); k.log_block_h = (uint8_t)(ycb + 2);
         k.has_precincts = scoc & 1; k.reserved[0] = (uint8_t)(((style & 0x08u) ? 1u : 0u) | (dfs_defined ? 0x80u | ((nd_byte & 0xFu) << 1) : 0u));
@@ -973,43 +1007,43 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         if (scoc & 1)
           for (uint32_t i = 0; i <= nd; ++i) {
             k.precinct_exps[i] = (uint8_t)r.u8();
-            if (i && ((k.precinct_exps[i] & 0xF) == 0 || (k.precinct_exps[i] >> 4) == 0)) return OJPHGPU_E_CODESTREAM;   // :1256-1264
+            if (i && ((k.precinct_exps[i] & 0xF) == 0 || (k.precinct_exps[i] >> 4) == 0)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // :1256-1264
           }
       }
     } else if (m == NLT) {                                  // param_nlt::read (ojph_params.cpp:2238-2266)
-      if (L != 6) return OJPHGPU_E_CODESTREAM;
+      if (L != 6) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t comp = r.u16(), bd = r.u8(), type = r.u8();
-      if (type != 0 && type != 3) return OJPHGPU_E_INVALID;      // gamma / LUT styles: the reference refuses them, too
+      if (type != 0 && type != 3) return t2_refused(OJPHGPU_E_INVALID, __LINE__);      // gamma / LUT styles: the reference refuses them, too
       p.nlt_reserved[0] = 1;                                       // BDnlt values come from the codestream
       if (comp == 65535) { p.nlt_default = (uint8_t)(type + 1); p.nlt_bd_default = (uint8_t)bd; }
       else if (!have_siz || comp < p.num_comps) {
-        if (comp >= OJPHGPU_MAX_COC_COMPS) return OJPHGPU_E_INVALID;   // per-component entries: first 16 components
+        if (comp >= OJPHGPU_MAX_COC_COMPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);   // per-component entries: first 16 components
         if (p.nlt_comp[comp] == 0) p.nlt_rank[comp] = (uint8_t)++num_nlts;
         p.nlt_comp[comp] = (uint8_t)(type + 1); p.nlt_bd[comp] = (uint8_t)bd;
       }
     } else if (m == DFS) {                                  // param_dfs::read (ojph_params.cpp:2596-2644)
-      if (L < 5) return OJPHGPU_E_CODESTREAM;
+      if (L < 5) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t sdfs = r.u16(), ids = r.u8();
-      if (sdfs > 15 || ids == 0) return OJPHGPU_E_CODESTREAM;
-      if (L != 5 + (ids + 3) / 4) return OJPHGPU_E_CODESTREAM;
+      if (sdfs > 15 || ids == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+      if (L != 5 + (ids + 3) / 4) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       ojphgpu_dfs* f = nullptr;
       for (ojphgpu_dfs& o : p.dfs) if (!o.used) { f = &o; break; }
-      if (!f) return OJPHGPU_E_INVALID;                            // more DFS marker segments than the tables hold
+      if (!f) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                            // more DFS marker segments than the tables hold
       f->used = 1; f->index = (uint8_t)sdfs; f->num_levels = (uint8_t)std::min<uint32_t>(ids, 32);
       for (uint32_t i = 0; i < ids; i += 4) {
         const uint32_t v = r.u8();
         for (uint32_t j = 0; j < 4 && i + j < 32 && i + j < ids; ++j) f->types[i + j] = (uint8_t)((v >> (6 - 2 * j)) & 3u);
       }
     } else if (m == ATK) {                                  // param_atk::read (ojph_params.cpp:2770-2866)
-      if (L < 5) return OJPHGPU_E_CODESTREAM;
+      if (L < 5) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
       const uint32_t satk = r.u16();
       const uint32_t idx = satk & 0xFF, ctype = (satk >> 8) & 7;
       const bool ws = (satk & 0x800) != 0, rev = (satk & 0x1000) != 0, m_init0 = (satk & 0x2000) == 0, ws_ext = (satk & 0x4000) != 0;
-      if (idx < 2) return OJPHGPU_E_CODESTREAM;                    // :2785-2791
-      if (!m_init0 || !ws || !ws_ext || (rev && ctype >= 2)) return OJPHGPU_E_INVALID;   // what the reference refuses, too (:2793-2805)
+      if (idx < 2) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                    // :2785-2791
+      if (!m_init0 || !ws || !ws_ext || (rev && ctype >= 2)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);   // what the reference refuses, too (:2793-2805)
       ojphgpu_atk* a = nullptr;
-      for (ojphgpu_atk& o : p.atk) { if (o.index == idx) return OJPHGPU_E_CODESTREAM; if (!o.index && !a) a = &o; }
-      if (!a) return OJPHGPU_E_INVALID;
+      for (ojphgpu_atk& o : p.atk) { if (o.index == idx) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); if (!o.index && !a) a = &o; }
+      if (!a) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
       auto coeff_f = [&](float& out) -> bool {                      // read_coefficient(float) :2687-2746
         if (ctype == 0) { out = (float)r.u8(); return true; }
         if (ctype == 1) { out = (float)r.u16(); return true; }
@@ -1024,36 +1058,35 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         return false;
       };
       a->index = (uint8_t)idx; a->reversible = rev ? 1 : 0; a->coeff_type = (uint8_t)ctype; a->K = 1.0f;
-      if (!rev && !coeff_f(a->K)) return OJPHGPU_E_INVALID;
+      if (!rev && !coeff_f(a->K)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
       const uint32_t natk = r.u8();
-      if (natk == 0 || natk > OJPHGPU_MAX_LIFT_STEPS) return OJPHGPU_E_INVALID;
+      if (natk == 0 || natk > OJPHGPU_MAX_LIFT_STEPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
       a->num_steps = (uint8_t)natk;
       for (uint32_t k = 0; k < natk; ++k) {
         ojphgpu_lift_step& st = a->steps[k];
         if (rev) {
           st.e = (int32_t)r.u8(); st.b = (int32_t)(int16_t)r.u16();
           const uint32_t lc = r.u8();
-          if (lc != 1) return lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID;   // :2834-2839: one coefficient per step
+          if (lc != 1) return t2_refused(lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID, __LINE__);   // :2834-2839: one coefficient per step
           st.a = ctype == 0 ? (int32_t)(int8_t)r.u8() : (int32_t)(int16_t)r.u16();
         } else {
           const uint32_t lc = r.u8();
-          if (lc != 1) return lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID;
-          if (!coeff_f(st.A)) return OJPHGPU_E_INVALID;
+          if (lc != 1) return t2_refused(lc == 0 ? OJPHGPU_E_CODESTREAM : OJPHGPU_E_INVALID, __LINE__);
+          if (!coeff_f(st.A)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
         }
       }
       if (a->coeff_type > 3) a->coeff_type = 2;                    // (written again as floats)
-      if (r.pos != next) return OJPHGPU_E_CODESTREAM;              // "The length of an ATK marker segment is not correct"
-    } else if (m == RGN || m == POC || m == PPM) {
-      return OJPHGPU_E_INVALID;                                    // unsupported markers
+      if (r.pos != next) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);              // "The length of an ATK marker segment is not correct"
     }
-    if (r.bad) return OJPHGPU_E_CODESTREAM;                        // a field ran past its segment
-    r.pos = next; r.lim = r.n;
+    if (r.bad) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                        // a field ran past its segment
+    hf.pos = next;
   }
-  r.lim = r.n;
-  if (!have_siz || !have_cod || !have_qcd) return OJPHGPU_E_CODESTREAM;
+  if (!have_siz || !have_cod || !have_qcd) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
   std::unique_ptr<ojphgpu_plan> hold(new (std::nothrow) ojphgpu_plan());   // freed on every way out but the last
   ojphgpu_plan* h = hold.get();
   if (!h) return OJPHGPU_E_NOMEM;
+  h->plan.parsed = true;
+  if (p.prog_order > 4) { h->plan.no_packets = true; p.prog_order = 0; }   // (the plan is laid out as LRCP; nothing is read into it)
   int rc = build_plan(p, h->plan);
   if (rc != OJPHGPU_OK) { return rc; }
   Plan& P = h->plan;
@@ -1062,24 +1095,24 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   // wrong union member; here the codestream is refused)
   P.qcd.sqcd = sqcd; P.qcd.guard_bits = sqcd >> 5;
   P.qcd.q8 = q8; P.qcd.q16 = q16;
-  if (q8.empty() && q16.empty()) { return OJPHGPU_E_CODESTREAM; }
+  if (q8.empty() && q16.empty()) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }
   P.qcc.assign(p.num_comps, QuantSet());                       // only the markers of the codestream count
   for (const Qcc& k : qccs) {
-    if (P.qcc[k.comp].present) { return OJPHGPU_E_CODESTREAM; }   // two QCCs for one component (:827-830)
+    if (P.qcc[k.comp].present) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }   // two QCCs for one component (:827-830)
     P.qcc[k.comp] = k.q;
   }
   P.qcc_order.clear();
   for (uint32_t c = 0; c < p.num_comps; ++c) if (P.qcc[c].present) P.qcc_order.push_back(c);
   for (uint32_t c = 0; c < p.num_comps; ++c)
-    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { return OJPHGPU_E_CODESTREAM; }
+    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }
   for (Band& B : P.bands) {
     B.K_max = band_Kmax(P, B.comp, B.res, B.band);
     // K_max of a parsed QCD / QCC is whatever the codestream says: an exponent of 0 with no guard bit
     // wraps below zero, and more than 31 magnitude bits is the reference's 64-bit sample path
     // (ojph_codeblock.cpp:74-99), which this library does not have -- neither may reach 31 - K_max
-    if ((int32_t)B.K_max < 0) return OJPHGPU_E_CODESTREAM;
-    if (B.K_max > 61) return OJPHGPU_E_INVALID;                 // (the 64-bit block coder's own limit)
-    if (!P.style(B.comp).rev && B.K_max > 31) return OJPHGPU_E_INVALID;   // irreversible: the 32-bit path only (derive_precision)
+    if ((int32_t)B.K_max < 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+    if (B.K_max > 61) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                 // (the 64-bit block coder's own limit)
+    if (!P.style(B.comp).rev && B.K_max > 31) return t2_refused(OJPHGPU_E_INVALID, __LINE__);   // irreversible: the 32-bit path only (derive_precision)
     if (!P.style(B.comp).rev) {
       float dlt = band_delta(P, B.comp, B.res, B.band);
       dlt /= (float)(1u << (31 - B.K_max));
@@ -1087,7 +1120,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
     }
   }
   // which components need the 64-bit sample path is a property of THESE marker segments; the planes are placed again
-  if (!derive_precision(P)) return OJPHGPU_E_INVALID;
+  if (!derive_precision(P)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
   assign_planes(P);
   P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
   // ---- tile-parts: codestream::read (ojph_codestream_local.cpp:912-1113) ----
@@ -1099,7 +1132,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   std::vector<uint32_t> next_part(P.tiles.size(), 0);
   std::vector<PaddedBlock> padded;
   std::vector<uint8_t> has_data(P.blocks.size(), 0);
-  RefFile f{ d, len, std::min(r.pos + 2, len) };                       // read_headers has taken the first SOT marker
+  RefFile f{ d, len, hf.pos };                                          // read_headers has taken the first SOT marker
   static const uint8_t first_part_markers[11] = { 0x52, 0x53, 0x5C, 0x5D, 0x5E, 0x5F, 0x61, 0x58, 0x64, 0x76, 0x93 };   // COD COC QCD QCC RGN POC PPT PLT COM NLT SOD
   static const uint8_t next_markers[2] = { 0x90, 0xD9 };                // SOT, EOC
   for (;;) {
@@ -1117,17 +1150,17 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       else if (!need(9)) sot_ok = false;
       else if (!need(10)) sot_ok = false;
       if (sot_ok) { psot = (uint32_t)h[4] << 24 | (uint32_t)h[5] << 16 | (uint32_t)h[6] << 8 | h[7]; tpsot = h[8]; tnsot = h[9]; }
-      else if (!resilient) return OJPHGPU_E_CODESTREAM;
+      else if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
     }
     if (sot_ok) {
       const uint64_t tile_start = f.pos;
       bool skip_tile = false;
       if (isot >= P.tiles.size()) {                                     // "wrong tile index" :925-933
-        if (!resilient) return OJPHGPU_E_CODESTREAM;
+        if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
         skip_tile = true;
       }
       if (!skip_tile) {
-        if (tpsot && tnsot && tpsot >= tnsot && !resilient) return OJPHGPU_E_CODESTREAM;      // :939-950
+        if (tpsot && tnsot && tpsot >= tnsot && !resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);      // :939-950
         // tile-part header: the first tile-part of a tile may hold COD COC QCD QCC RGN, every one POC PPT PLT COM NLT; all
         // of them are passed over ("... in a tile is not supported yet" is a warning), up to the SOD (:952-1093)
         const uint8_t* list = tpsot ? first_part_markers + 5 : first_part_markers;
@@ -1136,14 +1169,14 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         for (;;) {
           const int idx = find_marker(f, list, nlist);
           if (idx == nlist - 1) { sod_found = true; break; }
-          if (idx < 0) { if (!resilient) return OJPHGPU_E_CODESTREAM; break; }   // "File terminated early before start of data is found"
+          if (idx < 0) { if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); break; }   // "File terminated early before start of data is found"
           uint8_t l0 = 0, l1 = 0;                                         // skip_marker :734-766
-          if (!f.get(l0) || !f.get(l1)) { if (!resilient) return OJPHGPU_E_CODESTREAM; break; }   // (a lone byte stays taken)
+          if (!f.get(l0) || !f.get(l1)) { if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); break; }   // (a lone byte stays taken)
           f.seek_cur((int64_t)((uint32_t)l0 << 8 | l1) - 2);              // (a length below 2 steps backwards; out of the file: no move)
         }
         if (sod_found) {
           // tile::parse_tile_header (ojph_tile.cpp:777-935)
-          if (tpsot != (next_part[isot] & 0xFFFFFFFFu) && !resilient) return OJPHGPU_E_CODESTREAM;   // "wrong tile part index"
+          if (tpsot != (next_part[isot] & 0xFFFFFFFFu) && !resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);   // "wrong tile part index"
           ++next_part[isot];
           const uint32_t payload = psot > 0 ? psot - 12u : 0u;            // (param_sot::get_payload_length; 32-bit arithmetic throughout)
           const uint64_t tile_end = tile_start + payload;
@@ -1151,12 +1184,12 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
           if (data_left != 0) {
             const Tile& T = P.tiles[isot];
             try {
-              while (data_left > 0 && next_pkt[isot] < T.packets.size()) {
+              while (data_left > 0 && next_pkt[isot] < T.packets.size() && !P.no_packets) {
                 parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], f, data_left, use_sop, use_eph, padded, has_data);
                 ++next_pkt[isot];
               }
             } catch (const PacketThrow&) {
-              if (!resilient) return OJPHGPU_E_CODESTREAM;
+              if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
             }
             f.seek_set(tile_end);                                         // (beyond the file: the position stays where parsing stopped)
           }
@@ -1189,7 +1222,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       listed = !refused;
     } else if (k.num_passes == 2) { k.len2 = pb.got - k.len1; continue; }
     else listed = true;
-    if (refused && !resilient) return OJPHGPU_E_CODESTREAM;
+    if (refused && !resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
     if (listed) P.padded.push_back(Plan::PaddedBlock{ pb.id, pb.got, k });
     k.len1 = k.len2 = 0; k.num_passes = 0;
   }

@@ -12,6 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
 
 
+class TooLarge(ValueError):
+    pass
+
+
 class RefCoc(C.Structure):
     _fields_ = [("comp", C.c_uint8), ("mask", C.c_uint8), ("reversible", C.c_uint8), ("num_decomps", C.c_uint8),
                 ("log_bw", C.c_uint8), ("log_bh", C.c_uint8), ("pad", C.c_uint8 * 2), ("precinct_exps", C.c_uint8 * 36)]
@@ -159,8 +163,9 @@ class Ref:
             raise RuntimeError("reference encode failed (%d)" % n)
         return out[:n].tobytes()
 
-    def decode(self, data: bytes, resilient=False, skip=(0, 0)):
-        """skip = (skipped_res_for_data, skipped_res_for_recon) of codestream::restrict_input_resolution"""
+    def decode(self, data: bytes, resilient=False, skip=(0, 0), max_samples=None):
+        """skip = (skipped_res_for_data, skipped_res_for_recon) of codestream::restrict_input_resolution;
+        max_samples: raise TooLarge instead of decoding a frame of more samples (fuzzers of damaged SIZ segments)"""
         buf = np.frombuffer(data, dtype=np.uint8)
         info = np.zeros(8 + 32, dtype=np.uint32)
         r = self.lib.ref_decode_skip(buf.ctypes.data, len(data), None, info.ctypes.data, int(resilient), skip[0], skip[1])
@@ -169,6 +174,8 @@ class Ref:
         w, h, nc = int(info[0]), int(info[1]), int(info[2])
         dims = [(int(info[9 + 2 * c]), int(info[8 + 2 * c])) if c < 16 else (h, w) for c in range(nc)]
         uniform = all(d == dims[0] for d in dims)
+        if max_samples is not None and sum(a * b for a, b in dims) > max_samples:
+            raise TooLarge("%d components of %s" % (nc, dims[:4]))
         if uniform:
             planes = np.zeros((nc, h, w), dtype=np.int32)
             views = [planes[c] for c in range(nc)]

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Codestreams of random parameter sets (written by the LIVE reference) with one to three bytes changed behind the first SOD -- packet
-headers, code-block bytes, later SOT segments -- read with and without resilience: the reference's verdict (raise / decode) and its
-image are the oracle pipeline's.  CPU only.      python tools/fuzz_flip_cpu.py [seconds] [first seed]"""
-import os, sys, time
+headers, code-block bytes, later SOT segments -- or, every third one, inside an SOT segment / its SOD -- read with and without resilience: the reference's verdict (raise / decode) and its
+image are the oracle pipeline's.  CPU only.      python tools/fuzz_flip_cpu.py [seconds] [first seed] [header]
+(header: the changed bytes lie in the main header instead.)"""
+import os, sys, time, resource
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +13,62 @@ from tests import cpu_pipeline as cp
 from tests.random_cases import random_case
 from oracle import refbind
 
+resource.setrlimit(resource.RLIMIT_AS, (12 << 30, 12 << 30))   # a damaged SIZ may ask for a plan of billions of blocks: E_NOMEM, not the OOM killer
+
+
+_REFS = {}
+
+
+def _ref_job(part, resilient):
+    if "r" not in _REFS:
+        _REFS["r"] = refbind.Ref(generic=True)
+    try:
+        return ("ok", _REFS["r"].decode(part, resilient=resilient, max_samples=1 << 22)[0])
+    except refbind.TooLarge:
+        return ("large", None)
+    except RuntimeError as e:
+        return ("raise", str(e))
+
+
+def _our_job(part, resilient):
+    try:
+        pl = parse_codestream(part, resilient=resilient)
+        if sum(c["w"] * c["h"] for c in (pl.comp_info(i) for i in range(int(pl.params.num_comps)))) > (1 << 22):
+            return ("large", None)
+        return ("ok", cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient)))
+    except (capi.OjphError, RuntimeError, MemoryError) as e:
+        return ("raise", str(e))
+
+
+class Guard:
+    """jobs in a worker process that is replaced when one of them does not come back: the reference spins on some damaged main
+    headers, and a damaged SIZ can ask for a plan of billions of blocks"""
+    def __init__(self):
+        import multiprocessing
+        self.ctx = multiprocessing.get_context("fork")
+        self.pool = self.ctx.Pool(1)
+
+    def run(self, fn, args, seconds=8):
+        import multiprocessing
+        try:
+            return self.pool.apply_async(fn, args).get(seconds)
+        except multiprocessing.TimeoutError:
+            self.pool.terminate(); self.pool.join()
+            self.pool = self.ctx.Pool(1)
+            return ("hang", None)
+        except Exception as e:                    # (the worker died: out of memory)
+            self.pool.terminate(); self.pool.join()
+            self.pool = self.ctx.Pool(1)
+            return ("raise", "worker: " + repr(e))
+
+
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 600000
 rng = np.random.default_rng(seed)
+HEADER = len(sys.argv) > 3 and sys.argv[3] == "header"
+guard = Guard() if HEADER else None
 refs = {True: refbind.Ref(generic=True), False: refbind.Ref(generic=True)}   # (the generic C++ block decoder: the AVX2 one decodes DAMAGED blocks differently from it)
-n = bad = streams = raised = 0
+n = bad = streams = raised = skipped = 0
 while time.time() < t_end:
     planes, kw, size = random_case(seed); seed += 1
     if any(q.size == 0 for q in planes) or sum(q.size for q in planes) > 40000:
@@ -28,29 +80,57 @@ while time.time() < t_end:
     except RuntimeError:
         continue
     sod = cs.find(b"\xff\x93")
+    first_sot = cs.find(b"\xff\x90\x00\x0a")
     if sod < 0 or len(cs) - sod < 8:
         continue
     streams += 1
+    sots = [i for i in range(first_sot, len(cs) - 14) if cs[i] == 0xFF and cs[i + 1] == 0x90 and cs[i + 2] == 0 and cs[i + 3] == 10 and cs[i + 12] == 0xFF]
     for trial in range(40):
         b = bytearray(cs)
-        for _ in range(int(rng.integers(1, 4))):
-            b[int(rng.integers(sod + 2, len(b)))] = int(rng.choice([0xFF, 0x00, 0x90, 0x7F, int(rng.integers(0, 256))]))
+        if HEADER:                           # the main header: SOC .. the first SOT marker
+            for _ in range(int(rng.integers(1, 3))):
+                b[int(rng.integers(0, first_sot + 2))] = int(rng.choice([0xFF, 0x00, 0x01, 0x52, 0x90, int(rng.integers(0, 256)), int(rng.integers(0, 256))]))
+        elif trial % 3 == 2:                 # aimed at the SOT segments (Isot, Psot, TPsot, TNsot) and the SOD behind them
+            at = sots[int(rng.integers(0, len(sots)))]
+            for _ in range(int(rng.integers(1, 3))):
+                b[at + int(rng.integers(0, 14))] = int(rng.choice([0xFF, 0x00, 0x01, 0x90, 0x93, int(rng.integers(0, 256))]))
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(sod + 2, len(b)))] = int(rng.choice([0xFF, 0x00, 0x90, 0x7F, int(rng.integers(0, 256))]))
         part = bytes(b)
         for resilient in (False, True):
-            try:
-                want, _ = r.decode(part, resilient=resilient)
-            except RuntimeError:
-                want = None
-            try:
-                pl = parse_codestream(part, resilient=resilient)
-                got = cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient) if "resilient" in cp.decode_blocks.__code__.co_varnames else cp.decode_blocks(pl, part))
-            except (capi.OjphError, RuntimeError):
-                got = None
+            if HEADER:                       # (in a worker: the reference can spin on a damaged main header, a plan can ask for all memory)
+                kind, want = guard.run(_ref_job, (part, resilient))
+                if kind in ("large", "hang"):
+                    skipped += 1
+                    continue
+                if kind == "raise":
+                    want = None
+                kind, got = guard.run(_our_job, (part, resilient), 30)
+                if kind == "hang":
+                    print("HANGS here: seed %d, bytes %s" % (seed - 1, [(i, part[i]) for i in range(len(cs)) if cs[i] != part[i]]), flush=True)
+                if kind != "ok":
+                    got = None
+            else:
+                try:
+                    want, _ = r.decode(part, resilient=resilient, max_samples=1 << 22)
+                except refbind.TooLarge:
+                    continue
+                except RuntimeError:
+                    want = None
+                try:
+                    pl = parse_codestream(part, resilient=resilient)
+                    got = cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient))
+                except (capi.OjphError, RuntimeError, MemoryError):
+                    got = None
             n += 1; raised += want is None
             same = (want is None) == (got is None) and (want is None or (all(np.array_equal(a, c) for a, c in zip(got, want)) if isinstance(want, list) else np.array_equal(got, want)))
             if not same:
                 bad += 1
+                if os.environ.get("FUZZ_DUMP"):
+                    os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
+                    open(os.path.join(os.environ["FUZZ_DUMP"], "%d_%d_%d.j2c" % (seed - 1, trial, int(resilient))), "wb").write(part)
                 diff = [i for i in range(len(cs)) if cs[i] != part[i]]
                 print("DIFFERS: seed %d bytes changed at %s of %d (SOD at %d), resilient=%s: reference %s, here %s  %s" %
                       (seed - 1, diff, len(cs), sod, resilient, "raises" if want is None else "decodes", "raises" if got is None else "decodes", kw), flush=True)
-print("%d damaged codestreams (%d sources; the reference raised on %d): %d handled differently from the live reference" % (n, streams, raised, bad))
+print("%d damaged codestreams (%d sources; the reference raised on %d; %d set aside: the reference spins or the frame is huge): %d handled differently from the live reference" % (n, streams, raised, skipped, bad))
