@@ -576,14 +576,14 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
   }
   {
     uint32_t lpw = 15, lph = 15;
+    bool per_res = false;                                         // a list of precinct sizes, one per resolution
+    for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
     if (p.precinct_w && p.precinct_h) {
       lpw = ilog2(p.precinct_w); lph = ilog2(p.precinct_h);
       if ((1u << lpw) != p.precinct_w || (1u << lph) != p.precinct_h || lpw > 15 || lph > 15)
         return fail("precinct size must be a power of two <= 32768");
-      if (p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");
+      if (!per_res && p.num_decomps > 0 && (lpw == 0 || lph == 0)) return fail("precinct size too small");   // (one size for every resolution; a list may start with a 1: ojph_params.cpp:1190-1198)
     }
-    bool per_res = false;                                         // a list of precinct sizes, one per resolution
-    for (uint32_t i = 0; i <= p.num_decomps && i < 36; ++i) per_res |= p.precinct_exps[i] != 0;
     if (per_res) {
       if (p.num_decomps >= 36) return fail("too many resolutions for a precinct list");
       for (uint32_t i = 1; i <= p.num_decomps; ++i)

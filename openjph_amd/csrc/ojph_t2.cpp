@@ -1088,11 +1088,11 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   h->plan.parsed = true;
   if (p.prog_order > 4) { h->plan.no_packets = true; p.prog_order = 0; }   // (the plan is laid out as LRCP; nothing is read into it)
   int rc = build_plan(p, h->plan);
-  if (rc != OJPHGPU_OK) { return rc; }
+  if (rc != OJPHGPU_OK) { if (getenv("OJPHGPU_T2_DEBUG")) fprintf(stderr, "ojphgpu_t2_parse: build_plan: %d %s\n", rc, h->plan.error.c_str()); return rc; }
   Plan& P = h->plan;
-  // the codestream's own quantisation parameters override the derived ones; a reversibly transformed
-  // component needs reversible-style steps and the other way round (the reference would read the
-  // wrong union member; here the codestream is refused)
+  // the codestream's own quantisation parameters override the derived ones; an irreversibly transformed
+  // component needs scalar-expounded steps (the reference's get_irrev_delta raises otherwise), a reversibly
+  // transformed one takes its K_max from either style
   P.qcd.sqcd = sqcd; P.qcd.guard_bits = sqcd >> 5;
   P.qcd.q8 = q8; P.qcd.q16 = q16;
   if (q8.empty() && q16.empty()) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }
@@ -1104,7 +1104,7 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   P.qcc_order.clear();
   for (uint32_t c = 0; c < p.num_comps; ++c) if (P.qcc[c].present) P.qcc_order.push_back(c);
   for (uint32_t c = 0; c < p.num_comps; ++c)
-    if ((P.quant(c).sqcd & 0x1F) != (P.style(c).rev ? 0u : 2u)) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }
+    if (!P.style(c).rev && (P.quant(c).sqcd & 0x1F) != 2u) { return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__); }   // get_irrev_delta's OJPH_ERROR (ojph_params.cpp:1655-1659); a reversible component takes K_max from whatever style there is (:1715-1749)
   for (Band& B : P.bands) {
     B.K_max = band_Kmax(P, B.comp, B.res, B.band);
     // K_max of a parsed QCD / QCC is whatever the codestream says: an exponent of 0 with no guard bit
