@@ -652,7 +652,15 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     if (plan.parts_per_tile > 255) return fail("tile-part numbers beyond 255 (components with fewer decompositions leave gaps)");
   }
   plan.p = p;
-  if (!derive_quant(plan)) return OJPHGPU_E_INVALID;
+  // (a parsed codestream brings its own QCD / QCC: what the writer could not derive for these parameters -- more than 38 bits,
+  // a kernel gain beyond the guard bits -- does not keep it from being read)
+  if (!derive_quant(plan)) {
+    if (!plan.parsed) return OJPHGPU_E_INVALID;
+    plan.error.clear();                                            // place holders until the parser puts the codestream's own in
+    plan.qcc.assign(p.num_comps, QuantSet()); plan.qcc_order.clear();
+    plan.qcd = QuantSet(); plan.qcd.sqcd = 1u << 5; plan.qcd.guard_bits = 1;
+    plan.qcd.q8.assign(97, (uint8_t)(8u << 3)); plan.qcd.q16.assign(97, (uint16_t)(8u << 11));
+  }
   const bool parsed_nlt = p.nlt_bd_default != 0 || std::any_of(p.nlt_bd, p.nlt_bd + OJPHGPU_MAX_COC_COMPS, [](uint8_t v) { return v != 0; }) || p.nlt_reserved[0] != 0;
   if (!derive_nlt(plan, parsed_nlt)) return OJPHGPU_E_INVALID;
 

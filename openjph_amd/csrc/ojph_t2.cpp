@@ -900,6 +900,23 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
       hf.pos = r.pos; hf.seek_cur((int64_t)L - 2);
       continue;
     }
+    if (m == DFS) {                                         // param_dfs::read (ojph_params.cpp:2596-2644) never looks at Ldfs
+      const uint32_t sdfs = r.u16(), ids = r.u8();
+      if (r.bad || sdfs > 15 || ids == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+      ojphgpu_dfs* f = nullptr, scratch;
+      for (ojphgpu_dfs& o : p.dfs) if (!o.used) { f = &o; break; }
+      if (!f) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                            // more DFS marker segments than the tables hold
+      if (L == 0) f = &scratch;                             // Ldfs == 0 is the reference's "this object is not in use" (:2598): read, and forgotten
+      memset(f, 0, sizeof(*f));
+      f->used = 1; f->index = (uint8_t)sdfs; f->num_levels = (uint8_t)std::min<uint32_t>(ids, 32);
+      for (uint32_t i = 0; i < ids; i += 4) {
+        const uint32_t v = r.u8();
+        for (uint32_t j = 0; j < 4 && i + j < 32 && i + j < ids; ++j) f->types[i + j] = (uint8_t)((v >> (6 - 2 * j)) & 3u);
+      }
+      if (r.bad) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                      // "error reading DFS-Ddfs parameters"
+      hf.pos = r.pos;
+      continue;
+    }
     if (L < 2 || !r.ok(L - 2)) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
     size_t next = r.pos + L - 2;
     r.lim = next;                                                  // no field of this segment lies beyond it
@@ -1020,19 +1037,6 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
         if (comp >= OJPHGPU_MAX_COC_COMPS) return t2_refused(OJPHGPU_E_INVALID, __LINE__);   // per-component entries: first 16 components
         if (p.nlt_comp[comp] == 0) p.nlt_rank[comp] = (uint8_t)++num_nlts;
         p.nlt_comp[comp] = (uint8_t)(type + 1); p.nlt_bd[comp] = (uint8_t)bd;
-      }
-    } else if (m == DFS) {                                  // param_dfs::read (ojph_params.cpp:2596-2644)
-      if (L < 5) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
-      const uint32_t sdfs = r.u16(), ids = r.u8();
-      if (sdfs > 15 || ids == 0) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
-      if (L != 5 + (ids + 3) / 4) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
-      ojphgpu_dfs* f = nullptr;
-      for (ojphgpu_dfs& o : p.dfs) if (!o.used) { f = &o; break; }
-      if (!f) return t2_refused(OJPHGPU_E_INVALID, __LINE__);                            // more DFS marker segments than the tables hold
-      f->used = 1; f->index = (uint8_t)sdfs; f->num_levels = (uint8_t)std::min<uint32_t>(ids, 32);
-      for (uint32_t i = 0; i < ids; i += 4) {
-        const uint32_t v = r.u8();
-        for (uint32_t j = 0; j < 4 && i + j < 32 && i + j < ids; ++j) f->types[i + j] = (uint8_t)((v >> (6 - 2 * j)) & 3u);
       }
     } else if (m == ATK) {                                  // param_atk::read (ojph_params.cpp:2770-2866)
       if (L < 5) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);

@@ -1154,8 +1154,18 @@ static void NAME(T* x, long st, int n, int even, const ojo_lift_step* steps, int
         const float m = a * sum;                                                                                       \
         x[t * st] = (T)(synthesis ? (float)x[t * st] - m : (float)x[t * st] + m);                                      \
       } else {                                                                                                         \
-        const int64_t v = ((int64_t)steps[j].b + (int64_t)steps[j].a * ((int64_t)x[l * st] + (int64_t)x[r * st])) >> steps[j].e; \
-        x[t * st] = (T)(synthesis ? (int64_t)x[t * st] - v : (int64_t)x[t * st] + v);                                  \
+        /* the reference's own width, wrapping (gen_rev_vert_step32 / 64, ojph_transform.cpp:209-310: si32 / si64 throughout; a */ \
+        /* kernel whose gain overflows it is outside the standard, but a damaged ATK segment is read and applied all the same);  */ \
+        /* a shift count beyond the width counts modulo it, as the x86 and gfx9 shifters take it */                               \
+        if (sizeof(T) == 4) {                                                                                          \
+          const uint32_t sum = (uint32_t)x[l * st] + (uint32_t)x[r * st];                                              \
+          const int32_t v = (int32_t)((uint32_t)steps[j].b + (uint32_t)steps[j].a * sum) >> (steps[j].e & 31);         \
+          x[t * st] = (T)(int32_t)(synthesis ? (uint32_t)x[t * st] - (uint32_t)v : (uint32_t)x[t * st] + (uint32_t)v); \
+        } else {                                                                                                       \
+          const uint64_t sum = (uint64_t)x[l * st] + (uint64_t)x[r * st];                                              \
+          const int64_t v = (int64_t)((uint64_t)(int64_t)steps[j].b + (uint64_t)(int64_t)steps[j].a * sum) >> (steps[j].e & 63); \
+          x[t * st] = (T)(int64_t)(synthesis ? (uint64_t)x[t * st] - (uint64_t)v : (uint64_t)x[t * st] + (uint64_t)v); \
+        }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
   }                                                                                                                    \

@@ -2,7 +2,7 @@
 """Codestreams of random parameter sets (written by the LIVE reference) with one to three bytes changed behind the first SOD -- packet
 headers, code-block bytes, later SOT segments -- or, every third one, inside an SOT segment / its SOD -- read with and without resilience: the reference's verdict (raise / decode) and its
 image are the oracle pipeline's.  CPU only.      python tools/fuzz_flip_cpu.py [seconds] [first seed] [header]
-(header: the changed bytes lie in the main header instead.)"""
+(header: the changed bytes lie in the main header instead; part2: the same with Part-2 codestreams written by this library.)"""
 import os, sys, time, resource
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,10 +13,12 @@ from tests import cpu_pipeline as cp
 from tests.random_cases import random_case
 from oracle import refbind
 
-resource.setrlimit(resource.RLIMIT_AS, (12 << 30, 12 << 30))   # a damaged SIZ may ask for a plan of billions of blocks: E_NOMEM, not the OOM killer
-
 
 _REFS = {}
+
+
+def _limit():     # the worker only: a damaged SIZ may ask for a plan of billions of blocks -- E_NOMEM, not the OOM killer
+    resource.setrlimit(resource.RLIMIT_AS, (12 << 30, 12 << 30))
 
 
 def _ref_job(part, resilient):
@@ -46,7 +48,7 @@ class Guard:
     def __init__(self):
         import multiprocessing
         self.ctx = multiprocessing.get_context("fork")
-        self.pool = self.ctx.Pool(1)
+        self.pool = self.ctx.Pool(1, initializer=_limit)
 
     def run(self, fn, args, seconds=8):
         import multiprocessing
@@ -54,83 +56,102 @@ class Guard:
             return self.pool.apply_async(fn, args).get(seconds)
         except multiprocessing.TimeoutError:
             self.pool.terminate(); self.pool.join()
-            self.pool = self.ctx.Pool(1)
+            self.pool = self.ctx.Pool(1, initializer=_limit)
             return ("hang", None)
         except Exception as e:                    # (the worker died: out of memory)
             self.pool.terminate(); self.pool.join()
-            self.pool = self.ctx.Pool(1)
+            self.pool = self.ctx.Pool(1, initializer=_limit)
             return ("raise", "worker: " + repr(e))
 
 
-t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 600000
-rng = np.random.default_rng(seed)
-HEADER = len(sys.argv) > 3 and sys.argv[3] == "header"
-guard = Guard() if HEADER else None
-refs = {True: refbind.Ref(generic=True), False: refbind.Ref(generic=True)}   # (the generic C++ block decoder: the AVX2 one decodes DAMAGED blocks differently from it)
-n = bad = streams = raised = skipped = 0
-while time.time() < t_end:
-    planes, kw, size = random_case(seed); seed += 1
-    if any(q.size == 0 for q in planes) or sum(q.size for q in planes) > 40000:
-        continue
-    r = refs[bool(kw["reversible"])]
-    k2 = dict(kw); bd, sg = k2.pop("bit_depth"), k2.pop("is_signed")
-    try:
-        cs = r.encode(planes, bd, is_signed=sg, size=size, **k2)
-    except RuntimeError:
-        continue
-    sod = cs.find(b"\xff\x93")
-    first_sot = cs.find(b"\xff\x90\x00\x0a")
-    if sod < 0 or len(cs) - sod < 8:
-        continue
-    streams += 1
-    sots = [i for i in range(first_sot, len(cs) - 14) if cs[i] == 0xFF and cs[i + 1] == 0x90 and cs[i + 2] == 0 and cs[i + 3] == 10 and cs[i + 12] == 0xFF]
-    for trial in range(40):
-        b = bytearray(cs)
-        if HEADER:                           # the main header: SOC .. the first SOT marker
-            for _ in range(int(rng.integers(1, 3))):
-                b[int(rng.integers(0, first_sot + 2))] = int(rng.choice([0xFF, 0x00, 0x01, 0x52, 0x90, int(rng.integers(0, 256)), int(rng.integers(0, 256))]))
-        elif trial % 3 == 2:                 # aimed at the SOT segments (Isot, Psot, TPsot, TNsot) and the SOD behind them
-            at = sots[int(rng.integers(0, len(sots)))]
-            for _ in range(int(rng.integers(1, 3))):
-                b[at + int(rng.integers(0, 14))] = int(rng.choice([0xFF, 0x00, 0x01, 0x90, 0x93, int(rng.integers(0, 256))]))
+def main(seconds=None, seed=None, header=None, sources=None):
+    argv = sys.argv
+    t_end = time.time() + (seconds if seconds is not None else float(argv[1]) if len(argv) > 1 else 60)
+    seed = seed if seed is not None else int(argv[2]) if len(argv) > 2 else 600000
+    rng = np.random.default_rng(seed)
+    HEADER = header if header is not None else (len(argv) > 3 and argv[3] in ("header", "part2"))
+    PART2 = header == "part2" or (header is None and len(argv) > 3 and argv[3] == "part2")
+    guard = Guard() if HEADER else None
+    refs = {True: refbind.Ref(generic=True), False: refbind.Ref(generic=True)}   # (the generic C++ block decoder: the AVX2 one decodes DAMAGED blocks differently from it)
+    n = bad = streams = raised = skipped = 0
+    while time.time() < t_end and (sources is None or streams < sources):
+        if PART2:                        # codestreams with ATK / DFS / COC / QCC / NLT marker segments, written here (tests/part2_cases.py)
+            from tests.part2_cases import CASES, split, image
+            nc, h, w, bd, kw = split(CASES[seed % len(CASES)]); seed += 1
+            if bd > 16:
+                continue
+            cs = bytes(cp.encode(image(nc, h, w, bd), **kw)[0])
+            kw = {a: v for a, v in kw.items() if a != "atk"}
+            r = refs[True]
         else:
-            for _ in range(int(rng.integers(1, 4))):
-                b[int(rng.integers(sod + 2, len(b)))] = int(rng.choice([0xFF, 0x00, 0x90, 0x7F, int(rng.integers(0, 256))]))
-        part = bytes(b)
-        for resilient in (False, True):
-            if HEADER:                       # (in a worker: the reference can spin on a damaged main header, a plan can ask for all memory)
-                kind, want = guard.run(_ref_job, (part, resilient))
-                if kind in ("large", "hang"):
-                    skipped += 1
-                    continue
-                if kind == "raise":
-                    want = None
-                kind, got = guard.run(_our_job, (part, resilient), 30)
-                if kind == "hang":
-                    print("HANGS here: seed %d, bytes %s" % (seed - 1, [(i, part[i]) for i in range(len(cs)) if cs[i] != part[i]]), flush=True)
-                if kind != "ok":
-                    got = None
+            planes, kw, size = random_case(seed); seed += 1
+            if any(q.size == 0 for q in planes) or sum(q.size for q in planes) > 40000:
+                continue
+            r = refs[bool(kw["reversible"])]
+            k2 = dict(kw); bd, sg = k2.pop("bit_depth"), k2.pop("is_signed")
+            try:
+                cs = r.encode(planes, bd, is_signed=sg, size=size, **k2)
+            except RuntimeError:
+                continue
+        sod = cs.find(b"\xff\x93")
+        first_sot = cs.find(b"\xff\x90\x00\x0a")
+        if sod < 0 or len(cs) - sod < 8:
+            continue
+        streams += 1
+        sots = [i for i in range(first_sot, len(cs) - 14) if cs[i] == 0xFF and cs[i + 1] == 0x90 and cs[i + 2] == 0 and cs[i + 3] == 10 and cs[i + 12] == 0xFF]
+        for trial in range(40):
+            b = bytearray(cs)
+            if HEADER:                           # the main header: SOC .. the first SOT marker
+                for _ in range(int(rng.integers(1, 3))):
+                    b[int(rng.integers(0, first_sot + 2))] = int(rng.choice([0xFF, 0x00, 0x01, 0x52, 0x90, int(rng.integers(0, 256)), int(rng.integers(0, 256))]))
+            elif trial % 3 == 2:                 # aimed at the SOT segments (Isot, Psot, TPsot, TNsot) and the SOD behind them
+                at = sots[int(rng.integers(0, len(sots)))]
+                for _ in range(int(rng.integers(1, 3))):
+                    b[at + int(rng.integers(0, 14))] = int(rng.choice([0xFF, 0x00, 0x01, 0x90, 0x93, int(rng.integers(0, 256))]))
             else:
-                try:
-                    want, _ = r.decode(part, resilient=resilient, max_samples=1 << 22)
-                except refbind.TooLarge:
-                    continue
-                except RuntimeError:
-                    want = None
-                try:
-                    pl = parse_codestream(part, resilient=resilient)
-                    got = cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient))
-                except (capi.OjphError, RuntimeError, MemoryError):
-                    got = None
-            n += 1; raised += want is None
-            same = (want is None) == (got is None) and (want is None or (all(np.array_equal(a, c) for a, c in zip(got, want)) if isinstance(want, list) else np.array_equal(got, want)))
-            if not same:
-                bad += 1
-                if os.environ.get("FUZZ_DUMP"):
-                    os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
-                    open(os.path.join(os.environ["FUZZ_DUMP"], "%d_%d_%d.j2c" % (seed - 1, trial, int(resilient))), "wb").write(part)
-                diff = [i for i in range(len(cs)) if cs[i] != part[i]]
-                print("DIFFERS: seed %d bytes changed at %s of %d (SOD at %d), resilient=%s: reference %s, here %s  %s" %
-                      (seed - 1, diff, len(cs), sod, resilient, "raises" if want is None else "decodes", "raises" if got is None else "decodes", kw), flush=True)
-print("%d damaged codestreams (%d sources; the reference raised on %d; %d set aside: the reference spins or the frame is huge): %d handled differently from the live reference" % (n, streams, raised, skipped, bad))
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(sod + 2, len(b)))] = int(rng.choice([0xFF, 0x00, 0x90, 0x7F, int(rng.integers(0, 256))]))
+            part = bytes(b)
+            for resilient in (False, True):
+                if HEADER:                       # (in a worker: the reference can spin on a damaged main header, a plan can ask for all memory)
+                    kind, want = guard.run(_ref_job, (part, resilient))
+                    if kind in ("large", "hang"):
+                        skipped += 1
+                        continue
+                    if kind == "raise":
+                        want = None
+                    kind, got = guard.run(_our_job, (part, resilient), 30)
+                    if kind == "hang":
+                        print("HANGS here: seed %d, bytes %s" % (seed - 1, [(i, part[i]) for i in range(len(cs)) if cs[i] != part[i]]), flush=True)
+                    if kind != "ok":
+                        got = None
+                else:
+                    try:
+                        want, _ = r.decode(part, resilient=resilient, max_samples=1 << 22)
+                    except refbind.TooLarge:
+                        continue
+                    except RuntimeError:
+                        want = None
+                    try:
+                        pl = parse_codestream(part, resilient=resilient)
+                        got = cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient))
+                    except (capi.OjphError, RuntimeError, MemoryError):
+                        got = None
+                n += 1; raised += want is None
+                same = (want is None) == (got is None) and (want is None or (all(np.array_equal(a, c) for a, c in zip(got, want)) if isinstance(want, list) else np.array_equal(got, want)))
+                if not same:
+                    bad += 1
+                    if os.environ.get("FUZZ_DUMP"):
+                        os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
+                        open(os.path.join(os.environ["FUZZ_DUMP"], "%d_%d_%d.j2c" % (seed - 1, trial, int(resilient))), "wb").write(part)
+                    diff = [i for i in range(len(cs)) if cs[i] != part[i]]
+                    print("DIFFERS: seed %d bytes changed at %s of %d (SOD at %d), resilient=%s: reference %s, here %s  %s" %
+                          (seed - 1, diff, len(cs), sod, resilient, "raises" if want is None else "decodes", "raises" if got is None else "decodes", kw), flush=True)
+    print("%d damaged codestreams (%d sources; the reference raised on %d; %d set aside: the reference spins or the frame is huge): %d handled differently from the live reference" % (n, streams, raised, skipped, bad))
+    if guard is not None:
+        guard.pool.terminate(); guard.pool.join()
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
