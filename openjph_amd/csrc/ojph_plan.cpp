@@ -542,12 +542,12 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
     AtkDef d; d.index = a.index; d.rev = a.reversible != 0; d.coeff_type = a.coeff_type; d.K = a.reversible ? 1.0f : a.K;
     for (uint32_t k = 0; k < a.num_steps; ++k) {
       ojphgpu_lift_step st = a.steps[k];
-      if (d.rev) { st.A = 0.0f; if (st.e < 0 || st.e > 62) return fail("ATK lifting step with an impossible shift"); }
+      if (d.rev) { st.A = 0.0f; if (st.e < 0 || st.e > (plan.parsed ? 255 : 62)) return fail("ATK lifting step with an impossible shift"); }   // (read: whatever the Eatk byte says -- the shifters count modulo the width)
       else { st.a = st.b = st.e = 0; }
       a.steps[k] = st; d.steps.push_back(st);
     }
     for (uint32_t k = a.num_steps; k < OJPHGPU_MAX_LIFT_STEPS; ++k) memset(&a.steps[k], 0, sizeof(a.steps[k]));
-    if (!d.rev && !(d.K > 0.0f)) return fail("ATK scaling factor must be positive");
+    if (!plan.parsed && !d.rev && !(d.K > 0.0f)) return fail("ATK scaling factor must be positive");
     plan.atks.push_back(d);
   }
   for (uint32_t i = 0; i < OJPHGPU_MAX_DFS; ++i) {

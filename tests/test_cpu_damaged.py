@@ -1,0 +1,124 @@
+"""Damaged codestreams, case by case: what tools/fuzz_flip_cpu.py finds statistically, spelt out.  Every case is
+read by the LIVE reference (generic build) and by the host parser + oracle pipeline, with and without resilience: the same
+verdict, the same picture."""
+import numpy as np
+import pytest
+
+from openjph_amd import capi
+from openjph_amd.plan import parse_codestream
+from tests import cpu_pipeline as cp
+from tests.synth import synth_image
+
+
+def _both(refgen, part):
+    out = []
+    for resilient in (False, True):
+        try:
+            want, _ = refgen.decode(part, resilient=resilient)
+        except RuntimeError:
+            want = None
+        try:
+            pl = parse_codestream(part, resilient=resilient)
+            got = cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient))
+        except (capi.OjphError, RuntimeError):
+            got = None
+        assert (want is None) == (got is None), "resilient=%s: reference %s, here %s" % (
+            resilient, "raises" if want is None else "decodes", "raises" if got is None else "decodes")
+        if want is not None:
+            assert np.array_equal(np.asarray(got), np.asarray(want)), "resilient=%s: pictures differ" % resilient
+        out.append(want)
+    return out
+
+
+@pytest.fixture(scope="module")
+def stream(refgen):
+    img = synth_image(1, 72, 88, 8, seed=5)
+    cs = refgen.encode(img, 8, num_decomps=3, block=(16, 16), prog_order="LRCP", tileparts="R")
+    sots = [i for i in range(len(cs) - 12) if cs[i:i + 4] == b"\xff\x90\x00\x0a"]
+    assert len(sots) == 4                       # one tile-part per resolution
+    clean, _ = refgen.decode(cs)
+    return cs, sots, np.asarray(clean)
+
+
+def test_bytes_between_tile_parts_are_passed_over(refgen, stream):
+    """find_marker (ojph_codestream_local.cpp:706-730): whatever lies between a tile-part's end and the next 0xFF90 is skipped"""
+    cs, sots, clean = stream
+    part = cs[:sots[2]] + b"\x01\x02\x03\x04\x05" + cs[sots[2]:]
+    strict, resilient = _both(refgen, part)
+    assert np.array_equal(np.asarray(strict), clean) and np.array_equal(np.asarray(resilient), clean)
+
+
+def test_a_damaged_sod_is_searched_for(refgen, stream):
+    """the SOD of a later tile-part overwritten: the search runs into the packet bytes (and finds an SOD there, or the next SOT)"""
+    cs, sots, clean = stream
+    b = bytearray(cs); b[sots[2] + 12] = 0x2C
+    _both(refgen, bytes(b))
+
+
+def test_unknown_progression_order_reads_no_packet(refgen, stream):
+    """tile::parse_tile_header has no branch for a progression byte above 4 (ojph_tile.cpp:900-901): every block stays empty"""
+    cs, sots, clean = stream
+    cod = cs.find(b"\xff\x52")
+    b = bytearray(cs); b[cod + 5] = 7
+    strict, resilient = _both(refgen, bytes(b))
+    assert strict is not None and len(np.unique(np.asarray(strict))) == 1
+
+
+def test_a_precinct_whose_header_threw_is_read_again_from_the_next_tile_part(refgen, stream):
+    """the first packet header of tile-part 1 claims missing MSBs beyond K_max: an error -- or, resilient, the rest of the tile-part
+    is skipped and the SAME precinct is parsed from tile-part 2's bytes (resolution::parse_one_precinct moves on only after a
+    parse has returned), with whatever the failed attempt left in its blocks' headers"""
+    cs, sots, clean = stream
+    hits = 0
+    for value in (0x80, 0x81, 0xC0, 0xE0, 0xF0, 0xFF, 0xAA, 0x00):
+        b = bytearray(cs); b[sots[1] + 14] = value          # first byte of the tile-part's first packet header
+        strict, resilient = _both(refgen, bytes(b))
+        hits += strict is None and resilient is not None
+    assert hits >= 1
+
+
+def test_a_tile_part_shorter_than_its_packets_pads_the_last_block(refgen, stream):
+    """Psot of the last tile-part made 1 .. 40 bytes smaller while the file still holds the bytes: bb_read_chunk hands the block
+    decoder what the tile-part has left plus zeros (ojph_bitbuffer_read.h:134-150) -- refused (Scup reads 0: an error, or a zero
+    block when resilient) or, when only refinement bytes are missing, decoded"""
+    cs, sots, clean = stream
+    raised = 0
+    for less in (1, 2, 3, 7, 20, 40):
+        b = bytearray(cs)
+        psot = int.from_bytes(cs[sots[3] + 6:sots[3] + 10], "big") - less
+        b[sots[3] + 6:sots[3] + 10] = psot.to_bytes(4, "big")
+        strict, resilient = _both(refgen, bytes(b))
+        raised += strict is None
+        assert resilient is not None
+    assert raised >= 1
+
+
+def test_damaged_sot_fields(refgen, stream):
+    """Lsot, Isot, TPsot, TNsot and Psot of a later tile-part, one at a time (param_sot::read, ojph_params.cpp:2390-2461; the tile index
+    and tile-part index checks of codestream::read / tile::parse_tile_header)"""
+    cs, sots, clean = stream
+    at = sots[2]
+    for off, value in ((3, 9), (4, 0xFF), (5, 0xFF), (5, 1), (10, 7), (11, 1), (6, 0xFF), (9, 0), (7, 0x40)):
+        b = bytearray(cs); b[at + off] = value
+        _both(refgen, bytes(b))
+
+
+def test_main_header_garbage_and_unsupported_segments(refgen, stream):
+    """bytes in front of SOC, an unknown marker segment and RGN / POC / PPM segments in the main header: passed over or skipped
+    with a warning by read_headers (ojph_codestream_local.cpp:768-881)"""
+    cs, sots, clean = stream
+    qcd = cs.find(b"\xff\x5c")
+    for extra in (b"\xff\x5e\x00\x05\x00\x00\x03", b"\xff\x5f\x00\x09\x00\x00\x00\x01\x01\x01\x00", b"\xff\x60\x00\x04\x00\x00", b"\xff\x30", b"\x00\x11\x22"):
+        strict, resilient = _both(refgen, cs[:qcd] + extra + cs[qcd:])
+        assert np.array_equal(np.asarray(strict), clean)
+    strict, _ = _both(refgen, b"\x00\x00\x00\x0cjP  \r\n\x87\n" + cs)
+    assert np.array_equal(np.asarray(strict), clean)
+
+
+def test_cap_and_quantisation_segments_are_checked_like_the_reference(refgen, stream):
+    cs, sots, clean = stream
+    cap, qcd, cod = cs.find(b"\xff\x50"), cs.find(b"\xff\x5c"), cs.find(b"\xff\x52")
+    for at, value in ((cap + 5, 0x03), (cap + 5, 0x00), (cap + 3, 10), (qcd + 3, 0xFF), (qcd + 4, 0x41), (qcd + 4, 0x43), (cod + 10, 9), (cod + 12, 0x41),
+                      (cod + 8, 0x90), (cod + 9, 0x21), (cod + 13, 0)):
+        b = bytearray(cs); b[at] = value
+        _both(refgen, bytes(b))
