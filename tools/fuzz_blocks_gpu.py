@@ -2,13 +2,15 @@
 """The HIP block decoders (32- and 64-bit sample paths, cleanup + refinement launches) against the oracle on the DAMAGED blocks of
 tools/fuzz_blocks_cpu.py (there the oracle is pinned to the live reference on the very same blocks): same refused / decoded
 verdict per block, same de-quantised samples.  Needs a GPU.     python tools/fuzz_blocks_gpu.py [seconds] [first seed]
-Written when round 4's GPU minutes were spent: NOT yet run (DESIGN.md section 8 lists what it is expected to find)."""
+Written when round 4's GPU minutes were spent: NOT yet run on a GPU (DESIGN.md section 8 item 9 lists what it is expected to find;
+FUZZ_BLOCKS_SELFTEST=1 runs its bookkeeping with the oracle in the device's place)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from openjph_amd import codec
+SELFTEST = bool(os.environ.get("FUZZ_BLOCKS_SELFTEST"))     # no GPU: the oracle stands in for the device (checks this tool's own bookkeeping)
 from oracle import oraclebind as ob
 from fuzz_blocks_cpu import damaged_blocks
 
@@ -36,11 +38,19 @@ def run_batch(trials, wide):
         expect.append((ok, dq))
         off += pitch * h; doff += len(t)
     if wide:
-        coef = torch.full((off + 64,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64).cuda()
+        coef = torch.full((off + 64,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64)
     else:
-        coef = torch.full((off + 64,), 0x5A5A5A5A, dtype=torch.int32).cuda()
-    status = codec.ht_decode(descs, np.frombuffer(b"".join(t[6] for t in trials), np.uint8), coef)
-    got = coef.cpu().numpy()
+        coef = torch.full((off + 64,), 0x5A5A5A5A, dtype=torch.int32)
+    if SELFTEST:
+        got = coef.numpy(); status = np.zeros(len(trials), np.uint8)
+        for i, (ok, want) in enumerate(expect):
+            d = descs[i]; w, h = trials[i][2], trials[i][3]; es = 8 if wide else 4
+            status[i] = 0 if ok else 1
+            np.lib.stride_tricks.as_strided(got[int(d["coef_off"]) // (2 if wide else 1):], (h, w), (int(d["pitch"]) * es, es))[:] = want
+    else:
+        dcoef = coef.cuda()
+        status = codec.ht_decode(descs, np.frombuffer(b"".join(t[6] for t in trials), np.uint8), dcoef)
+        got = dcoef.cpu().numpy()
     bad = []
     for i, (ok, want) in enumerate(expect):
         d = descs[i]; w, h = trials[i][2], trials[i][3]
