@@ -739,7 +739,7 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
             B.delta = 0.0f; B.delta_inv = 0.0f;
             if (!st.rev) {                                         // ojph_subband.cpp:156-164
               float d = band_delta(plan, c, r, b);
-              d /= (float)(1u << (31 - B.K_max));
+              d /= (float)(1u << ((31u - B.K_max) & 31u));          // (K_max beyond 31: refused further on -- writer: make_quant, parser: its own K_max test)
               B.delta = d; B.delta_inv = 1.0f / d;
             }
             B.xcb = std::min(lbw, lpw - xoff); B.ycb = std::min(lbh, lph - yoff);
