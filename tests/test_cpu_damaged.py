@@ -122,3 +122,58 @@ def test_cap_and_quantisation_segments_are_checked_like_the_reference(refgen, st
                       (cod + 8, 0x90), (cod + 9, 0x21), (cod + 13, 0)):
         b = bytearray(cs); b[at] = value
         _both(refgen, bytes(b))
+
+
+def _with_sop_eph(cs, sop, eph):
+    """a single-tile, single-component LRCP codestream with one precinct per resolution, rewritten with SOP marker segments in
+    front of its packets and / or EPH markers behind its packet headers (the reference's encoder writes neither)"""
+    pl = parse_codestream(cs)
+    coded = pl.coded_blocks()
+    by_res = {}
+    for k in range(pl.num_blocks):
+        if coded[k]["len1"]:
+            res = int(pl.bands[int(pl.blocks[k]["band"])]["res"])
+            o = int(coded[k]["offset"]); n = int(coded[k]["len1"]) + int(coded[k]["len2"])
+            lo, hi = by_res.get(res, (1 << 60, 0))
+            by_res[res] = (min(lo, o), max(hi, o + n))
+    sot = cs.find(b"\xff\x90\x00\x0a")
+    out = bytearray(cs[:sot + 14])
+    pos = sot + 14
+    for seq, res in enumerate(sorted(by_res)):
+        body, end = by_res[res]
+        if sop:
+            out += b"\xff\x91\x00\x04" + seq.to_bytes(2, "big")
+        out += cs[pos:body]                                   # the packet header
+        if eph:
+            out += b"\xff\x92"
+        out += cs[body:end]
+        pos = end
+    assert cs[pos:pos + 2] == b"\xff\xd9"
+    out += cs[pos:]
+    out[sot + 6:sot + 10] = (len(out) - 2 - sot).to_bytes(4, "big")       # Psot
+    cod = bytes(out).find(b"\xff\x52")
+    out[cod + 4] |= (2 if sop else 0) | (4 if eph else 0)                   # Scod
+    return bytes(out)
+
+
+def test_sop_and_eph_markers(refgen):
+    """bb_skip_sop / bb_skip_eph (ojph_bitbuffer_read.h:153-221): read when the COD announces them; an SOP of the wrong length or
+    a missing EPH is a throw"""
+    img = synth_image(1, 64, 64, 8, seed=11)
+    cs = refgen.encode(img, 8, num_decomps=2, block=(16, 16), prog_order="LRCP")
+    clean = np.asarray(refgen.decode(cs)[0])
+    for sop, eph in ((True, True), (True, False), (False, True)):
+        part = _with_sop_eph(cs, sop, eph)
+        strict, resilient = _both(refgen, part)
+        assert np.array_equal(np.asarray(strict), clean), (sop, eph)
+        if sop:                                                 # an SOP length of 5, an SOP that is not there
+            at = part.find(b"\xff\x91\x00\x04", part.find(b"\xff\x93") + 8)
+            b = bytearray(part); b[at + 3] = 5
+            _both(refgen, bytes(b))
+            b = bytearray(part); b[at + 1] = 0x55
+            _both(refgen, bytes(b))
+        if eph:                                                 # an EPH overwritten
+            at = part.find(b"\xff\x92", part.find(b"\xff\x93") + 2)
+            b = bytearray(part); b[at + 1] = 0x00
+            strict, resilient = _both(refgen, bytes(b))
+            assert strict is None
