@@ -177,3 +177,35 @@ def test_sop_and_eph_markers(refgen):
             b = bytearray(part); b[at + 1] = 0x00
             strict, resilient = _both(refgen, bytes(b))
             assert strict is None
+
+
+def test_psot_zero_on_the_last_tile_part(refgen, stream):
+    """Psot = 0 ("until the EOC") is legal for the last tile-part: param_sot::get_payload_length answers 0, data_left wraps to nearly
+    2^32, the packets are limited by the file alone, and the final seek goes BACK to the start of the tile-part, from where the
+    EOC is searched for (ojph_tile.cpp:790-796, :934)"""
+    cs, sots, clean = stream
+    b = bytearray(cs); b[sots[3] + 6:sots[3] + 10] = b"\x00\x00\x00\x00"
+    strict, resilient = _both(refgen, bytes(b))
+    assert np.array_equal(np.asarray(strict), clean)
+    single = refgen.encode(synth_image(1, 40, 56, 8, seed=3), 8, num_decomps=2)
+    at = single.find(b"\xff\x90\x00\x0a")
+    b = bytearray(single); b[at + 6:at + 10] = b"\x00\x00\x00\x00"
+    strict, resilient = _both(refgen, bytes(b))
+    assert np.array_equal(np.asarray(strict), np.asarray(refgen.decode(single)[0]))
+
+
+def test_padded_blocks_are_listed(refgen, stream):
+    """ojphgpu_plan_padded_blocks: one byte short of its cleanup segment with a plausible Scup, the last block is decoded by the
+    reference from its bytes plus a zero -- listed with what the packet header said, not coded in ojphgpu_plan_coded_blocks"""
+    cs, sots, clean = stream
+    b = bytearray(cs)
+    psot = int.from_bytes(cs[sots[3] + 6:sots[3] + 10], "big") - 1
+    b[sots[3] + 6:sots[3] + 10] = psot.to_bytes(4, "big")
+    pl = parse_codestream(bytes(b), resilient=True)
+    listed = pl.padded_blocks()
+    assert len(listed) == 1
+    q = listed[0]
+    whole = parse_codestream(cs).coded_blocks()[int(q["block"])]
+    assert int(q["got"]) == int(q["len1"]) + int(q["len2"]) - 1 and int(q["offset"]) == int(whole["offset"]) and int(q["len1"]) == int(whole["len1"])
+    assert int(pl.coded_blocks()[int(q["block"])]["len1"]) == 0
+    assert len(parse_codestream(cs).padded_blocks()) == 0
