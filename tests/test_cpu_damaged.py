@@ -209,3 +209,22 @@ def test_padded_blocks_are_listed(refgen, stream):
     assert int(q["got"]) == int(q["len1"]) + int(q["len2"]) - 1 and int(q["offset"]) == int(whole["offset"]) and int(q["len1"]) == int(whole["len1"])
     assert int(pl.coded_blocks()[int(q["block"])]["len1"]) == 0
     assert len(parse_codestream(cs).padded_blocks()) == 0
+
+
+def test_marker_segments_in_tile_part_headers(refgen, stream):
+    """PLT / COM segments in a tile-part header are skipped; PPT / POC / COD / QCD there are "not supported yet" -- a warning, and
+    skipped all the same (ojph_codestream_local.cpp:952-1093); with Psot adjusted the picture is the clean one, without it the
+    tile-part is that many bytes short"""
+    cs, sots, clean = stream
+    for seg in (b"\xff\x58\x00\x05\x00\x01\x02", b"\xff\x64\x00\x06\x00\x01hi", b"\xff\x61\x00\x04\x00\x07", b"\xff\x5f\x00\x09\x00\x00\x00\x01\x01\x01\x00",
+                b"\xff\x5c\x00\x05\x40\x40\x48"):
+        for which in (0, 2):
+            at = sots[which]
+            first_only = seg[1] == 0x5C and which != 0             # (a QCD is looked for in a tile's FIRST tile-part only)
+            b = bytearray(cs[:at + 12] + seg + cs[at + 12:])
+            psot = int.from_bytes(cs[at + 6:at + 10], "big") + len(seg)
+            b[at + 6:at + 10] = psot.to_bytes(4, "big")
+            strict, resilient = _both(refgen, bytes(b))
+            if not first_only:
+                assert np.array_equal(np.asarray(strict), clean), (seg[:2].hex(), which)
+            _both(refgen, cs[:at + 12] + seg + cs[at + 12:])           # Psot left as it was
