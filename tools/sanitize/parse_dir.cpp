@@ -5,7 +5,7 @@
 #include <dirent.h>
 #include <string>
 int main(int argc, char** argv) {
-  int n = 0, ok = 0;
+  int n = 0, ok = 0, rewritten = 0;
   for (int a = 1; a < argc; ++a) {
     DIR* d = opendir(argv[a]); if (!d) continue;
     while (dirent* e = readdir(d)) {
@@ -25,12 +25,16 @@ int main(int argc, char** argv) {
           std::vector<ojphgpu_coded_block> cb(c[2]); ojphgpu_plan_coded_blocks(plan, cb.data(), cb.size());
           for (auto& k2 : cb) if (k2.len1 && k2.offset + k2.len1 + k2.len2 > b.size()) { printf("OUT OF RANGE block in %s\n", p.c_str()); break; }
           size_t cnt = 0; ojphgpu_plan_padded_blocks(plan, nullptr, 0, &cnt);
+          // the writer on what was read (a transcoder's use): whatever it makes of a damaged plan, it stays inside its buffers
+          size_t need = 0; std::vector<uint8_t> outb(b.size() + 65536);
+          int wrc = ojphgpu_t2_write(plan, b.data(), cb.data(), outb.data(), outb.size(), &need);
+          if (wrc == 0) ++rewritten;
           ojphgpu_plan_destroy(plan);
         }
       }
     }
     closedir(d);
   }
-  printf("%d parses, %d plans\n", n, ok);
+  printf("%d parses, %d plans, %d written again\n", n, ok, rewritten);
   return 0;
 }
