@@ -703,7 +703,7 @@ struct BitBuf {            // bit_read_buf (ojph_bitbuffer_read.h:56-130): at mo
 // Code-block BYTES (:526-569): a chunk takes min(its length, what the tile-part has left) bytes from the file; only when
 // the FILE has fewer, the block -- and every block after it -- counts as not coded (no error in either mode).  When the
 // tile-part has fewer than the header says but the file delivers them, the reference keeps the block with the missing
-// bytes as ZEROS: `padded` counts those (see t2_parse).
+// bytes as ZEROS: `padded` lists those (settled at the end of t2_parse).
 struct PaddedBlock { uint32_t id, got; };       // block id, bytes the file delivered
 
 // A precinct whose header threw is read AGAIN from the next tile-part of its tile (resolution::parse_one_precinct,
@@ -711,9 +711,6 @@ struct PaddedBlock { uint32_t id, got; };       // block id, bytes the file deli
 // wrote into its blocks' headers STAYS (coded_cb_header: lengths, passes, missing MSBs; no bytes -- next_coded is still NULL):
 // a block the next attempt does not find included keeps those lengths and takes that many bytes in the body phase
 // (:526-569 goes by pass_length alone).  `has_data` is next_coded != NULL; blocks without it are emptied at the end of t2_parse.
-static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data_left, bool use_sop, bool use_eph,
-                         std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data);
-
 static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data_left, bool use_sop, bool use_eph,
                          std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data)
 {
