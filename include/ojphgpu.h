@@ -244,6 +244,12 @@ int  ojphgpu_t2_write_main_header(const ojphgpu_plan* plan, const uint32_t* tile
                                   uint8_t* h_out, size_t cap, size_t* out_len);
 /* Parses main header + all tile-parts; creates the plan the codestream implies. */
 int  ojphgpu_t2_parse(const uint8_t* h_codestream, size_t len, int resilient, ojphgpu_plan** out);
+/* read_headers + restrict_input_resolution + read in the reference's order: the same as ojphgpu_t2_parse followed by
+ * ojphgpu_plan_restrict_resolution on an undamaged codestream; on a damaged or truncated one the tile-parts are read the way
+ * the reference reads them under the restriction (resolution-major progressions stop at the highest resolution wanted, packets
+ * of unwanted resolutions are stepped over: ojph_tile.cpp:806-848, ojph_precinct.cpp:531-541). */
+int  ojphgpu_t2_parse_restricted(const uint8_t* h_codestream, size_t len, int resilient, uint32_t skipped_res_for_data,
+                                 uint32_t skipped_res_for_recon, ojphgpu_plan** out);
 /* after ojphgpu_t2_parse: per-block coded info (offsets are into the parsed codestream) */
 int  ojphgpu_plan_coded_blocks(const ojphgpu_plan* plan, ojphgpu_coded_block* out, size_t n);
 /* after ojphgpu_t2_parse of a DAMAGED codestream: the blocks the reference would decode from bytes the codestream does not

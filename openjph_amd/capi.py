@@ -179,6 +179,7 @@ SIGNATURES = {
     "ojphgpu_plan_comp_plane": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_plan_coded_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ojphgpu_t2_parse_restricted": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ojphgpu_plan_padded_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_t2_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_size_t)]),

@@ -712,7 +712,7 @@ struct PaddedBlock { uint32_t id, got; };       // block id, bytes the file deli
 // a block the next attempt does not find included keeps those lengths and takes that many bytes in the body phase
 // (:526-569 goes by pass_length alone).  `has_data` is next_coded != NULL; blocks without it are emptied at the end of t2_parse.
 static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data_left, bool use_sop, bool use_eph,
-                         std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data)
+                         std::vector<PaddedBlock>& padded, std::vector<uint8_t>& has_data, bool stepped_over)
 {
   const Resolution& R = P.ress[P.tcomps[P.tiles[pc.tile].comps[pc.comp]].res[pc.res]];
   BitBuf bb{ &f, data_left };
@@ -814,6 +814,13 @@ static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data
         const uint32_t nbytes = k.len1 + k.len2;
         if (!nbytes) continue;
         if (!data_left) { k.len1 = k.len2 = 0; continue; }
+        if (stepped_over) {                                             // "no need to read" (:531-541): a seek the file may refuse
+          const size_t before = f.pos;
+          f.seek_cur((int64_t)std::min(nbytes, bb.bytes_left));
+          bb.bytes_left -= (uint32_t)(f.pos - before);
+          k.len1 = k.len2 = 0;
+          continue;
+        }
         const uint32_t want = std::min(nbytes, bb.bytes_left);         // bb_read_chunk (ojph_bitbuffer_read.h:134-150)
         k.offset = f.pos;
         const uint32_t got = (uint32_t)f.skip(want);
@@ -826,7 +833,7 @@ static void parse_packet(Plan& P, const Precinct& pc, RefFile& f, uint32_t& data
   data_left = bb.bytes_left;
 }
 
-static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out);
+static int t2_parse(const uint8_t* d, size_t len, int resilient, const uint32_t* skip, ojphgpu_plan** out);
 
 extern "C" int ojphgpu_plan_padded_blocks(const ojphgpu_plan* plan, ojphgpu_padded_block* out, size_t cap, size_t* count)
 {
@@ -849,7 +856,20 @@ extern "C" int ojphgpu_t2_parse(const uint8_t* d, size_t len, int resilient, ojp
   if (!d || !out) return OJPHGPU_E_INVALID;
   *out = nullptr;
   ojphgpu_plan* made = nullptr;                    // owned here until the parse has succeeded
-  const int rc = no_throw([&] { return t2_parse(d, len, resilient, &made); });
+  const int rc = no_throw([&] { return t2_parse(d, len, resilient, nullptr, &made); });
+  if (rc != OJPHGPU_OK) { return rc; }
+  *out = made;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_t2_parse_restricted(const uint8_t* d, size_t len, int resilient, uint32_t skipped_res_for_data,
+                                           uint32_t skipped_res_for_recon, ojphgpu_plan** out)
+{
+  if (!d || !out) return OJPHGPU_E_INVALID;
+  *out = nullptr;
+  ojphgpu_plan* made = nullptr;
+  const uint32_t skip[2] = { skipped_res_for_data, skipped_res_for_recon };
+  const int rc = no_throw([&] { return t2_parse(d, len, resilient, skip, &made); });
   if (rc != OJPHGPU_OK) { return rc; }
   *out = made;
   return OJPHGPU_OK;
@@ -862,7 +882,7 @@ static int t2_refused(int rc, int line)
   return rc;
 }
 
-static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** out)
+static int t2_parse(const uint8_t* d, size_t len, int resilient, const uint32_t* skip, ojphgpu_plan** out)
 {
   *out = nullptr;
   ojphgpu_params p; memset(&p, 0, sizeof(p));
@@ -1124,6 +1144,16 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
   if (!derive_precision(P)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
   assign_planes(P);
   P.coded.assign(P.blocks.size(), CodedBlock{0, 0, 0, 0, 0});
+  // codestream::restrict_input_resolution between read_headers and read (ojph_codestream_local.cpp:883-900): the tile-parts are
+  // then READ differently -- LRCP / RLCP / RPCL stop at the highest resolution wanted (ojph_tile.cpp:806-848), and a packet of a
+  // resolution its component does not want has its header parsed and its bytes stepped over, not read (ojph_precinct.cpp:531-541)
+  uint32_t skip_read = 0, max_decomps = 0;
+  for (uint32_t c = 0; c < p.num_comps; ++c) max_decomps = std::max(max_decomps, P.style(c).L);
+  if (skip) {
+    const int rr = ojphgpu_plan_restrict_resolution(h, skip[0], skip[1]);
+    if (rr != OJPHGPU_OK) return t2_refused(rr, __LINE__);
+    skip_read = skip[0];
+  }
   // ---- tile-parts: codestream::read (ojph_codestream_local.cpp:912-1113) ----
   // Markers are SEARCHED for (find_marker), not expected: whatever lies between the end of one tile-part and the next 0xFF90 /
   // 0xFFD9 is passed over, and so is anything between the SOT segment and the first marker a tile-part header may hold.  What a
@@ -1186,7 +1216,10 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, ojphgpu_plan** 
             const Tile& T = P.tiles[isot];
             try {
               while (data_left > 0 && next_pkt[isot] < T.packets.size() && !P.no_packets) {
-                parse_packet(P, P.precincts[T.packets[next_pkt[isot]]], f, data_left, use_sop, use_eph, padded, has_data);
+                const Precinct& pc = P.precincts[T.packets[next_pkt[isot]]];
+                if (skip_read && P.p.prog_order <= 2 && pc.res > max_decomps - skip_read) break;   // (resolution-major orders: these are the tail)
+                const bool stepped_over = skip_read && pc.res > P.style(pc.comp).L - skip_read;
+                parse_packet(P, pc, f, data_left, use_sop, use_eph, padded, has_data, stepped_over);
                 ++next_pkt[isot];
               }
             } catch (const PacketThrow&) {

@@ -311,8 +311,15 @@ class Plan:
         return out[:need.value].tobytes()
 
 
-def parse_codestream(data: bytes, resilient=False) -> Plan:
+def parse_codestream(data: bytes, resilient=False, skip=None) -> Plan:
+    """skip = (skipped_res_for_data, skipped_res_for_recon): restrict_input_resolution BEFORE the tile-parts are read, as the
+    reference orders it (ojphgpu_t2_parse_restricted) -- on undamaged codestreams the same as Plan.restrict_resolution afterwards"""
     buf = np.frombuffer(data, dtype=np.uint8)
     h = C.c_void_p()
-    check(capi.lib().ojphgpu_t2_parse(buf.ctypes.data, len(data), int(resilient), C.byref(h)), "t2_parse")
-    return Plan(handle=h)
+    if skip is None:
+        check(capi.lib().ojphgpu_t2_parse(buf.ctypes.data, len(data), int(resilient), C.byref(h)), "t2_parse")
+        return Plan(handle=h)
+    check(capi.lib().ojphgpu_t2_parse_restricted(buf.ctypes.data, len(data), int(resilient), int(skip[0]), int(skip[1]), C.byref(h)), "t2_parse")
+    pl = Plan(handle=h)
+    pl.skip = (int(skip[0]), int(skip[1]))
+    return pl

@@ -256,3 +256,31 @@ def test_damaged_codestreams_against_the_committed_reference_verdicts():
                 # reader goes on (its writer would refuse), this library refuses (the convert kernels take one format for the three)
                 assert name in ("s1_t15", "s1_t51") and got == "raises", "%s: reference %s, here %s" % (key, gold[key][:12], got[:12])
     assert checked == 480 and deviations == 4, (checked, deviations)
+
+
+def test_restricted_reading_follows_the_reference_order(refgen, stream):
+    """ojphgpu_t2_parse_restricted = read_headers, restrict_input_resolution, read: on a whole codestream the same as restricting
+    the parsed plan; on cut and damaged ones the reference's restricted reading (LRCP stops at the highest resolution wanted, the
+    bytes of unwanted packets are stepped over) -- same verdict, same reduced picture"""
+    cs, sots, clean = stream
+    whole = parse_codestream(cs); whole.restrict_resolution(1, 1)
+    early = parse_codestream(cs, skip=(1, 1))
+    a = cp.inverse_stages(whole, cp.decode_blocks(whole, cs)); b = cp.inverse_stages(early, cp.decode_blocks(early, cs))
+    assert np.array_equal(np.asarray(a), np.asarray(b)) and np.array_equal(np.asarray(a), np.asarray(refgen.decode(cs, skip=(1, 1))[0]))
+    parts = [cs[:k] for k in (sots[1] + 5, sots[2] + 13, sots[3] + 40, len(cs) - 30, len(cs) - 3)]
+    dmg = bytearray(cs); dmg[sots[3] + 14] = 0xFF; parts.append(bytes(dmg))          # the unwanted resolution's packet header
+    dmg = bytearray(cs); dmg[sots[1] + 14] = 0xF0; parts.append(bytes(dmg))
+    for part in parts:
+        for skip in ((1, 1), (2, 1), (3, 3)):
+            for resilient in (False, True):
+                try:
+                    want = np.asarray(refgen.decode(part, resilient=resilient, skip=skip)[0])
+                except RuntimeError:
+                    want = None
+                try:
+                    pl = parse_codestream(part, resilient=resilient, skip=skip)
+                    got = np.asarray(cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient)))
+                except (capi.OjphError, RuntimeError):
+                    got = None
+                assert (want is None) == (got is None), (len(part), skip, resilient)
+                assert want is None or np.array_equal(got, want), (len(part), skip, resilient)

@@ -21,20 +21,20 @@ def _limit():     # the worker only: a damaged SIZ may ask for a plan of billion
     resource.setrlimit(resource.RLIMIT_AS, (12 << 30, 12 << 30))
 
 
-def _ref_job(part, resilient):
+def _ref_job(part, resilient, skip=None):
     if "r" not in _REFS:
         _REFS["r"] = refbind.Ref(generic=True)
     try:
-        return ("ok", _REFS["r"].decode(part, resilient=resilient, max_samples=1 << 22)[0])
+        return ("ok", _REFS["r"].decode(part, resilient=resilient, max_samples=1 << 22, skip=skip or (0, 0))[0])
     except refbind.TooLarge:
         return ("large", None)
     except RuntimeError as e:
         return ("raise", str(e))
 
 
-def _our_job(part, resilient):
+def _our_job(part, resilient, skip=None):
     try:
-        pl = parse_codestream(part, resilient=resilient)
+        pl = parse_codestream(part, resilient=resilient, skip=skip)
         if sum(c["w"] * c["h"] for c in (pl.comp_info(i) for i in range(int(pl.params.num_comps)))) > (1 << 22):
             return ("large", None)
         return ("ok", cp.inverse_stages(pl, cp.decode_blocks(pl, part, resilient=resilient)))
@@ -71,7 +71,8 @@ def main(seconds=None, seed=None, header=None, sources=None):
     rng = np.random.default_rng(seed)
     HEADER = header if header is not None else (len(argv) > 3 and argv[3] in ("header", "part2"))
     PART2 = header == "part2" or (header is None and len(argv) > 3 and argv[3] == "part2")
-    guard = Guard() if HEADER else None
+    SKIP = tuple(int(v) for v in os.environ["FUZZ_SKIP"].split(",")) if os.environ.get("FUZZ_SKIP") else None   # "1,1": restrict_input_resolution(1, 1) on both sides
+    guard = Guard() if (HEADER or SKIP) else None
     refs = {True: refbind.Ref(generic=True), False: refbind.Ref(generic=True)}   # (the generic C++ block decoder: the AVX2 one decodes DAMAGED blocks differently from it)
     n = bad = streams = raised = skipped = 0
     while time.time() < t_end and (sources is None or streams < sources):
@@ -100,10 +101,14 @@ def main(seconds=None, seed=None, header=None, sources=None):
         streams += 1
         sots = [i for i in range(first_sot, len(cs) - 14) if cs[i] == 0xFF and cs[i + 1] == 0x90 and cs[i + 2] == 0 and cs[i + 3] == 10 and cs[i + 12] == 0xFF]
         for trial in range(40):
+            if guard is not None and time.time() > t_end:     # (a spinning or crashing reference costs seconds per case)
+                break
             b = bytearray(cs)
             if HEADER:                           # the main header: SOC .. the first SOT marker
                 for _ in range(int(rng.integers(1, 3))):
                     b[int(rng.integers(0, first_sot + 2))] = int(rng.choice([0xFF, 0x00, 0x01, 0x52, 0x90, int(rng.integers(0, 256)), int(rng.integers(0, 256))]))
+            elif SKIP and trial % 4 == 3:        # (restricted reading: cuts as well -- the stepped-over bytes are a seek the file may refuse)
+                b = b[:int(rng.integers(first_sot + 2, len(b)))]
             elif trial % 3 == 2:                 # aimed at the SOT segments (Isot, Psot, TPsot, TNsot) and the SOD behind them
                 at = sots[int(rng.integers(0, len(sots)))]
                 for _ in range(int(rng.integers(1, 3))):
@@ -113,14 +118,14 @@ def main(seconds=None, seed=None, header=None, sources=None):
                     b[int(rng.integers(sod + 2, len(b)))] = int(rng.choice([0xFF, 0x00, 0x90, 0x7F, int(rng.integers(0, 256))]))
             part = bytes(b)
             for resilient in (False, True):
-                if HEADER:                       # (in a worker: the reference can spin on a damaged main header, a plan can ask for all memory)
-                    kind, want = guard.run(_ref_job, (part, resilient))
+                if HEADER or SKIP:               # (in a worker: the reference can spin on a damaged main header, a plan can ask for all memory)
+                    kind, want = guard.run(_ref_job, (part, resilient, SKIP))
                     if kind in ("large", "hang"):
                         skipped += 1
                         continue
                     if kind == "raise":
                         want = None
-                    kind, got = guard.run(_our_job, (part, resilient), 30)
+                    kind, got = guard.run(_our_job, (part, resilient, SKIP), 30)
                     if kind == "hang":
                         print("HANGS here: seed %d, bytes %s" % (seed - 1, [(i, part[i]) for i in range(len(cs)) if cs[i] != part[i]]), flush=True)
                     if kind != "ok":
@@ -144,7 +149,7 @@ def main(seconds=None, seed=None, header=None, sources=None):
                     if os.environ.get("FUZZ_DUMP"):
                         os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
                         open(os.path.join(os.environ["FUZZ_DUMP"], "%d_%d_%d.j2c" % (seed - 1, trial, int(resilient))), "wb").write(part)
-                    diff = [i for i in range(len(cs)) if cs[i] != part[i]]
+                    diff = [i for i in range(min(len(cs), len(part))) if cs[i] != part[i]] + ([len(part)] if len(part) != len(cs) else [])
                     print("DIFFERS: seed %d bytes changed at %s of %d (SOD at %d), resilient=%s: reference %s, here %s  %s" %
                           (seed - 1, diff, len(cs), sod, resilient, "raises" if want is None else "decodes", "raises" if got is None else "decodes", kw), flush=True)
     print("%d damaged codestreams (%d sources; the reference raised on %d; %d set aside: the reference spins or the frame is huge): %d handled differently from the live reference" % (n, streams, raised, skipped, bad))
