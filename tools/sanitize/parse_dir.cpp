@@ -15,9 +15,9 @@ int main(int argc, char** argv) {
       while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) b.insert(b.end(), tmp, tmp + k);
       fclose(f);
       if (b.size() < 4) continue;
-      for (int res = 0; res < 2; ++res) {
+      for (int res = 0; res < 4; ++res) {                 // 2, 3: restricted reading (one resolution dropped)
         ojphgpu_plan* plan = nullptr;
-        int rc = ojphgpu_t2_parse(b.data(), b.size(), res, &plan);
+        int rc = res < 2 ? ojphgpu_t2_parse(b.data(), b.size(), res, &plan) : ojphgpu_t2_parse_restricted(b.data(), b.size(), res & 1, 1, 1, &plan);
         ++n;
         if (rc == 0 && plan) {
           ++ok;
