@@ -122,3 +122,13 @@ def test_damaged_blocks_decode_like_the_reference(refgen):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_blocks_cpu
     assert fuzz_blocks_cpu.main(seconds=6.0, seed=700000) == 0
+
+
+def test_gpu_block_fuzz_tool_bookkeeping():
+    """tools/fuzz_blocks_gpu.py with the oracle in the device's place (FUZZ_BLOCKS_SELFTEST): descriptors, offsets and the comparison
+    of the tool that is to run first on the next GPU visit"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_blocks_gpu.py"), "3"], capture_output=True, text=True,
+                         env=dict(os.environ, FUZZ_BLOCKS_SELFTEST="1"), timeout=300)
+    assert out.returncode == 0 and "0 decoded differently" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
