@@ -403,9 +403,12 @@ int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_blocks, uint3
 /* fourth launch, only needed when some block has num_passes > 1 (foreign codestreams): SigProp +
  * MagRef passes (ojph_block_decoder32.cpp:1318-1609) over the blocks that carry them; step 2 left
  * those blocks as sign-magnitude words, this launch refines and de-quantises them.  Bit 1 of
- * blocks[i].reversible selects the vertically (stripe) causal mode of the code-block style. */
+ * blocks[i].reversible selects the vertically (stripe) causal mode of the code-block style.
+ * d_quad_scratch: the records ojphgpu_ht_decode_step1 wrote -- the significance the passes start from
+ * is the quads' rho bits, as in the reference (:1321-1351), not "the decoded sample is not zero". */
 int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
-                             const uint8_t* d_data, void* d_coef, const uint8_t* d_block_status);
+                             const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
+                             const uint8_t* d_block_status);
 
 typedef struct ojphgpu_convert_desc { /* one tile-component */
   uint64_t plane_off;                /* element offset in the arena */

@@ -207,7 +207,7 @@ SIGNATURES = {
                                           C.c_void_p]),
     "ojphgpu_ht_decode_step2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
-    "ojphgpu_ht_decode_refine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ojphgpu_ht_decode_refine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ojphgpu_decoder_ht_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ojphgpu_convert_forward": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

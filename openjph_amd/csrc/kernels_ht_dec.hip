@@ -115,8 +115,10 @@ __device__ __forceinline__ uint32_t mel_exp(uint32_t k)      // {0,0,0,1,1,1,2,2
 // returns scup or 0
 __device__ __forceinline__ uint32_t check_block(const ojphgpu_cb_desc& d, const uint8_t* cb)
 {
-  // (32-bit path: block_decoder32.cpp:768-789; the 64-bit function has no such test, its p = 62 - missing_msbs must stay >= 2)
-  if (d.num_passes > 3 || d.missing_msbs >= ((d.reversible & 4u) ? 61u : 30u) || d.len1 < 2) return 0;
+  // (32-bit path: block_decoder32.cpp:768-789; the 64-bit function has no such test (:792-827): its p = 62 - missing_msbs
+  // must stay >= 1 for the cleanup pass, >= 2 when refinement passes follow)
+  const uint32_t mm_lim = (d.reversible & 4u) ? ((d.num_passes > 1 && d.len2 > 0) ? 61u : 62u) : 30u;
+  if (d.num_passes > 3 || d.missing_msbs >= mm_lim || d.len1 < 2) return 0;
   const uint32_t lcup = d.len1;
   const uint32_t scup = ((uint32_t)cb[lcup - 1] << 4) + (cb[lcup - 2] & 0xFu);
   if (scup < 2 || scup > lcup || scup > 4079) return 0;
@@ -1559,9 +1561,32 @@ struct BwdBits {            // MagRef: backward from the end, VLC stuffing rule,
   }
 };
 
+// sigma of a block from the records step 1 left in the quad scratch (32-bit records, pair-major: rec + (qy PW + qx / 2)
+// REC_STRIDE + (qx & 1), rho in bits 4..7): the reference fills sigma from the quads' rho bits (:1321-1351), NOT from "the
+// sample is not zero" -- on a damaged VLC segment a quad may call samples of its second column / second row significant
+// where an odd-sized block has no such column / row, and those bits count as neighbours in SigProp and take a bit each in
+// MagRef (their samples do not exist and are never written).  Lane l takes quad columns l, l + 64, ...
+__device__ __forceinline__ void sigma_from_records(const uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH, uint16_t* sigma,
+                                                   uint32_t mstr, int lane)
+{
+  const uint32_t PW = (QW + 1u) >> 1;
+  for (uint32_t qy = 0; qy < QH; ++qy)
+    for (uint32_t qx = (uint32_t)lane; qx < QW; qx += 64u) {
+      const uint32_t rho = (rec[(size_t)(qy * PW + (qx >> 1)) * REC_STRIDE + (qx & 1u)] >> 4) & 0xFu;
+      if (rho == 0u) continue;
+      // the quad's samples (x, y) = (2 qx + (n >> 1), 2 qy + (n & 1)): columns x & 3 in {0, 1} or {2, 3} of group qx / 2,
+      // rows y & 3 in {0, 1} or {2, 3} of stripe qy / 2
+      const uint32_t cb = 2u * (qx & 1u), rb = 2u * (qy & 1u);
+      const uint32_t bits = ((rho & 1u) << (4u * cb + rb)) | (((rho >> 1) & 1u) << (4u * cb + rb + 1u)) |
+                            (((rho >> 2) & 1u) << (4u * cb + 4u + rb)) | (((rho >> 3) & 1u) << (4u * cb + 4u + rb + 1u));
+      const uint32_t e = (qy >> 1) * mstr + (qx >> 1);
+      atomicOr(reinterpret_cast<uint32_t*>(sigma) + (e >> 1), bits << (16u * (e & 1u)));
+    }
+}
+
 __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
-    uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
 {
   __shared__ RefineLds s_wave[RWAVES];
   const int lane = threadIdx.x & 63;
@@ -1581,14 +1606,8 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
   for (uint32_t i = lane; i < PREV_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.prev_row)[i] = 0;
   wave_sync();
   for (uint32_t y = 0; y < H; ++y)
-    for (uint32_t x = lane; x < W; x += 64) {
-      const uint32_t v = plane[(size_t)y * pitch + x];
-      L.smp[y * W + x] = v;
-      if (v) {
-        const uint32_t e = (y >> 2) * (uint32_t)mstr + (x >> 2);
-        atomicOr(reinterpret_cast<uint32_t*>(L.sigma) + (e >> 1), (1u << (4 * (x & 3) + (y & 3))) << (16 * (e & 1)));
-      }
-    }
+    for (uint32_t x = lane; x < W; x += 64) L.smp[y * W + x] = plane[(size_t)y * pitch + x];
+  sigma_from_records(quads + d.scratch_cap, (W + 1u) >> 1, (H + 1u) >> 1, L.sigma, (uint32_t)mstr, lane);
   const uint8_t* seg = data + d.data_off + d.len1;
   const int len2 = (int)d.len2;                              // < 2047 (ojph_precinct.cpp:509)
   for (int i = lane; i < len2 && i < 2048; i += 64) L.bytes[i] = seg[i];
@@ -1646,11 +1665,13 @@ __global__ __launch_bounds__(64 * RWAVES) void ht_dec_refine_kernel(
       BwdBits mrp; mrp.init(L.bytes, len2 < 2048 ? len2 : 2048);
       const uint32_t half = 1u << (p - 2);
       for (int y = 0; y < (int)H; y += 4)
-        for (int x = 0; x < (int)W; ++x) {
+        for (int x = 0; x < 4 * ngroups; ++x) {
           const uint32_t nib = ((uint32_t)L.sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
           for (int r = 0; r < 4; ++r)
-            if (nib & (1u << r))
-              L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((1u - mrp.bit()) << (p - 1)) | half;
+            if (nib & (1u << r)) {
+              const uint32_t sym = mrp.bit();           // (a flagged sample outside the block takes its bit too: :1583-1606)
+              if (x < (int)W && y + r < (int)H) L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((1u - sym) << (p - 1)) | half;
+            }
         }
     }
   }
@@ -1877,7 +1898,7 @@ struct RefineLds64 {
 
 __global__ __launch_bounds__(64) void ht_dec64_refine_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
-    uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, const uint8_t* __restrict__ block_status)
 {
   __shared__ RefineLds64 L;
   const int lane = threadIdx.x & 63;
@@ -1894,14 +1915,8 @@ __global__ __launch_bounds__(64) void ht_dec64_refine_kernel(
   for (uint32_t i = lane; i < PREV_ENTRIES / 2; i += 64) reinterpret_cast<uint32_t*>(L.prev_row)[i] = 0;
   wave_sync();
   for (uint32_t y = 0; y < H; ++y)
-    for (uint32_t x = lane; x < W; x += 64) {
-      const uint64_t v = plane[(size_t)y * pitch + x];
-      L.smp[y * W + x] = v;
-      if (v) {
-        const uint32_t e = (y >> 2) * (uint32_t)mstr + (x >> 2);
-        atomicOr(reinterpret_cast<uint32_t*>(L.sigma) + (e >> 1), (1u << (4 * (x & 3) + (y & 3))) << (16 * (e & 1)));
-      }
-    }
+    for (uint32_t x = lane; x < W; x += 64) L.smp[y * W + x] = plane[(size_t)y * pitch + x];
+  sigma_from_records(quads + d.scratch_cap, (W + 1u) >> 1, (H + 1u) >> 1, L.sigma, (uint32_t)mstr, lane);   // (block_decoder64.cpp:1363-1393)
   const uint8_t* seg = data + d.data_off + d.len1;
   const int len2 = (int)d.len2;
   for (int i = lane; i < len2 && i < 2048; i += 64) L.bytes[i] = seg[i];
@@ -1956,11 +1971,13 @@ __global__ __launch_bounds__(64) void ht_dec64_refine_kernel(
       BwdBits mrp; mrp.init(L.bytes, len2 < 2048 ? len2 : 2048);
       const uint64_t half = 1ull << (p - 2);
       for (int y = 0; y < (int)H; y += 4)
-        for (int x = 0; x < (int)W; ++x) {
+        for (int x = 0; x < 4 * ngroups; ++x) {
           const uint32_t nib = ((uint32_t)L.sigma[(y >> 2) * mstr + (x >> 2)] >> (4 * (x & 3))) & 0xFu;
           for (int r = 0; r < 4; ++r)
-            if (nib & (1u << r))
-              L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((uint64_t)(1u - mrp.bit()) << (p - 1)) | half;
+            if (nib & (1u << r)) {
+              const uint32_t sym = mrp.bit();           // (also for a flagged sample outside the block)
+              if (x < (int)W && y + r < (int)H) L.smp[(uint32_t)(y + r) * W + (uint32_t)x] ^= ((uint64_t)(1u - sym) << (p - 1)) | half;
+            }
         }
     }
   }
@@ -2182,7 +2199,8 @@ int ht_decode64_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n
   hipLaunchKernelGGL(ht_dec64_step2_kernel, dim3((n + W64_WAVES - 1) / W64_WAVES), dim3(64 * W64_WAVES), 0, s, d_blocks, n, d_data,
                      (const uint32_t*)d_aux, (const uint32_t*)d_quad_scratch, (uint32_t*)d_coef, d_block_status);
   if (refine)
-    hipLaunchKernelGGL(ht_dec64_refine_kernel, dim3(n), dim3(64), 0, s, d_blocks, n, d_data, (uint32_t*)d_coef, (const uint8_t*)d_block_status);
+    hipLaunchKernelGGL(ht_dec64_refine_kernel, dim3(n), dim3(64), 0, s, d_blocks, n, d_data, (const uint32_t*)d_quad_scratch, (uint32_t*)d_coef,
+                       (const uint8_t*)d_block_status);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 }  // namespace ojphgpu
@@ -2195,12 +2213,13 @@ extern "C" int ojphgpu_ht_decode_step2(void* stream, const ojphgpu_cb_desc* d_bl
 }
 
 extern "C" int ojphgpu_ht_decode_refine(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n,
-                                         const uint8_t* d_data, void* d_coef, const uint8_t* d_block_status)
+                                         const uint8_t* d_data, const uint32_t* d_quad_scratch, void* d_coef,
+                                         const uint8_t* d_block_status)
 {
   if (n == 0) return OJPHGPU_OK;
-  if (!d_blocks || !d_data || !d_coef || !d_block_status) return OJPHGPU_E_INVALID;
+  if (!d_blocks || !d_data || !d_quad_scratch || !d_coef || !d_block_status) return OJPHGPU_E_INVALID;
   hipLaunchKernelGGL(ht_dec_refine_kernel, dim3((n + RWAVES - 1) / RWAVES), dim3(64 * RWAVES), 0, (hipStream_t)stream,
-                     d_blocks, n, d_data, (uint32_t*)d_coef, d_block_status);
+                     d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
@@ -2211,7 +2230,7 @@ extern "C" int ojphgpu_ht_decode(void* stream, const ojphgpu_cb_desc* d_blocks, 
   int rc = ojphgpu_ht_decode_prep(stream, d_blocks, n, d_data, d_aux);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step1(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_block_status);
   if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_step2(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status);
-  if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_refine(stream, d_blocks, n, d_data, d_coef, d_block_status);
+  if (rc == OJPHGPU_OK) rc = ojphgpu_ht_decode_refine(stream, d_blocks, n, d_data, d_quad_scratch, d_coef, d_block_status);
   // blocks on the 64-bit sample path (descriptor flag; every launch above skipped them)
   if (rc == OJPHGPU_OK) rc = ojphgpu::ht_decode64_launch(stream, d_blocks, n, d_data, d_aux, d_quad_scratch, d_coef, d_block_status, 1);
   return rc;

@@ -104,17 +104,27 @@ __device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v,
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// quantise transfer of one raw coefficient: sign | magnitude, MSB aligned
-__device__ __forceinline__ uint32_t to_sign_mag(uint32_t raw, bool reversible, uint32_t shift, float delta_inv)
+// quantise transfer of one raw coefficient: sign | magnitude, MSB aligned.  A coefficient with more than K_max magnitude
+// bits (Part-2 kernels whose gain outruns the guard bits) leaves the reference's transfer the way its 32-bit arithmetic
+// has it: reversible, |v| << shift drops what does not fit and bit K_max of |v| lands on the sign position
+// (ojph_codestream_gen.cpp:70-76); irreversible, the float -> int conversion of a product beyond 2^31 gives INT_MIN (what
+// cvttss2si and its vector forms return for every out-of-range input, NaN included), i.e. the word 0x80000000: a zero.
+// Either way that bit counts in max_val, and codeblock::encode (ojph_codeblock.cpp:142-175) codes a block whose max_val
+// is not zero even when no sample of it is significant: `over` collects it.
+__device__ __forceinline__ uint32_t to_sign_mag(uint32_t raw, bool reversible, uint32_t shift, float delta_inv, uint32_t& over)
 {
-  int t;
   if (reversible) {
-    int v = (int)raw;
-    uint32_t m = (uint32_t)(v >= 0 ? v : -v) << shift;                   // ojph_codestream_gen.cpp:70-76
+    const int v = (int)raw;
+    const uint32_t m = (v >= 0 ? (uint32_t)v : 0u - (uint32_t)v) << shift;
+    over |= m >> 31;
     return (v >= 0 ? 0u : 0x80000000u) | m;
   }
-  t = (int)__fmul_rn(__uint_as_float(raw), delta_inv);                    // :113-118, C truncation
-  return (t >= 0 ? 0u : 0x80000000u) | (uint32_t)(t >= 0 ? t : -t);
+  const float f = __fmul_rn(__uint_as_float(raw), delta_inv);            // :113-118, C truncation
+  const bool out = !(fabsf(f) < 2147483648.0f);
+  const int t = out ? (int)0x80000000u : (int)f;
+  const uint32_t m = t >= 0 ? (uint32_t)t : 0u - (uint32_t)t;
+  over |= m >> 31;
+  return (t >= 0 ? 0u : 0x80000000u) | m;
 }
 
 __device__ __forceinline__ uint32_t expo(uint32_t val) { return val ? 32u - (uint32_t)__clz((int)(val - 1)) : 0u; }
@@ -239,13 +249,16 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
   uint32_t err = 0, any_sig = 0;
   uint32_t carry_rho = 0;                               // rho of the last quad of the previous step
 
+  uint32_t over = 0;                                    // some magnitude reached the sign position (see to_sign_mag)
   auto sample = [&](int x, int y) -> V {                // quantised sign-magnitude, 0 outside the block
     if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return (V)0;
     if constexpr (S64) {                                // gen_rev_tx_to_cb64
       const long long v = reinterpret_cast<const long long*>(src)[(size_t)y * pitch + x];
-      return (v >= 0 ? 0ull : 0x8000000000000000ull) | ((uint64_t)(v >= 0 ? v : -v) << p);
+      const uint64_t m = (v >= 0 ? (uint64_t)v : 0ull - (uint64_t)v) << p;
+      over |= (uint32_t)(m >> 63);
+      return (v >= 0 ? 0ull : 0x8000000000000000ull) | m;
     } else
-      return to_sign_mag(src[(size_t)y * pitch + x], rev, p, delta_inv);
+      return to_sign_mag(src[(size_t)y * pitch + x], rev, p, delta_inv, over);
   };
 
   for (uint32_t base = 0; base < NP; base += 64) {
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_encode_wide_kernel(
     const bool q0on = active, q1on = has_q1;
     if (!q1on) { uq[1] = 0; for (int nn = 4; nn < 8; ++nn) { msl[nn] = 0; msv[nn] = 0; } }
     if (!q0on) { uq[0] = 0; for (int nn = 0; nn < 4; ++nn) { msl[nn] = 0; msv[nn] = 0; } }
-    any_sig |= (__ballot((rho[0] | rho[1]) != 0 && active) != 0ull) ? 1u : 0u;
+    any_sig |= (__ballot(((rho[0] | rho[1]) != 0 && active) || over != 0u) != 0ull) ? 1u : 0u;
 
     // ---- VLC bits of the pair: cwd(q0) cwd(q1) then the interleaved U-VLC ----
     uint64_t vb = 0; uint32_t vl = 0;                   // (S64: up to 2 x 7 + 2 x (3 + 5 + 4) = 38 bits)
@@ -965,6 +978,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       for (int k = 0; k < 4; ++k) { ntop[k] = active ? ntop[k] : 0u; nbot[k] = bot ? nbot[k] : 0u; }
     }
     uint32_t mu[8], sx[8];                              // sx: a word whose bit 31 is the sample's sign
+    uint32_t nz = 0;                                    // OR of the step's magnitudes (rev: before the mask, bit K_max included)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // quad order: n = 0:(x,y) 1:(x,y+1) 2:(x+1,y) 3:(x+1,y+1)
 #pragma unroll
@@ -975,19 +989,33 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
           const uint32_t a = (uint32_t)(v >= 0 ? v : -v);
           mu[2 * k + j] = a & colm[k];                                        // :70-76, with the same wrap-around when |v| >= 2^K_max:
           sx[2 * k + j] = raw | (a << p);                                     // its top bit lands on the sign
+          nz |= a;                                                            // (clamped loads: every lane holds samples of the block's own rows)
         } else {
           mu[2 * k + j] = (uint32_t)__fmul_rn(fabsf(__uint_as_float(raw)), colf[k]);   // :113-118, C truncation
           sx[2 * k + j] = raw;
+          nz |= mu[2 * k + j];
         }
       }
     }
+    // A magnitude of more than K_max bits (Part-2 kernels whose gain outruns the guard bits; see to_sign_mag): reversible,
+    // the bits above K_max are dropped and bit K_max has landed on the sign; irreversible, the reference's conversion of a
+    // product beyond 2^31 returns INT_MIN -- the sample codes as a zero.  Both leave a bit in the reference's max_val,
+    // and a block with a non-zero max_val is coded even if none of its samples is significant (ojph_codeblock.cpp:142-175).
+    if (__ballot((nz >> K) != 0u) != 0ull) {            // (wave-uniform, and never taken by a Part-1 codestream)
+      any_sig |= (rev ? __ballot(((nz >> K) & 1u) != 0u) != 0ull : true) ? 1u : 0u;
+      if (!rev) {
+        nz = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mu[i] = (mu[i] >> K) ? 0u : mu[i]; nz |= mu[i]; }
+      }
+    }
+    if (rev) nz &= (1u << K) - 1u;                      // = the OR of the mu of the block's samples
     if (step + 1 < nsteps) load_rows(qy + RPS, ntop, nbot); // request the next step's samples now
     if (ABL & 16) { any_sig |= (uint32_t)(__ballot((mu[0] ^ mu[1] ^ mu[2] ^ mu[3] ^ mu[4] ^ mu[5] ^ mu[6] ^ mu[7]) == 0x12345u) != 0ull); continue; }
     // A step without a significant sample, below a step without one: every quad has context 0 and rho 0, i.e. one
     // MEL "0" event and nothing else (no VLC codeword, no U-VLC, no MagSgn bits).  The events are all alike, so only
     // their number matters.  (Smooth content at moderate rates is mostly such steps in the top resolution's sub-bands.)
     {
-      const uint32_t nz = (mu[0] | mu[1]) | (mu[2] | mu[3]) | (mu[4] | mu[5]) | (mu[6] | mu[7]);
       const bool step_sig = __ballot(nz != 0u) != 0ull;
       const bool skip = !step_sig && !prev_sig;
       prev_sig = step_sig;

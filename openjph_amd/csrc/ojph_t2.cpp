@@ -621,6 +621,7 @@ struct Reader {
 // this model of it.
 struct RefFile {
   const uint8_t* d; size_t n, pos;
+  uint64_t scanned = 0;                              // bytes find_marker has looked at (the tile-part loop bounds its searches by it)
   bool eof() const { return pos >= n; }
   size_t avail() const { return n - pos; }
   bool get(uint8_t& b) { if (pos >= n) return false; b = d[pos++]; return true; }
@@ -636,8 +637,10 @@ int find_marker(RefFile& f, const uint8_t* low, int count)
   uint8_t c;
   while (!f.eof()) {
     if (!f.get(c)) return -1;
+    ++f.scanned;
     if (c != 0xFF) continue;
     if (!f.get(c)) return -1;
+    ++f.scanned;
     for (int i = 0; i < count; ++i) if (c == low[i]) return i;
   }
   return -1;
@@ -1166,7 +1169,17 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, const uint32_t*
   RefFile f{ d, len, hf.pos };                                          // read_headers has taken the first SOT marker
   static const uint8_t first_part_markers[11] = { 0x52, 0x53, 0x5C, 0x5D, 0x5E, 0x5F, 0x61, 0x58, 0x64, 0x76, 0x93 };   // COD COC QCD QCC RGN POC PPT PLT COM NLT SOD
   static const uint8_t next_markers[2] = { 0x90, 0xD9 };                // SOT, EOC
+  // The searches are bounded.  A tile-part's end may lie BEFORE the place the search for its SOD stopped (Psot = 12 and
+  // the like): the position moves back and every SOT segment of a crafted file (up to 65535 tiles x 255 parts of them, twelve
+  // bytes each) can send a search over the rest of the file -- the reference reads such a file in quadratic time, a decode
+  // service must not.  A codestream that is merely damaged has each of its bytes searched once or twice; past four times
+  // the file's length (+ 64 KB) reading stops: an error, or -- resilient -- the end of what is read, like a file that ends there.
+  const uint64_t scan_budget = 4ull * (uint64_t)len + 65536ull;
   for (;;) {
+    if (f.scanned > scan_budget) {
+      if (!resilient) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);
+      break;
+    }
     // param_sot::read (ojph_params.cpp:2390-2461)
     bool sot_ok = true;
     uint32_t isot = 0, psot = 0, tpsot = 0, tnsot = 0;

@@ -556,9 +556,20 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi)
 {
   uint64_t max_off = 0, min_off = ~0ull;
-  fi.any_refine = false; fi.max_len1 = 0; fi.kinds = 0;
+  fi.any_refine = false; fi.max_len1 = 0; fi.kinds = 0; fi.pads.clear(); fi.pad_len = 0;
+  // blocks whose tile-part ended before their bytes did: the reference decodes what there is with zeros behind it
+  // (bb_read_chunk, ojph_bitbuffer_read.h:134-150).  `coded` calls them not coded; here they get what the packet header
+  // said and a place of their own behind the uploaded byte range (PadCopy), where the upload puts bytes + zeros.
+  auto padded_of = [&](uint32_t id) -> const Plan::PaddedBlock* {
+    for (const Plan::PaddedBlock& pb : Q.padded) if (pb.block == id) return &pb;
+    return nullptr;
+  };
+  std::vector<std::pair<size_t, const Plan::PaddedBlock*>> padded_at;
   for (size_t i = 0; i < ids.size(); ++i) {
-    const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band]; const CodedBlock& c = Q.coded[ids[i]];   // this frame's own K_max / delta
+    const Block& k = P.blocks[ids[i]]; const Band& B = Q.bands[k.band];
+    const Plan::PaddedBlock* pb = Q.padded.empty() ? nullptr : padded_of(ids[i]);
+    const CodedBlock& c = pb ? pb->hdr : Q.coded[ids[i]];   // this frame's own K_max / delta
+    if (pb) padded_at.emplace_back(i, pb);
     ojphgpu_cb_desc& o = bd[i]; memset(&o, 0, sizeof(o));
     const bool wide = is_wide(Q, B.comp);                  // (same_frame_geometry: the same components as in P)
     o.coef_off = arena_off + P.bands[k.band].plane_off + ((uint64_t)k.r.y0 * B.pitch + k.r.x0) * (wide ? 2u : 1u); o.pitch = B.pitch;
@@ -569,7 +580,7 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8));
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     fi.max_len1 = std::max(fi.max_len1, c.len1);
-    if (c.len1 + c.len2) {
+    if ((c.len1 + c.len2) && !pb) {
       max_off = std::max<uint64_t>(max_off, c.offset + c.len1 + c.len2);
       min_off = std::min<uint64_t>(min_off, c.offset);
     }
@@ -581,6 +592,27 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     if (o.len1 + o.len2) o.data_off = o.data_off - min_off + data_base; else o.data_off = 0;
   }
   fi.first = min_off; fi.len = max_off - min_off;
+  uint64_t at = (fi.len + 63) & ~(uint64_t)63;                          // padded blocks: behind the range, 64 bytes apart at least
+  for (const auto& pp : padded_at) {
+    ojphgpu_cb_desc& o = bd[pp.first]; const Plan::PaddedBlock& pb = *pp.second;
+    const uint32_t total = pb.hdr.len1 + pb.hdr.len2;
+    if (total == 0) continue;
+    at += 64;                                                           // (room below the block: the VLC partner's 16-byte loads)
+    fi.pads.push_back(PadCopy{ pb.hdr.offset, at, std::min(pb.got, total), total });
+    o.data_off = data_base + at;
+    at = (at + total + 63) & ~(uint64_t)63;
+  }
+  fi.pad_len = at - ((fi.len + 63) & ~(uint64_t)63);
+}
+
+int ojphgpu_decoder_upload_pads(hipStream_t s, uint8_t* d_frame_data, const uint8_t* h_codestream, size_t cs_len, const std::vector<PadCopy>& pads)
+{
+  for (const PadCopy& c : pads) {
+    if (c.src + c.got > cs_len) return OJPHGPU_E_INVALID;
+    HIPCHK(hipMemsetAsync(d_frame_data + c.dst - 64, 0, (size_t)c.total + 128, s));     // zeros: the padding, and a margin either side
+    if (c.got) HIPCHK(hipMemcpyAsync(d_frame_data + c.dst, h_codestream + c.src, c.got, hipMemcpyHostToDevice, s));
+  }
+  return OJPHGPU_OK;
 }
 
 static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, int device, void* stream, uint32_t tile_first,
@@ -639,13 +671,14 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   d->nblocks = (uint32_t)(ids.size() * nframes);
   std::vector<ojphgpu_cb_desc> bd(ids.size() * nframes);
   uint64_t nquads = 0, naux = 0, data_total = 0;
-  d->f_first.assign(nframes, 0); d->f_len.assign(nframes, 0); d->f_base.assign(nframes, 0);
+  d->f_first.assign(nframes, 0); d->f_len.assign(nframes, 0); d->f_base.assign(nframes, 0); d->f_pads.assign(nframes, {});
   for (uint32_t f = 0; f < nframes; ++f) {
     DecFrameInfo fi;
     ojphgpu_decoder_fill_descs(P, plans[f]->plan, ids, (uint64_t)f * P.arena_elems, data_total, bd.data() + (size_t)f * ids.size(), fi);
     d->any_refine |= fi.any_refine; d->kinds |= fi.kinds; d->max_len1 = std::max(d->max_len1, fi.max_len1);
     d->f_first[f] = (size_t)fi.first; d->f_len[f] = (size_t)fi.len; d->f_base[f] = (size_t)data_total;
-    data_total += (fi.len + 63) & ~(uint64_t)63;
+    d->f_pads[f] = fi.pads;
+    data_total += fi.data_bytes();
   }
   d->data_first = d->f_first[0];
   d->data_len = (size_t)data_total;
@@ -662,7 +695,7 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
   }
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
-      d->data.alloc(d->data_len + 64) || d->status.alloc(bd.size() + 16))
+      d->data.alloc(d->data_len + 128) || d->status.alloc(bd.size() + 16))
     return bail(OJPHGPU_E_NOMEM);
   if (hipMemset(d->status.p, 0, bd.size() + 16) != hipSuccess) return bail(OJPHGPU_E_HIP);      // (the RETRY word behind the status bytes)
   if (hipMemset(d->arena.p, 0, P.arena_elems * 4 * nframes) != hipSuccess) return bail(OJPHGPU_E_HIP);
@@ -687,7 +720,7 @@ extern "C" int ojphgpu_decoder_upload_frame(ojphgpu_decoder* d, uint32_t frame, 
   if (d->f_len[frame])
     HIPCHK(hipMemcpyAsync((uint8_t*)d->data.p + d->f_base[frame], h_codestream + d->f_first[frame], d->f_len[frame],
                           hipMemcpyHostToDevice, d->stream));
-  return OJPHGPU_OK;
+  return ojphgpu_decoder_upload_pads(d->stream, (uint8_t*)d->data.p + d->f_base[frame], h_codestream, len, d->f_pads[frame]);
 }
 
 // prep + step 1 of every block (one launch each: step 1 costs one serial chain however few blocks it gets)
@@ -727,7 +760,7 @@ static int decode_samples(ojphgpu_decoder* d, hipStream_t s, uint32_t first, uin
   T.end(sp, s);
   if (d->any_refine && (d->kinds & 3)) {
     sp = T.begin(SP_REFINE, s);
-    rc = ojphgpu_ht_decode_refine(s, cbd, count, data, d->arena.p, status);
+    rc = ojphgpu_ht_decode_refine(s, cbd, count, data, (const uint32_t*)d->quads.p, d->arena.p, status);
     if (rc) return rc;
     T.end(sp, s);
   }

@@ -98,9 +98,16 @@ int run_workers(size_t n, F f)
 {
   std::vector<int> rc(n, 0);
   std::vector<std::thread> th;
-  for (size_t k = 1; k < n; ++k) th.emplace_back([&, k] { rc[k] = no_throw([&] { return f(k); }); });
-  rc[0] = no_throw([&] { return f(0); });
+  // (a thread that cannot be created must not take the process down across the C ABI: what was started is joined, the
+  // call fails)
+  bool spawned = true;
+  try {
+    th.reserve(n);
+    for (size_t k = 1; k < n; ++k) th.emplace_back([&, k] { rc[k] = no_throw([&] { return f(k); }); });
+  } catch (...) { spawned = false; }
+  if (spawned) rc[0] = no_throw([&] { return f(0); });
   for (std::thread& t : th) t.join();
+  if (!spawned) return OJPHGPU_E_NOMEM;
   for (int r : rc) if (r) return r;
   return OJPHGPU_OK;
 }
@@ -164,6 +171,7 @@ extern "C" int ojphgpu_multi_encoder_create(const ojphgpu_plan* plan, const int*
         if (B.tile >= W.tiles.first && B.tile - W.tiles.first < W.tiles.count) bound += block_scratch_bytes(b.r.w, b.r.h, B.K_max) + 8;
       }
       bound += (uint64_t)W.tiles.count * P.parts_per_tile * 16;
+      for (uint32_t t = W.tiles.first; t < W.tiles.first + W.tiles.count; ++t) bound += (uint64_t)P.tiles[t].packets.size() * 8;   // (an empty packet is a byte, SOP / EPH six more)
       W.out_cap = (size_t)bound;
       HIPCHK(hipMalloc(&W.d_out, W.out_cap));
     }
@@ -194,7 +202,16 @@ extern "C" int ojphgpu_multi_encode_container(ojphgpu_multi_encoder* m, const vo
     r = container_bits == 16 ? ojphgpu_encoder_run_device16(W.enc, (const uint16_t*)W.d_image)
       : container_bits == 8 ? ojphgpu_encoder_run_device8(W.enc, (const uint8_t*)W.d_image) : ojphgpu_encoder_run_device(W.enc, (const int32_t*)W.d_image);
     if (r) return r;
-    return ojphgpu_encoder_finish_tiles_device(W.enc, (uint8_t*)W.d_out, W.out_cap, &W.len, m->psot.data() + (size_t)W.tiles.first * ppt);
+    r = ojphgpu_encoder_finish_tiles_device(W.enc, (uint8_t*)W.d_out, W.out_cap, &W.len, m->psot.data() + (size_t)W.tiles.first * ppt);
+    if (r == OJPHGPU_E_OVERFLOW && W.len > W.out_cap) {
+      // the bound of _create was short (it is an estimate; E_OVERFLOW of THIS entry point means "the caller's buffer", which
+      // a worker's staging area is not): W.len holds what the run needs -- a larger area, and the assembly once more
+      void* bigger = nullptr;
+      if (hipMalloc(&bigger, W.len + 64) != hipSuccess) { (void)hipGetLastError(); return OJPHGPU_E_NOMEM; }
+      (void)hipFree(W.d_out); W.d_out = bigger; W.out_cap = W.len + 64;
+      r = ojphgpu_encoder_finish_tiles_device(W.enc, (uint8_t*)W.d_out, W.out_cap, &W.len, m->psot.data() + (size_t)W.tiles.first * ppt);
+    }
+    return r == OJPHGPU_E_OVERFLOW ? OJPHGPU_E_INVALID : r;
   });
   if (rc) return rc;
   // 2. the one meeting point: main header from everybody's Psot, a prefix sum of the runs' lengths

@@ -336,6 +336,11 @@ struct ojphgpu_encoder {
 // the device part of an encode: d_image holds the frame in `container`-bit elements (32 / 16)
 int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int container);
 
+// A block the reference decodes from bytes the codestream does not hold (Plan::padded: its tile-part ended early and
+// bb_read_chunk, ojph_bitbuffer_read.h:134-150, handed over zeros for the rest): `got` bytes at `src` of the codestream,
+// then zeros up to `total`, placed at `dst` -- an offset into the frame's part of the device data buffer, BEHIND the byte
+// range that is uploaded as it is.
+struct PadCopy { uint64_t src, dst; uint32_t got, total; };
 struct ojphgpu_decoder {
   const Plan* P = nullptr;
   int device = 0; hipStream_t stream = nullptr;
@@ -363,6 +368,7 @@ struct ojphgpu_decoder {
   bool any_refine = false;                         // some block carries SigProp / MagRef passes
   int kinds = 0;                                   // block kinds of the frame(s), for ht_decode_step2_launch
   std::vector<size_t> f_first, f_len, f_base;      // per frame: codestream byte range uploaded, its place in `data`
+  std::vector<std::vector<PadCopy>> f_pads;        // per frame: blocks uploaded with zeros behind their bytes (PadCopy)
   uint32_t nblocks = 0;                            // code-blocks of the tile range (all frames)
   std::vector<LevelBatch> batches;
   uint32_t conv_max_w = 0, conv_max_h = 0, max_len1 = 0;
@@ -373,7 +379,13 @@ struct ojphgpu_decoder {
   // what a run reads: the object's own buffers (null), or those of a frame pipeline's slot
   const void* o_cb_descs = nullptr; const void* o_data = nullptr; void* o_status = nullptr;
 };
-struct DecFrameInfo { uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0; };   // kinds: see ht_decode_step2_launch; bit 5: blocks on the 64-bit sample path
+struct DecFrameInfo {
+  uint64_t first = 0, len = 0; bool any_refine = false; uint32_t max_len1 = 0; int kinds = 0;   // kinds: see ht_decode_step2_launch; bit 5: blocks on the 64-bit sample path
+  std::vector<PadCopy> pads; uint64_t pad_len = 0;         // padded blocks: their copies, the bytes they take behind `len` (rounded up to 64)
+  uint64_t data_bytes() const { return ((len + 63) & ~(uint64_t)63) + pad_len; }
+};
+// enqueues the copies of a frame's padded blocks (d_frame_data = where the frame's byte range starts in device memory)
+int ojphgpu_decoder_upload_pads(hipStream_t s, uint8_t* d_frame_data, const uint8_t* h_codestream, size_t cs_len, const std::vector<PadCopy>& pads);
 int  ojphgpu_same_frame_geometry(const Plan& P, const Plan& Q, bool compare_blocks);
 void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<uint32_t>& ids, uint64_t arena_off,
                                 uint64_t data_base, ojphgpu_cb_desc* bd, DecFrameInfo& fi);

@@ -484,8 +484,9 @@ static void dec_process_frame(ojphgpu_dec_pipe* p, DecSlot& s)
     if ((naux + 16) * 4 > d->aux.n || (nquads + 16) * 4 > d->quads.n) return OJPHGPU_E_INVALID;     // sized for the worst case at create
     s.t_parse = now_ms() - t0;
     if (fi.first + fi.len > s.cs_len) return OJPHGPU_E_CODESTREAM;
-    if (s.data.reserve((size_t)fi.len + (size_t)fi.len / 4 + 64)) return OJPHGPU_E_NOMEM;
+    if (s.data.reserve((size_t)fi.data_bytes() + (size_t)fi.len / 4 + 128)) return OJPHGPU_E_NOMEM;
     if ((r2 = upload(p->mode, p->s_h2d, s.data.b.p, s.h_cs, (size_t)fi.first, (size_t)fi.len)) != 0) return r2;
+    if ((r2 = ojphgpu_decoder_upload_pads(p->s_h2d, (uint8_t*)s.data.b.p, s.h_cs.p, s.cs_len, fi.pads)) != 0) return r2;   // (damaged codestreams only)
     if ((r2 = upload(p->mode, p->s_h2d, s.cb_descs.p, s.h_descs, 0, nb * sizeof(ojphgpu_cb_desc))) != 0) return r2;
     HIPCHK(hipEventRecord(s.ev_in, p->s_h2d));
     // kernels of the frame on the object's compute stream, then the downloads; `separate`: the repeat a fused launch asked for

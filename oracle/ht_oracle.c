@@ -677,7 +677,9 @@ static int ht_decode_core(const uint8_t* coded, int len1, int len2, int num_pass
   if (!wide) {
     if (missing_msbs >= 30) return 0;                       /* block_decoder32.cpp:768-789 */
     if (missing_msbs == 29 && num_passes > 1) num_passes = 1;
-  } else if (missing_msbs > 60) return 0;                   /* (the reference shifts by a negative count there: nothing to match) */
+  } else if (missing_msbs > 61 || (missing_msbs == 61 && num_passes > 1))
+    return 0;              /* p = 1 decodes with the cleanup pass alone (block_decoder64.cpp:792-827 has no test); the
+                            * refinement passes (3 << (p - 2)) and p = 0 shift by a negative count there: nothing to match */
   int p = 62 - missing_msbs;
   if (len1 < 2) return 0;
   int lcup = len1;

@@ -284,3 +284,24 @@ def test_restricted_reading_follows_the_reference_order(refgen, stream):
                     got = None
                 assert (want is None) == (got is None), (len(part), skip, resilient)
                 assert want is None or np.array_equal(got, want), (len(part), skip, resilient)
+
+
+def test_back_to_back_sot_segments_are_read_in_linear_time():
+    """A crafted file: tens of thousands of SOT segments with Psot = 12 (a tile-part that ends where its payload begins, so
+    the position moves BACK behind every search for an SOD) in front of one SOD far away.  The reference's reader -- and this
+    parser when it followed it to the letter -- takes quadratic time on it (a 10 MB file holds a host thread
+    for hours).  The searches are bounded now: strict reading refuses the file, resilient reading stops where the budget ends."""
+    import time
+    img = synth_image(1, 32, 32, 8, seed=1)
+    cs = bytes(cp.encode(img, bit_depth=8, num_decomps=1)[0])
+    sot = cs.find(b"\xff\x90\x00\x0a")
+    head, body = cs[:sot], cs[sot + 14:]                       # (main header; the tile-part behind its SOT segment and SOD)
+    n = 150000
+    seg = b"\xff\x90\x00\x0a\x00\x00" + (12).to_bytes(4, "big") + b"\x00\x01"
+    crafted = head + seg * n + b"\x00" * 200000 + b"\xff\x93" + body
+    t0 = time.time()
+    with pytest.raises(capi.OjphError):
+        parse_codestream(crafted, resilient=False)
+    pl = parse_codestream(crafted, resilient=True)
+    assert time.time() - t0 < 20.0                             # (unbounded: n searches over ~1 MB each)
+    assert pl.num_blocks > 0

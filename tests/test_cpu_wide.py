@@ -132,3 +132,44 @@ def test_gpu_block_fuzz_tool_bookkeeping():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_blocks_gpu.py"), "3"], capture_output=True, text=True,
                          env=dict(os.environ, FUZZ_BLOCKS_SELFTEST="1"), timeout=300)
     assert out.returncode == 0 and "0 decoded differently" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
+
+
+def test_blocks_without_a_significant_sample_are_coded_like_the_reference(refgen):
+    """What codeblock::encode (ojph_codeblock.cpp:142-175) hands the block coder when only the transfer's overflow made max_val
+    non-zero (a coefficient beyond K_max bits: the reversible shift puts bit K_max on the sign, the irreversible conversion
+    returns 0x80000000): words that are zero or sign-only.  The oracle's coder writes the reference's bytes for them, alone and
+    among ordinary samples -- the case the HIP coders' `over` path (kernels_ht_enc.hip) is compared against on the GPU."""
+    from oracle import oraclebind as ob
+    for (w, h) in [(64, 64), (32, 32), (5, 7), (1, 1), (17, 64), (128, 32)]:
+        for fill in (0, 0x80000000):
+            for mm in (3, 9):
+                st = (w + 7) & ~7
+                buf = np.full((h, st), fill, np.uint32)
+                assert bytes(ob.ht_encode(buf, w, h, st, mm)) == bytes(refgen.encode_block(buf, mm, w, h, st))
+                rng = np.random.default_rng(w * h + mm)
+                for _ in range(3):
+                    buf[rng.integers(0, h), rng.integers(0, w)] = (int(rng.integers(1, 4)) << (30 - mm)) | (0x80000000 if rng.random() < 0.5 else 0)
+                assert bytes(ob.ht_encode(buf, w, h, st, mm)) == bytes(refgen.encode_block(buf, mm, w, h, st))
+
+
+def test_64bit_decoder_with_61_missing_msbs(refgen):
+    """ojph_decode_codeblock64 has no test on missing_msbs (block_decoder64.cpp:792-827): p = 62 - 61 = 1 decodes with the
+    cleanup pass alone; with refinement passes (3 << (p - 2)) there is nothing to match and the oracle refuses"""
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(5)
+    n = 0
+    for it in range(60):
+        w, h = [(64, 64), (32, 32), (5, 7), (3, 3), (17, 20)][it % 5]
+        st, mm = (w + 7) & ~7, 61
+        mag = (rng.random((h, st)) < 0.3).astype(np.uint64)
+        sign = (rng.random((h, st)) < 0.5).astype(np.uint64) << np.uint64(63)
+        buf = ((mag << np.uint64(62 - mm)) | (sign * mag)).astype(np.uint64)
+        cs = bytes(ob.ht_encode64(buf, w, h, st, mm))
+        if not cs:
+            continue
+        ok, d = ob.ht_decode64(cs, w, h, st, mm)
+        ok2, d2 = refgen.decode_block64(cs, mm, w, h, st)
+        assert ok and ok2 and np.array_equal(d[:, :w], d2[:, :w])
+        assert not ob.ht_decode64(cs + b"\x00\x00", w, h, st, mm, len2=2, num_passes=2)[0]
+        n += 1
+    assert n > 40

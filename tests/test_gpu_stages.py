@@ -172,6 +172,72 @@ def test_ht_encode_irreversible_quantisation():
         assert out[o:o + nn].tobytes() == e, "block %d (%d vs %d bytes)" % (i, nn, len(e))
 
 
+def test_ht_encode_coefficients_beyond_K_max():
+    """Coefficients with more magnitude bits than K_max (Part-2 kernels whose gain outruns the guard bits) leave the
+    reference's transfer the way its 32-bit arithmetic has it (ojph_codestream_gen.cpp:59-121): reversible, the bits above
+    K_max are shifted out and bit K_max lands on the sign; irreversible, the conversion of a product beyond 2^31 returns
+    INT_MIN -- a zero.  Either leaves a bit in max_val, and a block with a non-zero max_val is coded even when none of its
+    samples is significant (ojph_codeblock.cpp:142-175).  The narrow and the wide kernel against the oracle's transfer +
+    coder (pinned to the reference on such words: tests/test_cpu_wide.py)."""
+    torch = _torch()
+    from openjph_amd import codec
+    from openjph_amd.csrc_consts import block_scratch_bytes
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(77)
+    shapes = [(64, 64), (32, 32), (37, 50), (64, 17), (5, 7), (128, 32), (16, 16), (63, 63)]
+    trials = []
+    for it in range(96):
+        w, h = shapes[it % len(shapes)]
+        rev = (it // len(shapes)) % 2 == 0
+        kind = (it // (2 * len(shapes))) % 3        # 0: one overflowing sample in an otherwise zero block, 1: a few among ordinary samples, 2: many
+        kmax = int(rng.integers(6, 14))
+        trials.append((w, h, rev, kind, kmax))
+    descs = np.zeros(len(trials), codec.cb_desc_dtype)
+    coefs, expect, off, soff = [], [], 0, 0
+    for i, (w, h, rev, kind, kmax) in enumerate(trials):
+        pitch = (w + 63) & ~63
+        dens = 0.0 if kind == 0 else 0.3
+        mag = (rng.integers(0, 1 << kmax, size=(h, w)) * (rng.random((h, w)) < dens)).astype(np.int64)
+        nover = 1 if kind == 0 else (3 if kind == 1 else max(1, w * h // 6))
+        for _ in range(nover):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            mag[y, x] = (1 << kmax) * int(rng.choice([1, 1, 2, 3, 5, 64])) + int(rng.integers(0, 1 << kmax)) * int(rng.integers(0, 2))
+        sign = rng.integers(0, 2, size=(h, w))
+        v = np.where(sign == 1, -mag, mag)
+        d = descs[i]
+        if rev:
+            plane = np.zeros((h, pitch), np.int32); plane[:, :w] = v
+            q, mx = ob.quant_rev(np.ascontiguousarray(plane[:, :w]), kmax)
+            d["delta"] = 0.0
+            coefs.append(plane.ravel())
+        else:
+            delta = np.float32(2.0 ** -5 * 1.25) / np.float32(1 << (31 - kmax))
+            delta_inv = np.float32(1.0) / np.float32(delta)
+            plane = np.zeros((h, pitch), np.float32)
+            plane[:, :w] = (v.astype(np.float64) * float(np.float32(2.0 ** -5 * 1.25)) * 1.0001).astype(np.float32)
+            if kind == 2:
+                plane[0, 0] = np.float32(np.inf); plane[h - 1, w - 1] = np.float32(-3.0e38)
+            q, mx = ob.quant_irv(np.ascontiguousarray(plane[:, :w]), float(delta_inv))
+            d["delta"] = delta
+            coefs.append(plane.view(np.int32).ravel())
+        expect.append(ob.ht_encode(q, w, h, w, kmax - 1, 0) if mx >= (1 << (31 - kmax)) else b"")
+        d["coef_off"], d["pitch"], d["w"], d["h"] = off, pitch, w, h
+        d["K_max"], d["reversible"] = kmax, 1 if rev else 0
+        d["data_off"], d["scratch_cap"] = soff, block_scratch_bytes(w, h, kmax)
+        off += plane.size; soff += int(d["scratch_cap"])
+    assert sum(1 for e in expect if 0 < len(e) < 24) >= 8          # (the "coded although nothing is significant" blocks are among them)
+    coef = torch.from_numpy(np.concatenate(coefs)).cuda()
+    res, out, status = codec.ht_encode(descs, coef, soff, soff)
+    assert status == 0
+    bad = []
+    for i, e in enumerate(expect):
+        o, n = int(res[i, 0]), int(res[i, 1])
+        g = out[o:o + n].tobytes()
+        if g != e:
+            bad.append((i, trials[i], len(g), len(e)))
+    assert not bad, "HT encode mismatches (idx, (w, h, rev, kind, kmax), got_len, want_len): %s" % bad[:8]
+
+
 def test_ht_decode_vs_oracle():
     torch = _torch()
     from openjph_amd import codec

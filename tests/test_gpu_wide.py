@@ -77,6 +77,42 @@ def test_ht_encode64_vs_oracle():
     assert not bad, "64-bit HT encode mismatches (idx, case, got_len, want_len, first_diff): %s" % bad[:8]
 
 
+def test_ht_encode64_coefficients_beyond_K_max():
+    """gen_rev_tx_to_cb64 (ojph_codestream_gen.cpp:81-100) on |v| >= 2^K_max: the shift drops what does not fit, bit K_max lands
+    on the sign position and counts in max_val -- a block whose only non-zero word is such a sign is coded all the same
+    (ojph_codeblock.cpp:161-172)"""
+    torch = _torch()
+    from openjph_amd import codec
+    from openjph_amd.csrc_consts import block_scratch_bytes
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(65)
+    cases = [(w, h, int(rng.integers(31, 39)), k) for k in range(3) for (w, h) in [(64, 64), (32, 32), (17, 64), (5, 7), (128, 32)]]
+    descs = np.zeros(len(cases), codec.cb_desc_dtype)
+    coefs, expect, off, soff = [], [], 0, 0
+    for i, (w, h, kmax, kind) in enumerate(cases):
+        pitch = (w + 63) & ~63
+        sm, v = wide_block(rng, w, h, kmax, 0.0 if kind == 0 else 0.3, kmax)
+        for _ in range(1 if kind == 0 else 4 if kind == 1 else w * h // 5):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            v[y, x] = ((1 << kmax) * int(rng.choice([1, 1, 3])) + int(rng.integers(0, 1 << 20))) * int(rng.choice([-1, 1]))
+        val = (np.abs(v).astype(np.uint64) << np.uint64(63 - kmax)).astype(np.uint64)
+        sm = (np.where(v < 0, np.uint64(1) << np.uint64(63), np.uint64(0)) | val).astype(np.uint64)
+        plane = np.zeros((h, pitch), np.int64); plane[:, :w] = v
+        coefs.append(plane.ravel())
+        mx = int(np.bitwise_or.reduce(val.ravel()))
+        expect.append(bytes(ob.ht_encode64(sm, w, h, w, kmax - 1, 0)) if mx >= (1 << (63 - kmax)) else b"")
+        d = descs[i]
+        d["coef_off"], d["pitch"], d["w"], d["h"] = 2 * off, pitch, w, h
+        d["K_max"], d["reversible"], d["delta"] = kmax, 1 | 4, 0.0
+        d["data_off"], d["scratch_cap"] = soff, block_scratch_bytes(w, h, kmax)
+        off += plane.size; soff += int(d["scratch_cap"])
+    coef = torch.from_numpy(np.concatenate(coefs)).cuda()
+    res, out, status = codec.ht_encode(descs, coef, soff, soff)
+    assert status == 0
+    bad = [(i, cases[i], int(res[i, 1]), len(e)) for i, e in enumerate(expect) if out[int(res[i, 0]):int(res[i, 0]) + int(res[i, 1])].tobytes() != e]
+    assert not bad, bad[:6]
+
+
 def _decode64_expect(ob, coded, w, h, kmax, len2=0, npass=1, causal=False):
     ok, dec = ob.ht_decode64(coded, w, h, w, kmax - 1, len2=len2, num_passes=npass, stripe_causal=causal)
     if not ok:
@@ -143,6 +179,54 @@ def test_ht_decode64_vs_oracle_incl_corrupt_and_refinement():
         assert np.array_equal(g, want), "trial %d %s: %d samples differ" % (i, trials[i][:3] + trials[i][4:], int((g != want).sum()))
         n_rej += not ok
     assert n_rej >= 1
+
+
+def test_ht_decode64_with_61_missing_msbs():
+    """p = 62 - 61 = 1: ojph_decode_codeblock64 has no test on missing_msbs (block_decoder64.cpp:792-827) and decodes the
+    cleanup pass; with refinement passes behind it (3 << (p - 2)) the block is refused here and by the oracle
+    (tests/test_cpu_wide.py::test_64bit_decoder_with_61_missing_msbs pins the oracle to the reference)"""
+    torch = _torch()
+    from openjph_amd import codec
+    from oracle import oraclebind as ob
+    rng = np.random.default_rng(61)
+    trials = []
+    for it in range(24):
+        w, h = [(64, 64), (32, 32), (5, 7), (3, 3), (17, 20), (128, 32)][it % 6]
+        st, mm = (w + 7) & ~7, 61
+        mag = (rng.random((h, st)) < 0.3).astype(np.uint64)
+        sign = (rng.random((h, st)) < 0.5).astype(np.uint64) << np.uint64(63)
+        buf = ((mag << np.uint64(1)) | (sign * mag)).astype(np.uint64)
+        cs = bytes(ob.ht_encode64(buf, w, h, st, mm))
+        if cs:
+            trials.append((w, h, cs, 0, 1))
+            if it % 4 == 0:
+                trials.append((w, h, cs + b"\x12\x34", 2, 2))     # refinement bytes behind it: refused
+    descs = np.zeros(len(trials), codec.cb_desc_dtype)
+    off = doff = 0
+    expect = []
+    for i, (w, h, t, len2, npass) in enumerate(trials):
+        pitch = (w + 63) & ~63
+        d = descs[i]
+        d["coef_off"], d["pitch"], d["w"], d["h"] = 2 * off, pitch, w, h
+        d["K_max"], d["reversible"], d["missing_msbs"] = 62, 1 | 4, 61
+        d["num_passes"], d["len1"], d["len2"], d["data_off"] = npass, len(t) - len2, len2, doff
+        ok, dec = ob.ht_decode64(t, w, h, (w + 7) & ~7, 61, len2=len2, num_passes=npass)
+        dq = np.zeros((h, w), np.int64)
+        if ok:
+            dec = np.ascontiguousarray(dec[:, :w])
+            ob.lib().ojo_dequant_rev64(dec.ctypes.data, dq.ctypes.data, dec.size, 62)
+        expect.append((ok, dq))
+        off += pitch * h; doff += len(t)
+    coef = torch.full((off + 64,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64).cuda()
+    status = codec.ht_decode(descs, np.frombuffer(b"".join(t[2] for t in trials), np.uint8), coef)
+    got = coef.cpu().numpy()
+    for i, (ok, want) in enumerate(expect):
+        w, h = trials[i][0], trials[i][1]
+        d = descs[i]
+        assert (status[i] == 0) == ok == (trials[i][4] == 1), (i, int(status[i]), ok)
+        g = np.lib.stride_tricks.as_strided(got[int(d["coef_off"]) // 2:], (h, w), (int(d["pitch"]) * 8, 8))
+        assert np.array_equal(g, want), "trial %d: %d samples differ" % (i, int((g != want).sum()))
+        assert not ok or np.any(want)
 
 
 def _layout(shapes, elems):
