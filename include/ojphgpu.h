@@ -35,6 +35,8 @@ extern "C" {
 #define OJPHGPU_E_OVERFLOW     -5   /* output buffer too small; *out_len holds the need       */
 #define OJPHGPU_E_BLOCK        -6   /* a code-block failed to decode (non-resilient mode)     */
 #define OJPHGPU_E_AGAIN        -7   /* a frame pipeline has no free slot: collect a result first */
+#define OJPHGPU_E_UNCOLLECTED  -8   /* ojphgpu_decoder_run_device*: the run BEFORE this one asked to be decoded again (see
+                                     * ojphgpu_decoder_failed_blocks) and was never collected -- its frame was incomplete */
 
 /* ------------------------------------------------------------------------------------------ *
  * 1. Codestream parameters: what ojph::param_siz / param_cod / param_qcd setters carry
@@ -521,7 +523,9 @@ int  ojphgpu_decode16(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t 
  * one-launch block decoder of that run gave up waiting for its own step-1 part (a chip held up for seconds by other
  * work; it marks the run instead of failing blocks), the frame is decoded again here through the separate launches,
  * into the same d_image -- so read d_image after this call, not before.  The reference decides per block at
- * codeblock::decode (ojph_codeblock.cpp:190-224); this is where its verdicts become visible. */
+ * codeblock::decode (ojph_codeblock.cpp:190-224); this is where its verdicts become visible.
+ * A caller that consumes d_image on the device and never collects is told by its NEXT ojphgpu_decoder_run_device* call,
+ * which returns OJPHGPU_E_UNCOLLECTED (once, nothing enqueued) when the run before it had asked for the repeat. */
 int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
 /* how many runs of this decoder were repeated that way (0 in any normal process) */
 int  ojphgpu_decoder_fused_retries(ojphgpu_decoder* dec, uint32_t* count);

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libojphgpu.so")
 
-OK, E_INVALID, E_NOMEM, E_HIP, E_CODESTREAM, E_OVERFLOW, E_BLOCK, E_AGAIN = 0, -1, -2, -3, -4, -5, -6, -7
+OK, E_INVALID, E_NOMEM, E_HIP, E_CODESTREAM, E_OVERFLOW, E_BLOCK, E_AGAIN, E_UNCOLLECTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 PROG_ORDERS = {"LRCP": 0, "RLCP": 1, "RPCL": 2, "PCRL": 3, "CPRL": 4}
 
 
@@ -315,7 +315,8 @@ class OjphError(RuntimeError):
         names = {E_INVALID: "invalid argument / unsupported parameters", E_NOMEM: "out of memory",
                  E_HIP: "HIP runtime error (no GPU?)", E_CODESTREAM: "malformed codestream",
                  E_OVERFLOW: "output buffer too small", E_BLOCK: "error decoding a codeblock",
-                 E_AGAIN: "no free pipeline slot"}
+                 E_AGAIN: "no free pipeline slot",
+                 E_UNCOLLECTED: "the previous run of this decoder asked for a repeat and was never collected"}
         super().__init__("ojph error: %s (%d) %s" % (names.get(code, "?"), code, what))
         self.code = code
 

@@ -45,7 +45,7 @@ bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus);   // one la
 uint32_t ht_decode_fused_grid(uint32_t n, uint32_t cus);  // workgroups of that launch
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
                            void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
-                           uint32_t cus);
+                           uint32_t cus, uint32_t* d_host_retry);
 // the blocks of a range that are on the 64-bit sample path (ojph_decode_codeblock64): all their launches
 uint32_t ht_decode64_extra_aux_words(uint32_t len1);
 int ht_decode64_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_aux,

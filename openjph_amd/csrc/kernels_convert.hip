@@ -93,25 +93,27 @@ __global__ __launch_bounds__(256) void convert_forward_kernel(ConvParams p, cons
   const ConvParams pc = p;                        // launch-wide parameters; p becomes the component's
   uint32_t c_first = 0;                           // components past the colour-transformed triple go the plain way
   if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
-    p = with_fmt(pc, d0);
+    // (the three components share their geometry; each has its own sample format -- the reference converts component by
+    // component, ojph_tile.cpp:332-437, and a codestream whose SIZ gives them different depths is read that way)
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
-    int r = nlt3_map(sample_in<S>(image[at(d0)], p), p), g = nlt3_map(sample_in<S>(image[at(d1)], p), p), b = nlt3_map(sample_in<S>(image[at(d2)], p), p);
+    p = with_fmt(pc, d0);
+    const ConvParams p1 = with_fmt(pc, d1), p2 = with_fmt(pc, d2);
+    int r = nlt3_map(sample_in<S>(image[at(d0)], p), p), g = nlt3_map(sample_in<S>(image[at(d1)], p1), p1), b = nlt3_map(sample_in<S>(image[at(d2)], p2), p2);
     if (p.reversible && p.wide) {
-      const unsigned shift = 0u - (unsigned)level_shift32(p);
-      const long long rr = (int)((unsigned)r + shift), gg = (int)((unsigned)g + shift), bb = (int)((unsigned)b + shift);
+      const long long rr = (int)((unsigned)r - (unsigned)level_shift32(p)), gg = (int)((unsigned)g - (unsigned)level_shift32(p1)),
+                      bb = (int)((unsigned)b - (unsigned)level_shift32(p2));
       plane64(arena, d0)[(size_t)y * d0.pitch + x] = (rr + (gg << 1) + bb) >> 2;
       plane64(arena, d1)[(size_t)y * d1.pitch + x] = bb - gg;
       plane64(arena, d2)[(size_t)y * d2.pitch + x] = rr - gg;
     } else if (p.reversible) {
-      const int shift = p.is_signed ? 0 : -(int)(1u << (p.bit_depth - 1));
-      r += shift; g += shift; b += shift;
+      r -= level_shift32(p); g -= level_shift32(p1); b -= level_shift32(p2);
       int yy = (r + (g << 1) + b) >> 2, cb = b - g, cr = r - g;
       arena[d0.plane_off + (size_t)y * d0.pitch + x] = (uint32_t)yy;
       arena[d1.plane_off + (size_t)y * d1.pitch + x] = (uint32_t)cb;
       arena[d2.plane_off + (size_t)y * d2.pitch + x] = (uint32_t)cr;
     } else {
       const float beta_cb = (float)(0.5 / (1 - (double)ALPHA_BF)), beta_cr = (float)(0.5 / (1 - (double)ALPHA_RF));
-      float rf = to_float(r, p), gf = to_float(g, p), bf = to_float(b, p);
+      float rf = to_float(r, p), gf = to_float(g, p1), bf = to_float(b, p2);
       float yy = __fadd_rn(__fadd_rn(__fmul_rn(ALPHA_RF, rf), __fmul_rn(ALPHA_GF, gf)), __fmul_rn(ALPHA_BF, bf));
       float cb = __fmul_rn(beta_cb, __fsub_rn(bf, yy)), cr = __fmul_rn(beta_cr, __fsub_rn(rf, yy));
       arena[d0.plane_off + (size_t)y * d0.pitch + x] = __float_as_uint(yy);
@@ -155,26 +157,26 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
   const ConvParams pc = p;                        // launch-wide parameters; p becomes the component's
   uint32_t c_first = 0;
   if (pc.color && (c_first = 3, x < d0.w && y < d0.h)) {   // the first three components share geometry and sample format
-    p = with_fmt(pc, d0);
     const ojphgpu_convert_desc d1 = descs[tile * nc + 1], d2 = descs[tile * nc + 2];
+    p = with_fmt(pc, d0);                                    // (each component leaves in its own sample format: ojph_tile.cpp:439-518)
+    const ConvParams p1 = with_fmt(pc, d1), p2 = with_fmt(pc, d2);
     if (p.reversible && p.wide) {
       const long long yy = plane64(arena, d0)[(size_t)y * d0.pitch + x], cb = plane64(arena, d1)[(size_t)y * d1.pitch + x],
                       cr = plane64(arena, d2)[(size_t)y * d2.pitch + x];
       const long long g = yy - ((cb + cr) >> 2);
-      const unsigned shift = (unsigned)level_shift32(p);
-      image[at(d0)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cr + g) + shift), p), p);
-      image[at(d1)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)g + shift), p), p);
-      image[at(d2)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cb + g) + shift), p), p);
+      image[at(d0)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cr + g) + (unsigned)level_shift32(p)), p), p);
+      image[at(d1)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)g + (unsigned)level_shift32(p1)), p1), p1);
+      image[at(d2)] = sample_out<S>(nlt3_map32((int)((unsigned)(int)(cb + g) + (unsigned)level_shift32(p2)), p2), p2);
     }
     uint32_t a = arena[d0.plane_off + (size_t)y * d0.pitch + x];
     uint32_t b = arena[d1.plane_off + (size_t)y * d1.pitch + x];
     uint32_t c = arena[d2.plane_off + (size_t)y * d2.pitch + x];
     if (p.reversible && p.wide) {
     } else if (p.reversible) {
-      const int shift = p.is_signed ? 0 : (int)(1u << (p.bit_depth - 1));
       int yy = (int)a, cb = (int)b, cr = (int)c;
       int g = yy - ((cb + cr) >> 2);
-      image[at(d0)] = sample_out<S>(nlt3_map(cr + g + shift, p), p); image[at(d1)] = sample_out<S>(nlt3_map(g + shift, p), p); image[at(d2)] = sample_out<S>(nlt3_map(cb + g + shift, p), p);
+      image[at(d0)] = sample_out<S>(nlt3_map(cr + g + level_shift32(p), p), p); image[at(d1)] = sample_out<S>(nlt3_map(g + level_shift32(p1), p1), p1);
+      image[at(d2)] = sample_out<S>(nlt3_map(cb + g + level_shift32(p2), p2), p2);
     } else {
       const float g_cb2g = (float)(2.0 * (double)ALPHA_BF * (1.0 - (double)ALPHA_BF) / (double)ALPHA_GF);
       const float g_cr2g = (float)(2.0 * (double)ALPHA_RF * (1.0 - (double)ALPHA_RF) / (double)ALPHA_GF);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void convert_inverse_kernel(ConvParams p, cons
       float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(g_cr2g, cr)), __fmul_rn(g_cb2g, cb));
       float r = __fadd_rn(yy, __fmul_rn(g_cr2r, cr));
       float bb = __fadd_rn(yy, __fmul_rn(g_cb2b, cb));
-      image[at(d0)] = sample_out<S>(nlt3_map(to_int(r, p), p), p); image[at(d1)] = sample_out<S>(nlt3_map(to_int(g, p), p), p); image[at(d2)] = sample_out<S>(nlt3_map(to_int(bb, p), p), p);
+      image[at(d0)] = sample_out<S>(nlt3_map(to_int(r, p), p), p); image[at(d1)] = sample_out<S>(nlt3_map(to_int(g, p1), p1), p1); image[at(d2)] = sample_out<S>(nlt3_map(to_int(bb, p2), p2), p2);
     }
   }
   for (uint32_t c = c_first; c < nc; ++c) {

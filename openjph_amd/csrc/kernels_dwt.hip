@@ -262,10 +262,10 @@ template <> struct Ct<false> {
 
 // NC = 3: the rows of the three colour planes become the rows of Y, Cb, Cr
 template <bool REV, int IMG, int NC, typename E>
-__device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const Conv& cv, Pair<typename Wv<REV>::T>* out)
+__device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const Conv* cv, Pair<typename Wv<REV>::T>* out)
 {
 #pragma unroll
-  for (int k = 0; k < NC; ++k) out[k] = unpack<REV, IMG>(v[k], g, cv);
+  for (int k = 0; k < NC; ++k) out[k] = unpack<REV, IMG>(v[k], g, cv[k]);
   if (NC == 3) {
     const Pair<typename Wv<REV>::T> r = out[0], gg = out[1], b = out[2];
     Ct<REV>::fwd(r.l, gg.l, b.l, out[0].l, out[1].l, out[2].l);
@@ -310,7 +310,6 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   // block-coder launch of the side stream, its wavefronts go first
   __builtin_amdgcn_s_setprio(2);
   const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
-  if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;
@@ -323,9 +322,12 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const int i1 = min(i0 + row_pairs, npy);
 
   const char* src[NC]; T* ll[NC]; T* hl[NC]; T* lh[NC]; T* hh[NC];
+  Conv cvs[NC];                                            // every plane's own sample format (the colour planes of a damaged SIZ may differ: ojph_tile.cpp:332-437)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
+    cvs[k] = cv;
+    if (IMG && dk.reserved) { cvs[k].bit_depth = (int)(dk.reserved & 0xFFu); cvs[k].is_signed = (int)((dk.reserved >> 8) & 1u); }
     src[k] = IMG ? (const char*)image + dk.src_off * sizeof(E) : (const char*)(base + dk.src_off);
     ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
   }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
     if (i0 > 0) return;
     RawRow r0[NC]; Pair<T> x[NC];
     ldrow(0, r0);
-    unpack_all<REV, IMG, NC>(r0, g, cv, x);
+    unpack_all<REV, IMG, NC>(r0, g, cvs, x);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       if (oy != 0) { x[k].l = W::dbl(x[k].l); x[k].h = W::dbl(x[k].h); }
@@ -370,14 +372,14 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   int out_t = 0; bool has_lo = false, has_hi = false;
   RawRow rh[NC], rn[NC];
   ldrow(2 * t0 - oy, rh);
-  unpack_all<REV, IMG, NC>(rh, g, cv, xl);
+  unpack_all<REV, IMG, NC>(rh, g, cvs, xl);
   ldrow(2 * t0 + 1 - oy, rh); ldrow(2 * t0 + 2 - oy, rn);                     // rows of iteration t0
   for (int t = t0; t <= i1; ++t) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) arrived(rh[k].x, rh[k].y, rn[k].x, rn[k].y);
     Pair<T> xh[NC];
-    unpack_all<REV, IMG, NC>(rh, g, cv, xh);
-    unpack_all<REV, IMG, NC>(rn, g, cv, xn);
+    unpack_all<REV, IMG, NC>(rh, g, cvs, xh);
+    unpack_all<REV, IMG, NC>(rn, g, cvs, xn);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
@@ -494,7 +496,7 @@ __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g
 
 // one reconstructed row of all NC planes; NC = 3: Y, Cb, Cr -> R, G, B on the way out
 template <bool REV, int IMG, int NC>
-__device__ __forceinline__ void store_rows(char* const* dst, size_t off, const Geo& g, const Pair<typename Wv<REV>::T>* v, const Conv& cv)
+__device__ __forceinline__ void store_rows(char* const* dst, size_t off, const Geo& g, const Pair<typename Wv<REV>::T>* v, const Conv* cv)
 {
   typedef typename Wv<REV>::T T;
   if (NC == 3) {
@@ -502,12 +504,12 @@ __device__ __forceinline__ void store_rows(char* const* dst, size_t off, const G
     T rl, gl, bl, rh, gh, bh;
     Ct<REV>::inv(v[0].l, v[1].l, v[2].l, rl, gl, bl);
     Ct<REV>::inv(v[0].h, v[1].h, v[2].h, rh, gh, bh);
-    store_image_pair<REV, IMG>(dst[0] + off, g, Cv<REV>::to_image(rl, cv), Cv<REV>::to_image(rh, cv), cv);
-    store_image_pair<REV, IMG>(dst[1] + off, g, Cv<REV>::to_image(gl, cv), Cv<REV>::to_image(gh, cv), cv);
-    store_image_pair<REV, IMG>(dst[2] + off, g, Cv<REV>::to_image(bl, cv), Cv<REV>::to_image(bh, cv), cv);
+    store_image_pair<REV, IMG>(dst[0] + off, g, Cv<REV>::to_image(rl, cv[0]), Cv<REV>::to_image(rh, cv[0]), cv[0]);
+    store_image_pair<REV, IMG>(dst[1] + off, g, Cv<REV>::to_image(gl, cv[1]), Cv<REV>::to_image(gh, cv[1]), cv[1]);
+    store_image_pair<REV, IMG>(dst[2] + off, g, Cv<REV>::to_image(bl, cv[2]), Cv<REV>::to_image(bh, cv[2]), cv[2]);
   } else {
 #pragma unroll
-    for (int k = 0; k < NC; ++k) store_pair<REV, IMG>(dst[k] + off, g, v[k].l, v[k].h, cv);
+    for (int k = 0; k < NC; ++k) store_pair<REV, IMG>(dst[k] + off, g, v[k].l, v[k].h, cv[k]);
   }
 }
 
@@ -525,7 +527,6 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   // block-coder launch of the side stream, its wavefronts go first
   __builtin_amdgcn_s_setprio(2);
   const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
-  if (IMG && d.reserved) { cv.bit_depth = (int)(d.reserved & 0xFFu); cv.is_signed = (int)((d.reserved >> 8) & 1u); }   // the component's own sample format
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
   const int strip_x = blockIdx.x * 4 + wave;
@@ -539,9 +540,12 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
 
   typedef typename ImgElem<IMG, T>::type E;                        // element type of the destination rows
   char* dst[NC]; const T* ll[NC]; const T* hl[NC]; const T* lh[NC]; const T* hh[NC];
+  Conv cvs[NC];                                            // every plane's own sample format (ojph_tile.cpp:439-518 converts component by component)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
+    cvs[k] = cv;
+    if (IMG && dk.reserved) { cvs[k].bit_depth = (int)(dk.reserved & 0xFFu); cvs[k].is_signed = (int)((dk.reserved >> 8) & 1u); }
     dst[k] = IMG ? (char*)image + dk.src_off * sizeof(E) : (char*)(base + dk.src_off);
     ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
   }
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
       horz_synthesis<REV>(x[k].l, x[k].h, g);
       if (oy != 0) { x[k].l = W::halve(x[k].l); x[k].h = W::halve(x[k].h); }
     }
-    store_rows<REV, IMG, NC>(dst, 0, g, x, cv);
+    store_rows<REV, IMG, NC>(dst, 0, g, x, cvs);
     return;
   }
 
@@ -618,9 +622,9 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
         xh[k].h = W::s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
       }
       if (t - 2 >= i0 && t - 2 < i1 && (!CHK || eHpp))
-        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cv);
+        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cvs);
       if (t - 1 >= i0 && t - 1 < i1 && (!CHK || eLp))
-        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cv);
+        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cvs);
     };
     if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * t + 1 - oy < h) lift(std::false_type());
     else lift(std::true_type());

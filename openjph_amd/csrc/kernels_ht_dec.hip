@@ -1296,6 +1296,16 @@ __device__ __forceinline__ uint32_t wait_rows(const uint32_t* flag, uint32_t epo
   }
 }
 
+// "decode this run again through the separate launches": the RETRY word behind the block status array (what whoever collects
+// the run reads), and -- host_retry, a word of host memory the device can write, or null -- the same where the host sees it
+// WITHOUT a copy: a caller that never collects its runs (ojphgpu_decoder_run_device and device-side consumers) is told by
+// its next call (OJPHGPU_E_UNCOLLECTED).  Only ever executed when a wait has run out.
+__device__ __forceinline__ void ask_for_repeat(uint32_t* retry, uint32_t* host_retry, uint32_t epoch)
+{
+  st_agent(retry, epoch);
+  if (host_retry) __hip_atomic_store(host_retry, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // NR: un-stuffing rings per worker wavefront -- 1: one ring, every slice of a block re-un-stuffs from the latest chunk
 // boundary below its first bit; > 1: a ring per block (per_wave <= NR), a slice goes on where the one before stopped.
 template <int TX, int CH, int WGW, int NR>            // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
@@ -1303,7 +1313,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
     uint32_t* __restrict__ fstate, uint32_t n1, uint32_t per_wave, uint32_t max_qh, uint32_t epoch, uint32_t dbg,
-    uint32_t ticket_off, uint32_t wait_ticks)
+    uint32_t ticket_off, uint32_t wait_ticks, uint32_t* __restrict__ host_retry)
 {
   // one LDS area, carved per role: the step-1 role's tables, event strings, VLC rings and mailboxes -- or the workers'
   // un-stuffing rings and block states
@@ -1419,7 +1429,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
           // the chains are resident (tickets), so this is a chip held up for seconds by something else: the run is
           // marked for a repeat through the separate launches and this wavefront stops (what it leaves undecoded is
           // decoded by the repeat)
-          if (lane == 0) st_agent(retry, epoch);
+          if (lane == 0) ask_for_repeat(retry, host_retry, epoch);
           return;
         }
         // The SIMD serves its wavefronts oldest first: of the six workers of a SIMD the one in slot 0 was through at 0.27 ms,
@@ -1499,7 +1509,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
       step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64), sched);
       s_done[lane] = 1u;
-      if (mel.stuck || vlc.stuck) st_agent(retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
+      if (mel.stuck || vlc.stuck) ask_for_repeat(retry, host_retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
     }
   }
   if (chain) publish_rows(flag, epoch, 0xFFFFu, lane);     // every row of every block of this wavefront is complete
@@ -2149,10 +2159,11 @@ bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus)
 // d_state: ht_decode_fused_state_words(n) words, zeroed once, and epoch > 0 growing from launch to launch on it (the
 // ticket counters carry it); d_blocks: the array ojphgpu_ht_decode_layout laid out, from its first element (the
 // 16-bit records of a block are found from its position among the 64 of its chain wavefront); d_block_status: n bytes + the 4-byte RETRY word behind
-// them at the next multiple of 4 (== epoch after the run: a wait ran out, decode the blocks again by the separate launches)
+// them at the next multiple of 4 (== epoch after the run: a wait ran out, decode the blocks again by the separate launches);
+// d_host_retry: null, or the device address of a word of mapped host memory that receives the same epoch (ask_for_repeat)
 int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data, uint32_t* d_quad_scratch,
                            void* d_coef, uint8_t* d_block_status, uint32_t* d_state, uint32_t epoch, uint32_t max_h, int kinds,
-                           uint32_t cus)
+                           uint32_t cus, uint32_t* d_host_retry)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -2168,7 +2179,7 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   const uint32_t ticket_off = (uint32_t)ht_decode_fused_state_words(n) - TICKET_WORDS;   // the ticket counters: behind the flags
   const dim3 grid(n1 + wwgs), wg(64 * wgw);
 #define FUSED_LAUNCH(T, C, W, R) hipLaunchKernelGGL((ht_dec_fused_kernel<T, C, W, R>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
-                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, max_qh, epoch, dbg, ticket_off, wait_ticks)
+                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, max_qh, epoch, dbg, ticket_off, wait_ticks, d_host_retry)
   // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
   static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
   if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }

@@ -35,7 +35,7 @@
 namespace {
 
 struct LiftArgs {
-  const ojphgpu_dwt_desc* descs;
+  const ojphgpu_dwt_desc* descs; uint32_t n;          // the planes of the batch
   uint32_t* base;
   int dir;            // 0: along the rows (horizontal), 1: along the columns (vertical)
   int tgt_high;       // the step updates the high-pass samples (odd canvas coordinates)
@@ -46,12 +46,15 @@ struct LiftArgs {
 template <typename T> __device__ __forceinline__ T* plane(uint32_t* base, uint64_t off) { return reinterpret_cast<T*>(base + off); }
 
 // one lifting step over every plane of the batch
+// (the grid's y and z are capped at 65535: rows and planes beyond that are walked by the same workgroups)
+#define LIFT_FOR_EACH_PLANE_ROW(q, d, x, y)                                                   \
+  for (uint32_t z_ = blockIdx.z; z_ < (q).n; z_ += gridDim.z)                                  \
+    for (uint32_t y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x; y < (q).descs[z_].h; y += gridDim.y) \
+      if (const ojphgpu_dwt_desc& d = (q).descs[z_]; x < d.w)
+
 template <typename T>
-__global__ __launch_bounds__(256) void lift_step_kernel(LiftArgs q)
+__device__ __forceinline__ void lift_step_sample(const LiftArgs& q, const ojphgpu_dwt_desc& d, uint32_t x, uint32_t y)
 {
-  const ojphgpu_dwt_desc d = q.descs[blockIdx.z];
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= d.w || y >= d.h) return;
   const uint32_t n = q.dir ? d.h : d.w, pos = q.dir ? y : x;
   if (n <= 1) return;
   const bool even = (q.dir ? d.y_even : d.x_even) != 0;
@@ -66,22 +69,27 @@ __global__ __launch_bounds__(256) void lift_step_kernel(LiftArgs q)
     const float m = __fmul_rn(q.A, __fadd_rn(lv, rv));
     t = q.synthesis ? __fsub_rn(t, m) : __fadd_rn(t, m);
   } else {
-    const T v = (T)(((T)q.b + (T)q.a * (T)(lv + rv)) >> q.e);
+    // (the shift counts modulo the width of T, as the reference's shifts do on the hosts it runs on and the oracle restates:
+    // an Eatk byte may say anything up to 255)
+    const T v = (T)(((T)q.b + (T)q.a * (T)(lv + rv)) >> (q.e & (int)(8 * sizeof(T) - 1)));
     t = q.synthesis ? (T)(t - v) : (T)(t + v);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lift_step_kernel(LiftArgs q)
+{
+  LIFT_FOR_EACH_PLANE_ROW(q, d, x, y) lift_step_sample<T>(q, d, x, y);
 }
 
 // what surrounds the steps of one direction: the irreversible K scaling (analysis: after the steps, synthesis: before
 // them) and the one-sample sequence at an odd coordinate (doubled / halved); lp_is_high: the horizontal analysis of the
 // reference scales the sub-sequence its `lp` pointer ends on by 1 / K -- the high-pass one after an odd number of steps
-struct ScaleArgs { const ojphgpu_dwt_desc* descs; uint32_t* base; int dir, synthesis, lp_is_high; float K, Kinv; };
+struct ScaleArgs { const ojphgpu_dwt_desc* descs; uint32_t n; uint32_t* base; int dir, synthesis, lp_is_high; float K, Kinv; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void lift_scale_kernel(ScaleArgs q)
+__device__ __forceinline__ void lift_scale_sample(const ScaleArgs& q, const ojphgpu_dwt_desc& d, uint32_t x, uint32_t y)
 {
-  const ojphgpu_dwt_desc d = q.descs[blockIdx.z];
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= d.w || y >= d.h) return;
   const uint32_t n = q.dir ? d.h : d.w, pos = q.dir ? y : x;
   const bool even = (q.dir ? d.y_even : d.x_even) != 0;
   T* p = plane<T>(q.base, d.src_off);
@@ -100,15 +108,18 @@ __global__ __launch_bounds__(256) void lift_scale_kernel(ScaleArgs q)
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void lift_scale_kernel(ScaleArgs q)
+{
+  LIFT_FOR_EACH_PLANE_ROW(q, d, x, y) lift_scale_sample<T>(q, d, x, y);
+}
+
 // plane <-> sub-bands.  horz / vert = 0: the level does not transform that direction, all its samples are "low" there
-struct SplitArgs { const ojphgpu_dwt_desc* descs; uint32_t* base; int horz, vert; };
+struct SplitArgs { const ojphgpu_dwt_desc* descs; uint32_t n; uint32_t* base; int horz, vert; };
 
 template <typename T, bool JOIN>
-__global__ __launch_bounds__(256) void lift_split_kernel(SplitArgs q)
+__device__ __forceinline__ void lift_split_sample(const SplitArgs& q, const ojphgpu_dwt_desc& d, uint32_t x, uint32_t y)
 {
-  const ojphgpu_dwt_desc d = q.descs[blockIdx.z];
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= d.w || y >= d.h) return;
   const bool xh = q.horz && (((x & 1u) == 0u) != (d.x_even != 0));
   const bool yh = q.vert && (((y & 1u) == 0u) != (d.y_even != 0));
   // index inside the sub-sequence: every pair of positions (2k, 2k + 1) holds one sample of each kind, whatever the parity
@@ -122,25 +133,31 @@ __global__ __launch_bounds__(256) void lift_split_kernel(SplitArgs q)
   else band[(size_t)by * pitch + bx] = src[(size_t)y * d.src_pitch + x];
 }
 
+template <typename T, bool JOIN>
+__global__ __launch_bounds__(256) void lift_split_kernel(SplitArgs q)
+{
+  LIFT_FOR_EACH_PLANE_ROW(q, d, x, y) lift_split_sample<T, JOIN>(q, d, x, y);
+}
+
 template <typename T>
 int level(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* descs, uint32_t n, uint32_t max_w, uint32_t max_h,
           void* base, bool synthesis)
 {
-  const dim3 grid((max_w + 255) / 256, max_h, n), wg(256);
+  const dim3 grid((max_w + 255) / 256, max_h < 65535u ? max_h : 65535u, n < 65535u ? n : 65535u), wg(256);   // (the kernels walk what a grid cannot hold)
   const float K = k->K, Kinv = 1.0f / k->K;                    // (1.0f / K in fp32, as gen_irv_horz_ana computes it: host code, no contraction)
   auto steps = [&](int dir) {
     for (uint32_t i = 0; i < k->num_steps; ++i) {
       const uint32_t j = synthesis ? i : k->num_steps - 1u - i;
-      LiftArgs a{ descs, (uint32_t*)base, dir, synthesis ? (int)(i & 1u) : (int)!(i & 1u), synthesis ? 1 : 0,
+      LiftArgs a{ descs, n, (uint32_t*)base, dir, synthesis ? (int)(i & 1u) : (int)!(i & 1u), synthesis ? 1 : 0,
                   k->steps[j].a, k->steps[j].b, k->steps[j].e, k->steps[j].A };
       hipLaunchKernelGGL(lift_step_kernel<T>, grid, wg, 0, s, a);
     }
   };
   auto scale = [&](int dir) {
-    ScaleArgs a{ descs, (uint32_t*)base, dir, synthesis ? 1 : 0, (dir == 0 && !synthesis) ? (int)(k->num_steps & 1u) : 0, K, Kinv };
+    ScaleArgs a{ descs, n, (uint32_t*)base, dir, synthesis ? 1 : 0, (dir == 0 && !synthesis) ? (int)(k->num_steps & 1u) : 0, K, Kinv };
     hipLaunchKernelGGL(lift_scale_kernel<T>, grid, wg, 0, s, a);
   };
-  SplitArgs sp{ descs, (uint32_t*)base, k->horz ? 1 : 0, k->vert ? 1 : 0 };
+  SplitArgs sp{ descs, n, (uint32_t*)base, k->horz ? 1 : 0, k->vert ? 1 : 0 };
   if (!synthesis) {
     if (k->vert) { steps(1); scale(1); }
     if (k->horz) { steps(0); scale(0); }
@@ -158,8 +175,7 @@ int run(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, ui
 {
   if (!k || !d_descs || !d_base || k->num_steps > OJPHGPU_MAX_LIFT_STEPS || k->elem > 2) return OJPHGPU_E_INVALID;
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
-  if (max_h > 65535u || n > 65535u) return OJPHGPU_E_INVALID;             // grid limits (rows and planes per launch)
-  for (uint32_t i = 0; i < k->num_steps; ++i) if (k->elem != 2 && k->steps[i].e > 62) return OJPHGPU_E_INVALID;
+  for (uint32_t i = 0; i < k->num_steps; ++i) if (k->elem != 2 && (k->steps[i].e < 0 || k->steps[i].e > 255)) return OJPHGPU_E_INVALID;   // (an Eatk byte; counted modulo the sample width)
   hipStream_t s = (hipStream_t)stream;
   if (k->elem == 0) return level<int>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
   if (k->elem == 1) return level<long long>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);

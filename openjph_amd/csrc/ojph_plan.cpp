@@ -524,10 +524,14 @@ int build_plan(const ojphgpu_params& pin, Plan& plan)
       if ((g.dx & (g.dx - 1)) || (g.dy & (g.dy - 1)))
         return fail("For RPCL and PCRL progression orders, component downsampling factors have to be powers of 2");
   if (p.color_transform)                                                           // ojph_codestream_local.cpp:586-597
-    for (uint32_t c = 1; c < 3; ++c)
-      if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy ||
-          plan.comps[c].bit_depth != plan.comps[0].bit_depth || plan.comps[c].is_signed != plan.comps[0].is_signed)
-        return fail("the colour transform needs the first three components to have the same sub-sampling, bit depth and signedness");   // ojph_params_local.h:455-490
+    for (uint32_t c = 1; c < 3; ++c) {
+      if (plan.comps[c].dx != plan.comps[0].dx || plan.comps[c].dy != plan.comps[0].dy)
+        return fail("the colour transform needs the first three components to have the same sub-sampling");
+      // bit depth and signedness: the WRITER's test (param_cod::check_validity, ojph_params_local.h:455-490).  The reader
+      // has none: it converts component by component (ojph_tile.cpp:439-518), and so do the kernels here.
+      if (!plan.parsed && (plan.comps[c].bit_depth != plan.comps[0].bit_depth || plan.comps[c].is_signed != plan.comps[0].is_signed))
+        return fail("the colour transform needs the first three components to have the same bit depth and signedness");
+    }
   (void)subsampled;
   // Part 2: the ATK / DFS marker segments (what the reference's reader accepts, ojph_params.cpp:2596-2644, :2770-2866)
   plan.atks.clear(); plan.dfss.clear();

@@ -1099,7 +1099,10 @@ static int t2_parse(const uint8_t* d, size_t len, int resilient, const uint32_t*
           if (!coeff_f(st.A)) return t2_refused(OJPHGPU_E_INVALID, __LINE__);
         }
       }
-      if (a->coeff_type > 3) a->coeff_type = 2;                    // (written again as floats)
+      // an irreversible kernel's coefficients are held as floats whatever type the segment wrote them in (read_coefficient(float)
+      // accepts 8- and 16-bit ones as well): the plan knows float (2) and double (3) only, everything else is written again as floats
+      if (!rev && a->coeff_type != 2 && a->coeff_type != 3) a->coeff_type = 2;
+      if (a->coeff_type > 3) a->coeff_type = 2;
       if (r.pos != next) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);              // "The length of an ATK marker segment is not correct"
     }
     if (r.bad) return t2_refused(OJPHGPU_E_CODESTREAM, __LINE__);                        // a field ran past its segment

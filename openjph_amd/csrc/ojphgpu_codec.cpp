@@ -491,6 +491,7 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
   (void)hipSetDevice(d->device);
   for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads, &d->aux })
     b->release();
+  if (d->h_retry) (void)hipHostFree(d->h_retry);
   if (d->side) (void)hipStreamDestroy(d->side);
   if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
   if (d->ev_join) (void)hipEventDestroy(d->ev_join);
@@ -692,6 +693,11 @@ static int decoder_create(const ojphgpu_plan* const* plans, uint32_t nframes, in
     const size_t fw = (size_t)ojphgpu::ht_decode_fused_state_words((uint32_t)bd.size());
     if (d->fstate.alloc(fw * 4)) return bail(OJPHGPU_E_NOMEM);
     if (hipMemset(d->fstate.p, 0, fw * 4) != hipSuccess) return bail(OJPHGPU_E_HIP);
+    // (a word the launch can reach in host memory: see ojphgpu_decoder::h_retry; without it the notice is simply not given)
+    void* hp = nullptr; void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+      d->h_retry = (uint32_t*)hp; d->d_h_retry = (uint32_t*)dp; *d->h_retry = 0;
+    } else { (void)hipGetLastError(); if (hp) (void)hipHostFree(hp); }
   }
   if (d->arena.alloc(P.arena_elems * 4 * nframes) || d->dwt_descs.alloc(dd.size() * sizeof(dd[0])) ||
       d->img_descs.alloc(idd.size() * sizeof(dd[0])) || d->cb_descs.alloc(bd.size() * sizeof(bd[0])) || d->conv_descs.alloc(cd.size() * sizeof(cd[0])) ||
@@ -782,6 +788,13 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   if (container != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container) return OJPHGPU_E_INVALID;
   hipStream_t s = d->stream;
   Spans& T = d->timer;
+  // the run before this one asked to be decoded again and nobody collected it (ojphgpu_decoder_failed_blocks does): its
+  // frame was handed out partly decoded.  Said once; collecting, or the next run, clears it.  (A frame pipeline's runs
+  // -- o_status set -- are always collected by the pipeline.)
+  if (d->uncollected && !d->o_status && !d->force_separate && d->h_retry && *(volatile uint32_t*)d->h_retry == d->fused_epoch && d->fused_epoch != 0) {
+    d->uncollected = false;
+    return OJPHGPU_E_UNCOLLECTED;
+  }
   T.start(s);
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
   // every block is at most 64 samples wide, of one wavelet and without refinement passes -- and where it pays: blocks
@@ -797,8 +810,9 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     const uint8_t* data = (const uint8_t*)(d->o_data ? d->o_data : d->data.p);
     const int sp = T.begin(SP_STEP2, s);
     rc = ojphgpu::ht_decode_fused_launch(s, cbd, d->nblocks, data, (uint32_t*)d->quads.p, d->arena.p, status, (uint32_t*)d->fstate.p,
-                                         ++d->fused_epoch, d->max_block_h, d->kinds, d->cus);
+                                         ++d->fused_epoch, d->max_block_h, d->kinds, d->cus, d->d_h_retry);
     if (rc) return rc;
+    d->uncollected = true;
     T.end(sp, s);
   } else {
     rc = decode_chains(d, s);
@@ -872,6 +886,7 @@ extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count
   if (!d || !count || !d->ran) return OJPHGPU_E_INVALID;
   const size_t tail = ((size_t)d->nblocks + 3u) & ~(size_t)3u;
   std::vector<uint8_t> st(tail + 4);
+  d->uncollected = false;
   const uint8_t* status = (const uint8_t*)(d->o_status ? d->o_status : d->status.p);
   for (int pass = 0; pass < 2; ++pass) {
     HIPCHK(hipMemcpyAsync(st.data(), status, st.size(), hipMemcpyDeviceToHost, d->stream));

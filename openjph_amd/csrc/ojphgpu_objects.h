@@ -353,6 +353,11 @@ struct ojphgpu_decoder {
   bool last_fused = false, force_separate = false;
   void* last_image = nullptr; int last_container = 0;
   uint32_t fused_retries = 0;                       // runs repeated that way so far
+  // A caller of ojphgpu_decoder_run_device that never collects its runs would never learn that one asked for a repeat: the
+  // fused launch also writes the run's epoch into h_retry -- a word of mapped host memory (d_h_retry: its device address) --
+  // and the next run of this object finds it there (OJPHGPU_E_UNCOLLECTED).  uncollected: a fused run has been enqueued
+  // and nobody has read its verdicts yet.
+  uint32_t* h_retry = nullptr; uint32_t* d_h_retry = nullptr; bool uncollected = false;
   // eight repeats in a row and the object stops using the one launch: a wait that runs out costs seconds, and a chip (or a
   // device layout) on which it keeps running out is better served by the separate launches than by trying again
   uint32_t fused_strikes = 0; bool fused_off = false;

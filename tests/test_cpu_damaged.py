@@ -233,12 +233,13 @@ def test_marker_segments_in_tile_part_headers(refgen, stream):
 def test_damaged_codestreams_against_the_committed_reference_verdicts():
     """tests/golden/damaged.json (made by tests/golden/make_damaged.py with the live reference): 240 damaged codestreams, rebuilt here
     from the oracle pipeline's own encoder, each read with and without resilience -- the reference's "raises" or the digest of
-    its picture.  Holds where /root/reference and oracle/_ref do not exist.  The known deviations are
-    named, not hidden."""
+    its picture.  Holds where /root/reference and oracle/_ref do not exist.  No deviations: the two cases that used to be refused
+    (a SIZ byte gives the colour-transformed components different sample formats; the reference's reader converts component by
+    component, ojph_tile.cpp:439-518) are read since round 5."""
     import json, os
     from tests.damaged_cases import cases, digest
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "damaged.json")))["cases"]
-    checked = deviations = 0
+    checked = 0
     for name, part in cases():
         for resilient in (False, True):
             key = "%s_%d" % (name, int(resilient))
@@ -250,12 +251,8 @@ def test_damaged_codestreams_against_the_committed_reference_verdicts():
             except (capi.OjphError, RuntimeError):
                 got = "raises"
             checked += 1
-            if got != gold[key]:
-                deviations += 1
-                # the two known ones: a SIZ byte gives the colour-transformed components different formats -- the reference's
-                # reader goes on (its writer would refuse), this library refuses (the convert kernels take one format for the three)
-                assert name in ("s1_t15", "s1_t51") and got == "raises", "%s: reference %s, here %s" % (key, gold[key][:12], got[:12])
-    assert checked == 480 and deviations == 4, (checked, deviations)
+            assert got == gold[key], "%s: reference %s, here %s" % (key, gold[key][:12], got[:12])
+    assert checked == 480
 
 
 def test_restricted_reading_follows_the_reference_order(refgen, stream):

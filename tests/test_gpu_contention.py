@@ -119,6 +119,18 @@ for kw, shape in ((dict(bit_depth=8, num_decomps=2), (1, 700, 900)), (dict(bit_d
         d_img = dec.run_device()
         assert dec.failed_blocks() == 0 and np.array_equal(d_img.cpu().numpy(), want), run
     assert dec.fused_retries() == 8, dec.fused_retries()
+    # a caller that never collects: the NEXT run of the object says that the one before it had asked for the repeat
+    import torch
+    from openjph_amd import capi
+    dec = codec.Decoder(cs)
+    dec.run_device(); torch.cuda.synchronize()
+    try:
+        dec.run_device()
+        raise SystemExit("an uncollected repeat went unnoticed")
+    except capi.OjphError as e:
+        assert e.code == capi.E_UNCOLLECTED, e
+    d_img = dec.run_device()                                # said once; this run is enqueued
+    assert dec.failed_blocks() == 0 and np.array_equal(d_img.cpu().numpy(), want)
 print("OK")
 ''' % ROOT
 

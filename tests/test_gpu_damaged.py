@@ -35,7 +35,9 @@ def test_damaged_codestream_reads_like_the_reference(key, streams):
     name, resilient = key[:-2], key.endswith("_1")
     try:
         dec = codec.Decoder(streams[name], resilient=resilient)
-        got = digest(np.asarray(dec.decode()))
+        frame = np.asarray(dec.decode())
+        # (a damaged SIZ may give the components different sizes: the reference's planes one by one, like the committed digest)
+        got = digest(frame if len(dec.plan.frame_shape) == 3 else dec.plan.unpack_frame(frame))
     except (capi.OjphError, RuntimeError):
         got = "raises"
     assert got == GOLD[key], "reference: %s, HIP decoder: %s" % (GOLD[key][:16], got[:16])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The HIP decoder on the damaged codestreams of tests/damaged_cases.py against the live reference's committed verdicts
-(tests/golden/damaged.json): "raises" or the digest of the picture, with and without resilience.  Needs a GPU.  Written when round 4's
-GPU minutes were spent: NOT yet run (expected differences: DESIGN.md section 8 item 9).      python tools/check_damaged_gpu.py"""
+(tests/golden/damaged.json): "raises" or the digest of the picture, with and without resilience.  Needs a GPU
+(tests/test_gpu_damaged.py is the same comparison as -m gpu tests).      python tools/check_damaged_gpu.py"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,8 @@ for name, part in cases():
             continue
         try:
             dec = codec.Decoder(part, resilient=resilient)
-            got = digest(np.asarray(dec.decode()))          # (the four sources have components of one size: one (nc, h, w) array, like the reference's)
+            frame = np.asarray(dec.decode())
+            got = digest(frame if len(dec.plan.frame_shape) == 3 else dec.plan.unpack_frame(frame))   # (a damaged SIZ may give the components different sizes)
         except (capi.OjphError, RuntimeError):
             got = "raises"
         n += 1
