@@ -55,7 +55,11 @@ void build_ht_tables(HtTables& t)
       const unsigned e = t.dec_vlc[k][i], rho = (e >> 4) & 15u, e1 = (e >> 8) & 15u, ek = (e >> 12) & 15u;
       unsigned packed = (rho & (rho - 1u)) ? 0x100u : 0u;
       for (int s = 0; s < 4; ++s) packed |= (((rho >> s) & 1u) + ((ek >> s) & 1u) + ((e1 >> s) & 1u)) << (2 * s);
-      t.dec_vlc32[k][i] = e | (packed << 16);
+      // bits 8..10 (e_1 / e_k live in the upper half here): what the CHAIN derives from rho for its next look-ups, ready made --
+      // bit 8 = a significant sample in the quad's right column (rho bits 2 | 3: the next quad's context bit 8 in rows below
+      // the first), bits 9, 10 = its bottom-row samples (rho bits 1, 3: the row below's neighbourhood)
+      const unsigned chain = (((rho >> 2) | (rho >> 3)) & 1u) << 8 | ((rho >> 1) & 1u) << 9 | ((rho >> 3) & 1u) << 10;
+      t.dec_vlc32[k][i] = (e & 0xFFu) | chain | (packed << 16);
     }
   }
   // U-VLC prefix (T.814 table 3), indexed by the next 3 stream bits:

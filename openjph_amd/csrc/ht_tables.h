@@ -13,7 +13,8 @@ namespace ojphgpu {
 struct HtTables {
   uint16_t enc_vlc[2][2048];   // [(c_q << 8) | (rho << 4) | eps] -> (cwd << 8) | (len << 4) | e_k
   uint16_t dec_vlc[2][1024];   // [(c_q << 7) | 7 bits] -> e_k<<12 | e_1<<8 | rho<<4 | u_off<<3 | len
-  // the same entries with, in the upper half, what step 2 needs of them in 9 bits (the fused launch's 16-bit records):
+  // the fused launch's table: bits 0..7 as above; bits 8..10 what the chain needs next, derived from rho (ht_tables.cpp);
+  // and in the upper half what step 2 needs of the entry in 9 bits (the fused launch's 16-bit records):
   // bits 16 + 2i, 17 + 2i: sample i of the quad -- 0 insignificant, 1 significant, 2 significant with its e_k bit, 3 with
   // e_k and e_1 (e_1 is a subset of e_k, e_k of rho in every row of the standard's tables); bit 24: more than one sample
   // significant (gamma of T.814, block_decoder32.cpp:1218)
@@ -35,7 +36,8 @@ namespace ojphgpu {
 // ojphgpu_ht_encode with the caller's knowledge of which block widths the range holds (kernels_ht_enc.hip)
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
-                     int widths, const uint32_t* d_regions, uint32_t nreg);   // regions: see claim_output (kernels_ht_enc.hip)
+                     int widths, const uint32_t* d_regions, uint32_t nreg,    // regions: see claim_output (kernels_ht_enc.hip)
+                     uint32_t* d_tickets);                                    // persistent workgroups: see ht_encode_kernel
 // ojphgpu_ht_decode_step2 with the caller's knowledge of the blocks of the range (kernels_ht_dec.hip)
 // step 1 + step 2 in one launch (kernels_ht_dec.hip, ht_dec_fused_kernel): chains first, step-2 workers behind them
 bool dec_fuses();

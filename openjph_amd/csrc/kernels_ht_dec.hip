@@ -68,6 +68,9 @@ namespace {
 constexpr int WAVES = 4;
 constexpr uint32_t RING_WORDS = 256;          // step 2: 8 Kbit of un-stuffed MagSgn per wavefront (>= 4160 + 2048 + 32 in flight)
 constexpr uint32_t RING_MASK = RING_WORDS - 1;
+// The ring is followed by COPIES of its first two words (every writer of word 0 / 1 writes word 256 / 257 as well): a row
+// reads three consecutive words from wi & RING_MASK on without wrapping each index (three address computations less per row)
+constexpr uint32_t RING_ALLOC = RING_WORDS + 2;
 constexpr uint32_t ROW_BITS_MAX = 64 * 2 * 32; // a quad row of 64 columns consumes at most this many bits
 constexpr uint32_t EXP_BYTES = 1024 + 8;      // wide blocks (> 64 columns): exponent row in LDS
 
@@ -86,6 +89,7 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value into a scalar register
 
 // wave64 inclusive prefix sum with DPP adds (row shifts inside 16-lane rows, then row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
@@ -100,9 +104,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
   return (uint32_t)x;
 }
 // value of lane-1 / lane+1 (0 at the ends); quad_perm swap of lanes 2k <-> 2k+1
-__device__ __forceinline__ uint32_t from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
-__device__ __forceinline__ uint32_t from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
-__device__ __forceinline__ uint32_t from_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }  // quad_perm:[1,0,3,2]
+// (bound_ctrl: a lane without a source reads 0 -- no register has to be cleared for the "old" value first, and a max / add
+// of the result folds into the DPP instruction)
+__device__ __forceinline__ uint32_t from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t from_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }  // quad_perm:[1,0,3,2]
 
 __device__ __forceinline__ uint32_t mel_exp(uint32_t k)      // {0,0,0,1,1,1,2,2,2,3,3,4,5}
 {
@@ -521,7 +527,8 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       }
       tleft = t1;
       if (NARROW) {
-        const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
+        const uint32_t nib = FUSED ? (((t0 >> 9) & 3u) | ((t1 >> 7) & 0xCu))
+                                   : (((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u));
         sig_cur |= (uint64_t)nib << (2u * qx);
       }
       uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
@@ -576,14 +583,16 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       }
       // both look-ups and their MEL corrections as selects, no branches (the second quad of an odd-width block's last
       // pair does not exist: its look-up is made all the same and dropped)
-      const uint32_t c_q0 = ((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1) | k0;           // :1022
+      // (FUSED: the table's entries carry "a significant sample in the right column" ready made in bit 8, and the bottom
+      // row's two significance bits in bits 9, 10 -- ht_tables.cpp)
+      const uint32_t c_q0 = FUSED ? ((tleft & 0x100u) | k0) : (((tleft & 0x40u) << 2) | ((tleft & 0x80u) << 1) | k0);           // :1022
       uint32_t t0 = tbl[c_q0 + (v & 0x7Fu)];
       const bool z0 = c_q0 == 0;
       t0 = (z0 & ((evq & 1u) == 0)) ? 0u : t0;
       ecnt = z0 ? 1u : 0u;
       v >>= (t0 & 7u); used += t0 & 7u;
       const bool ex1 = qx + 1 < QW;
-      const uint32_t c_q1 = ((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1) | k1;                 // :1059
+      const uint32_t c_q1 = FUSED ? ((t0 & 0x100u) | k1) : (((t0 & 0x40u) << 2) | ((t0 & 0x80u) << 1) | k1);                 // :1059
       uint32_t t1 = tbl[c_q1 + (v & 0x7Fu)];
       const bool z1 = ex1 & (c_q1 == 0);
       t1 = ((!ex1) | (z1 & (((evq >> ecnt) & 1u) == 0))) ? 0u : t1;
@@ -591,7 +600,8 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       v >>= (t1 & 7u); used += t1 & 7u;
       tleft = t1;
       if (NARROW) {
-        const uint32_t nib = ((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u);
+        const uint32_t nib = FUSED ? (((t0 >> 9) & 3u) | ((t1 >> 7) & 0xCu))
+                                   : (((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u));
         sig_cur |= (uint64_t)nib << (2u * qx);
       }
       // the pair's U-VLC by arithmetic instead of the uvlc_tbl1 look-up (:1065-1085): one LDS round trip less on the chain
@@ -907,9 +917,10 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
 __device__ __forceinline__ uint32_t dequantise(uint32_t val, bool rev, uint32_t shift, float delta)
 {
   const uint32_t mag = val & 0x7FFFFFFFu;
-  if (rev) { const int iv = (int)(mag >> shift); return (uint32_t)((val >> 31) ? -iv : iv); }
-  const float fv = __fmul_rn((float)mag, delta);
-  return __float_as_uint((val >> 31) ? -fv : fv);
+  if (rev) { const uint32_t iv = mag >> shift, sg = (uint32_t)((int)val >> 31); return (iv ^ sg) - sg; }   // -iv for a set sign
+  // (the product of two non-negative floats has a clear sign bit: OR-ing the sample's sign in negates it, -0.0f for a zero
+  // magnitude included -- as "-fv" does)
+  return __float_as_uint(__fmul_rn((float)mag, delta)) | (val & 0x80000000u);
 }
 
 // does the block carry SigProp / MagRef passes that will be decoded (block_decoder32.cpp:752-789)?
@@ -992,8 +1003,10 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   // the records of ALL its quad rows (they are complete: the chain has published them) -- one round trip per slice where
   // a record fetched one row ahead made it one per row (an agent-scope load takes longer than a row's arithmetic).
   if (KEEP && prepare && check_block(d, cb) == 0u) return;    // (step 1 fails this block; its slices stop at the verdict)
-  const uint32_t st = (KEEP && prepare) ? 0u : SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi];
-  const uint32_t len_b1 = cb[lcup - 1], len_b2 = cb[lcup >= 2u ? lcup - 2u : 0u];   // (a one-byte segment has failed in step 1; its bytes are not used)
+  // (what every lane reads from one address is kept as what it is, a scalar: comparisons and sums of such values then run
+  // on the scalar unit, beside the vector instructions of another wavefront)
+  const uint32_t st = (KEEP && prepare) ? 0u : rdfirst(SLICED ? (uint32_t)__hip_atomic_load(block_status + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)block_status[bi]);
+  const uint32_t len_b1 = rdfirst(cb[lcup - 1]), len_b2 = rdfirst(cb[lcup >= 2u ? lcup - 2u : 0u]);   // (a one-byte segment has failed in step 1; its bytes are not used)
   uint32_t ents[SLICED ? S2_ROWS : 1u];
   if (SLICED && !(KEEP && prepare)) {                                              // 16-bit records, [row][quarter][block] (flush_row16)
     const uint16_t* r16 = reinterpret_cast<const uint16_t*>(quads + rec16_base(d, bi) + (size_t)qy_begin * (64u * REC16_ROW_WORDS) + ((uint32_t)lane >> 4) * 256u)
@@ -1015,7 +1028,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   const bool wide = WD == 1 ? false : W > 64;
 
   if (!KEEP || prepare)
-    for (uint32_t i = lane; i < RING_WORDS; i += 64) ring[i] = 0;
+    for (uint32_t i = lane; i < RING_ALLOC; i += 64) ring[i] = 0;
   if (wide) for (uint32_t i = lane; i < 2 * EXP_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(s_exp_w)[i] = 0;
   wave_sync();
 
@@ -1029,21 +1042,22 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       hs[0] = src_pos; hd[0] = dst_bits;
     }
     const uint32_t wb = (dst_bits + 31u) >> 5;               // words above the current partial word are stale
-    ring[(wb + (uint32_t)lane) & RING_MASK] = 0;
-    if (lane < 2) ring[(wb + 64u + (uint32_t)lane) & RING_MASK] = 0;
+    {
+      const uint32_t z0 = (wb + (uint32_t)lane) & RING_MASK;
+      ring[z0] = 0;
+      if (z0 < 2u) ring[z0 + RING_WORDS] = 0;                // (the copies, see RING_ALLOC)
+      if (lane < 2) { const uint32_t z1 = (wb + 64u + (uint32_t)lane) & RING_MASK; ring[z1] = 0; if (z1 < 2u) ring[z1 + RING_WORDS] = 0; }
+    }
     wave_sync();
     const uint32_t i0 = src_pos + 4u * (uint32_t)lane;
     uint32_t val = 0, nb = 0;
+    // the lane's four bytes (i0 is a multiple of 4; the bytes behind the MagSgn part -- MEL, VLC, the next block, or the slack
+    // every data buffer ends with -- are read along and masked) and the four before them: the neighbour lane's, by a DPP
+    // move; lane 0 fetches its own
+    const uint32_t word = i0 < ms_len ? load_u32_unaligned(cb + i0) : 0u;
+    uint32_t pw = from_prev(word);
+    if (lane == 0) pw = i0 ? load_u32_unaligned(cb + i0 - 4) : 0u;
     if (i0 < ms_len) {
-      // the lane's four bytes and the four before them (i0 is a multiple of 4)
-      const uint32_t pw = i0 ? load_u32_unaligned(cb + i0 - 4) : 0u;
-      uint32_t word;
-      if (i0 + 4 <= ms_len) word = load_u32_unaligned(cb + i0);
-      else {
-        word = cb[i0];
-        if (i0 + 1 < ms_len) word |= (uint32_t)cb[i0 + 1] << 8;
-        if (i0 + 2 < ms_len) word |= (uint32_t)cb[i0 + 2] << 16;
-      }
       const uint32_t cnt = min(4u, ms_len - i0);
       const uint32_t valid = cnt == 4u ? 0xFFFFFFFFu : (1u << (8u * cnt)) - 1u;
       // all four bytes at once: byte k of P / P2 is the raw byte k-1 / k-2 of the stream
@@ -1063,8 +1077,10 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
     const uint32_t pos = dst_bits + incl - nb;
     if (nb) {
       const uint32_t w = pos >> 5, sh = pos & 31;
-      atomicOr(&ring[w & RING_MASK], val << sh);
-      if (sh + nb > 32) atomicOr(&ring[(w + 1) & RING_MASK], val >> (32 - sh));
+      const uint32_t wa = w & RING_MASK, wb2 = (w + 1) & RING_MASK;
+      atomicOr(&ring[wa], val << sh);
+      if (wa < 2u) atomicOr(&ring[wa + RING_WORDS], val << sh);
+      if (sh + nb > 32) { atomicOr(&ring[wb2], val >> (32 - sh)); if (wb2 < 2u) atomicOr(&ring[wb2 + RING_WORDS], val >> (32 - sh)); }
     }
     dst_bits += rdlane(incl, 63);
     src_pos += 256;
@@ -1085,9 +1101,9 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
     return;
   }
   if (SLICED && (KEEP || qy_begin > 0)) {                // take over where the previous slice's worker stopped
-    if (state[19] != 0u) return;
+    if (rdfirst(state[19]) != 0u) return;
     e_prev = (state[(uint32_t)lane >> 2] >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
-    mpos = state[16]; src_pos = state[17]; dst_bits = state[18];
+    mpos = rdfirst(state[16]); src_pos = rdfirst(state[17]); dst_bits = rdfirst(state[18]);
     hs[0] = src_pos; hd[0] = dst_bits;
   }
   uint32_t ent_next = 0;
@@ -1098,7 +1114,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   for (uint32_t qy = qy_begin; qy < qy_last && !bad; ++qy) {
     const uint8_t* vexp = s_exp_w + (qy & 1) * EXP_BYTES;   // wide blocks: exponents of the sample row above (+1 offset)
     uint8_t* vnew = s_exp_w + ((qy & 1) ^ 1) * EXP_BYTES;
-    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+    for (uint32_t c0 = 0; c0 < (WD == 1 ? 1u : W); c0 += 64) {   // (WD 1: one pass, col = lane -- known at compile time)
       while (src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)(ROW_BITS_MAX + 64u)) unstuff_chunk();   // (a resumed slice starts below mpos)
       const bool exhausted = src_pos >= ms_len;            // then bits at and beyond dst_bits read as 1 (:609-632)
       const uint32_t col = c0 + (uint32_t)lane;
@@ -1122,17 +1138,18 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
         if (!SLICED) gamma &= gamma - 0x10u;                                            // :1218
         uint32_t em;                      // max exponent over columns 2qx-1 .. 2qx+2 of the sample row above
         if (!wide) {
-          const uint32_t pm = max(e_prev, from_pair(e_prev));
+          // even lane 2k: max(e[2k-1], e[2k]); odd lane 2k+1: max(e[2k+1], e[2k+2]); then the pair's two halves together
           const uint32_t e_nx = from_next(e_prev), e_pv = from_prev(e_prev);   // both moves run with every lane enabled
-          const uint32_t side = half ? e_nx : e_pv;
-          em = max(pm, max(side, from_pair(side)));
+          const uint32_t hm = max(e_prev, half ? e_nx : e_pv);
+          em = max(hm, from_pair(hm));
         } else {
           const uint32_t b = 2 * qx;
           em = act ? max(max((uint32_t)vexp[b], (uint32_t)vexp[b + 1]), max((uint32_t)vexp[b + 2], (uint32_t)vexp[b + 3])) : 0u;
         }
         U_q += gamma ? max(em, 1u) : 1u;                                                // :1219-1223
       }
-      if (__ballot(act && U_q > mmsbp2) != 0ull) { bad = true; break; }                 // :1114,:1224
+      // (an idle lane's record is 0: its U_q is 0 or 1, never above missing_msbs + 2 >= 2 -- no "act &&" needed)
+      if (__ballot(U_q > mmsbp2) != 0ull) { bad = true; break; }                        // :1114,:1224
       // this lane's samples: n0 = (col, 2qy), n1 = (col, 2qy+1); quad bits 2*half and 2*half+1
       // sg*: the sample is significant, ek* / eb*: its e_k / e_1 bit
       const uint32_t sel = SLICED ? inf >> (4u * half) : inf >> (2u * half);
@@ -1147,7 +1164,8 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       const uint32_t at = mpos + incl - tot;
       mpos += rdlane(incl, 63);
       const uint32_t wi = at >> 5, sh = at & 31;
-      const uint32_t w0 = ring[wi & RING_MASK], w1 = ring[(wi + 1) & RING_MASK], w2 = ring[(wi + 2) & RING_MASK];
+      const uint32_t* rw = ring + (wi & RING_MASK);
+      const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];           // (rw[1], rw[2] may be the copies behind the ring)
       uint64_t win = (uint64_t)__funnelshift_r(w0, w1, sh) | ((uint64_t)__funnelshift_r(w1, w2, sh) << 32);
       if (exhausted) {
         if (at >= dst_bits) win = ~0ull;
@@ -1164,7 +1182,7 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
         out0 = raw_out ? val : dequantise(val, rev, shift, delta);
       }
       {
-        const uint32_t ms_val = (uint32_t)(win >> m0);
+        const uint32_t ms_val = __builtin_amdgcn_alignbit((uint32_t)(win >> 32), (uint32_t)win, m0);   // (uint32_t)(win >> m0): m0 <= U_q <= 31
         uint32_t v_n = ms_val & ((1u << m1) - 1u);
         v_n |= eb1 << m1;
         v_n |= 1u;
@@ -1180,11 +1198,18 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
       // step's stores are issued: loads and stores share one in-order counter on gfx9, so a wait placed after the
       // stores (where the compiler puts it: at the loop top) would also wait for the stores to reach L2.
       if (!SLICED) asm volatile("" : "+v"(ent_next));
-      if (act) {
+#ifndef S2_ABL
+#define S2_ABL 0                  // attribution experiments (never in the product): 1 the sample stores only happen for a value that never occurs
+#endif
+      if (act && (!(S2_ABL & 1) || (out0 ^ out1) == 0x9E3779B9u)) {
         const uint32_t y = 2 * qy;
-        uint32_t* o = dst + (size_t)y * pitch + col;
-        o[0] = out0;
-        if (y + 1 < H) o[pitch] = out1;
+        // (a scalar row address + the lane's 32-bit byte offset: the store takes them as they are, no 64-bit vector add)
+        char* rowp = reinterpret_cast<char*>(dst + (size_t)y * pitch);
+        char* rowp1 = rowp + (size_t)pitch * 4u;
+        uint32_t coff = col * 4u;
+        asm volatile("" : "+v"(coff));                 // (kept a 32-bit offset HERE: hoisted out of the loop it becomes a 64-bit vector add per store)
+        *reinterpret_cast<uint32_t*>(rowp + coff) = out0;
+        if (y + 1 < H) { asm volatile("" : "+v"(coff)); *reinterpret_cast<uint32_t*>(rowp1 + coff) = out1; }
       }
     }
     if (wide) wave_sync();
@@ -1211,7 +1236,7 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
 {
-  __shared__ uint32_t s_ring[WAVES][RING_WORDS];
+  __shared__ uint32_t s_ring[WAVES][RING_ALLOC];
   __shared__ uint8_t s_exp[WAVES][2][EXP_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
@@ -1320,7 +1345,7 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
   constexpr uint32_t EV_OFF = 2048 + 160, VR_OFF = EV_OFF + CH * EV_RING * 64, CTL_OFF = VR_OFF + CH * VR_WORDS * 64;
   constexpr uint32_t REC_OFF = CTL_OFF + CH * 5 * 64;                       // a row of pair words per chain wavefront (flush_row16)
   constexpr uint32_t CHAIN_WORDS = REC_OFF + CH * REC16_ROW_WORDS * 64;
-  constexpr uint32_t WORKER_WORDS = NR * RING_WORDS + S2_MAX_PER_WAVE * S2_STATE_WORDS;
+  constexpr uint32_t WORKER_WORDS = NR * RING_ALLOC + S2_MAX_PER_WAVE * S2_STATE_WORDS;
   constexpr uint32_t LDS_WORDS = CHAIN_WORDS > WGW * WORKER_WORDS ? CHAIN_WORDS : WGW * WORKER_WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDS_WORDS];
   uint32_t* const s_vlc = s_mem;                            // dec_vlc32: 2 x 1024 entries
@@ -1385,8 +1410,8 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
       for (uint32_t k = 0; k < nb; ++k) {
         const uint32_t bi = wave_no + k * nwaves;
         const ojphgpu_cb_desc d = blocks[bi];
-        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, wlds + k * RING_WORDS, nullptr, (int)lane, 0u, 0u,
-                                           wlds + NR * RING_WORDS + k * S2_STATE_WORDS, true);
+        step2_block<TX, 1, true, (NR > 1)>(d, bi, data, quads, coef, block_status, wlds + k * RING_ALLOC, nullptr, (int)lane, 0u, 0u,
+                                           wlds + NR * RING_ALLOC + k * S2_STATE_WORDS, true);
       }
 #ifdef FUSED_TIMELINE
     uint32_t* tl = g_tl + (size_t)((n1 * (uint32_t)WGW + wave_no) & 8191u) * 12u;
@@ -1409,8 +1434,8 @@ __global__ __launch_bounds__(64 * WGW) void ht_dec_fused_kernel(
         if (d.w == 0 || d.h == 0) continue;
         const uint32_t QH = ((uint32_t)d.h + 1) >> 1;
         if (q0 >= QH) continue;
-        uint32_t* ring = wlds + (NR > 1 ? k : 0u) * RING_WORDS;
-        uint32_t* state = wlds + NR * RING_WORDS + k * S2_STATE_WORDS;
+        uint32_t* ring = wlds + (NR > 1 ? k : 0u) * RING_ALLOC;
+        uint32_t* state = wlds + NR * RING_ALLOC + k * S2_STATE_WORDS;
         const uint32_t need = q1 < QH ? q1 : QH;
         bool there = true;
         const uint32_t fl = rdlane(flv, (int)k);
