@@ -46,6 +46,18 @@ WORKLOADS = {
     "c1_256_gray_8b_rev53": (256, 256, 1, 8, True, False, -1.0, (0, 0)),
     # BASELINE config #5: independent 4K 10-bit frames coded as a batch (--frames B per step and per GPU)
     "c5_4k_444_10b_irv97_batch": (3840, 2160, 3, 10, False, False, -1.0, (0, 0)),
+    # SURVEY.md section 8(f) N4 -- the paths only deep or Part-2 codestreams take, so that they have a number too:
+    # 32-bit samples (more than 32 bits of precision: the reference's 64-bit sample path, int64 planes, ojph_encode_codeblock64 /
+    # ojph_decode_codeblock64, the general lifting kernels)
+    "c6_4k_gray_32b_rev53": (3840, 2160, 1, 32, True, False, -1.0, (0, 0)),
+    # the 9/7 written as an ATK marker segment (four float lifting steps + K): the same arithmetic as c3 / c5 through the
+    # general lifting kernels -- decodes to the plain 9/7's samples bit for bit (tests/test_gpu_part2.py)
+    "c7_4k_444_12b_atk97": (3840, 2160, 3, 12, False, False, 0.001, (0, 0)),
+}
+ATK97 = {2: dict(steps=[0.443506852043971, 0.882911075530934, -0.052980118572961, -1.586134342059924], K=1.230174104914001)}
+WORKLOAD_EXTRA = {          # what a workload needs beyond the tuple: make_params keywords, the sample container it exists in
+    "c6_4k_gray_32b_rev53": dict(container=32),
+    "c7_4k_444_12b_atk97": dict(params=dict(atk=ATK97, wavelet=2)),
 }
 
 
@@ -61,13 +73,17 @@ def workload_image(name, seed_offset=0, frame=0):
         return synth.survey_c4(seed=1234 + seed_offset)
     if name.startswith("c5"):
         return synth.survey_c5(frame=frame, seed=1234 + seed_offset)
+    if name.startswith("c6"):
+        return synth.survey_c6(seed=1234 + seed_offset)
+    if name.startswith("c7"):
+        return synth.survey_c7(seed=1234 + seed_offset)
     return synth.c1_image()
 
 
-def dwt_alg_bytes(nsamples, levels, container=32):
-    """each level reads its input once and writes its four sub-bands once, 4-byte elements; the image
-    side of the top level moves container / 8 bytes per sample"""
-    return 8.0 * nsamples * sum(4.0 ** -l for l in range(levels)) - (4.0 - container / 8.0) * nsamples * (1 if levels else 0)
+def dwt_alg_bytes(nsamples, levels, container=32, elem=4):
+    """each level reads its input once and writes its four sub-bands once, `elem`-byte elements (4; 8 on the 64-bit sample
+    path); the image side of the top level moves container / 8 bytes per sample"""
+    return 2.0 * elem * nsamples * sum(4.0 ** -l for l in range(levels)) - (elem - container / 8.0) * nsamples * (1 if levels else 0)
 
 
 def plan_is_tiled(tile):
@@ -168,6 +184,9 @@ def main():
     from openjph_amd.plan import make_params
 
     w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[args.workload]
+    extra = WORKLOAD_EXTRA.get(args.workload, {})
+    if "container" in extra:
+        args.container = extra["container"]
     frames = args.frames if args.frames > 0 else (8 if "batch" in args.workload else 1)
     nsamples = w * h * nc * frames
     if frames > 1:
@@ -177,7 +196,7 @@ def main():
     def to_dev(a):                               # the frame as it sits in HBM
         return torch.from_numpy(a.astype({8: np.int8, 16: np.int16}[args.container]) if args.container != 32 else a).to(dev)
     d_img = to_dev(img)
-    params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile)
+    params = make_params(w, h, nc, bit_depth=bd, reversible=rev, color_transform=ct, qstep=qstep, tile=tile, **extra.get("params", {}))
     from openjph_amd.plan import Plan
     from openjph_amd import shard
     plan = Plan(params)
@@ -292,12 +311,15 @@ def main():
         for k, v in acc.items():
             acc[k] = [x / reps for x in v] if isinstance(v, list) else v / reps
     ns = nsamples_rank
+    # bytes of a working sample: 4 (int32 / float planes); 8 on the reference's 64-bit sample path (components of more than
+    # 32 bits of precision: int64 planes) -- the algorithmic bytes of 8(d) with that element size
+    elem = 8.0 if any(plan.comp_style(c)["wide"] for c in range(nc)) else 4.0
     kernels = {
-        "dwt_forward(all levels)": (dwt_alg_bytes(ns, levels, args.container), te["dwt_ms"]),
-        "dwt_forward(level 1)": ((4.0 + args.container / 8.0) * ns, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
-        "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels, args.container), td["dwt_ms"]),
-        "dwt_inverse(level 1)": ((4.0 + args.container / 8.0) * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
-        "ht_encode": ((4.0 + c_rate) * ns, te["ht_ms"]),            # all launches of the block encoder (sum)
+        "dwt_forward(all levels)": (dwt_alg_bytes(ns, levels, args.container, elem), te["dwt_ms"]),
+        "dwt_forward(level 1)": ((elem + args.container / 8.0) * ns, te["dwt_levels_ms"][0] if te["dwt_levels_ms"] else 0.0),
+        "dwt_inverse(all levels)": (dwt_alg_bytes(ns, levels, args.container, elem), td["dwt_ms"]),
+        "dwt_inverse(level 1)": ((elem + args.container / 8.0) * ns, td["dwt_levels_ms"][-1] if td["dwt_levels_ms"] else 0.0),
+        "ht_encode": ((elem + c_rate) * ns, te["ht_ms"]),           # all launches of the block encoder (sum)
         # block decoder, SURVEY.md section 8(d): it reads the c N coded bytes and writes the 4 N coefficient bytes -- (c + 4) N
         # for the whole decoder.  Split by launch: step 1 reads the MEL / VLC share of the coded bytes (about a fifth), step 2
         # the MagSgn share and writes the coefficients.  The per-quad records step 1 hands to step 2 (4 bytes per quad = 1 byte
@@ -305,7 +327,7 @@ def main():
         # real traffic, not algorithmic -- reported next to the algorithmic figure, never inside it.
         "ht_dec_prep": (0.0, td["ht_prep_ms"]),
         "ht_dec_step1": (0.2 * c_rate * ns, td["ht_step1_ms"]),
-        "ht_dec_step2": ((0.8 * c_rate + 4.0) * ns, td["ht_step2_ms"]),
+        "ht_dec_step2": ((0.8 * c_rate + elem) * ns, td["ht_step2_ms"]),
     }
     intermediate = {"ht_dec_prep": 0.8 * c_rate * ns, "ht_dec_step1": 1.0 * ns, "ht_dec_step2": 1.0 * ns}
     if td["ht_step1_ms"] == 0.0 and td["ht_prep_ms"] < 0.02 and td["ht_step2_ms"] > 0:
@@ -330,11 +352,11 @@ def main():
         area = np.array([int(b["w"]) * int(b["h"]) for b in pl.blocks], dtype=np.float64)
         coded = (cb["len1"].astype(np.float64) + cb["len2"])
         del kernels["ht_encode"]
-        kernels["ht_encode[top resolution, side stream]"] = (4.0 * area[top].sum() + coded[top].sum(), te["ht_launches_ms"][0])
-        kernels["ht_encode[lower resolutions]"] = (4.0 * area[~top].sum() + coded[~top].sum(), te["ht_launches_ms"][1])
+        kernels["ht_encode[top resolution, side stream]"] = (elem * area[top].sum() + coded[top].sum(), te["ht_launches_ms"][0])
+        kernels["ht_encode[lower resolutions]"] = (elem * area[~top].sum() + coded[~top].sum(), te["ht_launches_ms"][1])
     if te["convert_ms"] > 0 or td["convert_ms"] > 0:   # otherwise the conversion (and the colour transform) is fused into the top DWT level
-        kernels["convert_forward"] = ((4.0 + args.container / 8.0) * ns, te["convert_ms"])
-        kernels["convert_inverse"] = ((4.0 + args.container / 8.0) * ns, td["convert_ms"])
+        kernels["convert_forward"] = ((elem + args.container / 8.0) * ns, te["convert_ms"])
+        kernels["convert_inverse"] = ((elem + args.container / 8.0) * ns, td["convert_ms"])
     kinfo = {}
     for k, (b, ms) in kernels.items():
         kinfo[k] = {"ms": round(ms, 4), "alg_GB": round(b / 1e9, 4), "GBps": round(b / 1e6 / ms, 1) if ms > 0 else None}
@@ -443,13 +465,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "per_rank_ms_per_step": per_rank_ms,
         "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
-        "dtype": "i32" if rev else "f32", "data": "synthetic",
+        "dtype": ("i64" if elem == 8 else "i32") if rev else "f32", "data": "synthetic",
         "value_covers": "device-resident step: samples in HBM -> convert + DWT + quantise + HT block encode -> coded block bytes in HBM, "
                         "then those bytes -> HT block decode + inverse DWT + convert -> samples in HBM; PCIe and host Tier-2 are "
                         "outside (e2e_steady_Msamples_s has them inside)",
         "e2e_steady_Msamples_s": ({k: v["Msamples_s"] for k, v in e2e.items() if isinstance(v, dict) and "Msamples_s" in v} if e2e and "error" not in e2e else None),
         "config": {"workload": args.workload, "width": w, "height": h, "components": nc, "bit_depth": bd,
-                   "wavelet": "5/3 reversible" if rev else "9/7 irreversible", "qstep": qstep if not rev else None,
+                   "wavelet": ("5/3 reversible" if rev else "9/7 irreversible") + (" as an ATK marker segment (general lifting kernels)" if "params" in extra else "")
+                              + (", 64-bit sample path" if elem == 8 else ""), "qstep": qstep if not rev else None,
                    "decomps": levels, "block": [int(params.block_w), int(params.block_h)],
                    "tile": list(tile), "frames_per_step": frames * (1 if tiled else world),
                    "sharding": ("%d tiles per GPU of one frame" % my_tiles[1]) if tiled else "one frame per GPU (replicas)",
@@ -948,6 +971,9 @@ def cpu_baseline(img, bd, rev, ct, qstep, tile, reps):
         best_e = min(best_e, t1 - t0); best_d = min(best_d, t2 - t1)
     n = img.size
     out = {"value": round(n / (best_e + best_d) / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+           "note": "ATK workloads: the reference has no ATK writer; timed is its plain 9/7 on the same frame -- every wavelet of the "
+                   "reference runs through the one general lifting path (ojph_transform.cpp:209-852), so this IS the arithmetic an ATK "
+                   "codestream of these steps costs it",
             "covers": "the whole library call: sample conversion + DWT + block coder + its Tier-2 and memory-file I/O "
                       "(compare with e2e_steady_Msamples_s; `value` is the device-resident step without Tier-2 / PCIe)",
             "sample": "the full %dx%dx%d frame, best of %d (encode %.3f s, decode %.3f s; simd level %d; host has %d cpus)"

@@ -36,8 +36,7 @@ namespace ojphgpu {
 // ojphgpu_ht_encode with the caller's knowledge of which block widths the range holds (kernels_ht_enc.hip)
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
-                     int widths, const uint32_t* d_regions, uint32_t nreg,    // regions: see claim_output (kernels_ht_enc.hip)
-                     uint32_t* d_tickets);                                    // persistent workgroups: see ht_encode_kernel
+                     int widths, const uint32_t* d_regions, uint32_t nreg);   // regions: see claim_output (kernels_ht_enc.hip)
 // ojphgpu_ht_decode_step2 with the caller's knowledge of the blocks of the range (kernels_ht_dec.hip)
 // step 1 + step 2 in one launch (kernels_ht_dec.hip, ht_dec_fused_kernel): chains first, step-2 workers behind them
 bool dec_fuses();

@@ -692,30 +692,24 @@ __device__ __forceinline__ void mel_stuff(const uint32_t* raw, uint32_t total_bi
 // LOGP: a step covers 2^LOGP quad pairs across (lane & (2^LOGP - 1)) by 64 / 2^LOGP quad rows down.  4 = the layout
 // described above (blocks up to 64 columns, 4 quad rows per step); 3 = blocks up to 32 columns (the 32 x 32 blocks of
 // the IMF profile), 8 quad rows per step -- with the 16-pair layout half of the lanes of such a block would idle.
-// PERSISTENT WORKGROUPS (ticket != null): the launch has as many workgroups as the chip holds at once, and a workgroup
-// codes group after group of NWAVES blocks -- its first group is its own index, every further one a number taken from
-// `ticket` (a counter the host cleared; one atomic per GROUP, requested while the group before is being coded, so nobody
-// waits for it and the counter's memory channel sees a quarter of the rate claim_output's cursors are spread out for).
-// What a workgroup pays once instead of once per four blocks: its dispatch, the 8 KB of tables into LDS, the barrier behind
-// them.  ticket == null: one group per workgroup, as launched by the stage entry point of the C ABI.
 template <bool REV, int LOGP>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES_PER_EU, 8))) void ht_encode_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint32_t* __restrict__ coef,
     uint8_t* __restrict__ scratch, uint8_t* __restrict__ out, uint32_t out_cap,
     ojphgpu_cb_result* __restrict__ results, uint32_t* __restrict__ cursor, uint32_t* __restrict__ status,
-    const uint32_t* __restrict__ regions, uint32_t nreg, uint32_t* __restrict__ ticket)
+    const uint32_t* __restrict__ regions, uint32_t nreg)
 {
   __shared__ uint16_t s_vlc[2][2048];
   __shared__ uint32_t s_uvlc[64];                   // U-VLC codewords of u = 0..63 (u <= 31 here), see uvlc_word
   __shared__ NarrowLds s_wave[NWAVES];
-  __shared__ uint32_t s_next[2];                    // the group a persistent workgroup codes next (double-buffered across its barrier)
   for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&s_vlc[0][0])[i] = (&ojphgpu::g_enc_vlc[0][0])[i];
   if (threadIdx.x < 64) s_uvlc[threadIdx.x] = uvlc_word(threadIdx.x);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  auto code_block = [&](const uint32_t bi) {          // one code-block by this wavefront (a `return` = this block is done)
+  const uint32_t bi = blockIdx.x * NWAVES + wave;
+  if (bi >= n) return;
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
   constexpr uint32_t PPR = 1u << LOGP, RPS = 64u >> LOGP;                 // quad pairs per row of a step, quad rows per step
@@ -1341,21 +1335,6 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     results[bi].offset = off; results[bi].length = total;
     if (err) atomicOr(status, 1u);
   }
-  };   // code_block
-
-  const uint32_t ngroups = (n + (uint32_t)NWAVES - 1u) / (uint32_t)NWAVES;
-  uint32_t grp = blockIdx.x;
-  for (uint32_t it = 0;; ++it) {
-    uint32_t nx = 0;
-    if (ticket && threadIdx.x == 0) nx = gridDim.x + atomicAdd(ticket, 1u);   // (looked at behind the block: the atomic's round trip is not waited for)
-    const uint32_t bi = grp * (uint32_t)NWAVES + (uint32_t)wave;
-    if (grp < ngroups && bi < n) code_block(bi);
-    if (!ticket) break;
-    if (threadIdx.x == 0) s_next[it & 1u] = nx;
-    __syncthreads();
-    grp = rdfirst(s_next[it & 1u]);
-    if (grp >= ngroups) break;
-  }
 }
 
 }  // namespace
@@ -1366,11 +1345,9 @@ namespace ojphgpu {
 // up to 64 samples is wider than 32 (they take the 8-pairs-by-8-rows layout); bit 5 = it holds blocks of 64-bit samples
 // (cb_desc.reversible bit 2).  Every kernel skips the blocks of the other kind, so a caller that does not know passes
 // 3 | 32 (wavelet bits clear = both).
-// d_tickets: null, or two zeroed words (one per wavelet's launch of the narrow kernel) in a cache line of their own:
-// the narrow kernels then run as persistent workgroups (see ht_encode_kernel)
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
-                     int widths, const uint32_t* d_regions, uint32_t nreg, uint32_t* d_tickets)
+                     int widths, const uint32_t* d_regions, uint32_t nreg)
 {
   if (n == 0) return OJPHGPU_OK;
   if (ensure_tables() != 0) return OJPHGPU_E_HIP;
@@ -1380,32 +1357,19 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   if ((widths & 12) == 0) widths |= 12;                   // the caller does not know the wavelets: both instantiations
   // timing experiment: dynamic LDS nobody uses lowers the workgroups per CU (OJPHGPU_ENC_LDS_BALLAST bytes)
   static const unsigned ballast = [] { const char* e = getenv("OJPHGPU_ENC_LDS_BALLAST"); const long v = e ? atol(e) : 0; return v > 0 && v < 100000 ? (unsigned)v : 0u; }();
-  // persistent workgroups: as many as the chip holds at once (NWG_PER_CU per compute unit); fewer groups than that: one each
-  static const bool persistent = [] { const char* e = getenv("OJPHGPU_ENC_PERSISTENT"); return !e || atoi(e) != 0; }();
-  const uint32_t ngroups = (n + NWAVES - 1) / NWAVES;
-  uint32_t resident = 0;
-  if (d_tickets && persistent) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-    static uint32_t cus_of[64] = { 0 };
-    if (dev >= 0 && dev < 64 && cus_of[dev] == 0) cus_of[dev] = device_cus(dev);
-    resident = (dev >= 0 && dev < 64 ? cus_of[dev] : 256u) * (uint32_t)NWG_PER_CU;
-  }
-  const bool pers = resident != 0 && ngroups > resident;
-  uint32_t* const t_rev = pers ? d_tickets : nullptr; uint32_t* const t_irv = pers ? d_tickets + 1 : nullptr;
-  const dim3 ngrid(pers ? resident : ngroups);
+  const dim3 ngrid((n + NWAVES - 1) / NWAVES);
   if ((widths & 1) && (widths & 4) && (widths & 16))
     hipLaunchKernelGGL((ht_encode_kernel<true, 3>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg, t_rev);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   else if ((widths & 1) && (widths & 4))
     hipLaunchKernelGGL((ht_encode_kernel<true, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg, t_rev);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if ((widths & 1) && (widths & 8) && (widths & 16))
     hipLaunchKernelGGL((ht_encode_kernel<false, 3>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg, t_irv);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   else if ((widths & 1) && (widths & 8))
     hipLaunchKernelGGL((ht_encode_kernel<false, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
-                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg, t_irv);
+                       (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel<false>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
@@ -1420,7 +1384,7 @@ extern "C" int ojphgpu_ht_encode(void* stream, const ojphgpu_cb_desc* d_blocks, 
                                   const void* d_coef, uint8_t* d_scratch, uint8_t* d_out, uint32_t out_cap,
                                   ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status)
 {
-  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3 | 32, nullptr, 0, nullptr);
+  return ojphgpu::ht_encode_launch(stream, d_blocks, n, d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, 3 | 32, nullptr, 0);
 }
 
 namespace ojphgpu {

@@ -189,8 +189,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     }
     e->nreg = R;
     if (R) cap = total; else e->h_regions.clear();
-    // (+ a cache line of ticket counters behind the cursors: two words per block-coder launch of a run, see ht_encode_kernel)
-    e->counters_bytes = (R ? (size_t)R * 128 : 128) + 128;
+    e->counters_bytes = R ? (size_t)R * 128 : 16;
   }
   e->out_cap = (uint32_t)cap;
 
@@ -249,8 +248,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
     HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     const int sh = T.begin(SP_HT_ENC, e->side);
     int r2 = ojphgpu::ht_encode_launch(e->side, cbd, e->n_top, e->arena.p, (uint8_t*)e->scratch.p, d_out,
-                                       e->out_cap, res, cnt, cnt + 1, e->widths_top, (const uint32_t*)e->regions.p, e->nreg,
-                                       cnt + e->counters_bytes / 4 - 32);
+                                       e->out_cap, res, cnt, cnt + 1, e->widths_top, (const uint32_t*)e->regions.p, e->nreg);
     if (r2) return r2;
     T.end(sh, e->side);
     HIPCHK(hipEventRecord(e->ev_join, e->side));
@@ -277,8 +275,7 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
   const uint32_t nb_all = (uint32_t)e->block_ids.size() * e->nframes;
   const int sh = T.begin(SP_HT_ENC, s);
   rc = ojphgpu::ht_encode_launch(s, cbd + e->n_top, nb_all - e->n_top, e->arena.p, (uint8_t*)e->scratch.p,
-                                 d_out, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest, (const uint32_t*)e->regions.p, e->nreg,
-                                 cnt + e->counters_bytes / 4 - 32 + 2);
+                                 d_out, e->out_cap, res + e->n_top, cnt, cnt + 1, e->widths_rest, (const uint32_t*)e->regions.p, e->nreg);
   if (rc) return rc;
   T.end(sh, s);
   if (e->n_top) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));     // join

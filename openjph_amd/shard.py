@@ -193,16 +193,74 @@ def gather_tile_lengths(lens: np.ndarray, num_tiles: int, first: int, group=None
     return full.cpu().numpy().astype(np.uint32)
 
 
-def encode_sharded(encode_tiles, plan, group=None, device=None):
-    """encode_tiles(first, count) -> (tile-part bytes, Psot array) for this rank's tile run (the GPU
-    encoder's finish_tiles, or the oracle pipeline in the CPU tests).  Returns the whole
-    codestream on rank 0, None elsewhere."""
+_NODE = {}          # per process group: do its ranks share this node, and the node's HostGather segment
+
+
+def ranks_share_a_node(group=None) -> bool:
+    """every rank of the group runs on this host (asked once per group)"""
+    import socket
+    import torch.distributed as dist
+    key = ("same", id(group))
+    if key not in _NODE:
+        names = [None] * dist.get_world_size(group)
+        dist.all_gather_object(names, socket.gethostname(), group=group)
+        _NODE[key] = len(set(names)) == 1
+    return _NODE[key]
+
+
+def gather_mode(group=None, gather=None) -> str:
+    """How the tile-parts of the ranks meet: "host" -- the node's shared segment (HostGather: every rank copies its own
+    tile-parts over its own link, nothing passes through rank 0's GPU; SURVEY.md section 8(e): "simpler and equally fast since
+    the data must reach host memory for the file write anyway") -- is the DEFAULT whenever all ranks share a node; "rccl" --
+    the gatherv to rank 0 over the process group (RCCL send / recv over xGMI on the GPU box, gloo in the CPU tests) -- when
+    they do not, or when asked for: gather="rccl" / OJPHGPU_GATHER=rccl."""
+    import os
+    mode = gather or os.environ.get("OJPHGPU_GATHER", "host")
+    if mode not in ("host", "rccl"):
+        raise ValueError("gather must be 'host' or 'rccl'")
+    return mode if mode == "rccl" or ranks_share_a_node(group) else "rccl"
+
+
+def node_segment(need: int, group=None):
+    """the group's HostGather segment, grown (collectively: every rank sees the same `need`) when a codestream outgrows it"""
+    import torch
+    key = ("seg", id(group))
+    hg = _NODE.get(key)
+    if hg is None or hg.capacity < need:
+        if hg is not None:
+            hg.close()
+        hg = HostGather(max(int(need * 1.5), 1 << 20), group, register=torch.cuda.is_available())
+        _NODE[key] = hg
+    return hg
+
+
+def close_node_segment(group=None):
+    """collective: releases the group's HostGather segment (before the process group goes away)"""
+    hg = _NODE.pop(("seg", id(group)), None)
+    if hg is not None:
+        hg.close()
+    _NODE.pop(("same", id(group)), None)
+
+
+def encode_sharded(encode_tiles, plan, group=None, device=None, gather=None):
+    """encode_tiles(first, count) -> (tile-part bytes or uint8 tensor, Psot array) for this rank's tile run (the GPU
+    encoder's finish_tiles / finish_tiles_device, or the oracle pipeline in the CPU tests).  Returns the whole
+    codestream on rank 0, None elsewhere.  The tile-parts meet as gather_mode() says: in the node's shared host segment by
+    default, by the gatherv to rank 0 when asked for (or when the ranks span nodes)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     first, count = tile_range(plan.num_tiles, rank, world)
     part, lens = encode_tiles(first, count) if count else (b"", np.zeros(0, np.uint32))
     all_lens = gather_tile_lengths(lens, plan.num_tiles, first, group, device, plan.parts_per_tile)
+    if gather_mode(group, gather) == "host":
+        ppt = plan.parts_per_tile
+        runs = [tile_range(plan.num_tiles, r, world) for r in range(world)]
+        sizes = [int(np.asarray(all_lens[f * ppt:(f + c) * ppt], dtype=np.uint64).sum()) for f, c in runs]
+        header = plan.t2_main_header(all_lens)               # (every rank: the segment's size follows from its length)
+        hg = node_segment(len(header) + sum(sizes) + 2, group)
+        n = hg.place(part, sizes, header if rank == 0 else None)
+        return bytes(hg.view[:n]) if rank == 0 else None
     parts, _ = gather_bytes(part, group, 0, device)
     if rank != 0:
         return None

@@ -88,6 +88,23 @@ def survey_c5(frame=0, seed=1234):
     return _noisy(_family(2160, 3840, 512, 240, 200, 80, 97, 61, 13), rng.normal(0, 24, (3, 2160, 3840)), 1023)
 
 
+def survey_c6(seed=1234):
+    """c6 (bench.py): 3840x2160x1, 32-bit unsigned samples -- the C2 family scaled to 32 bits -- in the si32 container the
+    reference's line_buf exchanges (values above 2^31 wrap, as they do there)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:2160, 0:3840].astype(np.float64)
+    v = 2.0 ** 31 + 0.47 * 2.0 ** 31 * np.sin(x / 97) + 0.39 * 2.0 ** 31 * np.cos(y / 61) + 0.12 * 2.0 ** 31 * np.sin((x + y) / 13)
+    v = v + rng.normal(0, 2.0 ** 26, v.shape)
+    v = np.clip(np.rint(v), 0, 2.0 ** 32 - 1).astype(np.int64)
+    return v.astype(np.uint64).astype(np.uint32).astype(np.int32)[None]
+
+
+def survey_c7(seed=1234):
+    """c7 (bench.py): 3840x2160x3 12-bit, the C3 family at 4K."""
+    rng = np.random.default_rng(seed)
+    return _noisy(_family(2160, 3840, 2048, 900, 800, 300, 197, 161, 23), rng.normal(0, 40, (3, 2160, 3840)), 4095)
+
+
 def c1_image():
     """BASELINE config #1 / reference tests/test_truncated_decode.cpp:111."""
     y, x = np.mgrid[0:256, 0:256]

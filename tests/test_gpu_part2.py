@@ -37,3 +37,25 @@ def test_part2_codestreams_on_the_gpu(case):
         w1, _ = cp.decode(want, skip=(1, 1))
         for c in range(nc):
             assert np.array_equal(d1[c], w1[c]), "reduced resolution: component %d differs" % c
+
+
+@pytest.mark.parametrize("shape", [(3, 270, 350, 12), (1, 129, 67, 10)])
+def test_the_97_as_an_atk_segment_is_the_97(shape):
+    """bench.py's c7 workload in small: the 9/7's four lifting steps and K written as an ATK marker segment go through the
+    general lifting kernels and must code and decode EXACTLY what the built-in 9/7 kernels do -- the same code-block bytes
+    (the codestreams differ in their marker segments only) and the same samples"""
+    from openjph_amd import codec
+    from openjph_amd.plan import parse_codestream
+    from tests.synth import synth_image
+    from bench import ATK97
+    nc, h, w, bd = shape
+    img = synth_image(nc, h, w, bd, seed=97)
+    kw = dict(bit_depth=bd, reversible=False, qstep=0.002, num_decomps=4)
+    plain = codec.encode(img, **kw)
+    atk = codec.encode(img, atk=ATK97, wavelet=2, **kw)
+    pa, pb = parse_codestream(plain), parse_codestream(atk)
+    ca, cb = pa.coded_blocks(), pb.coded_blocks()
+    assert len(ca) == len(cb)
+    for x, y in zip(ca, cb):
+        assert int(x["len1"]) == int(y["len1"]) and plain[int(x["offset"]):int(x["offset"]) + int(x["len1"])] == atk[int(y["offset"]):int(y["offset"]) + int(y["len1"])]
+    assert np.array_equal(codec.decode(plain), codec.decode(atk))

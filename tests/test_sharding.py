@@ -43,8 +43,14 @@ def _worker(rank, world, port, case, q):
         img = synth_image(case["nc"], case["h"], case["w"], case["bd"], seed=3)
         kw = dict(case["kw"], bit_depth=case["bd"])
         plan = Plan(make_params(case["w"], case["h"], case["nc"], **kw))
+        assert shard.gather_mode() == "host"                 # the ranks share this node: the shared segment is the default
         cs = shard.encode_sharded(lambda first, count: cp.encode_tiles(plan, img, first, count), plan)
-        # the same frame through the node's shared-memory gather (every rank places its own tile-parts; no receiving rank)
+        # ... and the gatherv to rank 0 over the process group, behind its switch: the same bytes
+        cs2 = shard.encode_sharded(lambda first, count: cp.encode_tiles(plan, img, first, count), plan, gather="rccl")
+        if rank == 0 and cs2 != cs:
+            cs = b"the two gathers differ"
+        shard.close_node_segment()
+        # the same frame with a caller-owned HostGather (every rank places its own tile-parts; no receiving rank)
         cap = [len(cs) + 4096 if rank == 0 else 0]
         dist.broadcast_object_list(cap, src=0)
         hg = shard.HostGather(cap[0], register=False)
