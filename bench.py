@@ -505,12 +505,17 @@ def main():
     if rv:
         result["roofline_valu"] = rv
         # which roof the dominant launch is nearer to: the HBM fraction above, or the VALU-issue fraction of the same launch
-        fv = (rv.get("kernels") or {}).get(dom, {}).get("frac")
+        kd = (rv.get("kernels") or {}).get(dom, {})
+        fv = kd.get("frac")
         if fv is not None:
             result["roofline"]["frac_valu_issue"] = fv
-            result["roofline"]["bound"] = "valu-issue" if fv > result["roofline"]["frac"] else "hbm"
-            result["roofline"]["bound_note"] = ("`bound` names the roof the launch sits closer to; achieved / peak / frac stay the HBM figures "
-                                                "(SURVEY 8(d) bytes over the HBM peak), frac_valu_issue is the same launch against the VALU-issue roof")
+            result["roofline"]["frac_valu_issue_at_2p4_cycles"] = kd.get("frac_at_2p4_cycles")
+            result["roofline"]["wait_share"] = kd.get("wait_share")
+            # which roof the launch is nearer to -- unless its wavefronts mostly WAIT: then neither roof explains it
+            result["roofline"]["bound"] = "latency" if kd.get("bound") == "latency" else ("valu-issue" if fv > result["roofline"]["frac"] else "hbm")
+            result["roofline"]["bound_note"] = ("`bound`: `latency` when the launch's wavefronts are parked at s_waitcnt for more than half of their cycles "
+                                                "(wait_share); otherwise the roof it sits closer to.  achieved / peak / frac stay the HBM figures (SURVEY 8(d) bytes "
+                                                "over the HBM peak); frac_valu_issue is the same launch against the 4.2-cycle VALU roof, ..._at_2p4_cycles against the 2.4-cycle one")
     if "dwt_forward(level 1)" in kernels and kernels["dwt_forward(level 1)"][1] > 0:
         # the HBM-bound kernel family of the path (north_star sets its roofline target on it); the
         # block coder launches above are bound by integer VALU issue, not by HBM.  Level 1 -- the two
@@ -788,20 +793,30 @@ def roofline_valu(workload, kinfo):
     if state != "current":
         return {"bound": "valu-issue", "kernels": {}, "source": "profiles/sq_counters.json (%s)" % state}
     sq = sq.get(workload, {})
+    waits = sq.get("_waits", {})
     out = {}
     for k, v in kinfo.items():
         base = k.split("(")[0].split("[")[0]
         c = sq.get(k) or sq.get(base)
         if not c or not v["ms"]:
             continue
-        issue_ms = c["valu_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
-        out[k] = {"valu_wave_insts": c["valu_insts"], "salu_wave_insts": c.get("salu_insts"), "valu_issue_ms_at_peak": round(issue_ms, 4),
-                  "measured_ms": v["ms"], "frac": round(issue_ms / v["ms"], 3)}
+        # two roofs, from the probe's two instruction classes: every VALU instruction of the cheap class (2.4 cycles per wave64
+        # instruction per SIMD) / of the dear one (4.2); the coders' mix lies between, nearer the dear one.  `frac` is the
+        # dear-class figure (the old 4-cycle roof was about that); frac_at_2p4_cycles the guide's optimistic one.
+        ms_at = lambda cyc: c["valu_insts"] * cyc / (1024 * 2.4e9) * 1e3
+        w = waits.get(k) or waits.get(base) or {}
+        out[k] = {"valu_wave_insts": c["valu_insts"], "salu_wave_insts": c.get("salu_insts"), "valu_issue_ms_at_4p2_cycles": round(ms_at(4.2), 4),
+                  "valu_issue_ms_at_2p4_cycles": round(ms_at(2.4), 4), "measured_ms": v["ms"],
+                  "frac": round(ms_at(4.2) / v["ms"], 3), "frac_at_2p4_cycles": round(ms_at(2.4) / v["ms"], 3),
+                  "wait_share": w.get("wait_share"), "issue_stall_share": w.get("issue_stall_share"),
+                  "bound": "latency" if (w.get("wait_share") or 0) > 0.5 else "valu-issue"}
     if not out:
         return None
-    return {"bound": "valu-issue", "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz (tools/micro/valu_issue.hip, profiles/r03_valu_issue_probe.txt: "
-                                           "4.2 cycles per instruction per SIMD for shifts-left / bit-field / compare / select / cross-lane / 3-operand forms, "
-                                           "2.4 for add / and / or / xor / shift-right / fp32 add-mul-fma; the coders' mix is mostly the former)", "kernels": out,
+    return {"bound": "valu-issue or latency, per kernel: `latency` where the kernel's wavefronts spend more than half of their cycles parked at s_waitcnt "
+                     "(wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the committed SQ pass)",
+            "peak": "1024 SIMDs x 1 wave64 VALU instruction / {2.4, 4.2} cycles x 2.4 GHz (tools/micro/valu_issue.hip, profiles/r03_valu_issue_probe.txt: "
+                    "4.2 cycles per instruction per SIMD for shifts-left / bit-field / compare / select / cross-lane / 3-operand forms, "
+                    "2.4 for add / and / or / xor / shift-right / fp32 add-mul-fma; the coders' mix is mostly the former)", "kernels": out,
             "source": "profiles/sq_counters.json (current: same kernel sources, %s)" % json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["_kernels_sha256"][:12],
             "issue_rate_probe": "tools/micro/valu_issue.hip, output in profiles/"}
 

@@ -36,6 +36,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include <cstdlib>
+#include <cstring>
 #include "../../include/ojphgpu.h"
 
 namespace {
@@ -49,6 +50,10 @@ template <bool REV> struct Wv;
 
 template <> struct Wv<true> {       // reversible 5/3 (ojph_params.cpp:2883-2896)
   typedef int T;
+  static constexpr bool REV = true, STEPS4 = false, HAS_K = false;
+  static constexpr int WARM = 1;    // row pairs a vertical chunk has to start early for its pipeline to be warm (two lifting steps)
+  static __device__ __forceinline__ T hK_lo(T v) { return v; }
+  static __device__ __forceinline__ T hK_hi(T v) { return v; }
   static __device__ __forceinline__ T a0(T h, T p, T q) { return h - ((p + q) >> 1); }     // predict
   static __device__ __forceinline__ T a1(T l, T p, T q) { return l + ((p + q + 2) >> 2); } // update
   static __device__ __forceinline__ T a2(T h, T, T) { return h; }
@@ -65,6 +70,11 @@ template <> struct Wv<true> {       // reversible 5/3 (ojph_params.cpp:2883-2896
 
 template <> struct Wv<false> {      // irreversible 9/7 (ojph_params.cpp:2870-2881)
   typedef float T;
+  static constexpr bool REV = false, STEPS4 = true, HAS_K = true;
+  static constexpr int WARM = 2;
+  // the horizontal analysis scales low by 1 / K, high by K (ojph_transform.cpp:763-775)
+  static __device__ __forceinline__ T hK_lo(T v) { return mulKinv(v); }
+  static __device__ __forceinline__ T hK_hi(T v) { return mulK(v); }
   // fp32 "add, mul, add" with no contraction: the generic reference build is the bit-exact pin
   static __device__ __forceinline__ T lift(T v, float c, T p, T q) { return __fadd_rn(v, __fmul_rn(c, __fadd_rn(p, q))); }
   static __device__ __forceinline__ T unlift(T v, float c, T p, T q) { return __fsub_rn(v, __fmul_rn(c, __fadd_rn(p, q))); }
@@ -82,12 +92,54 @@ template <> struct Wv<false> {      // irreversible 9/7 (ojph_params.cpp:2870-28
   static __device__ __forceinline__ T halve(T v) { return __fmul_rn(v, 0.5f); }
 };
 
+// ANY lifting kernel an ATK marker segment describes with up to four steps, and the 5/3 on 64-bit samples: the same
+// register pipeline with the steps as launch parameters.  (Part 2 codestreams and components deeper than 26 bits used to
+// take one element-wise launch per lifting step and direction -- kernels_lift.hip, 2 N + 2 passes over the plane per level;
+// those kernels remain for levels that transform one direction only and for kernels of more than four steps.)
+// NS = number of steps (compile time: a slot without a step is no instruction at all, not an "add zero" -- which would turn
+// a -0.0f into +0.0f); the steps sit in the order the direction applies them: analysis step NS-1 first, updating the odd
+// (high-pass) samples; synthesis step 0 first, updating the even ones -- application index i alternates exactly as the
+// pipeline's slots a0..a3 / s0..s3 do (param_atk, ojph_params.cpp:2654-2896; gen_rev_vert_step32 / 64, gen_irv_vert_step,
+// the horizontal functions, ojph_transform.cpp:209-852).
+template <typename TT, int NS> struct WvGen {
+  typedef TT T;
+  static constexpr bool REV = !std::is_floating_point<TT>::value, STEPS4 = NS > 2, HAS_K = std::is_floating_point<TT>::value;
+  static constexpr int WARM = NS > 2 ? 2 : 1;
+  int a[4], b[4], e[4]; float A[4]; float K, Kinv; int hswap;   // hswap: the horizontal analysis of an odd number of steps scales the OTHER sub-sequence by 1 / K (:765-777)
+  template <int I, bool ADD> __device__ __forceinline__ T step(T v, T p, T q) const {
+    if constexpr (I >= NS) return v;
+    else if constexpr (REV) {                               // (b + a (l + r)) >> e, the shift counted modulo the width (see kernels_lift.hip)
+      const T d = (T)(((T)b[I] + (T)a[I] * (T)(p + q)) >> (e[I] & (int)(8 * sizeof(T) - 1)));
+      return ADD ? (T)(v + d) : (T)(v - d);
+    } else {
+      const float m = __fmul_rn(A[I], __fadd_rn(p, q));
+      return ADD ? __fadd_rn(v, m) : __fsub_rn(v, m);
+    }
+  }
+  __device__ __forceinline__ T a0(T h, T p, T q) const { return step<0, true>(h, p, q); }
+  __device__ __forceinline__ T a1(T l, T p, T q) const { return step<1, true>(l, p, q); }
+  __device__ __forceinline__ T a2(T h, T p, T q) const { return step<2, true>(h, p, q); }
+  __device__ __forceinline__ T a3(T l, T p, T q) const { return step<3, true>(l, p, q); }
+  __device__ __forceinline__ T s0(T l, T p, T q) const { return step<0, false>(l, p, q); }
+  __device__ __forceinline__ T s1(T h, T p, T q) const { return step<1, false>(h, p, q); }
+  __device__ __forceinline__ T s2(T l, T p, T q) const { return step<2, false>(l, p, q); }
+  __device__ __forceinline__ T s3(T h, T p, T q) const { return step<3, false>(h, p, q); }
+  __device__ __forceinline__ T mulK(T v) const { if constexpr (HAS_K) return __fmul_rn(v, K); else return v; }
+  __device__ __forceinline__ T mulKinv(T v) const { if constexpr (HAS_K) return __fmul_rn(v, Kinv); else return v; }
+  __device__ __forceinline__ T hK_lo(T v) const { if constexpr (HAS_K) return __fmul_rn(v, hswap ? K : Kinv); else return v; }
+  __device__ __forceinline__ T hK_hi(T v) const { if constexpr (HAS_K) return __fmul_rn(v, hswap ? Kinv : K); else return v; }
+  __device__ __forceinline__ T dbl(T v) const { if constexpr (HAS_K) return __fmul_rn(v, 2.0f); else return (T)(v * 2); }
+  __device__ __forceinline__ T halve(T v) const { if constexpr (HAS_K) return __fmul_rn(v, 0.5f); else return (T)(v >> 1); }
+};
+
 // value of the same register in lane+1 / lane-1 (DPP wave shifts; the end lanes keep their own
 // value, they are halo lanes whose results are never stored)
 __device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
 __device__ __forceinline__ float lane_next(float v) { return __int_as_float(lane_next(__float_as_int(v))); }
 __device__ __forceinline__ float lane_prev(float v) { return __int_as_float(lane_prev(__float_as_int(v))); }
+__device__ __forceinline__ long long lane_next(long long v) { return (long long)(((unsigned long long)(unsigned)lane_next((int)(v >> 32)) << 32) | (unsigned)lane_next((int)v)); }
+__device__ __forceinline__ long long lane_prev(long long v) { return (long long)(((unsigned long long)(unsigned)lane_prev((int)(v >> 32)) << 32) | (unsigned)lane_prev((int)v)); }
 
 // neighbour selection with the "missing -> use the other one" rule
 // CHK = false: the caller knows every neighbour exists (interior of the plane) and the select folds away
@@ -109,39 +161,39 @@ struct Geo {
 
 __device__ __forceinline__ bool col_exists(int x, int w) { return x >= 0 && x < w; }
 
-template <bool REV, bool CHK = true>
-__device__ __forceinline__ void horz_analysis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
+template <class WP, bool CHK = true>
+__device__ __forceinline__ void horz_analysis(const WP& w, typename WP::T& vl, typename WP::T& vh, const Geo& g)
 {
-  typedef typename Wv<REV>::T T;
-  if (CHK && g.w == 1) { if (g.ox) vh = Wv<REV>::dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
+  typedef typename WP::T T;
+  if (CHK && g.w == 1) { if (g.ox) vh = w.dbl(vh); return; }   // ojph_transform.cpp:405-410, :777-782
   T nl = lane_next(vl);
-  vh = Wv<REV>::a0(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
+  vh = w.a0(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
   T ph = lane_prev(vh);
-  vl = Wv<REV>::a1(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
-  if (!REV) {
+  vl = w.a1(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
+  if (WP::STEPS4) {
     nl = lane_next(vl);
-    vh = Wv<REV>::a2(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
+    vh = w.a2(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
     ph = lane_prev(vh);
-    vl = Wv<REV>::a3(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
-    vl = Wv<REV>::mulKinv(vl); vh = Wv<REV>::mulK(vh);          // ojph_transform.cpp:763-775
+    vl = w.a3(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
   }
+  if (WP::HAS_K) { vl = w.hK_lo(vl); vh = w.hK_hi(vh); }          // ojph_transform.cpp:763-775
 }
 
-template <bool REV, bool CHK = true>
-__device__ __forceinline__ void horz_synthesis(typename Wv<REV>::T& vl, typename Wv<REV>::T& vh, const Geo& g)
+template <class WP, bool CHK = true>
+__device__ __forceinline__ void horz_synthesis(const WP& w, typename WP::T& vl, typename WP::T& vh, const Geo& g)
 {
-  typedef typename Wv<REV>::T T;
-  if (CHK && g.w == 1) { if (g.ox) vh = Wv<REV>::halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
-  if (!REV) { vl = Wv<REV>::mulK(vl); vh = Wv<REV>::mulKinv(vh); }   // :797-809
+  typedef typename WP::T T;
+  if (CHK && g.w == 1) { if (g.ox) vh = w.halve(vh); return; } // ojph_transform.cpp:583-588, :844-849
+  if (WP::HAS_K) { vl = w.mulK(vl); vh = w.mulKinv(vh); }   // :797-809
   T ph = lane_prev(vh);
-  vl = Wv<REV>::s0(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
+  vl = w.s0(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
   T nl = lane_next(vl);
-  vh = Wv<REV>::s1(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
-  if (!REV) {
+  vh = w.s1(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
+  if (WP::STEPS4) {
     ph = lane_prev(vh);
-    vl = Wv<REV>::s2(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
+    vl = w.s2(vl, pick<CHK>(g.eHp, ph, vh), pick<CHK>(g.eH, vh, ph));
     nl = lane_next(vl);
-    vh = Wv<REV>::s3(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
+    vh = w.s3(vh, pick<CHK>(g.eL, vl, nl), pick<CHK>(g.eLn, nl, vl));
   }
 }
 
@@ -225,13 +277,13 @@ __device__ __forceinline__ int sample_of(E v, const Conv& cv)
 }
 
 // IMG: the row came from an image plane and is converted here
-template <bool REV, int IMG, typename E>
-__device__ __forceinline__ Pair<typename Wv<REV>::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
+template <class WP, int IMG, typename E>
+__device__ __forceinline__ Pair<typename WP::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
 {
-  Pair<typename Wv<REV>::T> p;
+  Pair<typename WP::T> p;
   const auto a = g.from_y ? v.y : v.x, b = g.from_x ? v.x : v.y;
-  if (IMG) { p.l = Cv<REV>::from_image(sample_of<IMG>(a, cv), cv); p.h = Cv<REV>::from_image(sample_of<IMG>(b, cv), cv); }
-  else { p.l = (typename Wv<REV>::T)a; p.h = (typename Wv<REV>::T)b; }
+  if constexpr (IMG != 0) { p.l = Cv<WP::REV>::from_image(sample_of<IMG>(a, cv), cv); p.h = Cv<WP::REV>::from_image(sample_of<IMG>(b, cv), cv); }
+  else { p.l = (typename WP::T)a; p.h = (typename WP::T)b; }
   return p;
 }
 
@@ -261,15 +313,15 @@ template <> struct Ct<false> {
 };
 
 // NC = 3: the rows of the three colour planes become the rows of Y, Cb, Cr
-template <bool REV, int IMG, int NC, typename E>
-__device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const Conv* cv, Pair<typename Wv<REV>::T>* out)
+template <class WP, int IMG, int NC, typename E>
+__device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const Conv* cv, Pair<typename WP::T>* out)
 {
 #pragma unroll
-  for (int k = 0; k < NC; ++k) out[k] = unpack<REV, IMG>(v[k], g, cv[k]);
-  if (NC == 3) {
-    const Pair<typename Wv<REV>::T> r = out[0], gg = out[1], b = out[2];
-    Ct<REV>::fwd(r.l, gg.l, b.l, out[0].l, out[1].l, out[2].l);
-    Ct<REV>::fwd(r.h, gg.h, b.h, out[0].h, out[1].h, out[2].h);
+  for (int k = 0; k < NC; ++k) out[k] = unpack<WP, IMG>(v[k], g, cv[k]);
+  if constexpr (NC == 3) {
+    const Pair<typename WP::T> r = out[0], gg = out[1], b = out[2];
+    Ct<WP::REV>::fwd(r.l, gg.l, b.l, out[0].l, out[1].l, out[2].l);
+    Ct<WP::REV>::fwd(r.h, gg.h, b.h, out[0].h, out[1].h, out[2].h);
   }
 }
 
@@ -297,13 +349,14 @@ __device__ __forceinline__ void arrived(const signed char& a, const signed char&
 // are read once, turned into Y, Cb, Cr rows in registers (RCT / ICT) and run through three vertical pipelines, so a
 // colour-transformed frame needs no conversion pass over HBM (descs[3 z .. 3 z + 2] = the planes' descriptors, which
 // share their geometry).
-template <bool REV, int IMG, int NC>
+template <class WP, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
-                                                          typename Wv<REV>::T* __restrict__ base,
-                                                          const void* __restrict__ image, Conv cv, int row_pairs)
+                                                          uint32_t* __restrict__ base32,
+                                                          const void* __restrict__ image, Conv cv, int row_pairs, const WP w)
 {
-  typedef typename Wv<REV>::T T;
-  typedef Wv<REV> W;
+  typedef typename WP::T T;
+  constexpr bool REV = WP::REV;
+  (void)REV;
   typedef typename ImgElem<IMG, T>::type E;                        // element type of the source rows
   typedef Raw<E> RawRow;
   // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
@@ -328,8 +381,9 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
     const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
     cvs[k] = cv;
     if (IMG && dk.reserved) { cvs[k].bit_depth = (int)(dk.reserved & 0xFFu); cvs[k].is_signed = (int)((dk.reserved >> 8) & 1u); }
-    src[k] = IMG ? (const char*)image + dk.src_off * sizeof(E) : (const char*)(base + dk.src_off);
-    ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
+    // (offsets count 32-bit arena elements whatever T is: a 64-bit plane starts on an even element)
+    src[k] = IMG ? (const char*)image + dk.src_off * sizeof(E) : (const char*)(base32 + dk.src_off);
+    ll[k] = (T*)(base32 + dk.ll_off); hl[k] = (T*)(base32 + dk.hl_off); lh[k] = (T*)(base32 + dk.lh_off); hh[k] = (T*)(base32 + dk.hh_off);
   }
   const size_t sp = (size_t)d.src_pitch * sizeof(E);
   const int h = g.h, oy = g.oy;
@@ -353,18 +407,18 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
     if (i0 > 0) return;
     RawRow r0[NC]; Pair<T> x[NC];
     ldrow(0, r0);
-    unpack_all<REV, IMG, NC>(r0, g, cvs, x);
+    unpack_all<WP, IMG, NC>(r0, g, cvs, x);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      if (oy != 0) { x[k].l = W::dbl(x[k].l); x[k].h = W::dbl(x[k].h); }
-      horz_analysis<REV>(x[k].l, x[k].h, g);
+      if (oy != 0) { x[k].l = w.dbl(x[k].l); x[k].h = w.dbl(x[k].h); }
+      horz_analysis<WP>(w, x[k].l, x[k].h, g);
       put(k, 0, oy == 0, x[k].l, x[k].h);
     }
     return;
   }
 
   // vertical software pipeline over row pairs t; see file header
-  const int t0 = max(i0 - (REV ? 1 : 2), 0);
+  const int t0 = max(i0 - WP::WARM, 0);
   Pair<T> xl[NC], xn[NC], a[NC], ap[NC], b[NC], bp[NC], c[NC], cp[NC];   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
   Pair<T> out_lo[NC], out_hi[NC];        // transformed rows of pair out_t, stored one iteration later
 #pragma unroll
@@ -372,14 +426,14 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   int out_t = 0; bool has_lo = false, has_hi = false;
   RawRow rh[NC], rn[NC];
   ldrow(2 * t0 - oy, rh);
-  unpack_all<REV, IMG, NC>(rh, g, cvs, xl);
+  unpack_all<WP, IMG, NC>(rh, g, cvs, xl);
   ldrow(2 * t0 + 1 - oy, rh); ldrow(2 * t0 + 2 - oy, rn);                     // rows of iteration t0
   for (int t = t0; t <= i1; ++t) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) arrived(rh[k].x, rh[k].y, rn[k].x, rn[k].y);
     Pair<T> xh[NC];
-    unpack_all<REV, IMG, NC>(rh, g, cvs, xh);
-    unpack_all<REV, IMG, NC>(rn, g, cvs, xn);
+    unpack_all<WP, IMG, NC>(rh, g, cvs, xh);
+    unpack_all<WP, IMG, NC>(rn, g, cvs, xn);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
@@ -400,28 +454,28 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
       for (int k = 0; k < NC; ++k) {
         // a[t]
         ap[k] = a[k];
-        a[k].l = W::a0(xh[k].l, pick<CHK>(eLt, xl[k].l, xn[k].l), pick<CHK>(eLn, xn[k].l, xl[k].l));
-        a[k].h = W::a0(xh[k].h, pick<CHK>(eLt, xl[k].h, xn[k].h), pick<CHK>(eLn, xn[k].h, xl[k].h));
+        a[k].l = w.a0(xh[k].l, pick<CHK>(eLt, xl[k].l, xn[k].l), pick<CHK>(eLn, xn[k].l, xl[k].l));
+        a[k].h = w.a0(xh[k].h, pick<CHK>(eLt, xl[k].h, xn[k].h), pick<CHK>(eLn, xn[k].h, xl[k].h));
         // b[t]
         const Pair<T> bo = b[k];                // b[t-1]
-        b[k].l = W::a1(xl[k].l, pick<CHK>(eHp, ap[k].l, a[k].l), pick<CHK>(eHt, a[k].l, ap[k].l));
-        b[k].h = W::a1(xl[k].h, pick<CHK>(eHp, ap[k].h, a[k].h), pick<CHK>(eHt, a[k].h, ap[k].h));
+        b[k].l = w.a1(xl[k].l, pick<CHK>(eHp, ap[k].l, a[k].l), pick<CHK>(eHt, a[k].l, ap[k].l));
+        b[k].h = w.a1(xl[k].h, pick<CHK>(eHp, ap[k].h, a[k].h), pick<CHK>(eHt, a[k].h, ap[k].h));
         bp[k] = bo;
         // c[t-1]
         cp[k] = c[k];
-        c[k].l = W::a2(ap[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
-        c[k].h = W::a2(ap[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+        c[k].l = w.a2(ap[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+        c[k].h = w.a2(ap[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
         // d[t-1]
-        const T dl = W::a3(bp[k].l, pick<CHK>(eHpp, cp[k].l, c[k].l), pick<CHK>(eHp, c[k].l, cp[k].l));
-        const T dh = W::a3(bp[k].h, pick<CHK>(eHpp, cp[k].h, c[k].h), pick<CHK>(eHp, c[k].h, cp[k].h));
+        const T dl = w.a3(bp[k].l, pick<CHK>(eHpp, cp[k].l, c[k].l), pick<CHK>(eHp, c[k].l, cp[k].l));
+        const T dh = w.a3(bp[k].h, pick<CHK>(eHpp, cp[k].h, c[k].h), pick<CHK>(eHp, c[k].h, cp[k].h));
         if (emit) {
           if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
-            out_lo[k].l = W::mulKinv(dl); out_lo[k].h = W::mulKinv(dh);
-            horz_analysis<REV, CHK>(out_lo[k].l, out_lo[k].h, g);
+            out_lo[k].l = w.mulKinv(dl); out_lo[k].h = w.mulKinv(dh);
+            horz_analysis<WP, CHK>(w, out_lo[k].l, out_lo[k].h, g);
           }
           if (!CHK || eHp) {                                   // :663-664
-            out_hi[k].l = W::mulK(c[k].l); out_hi[k].h = W::mulK(c[k].h);
-            horz_analysis<REV, CHK>(out_hi[k].l, out_hi[k].h, g);
+            out_hi[k].l = w.mulK(c[k].l); out_hi[k].h = w.mulK(c[k].h);
+            horz_analysis<WP, CHK>(w, out_hi[k].l, out_hi[k].h, g);
           }
         }
       }
@@ -473,14 +527,15 @@ __device__ __forceinline__ void store_image_pair(void* __restrict__ rowp, const 
   }
 }
 
-template <bool REV, int IMG>
-__device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename Wv<REV>::T l, typename Wv<REV>::T h,
+template <class WP, int IMG>
+__device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g, typename WP::T l, typename WP::T h,
                                            const Conv& cv)
 {
-  typedef typename Wv<REV>::T T;
+  typedef typename WP::T T;
+  constexpr bool REV = WP::REV;
   if (!g.store) return;
   const int xl = 2 * g.j - g.ox;
-  if (IMG) store_image_pair<REV, IMG>(rowp, g, Cv<REV>::to_image(l, cv), Cv<REV>::to_image(h, cv), cv);
+  if constexpr (IMG != 0) store_image_pair<REV, IMG>(rowp, g, Cv<REV>::to_image(l, cv), Cv<REV>::to_image(h, cv), cv);
   else {
     T* row = (T*)rowp;
     if (g.ox == 0 && g.eL && g.eH) {
@@ -495,11 +550,12 @@ __device__ __forceinline__ void store_pair(void* __restrict__ rowp, const Geo& g
 }
 
 // one reconstructed row of all NC planes; NC = 3: Y, Cb, Cr -> R, G, B on the way out
-template <bool REV, int IMG, int NC>
-__device__ __forceinline__ void store_rows(char* const* dst, size_t off, const Geo& g, const Pair<typename Wv<REV>::T>* v, const Conv* cv)
+template <class WP, int IMG, int NC>
+__device__ __forceinline__ void store_rows(char* const* dst, size_t off, const Geo& g, const Pair<typename WP::T>* v, const Conv* cv)
 {
-  typedef typename Wv<REV>::T T;
-  if (NC == 3) {
+  typedef typename WP::T T;
+  constexpr bool REV = WP::REV;
+  if constexpr (NC == 3) {
     if (!g.store) return;
     T rl, gl, bl, rh, gh, bh;
     Ct<REV>::inv(v[0].l, v[1].l, v[2].l, rl, gl, bl);
@@ -509,20 +565,21 @@ __device__ __forceinline__ void store_rows(char* const* dst, size_t off, const G
     store_image_pair<REV, IMG>(dst[2] + off, g, Cv<REV>::to_image(bl, cv[2]), Cv<REV>::to_image(bh, cv[2]), cv[2]);
   } else {
 #pragma unroll
-    for (int k = 0; k < NC; ++k) store_pair<REV, IMG>(dst[k] + off, g, v[k].l, v[k].h, cv[k]);
+    for (int k = 0; k < NC; ++k) store_pair<WP, IMG>(dst[k] + off, g, v[k].l, v[k].h, cv[k]);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse: LL, HL, LH, HH -> plane (or image plane, IMG); NC as in the forward kernel
 // ---------------------------------------------------------------------------------------------
-template <bool REV, int IMG, int NC>
+template <class WP, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
-                                                          typename Wv<REV>::T* __restrict__ base,
-                                                          void* __restrict__ image, Conv cv, int row_pairs)
+                                                          uint32_t* __restrict__ base32,
+                                                          void* __restrict__ image, Conv cv, int row_pairs, const WP w)
 {
-  typedef typename Wv<REV>::T T;
-  typedef Wv<REV> W;
+  typedef typename WP::T T;
+  constexpr bool REV = WP::REV;
+  (void)REV;
   // a DWT launch is short and the next stage waits for it: when it shares the SIMDs with the long
   // block-coder launch of the side stream, its wavefronts go first
   __builtin_amdgcn_s_setprio(2);
@@ -546,8 +603,8 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     const ojphgpu_dwt_desc dk = k ? descs[blockIdx.z * NC + k] : d;
     cvs[k] = cv;
     if (IMG && dk.reserved) { cvs[k].bit_depth = (int)(dk.reserved & 0xFFu); cvs[k].is_signed = (int)((dk.reserved >> 8) & 1u); }
-    dst[k] = IMG ? (char*)image + dk.src_off * sizeof(E) : (char*)(base + dk.src_off);
-    ll[k] = base + dk.ll_off; hl[k] = base + dk.hl_off; lh[k] = base + dk.lh_off; hh[k] = base + dk.hh_off;
+    dst[k] = IMG ? (char*)image + dk.src_off * sizeof(E) : (char*)(base32 + dk.src_off);
+    ll[k] = (const T*)(base32 + dk.ll_off); hl[k] = (const T*)(base32 + dk.hl_off); lh[k] = (const T*)(base32 + dk.lh_off); hh[k] = (const T*)(base32 + dk.hh_off);
   }
   const size_t dp = (size_t)d.src_pitch * sizeof(E);
   const int h = g.h, oy = g.oy;
@@ -573,14 +630,14 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     fetch(0, oy == 0, true, x);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      horz_synthesis<REV>(x[k].l, x[k].h, g);
-      if (oy != 0) { x[k].l = W::halve(x[k].l); x[k].h = W::halve(x[k].h); }
+      horz_synthesis<WP>(w, x[k].l, x[k].h, g);
+      if (oy != 0) { x[k].l = w.halve(x[k].l); x[k].h = w.halve(x[k].h); }
     }
-    store_rows<REV, IMG, NC>(dst, 0, g, x, cvs);
+    store_rows<WP, IMG, NC>(dst, 0, g, x, cvs);
     return;
   }
 
-  const int t0 = max(i0 - (REV ? 1 : 2), 0);
+  const int t0 = max(i0 - WP::WARM, 0);
   Pair<T> z; z.l = z.h = 0;
   Pair<T> c[NC], cp[NC], b[NC], bp[NC], a[NC], ap[NC], xL[NC], xLp[NC];
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
@@ -603,28 +660,28 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
       for (int k = 0; k < NC; ++k) {
         Pair<T> dd = in_lo[k], cc = in_hi[k];
         cp[k] = c[k]; c[k] = z;
-        if (!CHK || eLt) { horz_synthesis<REV, CHK>(dd.l, dd.h, g); dd.l = W::mulK(dd.l); dd.h = W::mulK(dd.h); } else dd = z;   // :855-856
-        if (!CHK || eHt) { horz_synthesis<REV, CHK>(cc.l, cc.h, g); c[k].l = W::mulKinv(cc.l); c[k].h = W::mulKinv(cc.h); }    // :871-872
+        if (!CHK || eLt) { horz_synthesis<WP, CHK>(w, dd.l, dd.h, g); dd.l = w.mulK(dd.l); dd.h = w.mulK(dd.h); } else dd = z;   // :855-856
+        if (!CHK || eHt) { horz_synthesis<WP, CHK>(w, cc.l, cc.h, g); c[k].l = w.mulKinv(cc.l); c[k].h = w.mulKinv(cc.h); }    // :871-872
         // b[t]
         bp[k] = b[k];
-        b[k].l = W::s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
-        b[k].h = W::s0(dd.h, pick<CHK>(eHp, cp[k].h, c[k].h), pick<CHK>(eHt, c[k].h, cp[k].h));
+        b[k].l = w.s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
+        b[k].h = w.s0(dd.h, pick<CHK>(eHp, cp[k].h, c[k].h), pick<CHK>(eHt, c[k].h, cp[k].h));
         // a[t-1]
         ap[k] = a[k];
-        a[k].l = W::s1(cp[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
-        a[k].h = W::s1(cp[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+        a[k].l = w.s1(cp[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+        a[k].h = w.s1(cp[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
         // xL[t-1]
         xLp[k] = xL[k];
-        xL[k].l = W::s2(bp[k].l, pick<CHK>(eHpp, ap[k].l, a[k].l), pick<CHK>(eHp, a[k].l, ap[k].l));
-        xL[k].h = W::s2(bp[k].h, pick<CHK>(eHpp, ap[k].h, a[k].h), pick<CHK>(eHp, a[k].h, ap[k].h));
+        xL[k].l = w.s2(bp[k].l, pick<CHK>(eHpp, ap[k].l, a[k].l), pick<CHK>(eHp, a[k].l, ap[k].l));
+        xL[k].h = w.s2(bp[k].h, pick<CHK>(eHpp, ap[k].h, a[k].h), pick<CHK>(eHp, a[k].h, ap[k].h));
         // xH[t-2]
-        xh[k].l = W::s3(ap[k].l, pick<CHK>(eLpp, xLp[k].l, xL[k].l), pick<CHK>(eLp, xL[k].l, xLp[k].l));
-        xh[k].h = W::s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
+        xh[k].l = w.s3(ap[k].l, pick<CHK>(eLpp, xLp[k].l, xL[k].l), pick<CHK>(eLp, xL[k].l, xLp[k].l));
+        xh[k].h = w.s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
       }
       if (t - 2 >= i0 && t - 2 < i1 && (!CHK || eHpp))
-        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cvs);
+        store_rows<WP, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cvs);
       if (t - 1 >= i0 && t - 1 < i1 && (!CHK || eLp))
-        store_rows<REV, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cvs);
+        store_rows<WP, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cvs);
     };
     if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * t + 1 - oy < h) lift(std::false_type());
     else lift(std::true_type());
@@ -686,7 +743,7 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   }
   const dim3 grid = dwt_grid(n / (uint32_t)nc, max_w, max_h, rp);
   hipStream_t s = (hipStream_t)stream;
-#define OJPH_LAUNCH(K, REV, IMG, NC, TP) hipLaunchKernelGGL((K<REV, IMG, NC>), grid, dim3(256), 0, s, d_descs, (TP*)d_base, d_image, cv, rp)
+#define OJPH_LAUNCH(K, REV, IMG, NC, TP) hipLaunchKernelGGL((K<Wv<REV>, IMG, NC>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, rp, Wv<REV>())
 #define OJPH_LAUNCH_NC(K, REV, IMG, TP) do { if (nc == 3) OJPH_LAUNCH(K, REV, IMG, 3, TP); else OJPH_LAUNCH(K, REV, IMG, 1, TP); } while (0)
 #define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, 1, TP); else if (container == 16) OJPH_LAUNCH_NC(K, REV, 16, TP); \
                                          else if (container == 8) OJPH_LAUNCH_NC(K, REV, 8, TP); else OJPH_LAUNCH_NC(K, REV, 32, TP); } while (0)
@@ -698,7 +755,68 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
+// a general lifting kernel (ojphgpu_lift: steps in synthesis order) as the pipeline's policy for one direction of use
+template <typename TT, int NS>
+WvGen<TT, NS> make_policy(const ojphgpu_lift* k, bool synthesis)
+{
+  WvGen<TT, NS> w;
+  memset(&w, 0, sizeof(w));
+  for (int i = 0; i < NS; ++i) {
+    const ojphgpu_lift_step& st = k->steps[synthesis ? i : NS - 1 - i];      // application order: analysis runs the steps backwards
+    w.a[i] = st.a; w.b[i] = st.b; w.e[i] = st.e; w.A[i] = st.A;
+  }
+  w.K = k->K; w.Kinv = 1.0f / k->K;                                          // (fp32, as gen_irv_horz_ana computes it: host code, no contraction)
+  w.hswap = (!synthesis && (NS & 1)) ? 1 : 0;
+  return w;
+}
+
+template <typename TT, int NS>
+int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                   void* d_base, bool synthesis)
+{
+  const int rp = pick_row_pairs(n, max_w, max_h);
+  const dim3 grid = dwt_grid(n, max_w, max_h, rp);
+  const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
+  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, rp, w);
+  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, rp, w);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+
+template <typename TT>
+int launch_general_steps(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                         void* d_base, bool synthesis)
+{
+  switch (k->num_steps) {
+    case 1: return launch_general<TT, 1>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+    case 2: return launch_general<TT, 2>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+    case 3: return launch_general<TT, 3>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+    case 4: return launch_general<TT, 4>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+  }
+  return OJPHGPU_E_INVALID;
+}
+
 }  // namespace
+
+namespace ojphgpu {
+// One level of a GENERAL lifting kernel (kernels_lift.hip's ojphgpu_dwt_forward / _inverse_general) through the register
+// pipeline of this file: both directions transformed, one to four lifting steps, int32 / int64 / float planes -- one
+// launch that reads the plane once and writes its four sub-bands once (or the reverse), where the element-wise form takes
+// 2 N + 2 launches, each a full pass.  -> OJPHGPU_E_INVALID when the kernel does not fit (the caller keeps the other form).
+bool dwt_general_pipeline_fits(const ojphgpu_lift* k)
+{
+  return k && k->horz && k->vert && k->num_steps >= 1 && k->num_steps <= 4 && k->elem <= 2;
+}
+int dwt_general_pipeline(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                         void* d_base, bool synthesis)
+{
+  if (!dwt_general_pipeline_fits(k) || !d_descs || !d_base) return OJPHGPU_E_INVALID;
+  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (k->elem == 0) return launch_general_steps<int>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+  if (k->elem == 1) return launch_general_steps<long long>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+  return launch_general_steps<float>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
+}
+}  // namespace ojphgpu
 
 extern "C" int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
                                     uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)

@@ -414,8 +414,11 @@ struct SliceSched {
   __host__ __device__ explicit SliceSched(uint32_t mq) {
     max_qh = mq ? mq : 1u;
     tail = ((max_qh - 1u) / S2_ROWS) * S2_ROWS;
-    b1 = max_qh > tail + 4u ? max_qh - 4u : tail;
-    b2 = max_qh > b1 + 2u ? max_qh - 2u : b1;
+#ifndef S2_TAIL
+#define S2_TAIL 2                 // the last slice's cuts: 2 = 4 + 2 + 2 rows, 1 = 4 + 4, 0 = none (A/B switch)
+#endif
+    b1 = (S2_TAIL >= 1 && max_qh > tail + 4u) ? max_qh - 4u : tail;
+    b2 = (S2_TAIL >= 2 && max_qh > b1 + 2u) ? max_qh - 2u : b1;
     n = tail / S2_ROWS + 1u + (b1 > tail ? 1u : 0u) + (b2 > b1 ? 1u : 0u);
   }
   __host__ __device__ void bounds(uint32_t sl, uint32_t& lo, uint32_t& hi) const {
@@ -1260,290 +1263,6 @@ __device__ __forceinline__ void step2_block(const ojphgpu_cb_desc& d, uint32_t b
   }
 }
 
-// -------------------------------------------------------------------------------------------------
-// step 2 with TWO code-blocks to a wavefront: one lane = one QUAD (the fused launch's workers)
-// -------------------------------------------------------------------------------------------------
-// A wavefront of step2_block spends ~145 instructions on a quad row of ONE block (a lane per sample column), and the
-// workers of the fused launch are bound by exactly that: instructions issued, whatever their kind (measured, round 5:
-// with the prefix sum, the ring reads, the neighbour exponents, the un-stuffer and the stores all taken out the workers
-// alone still take 0.155 of their 0.204 ms; moving vector instructions to the scalar unit changes nothing).  Most of a
-// row's instructions do not depend on how many samples a lane holds: the record's fields, kappa from the row above, the
-// prefix sum, the ring addresses, the loop.  Here a lane holds a whole quad (two columns x two rows), a block of up to 64
-// columns takes 32 lanes, and the wavefront decodes a row of TWO blocks at once -- lanes 0..31 block A, lanes 32..63 block
-// B = the next block in the order (same chain wavefront, so one progress flag): the per-row overhead is paid once for two
-// blocks, only the four samples' own arithmetic is per lane.  Everything that is wave-uniform in step2_block is uniform per
-// HALF here and lives in vector registers (or in two scalars where control flow needs it).
-// Reference per block: ojph_block_decoder32.cpp:1091-1316, as step2_block.
-constexpr uint32_t PAIR_MIRROR = 4;                              // a quad takes up to 4 x 31 bits: five consecutive ring words are read
-constexpr uint32_t PAIR_RING_ALLOC = RING_WORDS + PAIR_MIRROR;
-constexpr uint32_t PAIR_STATE_WORDS = 22;                        // 0..15 bottom-row exponents (a byte per column), 16 mpos, 17 src_pos, 18 dst_bits, 19 verdict, 20 ms_len
-constexpr uint32_t PAIR_BLOCK_WORDS = PAIR_RING_ALLOC + PAIR_STATE_WORDS;
-
-// inclusive prefix sum inside each half of the wavefront (lanes 0..31, 32..63)
-__device__ __forceinline__ uint32_t half_incl_scan(uint32_t v)
-{
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3: the second 16 lanes of each half
-  return (uint32_t)x;
-}
-
-// MODE 0: the prepare call (rings cleared and filled, state set up: before the worker waits for anything), 1: a slice
-template <int TX, int MODE>
-__device__ __forceinline__ void step2_pair(const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, uint32_t bA,
-                                           const uint8_t* __restrict__ data, const uint32_t* __restrict__ quads,
-                                           uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status, uint32_t* lds,
-                                           uint32_t lane, uint32_t q0, uint32_t q1)
-{
-  const bool hb = lane >= 32u;                                   // the lane's half: block A or block B
-  const uint32_t l32 = lane & 31u;                               // = the lane's quad column
-  const bool haveB = bA + 1u < n;
-  const ojphgpu_cb_desc dA = blocks[bA], dB = blocks[haveB ? bA + 1u : bA];
-  const uint32_t bi = bA + (hb ? 1u : 0u);
-#define PSEL(f) (hb ? (uint32_t)dB.f : (uint32_t)dA.f)
-  const uint32_t W = PSEL(w), H = PSEL(h), pitch = PSEL(pitch), len1 = PSEL(len1), npass = PSEL(num_passes);
-  const uint32_t missing_msbs = PSEL(missing_msbs), K = PSEL(K_max);
-  const float delta = hb ? dB.delta : dA.delta;
-  const uint64_t coef_off = hb ? dB.coef_off : dA.coef_off, data_off = hb ? dB.data_off : dA.data_off;
-#undef PSEL
-  const uint32_t QW = (W + 1u) >> 1, QH = (H + 1u) >> 1;
-  uint32_t* ring = lds + (hb ? PAIR_BLOCK_WORDS : 0u);
-  uint32_t* state = ring + PAIR_RING_ALLOC;
-  uint32_t* dst = coef + coef_off;
-  const uint8_t* cb = data + data_off;
-  const uint32_t lcup = len1;
-  const bool exists = (!hb || haveB) && W != 0u && H != 0u;
-  const bool coded = exists && len1 != 0u && npass != 0u;
-  const bool rev = TX == 1;
-  const uint32_t p = 30u - missing_msbs, mmsbp2 = missing_msbs + 2u, shift = 31u - K;
-
-  auto zero_block = [&](bool which) {                           // (mem_clear, ojph_codeblock.cpp:247) by the lanes of the block's half
-    const uint32_t hv = which ? H : 0u;
-    const uint32_t hmax = max(rdlane(hv, 0), rdlane(hv, 32));   // (both halves walk the taller one's rows)
-    for (uint32_t y = 0; y < hmax; ++y)
-      if (which && y < H) {
-        if (l32 < W) dst[(size_t)y * pitch + l32] = 0u;
-        if (l32 + 32u < W) dst[(size_t)y * pitch + l32 + 32u] = 0u;
-      }
-  };
-
-  // ---- un-stuffs the next 128 MagSgn bytes of the blocks whose lanes say `need` into their rings (step2_block's rule) ----
-  uint32_t dst_bits = 0, src_pos = 0, mpos = 0, ms_len = 0;      // per half
-  auto unstuff = [&](bool need) {
-    {
-      const uint32_t wb = (dst_bits + 31u) >> 5;                 // words above the current partial word are stale
-      const uint32_t z0 = (wb + l32) & RING_MASK;
-      if (need) { ring[z0] = 0; if (z0 < PAIR_MIRROR) ring[z0 + RING_WORDS] = 0; }
-      if (need && l32 < 2u) { const uint32_t z1 = (wb + 32u + l32) & RING_MASK; ring[z1] = 0; if (z1 < PAIR_MIRROR) ring[z1 + RING_WORDS] = 0; }
-    }
-    wave_sync();
-    const uint32_t i0 = src_pos + 4u * l32;
-    const bool in = need && i0 < ms_len;
-    const uint32_t word = in ? load_u32_unaligned(cb + i0) : 0u;
-    uint32_t pw = from_prev(word);
-    if (l32 == 0u) pw = (in && i0) ? load_u32_unaligned(cb + i0 - 4) : 0u;
-    asm volatile("" :: "v"(word), "v"(pw));                      // (both loads awaited here on every path, see step2_block)
-    uint32_t val = 0, nb = 0;
-    if (in) {
-      const uint32_t cnt = min(4u, ms_len - i0);
-      const uint32_t valid = cnt == 4u ? 0xFFFFFFFFu : (1u << (8u * cnt)) - 1u;
-      const uint32_t P = (word << 8) | (pw >> 24), P2 = (word << 16) | (pw >> 16);
-      auto is_ff = [](uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; };
-      const uint32_t S = is_ff(P) & valid;
-      const uint32_t stray = (is_ff(P2) >> 7) & (P >> 7) & 0x01010101u;
-      uint32_t x = ((word | stray) & valid) & ~S;
-      x = (S & 0x00800000u) ? (x & 0x007FFFFFu) | ((x >> 1) & 0xFF800000u) : x;
-      x = (S & 0x00008000u) ? (x & 0x00007FFFu) | ((x >> 1) & 0xFFFF8000u) : x;
-      x = (S & 0x00000080u) ? (x & 0x0000007Fu) | ((x >> 1) & 0xFFFFFF80u) : x;
-      val = x;
-      nb = 8u * cnt - (uint32_t)__popc(S);
-    }
-    const uint32_t incl = half_incl_scan(nb);
-    const uint32_t pos = dst_bits + incl - nb;
-    if (nb) {
-      const uint32_t w = pos >> 5, sh = pos & 31u;
-      const uint32_t wa = w & RING_MASK, wb2 = (w + 1u) & RING_MASK;
-      atomicOr(&ring[wa], val << sh);
-      if (wa < PAIR_MIRROR) atomicOr(&ring[wa + RING_WORDS], val << sh);
-      if (sh + nb > 32u) { atomicOr(&ring[wb2], val >> (32u - sh)); if (wb2 < PAIR_MIRROR) atomicOr(&ring[wb2 + RING_WORDS], val >> (32u - sh)); }
-    }
-    uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);
-    asm volatile("" : "+s"(tA), "+s"(tB));
-    if (need) { dst_bits += hb ? tB : tA; src_pos += 128u; }
-    wave_sync();
-  };
-  constexpr uint32_t ROW_BITS = 32u * 4u * 31u + 64u;             // a quad row of 32 quads consumes at most 32 x 4 x 31 bits
-
-  if (MODE == 0) {                                               // ---- prepare ----
-    uint32_t verdict = 1u;                                       // 1: nothing to decode (absent, not coded: zeroed by slice 0), 2: refused
-    if (coded) {
-      // check_block (block_decoder32.cpp:752-819): passes, missing MSBs, lengths, Scup
-      const bool ok0 = npass <= 3u && missing_msbs < 30u && len1 >= 2u;
-      const uint32_t scup = ok0 ? (((uint32_t)cb[lcup - 1u] << 4) + (cb[lcup - 2u] & 0xFu)) : 0u;
-      const bool ok = ok0 && scup >= 2u && scup <= lcup && scup <= 4079u;
-      verdict = ok ? 0u : 2u;
-      ms_len = ok ? lcup - scup : 0u;
-    }
-    for (uint32_t i = l32; i < PAIR_RING_ALLOC; i += 32u) ring[i] = 0;
-    wave_sync();
-    const bool go = verdict == 0u;
-    for (;;) {
-      const bool need = go && src_pos < ms_len && dst_bits < ROW_BITS;
-      if (__ballot(need) == 0ull) break;
-      unstuff(need);
-    }
-    if (l32 < 16u) state[l32] = 0u;
-    if (l32 == 0u) { state[16] = 0u; state[17] = src_pos; state[18] = dst_bits; state[19] = coded ? verdict : (exists ? 3u : 1u); state[20] = ms_len; }
-    wave_sync();
-    return;
-  }
-
-  // ---- a slice: quad rows [q0, min(q1, QH)) of both blocks ----
-  uint32_t verdict = state[19];
-  if (q0 == 0u) {                                                // blocks that are not decoded are zeroed by their first slice
-    const bool z = verdict >= 2u;                                // 2: refused by check_block, 3: not coded
-    if (__ballot(z) != 0ull) zero_block(z);
-    if (z && l32 == 0u) state[19] = 1u;
-    verdict = z ? 1u : verdict;
-  }
-  bool on = coded && verdict == 0u && q0 < QH;
-  if (__ballot(on) == 0ull) return;
-  ms_len = state[20]; mpos = state[16]; src_pos = state[17]; dst_bits = state[18];
-  uint32_t ep = (state[l32 >> 1] >> (16u * (l32 & 1u))) & 0xFFFFu;   // exponents of the bottom samples of the lane's two columns, row above
-  // the slice's records: [row][quarter][block], 16 bits per quad (flush_row16): lane = quad
-  uint32_t ents[S2_ROWS];
-  {
-    const uint32_t bl = bi & 63u, cw_first = bi - bl;            // (rec16_base: the group of 64 blocks of the chain wavefront)
-    const uint32_t base_words = (hb ? dB.scratch_cap : dA.scratch_cap) - 2u * bl + bl * 4u;
-    (void)cw_first;
-    const uint16_t* r16 = reinterpret_cast<const uint16_t*>(quads + base_words + (size_t)q0 * (64u * REC16_ROW_WORDS) + (l32 >> 3) * 256u) + (l32 & 7u);
-    constexpr uint32_t row_step = 2u * 64u * REC16_ROW_WORDS;
-    const uint32_t qend = q1 < QH ? q1 : QH;
-    const uint32_t last = on ? qend - q0 - 1u : 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < S2_ROWS; ++i)
-      ents[i] = on ? (uint32_t)__hip_atomic_load(r16 + (i < last ? i : last) * row_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  }
-  const bool edgeL = l32 == 0u, edgeR = l32 == 31u;
-  const size_t row_bytes = (size_t)pitch * 4u;
-  char* rowp = reinterpret_cast<char*>(dst) + 8u * l32 + (size_t)(2u * q0) * row_bytes;   // the lane's two columns in sample row 2 q0
-  const bool two_cols = 2u * l32 + 1u < W;
-  uint64_t bad_halves = 0;
-  for (uint32_t qy = q0; qy < q1; ++qy) {
-    const bool rowon = on && qy < QH;
-    if (__ballot(rowon) == 0ull) break;
-    for (;;) {
-      const bool need = rowon && src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)ROW_BITS;
-      if (__ballot(need) == 0ull) break;
-      unstuff(need);
-    }
-    const bool exhausted = src_pos >= ms_len;
-    const bool act = rowon && l32 < QW;
-    const uint32_t ent = ents[0];
-#pragma unroll
-    for (uint32_t i = 0; i + 1 < S2_ROWS; ++i) ents[i] = ents[i + 1];
-    const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
-    uint32_t U_q = inf >> 9;
-    if (qy > 0u) {
-      // the largest exponent among the bottom samples of columns 2qx-1 .. 2qx+2 of the quad row above (:1219-1223)
-      uint32_t lf = from_prev(ep), rt = from_next(ep);
-      lf = edgeL ? 0u : lf; rt = edgeR ? 0u : rt;
-      const uint32_t em = max(max(ep & 0xFFu, ep >> 8), max(lf >> 8, rt & 0xFFu));
-      U_q += (inf & 0x100u) ? max(em, 1u) : 1u;
-    }
-    {
-      const uint64_t b = __ballot(U_q > mmsbp2);                 // :1114, :1224 (an idle lane's U_q is at most 1)
-      if (b != 0ull) {
-        bad_halves |= ((b & 0xFFFFFFFFull) ? 0xFFFFFFFFull : 0ull) | ((b >> 32) ? 0xFFFFFFFF00000000ull : 0ull);
-        on = on && ((bad_halves >> lane) & 1ull) == 0ull;
-        if (__ballot(on) == 0ull) break;
-      }
-    }
-    const bool live = act && on;
-    const uint32_t infl = live ? inf : 0u;
-    // the quad's four samples, n = 0: (x, y), 1: (x, y + 1), 2: (x + 1, y), 3: (x + 1, y + 1); two bits of state each
-    uint32_t st[4], m[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      st[k] = (infl >> (2 * k)) & 3u;
-      if (k >= 2) st[k] = two_cols ? st[k] : 0u;                 // (the right column of an odd-width block's last quad: no sample, no bits -- as step2_block's idle lane)
-      m[k] = st[k] ? U_q - (st[k] >> 1) : 0u;
-    }
-    const uint32_t tot = (m[0] + m[1]) + (m[2] + m[3]);
-    const uint32_t incl = half_incl_scan(tot);
-    const uint32_t at = mpos + incl - tot;
-    {
-      uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);     // the two blocks' bits of this row
-      asm volatile("" : "+s"(tA), "+s"(tB));                     // (both read here, one select -- not a branch per half)
-      mpos += hb ? tB : tA;
-    }
-    const uint32_t wi = at >> 5, sh = at & 31u;
-    const uint32_t* rw = ring + (wi & RING_MASK);
-    const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3], w4 = rw[4];
-    uint32_t win[4] = { __builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
-                        __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh) };
-    if (__ballot(live && exhausted && at + 128u > dst_bits) != 0ull) {   // beyond the segment the stream reads as ones (:609-632)
-      if (exhausted) {
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-          const uint32_t lo = at + 32u * j;                      // first bit of word j
-          if (lo >= dst_bits) win[j] = 0xFFFFFFFFu;
-          else if (lo + 32u > dst_bits) win[j] |= 0xFFFFFFFFu << (dst_bits - lo);
-        }
-      }
-    }
-    uint32_t out[4], vk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t ms_val = win[0];
-      const uint32_t eb = st[k] & (st[k] >> 1);
-      uint32_t v_n = ms_val & ((1u << m[k]) - 1u);
-      v_n |= eb << m[k];
-      v_n |= 1u;
-      const uint32_t keep = st[k] ? 0xFFFFFFFFu : 0u;
-      const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1u))) & keep;
-      vk[k] = v_n & keep;
-      out[k] = dequantise(val, rev, shift, delta);
-      if (k < 3) {                                               // the window moves on by the sample's bits (fewer words matter each time)
-        win[0] = __builtin_amdgcn_alignbit(win[1], win[0], m[k]);
-        if (k < 2) win[1] = __builtin_amdgcn_alignbit(win[2], win[1], m[k]);
-        if (k < 1) win[2] = __builtin_amdgcn_alignbit(win[3], win[2], m[k]);
-      }
-    }
-    {
-      const uint32_t eL = vk[1] ? 31u - (uint32_t)__clz((int)vk[1]) : 0u, eR = vk[3] ? 31u - (uint32_t)__clz((int)vk[3]) : 0u;
-      ep = live ? (eL | (eR << 8)) : ep;
-    }
-    if (live) {
-      char* r0 = rowp;
-      typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));   // an 8-byte store that only promises dword alignment
-      if (two_cols) { u32x2a4 v; v.x = out[0]; v.y = out[2]; *reinterpret_cast<u32x2a4*>(r0) = v; }
-      else *reinterpret_cast<uint32_t*>(r0) = out[0];
-      if (2u * qy + 1u < H) {
-        char* r1 = r0 + row_bytes;
-        if (two_cols) { u32x2a4 v; v.x = out[1]; v.y = out[3]; *reinterpret_cast<u32x2a4*>(r1) = v; }
-        else *reinterpret_cast<uint32_t*>(r1) = out[1];
-      }
-    }
-    rowp += 2u * row_bytes;
-  }
-  // ---- blocks that failed in this slice: zeroed, marked; the others hand their state to the next slice ----
-  const bool bad = ((bad_halves >> lane) & 1ull) != 0ull;
-  if (bad_halves != 0ull) {
-    zero_block(bad);
-    if (bad && l32 == 0u) { block_status[bi] = 1; state[19] = 1u; }
-  }
-  if (!bad && coded && verdict == 0u) {
-    const uint32_t e2 = ep | (from_next(ep) << 16);               // two quads' exponents to a word
-    if ((l32 & 1u) == 0u) state[l32 >> 1] = e2;
-    if (l32 == 0u) { state[16] = mpos; state[17] = src_pos; state[18] = dst_bits; }
-  }
-  wave_sync();
-}
-
 template <int TX, int WD>
 __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
@@ -1649,9 +1368,7 @@ __device__ __forceinline__ void ask_for_repeat(uint32_t* retry, uint32_t* host_r
 #endif
 // NR: un-stuffing rings per worker wavefront -- 1: one ring, every slice of a block re-un-stuffs from the latest chunk
 // boundary below its first bit; > 1: a ring per block (per_wave <= NR), a slice goes on where the one before stopped.
-// PAIR: the workers decode two blocks to a wavefront, a lane per quad (step2_pair); NR = blocks (rings) per worker
-// wavefront, an even number, per_wave = pairs per wavefront
-template <int TX, int CH, int WGW, int NR, bool PAIR = false>   // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
+template <int TX, int CH, int WGW, int NR>            // WGW wavefronts per workgroup: 3 CH of them work in the step-1 role, all in the worker role
 __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(6))) void ht_dec_fused_kernel(   // (two workgroups to a CU: six wavefronts per SIMD, 80 registers)
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status,
@@ -1663,7 +1380,7 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(6))) v
   constexpr uint32_t EV_OFF = 2048 + 160, VR_OFF = EV_OFF + CH * EV_RING * 64, CTL_OFF = VR_OFF + CH * VR_WORDS * 64;
   constexpr uint32_t REC_OFF = CTL_OFF + CH * 5 * 64;                       // a row of pair words per chain wavefront (flush_row16)
   constexpr uint32_t CHAIN_WORDS = REC_OFF + CH * REC16_ROW_WORDS * 64;
-  constexpr uint32_t WORKER_WORDS = PAIR ? NR * PAIR_BLOCK_WORDS : NR * RING_ALLOC + S2_MAX_PER_WAVE * S2_STATE_WORDS;
+  constexpr uint32_t WORKER_WORDS = NR * RING_ALLOC + S2_MAX_PER_WAVE * S2_STATE_WORDS;
   constexpr uint32_t LDS_WORDS = CHAIN_WORDS > WGW * WORKER_WORDS ? CHAIN_WORDS : WGW * WORKER_WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDS_WORDS];
   uint32_t* const s_vlc = s_mem;                            // dec_vlc32: 2 x 1024 entries
@@ -1713,47 +1430,6 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(6))) v
   if (threadIdx.x == 0) g_tl_flags = fstate;
 #endif
 
-  if (PAIR && wgid >= n1) {                                 // ---- a step-2 worker wavefront, two blocks at a time: `per_wave` PAIRS of blocks, slice by slice ----
-    if (dbg & 1u) return;
-    uint32_t* wlds = s_mem + wv * WORKER_WORDS;
-    const uint32_t wave_no = (wgid - n1) * (uint32_t)WGW + wv;
-    const uint32_t npairs = (n + 1u) >> 1;
-    const uint32_t nwaves = (npairs + per_wave - 1u) / per_wave;          // (pair j of this wavefront: number wave_no + j nwaves, as the blocks of the other form)
-    if (wave_no >= nwaves) return;
-    uint32_t np = 0;
-    while (np < per_wave && wave_no + np * nwaves < npairs) ++np;
-    for (uint32_t k = 0; k < np; ++k)                         // what does not depend on the chains, before the first wait
-      step2_pair<TX, 0>(blocks, n, 2u * (wave_no + k * nwaves), data, quads, coef, block_status, wlds + k * 2u * PAIR_BLOCK_WORDS, lane, 0u, 0u);
-    uint32_t wave_slot, prio_it = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
-    for (uint32_t sl = 0; sl < sched.n; ++sl) {
-      uint32_t q0, q1;
-      sched.bounds(sl, q0, q1);
-      const uint32_t flv = (lane < np && !(dbg & 2u)) ? ld_agent(fstate + ((2u * (wave_no + lane * nwaves)) >> 6)) : 0u;
-      for (uint32_t k = 0; k < np; ++k) {
-        const uint32_t bA = 2u * (wave_no + k * nwaves);
-        // rows of the slice that the pair's chain wavefront has to have published: of the taller of its coded blocks
-        uint32_t need = 0;
-        for (uint32_t j = 0; j < 2u && bA + j < n; ++j) {
-          const uint32_t hj = blocks[bA + j].h, wj = blocks[bA + j].w, l1 = blocks[bA + j].len1, pj = blocks[bA + j].num_passes;
-          const uint32_t QHj = (hj + 1u) >> 1;
-          if (wj && hj && l1 && pj && q0 < QHj) need = max(need, q1 < QHj ? q1 : QHj);
-        }
-        bool there = true;
-        const uint32_t fl = rdlane(flv, (int)k);
-        if (!(dbg & 2u) && need != 0u && !((fl >> 16) == (epoch & 0xFFFFu) && (fl & 0xFFFFu) >= need))
-          there = (uint32_t)__builtin_amdgcn_readfirstlane((int)wait_rows(fstate + (bA >> 6), epoch, need, wait_ticks)) != 0u;
-        if ((dbg & 4u) && sl == 1u && (bA >> 1) % 61u == 7u) there = false;       // (test switch: this wait "ran out")
-        if (!there) {
-          if (lane == 0) ask_for_repeat(retry, host_retry, epoch);
-          return;
-        }
-        if ((prio_it++ % PRIO_PERIOD) < wave_slot) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        step2_pair<TX, 1>(blocks, n, bA, data, quads, coef, block_status, wlds + k * 2u * PAIR_BLOCK_WORDS, lane, q0, q1);
-      }
-    }
-    return;
-  }
   if (wgid >= n1) {                                         // ---- a step-2 worker wavefront: `per_wave` blocks, slice by slice ----
     if (dbg & 1u) return;                                   // (timing experiment: the chains alone)
     uint32_t* wlds = s_mem + wv * WORKER_WORDS;
@@ -2499,14 +2175,7 @@ bool dec_fuses() { return dec_fuse_mode() != 0; }
 // Shape: workgroups of 12 wavefronts, 4 chains (+ 8 partners) in the step-1 role, two per CU (OJPHGPU_FUSED_SHAPE=0:
 // 8 wavefronts, 2 chains, < 40 KB of LDS, four per CU = all 32 wavefront slots of a CU in use -- measured slower, 0.43
 // against 0.39 ms for the 8K frame: the chains lose more issue slots to eight wavefronts per SIMD than the workers gain).
-constexpr int S2_PAIR_BLOCKS = 6;             // pair form: blocks (rings) per worker wavefront
-// the workers' form: two blocks to a wavefront (step2_pair) unless OJPHGPU_FUSED_PAIR=0
-static bool fused_pairs()
-{
-  static const bool v = [] { const char* e = getenv("OJPHGPU_FUSED_PAIR"); return !e || atoi(e) != 0; }();
-  return v;
-}
-struct FusedShape { uint32_t shape, ch, wgw, n1, per_wave, wwgs; bool pair; };
+struct FusedShape { uint32_t shape, ch, wgw, n1, per_wave, wwgs; };
 static FusedShape fused_shape(uint32_t n, uint32_t cus)
 {
   static const uint32_t shape = [] { const char* e = getenv("OJPHGPU_FUSED_SHAPE"); return e ? (uint32_t)atoi(e) : 1u; }();
@@ -2520,15 +2189,6 @@ static FusedShape fused_shape(uint32_t n, uint32_t cus)
   uint32_t per_wave = (n + waves - 1u) / waves;
   f.per_wave = per_wave < 1u ? 1u : per_wave > S2_MAX_PER_WAVE ? S2_MAX_PER_WAVE : per_wave;
   f.wwgs = ((n + f.per_wave - 1u) / f.per_wave + f.wgw - 1u) / f.wgw;
-  f.pair = false;
-  if (shape == 1 && fused_pairs()) {                       // pairs of blocks: per_wave counts PAIRS, every worker resident with a ring per block
-    const uint32_t npairs = (n + 1u) >> 1;
-    const uint32_t ppw = (npairs + waves - 1u) / waves;
-    if (ppw >= 1u && 2u * ppw <= (uint32_t)S2_PAIR_BLOCKS) {
-      f.pair = true; f.per_wave = ppw;
-      f.wwgs = ((npairs + ppw - 1u) / ppw + f.wgw - 1u) / f.wgw;
-    }
-  }
   return f;
 }
 // compute units of a device (the decoder objects ask once, for THEIR device, and hand the number to the calls below)
@@ -2552,7 +2212,7 @@ bool ht_decode_fused_pays(uint32_t n, uint32_t max_h, uint32_t cus)
   if (dec_fuse_mode() == 0) return false;
   if (fused_shape(n, cus).n1 > (cus ? cus : 256u)) return false;   // (a step-1 workgroup per CU at most: the tickets)
   if (dec_fuse_mode() >= 2) return true;
-  return max_h > 32u && (fused_shape(n, cus).pair || fused_shape(n, cus).per_wave <= (uint32_t)S2_RINGS);
+  return max_h > 32u && fused_shape(n, cus).per_wave <= (uint32_t)S2_RINGS;
 }
 // step 1 + step 2 of n blocks, all of them at most 64 samples wide, of one wavelet (kinds as in ht_decode_step2_launch)
 // and without refinement passes; max_h = the tallest block; epoch: a number that differs from run to run on this scratch;
@@ -2582,14 +2242,10 @@ int ht_decode_fused_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
                                                  (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, max_qh, epoch, dbg, ticket_off, wait_ticks, d_host_retry)
   // a ring per block where the twelve wavefronts' rings fit the LDS the step-1 role needs anyway (OJPHGPU_FUSED_RINGS=1: never)
   static const bool rings = [] { const char* e = getenv("OJPHGPU_FUSED_RINGS"); return !e || atoi(e) != 1; }();
-#define FUSED_LAUNCH_PAIR(T) hipLaunchKernelGGL((ht_dec_fused_kernel<T, 4, 12, S2_PAIR_BLOCKS, true>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, \
-                                                 (uint32_t*)d_coef, d_block_status, d_state, n1, per_wave, max_qh, epoch, dbg, ticket_off, wait_ticks, d_host_retry)
-  if (f.pair) { if (tx == 1) FUSED_LAUNCH_PAIR(1); else FUSED_LAUNCH_PAIR(2); }
-  else if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }
+  if (shape == 1 && rings && per_wave <= (uint32_t)S2_RINGS) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, S2_RINGS); else FUSED_LAUNCH(2, 4, 12, S2_RINGS); }
   else if (shape == 1) { if (tx == 1) FUSED_LAUNCH(1, 4, 12, 1); else FUSED_LAUNCH(2, 4, 12, 1); }
   else                 { if (tx == 1) FUSED_LAUNCH(1, 2, 8, 1); else FUSED_LAUNCH(2, 2, 8, 1); }
 #undef FUSED_LAUNCH
-#undef FUSED_LAUNCH_PAIR
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 }  // namespace ojphgpu

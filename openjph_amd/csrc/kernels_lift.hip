@@ -29,8 +29,17 @@
 // Traffic: (2 N + 2) passes over the plane per level instead of one -- accepted for this path, see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/ojphgpu.h"
+
+namespace ojphgpu {
+// kernels_dwt.hip: the same level in ONE launch of the register pipeline, for kernels of up to four steps that transform
+// both directions
+bool dwt_general_pipeline_fits(const ojphgpu_lift* k);
+int dwt_general_pipeline(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                         void* d_base, bool synthesis);
+}
 
 namespace {
 
@@ -176,6 +185,11 @@ int run(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, ui
   if (!k || !d_descs || !d_base || k->num_steps > OJPHGPU_MAX_LIFT_STEPS || k->elem > 2) return OJPHGPU_E_INVALID;
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   for (uint32_t i = 0; i < k->num_steps; ++i) if (k->elem != 2 && (k->steps[i].e < 0 || k->steps[i].e > 255)) return OJPHGPU_E_INVALID;   // (an Eatk byte; counted modulo the sample width)
+  // the usual Part-2 kernels and the 5/3 on 64-bit samples go through the register pipeline (one launch per level);
+  // OJPHGPU_LIFT_ELEMENTWISE=1 keeps every level on the element-wise launches below (A/B runs, and the pin of the two forms
+  // against each other in tests/test_gpu_wide.py)
+  static const bool elementwise = [] { const char* e = getenv("OJPHGPU_LIFT_ELEMENTWISE"); return e && atoi(e) != 0; }();
+  if (!elementwise && ojphgpu::dwt_general_pipeline_fits(k)) return ojphgpu::dwt_general_pipeline(stream, k, d_descs, n, max_w, max_h, d_base, synthesis);
   hipStream_t s = (hipStream_t)stream;
   if (k->elem == 0) return level<int>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
   if (k->elem == 1) return level<long long>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);

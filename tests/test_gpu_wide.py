@@ -247,6 +247,13 @@ KERNELS = [
     ("irv97", np.float32, [0.443506852043971, 0.882911075530934, -0.052980118572961, -1.586134342059924], 1.230174104914001),
     ("irv-2steps", np.float32, [0.25, -0.5], 1.41421356),
     ("irv-3steps", np.float32, [0.2, -0.4, 0.1], 1.1),
+    # one to four steps that transform both directions take the register pipeline (kernels_dwt.hip: WvGen), the rest the
+    # element-wise launches (kernels_lift.hip): every step count of the one, a kernel beyond it for the other
+    ("rev-1step", np.int32, [(1, 1, 1)], 1.0),
+    ("rev-3steps-int64", np.int64, [(-1, 1, 1), (3, 4, 3), (1, 0, 2)], 1.0),
+    ("irv-1step", np.float32, [0.3], 0.9),
+    ("rev-5steps", np.int32, [(1, 2, 2), (-1, 1, 1), (1, 4, 3), (-1, 2, 2), (1, 1, 1)], 1.0),
+    ("irv-5steps", np.float32, [0.1, -0.2, 0.3, -0.15, 0.05], 1.05),
 ]
 
 

@@ -43,6 +43,14 @@ for d in ("gpurun_out/sq1", "gpurun_out/sq2"):
         for key, sub in (("ht_dec_step1", "ht_dec_step1"), ("ht_dec_prep", "ht_dec_prep"), ("ht_dec_fused(step 1 + step 2)", "ht_dec_fused_kernel")):
             if d.endswith("sq1") and sub in k:
                 out[key] = {"valu_insts": tot["SQ_INSTS_VALU"] / n, "salu_insts": tot["SQ_INSTS_SALU"] / n}
+        # second pass: what share of its wavefront-cycles a kernel spends parked at s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES, over
+        # all its launches): above one half the launch is latency-bound whatever its instruction count says
+        if d.endswith("sq2") and tot.get("SQ_WAVE_CYCLES"):
+            share = {"wait_share": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4), "issue_stall_share": round(tot["SQ_WAIT_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 4)}
+            for key, sub in (("ht_encode", "ht_encode_kernel"), ("ht_dec_fused(step 1 + step 2)", "ht_dec_fused_kernel"), ("ht_dec_step1", "ht_dec_step1"),
+                             ("ht_dec_step2", "ht_dec_step2")):
+                if sub in k:
+                    out.setdefault("_waits", {})[key] = share
 import os, sys
 sys.path.insert(0, os.getcwd())
 from openjph_amd.build import kernel_sources_digest
