@@ -334,8 +334,14 @@ def main():
         # step 1 and step 2 ran as ONE launch (chains first, step-2 workers behind them slice by slice): one entry with the
         # decoder's (c + 4) N; the records pass through memory once in each direction inside the launch (2 N intermediate)
         b1, _ = kernels.pop("ht_dec_step1"); b2, _ = kernels.pop("ht_dec_step2"); kernels.pop("ht_dec_prep")
-        kernels["ht_dec_fused(step 1 + step 2)"] = (b1 + b2, td["ht_step2_ms"])
-        intermediate = {"ht_dec_fused(step 1 + step 2)": 2.0 * ns}
+        if elem == 8.0:
+            # 64-bit samples: ht_decode64_launch's three launches (flat strings, step 1 on them, 64-bit step 2) under one span;
+            # the flat strings and the records are written once and read once
+            kernels["ht_dec64(prep + step 1 + step 2, three launches)"] = (b1 + b2, td["ht_step2_ms"])
+            intermediate = {"ht_dec64(prep + step 1 + step 2, three launches)": 2.0 * ns + 2.0 * c_rate * ns}
+        else:
+            kernels["ht_dec_fused(step 1 + step 2)"] = (b1 + b2, td["ht_step2_ms"])
+            intermediate = {"ht_dec_fused(step 1 + step 2)": 2.0 * ns}
     elif td["ht_prep_ms"] < 0.02:
         # separate launches without the prep launch (step 1's partner wavefronts read the MEL / VLC bytes as they are):
         # the prep span is empty
@@ -849,7 +855,7 @@ def pcie_bandwidth(torch, nbytes=256 << 20, reps=4):
     return out
 
 
-def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None, packed=None):
+def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None, packed=None, start=None):
     """n frames through an encoder pipe in steady state; every slot is filled once (the frame a capture device would
     have written there), later submissions send the slot again: each frame pays its H2D, kernels, Tier-2, D2H"""
     from openjph_amd.pipeline import EncoderPipe
@@ -871,6 +877,8 @@ def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None, 
         first = c if first is None else first
     if want is not None:
         assert first == want, "pipeline codestream differs from the one-frame encoder's"
+    if start is not None:
+        start.wait(300)                                # (both pipes at once: the timed regions begin together, after both have filled their slots)
     t0 = time.perf_counter()
     sub = col = 0
     nbytes = 0
@@ -885,7 +893,7 @@ def run_encoder_pipe(plan, img, n, depth=4, threads=2, container=16, want=None, 
     return dt, st
 
 
-def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None, packed=None):
+def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None, packed=None, start=None):
     from openjph_amd.pipeline import DecoderPipe
     pipe = DecoderPipe(cs, depth=depth, container=container, host_threads=threads, packed=packed)
     k = 0
@@ -905,6 +913,8 @@ def run_decoder_pipe(cs, n, depth=4, threads=2, container=16, want=None, packed=
             first = unpack_bits(first, packed, want.size).reshape(want.shape)
             want = np.clip(want.astype(np.int64), 0, (1 << packed) - 1)      # packing clamps (a 9/7 decode can leave 2^B)
         assert np.array_equal(first.astype(np.int64), want.astype(np.int64)), "pipeline frame differs from the one-frame decoder's"
+    if start is not None:
+        start.wait(300)
     t0 = time.perf_counter()
     sub = col = 0
     while col < n:
@@ -933,8 +943,9 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
     out["decode"] = {"Msamples_s": round(nsamp * n / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
                      "host_parse_ms": round(st["host_parse_ms"], 3), "latency_ms": round(st["latency_ms"], 2)}
     res = {}
-    te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container)))
-    td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container)))
+    gate = threading.Barrier(2)                            # filling an encoder pipe's slots takes longer than a decoder pipe's whole timed run
+    te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container, start=gate)))
+    td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container, start=gate)))
     t0 = time.perf_counter()
     te.start(); td.start(); te.join(); td.join()
     if "e" in res and "d" in res:
@@ -956,8 +967,9 @@ def e2e_pipelines(plan, img, cs, n, container, torch):
             out["bit_packed"] = {"bits_per_sample_on_pcie": bd, "encode_Msamples_s": pe, "decode_Msamples_s": round(nsamp * n / dt / 1e6, 1)}
             # ... and both directions at once (the transcoder case): the two directions share ~70 GB/s of link payload
             res = {}
-            te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container, packed=bd)))
-            td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container, packed=bd)))
+            gate = threading.Barrier(2)
+            te = threading.Thread(target=lambda: res.__setitem__("e", run_encoder_pipe(plan, img, n, depth, threads, container=container, packed=bd, start=gate)))
+            td = threading.Thread(target=lambda: res.__setitem__("d", run_decoder_pipe(cs, n, depth, threads, container=container, packed=bd, start=gate)))
             te.start(); td.start(); te.join(); td.join()
             if "e" in res and "d" in res:
                 wall = max(res["e"][0], res["d"][0])

@@ -51,8 +51,8 @@ struct HostBuf {
 // nc = 3: the batch holds the top levels of the three colour components of every tile, as triples, and the
 // component transform is applied inside the DWT kernel (kernels_dwt.hip); group: 0 all components, 1 the colour
 // components (0..2), 2 the others -- how a depth is split when the colour transform is fused
-// general: the levels of ONE component that needs the general lifting kernels (kernels_lift.hip: a Part-2 wavelet or
-// decomposition, or 64-bit samples) -- k describes the level
+// general: levels of components that need the general lifting kernels (a Part-2 wavelet or decomposition, or 64-bit samples;
+// kernels_dwt.hip's WvGen pipeline or kernels_lift.hip) -- k describes the level; components with equal k share a batch
 struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool general; ojphgpu_lift k; };
 
 // DWT descriptors grouped so that one launch handles every tile-component
@@ -124,7 +124,12 @@ void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_de
       // the level `depth` steps below the component's reconstructed top is decomposition level (skipped + depth + 1)
       LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, P.style(c).rev, -1, 1, 0, true, P.lift_of(c, P.skip_recon + depth + 1) };
       for_levels_of(P, tr, depth, P.style(c).rev, 0, (int)c, [&](const ojphgpu_level_info& lv) { push_level_desc(lv, descs, b); });
-      if (b.count) batches.push_back(b);
+      if (!b.count) continue;
+      // components that share a kernel and a kind of level (the usual case: one ATK for the whole codestream) share the launch
+      LevelBatch* prev = batches.empty() ? nullptr : &batches.back();
+      if (prev && prev->general && prev->depth == depth && prev->first + prev->count == b.first && memcmp(&prev->k, &b.k, sizeof(b.k)) == 0) {
+        prev->count += b.count; prev->max_w = std::max(prev->max_w, b.max_w); prev->max_h = std::max(prev->max_h, b.max_h);
+      } else batches.push_back(b);
     }
   }
 }

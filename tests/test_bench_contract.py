@@ -126,3 +126,10 @@ def test_two_ranks_self_launched_on_one_gpu():
     assert s["n_gpus"] == 2 and s["tiles_per_rank"] == [128, 128] and len(s["per_rank_ms_per_step"]) == 2
     assert s["codestream_equals_reference_digest"] is True and s["tiles_lossless_on_every_rank"] is True
     assert s["gather"]["bytes_received_by_rank0"] > 100e6 and s["value"] > 0
+    # the two end-to-end forms of the gather: tile-parts sent to rank 0 (gatherv), and every rank placing its own in ONE shared
+    # host segment (shard.HostGather, the default of shard.encode_sharded on one node) -- both must be the reference's bytes
+    e = s["e2e_encode"]
+    assert e["codestream_equals_reference_digest"] is True and e["ms"] > 0
+    hs = e["shared_host_segment"]
+    assert "error" not in hs, hs
+    assert hs["codestream_equals_reference_digest"] is True and hs["ms"] > 0 and hs["Msamples_s"] > 0

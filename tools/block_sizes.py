@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device-resident encode / decode time of the 8K bench frame for several code-block sizes.   python tools/block_sizes.py"""
+"""Device-resident encode / decode time of the 8K bench frame for several code-block sizes.   python tools/block_sizes.py [64x64 32x32 ...]"""
 import os
 import sys
 
@@ -17,7 +17,8 @@ def main():
     w, h, nc, bd, rev, ct, qstep, tile = WORKLOADS[name]
     img = workload_image(name)
     d = torch.from_numpy(img.astype(np.int16)).cuda()
-    for block in ((64, 64), (32, 32), (128, 32), (64, 32), (16, 16)):
+    blocks = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(64, 64), (32, 32), (128, 32), (64, 32), (16, 16)]
+    for block in blocks:
         plan = Plan(make_params(w, h, nc, bit_depth=bd, reversible=rev, qstep=qstep, block=block))
         enc = codec.Encoder(plan=plan)
         cs = enc.encode(d)
