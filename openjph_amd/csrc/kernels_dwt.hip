@@ -37,6 +37,8 @@
 #include <type_traits>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "../../include/ojphgpu.h"
 
 namespace {
@@ -716,6 +718,34 @@ dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h, int rp)
   return dim3((sx + 3) / 4, (npy + rp - 1) / rp, n);
 }
 
+// workgroups of `fn` (256 threads, no dynamic LDS) the device holds at once
+int resident_workgroups(const void* fn)
+{
+  static std::mutex mu; static std::map<const void*, int> known;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find(fn);
+  if (it != known.end()) return it->second;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  return known[fn] = per_cu * cus;
+}
+
+// row pairs per chunk for a latency-bound launch (the colour-fused top level): the height whose workgroups need the fewest
+// (rounds x rows walked per workgroup); a chunk walks its row pairs plus about three of halo / warm-up
+int fit_rounds(const void* fn, uint32_t planes, uint32_t max_w, uint32_t max_h)
+{
+  const uint64_t cap = (uint64_t)resident_workgroups(fn);
+  int best = 8; uint64_t best_cost = ~0ull;
+  for (int rp = 4; rp <= 24; rp += 2) {
+    const dim3 g = dwt_grid(planes, max_w, max_h, rp);
+    const uint64_t wgs = (uint64_t)g.x * g.y * g.z, rounds = (wgs + cap - 1) / cap;
+    const uint64_t cost = rounds * (uint64_t)(rp + 3);
+    if (cost < best_cost) { best_cost = cost; best = rp; }
+  }
+  return best;
+}
+
 // container: 0 = no image (arena planes only), 32 = int32 image samples, 16 / 8 = 16- / 8-bit image samples;
 // nc = 3: the descriptors come in triples (the colour planes of a tile), see the kernels
 template <bool FWD>
@@ -734,16 +764,19 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
     const int cap = FWD ? rp_fwd : rp_inv;
     if (cap && rp == MAX_ROW_PAIRS) rp = cap;
   }
-  if (nc == 3) {
-    // a colour wavefront carries three pipelines: a third of the wavefronts of the plain kernel, each three times as
-    // long -- shorter vertical chunks bring the wavefront count back (the extra halo rows are cheap here: the
-    // image side is 1-2 bytes per sample)
-    static const int rp3 = [] { const char* e = getenv("OJPHGPU_DWT_RP_COLOUR"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 64 ? v : 8; }();
-    rp = rp3;
-  }
-  const dim3 grid = dwt_grid(n / (uint32_t)nc, max_w, max_h, rp);
+  // a colour wavefront carries three pipelines: a third of the wavefronts of the plain kernel, each three times as long, at
+  // 94-139 registers (3-5 wavefronts per SIMD) -- a launch bound by latency, not by HBM, whose duration is (rounds of
+  // workgroups the chip needs) x (rows a workgroup walks).  The chunk height is chosen per launch so that the workgroups
+  // fill whole rounds (fit_rounds; the extra halo rows of short chunks are cheap here: the image side is 1-2 bytes per
+  // sample).  4K RGB frame, top level: forward 0.085 -> 0.071 ms (8 row pairs per chunk were 1.2 rounds of its 1 024
+  // resident workgroups, 12 are 0.8), profiles/r05_a_colour_chunks.txt.  OJPHGPU_DWT_RP_COLOUR fixes the height.
+  static const int rp3 = [] { const char* e = getenv("OJPHGPU_DWT_RP_COLOUR"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 64 ? v : 0; }();
+  if (nc == 3) rp = rp3 ? rp3 : 8;
+  dim3 grid = dwt_grid(n / (uint32_t)nc, max_w, max_h, rp);
   hipStream_t s = (hipStream_t)stream;
-#define OJPH_LAUNCH(K, REV, IMG, NC, TP) hipLaunchKernelGGL((K<Wv<REV>, IMG, NC>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, rp, Wv<REV>())
+#define OJPH_LAUNCH(K, REV, IMG, NC, TP) do { auto fn = K<Wv<REV>, IMG, NC>; \
+    if (NC == 3 && !rp3) { rp = fit_rounds((const void*)fn, n / 3u, max_w, max_h); grid = dwt_grid(n / 3u, max_w, max_h, rp); } \
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, rp, Wv<REV>()); } while (0)
 #define OJPH_LAUNCH_NC(K, REV, IMG, TP) do { if (nc == 3) OJPH_LAUNCH(K, REV, IMG, 3, TP); else OJPH_LAUNCH(K, REV, IMG, 1, TP); } while (0)
 #define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, 1, TP); else if (container == 16) OJPH_LAUNCH_NC(K, REV, 16, TP); \
                                          else if (container == 8) OJPH_LAUNCH_NC(K, REV, 8, TP); else OJPH_LAUNCH_NC(K, REV, 32, TP); } while (0)

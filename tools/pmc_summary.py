@@ -89,14 +89,14 @@ def main():
             out["ht_encode[lower resolutions]"] = traffic(enc, "small")
         else:
             out["ht_encode"] = traffic(enc)
-        # template arguments: <reversible, image container bits (0 = arena planes only)>
+        # template arguments: <wavelet policy (kernels_dwt.hip: Wv<reversible>), image container bits (0 = arena planes only), planes per wavefront>
         for d in ("forward", "inverse"):
             top = None
             for rev in ("false", "true"):                    # <reversible, container bits, planes per wavefront>
                 for bits in ("16", "32", "8"):
                     for nc in ("1", "3"):
-                        top = top or pick("dwt_%s_kernel<%s, %s, %s>" % (d, rev, bits, nc))
-            low = pick("dwt_%s_kernel<false, 0, 1>" % d) or pick("dwt_%s_kernel<true, 0, 1>" % d)
+                        top = top or pick("dwt_%s_kernel<(anonymous namespace)::Wv<%s>, %s, %s>" % (d, rev, bits, nc))
+            low = pick("dwt_%s_kernel<(anonymous namespace)::Wv<false>, 0, 1>" % d) or pick("dwt_%s_kernel<(anonymous namespace)::Wv<true>, 0, 1>" % d)
             if top and low:
                 nl = len(fe.get(low, [])) // max(len(fe.get(top, [])), 1)
                 out["dwt_%s(all levels)" % d] = traffic(top) + nl * traffic(low)
