@@ -351,10 +351,31 @@ __device__ __forceinline__ void arrived(const signed char& a, const signed char&
 // are read once, turned into Y, Cb, Cr rows in registers (RCT / ICT) and run through three vertical pipelines, so a
 // colour-transformed frame needs no conversion pass over HBM (descs[3 z .. 3 z + 2] = the planes' descriptors, which
 // share their geometry).
+// Which (strip group, vertical chunk) a workgroup takes.  The dispatcher deals workgroups to the eight XCDs in turn (linear id
+// mod 8), each XCD with an L2 of its own; with the grid's natural order the chunk below a chunk sits on the NEXT XCD, and the
+// rows the two share (the vertical halo: two row pairs on either side for the synthesis, a fifth of a 20-pair chunk) come in
+// through two L2s.  XCD_REMAP (bit 16 of the row_pairs argument): the workgroups an XCD receives walk a contiguous band of
+// chunk rows instead -- a permutation of the plane's workgroups, so whatever the dispatcher really does, every chunk is taken
+// exactly once.
+constexpr int XCD_REMAP = 1 << 16;
+__device__ __forceinline__ void dwt_block_coords(int row_pairs_arg, int& bx, int& by)
+{
+  bx = (int)blockIdx.x; by = (int)blockIdx.y;
+  const uint32_t T = gridDim.x * gridDim.y;
+  if (!(row_pairs_arg & XCD_REMAP) || T < 16u) return;
+  const uint32_t L = blockIdx.x + gridDim.x * blockIdx.y;
+  const uint32_t o = (T * blockIdx.z) & 7u;                  // the plane's first workgroup is number T z of the launch
+  const uint32_t r = (L + o) & 7u, q = T >> 3, rem = T & 7u;  // r: the XCD this workgroup is (most likely) on
+  uint32_t start = 0;
+  for (uint32_t k = 0; k < r; ++k) start += q + ((((k - o) & 7u) < rem) ? 1u : 0u);   // workgroups of this plane on the XCDs before r
+  const uint32_t V = start + (L >> 3);
+  bx = (int)(V % gridDim.x); by = (int)(V / gridDim.x);
+}
+
 template <class WP, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
-                                                          const void* __restrict__ image, Conv cv, int row_pairs, const WP w)
+                                                          const void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
 {
   typedef typename WP::T T;
   constexpr bool REV = WP::REV;
@@ -367,12 +388,15 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  const int strip_x = blockIdx.x * 4 + wave;
+  int bx, by;
+  dwt_block_coords(row_pairs_arg, bx, by);
+  const int row_pairs = row_pairs_arg & 0xFFFF;
+  const int strip_x = bx * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
   const Geo g = make_geo(d, strip_x, lane);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
-  const int i0 = blockIdx.y * row_pairs;
+  const int i0 = by * row_pairs;
   if (i0 >= npy) return;
   const int i1 = min(i0 + row_pairs, npy);
 
@@ -577,7 +601,7 @@ __device__ __forceinline__ void store_rows(char* const* dst, size_t off, const G
 template <class WP, int IMG, int NC>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
-                                                          void* __restrict__ image, Conv cv, int row_pairs, const WP w)
+                                                          void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
 {
   typedef typename WP::T T;
   constexpr bool REV = WP::REV;
@@ -588,12 +612,15 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const ojphgpu_dwt_desc d = descs[blockIdx.z * NC];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler knows it
-  const int strip_x = blockIdx.x * 4 + wave;
+  int bx, by;
+  dwt_block_coords(row_pairs_arg, bx, by);
+  const int row_pairs = row_pairs_arg & 0xFFFF;
+  const int strip_x = bx * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
   const Geo g = make_geo(d, strip_x, lane);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
-  const int i0 = blockIdx.y * row_pairs;
+  const int i0 = by * row_pairs;
   if (i0 >= npy) return;
   const int i1 = min(i0 + row_pairs, npy);
 
@@ -711,6 +738,14 @@ int pick_row_pairs(uint32_t n, uint32_t max_w, uint32_t max_h)
   return (int)rp;
 }
 
+// the row_pairs argument of a launch: the height, and whether the workgroups take their chunks XCD by XCD (dwt_block_coords;
+// OJPHGPU_DWT_XCD=0 keeps the grid's own order)
+int row_pairs_arg(int rp)
+{
+  static const bool xcd = [] { const char* e = getenv("OJPHGPU_DWT_XCD"); return !e || atoi(e) != 0; }();
+  return rp | (xcd ? XCD_REMAP : 0);
+}
+
 dim3 dwt_grid(uint32_t n, uint32_t max_w, uint32_t max_h, int rp)
 {
   uint32_t npx = (max_w + 2) >> 1, npy = (max_h + 2) >> 1;
@@ -776,7 +811,7 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   hipStream_t s = (hipStream_t)stream;
 #define OJPH_LAUNCH(K, REV, IMG, NC, TP) do { auto fn = K<Wv<REV>, IMG, NC>; \
     if (NC == 3 && !rp3) { rp = fit_rounds((const void*)fn, n / 3u, max_w, max_h); grid = dwt_grid(n / 3u, max_w, max_h, rp); } \
-    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, rp, Wv<REV>()); } while (0)
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, row_pairs_arg(rp), Wv<REV>()); } while (0)
 #define OJPH_LAUNCH_NC(K, REV, IMG, TP) do { if (nc == 3) OJPH_LAUNCH(K, REV, IMG, 3, TP); else OJPH_LAUNCH(K, REV, IMG, 1, TP); } while (0)
 #define OJPH_LAUNCH_IMG(K, REV, TP) do { if (!d_image) OJPH_LAUNCH(K, REV, 0, 1, TP); else if (container == 16) OJPH_LAUNCH_NC(K, REV, 16, TP); \
                                          else if (container == 8) OJPH_LAUNCH_NC(K, REV, 8, TP); else OJPH_LAUNCH_NC(K, REV, 32, TP); } while (0)
@@ -810,8 +845,8 @@ int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc*
   const int rp = pick_row_pairs(n, max_w, max_h);
   const dim3 grid = dwt_grid(n, max_w, max_h, rp);
   const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
-  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, rp, w);
-  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, rp, w);
+  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
+  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
