@@ -1286,6 +1286,239 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 
 
 // -------------------------------------------------------------------------------------------------
+// step 2 with TWO code-blocks of at most 32 columns to a wavefront (the IMF profiles' 32 x 32 blocks)
+// -------------------------------------------------------------------------------------------------
+// step2_block maps the columns of ONE block onto the lanes: with blocks of 32 columns half of the wavefront idles through
+// every row.  Here lanes 0..31 are the columns of block bA and lanes 32..63 those of block bA + 1: one pass over the quad rows
+// decodes both.  What is wave-uniform in step2_block -- the MagSgn positions, the un-stuffer's state, the verdict -- is uniform
+// per HALF here (vector registers whose 32 lanes agree), the prefix sums stop at the half's end, each half has its ring.
+// Launches whose blocks are ALL at most 32 columns wide, without refinement passes, take this kernel (ht_decode_step2_launch,
+// kinds bit 6 clear).  Per block the arithmetic is step2_block's: ojph_block_decoder32.cpp:1091-1316.
+constexpr uint32_t DUAL_ROW_BITS = 32 * 2 * 32;                  // a quad row of 32 columns consumes at most this many bits
+
+// inclusive prefix sum inside each half of the wavefront (lanes 0..31, 32..63)
+__device__ __forceinline__ uint32_t half_incl_scan(uint32_t v)
+{
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3: the second 16 lanes of each half
+  return (uint32_t)x;
+}
+
+template <int TX>
+__device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, uint32_t bA,
+                                           const uint8_t* __restrict__ data, const uint32_t* __restrict__ quads,
+                                           uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status, uint32_t* rings, int lane)
+{
+  static_assert(TX == 1 || TX == 2, "one wavelet per launch, no refinement passes");
+  const bool hb = lane >= 32;                                    // the lane's half: block bA or block bA + 1
+  const uint32_t l32 = (uint32_t)lane & 31u;                     // = the lane's column in its block
+  const bool haveB = bA + 1u < n;
+  const ojphgpu_cb_desc dA = blocks[bA], dB = blocks[haveB ? bA + 1u : bA];
+  const uint32_t bi = bA + (hb ? 1u : 0u);
+#define DSEL(f) (hb ? (uint32_t)dB.f : (uint32_t)dA.f)
+  const uint32_t W = DSEL(w), H = DSEL(h), pitch = DSEL(pitch), lcup = DSEL(len1), npass = DSEL(num_passes);
+  const uint32_t missing_msbs = DSEL(missing_msbs), K = DSEL(K_max), rec_off = DSEL(scratch_cap);
+#undef DSEL
+  const float delta = hb ? dB.delta : dA.delta;
+  const uint64_t coef_off = hb ? dB.coef_off : dA.coef_off, data_off = hb ? dB.data_off : dA.data_off;
+  const bool rev = TX == 1;
+  const uint32_t QW = (W + 1u) >> 1, QH = (H + 1u) >> 1, PW = (QW + 1u) >> 1;
+  uint32_t* ring = rings + (hb ? RING_ALLOC : 0u);
+  uint32_t* dst = coef + coef_off;
+  const uint8_t* cb = data + data_off;
+  const uint32_t* rec = quads + rec_off;
+  const bool exists = (!hb || haveB) && W != 0u && H != 0u && W <= 32u && !((hb ? dB.reversible : dA.reversible) & 4u);
+  const bool coded = exists && lcup != 0u && npass != 0u;
+  const uint32_t p = 30u - missing_msbs, mmsbp2 = missing_msbs + 2u, shift = 31u - K;
+
+  auto zero_block = [&](bool which) {                            // (mem_clear, ojph_codeblock.cpp:247) by the lanes of the block's half
+    const uint32_t hv = which ? H : 0u;
+    const uint32_t hmax = max(rdlane(hv, 0), rdlane(hv, 32));    // (both halves walk the taller one's rows)
+    for (uint32_t y = 0; y < hmax; ++y)
+      if (which && y < H && l32 < W) dst[(size_t)y * pitch + l32] = 0u;
+  };
+
+  // the verdict of step 1 and the length of the MagSgn part (a one-byte segment has failed in step 1; its bytes are not used)
+  uint32_t st = 0, ms_len = 0;
+  if (coded) {
+    st = block_status[bi];
+    const uint32_t b1 = cb[lcup - 1u], b2 = cb[lcup >= 2u ? lcup - 2u : 0u];
+    ms_len = lcup - ((b1 << 4) + (b2 & 0xFu));
+  }
+  bool go = coded && st == 0u;                                   // this half decodes
+  {
+    const bool z = exists && !go;                                // not coded, or failed in step 1: the block is zero
+    if (__ballot(z) != 0ull) zero_block(z);
+  }
+  if (__ballot(go) == 0ull) return;
+  for (uint32_t i = l32; i < RING_ALLOC; i += 32u) ring[i] = 0;
+  wave_sync();
+
+  // ---- un-stuffs the next 128 MagSgn bytes of the halves whose lanes say `need` into their rings (step2_block's rule, :609-653) ----
+  uint32_t dst_bits = 0, src_pos = 0, mpos = 0;                  // per half: bits un-stuffed, bytes consumed, bits decoded
+  auto unstuff = [&](bool need) {
+    {
+      const uint32_t wb = (dst_bits + 31u) >> 5;                 // words above the current partial word are stale
+      const uint32_t z0 = (wb + l32) & RING_MASK;
+      if (need) { ring[z0] = 0; if (z0 < 2u) ring[z0 + RING_WORDS] = 0; }
+      if (need && l32 < 2u) { const uint32_t z1 = (wb + 32u + l32) & RING_MASK; ring[z1] = 0; if (z1 < 2u) ring[z1 + RING_WORDS] = 0; }
+    }
+    wave_sync();
+    const uint32_t i0 = src_pos + 4u * l32;
+    const bool in = need && i0 < ms_len;
+    const uint32_t word = in ? load_u32_unaligned(cb + i0) : 0u;
+    uint32_t pw = from_prev(word);
+    if (l32 == 0u) pw = (in && i0) ? load_u32_unaligned(cb + i0 - 4) : 0u;
+    asm volatile("" :: "v"(word), "v"(pw));                      // (both loads awaited here on every path, see step2_block)
+    uint32_t val = 0, nb = 0;
+    if (in) {
+      const uint32_t cnt = min(4u, ms_len - i0);
+      const uint32_t valid = cnt == 4u ? 0xFFFFFFFFu : (1u << (8u * cnt)) - 1u;
+      const uint32_t P = (word << 8) | (pw >> 24), P2 = (word << 16) | (pw >> 16);
+      auto is_ff = [](uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; };
+      const uint32_t S = is_ff(P) & valid;
+      const uint32_t stray = (is_ff(P2) >> 7) & (P >> 7) & 0x01010101u;
+      uint32_t x = ((word | stray) & valid) & ~S;
+      x = (S & 0x00800000u) ? (x & 0x007FFFFFu) | ((x >> 1) & 0xFF800000u) : x;
+      x = (S & 0x00008000u) ? (x & 0x00007FFFu) | ((x >> 1) & 0xFFFF8000u) : x;
+      x = (S & 0x00000080u) ? (x & 0x0000007Fu) | ((x >> 1) & 0xFFFFFF80u) : x;
+      val = x;
+      nb = 8u * cnt - (uint32_t)__popc(S);
+    }
+    const uint32_t incl = half_incl_scan(nb);
+    const uint32_t pos = dst_bits + incl - nb;
+    if (nb) {
+      const uint32_t w = pos >> 5, sh = pos & 31u;
+      const uint32_t wa = w & RING_MASK, wb2 = (w + 1u) & RING_MASK;
+      atomicOr(&ring[wa], val << sh);
+      if (wa < 2u) atomicOr(&ring[wa + RING_WORDS], val << sh);
+      if (sh + nb > 32u) { atomicOr(&ring[wb2], val >> (32u - sh)); if (wb2 < 2u) atomicOr(&ring[wb2 + RING_WORDS], val >> (32u - sh)); }
+    }
+    const uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);
+    if (need) { dst_bits += hb ? tB : tA; src_pos += 128u; }
+    wave_sync();
+  };
+
+  const uint32_t half = l32 & 1u;
+  const bool edgeL = l32 == 0u, edgeR = l32 == 31u;
+  const bool col_in = l32 < W;
+  auto rec_at = [&](uint32_t qy_) -> uint32_t {
+    return *(rec + (size_t)(qy_ * PW + (l32 >> 2)) * REC_STRIDE + ((l32 >> 1) & 1u));
+  };
+  uint32_t e_prev = 0;                                           // exponent of this column's bottom sample, row above
+  bool failed = false;                                           // this half met a row it cannot decode (:1114, :1224)
+  uint32_t ent_next = (go && col_in) ? rec_at(0) : 0u;           // records are fetched one step ahead
+  asm volatile("" : "+v"(ent_next));
+  const uint32_t qh_go = go ? QH : 0u;
+  const uint32_t qy_end = max(rdlane(qh_go, 0), rdlane(qh_go, 32));
+  for (uint32_t qy = 0; qy < qy_end; ++qy) {
+    bool rowon = go && qy < QH;
+    if (__ballot(rowon) == 0ull) break;
+    for (;;) {
+      const bool need = rowon && src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)(DUAL_ROW_BITS + 64u);
+      if (__ballot(need) == 0ull) break;
+      unstuff(need);
+    }
+    const bool exhausted = src_pos >= ms_len;                    // then bits at and beyond dst_bits read as 1 (:609-632)
+    const bool act = rowon && col_in;
+    const uint32_t ent = ent_next;
+    ent_next = (go && col_in && qy + 1u < QH) ? rec_at(qy + 1u) : 0u;
+    const uint32_t inf = act ? (ent & 0xFFFFu) : 0u;
+    uint32_t U_q = act ? ent >> 16 : 0u;
+    if (qy > 0) {
+      uint32_t gamma = inf & 0xF0u;
+      gamma &= gamma - 0x10u;                                                            // :1218
+      // even lane 2k: max(e[2k-1], e[2k]); odd lane 2k+1: max(e[2k+1], e[2k+2]); then the pair's two halves together --
+      // the columns beside a block's first and last one do not exist (the other block's lanes sit there)
+      const uint32_t e_nx = edgeR ? 0u : from_next(e_prev), e_pv = edgeL ? 0u : from_prev(e_prev);
+      const uint32_t hm = max(e_prev, half ? e_nx : e_pv);
+      const uint32_t em = max(hm, from_pair(hm));
+      U_q += gamma ? max(em, 1u) : 1u;                                                   // :1219-1223
+      if (!act) U_q = 0u;
+    }
+    {
+      const uint64_t over = __ballot(act && U_q > mmsbp2);                               // :1114, :1224
+      const bool mine = ((hb ? (uint32_t)(over >> 32) : (uint32_t)over) != 0u);
+      if (mine) { failed = true; go = false; rowon = false; }
+    }
+    const bool actr = rowon && col_in;
+    const uint32_t sel = inf >> (2u * half);
+    const bool sg0 = actr && (sel & 0x10u) != 0u, sg1 = actr && (sel & 0x20u) != 0u;
+    const uint32_t ek0 = (sel >> 12) & 1u, ek1 = (sel >> 13) & 1u;
+    const uint32_t eb0 = (sel >> 8) & 1u, eb1 = (sel >> 9) & 1u;
+    const uint32_t m0 = sg0 ? U_q - ek0 : 0u;
+    const uint32_t m1 = sg1 ? U_q - ek1 : 0u;
+    const uint32_t tot = m0 + m1;
+    const uint32_t incl = half_incl_scan(tot);
+    const uint32_t at = mpos + incl - tot;
+    {
+      const uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);
+      mpos += hb ? tB : tA;
+    }
+    const uint32_t wi = at >> 5, sh = at & 31u;
+    const uint32_t* rw = ring + (wi & RING_MASK);
+    const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];           // (rw[1], rw[2] may be the copies behind the ring)
+    uint64_t win = (uint64_t)__funnelshift_r(w0, w1, sh) | ((uint64_t)__funnelshift_r(w1, w2, sh) << 32);
+    if (exhausted) {
+      if (at >= dst_bits) win = ~0ull;
+      else if (at + 64u > dst_bits) win |= ~0ull << (dst_bits - at);
+    }
+    uint32_t out0, out1, v1;
+    {
+      const uint32_t ms_val = (uint32_t)win;
+      uint32_t v_n = ms_val & ((1u << m0) - 1u);                                         // :1127-1133
+      v_n |= eb0 << m0;
+      v_n |= 1u;
+      const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1u))) & (sg0 ? 0xFFFFFFFFu : 0u);
+      out0 = dequantise(val, rev, shift, delta);
+    }
+    {
+      const uint32_t ms_val = __builtin_amdgcn_alignbit((uint32_t)(win >> 32), (uint32_t)win, m0);   // (uint32_t)(win >> m0): m0 <= U_q <= 31
+      uint32_t v_n = ms_val & ((1u << m1) - 1u);
+      v_n |= eb1 << m1;
+      v_n |= 1u;
+      const uint32_t keep = sg1 ? 0xFFFFFFFFu : 0u;
+      const uint32_t val = ((ms_val << 31) | ((v_n + 2u) << (p - 1u))) & keep;
+      v1 = v_n & keep;
+      out1 = dequantise(val, rev, shift, delta);
+    }
+    e_prev = v1 ? 31u - (uint32_t)__clz((int)v1) : 0u;
+    asm volatile("" : "+v"(ent_next));                           // the next record is taken into its register before this row's stores (see step2_block)
+    if (actr) {
+      const uint32_t y = 2u * qy;
+      uint32_t* o = dst + (size_t)y * pitch + l32;
+      o[0] = out0;
+      if (y + 1u < H) o[pitch] = out1;
+    }
+  }
+  if (__ballot(failed) != 0ull) {
+    zero_block(failed);
+    if (failed && l32 == 0u) block_status[bi] = 1;
+  }
+}
+
+template <int TX>
+__global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_dual_kernel(
+    const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
+    const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
+{
+  __shared__ uint32_t s_ring[WAVES][2 * RING_ALLOC];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // consecutive blocks to ONE XCD, as in ht_dec_step2_kernel (their records share cache lines)
+  const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, xcd = blockIdx.x & 7u;
+  const uint32_t wg = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+  const uint32_t bA = 2u * (wg * WAVES + wave);
+  if (bA >= n) return;
+  step2_dual<TX>(blocks, n, bA, data, quads, coef, block_status, s_ring[wave], lane);
+}
+
+
+// -------------------------------------------------------------------------------------------------
 // step 1 and step 2 in ONE launch: chains first, step-2 workers behind them, slice by slice
 // -------------------------------------------------------------------------------------------------
 // Step 1 is a latency floor: the serial chain of a code-block takes 0.2 ms however many blocks there are, and while the
@@ -2139,7 +2372,8 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
 
 namespace ojphgpu {
 // kinds: what the caller knows about the blocks of the range (0 = nothing): bit 0 blocks of at most 64 columns occur,
-// bit 1 wider ones, bit 2 reversible ones, bit 3 irreversible ones, bit 4 blocks with SigProp / MagRef passes
+// bit 1 wider ones, bit 2 reversible ones, bit 3 irreversible ones, bit 4 blocks with SigProp / MagRef passes, bit 6
+// blocks of more than 32 columns occur (with bit 0 set and bit 6 clear every block is at most 32 columns wide)
 int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
                            const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds)
 {
@@ -2147,6 +2381,14 @@ int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
   const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
   const int wd = (kinds & 3) == 1 ? 1 : 0;
+  // two blocks to a wavefront where every block of the range is at most 32 columns wide (kinds bit 6 clear; OJPHGPU_DEC_DUAL=0: never)
+  static const bool dual_on = [] { const char* e = getenv("OJPHGPU_DEC_DUAL"); return !e || atoi(e) != 0; }();
+  if (dual_on && !(kinds & 64) && wd && (tx == 1 || tx == 2)) {
+    const dim3 g2(((n + 1) / 2 + WAVES - 1) / WAVES), wg2(64 * WAVES);
+    if (tx == 1) hipLaunchKernelGGL(ht_dec_step2_dual_kernel<1>, g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
+    else hipLaunchKernelGGL(ht_dec_step2_dual_kernel<2>, g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
+    return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+  }
   const dim3 grid((n + WAVES - 1) / WAVES), wg(64 * WAVES);
 #define STEP2_LAUNCH(T, W) hipLaunchKernelGGL((ht_dec_step2_kernel<T, W>), grid, wg, 0, (hipStream_t)stream, d_blocks, n, d_data, \
                                               d_quad_scratch, (uint32_t*)d_coef, d_block_status)

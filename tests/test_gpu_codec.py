@@ -625,3 +625,62 @@ print("OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"OJPHGPU_DEC_DUAL": "0"}], ids=["two-blocks-per-wavefront", "one"])
+def test_blocks_of_at_most_32_columns(env):
+    """frames whose code-blocks are all at most 32 columns wide take step 2 with TWO blocks to a wavefront (lanes 0..31 one
+    block, 32..63 the next: ht_dec_step2_dual_kernel; OJPHGPU_DEC_DUAL=0 keeps one block per wavefront): the oracle's samples
+    for square, tall, flat and tiny blocks, ragged right / bottom blocks (odd widths and heights), an odd number of blocks,
+    blocks that are not coded (a flat component), lossless and lossy, tiles, sub-sampled components -- and the same verdicts
+    as the oracle pipeline on streams whose block bytes are damaged (ojph_block_decoder32.cpp:1091-1316 per block)"""
+    import subprocess, sys
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openjph_amd import codec
+from tests import cpu_pipeline as cp
+from tests.synth import synth_image
+from openjph_amd.plan import parse_codestream
+cases = ((dict(bit_depth=8, block=(32, 32)), (1, 333, 517)), (dict(bit_depth=12, block=(32, 32), reversible=False, qstep=0.002, tile=(256, 192)), (3, 401, 611)),
+         (dict(bit_depth=10, block=(32, 64), num_decomps=2), (1, 259, 301)), (dict(bit_depth=8, block=(16, 256), num_decomps=2), (1, 1021, 90)),
+         (dict(bit_depth=9, block=(8, 512), num_decomps=1, reversible=False, qstep=0.01), (2, 1500, 40)), (dict(bit_depth=8, block=(32, 8), num_decomps=3), (1, 97, 203)),
+         (dict(bit_depth=8, block=(4, 4), num_decomps=2), (1, 37, 41)), (dict(bit_depth=8, block=(16, 16), num_decomps=5, color_transform=True), (3, 130, 94)),
+         (dict(bit_depth=8, block=(32, 32), num_decomps=1), (1, 33, 31)), (dict(bit_depth=8, block=(32, 32), num_decomps=0), (1, 21, 32)))
+for kw, shape in cases:
+    img = synth_image(shape[0], shape[1], shape[2], kw["bit_depth"], seed=17)
+    if shape[0] == 2:
+        img[1] = 7                                     # a flat component: most of its blocks are not coded
+    cs = codec.encode(img, **kw)
+    want, _ = cp.decode(cs)
+    dec = codec.Decoder(cs)
+    for _ in range(2):
+        got = dec.run_device().cpu().numpy()
+        assert dec.failed_blocks() == 0 and np.array_equal(got, want), kw
+# damaged block bytes: the same blocks refused, the same picture from the resilient read
+rng = np.random.default_rng(23)
+img = synth_image(1, 200, 300, 8, seed=3)
+cs = bytearray(codec.encode(img, bit_depth=8, block=(32, 32), num_decomps=3))
+sod = cs.index(b"\xff\x93") + 2
+bad = 0
+for trial in range(24):
+    c2 = bytearray(cs)
+    for _ in range(6):
+        at = int(rng.integers(sod + 40, len(c2) - 2)); c2[at] = int(rng.integers(0, 256))
+    try:
+        plan = parse_codestream(bytes(c2), resilient=True)
+        want = cp.inverse_stages(plan, cp.decode_blocks(plan, bytes(c2), resilient=True))
+    except Exception:
+        continue
+    try:
+        dec = codec.Decoder(bytes(c2), resilient=True)
+        got = dec.run_device().cpu().numpy()
+    except Exception as e:
+        raise AssertionError("the oracle pipeline reads this stream, the device path raised: %%r" %% (e,))
+    assert np.array_equal(got, want), trial
+    bad += dec.failed_blocks() != 0
+print("OK", bad)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stderr[-2000:]
