@@ -1286,60 +1286,93 @@ __global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_kernel(
 
 
 // -------------------------------------------------------------------------------------------------
-// step 2 with TWO code-blocks of at most 32 columns to a wavefront (the IMF profiles' 32 x 32 blocks)
+// step 2 with TWO code-blocks of at most 32 columns, or FOUR of at most 16, to a wavefront (the IMF profiles' 32 x 32 blocks)
 // -------------------------------------------------------------------------------------------------
 // step2_block maps the columns of ONE block onto the lanes: with blocks of 32 columns half of the wavefront idles through
-// every row.  Here lanes 0..31 are the columns of block bA and lanes 32..63 those of block bA + 1: one pass over the quad rows
-// decodes both.  What is wave-uniform in step2_block -- the MagSgn positions, the un-stuffer's state, the verdict -- is uniform
-// per HALF here (vector registers whose 32 lanes agree), the prefix sums stop at the half's end, each half has its ring.
-// Launches whose blocks are ALL at most 32 columns wide, without refinement passes, take this kernel (ht_decode_step2_launch,
-// kinds bit 6 clear).  Per block the arithmetic is step2_block's: ojph_block_decoder32.cpp:1091-1316.
-constexpr uint32_t DUAL_ROW_BITS = 32 * 2 * 32;                  // a quad row of 32 columns consumes at most this many bits
+// every row.  Here the wavefront is cut into NB segments of LPB = 64 / NB lanes, segment k holding the columns of block
+// bA + k: one pass over the quad rows decodes them all.  What is wave-uniform in step2_block -- the MagSgn positions, the
+// un-stuffer's state, the verdict -- is uniform per SEGMENT here (vector registers whose LPB lanes agree), the prefix sums stop
+// at the segment's end, each segment has its ring.  Launches whose blocks are ALL at most 32 (16) columns wide, without
+// refinement passes, take this kernel (ht_decode_step2_launch, kinds bits 6 and 7 clear).  Per block the arithmetic is
+// step2_block's: ojph_block_decoder32.cpp:1091-1316.
 
-// inclusive prefix sum inside each half of the wavefront (lanes 0..31, 32..63)
-__device__ __forceinline__ uint32_t half_incl_scan(uint32_t v)
+// inclusive prefix sum inside each segment of LPB lanes (32: lanes 0..31, 32..63; 16: the four DPP rows)
+template <int LPB>
+__device__ __forceinline__ uint32_t seg_incl_scan(uint32_t v)
 {
   int x = (int)v;
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
   x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
   x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
   x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3: the second 16 lanes of each half
+  if (LPB == 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3: the second 16 lanes of each half
   return (uint32_t)x;
 }
+// the value lane LPB - 1 of the lane's own segment holds (a segment's total after seg_incl_scan)
+template <int LPB>
+__device__ __forceinline__ uint32_t seg_last(uint32_t v, uint32_t seg)
+{
+  if (LPB == 32) { const uint32_t a = rdlane(v, 31), b = rdlane(v, 63); return seg ? b : a; }
+  const uint32_t a = rdlane(v, 15), b = rdlane(v, 31), c = rdlane(v, 47), d = rdlane(v, 63);
+  return seg & 2u ? (seg & 1u ? d : c) : (seg & 1u ? b : a);
+}
+// the part of a ballot that belongs to the lane's segment
+template <int LPB>
+__device__ __forceinline__ uint32_t seg_bits(uint64_t m, uint32_t seg)
+{
+  return (uint32_t)(m >> (seg * (uint32_t)LPB)) & (LPB == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+}
 
-template <int TX>
-__device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, uint32_t bA,
-                                           const uint8_t* __restrict__ data, const uint32_t* __restrict__ quads,
-                                           uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status, uint32_t* rings, int lane)
+template <int TX, int NB>
+__device__ __forceinline__ void step2_multi(const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, uint32_t bA,
+                                            const uint8_t* __restrict__ data, const uint32_t* __restrict__ quads,
+                                            uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status, uint32_t* rings, int lane)
 {
   static_assert(TX == 1 || TX == 2, "one wavelet per launch, no refinement passes");
-  const bool hb = lane >= 32;                                    // the lane's half: block bA or block bA + 1
-  const uint32_t l32 = (uint32_t)lane & 31u;                     // = the lane's column in its block
-  const bool haveB = bA + 1u < n;
-  const ojphgpu_cb_desc dA = blocks[bA], dB = blocks[haveB ? bA + 1u : bA];
-  const uint32_t bi = bA + (hb ? 1u : 0u);
-#define DSEL(f) (hb ? (uint32_t)dB.f : (uint32_t)dA.f)
-  const uint32_t W = DSEL(w), H = DSEL(h), pitch = DSEL(pitch), lcup = DSEL(len1), npass = DSEL(num_passes);
-  const uint32_t missing_msbs = DSEL(missing_msbs), K = DSEL(K_max), rec_off = DSEL(scratch_cap);
-#undef DSEL
-  const float delta = hb ? dB.delta : dA.delta;
-  const uint64_t coef_off = hb ? dB.coef_off : dA.coef_off, data_off = hb ? dB.data_off : dA.data_off;
+  static_assert(NB == 2 || NB == 4, "two blocks of 32 columns or four of 16");
+  constexpr int LPB = 64 / NB;
+  constexpr uint32_t ROW_BITS = (uint32_t)LPB * 2u * 32u;        // a quad row of LPB columns consumes at most this many bits
+  const uint32_t seg = (uint32_t)lane / (uint32_t)LPB;           // the lane's segment: block bA + seg
+  const uint32_t ll = (uint32_t)lane & (uint32_t)(LPB - 1);      // = the lane's column in its block
+  const uint32_t bi = bA + seg;
+  const bool have = bi < n;
+  // the blocks' descriptors arrive as scalars; every lane keeps its segment's
+  uint32_t W, H, pitch, lcup, npass, missing_msbs, K, rec_off, flags;
+  float delta; uint64_t coef_off, data_off;
+  {
+    const ojphgpu_cb_desc d0 = blocks[bA], d1 = blocks[bA + 1u < n ? bA + 1u : bA];
+#define DSEL2(f) (seg & 1u ? d1.f : d0.f)
+    if (NB == 2) {
+      W = DSEL2(w); H = DSEL2(h); pitch = DSEL2(pitch); lcup = DSEL2(len1); npass = DSEL2(num_passes); missing_msbs = DSEL2(missing_msbs);
+      K = DSEL2(K_max); rec_off = DSEL2(scratch_cap); flags = DSEL2(reversible); delta = DSEL2(delta); coef_off = DSEL2(coef_off); data_off = DSEL2(data_off);
+    } else {
+      const ojphgpu_cb_desc d2 = blocks[bA + 2u < n ? bA + 2u : bA], d3 = blocks[bA + 3u < n ? bA + 3u : bA];
+#define DSEL4(f) (seg & 2u ? (seg & 1u ? d3.f : d2.f) : DSEL2(f))
+      W = DSEL4(w); H = DSEL4(h); pitch = DSEL4(pitch); lcup = DSEL4(len1); npass = DSEL4(num_passes); missing_msbs = DSEL4(missing_msbs);
+      K = DSEL4(K_max); rec_off = DSEL4(scratch_cap); flags = DSEL4(reversible); delta = DSEL4(delta); coef_off = DSEL4(coef_off); data_off = DSEL4(data_off);
+#undef DSEL4
+    }
+#undef DSEL2
+  }
   const bool rev = TX == 1;
   const uint32_t QW = (W + 1u) >> 1, QH = (H + 1u) >> 1, PW = (QW + 1u) >> 1;
-  uint32_t* ring = rings + (hb ? RING_ALLOC : 0u);
+  uint32_t* ring = rings + seg * RING_ALLOC;
   uint32_t* dst = coef + coef_off;
   const uint8_t* cb = data + data_off;
   const uint32_t* rec = quads + rec_off;
-  const bool exists = (!hb || haveB) && W != 0u && H != 0u && W <= 32u && !((hb ? dB.reversible : dA.reversible) & 4u);
+  const bool exists = have && W != 0u && H != 0u && W <= (uint32_t)LPB && !(flags & 4u);
   const bool coded = exists && lcup != 0u && npass != 0u;
   const uint32_t p = 30u - missing_msbs, mmsbp2 = missing_msbs + 2u, shift = 31u - K;
 
-  auto zero_block = [&](bool which) {                            // (mem_clear, ojph_codeblock.cpp:247) by the lanes of the block's half
-    const uint32_t hv = which ? H : 0u;
-    const uint32_t hmax = max(rdlane(hv, 0), rdlane(hv, 32));    // (both halves walk the taller one's rows)
+  auto seg_max = [&](uint32_t v) -> uint32_t {                   // the largest value any segment holds (v uniform per segment)
+    uint32_t m = max(rdlane(v, 0), rdlane(v, LPB));
+    if (NB == 4) m = max(m, max(rdlane(v, 2 * LPB), rdlane(v, 3 * LPB)));
+    return m;
+  };
+  auto zero_block = [&](bool which) {                            // (mem_clear, ojph_codeblock.cpp:247) by the lanes of the block's segment
+    const uint32_t hmax = seg_max(which ? H : 0u);               // (every segment walks the tallest block's rows)
     for (uint32_t y = 0; y < hmax; ++y)
-      if (which && y < H && l32 < W) dst[(size_t)y * pitch + l32] = 0u;
+      if (which && y < H && ll < W) dst[(size_t)y * pitch + ll] = 0u;
   };
 
   // the verdict of step 1 and the length of the MagSgn part (a one-byte segment has failed in step 1; its bytes are not used)
@@ -1349,30 +1382,30 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
     const uint32_t b1 = cb[lcup - 1u], b2 = cb[lcup >= 2u ? lcup - 2u : 0u];
     ms_len = lcup - ((b1 << 4) + (b2 & 0xFu));
   }
-  bool go = coded && st == 0u;                                   // this half decodes
+  bool go = coded && st == 0u;                                   // this segment decodes
   {
     const bool z = exists && !go;                                // not coded, or failed in step 1: the block is zero
     if (__ballot(z) != 0ull) zero_block(z);
   }
   if (__ballot(go) == 0ull) return;
-  for (uint32_t i = l32; i < RING_ALLOC; i += 32u) ring[i] = 0;
+  for (uint32_t i = ll; i < RING_ALLOC; i += (uint32_t)LPB) ring[i] = 0;
   wave_sync();
 
-  // ---- un-stuffs the next 128 MagSgn bytes of the halves whose lanes say `need` into their rings (step2_block's rule, :609-653) ----
-  uint32_t dst_bits = 0, src_pos = 0, mpos = 0;                  // per half: bits un-stuffed, bytes consumed, bits decoded
+  // ---- un-stuffs the next 4 LPB MagSgn bytes of the segments whose lanes say `need` into their rings (step2_block's rule, :609-653) ----
+  uint32_t dst_bits = 0, src_pos = 0, mpos = 0;                  // per segment: bits un-stuffed, bytes consumed, bits decoded
   auto unstuff = [&](bool need) {
     {
       const uint32_t wb = (dst_bits + 31u) >> 5;                 // words above the current partial word are stale
-      const uint32_t z0 = (wb + l32) & RING_MASK;
+      const uint32_t z0 = (wb + ll) & RING_MASK;
       if (need) { ring[z0] = 0; if (z0 < 2u) ring[z0 + RING_WORDS] = 0; }
-      if (need && l32 < 2u) { const uint32_t z1 = (wb + 32u + l32) & RING_MASK; ring[z1] = 0; if (z1 < 2u) ring[z1 + RING_WORDS] = 0; }
+      if (need && ll < 2u) { const uint32_t z1 = (wb + (uint32_t)LPB + ll) & RING_MASK; ring[z1] = 0; if (z1 < 2u) ring[z1 + RING_WORDS] = 0; }
     }
     wave_sync();
-    const uint32_t i0 = src_pos + 4u * l32;
+    const uint32_t i0 = src_pos + 4u * ll;
     const bool in = need && i0 < ms_len;
     const uint32_t word = in ? load_u32_unaligned(cb + i0) : 0u;
     uint32_t pw = from_prev(word);
-    if (l32 == 0u) pw = (in && i0) ? load_u32_unaligned(cb + i0 - 4) : 0u;
+    if (ll == 0u) pw = (in && i0) ? load_u32_unaligned(cb + i0 - 4) : 0u;
     asm volatile("" :: "v"(word), "v"(pw));                      // (both loads awaited here on every path, see step2_block)
     uint32_t val = 0, nb = 0;
     if (in) {
@@ -1389,7 +1422,7 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
       val = x;
       nb = 8u * cnt - (uint32_t)__popc(S);
     }
-    const uint32_t incl = half_incl_scan(nb);
+    const uint32_t incl = seg_incl_scan<LPB>(nb);
     const uint32_t pos = dst_bits + incl - nb;
     if (nb) {
       const uint32_t w = pos >> 5, sh = pos & 31u;
@@ -1398,28 +1431,27 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
       if (wa < 2u) atomicOr(&ring[wa + RING_WORDS], val << sh);
       if (sh + nb > 32u) { atomicOr(&ring[wb2], val >> (32u - sh)); if (wb2 < 2u) atomicOr(&ring[wb2 + RING_WORDS], val >> (32u - sh)); }
     }
-    const uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);
-    if (need) { dst_bits += hb ? tB : tA; src_pos += 128u; }
+    const uint32_t total = seg_last<LPB>(incl, seg);
+    if (need) { dst_bits += total; src_pos += 4u * (uint32_t)LPB; }
     wave_sync();
   };
 
-  const uint32_t half = l32 & 1u;
-  const bool edgeL = l32 == 0u, edgeR = l32 == 31u;
-  const bool col_in = l32 < W;
+  const uint32_t half = ll & 1u;
+  const bool edgeL = ll == 0u, edgeR = ll == (uint32_t)(LPB - 1);
+  const bool col_in = ll < W;
   auto rec_at = [&](uint32_t qy_) -> uint32_t {
-    return *(rec + (size_t)(qy_ * PW + (l32 >> 2)) * REC_STRIDE + ((l32 >> 1) & 1u));
+    return *(rec + (size_t)(qy_ * PW + (ll >> 2)) * REC_STRIDE + ((ll >> 1) & 1u));
   };
   uint32_t e_prev = 0;                                           // exponent of this column's bottom sample, row above
-  bool failed = false;                                           // this half met a row it cannot decode (:1114, :1224)
+  bool failed = false;                                           // this segment met a row it cannot decode (:1114, :1224)
   uint32_t ent_next = (go && col_in) ? rec_at(0) : 0u;           // records are fetched one step ahead
   asm volatile("" : "+v"(ent_next));
-  const uint32_t qh_go = go ? QH : 0u;
-  const uint32_t qy_end = max(rdlane(qh_go, 0), rdlane(qh_go, 32));
+  const uint32_t qy_end = seg_max(go ? QH : 0u);
   for (uint32_t qy = 0; qy < qy_end; ++qy) {
     bool rowon = go && qy < QH;
     if (__ballot(rowon) == 0ull) break;
     for (;;) {
-      const bool need = rowon && src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)(DUAL_ROW_BITS + 64u);
+      const bool need = rowon && src_pos < ms_len && (int32_t)(dst_bits - mpos) < (int32_t)(ROW_BITS + 64u);
       if (__ballot(need) == 0ull) break;
       unstuff(need);
     }
@@ -1433,18 +1465,14 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
       uint32_t gamma = inf & 0xF0u;
       gamma &= gamma - 0x10u;                                                            // :1218
       // even lane 2k: max(e[2k-1], e[2k]); odd lane 2k+1: max(e[2k+1], e[2k+2]); then the pair's two halves together --
-      // the columns beside a block's first and last one do not exist (the other block's lanes sit there)
+      // the columns beside a block's first and last one do not exist (another block's lanes sit there)
       const uint32_t e_nx = edgeR ? 0u : from_next(e_prev), e_pv = edgeL ? 0u : from_prev(e_prev);
       const uint32_t hm = max(e_prev, half ? e_nx : e_pv);
       const uint32_t em = max(hm, from_pair(hm));
       U_q += gamma ? max(em, 1u) : 1u;                                                   // :1219-1223
       if (!act) U_q = 0u;
     }
-    {
-      const uint64_t over = __ballot(act && U_q > mmsbp2);                               // :1114, :1224
-      const bool mine = ((hb ? (uint32_t)(over >> 32) : (uint32_t)over) != 0u);
-      if (mine) { failed = true; go = false; rowon = false; }
-    }
+    if (seg_bits<LPB>(__ballot(act && U_q > mmsbp2), seg) != 0u) { failed = true; go = false; rowon = false; }   // :1114, :1224
     const bool actr = rowon && col_in;
     const uint32_t sel = inf >> (2u * half);
     const bool sg0 = actr && (sel & 0x10u) != 0u, sg1 = actr && (sel & 0x20u) != 0u;
@@ -1453,12 +1481,9 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
     const uint32_t m0 = sg0 ? U_q - ek0 : 0u;
     const uint32_t m1 = sg1 ? U_q - ek1 : 0u;
     const uint32_t tot = m0 + m1;
-    const uint32_t incl = half_incl_scan(tot);
+    const uint32_t incl = seg_incl_scan<LPB>(tot);
     const uint32_t at = mpos + incl - tot;
-    {
-      const uint32_t tA = rdlane(incl, 31), tB = rdlane(incl, 63);
-      mpos += hb ? tB : tA;
-    }
+    mpos += seg_last<LPB>(incl, seg);
     const uint32_t wi = at >> 5, sh = at & 31u;
     const uint32_t* rw = ring + (wi & RING_MASK);
     const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];           // (rw[1], rw[2] may be the copies behind the ring)
@@ -1490,31 +1515,31 @@ __device__ __forceinline__ void step2_dual(const ojphgpu_cb_desc* __restrict__ b
     asm volatile("" : "+v"(ent_next));                           // the next record is taken into its register before this row's stores (see step2_block)
     if (actr) {
       const uint32_t y = 2u * qy;
-      uint32_t* o = dst + (size_t)y * pitch + l32;
+      uint32_t* o = dst + (size_t)y * pitch + ll;
       o[0] = out0;
       if (y + 1u < H) o[pitch] = out1;
     }
   }
   if (__ballot(failed) != 0ull) {
     zero_block(failed);
-    if (failed && l32 == 0u) block_status[bi] = 1;
+    if (failed && ll == 0u) block_status[bi] = 1;
   }
 }
 
-template <int TX>
-__global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_dual_kernel(
+template <int TX, int NB>
+__global__ __launch_bounds__(64 * WAVES) void ht_dec_step2_multi_kernel(
     const ojphgpu_cb_desc* __restrict__ blocks, uint32_t n, const uint8_t* __restrict__ data,
     const uint32_t* __restrict__ quads, uint32_t* __restrict__ coef, uint8_t* __restrict__ block_status)
 {
-  __shared__ uint32_t s_ring[WAVES][2 * RING_ALLOC];
+  __shared__ uint32_t s_ring[WAVES][NB * RING_ALLOC];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // consecutive blocks to ONE XCD, as in ht_dec_step2_kernel (their records share cache lines)
   const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, xcd = blockIdx.x & 7u;
   const uint32_t wg = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
-  const uint32_t bA = 2u * (wg * WAVES + wave);
+  const uint32_t bA = (uint32_t)NB * (wg * WAVES + wave);
   if (bA >= n) return;
-  step2_dual<TX>(blocks, n, bA, data, quads, coef, block_status, s_ring[wave], lane);
+  step2_multi<TX, NB>(blocks, n, bA, data, quads, coef, block_status, s_ring[wave], lane);
 }
 
 
@@ -2373,7 +2398,8 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
 namespace ojphgpu {
 // kinds: what the caller knows about the blocks of the range (0 = nothing): bit 0 blocks of at most 64 columns occur,
 // bit 1 wider ones, bit 2 reversible ones, bit 3 irreversible ones, bit 4 blocks with SigProp / MagRef passes, bit 6
-// blocks of more than 32 columns occur (with bit 0 set and bit 6 clear every block is at most 32 columns wide)
+// blocks of more than 32 columns occur, bit 7 blocks of more than 16 (with bit 0 set and bit 6 / 7 clear every block is at most
+// 32 / 16 columns wide)
 int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
                            const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds)
 {
@@ -2381,12 +2407,16 @@ int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   if (!d_blocks || !d_data || !d_coef || !d_block_status || !d_quad_scratch) return OJPHGPU_E_INVALID;
   const int tx = (kinds & 16) ? 0 : (kinds & 12) == 4 ? 1 : (kinds & 12) == 8 ? 2 : 0;
   const int wd = (kinds & 3) == 1 ? 1 : 0;
-  // two blocks to a wavefront where every block of the range is at most 32 columns wide (kinds bit 6 clear; OJPHGPU_DEC_DUAL=0: never)
-  static const bool dual_on = [] { const char* e = getenv("OJPHGPU_DEC_DUAL"); return !e || atoi(e) != 0; }();
-  if (dual_on && !(kinds & 64) && wd && (tx == 1 || tx == 2)) {
-    const dim3 g2(((n + 1) / 2 + WAVES - 1) / WAVES), wg2(64 * WAVES);
-    if (tx == 1) hipLaunchKernelGGL(ht_dec_step2_dual_kernel<1>, g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
-    else hipLaunchKernelGGL(ht_dec_step2_dual_kernel<2>, g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status);
+  // two (four) blocks to a wavefront where every block of the range is at most 32 (16) columns wide (kinds bit 6 (7) clear;
+  // OJPHGPU_DEC_DUAL=0: never, =2: two at most)
+  static const int multi = [] { const char* e = getenv("OJPHGPU_DEC_DUAL"); return e ? atoi(e) : 4; }();
+  if (multi && !(kinds & 64) && wd && (tx == 1 || tx == 2)) {
+    const uint32_t nb = (!(kinds & 128) && multi >= 4) ? 4u : 2u;
+    const dim3 g2(((n + nb - 1) / nb + WAVES - 1) / WAVES), wg2(64 * WAVES);
+#define MULTI_LAUNCH(T, NB) hipLaunchKernelGGL((ht_dec_step2_multi_kernel<T, NB>), g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status)
+    if (nb == 4) { if (tx == 1) MULTI_LAUNCH(1, 4); else MULTI_LAUNCH(2, 4); }
+    else         { if (tx == 1) MULTI_LAUNCH(1, 2); else MULTI_LAUNCH(2, 2); }
+#undef MULTI_LAUNCH
     return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
   }
   const dim3 grid((n + WAVES - 1) / WAVES), wg(64 * WAVES);

@@ -578,7 +578,7 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u) | (wide ? 4u : 0u));   // bit 1: vertically causal, bit 2: 64-bit samples
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) { fi.any_refine = true; fi.kinds |= 16; }
-    fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8) | (k.r.w > 32 ? 64 : 0));
+    fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8) | (k.r.w > 32 ? 64 : 0) | (k.r.w > 16 ? 128 : 0));
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     fi.max_len1 = std::max(fi.max_len1, c.len1);
     if ((c.len1 + c.len2) && !pb) {

@@ -628,10 +628,10 @@ print("OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"OJPHGPU_DEC_DUAL": "0"}], ids=["two-blocks-per-wavefront", "one"])
+@pytest.mark.parametrize("env", [{}, {"OJPHGPU_DEC_DUAL": "2"}, {"OJPHGPU_DEC_DUAL": "0"}], ids=["four-or-two-blocks-per-wavefront", "two", "one"])
 def test_blocks_of_at_most_32_columns(env):
-    """frames whose code-blocks are all at most 32 columns wide take step 2 with TWO blocks to a wavefront (lanes 0..31 one
-    block, 32..63 the next: ht_dec_step2_dual_kernel; OJPHGPU_DEC_DUAL=0 keeps one block per wavefront): the oracle's samples
+    """frames whose code-blocks are all at most 32 (16) columns wide take step 2 with TWO (FOUR) blocks to a wavefront (a
+    segment of 32 / 16 lanes per block: ht_dec_step2_multi_kernel; OJPHGPU_DEC_DUAL=2: two at most, =0: one): the oracle's samples
     for square, tall, flat and tiny blocks, ragged right / bottom blocks (odd widths and heights), an odd number of blocks,
     blocks that are not coded (a flat component), lossless and lossy, tiles, sub-sampled components -- and the same verdicts
     as the oracle pipeline on streams whose block bytes are damaged (ojph_block_decoder32.cpp:1091-1316 per block)"""
