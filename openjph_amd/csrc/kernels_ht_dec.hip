@@ -53,6 +53,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/ojphgpu.h"
 #include "ht_tables.h"
 #include "ht_uvlc.h"
@@ -498,22 +499,25 @@ __device__ __forceinline__ void uvlc_extension(VlcRd& vlc, uint32_t& used, uint3
 
 // FUSED: `rec` = the block's first 16 bytes of quad row 0 in the 16-bit layout, s_vlc = the dec_vlc32 entries,
 // s_rec = the wavefront's staging area for one row of pair words (16 x 64 words of LDS).
-template <bool NARROW, bool FUSED = false, bool W64 = false, class VlcRd, class TblT>
+// NARROW: 0 = blocks of any width (the significance of the row above is re-read from the records: a memory round trip on the
+// chain), 1 = at most 32 quads per row (one 64-bit mask per lane), 2 = at most 64 quads per row (a 128-bit mask: 128 x 32 blocks)
+template <int NARROW, bool FUSED = false, bool W64 = false, class VlcRd, class TblT>
 __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __restrict__ rec, uint32_t QW, uint32_t QH,
                                            const TblT* s_vlc, const uint16_t* s_uvlc0, uint32_t* flag = nullptr, uint32_t epoch = 0,
                                            lds_u32* s_rec = nullptr, SliceSched sched = SliceSched(S2_ROWS))
 {
-  static_assert(!FUSED || NARROW, "the fused launch's records are for blocks of at most 64 columns");
+  static_assert(!FUSED || NARROW == 1, "the fused launch's records are for blocks of at most 64 columns");
+  typedef typename std::conditional<NARROW == 2, unsigned __int128, uint64_t>::type Mask;
   // the first quarter of row qy of the block in the 16-bit layout (see flush_row16)
   auto row16 = [&](uint32_t qy_) { return rec + (size_t)qy_ * (64u * REC16_ROW_WORDS); };
   // bit c of sig_prev: the bottom sample of column c of the quad row above is significant
   // (rho bit 1 of quad c/2 for even c, rho bit 3 for odd c)
-  uint64_t sig_prev = 0;
+  Mask sig_prev = 0;
   const uint32_t PW = (QW + 1) >> 1;              // quad pairs per row
 
   // ---- initial quad row (block_decoder32.cpp:854-975) ----
   {
-    uint32_t tleft = 0; uint64_t sig_cur = 0;
+    uint32_t tleft = 0; Mask sig_cur = 0;
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       uint32_t v = vlc.peek(), used = 0;  // 32 bits: a pair consumes at most 2*7 + 6 + 10 of them
       const uint32_t evq = mel.peek(); uint32_t ecnt = 0;     // the next 32 MEL events: a pair consumes at most 3
@@ -532,7 +536,7 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       if (NARROW) {
         const uint32_t nib = FUSED ? (((t0 >> 9) & 3u) | ((t1 >> 7) & 0xCu))
                                    : (((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u));
-        sig_cur |= (uint64_t)nib << (2u * qx);
+        sig_cur |= (Mask)nib << (2u * qx);
       }
       uint32_t mode = ((t0 & 0x8u) << 3) | ((t1 & 0x8u) << 4);
       if (mode == 0xC0u) { if ((evq >> ecnt) & 1u) mode += 0x40u; ecnt++; }                 // :943-952
@@ -558,8 +562,8 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
     uint32_t* row = rec + (size_t)qy * PW * REC_STRIDE;                 // quad pair px of this row: row + px * REC_STRIDE (not FUSED)
     const uint32_t* above = row - (size_t)PW * REC_STRIDE;
     auto above_rec = [&](uint32_t q) { return above[(size_t)(q >> 1) * REC_STRIDE + (q & 1u)]; };
-    uint32_t tleft = 0; uint64_t sig_cur = 0;
-    const uint64_t sig_or = sig_prev | (sig_prev >> 1);
+    uint32_t tleft = 0; Mask sig_cur = 0;
+    const Mask sig_or = sig_prev | (sig_prev >> 1);
     uint32_t carry = ((uint32_t)sig_prev & 1u) << 7;              // "column -1 | column 0", as bit 7 of the first context
     for (uint32_t qx = 0; qx < QW; qx += 2) {
       uint32_t v = vlc.peek(), used = 0;
@@ -605,7 +609,7 @@ __device__ __forceinline__ void step1_rows(VlcRd& vlc, EvRd& mel, uint32_t* __re
       if (NARROW) {
         const uint32_t nib = FUSED ? (((t0 >> 9) & 3u) | ((t1 >> 7) & 0xCu))
                                    : (((t0 >> 5) & 1u) | ((t0 >> 6) & 2u) | ((t1 >> 3) & 4u) | ((t1 >> 4) & 8u));
-        sig_cur |= (uint64_t)nib << (2u * qx);
+        sig_cur |= (Mask)nib << (2u * qx);
       }
       // the pair's U-VLC by arithmetic instead of the uvlc_tbl1 look-up (:1065-1085): one LDS round trip less on the chain
       uint32_t u0, u1;
@@ -851,8 +855,9 @@ __global__ __launch_bounds__(192 * CH) void ht_dec_step1_raw_kernel(
   uint32_t* rec = quads + d.scratch_cap;
   RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
   EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
-  if (__all(QW <= 32)) step1_rows<true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
-  else step1_rows<false>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  if (__all(QW <= 32)) step1_rows<1>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else if (__all(QW <= 64)) step1_rows<2>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else step1_rows<0>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   s_done[lane] = 1u;
   block_status[bi] = (mel.stuck || vlc.stuck) ? 1 : 0;
 }
@@ -906,8 +911,9 @@ __global__ __launch_bounds__(128 * CH) void ht_dec_step1_kernel(
 
   // every block of this wavefront at most 64 samples wide (the usual case): the significance of the
   // sample row above lives in one 64-bit mask per lane instead of being re-read from the records
-  if (__all(QW <= 32)) step1_rows<true, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
-  else step1_rows<false, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  if (__all(QW <= 32)) step1_rows<1, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else if (__all(QW <= 64)) step1_rows<2, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
+  else step1_rows<0, false, W64>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0);
   s_done[lane] = 1u;                               // the partner stops producing events for this block
   block_status[bi] = mel.stuck ? 1 : 0;
 }
@@ -1825,7 +1831,7 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(6))) v
       uint32_t* rec = quads + rec16_base(d, bi);
       RingRd vlc; vlc.init(s_vr, s_vprog, s_vcons, lane);
       EvRd mel; mel.init(s_ev, s_eprog, s_econs, evw, lane);
-      step1_rows<true, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64), sched);
+      step1_rows<1, true>(vlc, mel, rec, QW, QH, s_vlc, s_uvlc0, flag, epoch, (lds_u32*)(s_mem + REC_OFF + set * REC16_ROW_WORDS * 64), sched);
       s_done[lane] = 1u;
       if (mel.stuck || vlc.stuck) ask_for_repeat(retry, host_retry, epoch);   // (gave up on its partner: not a verdict on the block -- repeat the run)
     }

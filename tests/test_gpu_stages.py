@@ -90,9 +90,12 @@ def test_dwt_forward_inverse_vs_oracle(reversible):
             assert np.array_equal(g, inputs[i])
 
 
-def _block_cases(rng, n):
-    shapes = [(64, 64)] * 6 + [(32, 32), (128, 32), (32, 128), (4, 1024), (1024, 4), (64, 17), (17, 64), (1, 1),
-                                (3, 3), (5, 64), (64, 5), (2, 64), (63, 63), (33, 31), (8, 8), (1, 64), (64, 1)]
+WIDE_UP_TO_128 = [(128, 32), (72, 40), (128, 2), (96, 8), (65, 63), (127, 31), (100, 1), (128, 32), (66, 5), (128, 17)]
+
+
+def _block_cases(rng, n, shapes=None):
+    shapes = shapes or ([(64, 64)] * 6 + [(32, 32), (128, 32), (32, 128), (4, 1024), (1024, 4), (64, 17), (17, 64), (1, 1),
+                                          (3, 3), (5, 64), (64, 5), (2, 64), (63, 63), (33, 31), (8, 8), (1, 64), (64, 1)])
     out = []
     for i in range(n):
         w, h = shapes[i % len(shapes)]
@@ -238,12 +241,16 @@ def test_ht_encode_coefficients_beyond_K_max():
     assert not bad, "HT encode mismatches (idx, (w, h, rev, kind, kmax), got_len, want_len): %s" % bad[:8]
 
 
-def test_ht_decode_vs_oracle():
+@pytest.mark.parametrize("shapes", [None, WIDE_UP_TO_128], ids=["every-shape", "65-to-128-columns"])
+def test_ht_decode_vs_oracle(shapes):
+    """(the second set: every block of the launch between 65 and 128 columns wide -- the chains keep the significance of the row
+    above in a 128-bit mask per lane, step1_rows<2>; with wider blocks in the wavefront, as in the first set, they re-read it
+    from the records)"""
     torch = _torch()
     from openjph_amd import codec
     from oracle import oraclebind as ob
     rng = np.random.default_rng(9)
-    cases = _block_cases(rng, 92)
+    cases = _block_cases(rng, 92 if shapes is None else 130, shapes)
     descs = np.zeros(len(cases), codec.cb_desc_dtype)
     datas, expect, off, doff, max_len = [], [], 0, 0, 0
     for i, (w, h, kmax, dens, amp) in enumerate(cases):
