@@ -719,7 +719,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   const ojphgpu_cb_desc d = blocks[bi];
   const uint32_t W = d.w, H = d.h;
   constexpr uint32_t PPR = 1u << LOGP, RPS = 64u >> LOGP;                 // quad pairs per row of a step, quad rows per step
-  if (W > NARROW_MAX_W || W > 4u * PPR || ((d.reversible & 1u) != 0) != REV || (d.reversible & 4u) != 0) return;   // ht_encode_wide_kernel's, or another instantiation's
+  // LOGP 5 (32 pairs by 2 quad rows): the blocks of 65..128 columns of a launch none of whose blocks is wider (128 x 32)
+  const bool my_width = LOGP == 5 ? (W > NARROW_MAX_W && W <= 4u * PPR) : (W <= NARROW_MAX_W && W <= 4u * PPR);
+  if (!my_width || ((d.reversible & 1u) != 0) != REV || (d.reversible & 4u) != 0) return;   // ht_encode_wide_kernel's, or another instantiation's
   if (W == 0 || H == 0) { if (lane == 0) { results[bi].offset = 0; results[bi].length = 0; } return; }
   NarrowLds& L = s_wave[wave];
   uint8_t* outb = reinterpret_cast<uint8_t*>(L.out);
@@ -1349,7 +1351,8 @@ namespace ojphgpu {
 // `widths`: bit 0 = the range holds blocks up to 64 samples wide, bit 1 = it holds wider ones; bit 2 = it holds
 // blocks of reversibly transformed components, bit 3 = of irreversibly transformed ones; bit 4 = none of its blocks of
 // up to 64 samples is wider than 32 (they take the 8-pairs-by-8-rows layout); bit 5 = it holds blocks of 64-bit samples
-// (cb_desc.reversible bit 2).  Every kernel skips the blocks of the other kind, so a caller that does not know passes
+// (cb_desc.reversible bit 2); bit 6 = none of its wider blocks is wider than 128 samples (they take the narrow kernel's
+// 32-pairs-by-2-rows layout instead of the raster-order wide kernel).  Every kernel skips the blocks of the other kind, so a caller that does not know passes
 // 3 | 32 (wavelet bits clear = both).
 int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const void* d_coef, uint8_t* d_scratch,
                      uint8_t* d_out, uint32_t out_cap, ojphgpu_cb_result* d_results, uint32_t* d_cursor, uint32_t* d_status,
@@ -1376,7 +1379,14 @@ int ht_encode_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, 
   else if ((widths & 1) && (widths & 8))
     hipLaunchKernelGGL((ht_encode_kernel<false, 4>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
-  if (widths & 2)
+  if ((widths & 2) && (widths & 64)) {                      // wider blocks, none of them wider than 128 samples: 32 pairs by 2 quad rows
+    if (widths & 4)
+      hipLaunchKernelGGL((ht_encode_kernel<true, 5>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+                         (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
+    if (widths & 8)
+      hipLaunchKernelGGL((ht_encode_kernel<false, 5>), ngrid, dim3(64 * NWAVES), ballast, (hipStream_t)stream, d_blocks, n,
+                         (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
+  } else if (widths & 2)
     hipLaunchKernelGGL(ht_encode_wide_kernel<false>, grid, dim3(64 * WAVES), 0, (hipStream_t)stream, d_blocks, n,
                        (const uint32_t*)d_coef, d_scratch, d_out, out_cap, d_results, d_cursor, d_status, d_regions, nreg);
   if (widths & 32)                                          // blocks of components on the 64-bit sample path

@@ -133,7 +133,7 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
   }
   std::vector<ojphgpu_cb_desc> bd(e->block_ids.size());
   uint64_t scratch_bytes = 0, samples = 0;
-  bool over32_top = false, over32_rest = false;
+  bool over32_top = false, over32_rest = false, over128_top = false, over128_rest = false;
   for (size_t i = 0; i < bd.size(); ++i) {
     const Block& k = P.blocks[e->block_ids[i]]; const Band& B = P.bands[k.band];
     samples += (uint64_t)k.r.w * k.r.h;
@@ -146,9 +146,12 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     scratch_bytes += d.scratch_cap;
     (i < e->n_top ? e->widths_top : e->widths_rest) |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((d.reversible & 1) ? 4 : 8));   // which kernel variants the range needs
     if (!wide && k.r.w > 32 && k.r.w <= 64) (i < e->n_top ? over32_top : over32_rest) = true;
+    if (!wide && k.r.w > 128) (i < e->n_top ? over128_top : over128_rest) = true;
   }
   if (!over32_top) e->widths_top |= 16;                    // every block of the range at most 32 samples wide (e.g. the IMF profile's 32 x 32)
   if (!over32_rest) e->widths_rest |= 16;
+  if (!over128_top) e->widths_top |= 64;                   // no block wider than 128 samples: 128 x 32 blocks take the narrow kernel, too
+  if (!over128_rest) e->widths_rest |= 64;
   if (nframes > 1) {                                      // replicate the block descriptors, frame-major
     const size_t nb = bd.size();
     bd.resize(nb * nframes);

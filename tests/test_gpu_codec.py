@@ -23,6 +23,11 @@ CASES = [
     dict(nc=1, h=5, w=7, bd=8),
     dict(nc=1, h=200, w=200, bd=8, block=(128, 32)),
     dict(nc=1, h=200, w=200, bd=8, block=(4, 1024)),
+    # blocks of 65..128 columns, none wider: the narrow encoder's 32-pairs-by-2-rows layout (LOGP 5), step 1's 128-bit masks
+    dict(nc=1, h=333, w=517, bd=10, block=(128, 32), num_decomps=2),
+    dict(nc=3, h=203, w=395, bd=12, block=(128, 8), reversible=False, qstep=0.002, num_decomps=1),
+    dict(nc=1, h=97, w=260, bd=16, block=(128, 16), num_decomps=0),
+    dict(nc=2, h=70, w=300, bd=8, block=(128, 4), num_decomps=1, tile=(200, 64)),
     dict(nc=1, h=256, w=256, bd=8, signed=True),
     dict(nc=1, h=256, w=256, bd=8, num_decomps=0),
     dict(nc=1, h=256, w=256, bd=12, reversible=False),
