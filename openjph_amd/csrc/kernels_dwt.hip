@@ -20,8 +20,8 @@
 //     HBM latency of the row stream overlaps the lifting arithmetic of the previous row pair.
 //   * the number of row pairs a wavefront walks (its vertical chunk) is chosen per launch
 //     (pick_row_pairs): at most 20, so that a large plane takes two or three rounds of workgroups
-//     whose reads and writes mix at HBM, down to 8 at the small levels, where the kernel is
-//     otherwise bound by the length of the serial walk.
+//     whose reads and writes mix at HBM, down to 8 (analysis) / 4 (synthesis) at the small levels,
+//     where the kernel is otherwise bound by the length of the serial walk.
 //   * the first analysis level can read the int32 image planes directly (level shift / int ->
 //     float conversion of ojph_colour.cpp:238-436 applied in the load), and the last synthesis
 //     level can write them (float -> int with rounding + clamp), which removes one full
@@ -46,7 +46,7 @@ namespace {
 constexpr int HALO = 2;             // column pairs recomputed on each side of a strip
 constexpr int VALID = 64 - 2 * HALO; // 60 pairs = 120 columns produced per wavefront
 constexpr int MAX_ROW_PAIRS = 20;   // row pairs produced per strip and launch chunk (40 image rows), see pick_row_pairs
-constexpr int MIN_ROW_PAIRS = 8;
+constexpr int MIN_ROW_PAIRS = 8, MIN_ROW_PAIRS_INV = 4;
 
 template <bool REV> struct Wv;
 
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
 // and writes mix, and the level-1 launches gain 8-18 % (8K frame, 16K tiled image, batches of 4K
 // frames; A/B of 8..96 row pairs in one box visit: 20 is the best, below 16 the extra wavefronts of
 // the lower levels take issue slots from the block coder running beside them).
-int pick_row_pairs(uint32_t n, uint32_t max_w, uint32_t max_h)
+int pick_row_pairs(uint32_t n, uint32_t max_w, uint32_t max_h, bool synthesis)
 {
   const uint32_t npx = (max_w + 2) >> 1, npy = (max_h + 2) >> 1;
   const uint64_t strips = (uint64_t)((npx + VALID - 1) / VALID) * n;
@@ -732,8 +732,14 @@ int pick_row_pairs(uint32_t n, uint32_t max_w, uint32_t max_h)
   uint64_t chunks = (want_waves + strips - 1) / strips;
   if (chunks < 1) chunks = 1;
   uint64_t rp = (npy + chunks - 1) / chunks;
-  rp = (rp + 3) & ~3ull;
-  if (rp < (uint64_t)MIN_ROW_PAIRS) rp = MIN_ROW_PAIRS;
+  // the small levels are bound by the length of a wavefront's serial walk (a memory round trip per row pair): the synthesis
+  // launches, which run with little beside them, go down to 4 row pairs per chunk (8K frame: all levels 0.2535 -> 0.2465 ms,
+  // 4K RGB: 0.122 -> 0.115); the analysis launches share the chip with the block coder of the top resolution and keep 8 --
+  // more, shorter workgroups there measured no gain (profiles/r05_a_small_levels.txt).  OJPHGPU_DWT_RP_MIN sets both.
+  static const uint64_t rp_env = [] { const char* e = getenv("OJPHGPU_DWT_RP_MIN"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 2 && v <= 20 ? v : 0); }();
+  const uint64_t rp_min = rp_env ? rp_env : synthesis ? (uint64_t)MIN_ROW_PAIRS_INV : (uint64_t)MIN_ROW_PAIRS;
+  rp = rp_min >= 4 ? (rp + 3) & ~3ull : (rp + 1) & ~1ull;
+  if (rp < rp_min) rp = rp_min;
   if (rp > (uint64_t)MAX_ROW_PAIRS) rp = MAX_ROW_PAIRS;
   return (int)rp;
 }
@@ -789,7 +795,7 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
 {
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   if (!d_descs || !d_base || (nc != 1 && nc != 3) || n % (uint32_t)nc || (nc == 3 && !d_image)) return OJPHGPU_E_INVALID;
-  int rp = pick_row_pairs(n, max_w, max_h);
+  int rp = pick_row_pairs(n, max_w, max_h, !FWD);
   {
     // the synthesis re-reads two sub-band row pairs above and below each vertical chunk (the inverse top level moves 1.28 x
     // its algorithmic bytes at 20 row pairs per chunk): longer chunks there trade that against the burstiness shorter
@@ -842,7 +848,7 @@ template <typename TT, int NS>
 int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
                    void* d_base, bool synthesis)
 {
-  const int rp = pick_row_pairs(n, max_w, max_h);
+  const int rp = pick_row_pairs(n, max_w, max_h, synthesis);
   const dim3 grid = dwt_grid(n, max_w, max_h, rp);
   const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
   if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
