@@ -243,14 +243,18 @@ def main():
     torch.cuda.synchronize(dev)
     failed = dec.failed_blocks()
     assert failed == 0 or os.environ.get("OJPH_BENCH_NOCHECK"), "decode failed for %d code-blocks" % failed
+    mask = None
     if tiled:                                    # compare only this rank's tile rows / columns
         mask = torch.zeros_like(d_img, dtype=torch.bool)
         for t in range(my_tiles[0], my_tiles[0] + my_tiles[1]):
             _, _, (x0, y0, tw, th) = plan.comp_plane(t, 0)
             mask[:, y0:y0 + th, x0:x0 + tw] = True
-        err = ((d_out.int() - d_img.int()).abs() * mask).max().item()
-    else:
-        err = (d_out.int() - d_img.int()).abs().max().item()
+
+    def roundtrip_err():
+        if mask is not None:
+            return int(((d_out.int() - d_img.int()).abs() * mask).max().item())
+        return int((d_out.int() - d_img.int()).abs().max().item())
+    err = roundtrip_err()
     if rev:
         assert err == 0, "reversible round trip is not lossless"
     coded_bytes = enc.coded_bytes()
@@ -269,6 +273,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    d_out.zero_()                                # the timed steps must produce the frame again (checked after the loop)
+    _, epoch0 = dec.giveup_epoch()               # (synchronises)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -277,6 +284,44 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    # What the timed steps produced, checked AFTER them: the last step's decode is collected (block verdicts; a one-launch
+    # block decoder whose wait ran out would be repeated here and counted), no timed run gave up un-noticed (the give-up epoch
+    # of the decoder object, bracketing the loop), the samples of the LAST timed step against the input, and the coded size.
+    giveup1, epoch1 = dec.giveup_epoch()
+    failed_after = dec.failed_blocks()
+    retries_after = dec.fused_retries()
+    err_after = roundtrip_err()
+    assert failed_after == 0 or os.environ.get("OJPH_BENCH_NOCHECK"), "timed region: decode failed for %d code-blocks" % failed_after
+    assert err_after == err or os.environ.get("OJPH_BENCH_NOCHECK"), "timed region: round-trip error %d, was %d before it" % (err_after, err)
+    assert enc.coded_bytes() == coded_bytes, "timed region: the encoder's coded size changed"
+    # ... and the codestream (tiled: this rank's tile-parts) the LAST timed encode produced: the bytes of the first one,
+    # which the decoder above decodes and which the parity tests compare with the reference's
+    import hashlib
+    if tiled:
+        last_part, _ = enc.finish_tiles()
+        first_part = part.cpu().numpy().tobytes() if hasattr(part, "cpu") else bytes(part)
+        cs_same = bytes(last_part) == first_part
+        cs_digest = hashlib.sha256(bytes(last_part)).hexdigest()
+    else:
+        last_cs = enc.finish() if frames == 1 else [enc.finish(f) for f in range(frames)]
+        cs_same = last_cs == cs
+        cs_digest = hashlib.sha256(last_cs if frames == 1 else b"".join(last_cs)).hexdigest()
+    assert cs_same, "timed region: the last timed encode's codestream differs from the first encode's"
+    # rank 0's frame of C2 / C3 is the survey's known-answer frame: the reference's own codestream and decoded samples
+    # (digests in tests/golden/survey_ka.json, made by tests/golden/make_survey_ka.py from the reference built here)
+    ref_cs = ref_dec = None
+    if rank == 0 and frames == 1 and not tiled and args.workload[:2] in ("c2", "c3"):
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_ka.json")))[args.workload[:2]]
+        gold = gold.get("generic", gold)
+        ref_cs = bool(len(last_cs) == gold["bytes"] and cs_digest == gold["sha256"])
+        if "decoded_sha256" in gold:
+            ref_dec = bool(hashlib.sha256(np.ascontiguousarray(d_out.cpu().numpy().astype(np.int32)).tobytes()).hexdigest() == gold["decoded_sha256"])
+        assert ref_cs and ref_dec is not False, "timed region: codestream / decoded samples are not the reference's (tests/golden/survey_ka.json)"
+    verified = {"verified_after_timing": True, "failed_blocks": int(failed_after), "fused_retries": int(retries_after),
+                "fused_runs_timed": int(epoch1 - epoch0), "fused_giveups_in_timed_region": bool(giveup1 > epoch0),
+                "roundtrip_max_abs_err_last_step": int(err_after), "coded_bytes_last_step": int(coded_bytes),
+                "codestream_last_step_equals_first": bool(cs_same), "codestream_last_step_sha256": cs_digest,
+                "codestream_last_step_equals_reference_digest": ref_cs, "decoded_last_step_equals_reference_digest": ref_dec}
     per_rank_ms = [round(elapsed * 1e3 / args.steps, 4)]
     if world > 1:                                # every rank's own time travels: a straggler shows; value uses the maximum
         t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -500,6 +545,7 @@ def main():
                      "traffic_source": "profiles/pmc_traffic.json (%s)" % pmc_state},
         "kernels": kinfo,
     }
+    result.update(verified)
     if e2e:
         result["e2e"] = e2e
     if strong:
@@ -512,16 +558,7 @@ def main():
         result["roofline_valu"] = rv
         # which roof the dominant launch is nearer to: the HBM fraction above, or the VALU-issue fraction of the same launch
         kd = (rv.get("kernels") or {}).get(dom, {})
-        fv = kd.get("frac")
-        if fv is not None:
-            result["roofline"]["frac_valu_issue"] = fv
-            result["roofline"]["frac_valu_issue_at_2p4_cycles"] = kd.get("frac_at_2p4_cycles")
-            result["roofline"]["wait_share"] = kd.get("wait_share")
-            # which roof the launch is nearer to -- unless its wavefronts mostly WAIT: then neither roof explains it
-            result["roofline"]["bound"] = "latency" if kd.get("bound") == "latency" else ("valu-issue" if fv > result["roofline"]["frac"] else "hbm")
-            result["roofline"]["bound_note"] = ("`bound`: `latency` when the launch's wavefronts are parked at s_waitcnt for more than half of their cycles "
-                                                "(wait_share); otherwise the roof it sits closer to.  achieved / peak / frac stay the HBM figures (SURVEY 8(d) bytes "
-                                                "over the HBM peak); frac_valu_issue is the same launch against the 4.2-cycle VALU roof, ..._at_2p4_cycles against the 2.4-cycle one")
+        result["roofline"].update(limiter_fields(result["roofline"]["frac"], kd))
     if "dwt_forward(level 1)" in kernels and kernels["dwt_forward(level 1)"][1] > 0:
         # the HBM-bound kernel family of the path (north_star sets its roofline target on it); the
         # block coder launches above are bound by integer VALU issue, not by HBM.  Level 1 -- the two
@@ -773,6 +810,24 @@ def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):
                        "gatherv_GBps": round(moved / best[0] / 1e9, 2) if moved and best[0] > 0 else None}}
 
 
+def limiter_fields(frac_hbm, kd):
+    """`roofline.bound` is the contract's field and stays the roof `achieved / peak / frac` are quoted against ("hbm": SURVEY
+    8(d)'s algorithmic bytes over the HBM peak).  What actually LIMITS the launch is a separate field, `limiter`, from the
+    committed SQ counters of exactly this build (kd = roofline_valu's entry of the launch; empty when they are stale):
+    "latency" when its wavefronts are parked at s_waitcnt for more than half of their cycles (wait_share), otherwise the roof
+    it sits nearer to -- "valu-issue" (frac_valu_issue > frac) or "hbm".  -> the fields to merge into `roofline`."""
+    fv = (kd or {}).get("frac")
+    if fv is None:
+        return {"limiter": None}
+    ws = kd.get("wait_share")
+    lim = "latency" if (ws or 0) > 0.5 else ("valu-issue" if fv > frac_hbm else "hbm")
+    return {"frac_valu_issue": fv, "frac_valu_issue_at_2p4_cycles": kd.get("frac_at_2p4_cycles"), "wait_share": ws, "limiter": lim,
+            "limiter_note": "`limiter`: `latency` when the launch's wavefronts are parked at s_waitcnt for more than half of their cycles "
+                            "(wait_share); otherwise the roof it sits closer to.  bound / achieved / peak / frac stay the HBM figures (SURVEY 8(d) "
+                            "bytes over the HBM peak); frac_valu_issue is the same launch against the 4.2-cycle VALU roof, ..._at_2p4_cycles "
+                            "against the 2.4-cycle one"}
+
+
 def committed_counters(name):
     """profiles/<name> -- counter passes are separate rocprofv3 runs (tools/pmc_round.sh, tools/sq_round.sh), their
     results are committed.  They only describe THIS build if they were taken on the same kernel sources: the files carry
@@ -797,7 +852,7 @@ def roofline_valu(workload, kinfo):
     at up to 2.4 GHz; the time comes from this run."""
     sq, state = committed_counters("sq_counters.json")
     if state != "current":
-        return {"bound": "valu-issue", "kernels": {}, "source": "profiles/sq_counters.json (%s)" % state}
+        return {"limiter": None, "kernels": {}, "source": "profiles/sq_counters.json (%s)" % state}
     sq = sq.get(workload, {})
     waits = sq.get("_waits", {})
     out = {}
@@ -815,10 +870,10 @@ def roofline_valu(workload, kinfo):
                   "valu_issue_ms_at_2p4_cycles": round(ms_at(2.4), 4), "measured_ms": v["ms"],
                   "frac": round(ms_at(4.2) / v["ms"], 3), "frac_at_2p4_cycles": round(ms_at(2.4) / v["ms"], 3),
                   "wait_share": w.get("wait_share"), "issue_stall_share": w.get("issue_stall_share"),
-                  "bound": "latency" if (w.get("wait_share") or 0) > 0.5 else "valu-issue"}
+                  "limiter": "latency" if (w.get("wait_share") or 0) > 0.5 else "valu-issue"}
     if not out:
         return None
-    return {"bound": "valu-issue or latency, per kernel: `latency` where the kernel's wavefronts spend more than half of their cycles parked at s_waitcnt "
+    return {"limiter": "valu-issue or latency, per kernel: `latency` where the kernel's wavefronts spend more than half of their cycles parked at s_waitcnt "
                      "(wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the committed SQ pass)",
             "peak": "1024 SIMDs x 1 wave64 VALU instruction / {2.4, 4.2} cycles x 2.4 GHz (tools/micro/valu_issue.hip, profiles/r03_valu_issue_probe.txt: "
                     "4.2 cycles per instruction per SIMD for shifts-left / bit-field / compare / select / cross-lane / 3-operand forms, "

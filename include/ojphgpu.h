@@ -524,11 +524,17 @@ int  ojphgpu_decode16(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t 
  * work; it marks the run instead of failing blocks), the frame is decoded again here through the separate launches,
  * into the same d_image -- so read d_image after this call, not before.  The reference decides per block at
  * codeblock::decode (ojph_codeblock.cpp:190-224); this is where its verdicts become visible.
- * A caller that consumes d_image on the device and never collects is told by its NEXT ojphgpu_decoder_run_device* call,
- * which returns OJPHGPU_E_UNCOLLECTED (once, nothing enqueued) when the run before it had asked for the repeat. */
+ * A caller that consumes d_image on the device and never collects is told by a LATER ojphgpu_decoder_run_device* call,
+ * which returns OJPHGPU_E_UNCOLLECTED (once per give-up, nothing enqueued) when a run before it had asked for the repeat.
+ * The launch only says so when its wait has run out (about two seconds), so the notice may come more than one call
+ * after the run it is about. */
 int  ojphgpu_decoder_failed_blocks(ojphgpu_decoder* dec, uint32_t* count);
 /* how many runs of this decoder were repeated that way (0 in any normal process) */
 int  ojphgpu_decoder_fused_retries(ojphgpu_decoder* dec, uint32_t* count);
+/* synchronises the decoder's stream; *current = the number of one-launch (fused) block-decoder runs enqueued so far,
+ * *last_giveup = the number of the newest of them whose wait ran out (0 = none ever did).  A caller that times or pipelines
+ * uncollected runs brackets them with two calls: no run in between gave up iff last_giveup <= the first call's *current. */
+int  ojphgpu_decoder_giveup_epoch(ojphgpu_decoder* dec, uint32_t* last_giveup, uint32_t* current);
 int  ojphgpu_decode(ojphgpu_decoder* dec, const uint8_t* h_codestream, size_t len,
                     int32_t* h_image);
 

@@ -235,6 +235,7 @@ SIGNATURES = {
     "ojphgpu_decoder_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ojphgpu_decoder_failed_blocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "ojphgpu_decoder_fused_retries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ojphgpu_decoder_giveup_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ojphgpu_encoder_ht_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ojphgpu_encoder_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

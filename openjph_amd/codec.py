@@ -254,6 +254,13 @@ class Decoder:
         check(self._lib.ojphgpu_decoder_fused_retries(self._h, C.byref(n)), "decoder_fused_retries")
         return int(n.value)
 
+    def giveup_epoch(self):
+        """-> (last_giveup, current): the number of one-launch block-decoder runs enqueued so far, and the number of the newest
+        one whose wait ran out (0: none); synchronises the stream.  Brackets a series of uncollected runs (bench.py)."""
+        g, c = C.c_uint32(), C.c_uint32()
+        check(self._lib.ojphgpu_decoder_giveup_epoch(self._h, C.byref(g), C.byref(c)), "decoder_giveup_epoch")
+        return int(g.value), int(c.value)
+
     def decode(self) -> np.ndarray:
         img = self.run_device()
         failed = self.failed_blocks()

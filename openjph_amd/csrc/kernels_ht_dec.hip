@@ -2404,8 +2404,9 @@ extern "C" int ojphgpu_ht_decode_step1(void* stream, const ojphgpu_cb_desc* d_bl
 namespace ojphgpu {
 // kinds: what the caller knows about the blocks of the range (0 = nothing): bit 0 blocks of at most 64 columns occur,
 // bit 1 wider ones, bit 2 reversible ones, bit 3 irreversible ones, bit 4 blocks with SigProp / MagRef passes, bit 6
-// blocks of more than 32 columns occur, bit 7 blocks of more than 16 (with bit 0 set and bit 6 / 7 clear every block is at most
-// 32 / 16 columns wide)
+// blocks of more than 32 columns occur, bit 7 blocks of more than 16, bit 8 "bits 6 and 7 are filled in" -- only with bit 8
+// SET does a clear bit 6 / 7 mean that every block is at most 32 / 16 columns wide (opt-in: a caller that builds `kinds`
+// from bits 0..4 alone gets one block per wavefront, never the paired kernels, which leave wider blocks alone)
 int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32_t n, const uint8_t* d_data,
                            const uint32_t* d_quad_scratch, void* d_coef, uint8_t* d_block_status, int kinds)
 {
@@ -2416,7 +2417,7 @@ int ht_decode_step2_launch(void* stream, const ojphgpu_cb_desc* d_blocks, uint32
   // two (four) blocks to a wavefront where every block of the range is at most 32 (16) columns wide (kinds bit 6 (7) clear;
   // OJPHGPU_DEC_DUAL=0: never, =2: two at most)
   static const int multi = [] { const char* e = getenv("OJPHGPU_DEC_DUAL"); return e ? atoi(e) : 4; }();
-  if (multi && !(kinds & 64) && wd && (tx == 1 || tx == 2)) {
+  if (multi && (kinds & 256) && !(kinds & 64) && wd && (tx == 1 || tx == 2)) {
     const uint32_t nb = (!(kinds & 128) && multi >= 4) ? 4u : 2u;
     const dim3 g2(((n + nb - 1) / nb + WAVES - 1) / WAVES), wg2(64 * WAVES);
 #define MULTI_LAUNCH(T, NB) hipLaunchKernelGGL((ht_dec_step2_multi_kernel<T, NB>), g2, wg2, 0, (hipStream_t)stream, d_blocks, n, d_data, d_quad_scratch, (uint32_t*)d_coef, d_block_status)

@@ -564,9 +564,13 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
   // blocks whose tile-part ended before their bytes did: the reference decodes what there is with zeros behind it
   // (bb_read_chunk, ojph_bitbuffer_read.h:134-150).  `coded` calls them not coded; here they get what the packet header
   // said and a place of their own behind the uploaded byte range (PadCopy), where the upload puts bytes + zeros.
+  std::vector<std::pair<uint32_t, const Plan::PaddedBlock*>> padded_idx;   // by block id, first entry of an id wins (as a linear search would)
+  padded_idx.reserve(Q.padded.size());
+  for (const Plan::PaddedBlock& pb : Q.padded) padded_idx.emplace_back(pb.block, &pb);
+  std::stable_sort(padded_idx.begin(), padded_idx.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
   auto padded_of = [&](uint32_t id) -> const Plan::PaddedBlock* {
-    for (const Plan::PaddedBlock& pb : Q.padded) if (pb.block == id) return &pb;
-    return nullptr;
+    auto it = std::lower_bound(padded_idx.begin(), padded_idx.end(), id, [](const auto& a, uint32_t v) { return a.first < v; });
+    return it != padded_idx.end() && it->first == id ? it->second : nullptr;
   };
   std::vector<std::pair<size_t, const Plan::PaddedBlock*>> padded_at;
   for (size_t i = 0; i < ids.size(); ++i) {
@@ -581,7 +585,7 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     o.reversible = (uint8_t)((Q.style(B.comp).rev ? 1u : 0u) | (Q.style(B.comp).causal ? 2u : 0u) | (wide ? 4u : 0u));   // bit 1: vertically causal, bit 2: 64-bit samples
     o.missing_msbs = (uint8_t)std::min<uint32_t>(c.missing_msbs, 255); o.num_passes = (uint8_t)c.num_passes;
     if (c.num_passes > 1 && c.len2 > 0) { fi.any_refine = true; fi.kinds |= 16; }
-    fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8) | (k.r.w > 32 ? 64 : 0) | (k.r.w > 16 ? 128 : 0));
+    fi.kinds |= wide ? 32 : ((k.r.w > 64 ? 2 : 1) | ((o.reversible & 1u) ? 4 : 8) | (k.r.w > 32 ? 64 : 0) | (k.r.w > 16 ? 128 : 0) | 256);   // 256: the width bits 6 / 7 are filled in
     o.delta = B.delta; o.len1 = c.len1; o.len2 = c.len2; o.data_off = c.offset;
     fi.max_len1 = std::max(fi.max_len1, c.len1);
     if ((c.len1 + c.len2) && !pb) {
@@ -606,6 +610,7 @@ void ojphgpu_decoder_fill_descs(const Plan& P, const Plan& Q, const std::vector<
     o.data_off = data_base + at;
     at = (at + total + 63) & ~(uint64_t)63;
   }
+  if (!fi.pads.empty()) at += 64;                                       // (ojphgpu_decoder_upload_pads zeroes a 64-byte margin behind the last block too)
   fi.pad_len = at - ((fi.len + 63) & ~(uint64_t)63);
 }
 
@@ -791,12 +796,17 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
   if (container != 32) for (const CompGeo& g : P.comps) if (g.bit_depth > (uint32_t)container) return OJPHGPU_E_INVALID;
   hipStream_t s = d->stream;
   Spans& T = d->timer;
-  // the run before this one asked to be decoded again and nobody collected it (ojphgpu_decoder_failed_blocks does): its
-  // frame was handed out partly decoded.  Said once; collecting, or the next run, clears it.  (A frame pipeline's runs
-  // -- o_status set -- are always collected by the pipeline.)
-  if (d->uncollected && !d->o_status && !d->force_separate && d->h_retry && *(volatile uint32_t*)d->h_retry == d->fused_epoch && d->fused_epoch != 0) {
-    d->uncollected = false;
-    return OJPHGPU_E_UNCOLLECTED;
+  // A run before this one asked to be decoded again and nobody collected it (ojphgpu_decoder_failed_blocks does): its
+  // frame was handed out partly decoded.  The launch writes its epoch into h_retry only when its wait has run out (about two
+  // seconds after it started), so the notice may arrive more than one call later: epochs only grow, and every epoch found
+  // there that has not been acknowledged yet is reported once.  (A frame pipeline's runs -- o_status set -- are always
+  // collected by the pipeline.)
+  if (!d->o_status && !d->force_separate && d->h_retry) {
+    const uint32_t gave_up = *(volatile uint32_t*)d->h_retry;
+    if ((int32_t)(gave_up - d->retry_acked) > 0) {
+      d->retry_acked = gave_up; d->uncollected = false;
+      return OJPHGPU_E_UNCOLLECTED;
+    }
   }
   T.start(s);
   // One launch for step 1 and step 2 (chains first, step-2 workers behind them slice by slice, kernels_ht_dec.hip) when
@@ -907,9 +917,21 @@ extern "C" int ojphgpu_decoder_failed_blocks(ojphgpu_decoder* d, uint32_t* count
     }
     break;
   }
+  // (the stream is drained: every give-up of the runs enqueued so far has reached h_retry; the run collected here has been
+  // repeated above if it was one of them, earlier uncollected ones are beyond repair -- ojphgpu_decoder_giveup_epoch tells)
+  if (d->h_retry) d->retry_acked = *(volatile uint32_t*)d->h_retry;
   uint32_t n = 0;
   for (uint32_t i = 0; i < d->nblocks; ++i) n += st[i] != 0;
   *count = n;
+  return OJPHGPU_OK;
+}
+
+extern "C" int ojphgpu_decoder_giveup_epoch(ojphgpu_decoder* d, uint32_t* last_giveup, uint32_t* current)
+{
+  if (!d || !last_giveup || !current) return OJPHGPU_E_INVALID;
+  HIPCHK(hipStreamSynchronize(d->stream));
+  *last_giveup = d->h_retry ? *(volatile uint32_t*)d->h_retry : 0u;
+  *current = d->fused_epoch;
   return OJPHGPU_OK;
 }
 

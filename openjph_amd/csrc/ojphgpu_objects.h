@@ -363,6 +363,7 @@ struct ojphgpu_decoder {
   // and the next run of this object finds it there (OJPHGPU_E_UNCOLLECTED).  uncollected: a fused run has been enqueued
   // and nobody has read its verdicts yet.
   uint32_t* h_retry = nullptr; uint32_t* d_h_retry = nullptr; bool uncollected = false;
+  uint32_t retry_acked = 0;                         // the newest epoch found in h_retry that has been reported or collected
   // eight repeats in a row and the object stops using the one launch: a wait that runs out costs seconds, and a chip (or a
   // device layout) on which it keeps running out is better served by the separate launches than by trying again
   uint32_t fused_strikes = 0; bool fused_off = false;

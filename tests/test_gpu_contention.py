@@ -131,6 +131,29 @@ for kw, shape in ((dict(bit_depth=8, num_decomps=2), (1, 700, 900)), (dict(bit_d
         assert e.code == capi.E_UNCOLLECTED, e
     d_img = dec.run_device()                                # said once; this run is enqueued
     assert dec.failed_blocks() == 0 and np.array_equal(d_img.cpu().numpy(), want)
+    # ... also when the give-up lands late: runs enqueued back to back before any of them has said anything (a real wait runs
+    # out after two seconds).  Every give-up that was not collected is reported by SOME later run, once; the epochs bracket it
+    dec = codec.Decoder(cs)
+    g0, c0 = dec.giveup_epoch()
+    assert (g0, c0) == (0, 0)
+    notices = 0
+    for _ in range(3):
+        try:
+            dec.run_device()
+        except capi.OjphError as e:
+            assert e.code == capi.E_UNCOLLECTED, e
+            notices += 1
+    g1, c1 = dec.giveup_epoch()                             # synchronises: every enqueued run has given up by now
+    assert c1 == 3 - notices and g1 == c1 > c0, (g1, c1, notices)
+    try:
+        dec.run_device()
+        assert notices >= 1, "three uncollected give-ups went unnoticed"
+    except capi.OjphError as e:
+        assert e.code == capi.E_UNCOLLECTED, e
+        notices += 1
+    assert notices >= 1
+    d_img = dec.run_device() if dec.giveup_epoch()[1] == c1 else d_img
+    assert dec.failed_blocks() == 0
 print("OK")
 ''' % ROOT
 

@@ -3,8 +3,9 @@
 Inputs are SURVEY.md section 8(d)'s (tests/synth.py survey_c*; C2 / C3 reproduce the survey's known
 answers KA-3 / KA-4).  The expected codestreams / decoded images are the REAL reference's, made in the
 build container by tests/golden/make_survey_ka.py and committed as digests
-(tests/golden/survey_ka.json); where oracle/_ref/*.so travelled to this box the live library is asked
-as well.  Reversible 5/3: bit-identical codestream, lossless decode.  Irreversible 9/7: bit-identical
+(tests/golden/survey_ka.json): those tests need nothing but this repository.  Where oracle/_ref/*.so
+travelled to this box the live library is asked as well, in tests of their own (`..._live_reference`:
+skipped, visibly, when the library is absent -- the digest tests never are).  Reversible 5/3: bit-identical codestream, lossless decode.  Irreversible 9/7: bit-identical
 to the reference's generic build (the pin), and within the reference's own
 tolerance rule of its SIMD build (tests/test_executables.cpp:132-133: MSE within 1 %, PAE within 1).
 """
@@ -31,41 +32,64 @@ def quality(dec, img):
     return float((d * d).mean()), int(np.abs(d).max())
 
 
-def test_c2_4k_rgb_reversible_is_ka3(ref):
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def coded(name):
+    """-> (image, codestream, decoded) of a workload through the product path, once per session"""
     from openjph_amd import codec
+    if name == "c2":
+        img = synth.survey_c2()
+        cs = codec.encode(img, bit_depth=8, color_transform=True)
+    elif name == "c3":
+        img = synth.survey_c3()
+        cs = codec.Encoder(bit_depth=12, width=7680, height=4320, num_comps=3, reversible=False, qstep=0.001).encode(img)
+    else:
+        raise KeyError(name)
+    return img, cs, codec.decode(cs)
+
+
+def test_c2_4k_rgb_reversible_is_ka3():
     g = GOLD["c2"]
-    img = synth.survey_c2()
+    img, cs, dec = coded("c2")
     assert sha(img) == g["image_sha256"]
-    cs = codec.encode(img, bit_depth=8, color_transform=True)
     assert len(cs) == 16674994 == g["bytes"]                       # SURVEY.md appendix B, KA-3
-    assert sha(cs) == g["sha256"]
+    assert sha(cs) == g["sha256"]                                  # the reference's codestream, byte for byte
+    assert np.array_equal(dec, img)
+
+
+def test_c2_4k_rgb_reversible_live_reference(ref):
+    img, cs, _ = coded("c2")
     assert cs == ref.encode(img, 8, reversible=True, color_transform=True, planar=False)
-    assert np.array_equal(codec.decode(cs), img)
     back, _ = ref.decode(cs)
     assert np.array_equal(back, img)
 
 
-def test_c3_8k_irreversible_is_ka4(ref, refgen):
+def test_c3_8k_irreversible_is_ka4():
     """the headline configuration: 7680x4320x3, 12 bit, 9/7, qstep 0.001, 24 669 code-blocks"""
-    from openjph_amd import codec
     g = GOLD["c3"]
-    img = synth.survey_c3()
+    img, cs, dec = coded("c3")
     assert sha(img) == g["image_sha256"]
-    enc = codec.Encoder(bit_depth=12, width=7680, height=4320, num_comps=3, reversible=False, qstep=0.001)
-    cs = enc.encode(img)
     # bit-identical to the generic build of the reference (KA-4: 72 601 187 bytes)
     assert len(cs) == 72601187 == g["generic"]["bytes"]
     assert sha(cs) == g["generic"]["sha256"]
-    assert cs == refgen.encode(img, 12, reversible=False, color_transform=False, qstep=0.001)
-    dec = codec.decode(cs)
     assert sha(dec.astype(np.int32)) == g["generic"]["decoded_sha256"]
-    want, _ = refgen.decode(cs)
-    assert np.array_equal(dec, want)
     # the reference's own tolerance rule against its SIMD build: KA-4 says MSE 1.81186, PAE 8
     mse, pae = quality(dec, img)
     assert abs(mse - 1.81186) <= 0.01 * 1.81186 and abs(pae - 8) <= 1, (mse, pae)
+    assert abs(mse - g["generic"]["mse"]) < 1e-9 and pae == g["generic"]["pae"]
     assert abs(mse - g["simd"]["mse"]) <= 0.01 * g["simd"]["mse"] and abs(pae - g["simd"]["pae"]) <= 1
     assert abs(len(cs) - g["simd"]["bytes"]) <= 1e-4 * g["simd"]["bytes"]
+
+
+def test_c3_8k_irreversible_live_reference(ref, refgen):
+    from openjph_amd import codec
+    g = GOLD["c3"]
+    img, cs, dec = coded("c3")
+    assert cs == refgen.encode(img, 12, reversible=False, color_transform=False, qstep=0.001)
+    want, _ = refgen.decode(cs)
+    assert np.array_equal(dec, want)
     # decoder against decoder on the SIMD build's own codestream: PAE <= 1 (SURVEY.md section 8(c))
     cs_simd = ref.encode(img, 12, reversible=False, color_transform=False, qstep=0.001)
     assert sha(cs_simd) == g["simd"]["sha256"]
@@ -76,7 +100,7 @@ def test_c3_8k_irreversible_is_ka4(ref, refgen):
     assert np.array_equal(a, bg)
 
 
-def test_c4_16k_tiled_reversible(ref):
+def test_c4_16k_tiled_reversible():
     """16384x16384 16-bit, 1024x1024 tiles (256 tiles), 5/3: whole frame on one GPU and as two tile
     ranges (the multi-GPU unit of work) assembled like rank 0 does"""
     from openjph_amd import codec, shard
@@ -103,7 +127,18 @@ def test_c4_16k_tiled_reversible(ref):
         del e
     all_lens = np.concatenate(lens)
     assert sha(shard.assemble(plan.t2_main_header(all_lens), parts)) == g["sha256"]
-    back, _ = ref.decode(cs[:len(cs) // 7], resilient=True)     # the reference reads our tile-parts (a prefix: 1/7 of the file keeps this quick)
+    test_c4_16k_tiled_reversible.cs = cs
+
+
+def test_c4_16k_tiled_live_reference(ref):
+    """the reference reads our tile-parts (a prefix: 1/7 of the file keeps this quick)"""
+    from openjph_amd import codec
+    from openjph_amd.plan import Plan, make_params
+    img = synth.survey_c4()
+    cs = getattr(test_c4_16k_tiled_reversible, "cs", None)
+    if cs is None:
+        cs = codec.Encoder(plan=Plan(make_params(16384, 16384, 1, bit_depth=16, tile=(1024, 1024)))).encode(img)
+    back, _ = ref.decode(cs[:len(cs) // 7], resilient=True)
     n = 0
     for t in range(256 // 7 - 2):
         y0, x0 = (t // 16) * 1024, (t % 16) * 1024
@@ -111,7 +146,7 @@ def test_c4_16k_tiled_reversible(ref):
     assert n > 30
 
 
-def test_c5_batch_of_4k_frames(refgen):
+def test_c5_batch_of_4k_frames():
     """8 independent full-size 4K 10-bit frames through one set of launches (the unit a rank codes of the
     512-frame workload): every codestream / decoded frame equals the reference's"""
     from openjph_amd import codec
@@ -125,7 +160,6 @@ def test_c5_batch_of_4k_frames(refgen):
     streams = codec.Encoder(plan=plan, frames=B).encode(frames)
     for f in range(B):
         assert len(streams[f]) == g[f]["irv"]["bytes"] and sha(streams[f]) == g[f]["irv"]["sha256"], "frame %d" % f
-    assert streams[3] == refgen.encode(frames[3], 10, reversible=False, color_transform=False)
     dec = codec.Decoder(streams)
     out = dec.run_device().cpu().numpy()
     assert dec.failed_blocks() == 0
@@ -140,3 +174,11 @@ def test_c5_batch_of_4k_frames(refgen):
         assert len(streams[f]) == g[f]["rev"]["bytes"] and sha(streams[f]) == g[f]["rev"]["sha256"]
     out = codec.Decoder(streams).run_device().cpu().numpy()
     assert np.array_equal(out, frames[:2])
+
+
+def test_c5_frame_live_reference(refgen):
+    from openjph_amd import codec
+    frame = synth.survey_c5(3)
+    cs = codec.encode(frame, bit_depth=10, reversible=False)
+    assert sha(cs) == GOLD["c5"][3]["irv"]["sha256"]
+    assert cs == refgen.encode(frame, 10, reversible=False, color_transform=False)
