@@ -412,6 +412,7 @@ constexpr uint32_t S2_ROWS = S2_ROWS_N, S2_MAX_PER_WAVE = 8;
 // 8K frame: chains end at 0.245 ms, the launch with a last slice of 8 rows at 0.32 ms).  Slice `sl` = quad rows [lo, hi).
 struct SliceSched {
   uint32_t tail, b1, b2, max_qh, n;        // the last full-size boundary; the two cuts (== tail / b1 when they fall away); slices in all
+  uint32_t h1, h2;                         // cuts of the FIRST full-size slice (0: none): [0, h1) [h1, h2) [h2, S2_ROWS)
   __host__ __device__ explicit SliceSched(uint32_t mq) {
     max_qh = mq ? mq : 1u;
     tail = ((max_qh - 1u) / S2_ROWS) * S2_ROWS;
@@ -420,9 +421,27 @@ struct SliceSched {
 #endif
     b1 = (S2_TAIL >= 1 && max_qh > tail + 4u) ? max_qh - 4u : tail;
     b2 = (S2_TAIL >= 2 && max_qh > b1 + 2u) ? max_qh - 2u : b1;
-    n = tail / S2_ROWS + 1u + (b1 > tail ? 1u : 0u) + (b2 > b1 ? 1u : 0u);
+#ifndef S2_HEAD
+#define S2_HEAD 0                 // the first slice's cuts: 0 = none, 1 = 4 + 4 rows, 2 = 2 + 2 + 4, 3 = 2 + 6 (A/B switch)
+#endif
+    // (only where a second full-size slice follows: the workers start on the first rows while the chains are still far from done)
+    const bool head = S2_HEAD != 0 && tail >= S2_ROWS && S2_ROWS == 8u;
+    h1 = !head ? 0u : S2_HEAD == 1 ? 4u : 2u;
+    h2 = !head ? 0u : S2_HEAD == 2 ? 4u : 0u;
+    n = tail / S2_ROWS + 1u + (b1 > tail ? 1u : 0u) + (b2 > b1 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u);
   }
   __host__ __device__ void bounds(uint32_t sl, uint32_t& lo, uint32_t& hi) const {
+    const uint32_t extra = (h1 ? 1u : 0u) + (h2 ? 1u : 0u);       // pieces the first slice is cut into, beyond one
+    if (sl <= extra) {                                            // [0, h1) [h1, h2) [h2 or h1 or 0, first boundary)
+      const uint32_t first_end = tail >= S2_ROWS ? S2_ROWS : 0u;  // (0: no full-size slice at all -- then extra == 0 and the code below serves sl 0)
+      if (extra && first_end) {
+        const uint32_t c0 = 0u, c1 = h1, c2 = h2 ? h2 : first_end, c3 = first_end;
+        if (sl == 0u) { lo = c0; hi = c1; return; }
+        if (sl == 1u) { lo = c1; hi = c2; return; }
+        lo = c2; hi = c3; return;
+      }
+    }
+    sl -= extra;
     const uint32_t full = tail / S2_ROWS;
     if (sl < full) { lo = sl * S2_ROWS; hi = lo + S2_ROWS; return; }
     uint32_t j = sl - full;                // pieces of [tail, max_qh): [tail, b1) [b1, b2) [b2, max_qh), the empty ones left out
@@ -432,7 +451,7 @@ struct SliceSched {
     hi = max_qh;
   }
   __host__ __device__ bool publishes_after(uint32_t rows) const {   // rows = quad rows complete; (the last rows are published by the wavefront's end)
-    return rows < max_qh && (rows % S2_ROWS == 0u || (rows == b1 && b1 > tail) || (rows == b2 && b2 > b1));
+    return rows < max_qh && (rows % S2_ROWS == 0u || (rows == b1 && b1 > tail) || (rows == b2 && b2 > b1) || (h1 && rows == h1) || (h2 && rows == h2));
   }
 };
 constexpr int S2_RINGS = 5;                   // fused launch: worker wavefronts with at most this many blocks keep a ring per block
@@ -477,7 +496,7 @@ __device__ __forceinline__ void publish_rows(uint32_t* flag, uint32_t epoch, uin
   if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
     st_agent(flag, (epoch << 16) | rows);
 #ifdef FUSED_TIMELINE
-    const uint32_t k = rows == 0xFFFFu ? 7u : (rows >> 3) - 1u;
+    const uint32_t k = rows == 0xFFFFu ? 7u : (rows & 7u) ? 8u : (rows >> 3) - 1u;     // (only the publications of whole slices of 8 rows are kept)
     if (k < 8u) { g_tl_pub[((flag - g_tl_flags) & 1023u) * 8u + k] = (uint32_t)__builtin_amdgcn_s_memrealtime(); if (k < 4u) g_tl_pub[((flag - g_tl_flags) & 1023u) * 8u + 4u + k] = tl_a; }
 #endif
   }

@@ -492,7 +492,8 @@ extern "C" void ojphgpu_decoder_destroy(ojphgpu_decoder* d)
 {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads, &d->aux })
+  for (DeviceBuf* b : { &d->arena, &d->image, &d->dwt_descs, &d->img_descs, &d->cb_descs, &d->conv_descs, &d->data, &d->status, &d->quads, &d->aux,
+                       &d->fstate })
     b->release();
   if (d->h_retry) (void)hipHostFree(d->h_retry);
   if (d->side) (void)hipStreamDestroy(d->side);

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "openjph_amd", "libojphgpu.so")
 shutil.copy(LIB, "/tmp/lib_tl_orig.so")
-shutil.copy(os.path.join(ROOT, "openjph_amd", "variants", "lib_tl.so"), LIB)
+shutil.copy(os.path.join(ROOT, "openjph_amd", "variants", "lib_%s.so" % os.environ.get("TL_VARIANT", "tl")), LIB)
 try:
     from bench import workload_image, WORKLOADS
     from openjph_amd import codec
