@@ -172,13 +172,14 @@ def main():
     backend = os.environ.get("OJPH_BENCH_BACKEND", "nccl")
     if os.environ.get("OJPH_BENCH_ONE_GPU"):
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_info = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_info = start_process_group(backend, rank, world, local_rank, dev, torch, dist)
 
     from openjph_amd import codec
     from openjph_amd.plan import make_params
@@ -553,6 +554,8 @@ def main():
     result["dist"] = {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                       "world_size": dist.get_world_size() if world > 1 else 1,
                       "devices": torch.cuda.device_count(), "one_gpu_smoke": bool(os.environ.get("OJPH_BENCH_ONE_GPU"))}
+    if dist_info:
+        result["dist"].update(dist_info)
     rv = roofline_valu(args.workload, kinfo)
     if rv:
         result["roofline_valu"] = rv
@@ -591,6 +594,68 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def start_process_group(backend, rank, world, local_rank, dev, torch, dist):
+    """N > 1: the process group, and a self-check before anything is timed -- so that the first run on an 8-GPU node either
+    works or says at once what is wrong instead of hanging in a collective.  (The RCCL path has never met a second device in
+    this repository's own runs: RCCL refuses two ranks on one GPU, and the development boxes have one.)
+      * a watchdog around the group's first collective: no answer within OJPH_BENCH_PG_TIMEOUT_S (default 120) seconds -> the
+        rank prints who it is, what it was waiting for and the environment that matters, and exits with status 3;
+      * every rank's (host, device index, device UUID / PCI bus id) is gathered: the N ranks must sit on N distinct devices
+        (OJPH_BENCH_ONE_GPU smoke runs excepted) -- a launcher that gave two ranks the same LOCAL_RANK fails here, loudly;
+      * the RCCL version, the rendezvous address and the devices go into the line's `dist` object."""
+    import datetime
+    import socket
+    import threading
+    limit = float(os.environ.get("OJPH_BENCH_PG_TIMEOUT_S", "120"))
+
+    def watchdog(what):
+        def fire():
+            sys.stderr.write("bench.py rank %d/%d (local %d, %s): no answer from %s within %.0f s -- backend %s, MASTER_ADDR=%s MASTER_PORT=%s "
+                             "HSA_ENABLE_IPC_MODE_LEGACY=%s NCCL_DEBUG=%s, %d device(s) visible.  Set NCCL_DEBUG=INFO and run again; every rank must be "
+                             "started (torch.distributed.run --nproc-per-node N) and reach this point.\n"
+                             % (rank, world, local_rank, socket.gethostname(), what, limit, backend, os.environ.get("MASTER_ADDR"),
+                                os.environ.get("MASTER_PORT"), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ.get("NCCL_DEBUG"),
+                                torch.cuda.device_count()))
+            sys.stderr.flush()
+            os._exit(3)
+        t = threading.Timer(limit, fire)
+        t.daemon = True
+        t.start()
+        return t
+    w = watchdog("init_process_group (rendezvous)")
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=max(limit * 4, 600)))
+    w.cancel()
+    if dev is not None:
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", "") or "") or "%s/%s" % (getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?"))
+        mine = (socket.gethostname(), int(local_rank), ident, props.name)
+    else:                                                # (the CPU tests of this function: no device to name)
+        mine = (socket.gethostname(), int(local_rank), "no-device-%d" % local_rank, "cpu")
+    w = watchdog("the first collective (all_gather of the ranks' devices)")
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    t = torch.ones(1, device=dev if backend == "nccl" and dev is not None else "cpu")
+    dist.all_reduce(t)                                   # (a data-path collective as well: device tensors over RCCL)
+    if backend == "nccl" and dev is not None:
+        torch.cuda.synchronize(dev)
+    w.cancel()
+    assert int(t.item()) == world, "all_reduce over %d ranks returned %s" % (world, t.item())
+    distinct = len(set((h, u) for h, _, u, _ in everyone))
+    if not os.environ.get("OJPH_BENCH_ONE_GPU") and distinct != world:
+        sys.stderr.write("bench.py: %d ranks sit on %d distinct device(s): %s -- one process per GPU is the contract (LOCAL_RANK = device index)\n"
+                         % (world, distinct, everyone))
+        sys.stderr.flush()
+        dist.destroy_process_group()
+        sys.exit(4)
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {"rccl_version": ver if backend == "nccl" else None, "distinct_devices": distinct,
+            "rank_devices": ["%s:%d %s" % (h, i, n) for h, i, _, n in everyone], "self_check": "rendezvous, all_gather_object, all_reduce: ok",
+            "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}
 
 
 def strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist):

@@ -13,12 +13,17 @@
 // first pull() (decode).  Errors are reported as the reference reports OJPH_ERROR:
 // std::runtime_error("ojph error") after the message went to stderr.
 //
-// What the GPU path does not implement fails loudly in write_headers() /
-// read_headers() / the setter: the 64-bit sample path (bit depths above 26) and the Part-2 wavelets
-// (DFS / ATK).  Supported: per-component coding styles (COC: param_cod's comp_idx setters), per-component
-// quantisation (QCC: set_qfactor(comp, ..), set_irrev_quant(comp, ..)), NLT type 3, sub-sampling, components
-// of different bit depth / signedness, image and tile offsets, tile-part divisions, user COM markers,
-// qfactor, the IMF / BROADCAST profile checks, reduced-resolution and resilient decoding.
+// SURVEY.md section 8(f) N4 through this interface: components of up to 32 bits (the reference's 64-bit sample path, taken by
+// components that need more than 32 bits of precision inside the codec) are written and read -- the lines exchange() / pull()
+// hand out stay si32 (LFT_32BIT | LFT_INTEGER) exactly as the reference's do (ojph_codestream_local.cpp:178, :279: its
+// application-side lines are si32 at every bit depth; 64-bit lines exist only inside its tile components); codestreams with
+// Part-2 wavelets (DFS / ATK marker segments), SigProp / MagRef passes and the vertically causal block style are READ (the
+// reference has no writer for them: param_cod has no DFS / ATK setter, ojph_params.h:68-361), and
+// param_cod::get_block_vertical_causality() reports what the COD / COC said.  Also: per-component coding styles (COC:
+// param_cod's comp_idx setters), per-component quantisation (QCC: set_qfactor(comp, ..), set_irrev_quant(comp, ..)), NLT type
+// 3, sub-sampling, components of different bit depth / signedness, image and tile offsets, tile-part divisions, user COM
+// markers, qfactor, the IMF / BROADCAST profile checks, reduced-resolution and resilient decoding.  What the GPU path cannot
+// take fails loudly in write_headers() / read_headers() / the setter (std::runtime_error after the message, like OJPH_ERROR).
 // A restart()ed object codes a sequence of frames through a frame pipeline that outlives restart()
 // (pinned frame / codestream buffers, device objects made once per frame format).
 #ifndef OJPH_GPU_CODESTREAM_H
@@ -178,7 +183,7 @@ public:
   bool is_using_color_transform() const;
   bool packets_may_use_sop() const { return false; }
   bool packets_use_eph() const { return false; }
-  bool get_block_vertical_causality() const { return false; }
+  bool get_block_vertical_causality() const;         // the COD's code-block style bit 3, as parsed (ojph_params.cpp:368-370)
   // COC marker segments (ojph_params.h:146-158): the first call for a component creates its COC from
   // the SPcod defaults (5 decompositions, 64x64 blocks, wavelet_trans 0 = the 9/7, 32768x32768
   // precincts; ojph_params_local.h:344-353), not from the COD; later calls modify it.  Components 0..15.
@@ -192,7 +197,7 @@ public:
   bool is_reversible(ui32 comp_idx) const;
   size get_precinct_size(ui32 comp_idx, ui32 level_num) const;
   size get_log_precinct_size(ui32 comp_idx, ui32 level_num) const;
-  bool get_block_vertical_causality(ui32) const { return false; }
+  bool get_block_vertical_causality(ui32 comp_idx) const;   // the component's COC if it has one, else the COD (ojph_params.cpp:396-399)
 private:
   local::codestream_state* state;
 };

@@ -135,19 +135,30 @@ inline void write_pnm(const char* name, Image& img) {
   fclose(f);
 }
 
-// planar raw (.yuv / .raw): 1 byte per sample up to 8 bits, else 2 bytes little-endian (as the reference's yuv reader)
+// planar raw (.yuv / .raw), little-endian, (bit depth + 7) / 8 bytes per sample: 1 and 2 as the reference's yuv reader /
+// writer, 3 and 4 as its .raw reader / writer for deep samples (raw_in::read, ojph_img_io.cpp:1540-1617; raw_out::write,
+// :1679-1810 -- signed samples extend from the container's top bit on the way in; on the way out 3- and 4-byte samples are
+// limited to lower <= v <= upper with upper = 2^(depth-1) for signed, 2^depth for unsigned samples, the reference's bounds)
+inline size_t raw_bytes_per_sample(unsigned bit_depth) { return bit_depth > 24 ? 4 : bit_depth > 16 ? 3 : bit_depth > 8 ? 2 : 1; }
+
 inline void read_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "rb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
   // img.layout() was called: planes follow each other, each with its own sample size
   for (unsigned c = 0; c < img.num_comps; ++c) {
-    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = img.bd(c) > 8 ? 2 : 1;
+    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = raw_bytes_per_sample(img.bd(c));
     std::vector<unsigned char> raw(n * bps);
     if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); throw std::runtime_error("short raw file"); }
     int* dst = img.plane(c);
     for (size_t i = 0; i < n; ++i) {
-      int v = bps == 2 ? raw[2 * i] | (raw[2 * i + 1] << 8) : raw[i];
-      if (img.sg(c)) { const int sh = 32 - (int)img.bd(c); v = (int)((unsigned)v << sh) >> sh; }
+      const unsigned char* q = raw.data() + i * bps;
+      unsigned u = q[0];
+      for (size_t k = 1; k < bps; ++k) u |= (unsigned)q[k] << (8 * k);
+      int v = (int)u;
+      if (img.sg(c)) {
+        const int sh = bps > 2 ? 32 - 8 * (int)bps : 32 - (int)img.bd(c);   // (1- and 2-byte samples: from the bit depth, as before)
+        v = (int)(u << sh) >> sh;
+      }
       dst[i] = v;
     }
   }
@@ -158,12 +169,15 @@ inline void write_raw(const char* name, Image& img) {
   FILE* f = fopen(name, "wb");
   if (!f) throw std::runtime_error(std::string("cannot open ") + name);
   for (unsigned c = 0; c < img.num_comps; ++c) {
-    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = img.bd(c) > 8 ? 2 : 1;
+    const size_t n = (size_t)img.cw[c] * img.ch[c], bps = raw_bytes_per_sample(img.bd(c));
     std::vector<unsigned char> raw(n * bps);
     const int* src = img.plane(c);
+    const long long upper = img.sg(c) ? 1ll << (img.bd(c) - 1) : 1ll << img.bd(c), lower = img.sg(c) ? -(1ll << (img.bd(c) - 1)) : 0ll;
     for (size_t i = 0; i < n; ++i) {
-      const int v = src[i];
-      if (bps == 2) { raw[2 * i] = (unsigned char)v; raw[2 * i + 1] = (unsigned char)(v >> 8); } else raw[i] = (unsigned char)v;
+      long long v = img.sg(c) ? (long long)src[i] : (long long)(unsigned)src[i];
+      if (bps > 2) { v = v < upper ? v : upper; v = v >= lower ? v : lower; }
+      else v = src[i];
+      for (size_t k = 0; k < bps; ++k) raw[i * bps + k] = (unsigned char)(v >> (8 * k));
     }
     fwrite(raw.data(), 1, raw.size(), f);
   }

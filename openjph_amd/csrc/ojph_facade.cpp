@@ -429,6 +429,14 @@ void param_cod::set_precinct_size(ui32 comp_idx, int num_levels, size* precinct_
   }
 }
 void param_cod::set_reversible(ui32 comp_idx, bool reversible) { coc_of(state, comp_idx).reversible = reversible ? 1 : 0; }
+// (ojph_params.cpp:368-370, :396-399) bit 3 of the code-block style byte of the COD / of the component's COC, kept by the
+// parser in reserved[0] bit 0 (include/ojphgpu.h); a codestream this library writes never sets it
+bool param_cod::get_block_vertical_causality() const { return (state->p.reserved[0] & 1u) != 0; }
+bool param_cod::get_block_vertical_causality(ui32 c) const
+{
+  const ojphgpu_coc* k = coc_if(state, c);
+  return k ? (k->reserved[0] & 1u) != 0 : get_block_vertical_causality();
+}
 ui32 param_cod::get_num_decompositions(ui32 c) const { const ojphgpu_coc* k = coc_if(state, c); return k ? k->num_decomps : get_num_decompositions(); }
 size param_cod::get_log_block_dims(ui32 c) const { const ojphgpu_coc* k = coc_if(state, c); return k ? size(k->log_block_w, k->log_block_h) : get_log_block_dims(); }
 size param_cod::get_block_dims(ui32 c) const { const size l = get_log_block_dims(c); return size(1u << l.w, 1u << l.h); }

@@ -302,3 +302,157 @@ def test_cli_qfactor_and_mixed_bit_depths(tmp_path):
     r = run([EXPAND, "-i", str(tmp_path / "m.j2c"), "-o", str(tmp_path / "m_back.raw")])
     assert r.returncode == 0, r.stdout
     assert open(tmp_path / "m_back.raw", "rb").read() == open(tmp_path / "m.raw", "rb").read()
+
+
+# ---- SURVEY.md section 8(f) N4 through the N3 boundary: deep samples, Part-2 wavelets, the causal block style -----------
+FACADE_N4 = os.path.join(ROOT, "openjph_amd", "apps", "facade_deep_and_part2")
+
+
+def _raw_bytes(bd):
+    return 4 if bd > 24 else 3 if bd > 16 else 2 if bd > 8 else 1
+
+
+def write_raw(path, img, bd):
+    """planar little-endian raw, (bit depth + 7) / 8 bytes per sample (the reference's raw_in, ojph_img_io.cpp:1540-1617)"""
+    b = _raw_bytes(bd)
+    u = img.astype(np.int64).astype(np.uint64)
+    with open(path, "wb") as f:
+        for c in range(img.shape[0]):
+            f.write(np.stack([((u[c] >> (8 * k)) & 0xFF).astype(np.uint8) for k in range(b)], axis=-1).tobytes())
+
+
+def read_raw(path, shapes, bd, signed):
+    b = _raw_bytes(bd)
+    raw = np.fromfile(path, dtype=np.uint8)
+    out, at = [], 0
+    for (h, w) in shapes:
+        a = raw[at:at + h * w * b].reshape(h, w, b).astype(np.uint64); at += h * w * b
+        v = sum(a[..., k] << np.uint64(8 * k) for k in range(b)).astype(np.int64)
+        if signed:
+            v = np.where(v >= (1 << (8 * b - 1)), v - (1 << (8 * b)), v)
+        out.append(v)
+    assert at == raw.size
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd,signed", [(32, False), (32, True), (31, True), (27, False), (24, True), (20, False)])
+def test_cli_deep_samples(tmp_path, bd, signed):
+    """components of more than 16 bits through ojph_compress / ojph_expand: .raw files with 3- and 4-byte samples (the
+    reference's raw_in / raw_out), above 26 bits the reference's 64-bit sample path (ojph_encode_codeblock64 / ...decode...).
+    The codestream is the oracle pipeline's byte for byte (pinned to the live reference's encoder by tests/test_cpu_wide.py and,
+    where oracle/_ref travelled here, compared with it directly); the round trip is lossless"""
+    from oracle import refbind
+    from tests import cpu_pipeline as cp
+    from tests.test_gpu_wide import deep_image
+    h, w = 75, 131
+    img = deep_image(1, h, w, bd, signed)
+    src = tmp_path / "in.raw"
+    write_raw(src, img, bd)
+    j2c = tmp_path / "out.j2c"
+    r = run([COMPRESS, "-i", str(src), "-o", str(j2c), "-reversible", "true", "-dims", "{%d,%d}" % (w, h), "-num_comps", "1",
+             "-signed", "true" if signed else "false", "-bit_depth", str(bd), "-num_decomps", "4"])
+    assert r.returncode == 0, r.stdout
+    got = open(j2c, "rb").read()
+    want, *_ = cp.encode(img, bit_depth=bd, is_signed=signed, num_decomps=4)
+    assert got == want
+    if refbind.available():
+        assert got == refbind.Ref().encode(img, bd, reversible=True, color_transform=False, is_signed=signed, num_decomps=4)
+    back = tmp_path / "back.raw"
+    r = run([EXPAND, "-i", str(j2c), "-o", str(back)])
+    assert r.returncode == 0, r.stdout
+    dec, = read_raw(back, [(h, w)], bd, signed)
+    truth = img[0].astype(np.int64) if signed else img[0].astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(dec, truth)
+
+
+@pytest.mark.gpu
+def test_facade_deep_lines_are_si32_lines(tmp_path):
+    """tests/facade/deep_and_part2.cpp `write`: 32-, 31- and 28-bit frames in and out through exchange() / pull() -- si32 lines
+    as in the reference (ojph_codestream_local.cpp:178, :279), every sample back, the stream the oracle pipeline writes"""
+    from tests import cpu_pipeline as cp
+    for bd, sg in ((32, 0), (31, 1), (28, 0)):
+        path = tmp_path / ("deep_%d_%d.j2c" % (bd, sg))
+        r = run([FACADE_N4, "write", str(path), "150", "67", str(bd), str(sg)])
+        assert r.returncode == 0 and b"all checks passed" in r.stdout, r.stdout
+        cs = open(path, "rb").read()
+        dec, _ = cp.decode(cs)                              # the oracle pipeline reads what the facade wrote ...
+        want, *_ = cp.encode(dec, bit_depth=bd, is_signed=bool(sg), num_decomps=4)
+        assert cs == want                                   # ... and writes the same bytes from the same samples
+
+
+def _part2_streams():
+    from tests.part2_cases import CASES, case_id
+    return [pytest.param(c, id=case_id(c)) for c in CASES]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _part2_streams())
+def test_expand_and_facade_read_part2_streams(tmp_path, case):
+    """codestreams with ATK / DFS marker segments (and a deep one under a DFS decomposition) through ojph_expand and through
+    ojph::codestream::read_headers / create / pull: the samples of the oracle pipeline's decode -- pinned to the reference's
+    decoder by tests/test_cpu_part2.py -- and, where oracle/_ref travelled here, of the reference's decode of the same bytes
+    (param_atk::read / param_dfs::read, ojph_params.cpp:2596-2866; ojph_expand.cpp:389-425)"""
+    from oracle import refbind
+    from tests import cpu_pipeline as cp
+    from tests.part2_cases import image, split
+    nc, h, w, bd, kw = split(case)
+    img = image(nc, h, w, bd)
+    cs, plan, *_ = cp.encode(img, **kw)
+    want, _ = cp.decode(cs)
+    rev_all = all(plan.comp_style(i)["reversible"] for i in range(nc))
+    if refbind.available(generic=not rev_all):
+        rdec, _ = refbind.Ref(generic=not rev_all).decode(cs)
+        assert np.array_equal(np.asarray(want), np.asarray(rdec))
+    j2c = tmp_path / "p2.j2c"
+    open(j2c, "wb").write(cs)
+    # the facade: planes as int32
+    dump = tmp_path / "p2.bin"
+    r = run([FACADE_N4, "read", str(j2c), str(dump)])
+    assert r.returncode == 0 and b"all checks passed" in r.stdout, r.stdout
+    got = np.fromfile(dump, dtype=np.int32).reshape(nc, h, w)
+    assert np.array_equal(got, np.asarray(want).astype(np.int64).astype(np.uint64).astype(np.uint32).view(np.int32).reshape(nc, h, w))
+    # ojph_expand: a planar raw file
+    out = tmp_path / ("p2.raw" if bd > 16 else "p2.yuv")
+    r = run([EXPAND, "-i", str(j2c), "-o", str(out)])
+    assert r.returncode == 0, r.stdout
+    planes = read_raw(out, [(h, w)] * nc, bd, False)
+    lim = (1 << bd) - 1
+    for c in range(nc):
+        exp = np.asarray(want)[c].astype(np.int64)
+        exp = np.clip(exp, 0, lim + 1) if bd > 16 else exp & ((1 << (8 * _raw_bytes(bd))) - 1)      # (3- / 4-byte samples are limited like raw_out's)
+        assert np.array_equal(planes[c], exp), "component %d" % c
+
+
+@pytest.mark.gpu
+def test_facade_reports_the_vertically_causal_block_style(tmp_path):
+    """param_cod::get_block_vertical_causality() (ojph_params.h:144,158; ojph_params.cpp:368-370): bit 3 of the code-block
+    style byte of the COD / of a COC, as parsed.  The bit only matters to SigProp passes; a cleanup-only stream with the bit
+    set decodes to the same samples (the reference's too)"""
+    from oracle import refbind
+    from tests import cpu_pipeline as cp
+    img = synth_image(2, 70, 90, 8, seed=4)
+    cs, *_ = cp.encode(img, bit_depth=8, coc={1: dict(reversible=True, num_decomps=2)})
+    want, _ = cp.decode(cs)
+    cod = cs.index(b"\xff\x52")
+    assert cs[cod + 12] == 0x40
+    coc = cs.index(b"\xff\x53")
+    assert cs[coc + 9] == 0x40                              # marker(2) Lcoc(2) Ccoc(1) Scoc(1) decomps xcb ycb | style
+    for name, patch, flags in (("plain", {}, (0, 0, 0)), ("cod", {cod + 12: 0x48}, (1, 1, 0)), ("coc", {coc + 9: 0x48}, (0, 0, 1)),
+                               ("both", {cod + 12: 0x48, coc + 9: 0x48}, (1, 1, 1))):
+        b = bytearray(cs)
+        for at, v in patch.items():
+            b[at] = v
+        path = tmp_path / (name + ".j2c")
+        open(path, "wb").write(bytes(b))
+        r = run([FACADE_N4, "read", str(path), str(tmp_path / "o.bin")])
+        assert r.returncode == 0 and b"all checks passed" in r.stdout, r.stdout
+        text = r.stdout.decode()
+        assert "components 2 causal %d" % flags[0] in text, text
+        assert "comp 0:" in text and text.split("comp 0:")[1].splitlines()[0].endswith("causal %d" % flags[1]), text
+        assert text.split("comp 1:")[1].splitlines()[0].endswith("causal %d" % flags[2]), text
+        got = np.fromfile(tmp_path / "o.bin", dtype=np.int32).reshape(2, 70, 90)
+        assert np.array_equal(got, want)
+        if refbind.available():
+            rdec, _ = refbind.Ref().decode(bytes(b))
+            assert np.array_equal(np.asarray(rdec), want)

@@ -167,3 +167,43 @@ def test_tile_parts_assembled_on_the_device_and_gathered_over_rccl():
         assert shard.assemble(plan.t2_main_header(all_lens), parts) == want
     finally:
         dist.destroy_process_group()
+
+
+def _selfcheck_worker(rank, world, port, local_rank, mode, q):
+    """bench.start_process_group on CPU (gloo, no device): the self-check N > 1 runs begin with"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OJPH_BENCH_PG_TIMEOUT_S="8")
+    os.environ.pop("OJPH_BENCH_ONE_GPU", None)
+    import torch
+    import torch.distributed as dist
+    import bench
+    if mode == "absent" and rank == 1:
+        return                                                # a rank that never starts: the others must not wait for ever
+    info = bench.start_process_group("gloo", rank, world, local_rank, None, torch, dist)
+    if rank == 0:
+        q.put(info)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ok", "same_device", "absent"])
+def test_bench_multi_rank_self_check(mode):
+    """`bench.py --gpus N` checks its process group before it times anything: N ranks on N distinct devices, the first
+    collectives answered -- and a rank whose peers never come says so and exits (status 3) instead of hanging"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selfcheck_worker, args=(r, 2, port, 0 if mode == "same_device" else r, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert not p.is_alive(), "a rank hangs"
+    codes = [p.exitcode for p in procs]
+    if mode == "ok":
+        assert codes == [0, 0]
+        info = q.get(timeout=10)
+        assert info["distinct_devices"] == 2 and len(info["rank_devices"]) == 2 and "ok" in info["self_check"]
+    elif mode == "same_device":
+        assert codes == [4, 4], codes                         # two ranks on one device: refused, loudly
+    else:
+        assert codes[0] == 3 and codes[1] == 0, codes         # rank 0 gave up on the rendezvous with a diagnostic
