@@ -258,14 +258,28 @@ template <typename T> struct ImgElem<8, T> { typedef signed char type; };
 // only when it is consumed one iteration later (unpack).  No branch around a load and no use of the
 // loaded registers next to it means no wait at the load: the fetch of row pair t+1 is in flight
 // while pair t is lifted.  Samples that do not exist are never read by the lifting steps (pick()).
-template <typename E> struct Raw { E x, y; };
-template <typename E>
+// (What a load returns stays in the registers it arrived in until unpack(): two 16- or 8-bit samples as the ONE register
+// the load filled, two 32-bit samples as two.  A field extracted next to the load -- "r.y = v >> 16", or a copy that merges
+// the two arms of the w == 1 case -- is a use of the loaded register and puts a wait right behind the load.)
+template <typename E, bool SMALL = (sizeof(E) < 4)> struct Raw;
+template <typename E> struct Raw<E, true> { uint32_t p; };      // both samples as loaded: the first in the low bits (w == 1: the one sample, zero-extended)
+template <typename E> struct Raw<E, false> { E x, y; };         // (w == 1: both are the one sample)
+// W1: the plane is one column wide (a property of the plane, so of the whole workgroup: the kernels run their pipeline loop
+// in a W1 = true or a W1 = false instantiation, and the loads of the latter have no branch around them at all)
+template <typename E, bool W1>
 __device__ __forceinline__ Raw<E> load_raw(const void* __restrict__ rowp, const Geo& g)
 {
   const E* row = (const E*)rowp;
   Raw<E> r;
-  if (g.w == 1) { r.x = row[0]; r.y = r.x; }              // wave-uniform; the only sample is column 0
-  else { const typename Vec2<E>::type v = *reinterpret_cast<const typename Vec2<E>::type*>(row + g.xc); r.x = v.x; r.y = v.y; }
+  if constexpr (sizeof(E) < 4) {
+    typedef typename std::conditional<sizeof(E) == 2, unsigned short, unsigned char>::type UE;
+    typedef typename std::conditional<sizeof(E) == 2, uint32_t, unsigned short>::type PK __attribute__((aligned(sizeof(E))));
+    if constexpr (W1) r.p = (uint32_t)*reinterpret_cast<const UE*>(row);  // the only sample is column 0
+    else r.p = (uint32_t)*reinterpret_cast<const PK*>(row + g.xc);
+  } else {
+    if constexpr (W1) { r.x = row[0]; r.y = r.x; }
+    else { const typename Vec2<E>::type v = *reinterpret_cast<const typename Vec2<E>::type*>(row + g.xc); r.x = v.x; r.y = v.y; }
+  }
   return r;
 }
 
@@ -283,7 +297,12 @@ template <class WP, int IMG, typename E>
 __device__ __forceinline__ Pair<typename WP::T> unpack(const Raw<E>& v, const Geo& g, const Conv& cv)
 {
   Pair<typename WP::T> p;
-  const auto a = g.from_y ? v.y : v.x, b = g.from_x ? v.x : v.y;
+  E vx, vy;
+  if constexpr (sizeof(E) < 4) {
+    vx = (E)(v.p & ((1u << (8 * sizeof(E))) - 1u));
+    vy = g.w == 1 ? vx : (E)(v.p >> (8 * sizeof(E)));
+  } else { vx = v.x; vy = v.y; }
+  const auto a = g.from_y ? vy : vx, b = g.from_x ? vx : vy;
   if constexpr (IMG != 0) { p.l = Cv<WP::REV>::from_image(sample_of<IMG>(a, cv), cv); p.h = Cv<WP::REV>::from_image(sample_of<IMG>(b, cv), cv); }
   else { p.l = (typename WP::T)a; p.h = (typename WP::T)b; }
   return p;
@@ -334,14 +353,11 @@ __device__ __forceinline__ void unpack_all(const Raw<E>* v, const Geo& g, const 
 // nothing is ever waited for right after it was issued.  arrived() pins that wait to the top of the
 // iteration on every control path (otherwise a path that skips a fetched row leaves the wait to the
 // next write of the same registers -- which comes right after the stores).
-template <typename A>
-__device__ __forceinline__ void arrived(const A& a, const A& b, const A& c, const A& d)
+template <typename E>
+__device__ __forceinline__ void arrived(const Raw<E>& a, const Raw<E>& b)
 {
-  asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d));
-}
-__device__ __forceinline__ void arrived(const signed char& a, const signed char& b, const signed char& c, const signed char& d)
-{
-  asm volatile("" :: "v"((short)a), "v"((short)b), "v"((short)c), "v"((short)d));   // no 8-bit register class
+  if constexpr (sizeof(E) < 4) asm volatile("" :: "v"(a.p), "v"(b.p));
+  else asm volatile("" :: "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -372,7 +388,11 @@ __device__ __forceinline__ void dwt_block_coords(int row_pairs_arg, int& bx, int
   bx = (int)(V % gridDim.x); by = (int)(V / gridDim.x);
 }
 
-template <class WP, int IMG, int NC>
+// U = row pairs per trip of the pipeline loop (1 or 2).  A trip ends in ONE wait for everything it has in flight -- loads and
+// stores share vmcnt and are not counted down in order against each other, so a wait for the rows of the next pair drains
+// the stores as well -- and with U = 2 a wavefront has twice the bytes under way per wait: 4 row loads and 8 sub-band row
+// stores (forward), 8 and 4 (inverse).  Same arithmetic in the same order; only when rows are requested and stored changes.
+template <class WP, int IMG, int NC, int U = 1>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
                                                           const void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
@@ -415,10 +435,10 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const int h = g.h, oy = g.oy;
   auto exL = [&](int t) { int y = 2 * t - oy; return y >= 0 && y < h; };
   auto exH = [&](int t) { int y = 2 * t + 1 - oy; return y >= 0 && y < h; };
-  auto ldrow = [&](int y, RawRow* r) {                     // image row y of every plane, clamped into the plane
+  auto ldrow_w = [&](int y, RawRow* r, auto w1) {          // image row y of every plane, clamped into the plane
     const size_t o = (size_t)min(max(y, 0), h - 1) * sp;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) r[k] = load_raw<E>(src[k] + o, g);
+    for (int k = 0; k < NC; ++k) r[k] = load_raw<E, decltype(w1)::value>(src[k] + o, g);
   };
   auto put = [&](int k, int t, bool low_row, T vl, T vh) {   // one transformed row of plane k -> its two sub-bands
     if (!g.store) return;
@@ -432,7 +452,7 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
     if (i0 > 0) return;
     RawRow r0[NC]; Pair<T> x[NC];
-    ldrow(0, r0);
+    if (g.w == 1) ldrow_w(0, r0, std::true_type()); else ldrow_w(0, r0, std::false_type());
     unpack_all<WP, IMG, NC>(r0, g, cvs, x);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
@@ -444,79 +464,105 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   }
 
   // vertical software pipeline over row pairs t; see file header
+  auto pipeline = [&](auto w1) {
+  auto ldrow = [&](int y, RawRow* r) { ldrow_w(y, r, w1); };
   const int t0 = max(i0 - WP::WARM, 0);
-  Pair<T> xl[NC], xn[NC], a[NC], ap[NC], b[NC], bp[NC], c[NC], cp[NC];   // x[2t], x[2t+2], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
-  Pair<T> out_lo[NC], out_hi[NC];        // transformed rows of pair out_t, stored one iteration later
-#pragma unroll
-  for (int k = 0; k < NC; ++k) { xl[k].l = xl[k].h = 0; a[k] = ap[k] = b[k] = bp[k] = c[k] = cp[k] = out_lo[k] = out_hi[k] = xl[k]; }
-  int out_t = 0; bool has_lo = false, has_hi = false;
-  RawRow rh[NC], rn[NC];
-  ldrow(2 * t0 - oy, rh);
-  unpack_all<WP, IMG, NC>(rh, g, cvs, xl);
-  ldrow(2 * t0 + 1 - oy, rh); ldrow(2 * t0 + 2 - oy, rn);                     // rows of iteration t0
-  for (int t = t0; t <= i1; ++t) {
-#pragma unroll
-    for (int k = 0; k < NC; ++k) arrived(rh[k].x, rh[k].y, rn[k].x, rn[k].y);
-    Pair<T> xh[NC];
-    unpack_all<WP, IMG, NC>(rh, g, cvs, xh);
-    unpack_all<WP, IMG, NC>(rn, g, cvs, xn);
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
-      if (has_hi) put(k, out_t, false, out_hi[k].l, out_hi[k].h);
-    }
-    has_lo = has_hi = false;
-    if (t < i1) {                                          // request the rows of iteration t+1 now
-      ldrow(2 * t + 3 - oy, rh);
-      ldrow(2 * t + 4 - oy, rn);
-    }
-    // interior of the plane (every row t-2 .. t+1 exists, no strip edge): the selects fold away
-    auto lift = [&](auto chk) {
-      constexpr bool CHK = decltype(chk)::value;
-      const bool eLt = exL(t), eHt = exH(t), eLn = exL(t + 1);
-      const bool eHp = exH(t - 1), eLp = exL(t - 1), eHpp = exH(t - 2);
-      const bool emit = t - 1 >= i0 && t - 1 < i1;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        // a[t]
-        ap[k] = a[k];
-        a[k].l = w.a0(xh[k].l, pick<CHK>(eLt, xl[k].l, xn[k].l), pick<CHK>(eLn, xn[k].l, xl[k].l));
-        a[k].h = w.a0(xh[k].h, pick<CHK>(eLt, xl[k].h, xn[k].h), pick<CHK>(eLn, xn[k].h, xl[k].h));
-        // b[t]
-        const Pair<T> bo = b[k];                // b[t-1]
-        b[k].l = w.a1(xl[k].l, pick<CHK>(eHp, ap[k].l, a[k].l), pick<CHK>(eHt, a[k].l, ap[k].l));
-        b[k].h = w.a1(xl[k].h, pick<CHK>(eHp, ap[k].h, a[k].h), pick<CHK>(eHt, a[k].h, ap[k].h));
-        bp[k] = bo;
-        // c[t-1]
-        cp[k] = c[k];
-        c[k].l = w.a2(ap[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
-        c[k].h = w.a2(ap[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
-        // d[t-1]
-        const T dl = w.a3(bp[k].l, pick<CHK>(eHpp, cp[k].l, c[k].l), pick<CHK>(eHp, c[k].l, cp[k].l));
-        const T dh = w.a3(bp[k].h, pick<CHK>(eHpp, cp[k].h, c[k].h), pick<CHK>(eHp, c[k].h, cp[k].h));
-        if (emit) {
-          if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
-            out_lo[k].l = w.mulKinv(dl); out_lo[k].h = w.mulKinv(dh);
-            horz_analysis<WP, CHK>(w, out_lo[k].l, out_lo[k].h, g);
-          }
-          if (!CHK || eHp) {                                   // :663-664
-            out_hi[k].l = w.mulK(c[k].l); out_hi[k].h = w.mulK(c[k].h);
-            horz_analysis<WP, CHK>(w, out_hi[k].l, out_hi[k].h, g);
-          }
-        }
-      }
-      if (emit) { out_t = t - 1; has_lo = !CHK || eLp; has_hi = !CHK || eHp; }
-    };
-    if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * (t + 1) - oy < h) lift(std::false_type());
-    else lift(std::true_type());
-#pragma unroll
-    for (int k = 0; k < NC; ++k) xl[k] = xn[k];
-  }
+  Pair<T> xl[NC], a[NC], ap[NC], b[NC], bp[NC], c[NC], cp[NC];   // x[2t], a[t], a[t-1], b[t], b[t-1], c[t-1], c[t-2]
+  Pair<T> out_lo[U][NC], out_hi[U][NC];  // transformed rows of pair out_t, stored one trip later
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    if (has_lo) put(k, out_t, true, out_lo[k].l, out_lo[k].h);
-    if (has_hi) put(k, out_t, false, out_hi[k].l, out_hi[k].h);
+    xl[k].l = xl[k].h = 0; a[k] = ap[k] = b[k] = bp[k] = c[k] = cp[k] = xl[k];
+#pragma unroll
+    for (int u = 0; u < U; ++u) out_lo[u][k] = out_hi[u][k] = xl[k];
   }
+  int out_t[U]; bool has_lo[U], has_hi[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { out_t[u] = 0; has_lo[u] = has_hi[u] = false; }
+  RawRow rh[U][NC], rn[U][NC];
+  ldrow(2 * t0 - oy, rh[0]);
+  unpack_all<WP, IMG, NC>(rh[0], g, cvs, xl);
+#pragma unroll
+  for (int u = 0; u < U; ++u) { ldrow(2 * (t0 + u) + 1 - oy, rh[u]); ldrow(2 * (t0 + u) + 2 - oy, rn[u]); }   // rows of the first trip
+  for (int t = t0; t <= i1; t += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) arrived(rh[u][k], rn[u][k]);
+    Pair<T> xh[U][NC], xn[U][NC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unpack_all<WP, IMG, NC>(rh[u], g, cvs, xh[u]);
+      unpack_all<WP, IMG, NC>(rn[u], g, cvs, xn[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (has_lo[u]) put(k, out_t[u], true, out_lo[u][k].l, out_lo[u][k].h);
+        if (has_hi[u]) put(k, out_t[u], false, out_hi[u][k].l, out_hi[u][k].h);
+      }
+      has_lo[u] = has_hi[u] = false;
+    }
+    if (t + U <= i1) {                                     // request the rows of the next trip now
+#pragma unroll
+      for (int u = 0; u < U; ++u) { ldrow(2 * (t + U + u) + 1 - oy, rh[u]); ldrow(2 * (t + U + u) + 2 - oy, rn[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tt = t + u;
+      if (u != 0 && tt > i1) break;
+      // interior of the plane (every row tt-2 .. tt+1 exists, no strip edge): the selects fold away
+      auto lift = [&](auto chk) {
+        constexpr bool CHK = decltype(chk)::value;
+        const bool eLt = exL(tt), eHt = exH(tt), eLn = exL(tt + 1);
+        const bool eHp = exH(tt - 1), eLp = exL(tt - 1), eHpp = exH(tt - 2);
+        const bool emit = tt - 1 >= i0 && tt - 1 < i1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          // a[t]
+          ap[k] = a[k];
+          a[k].l = w.a0(xh[u][k].l, pick<CHK>(eLt, xl[k].l, xn[u][k].l), pick<CHK>(eLn, xn[u][k].l, xl[k].l));
+          a[k].h = w.a0(xh[u][k].h, pick<CHK>(eLt, xl[k].h, xn[u][k].h), pick<CHK>(eLn, xn[u][k].h, xl[k].h));
+          // b[t]
+          const Pair<T> bo = b[k];                // b[t-1]
+          b[k].l = w.a1(xl[k].l, pick<CHK>(eHp, ap[k].l, a[k].l), pick<CHK>(eHt, a[k].l, ap[k].l));
+          b[k].h = w.a1(xl[k].h, pick<CHK>(eHp, ap[k].h, a[k].h), pick<CHK>(eHt, a[k].h, ap[k].h));
+          bp[k] = bo;
+          // c[t-1]
+          cp[k] = c[k];
+          c[k].l = w.a2(ap[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+          c[k].h = w.a2(ap[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+          // d[t-1]
+          const T dl = w.a3(bp[k].l, pick<CHK>(eHpp, cp[k].l, c[k].l), pick<CHK>(eHp, c[k].l, cp[k].l));
+          const T dh = w.a3(bp[k].h, pick<CHK>(eHpp, cp[k].h, c[k].h), pick<CHK>(eHp, c[k].h, cp[k].h));
+          if (emit) {
+            if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
+              out_lo[u][k].l = w.mulKinv(dl); out_lo[u][k].h = w.mulKinv(dh);
+              horz_analysis<WP, CHK>(w, out_lo[u][k].l, out_lo[u][k].h, g);
+            }
+            if (!CHK || eHp) {                                   // :663-664
+              out_hi[u][k].l = w.mulK(c[k].l); out_hi[u][k].h = w.mulK(c[k].h);
+              horz_analysis<WP, CHK>(w, out_hi[u][k].l, out_hi[u][k].h, g);
+            }
+          }
+        }
+        if (emit) { out_t[u] = tt - 1; has_lo[u] = !CHK || eLp; has_hi[u] = !CHK || eHp; }
+      };
+      if (g.inner && 2 * (tt - 2) - oy >= 0 && 2 * (tt + 1) - oy < h) lift(std::false_type());
+      else lift(std::true_type());
+#pragma unroll
+      for (int k = 0; k < NC; ++k) xl[k] = xn[u][k];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (has_lo[u]) put(k, out_t[u], true, out_lo[u][k].l, out_lo[u][k].h);
+      if (has_hi[u]) put(k, out_t[u], false, out_hi[u][k].l, out_hi[u][k].h);
+    }
+  };
+  if (g.w == 1) pipeline(std::true_type()); else pipeline(std::false_type());
 }
 
 struct __attribute__((aligned(4))) I2 { int x, y; };        // 8-byte access that only promises dword alignment
@@ -598,7 +644,7 @@ __device__ __forceinline__ void store_rows(char* const* dst, size_t off, const G
 // ---------------------------------------------------------------------------------------------
 // inverse: LL, HL, LH, HH -> plane (or image plane, IMG); NC as in the forward kernel
 // ---------------------------------------------------------------------------------------------
-template <class WP, int IMG, int NC>
+template <class WP, int IMG, int NC, int U = 1>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
                                                           void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
@@ -666,55 +712,97 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     return;
   }
 
+  // The pipeline loop, in two instantiations.  W1 = false (every plane but the one-column ones): the sub-band rows are fetched
+  // UNCONDITIONALLY, from a row and a column clamped into the band (every band of a plane of at least 2 x 2 samples has
+  // samples), and what does not exist becomes zero when the fetched registers are consumed a trip later -- no branch and no
+  // instruction touches a loaded register next to its load, so nothing waits there.  (With the loads under "if (exists)" the
+  // compiler merged them with the zero they replace and, depending on the instantiation, put a wait behind every one of
+  // them: eight round trips per trip where one is needed.)  W1 = true: the conditional loads, as before.
+  auto pipeline = [&](auto w1) {
+  constexpr bool W1 = decltype(w1)::value;
+  const int nlc = ((g.ox + g.w + 1) >> 1) - ((g.ox + 1) >> 1), nlr = ((oy + h + 1) >> 1) - ((oy + 1) >> 1);   // low columns / rows of the plane
+  const int col_l = min(max(g.j - g.ox, 0), max(nlc - 1, 0)), col_h = min(max(g.j, 0), max(g.w - nlc - 1, 0));
+  auto fetch_any = [&](int t, bool low_row, Pair<T>* p) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const T* lo = low_row ? ll[k] : lh[k]; const T* hi = low_row ? hl[k] : hh[k];
+      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+      const int rows = low_row ? nlr : h - nlr;
+      const int r = min(max(low_row ? t - oy : t, 0), rows - 1);
+      p[k].l = lo[(size_t)r * lop + col_l];
+      p[k].h = hi[(size_t)r * hip + col_h];
+    }
+  };
+  auto request = [&](int t, Pair<T>* plo, Pair<T>* phi) {
+    if constexpr (W1) { fetch(t, true, exL(t), plo); fetch(t, false, exH(t), phi); }
+    else { fetch_any(t, true, plo); fetch_any(t, false, phi); }
+  };
+  auto existing = [&](int t, bool low_row, const Pair<T>& v) {   // a fetched pair as the lifting steps take it
+    if constexpr (W1) return v;
+    else { const bool ex = low_row ? exL(t) : exH(t); Pair<T> o; o.l = (ex && g.eL) ? v.l : (T)0; o.h = (ex && g.eH) ? v.h : (T)0; return o; }
+  };
   const int t0 = max(i0 - WP::WARM, 0);
   Pair<T> z; z.l = z.h = 0;
   Pair<T> c[NC], cp[NC], b[NC], bp[NC], a[NC], ap[NC], xL[NC], xLp[NC];
   // c[t], c[t-1], b[t], b[t-1], a[t-1], a[t-2], xL[t-1], xL[t-2]
 #pragma unroll
   for (int k = 0; k < NC; ++k) c[k] = cp[k] = b[k] = bp[k] = a[k] = ap[k] = xL[k] = xLp[k] = z;
-  Pair<T> nlo[NC], nhi[NC];
-  fetch(t0, true, exL(t0), nlo); fetch(t0, false, exH(t0), nhi);              // sub-band rows of iteration t0
-  for (int t = t0; t <= i1 + 1; ++t) {
-    Pair<T> in_lo[NC], in_hi[NC];
+  Pair<T> nlo[U][NC], nhi[U][NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { in_lo[k] = nlo[k]; in_hi[k] = nhi[k]; }
-    if (t <= i1) { fetch(t + 1, true, exL(t + 1), nlo); fetch(t + 1, false, exH(t + 1), nhi); }   // request t+1 now
-    // interior of the plane (every row t-2 .. t exists, no strip edge): the selects fold away
-    auto lift = [&](auto chk) {
-      constexpr bool CHK = decltype(chk)::value;
-      const bool eLt = exL(t), eHt = exH(t), eLp = exL(t - 1), eHp = exH(t - 1);
-      const bool eLpp = exL(t - 2), eHpp = exH(t - 2);
-      Pair<T> xh[NC];
+  for (int u = 0; u < U; ++u) request(t0 + u, nlo[u], nhi[u]);      // sub-band rows of the first trip
+  for (int t = t0; t <= i1 + 1; t += U) {
+    Pair<T> in_lo[U][NC], in_hi[U][NC];
 #pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        Pair<T> dd = in_lo[k], cc = in_hi[k];
-        cp[k] = c[k]; c[k] = z;
-        if (!CHK || eLt) { horz_synthesis<WP, CHK>(w, dd.l, dd.h, g); dd.l = w.mulK(dd.l); dd.h = w.mulK(dd.h); } else dd = z;   // :855-856
-        if (!CHK || eHt) { horz_synthesis<WP, CHK>(w, cc.l, cc.h, g); c[k].l = w.mulKinv(cc.l); c[k].h = w.mulKinv(cc.h); }    // :871-872
-        // b[t]
-        bp[k] = b[k];
-        b[k].l = w.s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
-        b[k].h = w.s0(dd.h, pick<CHK>(eHp, cp[k].h, c[k].h), pick<CHK>(eHt, c[k].h, cp[k].h));
-        // a[t-1]
-        ap[k] = a[k];
-        a[k].l = w.s1(cp[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
-        a[k].h = w.s1(cp[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
-        // xL[t-1]
-        xLp[k] = xL[k];
-        xL[k].l = w.s2(bp[k].l, pick<CHK>(eHpp, ap[k].l, a[k].l), pick<CHK>(eHp, a[k].l, ap[k].l));
-        xL[k].h = w.s2(bp[k].h, pick<CHK>(eHpp, ap[k].h, a[k].h), pick<CHK>(eHp, a[k].h, ap[k].h));
-        // xH[t-2]
-        xh[k].l = w.s3(ap[k].l, pick<CHK>(eLpp, xLp[k].l, xL[k].l), pick<CHK>(eLp, xL[k].l, xLp[k].l));
-        xh[k].h = w.s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
-      }
-      if (t - 2 >= i0 && t - 2 < i1 && (!CHK || eHpp))
-        store_rows<WP, IMG, NC>(dst, (size_t)(2 * (t - 2) + 1 - oy) * dp, g, xh, cvs);
-      if (t - 1 >= i0 && t - 1 < i1 && (!CHK || eLp))
-        store_rows<WP, IMG, NC>(dst, (size_t)(2 * (t - 1) - oy) * dp, g, xL, cvs);
-    };
-    if (g.inner && 2 * (t - 2) - oy >= 0 && 2 * t + 1 - oy < h) lift(std::false_type());
-    else lift(std::true_type());
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { in_lo[u][k] = existing(t + u, true, nlo[u][k]); in_hi[u][k] = existing(t + u, false, nhi[u][k]); }
+    if (t + U <= i1 + 1) {                                  // request the next trip's rows now
+#pragma unroll
+      for (int u = 0; u < U; ++u) request(t + U + u, nlo[u], nhi[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tt = t + u;
+      if (u != 0 && tt > i1 + 1) break;
+      // interior of the plane (every row tt-2 .. tt exists, no strip edge): the selects fold away
+      auto lift = [&](auto chk) {
+        constexpr bool CHK = decltype(chk)::value;
+        const bool eLt = exL(tt), eHt = exH(tt), eLp = exL(tt - 1), eHp = exH(tt - 1);
+        const bool eLpp = exL(tt - 2), eHpp = exH(tt - 2);
+        Pair<T> xh[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          Pair<T> dd = in_lo[u][k], cc = in_hi[u][k];
+          cp[k] = c[k]; c[k] = z;
+          if (!CHK || eLt) { horz_synthesis<WP, CHK>(w, dd.l, dd.h, g); dd.l = w.mulK(dd.l); dd.h = w.mulK(dd.h); } else dd = z;   // :855-856
+          if (!CHK || eHt) { horz_synthesis<WP, CHK>(w, cc.l, cc.h, g); c[k].l = w.mulKinv(cc.l); c[k].h = w.mulKinv(cc.h); }    // :871-872
+          // b[t]
+          bp[k] = b[k];
+          b[k].l = w.s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
+          b[k].h = w.s0(dd.h, pick<CHK>(eHp, cp[k].h, c[k].h), pick<CHK>(eHt, c[k].h, cp[k].h));
+          // a[t-1]
+          ap[k] = a[k];
+          a[k].l = w.s1(cp[k].l, pick<CHK>(eLp, bp[k].l, b[k].l), pick<CHK>(eLt, b[k].l, bp[k].l));
+          a[k].h = w.s1(cp[k].h, pick<CHK>(eLp, bp[k].h, b[k].h), pick<CHK>(eLt, b[k].h, bp[k].h));
+          // xL[t-1]
+          xLp[k] = xL[k];
+          xL[k].l = w.s2(bp[k].l, pick<CHK>(eHpp, ap[k].l, a[k].l), pick<CHK>(eHp, a[k].l, ap[k].l));
+          xL[k].h = w.s2(bp[k].h, pick<CHK>(eHpp, ap[k].h, a[k].h), pick<CHK>(eHp, a[k].h, ap[k].h));
+          // xH[t-2]
+          xh[k].l = w.s3(ap[k].l, pick<CHK>(eLpp, xLp[k].l, xL[k].l), pick<CHK>(eLp, xL[k].l, xLp[k].l));
+          xh[k].h = w.s3(ap[k].h, pick<CHK>(eLpp, xLp[k].h, xL[k].h), pick<CHK>(eLp, xL[k].h, xLp[k].h));
+        }
+        if (tt - 2 >= i0 && tt - 2 < i1 && (!CHK || eHpp))
+          store_rows<WP, IMG, NC>(dst, (size_t)(2 * (tt - 2) + 1 - oy) * dp, g, xh, cvs);
+        if (tt - 1 >= i0 && tt - 1 < i1 && (!CHK || eLp))
+          store_rows<WP, IMG, NC>(dst, (size_t)(2 * (tt - 1) - oy) * dp, g, xL, cvs);
+      };
+      if (g.inner && 2 * (tt - 2) - oy >= 0 && 2 * tt + 1 - oy < h) lift(std::false_type());
+      else lift(std::true_type());
+    }
   }
+  };
+  if (g.w == 1) pipeline(std::true_type()); else pipeline(std::false_type());
 }
 
 // Vertical chunk of a strip per workgroup; the result is wave-uniform per launch.  Tall chunks
@@ -789,6 +877,9 @@ int fit_rounds(const void* fn, uint32_t planes, uint32_t max_w, uint32_t max_h)
 
 // container: 0 = no image (arena planes only), 32 = int32 image samples, 16 / 8 = 16- / 8-bit image samples;
 // nc = 3: the descriptors come in triples (the colour planes of a tile), see the kernels
+#ifndef DWT_TRIP_DEFAULT
+#define DWT_TRIP_DEFAULT 2
+#endif
 template <bool FWD>
 int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
            void* d_base, void* d_image, Conv cv, int container = 32, int nc = 1)
@@ -815,7 +906,10 @@ int launch(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs, uint32
   if (nc == 3) rp = rp3 ? rp3 : 8;
   dim3 grid = dwt_grid(n / (uint32_t)nc, max_w, max_h, rp);
   hipStream_t s = (hipStream_t)stream;
-#define OJPH_LAUNCH(K, REV, IMG, NC, TP) do { auto fn = K<Wv<REV>, IMG, NC>; \
+  // two row pairs per trip of the pipeline loop for the one-plane launches (see the kernels' U; OJPHGPU_DWT_TRIP=1: one)
+  static const int trip = [] { const char* e = getenv("OJPHGPU_DWT_TRIP"); const int v = e ? atoi(e) : DWT_TRIP_DEFAULT; return v == 2 ? 2 : 1; }();
+#define OJPH_LAUNCH(K, REV, IMG, NC, TP) do { auto fn = K<Wv<REV>, IMG, NC, 1>; \
+    if (NC == 1 && trip == 2) fn = K<Wv<REV>, IMG, NC, (NC == 1 ? 2 : 1)>; \
     if (NC == 3 && !rp3) { rp = fit_rounds((const void*)fn, n / 3u, max_w, max_h); grid = dwt_grid(n / 3u, max_w, max_h, rp); } \
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, row_pairs_arg(rp), Wv<REV>()); } while (0)
 #define OJPH_LAUNCH_NC(K, REV, IMG, TP) do { if (nc == 3) OJPH_LAUNCH(K, REV, IMG, 3, TP); else OJPH_LAUNCH(K, REV, IMG, 1, TP); } while (0)
@@ -851,8 +945,10 @@ int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc*
   const int rp = pick_row_pairs(n, max_w, max_h, synthesis);
   const dim3 grid = dwt_grid(n, max_w, max_h, rp);
   const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
-  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
-  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
+  // (two row pairs per trip, like the 5/3 and 9/7 launches; 64-bit samples keep one: twice the registers per sample)
+  constexpr int U = sizeof(TT) > 4 ? 1 : DWT_TRIP_DEFAULT;
+  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1, U>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
+  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1, U>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
