@@ -894,7 +894,7 @@ def limiter_fields(frac_hbm, kd):
 
 
 def committed_counters(name):
-    """profiles/<name> -- counter passes are separate rocprofv3 runs (tools/pmc_round.sh, tools/sq_round.sh), their
+    """profiles/<name> -- counter passes are separate rocprofv3 runs (tools/evidence.sh: FETCH_SIZE / WRITE_SIZE passes, tools/sq_round.sh), their
     results are committed.  They only describe THIS build if they were taken on the same kernel sources: the files carry
     the digest of those sources (openjph_amd/build.py kernel_sources_digest) and a file with another digest, or none,
     is refused: -> ({}, "stale: ...").  -> (contents, "current") otherwise."""

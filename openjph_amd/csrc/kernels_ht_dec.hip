@@ -969,7 +969,7 @@ __device__ __forceinline__ bool needs_refinement(const ojphgpu_cb_desc& d)
 // un-stuffer (bytes consumed, a multiple of 256), 18 the un-stuffed bits that point corresponds to, 19 != 0: the block failed.
 constexpr uint32_t S2_STATE_WORDS = 24;       // (words 0..19 as above; 20: the length of the block's MagSgn part, kept from the prepare call)
 
-// -DFUSED_TIMELINE (tools/r4_timeline.py; never in the product build): every wavefront of the fused launch leaves, per
+// -DFUSED_TIMELINE (tools/fused_timeline.py; never in the product build): every wavefront of the fused launch leaves, per
 // run, 12 words in g_tl -- role, where it ran, when it started / ended (s_memrealtime, 100 MHz), and for a worker how
 // long it waited for chains and when it finished each slice of its blocks
 #ifdef FUSED_TIMELINE

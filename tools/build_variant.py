@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Builds openjph_amd/csrc/_build/lib_<name>.so: the product library with ONE source compiled with extra flags
-(A/B experiments inside one GPU-box visit, tools/ab.sh / tools/enc_only.py).
+(A/B experiments inside one GPU-box visit, tools/ab_variants.sh, tools/enc_only.py).
     python tools/build_variant.py <name> <source file in csrc> [flags ...]"""
 import os
 import subprocess

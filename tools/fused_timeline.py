@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE fused block-decoder launch on the 8K bench frame: when the chain wavefronts end, when the workers finish
 each slice, how long they wait, and whether sharing a CU with a step-1 workgroup matters.
-    python tools/build_variant.py tl kernels_ht_dec.hip -DFUSED_TIMELINE && python tools/r4_timeline.py [workload]"""
+    python tools/build_variant.py tl kernels_ht_dec.hip -DFUSED_TIMELINE && python tools/fused_timeline.py [workload]"""
 import ctypes as C, os, shutil, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
