@@ -97,7 +97,7 @@ template <> struct Wv<false> {      // irreversible 9/7 (ojph_params.cpp:2870-28
 // ANY lifting kernel an ATK marker segment describes with up to four steps, and the 5/3 on 64-bit samples: the same
 // register pipeline with the steps as launch parameters.  (Part 2 codestreams and components deeper than 26 bits used to
 // take one element-wise launch per lifting step and direction -- kernels_lift.hip, 2 N + 2 passes over the plane per level;
-// those kernels remain for levels that transform one direction only and for kernels of more than four steps.)
+// those kernels remain for kernels of more than four steps; levels that transform one direction only are the kernels' MODE.)
 // NS = number of steps (compile time: a slot without a step is no instruction at all, not an "add zero" -- which would turn
 // a -0.0f into +0.0f); the steps sit in the order the direction applies them: analysis step NS-1 first, updating the odd
 // (high-pass) samples; synthesis step 0 first, updating the even ones -- application index i alternates exactly as the
@@ -199,10 +199,10 @@ __device__ __forceinline__ void horz_synthesis(const WP& w, typename WP::T& vl, 
   }
 }
 
-__device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, int lane)
+__device__ __forceinline__ Geo make_geo(const ojphgpu_dwt_desc& d, int strip_x, int lane, bool plain_x = false, bool plain_y = false)
 {
   Geo g;
-  g.w = (int)d.w; g.h = (int)d.h; g.ox = d.x_even ? 0 : 1; g.oy = d.y_even ? 0 : 1;
+  g.w = (int)d.w; g.h = (int)d.h; g.ox = (d.x_even || plain_x) ? 0 : 1; g.oy = (d.y_even || plain_y) ? 0 : 1;
   g.j = strip_x * VALID - HALO + lane;
   int xl = 2 * g.j - g.ox, xh = xl + 1;
   g.eL = col_exists(xl, g.w); g.eH = col_exists(xh, g.w);
@@ -392,7 +392,11 @@ __device__ __forceinline__ void dwt_block_coords(int row_pairs_arg, int& bx, int
 // stores share vmcnt and are not counted down in order against each other, so a wait for the rows of the next pair drains
 // the stores as well -- and with U = 2 a wavefront has twice the bytes under way per wait: 4 row loads and 8 sub-band row
 // stores (forward), 8 and 4 (inverse).  Same arithmetic in the same order; only when rows are requested and stored changes.
-template <class WP, int IMG, int NC, int U = 1>
+// MODE (the levels of a DFS decomposition that transform ONE direction, resolution::push_line's HORZ_TRX / VERT_TRX,
+// ojph_resolution.cpp:290-300, :556-600; general lifting policies only): 0 = both directions; 1 = along the rows only -- every
+// row is lifted horizontally and goes, whole, to row y of LL | HL; 2 = along the columns only -- the lane's two columns are
+// plain neighbours (no horizontal step, no x parity), a low row goes to LL, a high row to LH, at its own columns.
+template <class WP, int IMG, int NC, int U = 1, int MODE = 0>
 __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
                                                           const void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
@@ -413,7 +417,8 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   const int row_pairs = row_pairs_arg & 0xFFFF;
   const int strip_x = bx * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
-  const Geo g = make_geo(d, strip_x, lane);
+  static_assert(MODE == 0 || (IMG == 0 && NC == 1), "one-direction levels exist below the top level of general-lifting components only");
+  const Geo g = make_geo(d, strip_x, lane, MODE == 2, MODE == 1);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
   const int i0 = by * row_pairs;
@@ -442,12 +447,38 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
   };
   auto put = [&](int k, int t, bool low_row, T vl, T vh) {   // one transformed row of plane k -> its two sub-bands
     if (!g.store) return;
-    T* lo = low_row ? ll[k] : lh[k]; T* hi = low_row ? hl[k] : hh[k];
-    const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
     const int r = low_row ? t - oy : t;                    // row index inside the sub-band
-    if (g.eL) lo[(size_t)r * lop + (g.j - g.ox)] = vl;
-    if (g.eH) hi[(size_t)r * hip + g.j] = vh;
+    if constexpr (MODE == 2) {                             // both columns into the same band, at their own positions
+      T* band = low_row ? ll[k] : lh[k];
+      const uint32_t bp = low_row ? d.ll_pitch : d.lh_pitch;
+      if (g.eL) band[(size_t)r * bp + 2 * g.j] = vl;
+      if (g.eH) band[(size_t)r * bp + 2 * g.j + 1] = vh;
+    } else {
+      T* lo = low_row ? ll[k] : lh[k]; T* hi = low_row ? hl[k] : hh[k];
+      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+      if (g.eL) lo[(size_t)r * lop + (g.j - g.ox)] = vl;
+      if (g.eH) hi[(size_t)r * hip + g.j] = vh;
+    }
   };
+
+  if constexpr (MODE == 1) {                               // rows only: no vertical state, two rows per trip
+    const int y1 = min(2 * i1, h);
+    auto rows = [&](auto w1) {
+      for (int y = 2 * i0; y < y1; y += 2) {
+        RawRow ra[NC], rb[NC]; Pair<T> xa[NC], xb[NC];
+        ldrow_w(y, ra, w1); ldrow_w(y + 1, rb, w1);
+        unpack_all<WP, IMG, NC>(ra, g, cvs, xa); unpack_all<WP, IMG, NC>(rb, g, cvs, xb);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          horz_analysis<WP>(w, xa[k].l, xa[k].h, g); horz_analysis<WP>(w, xb[k].l, xb[k].h, g);
+          put(k, y, true, xa[k].l, xa[k].h);
+          if (y + 1 < y1) put(k, y + 1, true, xb[k].l, xb[k].h);
+        }
+      }
+    };
+    if (g.w == 1) rows(std::true_type()); else rows(std::false_type());
+    return;
+  }
 
   if (h == 1) {                                            // ojph_resolution.cpp:604-634, :688-708
     if (i0 > 0) return;
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       if (oy != 0) { x[k].l = w.dbl(x[k].l); x[k].h = w.dbl(x[k].h); }
-      horz_analysis<WP>(w, x[k].l, x[k].h, g);
+      if constexpr (MODE != 2) horz_analysis<WP>(w, x[k].l, x[k].h, g);
       put(k, 0, oy == 0, x[k].l, x[k].h);
     }
     return;
@@ -538,11 +569,11 @@ __global__ __launch_bounds__(256) void dwt_forward_kernel(const ojphgpu_dwt_desc
           if (emit) {
             if (!CHK || eLp) {                                   // ojph_resolution.cpp:674-675
               out_lo[u][k].l = w.mulKinv(dl); out_lo[u][k].h = w.mulKinv(dh);
-              horz_analysis<WP, CHK>(w, out_lo[u][k].l, out_lo[u][k].h, g);
+              if constexpr (MODE != 2) horz_analysis<WP, CHK>(w, out_lo[u][k].l, out_lo[u][k].h, g);
             }
             if (!CHK || eHp) {                                   // :663-664
               out_hi[u][k].l = w.mulK(c[k].l); out_hi[u][k].h = w.mulK(c[k].h);
-              horz_analysis<WP, CHK>(w, out_hi[u][k].l, out_hi[u][k].h, g);
+              if constexpr (MODE != 2) horz_analysis<WP, CHK>(w, out_hi[u][k].l, out_hi[u][k].h, g);
             }
           }
         }
@@ -644,7 +675,7 @@ __device__ __forceinline__ void store_rows(char* const* dst, size_t off, const G
 // ---------------------------------------------------------------------------------------------
 // inverse: LL, HL, LH, HH -> plane (or image plane, IMG); NC as in the forward kernel
 // ---------------------------------------------------------------------------------------------
-template <class WP, int IMG, int NC, int U = 1>
+template <class WP, int IMG, int NC, int U = 1, int MODE = 0>
 __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc* __restrict__ descs,
                                                           uint32_t* __restrict__ base32,
                                                           void* __restrict__ image, Conv cv, int row_pairs_arg, const WP w)
@@ -663,7 +694,8 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   const int row_pairs = row_pairs_arg & 0xFFFF;
   const int strip_x = bx * 4 + wave;
   if (d.w == 0 || d.h == 0) return;
-  const Geo g = make_geo(d, strip_x, lane);
+  static_assert(MODE == 0 || (IMG == 0 && NC == 1), "one-direction levels exist below the top level of general-lifting components only");
+  const Geo g = make_geo(d, strip_x, lane, MODE == 2, MODE == 1);
   const int npx = (g.w + g.ox + 1) >> 1, npy = (g.h + g.oy + 1) >> 1;
   if (strip_x * VALID >= npx) return;
   const int i0 = by * row_pairs;
@@ -691,13 +723,33 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     for (int k = 0; k < NC; ++k) {
       p[k].l = p[k].h = 0;
       if (!ex) continue;
-      const T* lo = low_row ? ll[k] : lh[k]; const T* hi = low_row ? hl[k] : hh[k];
-      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
       const int r = low_row ? t - oy : t;
-      if (g.eL) p[k].l = lo[(size_t)r * lop + (g.j - g.ox)];
-      if (g.eH) p[k].h = hi[(size_t)r * hip + g.j];
+      if constexpr (MODE == 2) {                            // both columns from the same band
+        const T* band = low_row ? ll[k] : lh[k];
+        const uint32_t bp = low_row ? d.ll_pitch : d.lh_pitch;
+        if (g.eL) p[k].l = band[(size_t)r * bp + 2 * g.j];
+        if (g.eH) p[k].h = band[(size_t)r * bp + 2 * g.j + 1];
+      } else {
+        const T* lo = low_row ? ll[k] : lh[k]; const T* hi = low_row ? hl[k] : hh[k];
+        const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+        if (g.eL) p[k].l = lo[(size_t)r * lop + (g.j - g.ox)];
+        if (g.eH) p[k].h = hi[(size_t)r * hip + g.j];
+      }
     }
   };
+
+  if constexpr (MODE == 1) {                               // rows only: row y of LL | HL -> row y of the plane, two rows per trip
+    const int y1 = min(2 * i1, h);
+    for (int y = 2 * i0; y < y1; y += 2) {
+      Pair<T> xa[NC], xb[NC];
+      fetch(y, true, true, xa); fetch(y + 1, true, y + 1 < y1, xb);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { horz_synthesis<WP>(w, xa[k].l, xa[k].h, g); horz_synthesis<WP>(w, xb[k].l, xb[k].h, g); }
+      store_rows<WP, IMG, NC>(dst, (size_t)y * dp, g, xa, cvs);
+      if (y + 1 < y1) store_rows<WP, IMG, NC>(dst, (size_t)(y + 1) * dp, g, xb, cvs);
+    }
+    return;
+  }
 
   if (h == 1) {                                            // ojph_resolution.cpp:794-829, :900-923
     if (i0 > 0) return;
@@ -705,7 +757,7 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
     fetch(0, oy == 0, true, x);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      horz_synthesis<WP>(w, x[k].l, x[k].h, g);
+      if constexpr (MODE != 2) horz_synthesis<WP>(w, x[k].l, x[k].h, g);
       if (oy != 0) { x[k].l = w.halve(x[k].l); x[k].h = w.halve(x[k].h); }
     }
     store_rows<WP, IMG, NC>(dst, 0, g, x, cvs);
@@ -721,12 +773,13 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
   auto pipeline = [&](auto w1) {
   constexpr bool W1 = decltype(w1)::value;
   const int nlc = ((g.ox + g.w + 1) >> 1) - ((g.ox + 1) >> 1), nlr = ((oy + h + 1) >> 1) - ((oy + 1) >> 1);   // low columns / rows of the plane
-  const int col_l = min(max(g.j - g.ox, 0), max(nlc - 1, 0)), col_h = min(max(g.j, 0), max(g.w - nlc - 1, 0));
+  const int col_l = MODE == 2 ? min(max(2 * g.j, 0), g.w - 1) : min(max(g.j - g.ox, 0), max(nlc - 1, 0));
+  const int col_h = MODE == 2 ? min(max(2 * g.j + 1, 0), g.w - 1) : min(max(g.j, 0), max(g.w - nlc - 1, 0));
   auto fetch_any = [&](int t, bool low_row, Pair<T>* p) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      const T* lo = low_row ? ll[k] : lh[k]; const T* hi = low_row ? hl[k] : hh[k];
-      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = low_row ? d.hl_pitch : d.hh_pitch;
+      const T* lo = low_row ? ll[k] : lh[k]; const T* hi = MODE == 2 ? lo : (low_row ? hl[k] : hh[k]);
+      const uint32_t lop = low_row ? d.ll_pitch : d.lh_pitch, hip = MODE == 2 ? lop : (low_row ? d.hl_pitch : d.hh_pitch);
       const int rows = low_row ? nlr : h - nlr;
       const int r = min(max(low_row ? t - oy : t, 0), rows - 1);
       p[k].l = lo[(size_t)r * lop + col_l];
@@ -774,8 +827,8 @@ __global__ __launch_bounds__(256) void dwt_inverse_kernel(const ojphgpu_dwt_desc
         for (int k = 0; k < NC; ++k) {
           Pair<T> dd = in_lo[u][k], cc = in_hi[u][k];
           cp[k] = c[k]; c[k] = z;
-          if (!CHK || eLt) { horz_synthesis<WP, CHK>(w, dd.l, dd.h, g); dd.l = w.mulK(dd.l); dd.h = w.mulK(dd.h); } else dd = z;   // :855-856
-          if (!CHK || eHt) { horz_synthesis<WP, CHK>(w, cc.l, cc.h, g); c[k].l = w.mulKinv(cc.l); c[k].h = w.mulKinv(cc.h); }    // :871-872
+          if (!CHK || eLt) { if constexpr (MODE != 2) horz_synthesis<WP, CHK>(w, dd.l, dd.h, g); dd.l = w.mulK(dd.l); dd.h = w.mulK(dd.h); } else dd = z;   // :855-856
+          if (!CHK || eHt) { if constexpr (MODE != 2) horz_synthesis<WP, CHK>(w, cc.l, cc.h, g); c[k].l = w.mulKinv(cc.l); c[k].h = w.mulKinv(cc.h); }    // :871-872
           // b[t]
           bp[k] = b[k];
           b[k].l = w.s0(dd.l, pick<CHK>(eHp, cp[k].l, c[k].l), pick<CHK>(eHt, c[k].l, cp[k].l));
@@ -947,8 +1000,13 @@ int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc*
   const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
   // (two row pairs per trip, like the 5/3 and 9/7 launches; 64-bit samples keep one: twice the registers per sample)
   constexpr int U = sizeof(TT) > 4 ? 1 : DWT_TRIP_DEFAULT;
-  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1, U>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
-  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1, U>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w);
+#define OJPH_GENERAL(M, UU) do { \
+    if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, 0, 1, UU, M>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w); \
+    else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, 0, 1, UU, M>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)nullptr, Conv{ 0, 0 }, row_pairs_arg(rp), w); } while (0)
+  if (k->horz && k->vert) OJPH_GENERAL(0, U);
+  else if (k->horz) OJPH_GENERAL(1, 1);                    // (a DFS level that transforms the rows only / the columns only)
+  else OJPH_GENERAL(2, 1);
+#undef OJPH_GENERAL
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
@@ -974,7 +1032,7 @@ namespace ojphgpu {
 // 2 N + 2 launches, each a full pass.  -> OJPHGPU_E_INVALID when the kernel does not fit (the caller keeps the other form).
 bool dwt_general_pipeline_fits(const ojphgpu_lift* k)
 {
-  return k && k->horz && k->vert && k->num_steps >= 1 && k->num_steps <= 4 && k->elem <= 2;
+  return k && (k->horz || k->vert) && k->num_steps >= 1 && k->num_steps <= 4 && k->elem <= 2;
 }
 int dwt_general_pipeline(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
                          void* d_base, bool synthesis)

@@ -185,7 +185,8 @@ int run(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, ui
   if (!k || !d_descs || !d_base || k->num_steps > OJPHGPU_MAX_LIFT_STEPS || k->elem > 2) return OJPHGPU_E_INVALID;
   if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
   for (uint32_t i = 0; i < k->num_steps; ++i) if (k->elem != 2 && (k->steps[i].e < 0 || k->steps[i].e > 255)) return OJPHGPU_E_INVALID;   // (an Eatk byte; counted modulo the sample width)
-  // the usual Part-2 kernels and the 5/3 on 64-bit samples go through the register pipeline (one launch per level);
+  // the usual Part-2 kernels and the 5/3 on 64-bit samples go through the register pipeline (one launch per level -- also the
+  // levels of a DFS decomposition that transform one direction only); kernels of more than four steps take the launches below;
   // OJPHGPU_LIFT_ELEMENTWISE=1 keeps every level on the element-wise launches below (A/B runs, and the pin of the two forms
   // against each other in tests/test_gpu_wide.py)
   static const bool elementwise = [] { const char* e = getenv("OJPHGPU_LIFT_ELEMENTWISE"); return e && atoi(e) != 0; }();

@@ -381,3 +381,18 @@ def test_deep_samples_end_to_end(case):
     assert np.array_equal(dec, want_dec)
     if kw.get("reversible", True):
         assert np.array_equal(dec, img)
+
+
+def test_general_lifting_elementwise_form_too():
+    """the same cases with OJPHGPU_LIFT_ELEMENTWISE=1: every level through the element-wise launches of kernels_lift.hip (the
+    form kernels of five and more steps always take) instead of the register pipeline -- the two forms are pinned to the same
+    oracle, so to each other.  The switch is read once per process: a child process runs the test above."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OJPHGPU_LIFT_ELEMENTWISE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_wide.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_general_lifting_vs_oracle", "-p", "no:cacheprovider"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"36 passed" in r.stdout, r.stdout[-2000:]
