@@ -401,6 +401,11 @@ def main():
         pl = parse_codestream(first)
         cb = pl.coded_blocks()
         top = np.array([int(pl.bands[int(b["band"])]["res"]) == levels for b in pl.blocks])
+        # (the side stream's launch takes the first enc.top_blocks() of the top resolution's blocks in plan order -- the encoder
+        # cuts the two branches so that the side one ends first, ojphgpu_codec.cpp -- the rest of them join the other launch)
+        side = np.zeros_like(top)
+        side[np.flatnonzero(top)[:enc.top_blocks()]] = True
+        top = side
         area = np.array([int(b["w"]) * int(b["h"]) for b in pl.blocks], dtype=np.float64)
         coded = (cb["len1"].astype(np.float64) + cb["len2"])
         del kernels["ht_encode"]

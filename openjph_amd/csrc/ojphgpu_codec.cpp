@@ -117,6 +117,30 @@ static int encoder_create(const ojphgpu_plan* plan, int device, void* stream, ui
     auto top = [&](uint32_t id) { const Band& B = P.bands[P.blocks[id].band]; return B.res == P.style(B.comp).L; };
     auto mid = std::stable_partition(e->block_ids.begin(), e->block_ids.end(), top);
     e->n_top = (uint32_t)(mid - e->block_ids.begin());
+    {
+      // How many of the top resolution's blocks the side stream's launch takes; the rest join the main stream's launch behind
+      // the lower levels.  The main stream waits for the side stream at the end of the encode, and a wait on another queue
+      // that is not yet satisfied when it is reached costs ~20 us on top of what is waited for (kernel trace of a step:
+      // the next launch started 22 us after the side stream's had ended) -- so the branches are cut for the SIDE one to
+      // end first, by a model of what each costs on this device (MI355X, profiles/r06_*): the block coder 3.8 us per
+      // million samples of the top resolution and 1.6 x that below it (more bytes per sample, shorter launches), a lower
+      // analysis level its bytes at 3 TB/s or a 12 us launch floor.  8K 4:4:4: 90 % (step 0.957 -> 0.938 ms); a 4K frame's
+      // main branch is the longer one already: 100 %.  OJPHGPU_ENC_TOP_SHARE=<percent> overrides the model.
+      static const int share_env = [] { const char* v = getenv("OJPHGPU_ENC_TOP_SHARE"); const int x = v ? atoi(v) : 0; return x < 10 ? 0 : x > 100 ? 100 : x; }();
+      double s_top = 0, s_low = 0;                         // millions of samples
+      for (size_t i = 0; i < e->block_ids.size(); ++i) {
+        const Block& k = P.blocks[e->block_ids[i]];
+        (i < e->n_top ? s_top : s_low) += (double)k.r.w * k.r.h * 1e-6;
+      }
+      double dwt_us = 0, level_bytes = 8.0 * (s_top + s_low) * 1e6 / 4.0;
+      for (uint32_t l = 2; l <= max_recon_decomps(P); ++l, level_bytes /= 4.0) dwt_us += std::max(12.0, level_bytes / 3.0e6);
+      const double us_per_ms = 3.8, margin_us = 30.0;
+      const double move = (s_top + margin_us / us_per_ms - 1.6 * s_low - dwt_us / us_per_ms) / 2.0;   // top samples the main branch should take
+      int share = share_env;
+      if (!share) share = s_top > 0 && move > 0 ? (int)(100.0 * (1.0 - move / s_top)) : 100;
+      share = share < 50 ? 50 : share > 100 ? 100 : share;
+      e->n_top = (uint32_t)((uint64_t)e->n_top * (uint32_t)share / 100u);
+    }
     if (e->n_top == 0 || e->n_top == e->block_ids.size()) e->n_top = 0;
     else {
       // the side stream carries the long launch of the pair (the top resolution's blocks); the main stream's branch -- four
