@@ -238,7 +238,8 @@ def main():
     with torch.cuda.stream(s_dec):
         dec = codec.Decoder(cs, device=local_rank, tiles=my_tiles if frames == 1 else None)
     d_out = torch.zeros_like(d_img) if tiled else torch.empty_like(d_img)
-    torch.cuda.synchronize(dev)
+    d_out.zero_()                                # (also loads torch's fill kernel NOW: its first use stalls the host for tens of
+    torch.cuda.synchronize(dev)                  #  milliseconds, and a chip left idle that long starts the next steps at low clocks)
     t0 = time.perf_counter()
     dec.run_device(d_out)
     torch.cuda.synchronize(dev)
@@ -268,6 +269,13 @@ def main():
         dec.run_device(d_out)
 
     enc.set_timing(False); dec.set_timing(False)     # the timed region carries no per-launch event pairs
+    # Out of idle first: after 50 ms or more without work (the set-up above: parsing, uploads, checks on the host) the chip's
+    # first eight to ten steps run 5-10 % slower while its clocks come up (tools/step_times.py, profiles/r06_c_step_times.txt)
+    # -- more than the W warm-up steps a short run asks for (the driver's --steps 20 --warmup 5 measured 0.993 ms per step where
+    # 200 or 1500 steps measure 0.968).  These untimed steps are the same steps; `settle_steps` in the line says how many.
+    settle = int(os.environ.get("OJPH_BENCH_SETTLE_STEPS", "50"))
+    for _ in range(settle):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -277,14 +285,23 @@ def main():
     d_out.zero_()                                # the timed steps must produce the frame again (checked after the loop)
     _, epoch0 = dec.giveup_epoch()               # (synchronises)
     torch.cuda.synchronize(dev)
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if os.environ.get("OJPH_BENCH_STEP_EVENTS") else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if step_events:                              # (diagnosis only: an event after every step -- how the timed region's steps differ)
+        step_events[0].record()
+    for i in range(args.steps):
         step()
+        if step_events:
+            step_events[i + 1].record()
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    if step_events:
+        sys.stderr.write("timed region %.3f ms, enqueued after %.3f ms; per step (ms): %s\n" % (elapsed * 1e3, t_enq * 1e3, " ".join(
+            "%.3f" % step_events[i].elapsed_time(step_events[i + 1]) for i in range(min(args.steps, 40)))))
     # What the timed steps produced, checked AFTER them: the last step's decode is collected (block verdicts; a one-launch
     # block decoder whose wait ran out would be repeated here and counted), no timed run gave up un-noticed (the give-up epoch
     # of the decoder object, bracketing the loop), the samples of the LAST timed step against the input, and the coded size.
@@ -518,7 +535,7 @@ def main():
         "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
         "value": round(nsamples * (1 if tiled else world) / (ms_per_step * 1e-3) / 1e6, 2),
         "unit": "Msamples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle,
         "ms_per_step": round(ms_per_step, 4),
         "per_rank_ms_per_step": per_rank_ms,
         "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
