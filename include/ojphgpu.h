@@ -307,6 +307,15 @@ int ojphgpu_dwt_forward_general(void* stream, const ojphgpu_lift* kernel, const 
                                 uint32_t max_w, uint32_t max_h, void* d_base);
 int ojphgpu_dwt_inverse_general(void* stream, const ojphgpu_lift* kernel, const ojphgpu_dwt_desc* d_descs, uint32_t n,
                                 uint32_t max_w, uint32_t max_h, void* d_base);
+/* the top level of general-lifting components with the conversion from / to the image samples fused in, like
+ * ojphgpu_dwt_forward_image_ex / _inverse_image_ex do it for the 5/3 and the 9/7 (rev_convert / irv_convert_to_float / ..._to_integer,
+ * ojph_colour.cpp:238-436, applied in the level's loads / stores): int32 or float working samples (kernel->elem 0 / 2), one to
+ * four lifting steps, both directions; d_descs address the image planes as for the _image_ex calls (reserved = the plane's own
+ * bit depth | signed << 8, or 0 for params'); container_bits 8 / 16 / 32.  No colour transform. */
+int ojphgpu_dwt_forward_general_image(void* stream, const ojphgpu_lift* kernel, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                      uint32_t n, uint32_t max_w, uint32_t max_h, const void* d_image, void* d_base, int container_bits);
+int ojphgpu_dwt_inverse_general_image(void* stream, const ojphgpu_lift* kernel, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                      uint32_t n, uint32_t max_w, uint32_t max_h, void* d_image, void* d_base, int container_bits);
 
 /* The same transforms with the sample conversion of the adjacent stage fused in (no colour
  * transform): the first analysis level reads the int32 image planes directly -- level shift

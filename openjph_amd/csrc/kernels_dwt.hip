@@ -1010,6 +1010,47 @@ int launch_general(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc*
   return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
 }
 
+// the same with an image side (IMG = container bits): both directions only
+template <typename TT, int NS, int IMG>
+int launch_general_image(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                         void* d_base, void* d_image, Conv cv, bool synthesis)
+{
+  const int rp = pick_row_pairs(n, max_w, max_h, synthesis);
+  const dim3 grid = dwt_grid(n, max_w, max_h, rp);
+  const WvGen<TT, NS> w = make_policy<TT, NS>(k, synthesis);
+  constexpr int U = DWT_TRIP_DEFAULT;
+  if (synthesis) hipLaunchKernelGGL((dwt_inverse_kernel<WvGen<TT, NS>, IMG, 1, U, 0>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, d_image, cv, row_pairs_arg(rp), w);
+  else hipLaunchKernelGGL((dwt_forward_kernel<WvGen<TT, NS>, IMG, 1, U, 0>), grid, dim3(256), 0, s, d_descs, (uint32_t*)d_base, (const void*)d_image, cv, row_pairs_arg(rp), w);
+  return hipGetLastError() == hipSuccess ? OJPHGPU_OK : OJPHGPU_E_HIP;
+}
+template <typename TT, int IMG>
+int launch_general_image_steps(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
+                               void* d_base, void* d_image, Conv cv, bool synthesis)
+{
+  switch (k->num_steps) {
+    case 1: return launch_general_image<TT, 1, IMG>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis);
+    case 2: return launch_general_image<TT, 2, IMG>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis);
+    case 3: return launch_general_image<TT, 3, IMG>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis);
+    case 4: return launch_general_image<TT, 4, IMG>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis);
+  }
+  return OJPHGPU_E_INVALID;
+}
+int general_image(void* stream, const ojphgpu_lift* k, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs, uint32_t n,
+                  uint32_t max_w, uint32_t max_h, void* d_image, void* d_base, int container_bits, bool synthesis)
+{
+  if (!k || !params || !d_descs || !d_base || !d_image || !k->horz || !k->vert || k->num_steps < 1 || k->num_steps > 4 || (k->elem != 0 && k->elem != 2))
+    return OJPHGPU_E_INVALID;
+  if (params->bit_depth == 0 || params->bit_depth > (uint32_t)(container_bits == 32 ? 31 : container_bits)) return OJPHGPU_E_INVALID;
+  if (n == 0 || max_w == 0 || max_h == 0) return OJPHGPU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const Conv cv{ (int)params->bit_depth, (int)params->is_signed };
+#define OJPH_GI(TT) (container_bits == 16 ? launch_general_image_steps<TT, 16>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis) : \
+                     container_bits == 8 ? launch_general_image_steps<TT, 8>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis) : \
+                     container_bits == 32 ? launch_general_image_steps<TT, 32>(s, k, d_descs, n, max_w, max_h, d_base, d_image, cv, synthesis) : OJPHGPU_E_INVALID)
+  return k->elem == 0 ? OJPH_GI(int) : OJPH_GI(float);
+#undef OJPH_GI
+}
+
 template <typename TT>
 int launch_general_steps(hipStream_t s, const ojphgpu_lift* k, const ojphgpu_dwt_desc* d_descs, uint32_t n, uint32_t max_w, uint32_t max_h,
                          void* d_base, bool synthesis)
@@ -1045,6 +1086,17 @@ int dwt_general_pipeline(void* stream, const ojphgpu_lift* k, const ojphgpu_dwt_
   return launch_general_steps<float>(s, k, d_descs, n, max_w, max_h, d_base, synthesis);
 }
 }  // namespace ojphgpu
+
+extern "C" int ojphgpu_dwt_forward_general_image(void* stream, const ojphgpu_lift* kernel, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                                 uint32_t n, uint32_t max_w, uint32_t max_h, const void* d_image, void* d_base, int container_bits)
+{
+  return general_image(stream, kernel, params, d_descs, n, max_w, max_h, const_cast<void*>(d_image), d_base, container_bits, false);
+}
+extern "C" int ojphgpu_dwt_inverse_general_image(void* stream, const ojphgpu_lift* kernel, const ojphgpu_params* params, const ojphgpu_dwt_desc* d_descs,
+                                                 uint32_t n, uint32_t max_w, uint32_t max_h, void* d_image, void* d_base, int container_bits)
+{
+  return general_image(stream, kernel, params, d_descs, n, max_w, max_h, d_image, d_base, container_bits, true);
+}
 
 extern "C" int ojphgpu_dwt_forward(void* stream, int reversible, const ojphgpu_dwt_desc* d_descs,
                                     uint32_t n, uint32_t max_w, uint32_t max_h, void* d_base)

@@ -287,7 +287,8 @@ int ojphgpu_encoder_run_container(ojphgpu_encoder* e, const void* d_image, int c
     if (b.img_first >= 0) {                                 // level shift / int->float applied in the loads
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)e->img_descs.p + b.img_first;
-      rc = ojphgpu_dwt_forward_image_ex(s, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container, b.nc == 3);
+      rc = b.general ? ojphgpu_dwt_forward_general_image(s, &b.k, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container)
+                     : ojphgpu_dwt_forward_image_ex(s, &pp, idesc, b.count, b.max_w, b.max_h, d_image, e->arena.p, container, b.nc == 3);
     } else if (b.general)                                   // 64-bit samples, Part-2 wavelets / decompositions: the general lifting kernels
       rc = ojphgpu_dwt_forward_general(s, &b.k, (const ojphgpu_dwt_desc*)e->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, e->arena.p);
     else
@@ -879,7 +880,8 @@ int ojphgpu_decoder_run_container(ojphgpu_decoder* d, void* d_image, int contain
     if (b.img_first >= 0) {                                 // float->int / level shift applied in the stores
       ojphgpu_params pp = P.p; pp.reversible = b.rev ? 1 : 0;
       const ojphgpu_dwt_desc* idesc = (const ojphgpu_dwt_desc*)d->img_descs.p + b.img_first;
-      rc = ojphgpu_dwt_inverse_image_ex(ls, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container, b.nc == 3);
+      rc = b.general ? ojphgpu_dwt_inverse_general_image(ls, &b.k, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container)
+                     : ojphgpu_dwt_inverse_image_ex(ls, &pp, idesc, b.count, b.max_w, b.max_h, d_image, d->arena.p, container, b.nc == 3);
     } else if (b.general)
       rc = ojphgpu_dwt_inverse_general(ls, &b.k, (const ojphgpu_dwt_desc*)d->dwt_descs.p + b.first, b.count, b.max_w, b.max_h, d->arena.p);
     else

@@ -53,7 +53,8 @@ struct HostBuf {
 // components (0..2), 2 the others -- how a depth is split when the colour transform is fused
 // general: levels of components that need the general lifting kernels (a Part-2 wavelet or decomposition, or 64-bit samples;
 // kernels_dwt.hip's WvGen pipeline or kernels_lift.hip) -- k describes the level; components with equal k share a batch
-struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool general; ojphgpu_lift k; };
+struct LevelBatch { uint32_t first, count, max_w, max_h, depth; bool rev; int img_first; int nc; int group; bool general; ojphgpu_lift k;
+                    std::vector<uint32_t> comps; };        // comps: the components of a general-lifting batch, in descriptor order
 
 // DWT descriptors grouped so that one launch handles every tile-component
 struct TileRange { uint32_t first, count; bool has(uint32_t t) const { return t >= first && t - first < count; } };
@@ -67,12 +68,38 @@ inline bool is_wide(const Plan& P, uint32_t comp) { return comp < P.wide.size() 
 // arithmetic was built and tested for the depths the 32-bit path had until round 4)
 inline bool deep(const Plan& P, uint32_t comp) { return P.comps[comp].bit_depth > 26 || P.general(comp); }
 
+// A component of the general lifting kernels (an ATK marker segment's wavelet) whose top level can take the conversion from /
+// to the image samples itself, like the 5/3 and 9/7 launches do (kernels_dwt.hip: WvGen with an image side): 32-bit working
+// samples, at most 26 bits deep, a top level that transforms both directions with at most four steps, no colour transform
+// over it.  All or nothing per codestream (general_fused): the conversion kernels then have nothing left to do for them.
+inline bool general_image_fusable(const Plan& P, uint32_t c)
+{
+  if (!P.general(c) || is_wide(P, c) || P.comps[c].bit_depth > 26 || P.recon_decomps(c) == 0) return false;
+  if (P.p.color_transform && c < 3) return false;
+  const ojphgpu_lift k = P.lift_of(c, P.skip_recon + 1);
+  return k.horz && k.vert && k.num_steps >= 1 && k.num_steps <= 4 && k.elem != 1;
+}
+inline bool general_fused(const Plan& P);
+
 inline bool colour_fused(const Plan& P)
 {
   if (!P.p.color_transform || P.any_nlt3 || P.p.num_comps < 3) return false;
   for (uint32_t c = 0; c < 3; ++c) if (P.recon_decomps(c) == 0 || deep(P, c)) return false;
   const char* off = getenv("OJPHGPU_NO_COLOUR_FUSION");          // test switch: "1" keeps the stand-alone conversion kernels
   return !(off && off[0] && off[0] != '0');
+}
+
+inline bool general_fused(const Plan& P)
+{
+  const char* off = getenv("OJPHGPU_NO_GENERAL_FUSION");         // test switch: "1" keeps the stand-alone conversion kernels
+  if ((off && off[0] && off[0] != '0') || P.any_nlt3 || (P.p.color_transform && !colour_fused(P))) return false;
+  bool any = false;
+  for (uint32_t c = 0; c < P.p.num_comps; ++c) {
+    if (!P.general(c) || P.recon_decomps(c) == 0) continue;
+    if (!general_image_fusable(P, c)) return false;
+    any = true;
+  }
+  return any;
 }
 
 // gen_comp < 0: the levels of the components the two built-in wavelets' kernels transform; >= 0: of that component alone
@@ -125,10 +152,12 @@ void build_level_batches(const Plan& P, TileRange tr, std::vector<ojphgpu_dwt_de
       LevelBatch b{ (uint32_t)descs.size(), 0, 0, 0, depth, P.style(c).rev, -1, 1, 0, true, P.lift_of(c, P.skip_recon + depth + 1) };
       for_levels_of(P, tr, depth, P.style(c).rev, 0, (int)c, [&](const ojphgpu_level_info& lv) { push_level_desc(lv, descs, b); });
       if (!b.count) continue;
+      b.comps.push_back(c);
       // components that share a kernel and a kind of level (the usual case: one ATK for the whole codestream) share the launch
       LevelBatch* prev = batches.empty() ? nullptr : &batches.back();
       if (prev && prev->general && prev->depth == depth && prev->first + prev->count == b.first && memcmp(&prev->k, &b.k, sizeof(b.k)) == 0) {
         prev->count += b.count; prev->max_w = std::max(prev->max_w, b.max_w); prev->max_h = std::max(prev->max_h, b.max_h);
+        prev->comps.push_back(c);
       } else batches.push_back(b);
     }
   }
@@ -142,7 +171,24 @@ void build_image_level_descs(const Plan& P, TileRange tr, const std::vector<ojph
 {
   out.clear();
   if (P.any_nlt3 || (P.p.color_transform && !colour_fused(P))) return;   // those conversions live in the conversion kernels
+  const bool gfused = general_fused(P);
+  auto image_desc = [&](const ojphgpu_level_info& lv, ojphgpu_dwt_desc d) {
+    const TileComp& tc = P.tcomps[P.tiles[lv.tile].comps[lv.comp]];
+    const CompGeo& g = P.comps[lv.comp];
+    const Rect& rr = P.ress[tc.res[lv.res]].r;              // the tile-component at the reconstructed resolution
+    d.src_off = g.frame_off + (uint64_t)(rr.y0 - g.y0) * g.w + (rr.x0 - g.x0);
+    d.src_pitch = g.w;
+    d.reserved = g.bit_depth | (g.is_signed ? 0x100u : 0u);   // the component's sample format for the fused conversion
+    return d;
+  };
   for (LevelBatch& b : batches) {
+    if (b.depth == 0 && b.count && b.general && gfused) {    // the general lifting kernels' top level, conversion included
+      b.img_first = (int)out.size();
+      size_t k = 0;
+      for (uint32_t c : b.comps)
+        for_levels_of(P, tr, 0, P.style(c).rev, 0, (int)c, [&](const ojphgpu_level_info& lv) { out.push_back(image_desc(lv, descs[b.first + k++])); });
+      continue;
+    }
     if (b.depth != 0 || b.count == 0 || b.general) continue;
     bool all_shallow = true;                                  // (a batch with a deep component keeps the conversion kernels)
     for_levels_of(P, tr, 0, b.rev, b.group, -1, [&](const ojphgpu_level_info& lv) { all_shallow = all_shallow && !deep(P, lv.comp); });
@@ -189,7 +235,7 @@ bool build_convert_descs(const Plan& P, TileRange tr, std::vector<ojphgpu_conver
       const int grp = colour_fused(P) ? (c < 3 ? 1 : 2) : 0;
       for (uint32_t o = 0; o < P.p.num_comps; ++o)
         batch_deep = batch_deep || (P.style(o).rev == P.style(c).rev && in_group(o, grp) && !P.general(o) && deep(P, o) && P.recon_decomps(o) > 0);
-      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0 || P.general(c) || batch_deep) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
+      if ((P.p.color_transform && !colour_fused(P)) || P.any_nlt3 || L == 0 || (P.general(c) && !general_fused(P)) || batch_deep) { d.w = R.r.w; d.h = R.r.h; any |= d.w && d.h; }
       descs.push_back(d);
       max_w = std::max(max_w, d.w); max_h = std::max(max_h, d.h);
     }
