@@ -517,6 +517,7 @@ def main():
 
     # the strong-scaling question of north_star (one 16K frame, 256 tiles over the ranks) inside the same run
     strong = None
+    strong_hung = False
     if not args.no_strong and args.workload.startswith("c3") and frames == 1:
         import gc
         try:
@@ -524,12 +525,36 @@ def main():
         except NameError:
             pass
         gc.collect(); torch.cuda.synchronize(dev)
-        try:
-            strong = strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist)
-        except Exception as e:
-            if world > 1:
-                raise                                    # a rank that drops out would leave the others in a collective
-            strong = {"error": str(e)[:300]}
+        if world == 1:
+            try:
+                strong = strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist)
+            except Exception as e:
+                strong = {"error": str(e)[:300]}
+        else:
+            # N > 1: this part holds the one exchange the path has -- the RCCL gatherv of the tile-parts, point-to-point sends and
+            # receives of device tensors -- which no run of this repository has ever made with two devices.  It must not be able to
+            # take the headline line with it: it runs on a thread of its own with a deadline (OJPH_BENCH_STRONG_TIMEOUT_S, 300);
+            # a rank whose part has not come back by then reports that instead, the line is printed, and the process leaves
+            # without waiting for the process group (os._exit below: a collective that hangs cannot be cancelled).
+            import threading
+            box = {}
+
+            def strong_part():
+                try:
+                    torch.cuda.set_device(local_rank)            # (the current device is a per-thread setting)
+                    box["r"] = strong_scaling_c4(args, rank, world, local_rank, dev, backend, torch, dist)
+                except Exception as e:                           # noqa: BLE001 -- reported in the line
+                    box["r"] = {"error": "rank %d: %s" % (rank, str(e)[:300])}
+            th = threading.Thread(target=strong_part, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("OJPH_BENCH_STRONG_TIMEOUT_S", "300")))
+            if th.is_alive():
+                strong_hung = True
+                strong = {"error": "rank %d: the tile-sharded part (RCCL gatherv of the tile-parts) did not come back in time; set NCCL_DEBUG=INFO, "
+                                   "or OJPH_BENCH_BACKEND=gloo to take RCCL out of the picture" % rank}
+                sys.stderr.write("bench.py rank %d/%d: strong_scaling_c4 did not come back; the line is printed without it\n" % (rank, world))
+            else:
+                strong = box.get("r")
 
     result = {
         "metric": "Msamples/s encode+decode, 8K 12-bit 4:4:4; achieved HBM GB/s vs roofline",
@@ -613,8 +638,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline(img if frames == 1 else img[0], bd, rev, ct, qstep, tile, args.cpu_reps)
         result["cpu_baseline"]["all_cores"] = cpu_all
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        if strong_hung:                              # a hung collective cannot be torn down: leave, the line is out
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
