@@ -32,6 +32,21 @@ def main():
             enc.run_device(d); te += enc.timing()["total_ms"]
             dec.run_device(dtype=torch.int16); td += dec.timing()["total_ms"]
         print("qstep %.3f  %.3f bytes/sample  encode %.3f ms  decode %.3f ms" % (qstep, len(cs) / img.size, te / n, td / n), flush=True)
+        if os.environ.get("SWEEP_STAGES"):                    # where the time goes: the stages of the last timed run, and the same loops untimed
+            t = enc.timing()
+            print("    encode stages: dwt %.3f  ht %.3f  ht launches %s  levels %s" % (
+                t["dwt_ms"], t["ht_ms"], ["%.3f" % x for x in t["ht_launches_ms"]], ["%.3f" % x for x in t["dwt_levels_ms"]]), flush=True)
+            for what, run in (("encode", lambda: enc.run_device(d)), ("decode", lambda: dec.run_device(dtype=torch.int16))):
+                for _ in range(20):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record(torch.cuda.current_stream())
+                for _ in range(100):
+                    run()
+                e1.record(torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                print("    %s alone, 100 runs back to back: %.3f ms each" % (what, e0.elapsed_time(e1) / 100), flush=True)
         del enc, dec
 
 
