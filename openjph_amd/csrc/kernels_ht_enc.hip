@@ -601,8 +601,9 @@ struct NarrowLds {
   uint32_t out[OUT_CAP / 4];
   uint32_t ms[PMS_WORDS];
   uint32_t vlc[PVLC_WORDS];
-  uint8_t  mel[MEL_CAP];
+  uint8_t  mel[MEL_CAP + 8];             // (the raw MEL bit string, MEL_RAW_WORDS words, until the block ends; then its bytes)
 };
+static_assert(MEL_CAP + 8 >= 4 * (MEL_CAP / 4 + 2), "raw MEL words");
 #ifndef NWG_PER_CU
 #define NWG_PER_CU 4                    // workgroups of the narrow kernel that must fit one CU's 160 KB of LDS
 #endif
@@ -624,40 +625,43 @@ __device__ __forceinline__ uint32_t uvlc_word(uint32_t u)
   return pre | (pl << 8) | (suf << 16) | (sl << 24);
 }
 
-// MEL coder of the narrow kernel (ojph_block_encoder.cpp:317-362): the adaptive run-length state machine is serial and
-// wave-uniform, i.e. scalar code, and it runs once per MEL event -- on content whose significance is scattered (a "1"
-// event every few quads: the usual lossy rates) it was a quarter of the whole encode.  So the serial part does the
-// minimum: it appends code bits to a 64-bit accumulator and stores a raw word every 32 bits; the byte stuffing
-// ("7 bits after an 0xFF") is done once per block by the whole wavefront (mel_stuff), the way the VLC bytes are made.
-struct MelFast {           // all wave-uniform
-  uint32_t k, run, nb, wpos, err; uint64_t acc;
-};
-constexpr uint32_t MEL_RAW_WORDS = MEL_CAP / 4;   // more raw bits than that cannot fit MEL_CAP bytes either
+// MEL coder of the narrow kernel (ojph_block_encoder.cpp:317-362).  The adaptive run-length state machine is serial -- what an
+// event costs depends on the state k the events before it left -- and on content whose significance is scattered (a "1"
+// event every few quads: the usual lossy rates) a scalar walk that produced every event's bits was the larger half of the
+// whole encode (8K frame at 0.2 bytes per sample: 0.43 ms of block coding, 0.21 of it without the walk).  So the serial part
+// does the minimum -- it carries the STATE from "1" event to "1" event -- and the bits are made by the lanes:
+//   * the state is k and the zeros seen since the coder was last at the start of run k, kept as ONE number c = P[k] + run,
+//     P[k] = the zeros it takes from k = 0 to reach k (0 1 2 3 5 7 9 13 17 21 29 37 53; beyond k = 12 every run is 32).  Zeros
+//     just add to c; k and run at any moment follow from c with a shift, a population count and a leading-zero count on the
+//     64-bit constant that has bit P[k] set for every k (mel_at).  A "1" event sends the coder to (k - 1, run 0), c = P[k - 1];
+//   * the events of a step are brought into coding order across the lanes (a permute of the lanes' flag bits), one ballot gives
+//     the "1" events of 64 consecutive events, and the scalar loop visits those only: it notes (k, c) at the event in the
+//     event's lane and steps the state -- about 25 scalar instructions per "1" event, none per "0" event;
+//   * every event lane then works out its own bits from (k, c) -- the '1' bits of the runs completed since the last "1" event,
+//     the '0' and the e bits of the open run's length -- a prefix sum over their lengths places them, and they are OR-ed,
+//     MSB first, into the raw bit string in LDS.  Zeros behind the last "1" event stay in c until the next one (or the
+//     end of the block) asks for their bits; c is kept below 85 + what a step can add, so no lane has more than 24 bits.
+// The byte stuffing ("7 bits after an 0xFF") is done once per block by the whole wavefront (mel_stuff).
+constexpr uint64_t MEL_PM = (1ull << 0) | (1ull << 1) | (1ull << 2) | (1ull << 3) | (1ull << 5) | (1ull << 7) | (1ull << 9) | (1ull << 13) |
+                            (1ull << 17) | (1ull << 21) | (1ull << 29) | (1ull << 37) | (1ull << 53);
+constexpr uint32_t MEL_RAW_BITS = 8u * MEL_CAP;   // more raw bits than that cannot fit MEL_CAP bytes either
+constexpr uint32_t MEL_RAW_WORDS = MEL_CAP / 4 + 2;   // (+ the word a code may straddle into, + the zero word mel_stuff reads behind the last one)
 
-__device__ __forceinline__ void melf_append(MelFast& m, uint32_t* raw, uint32_t code, uint32_t n, int lane)
+// the coder that started run k with c - P[k] zeros behind it, `c` zeros later: K = where it is now, run = the zeros of its
+// open run, ones = the runs it has completed on the way (a '1' bit each)
+__device__ __forceinline__ void mel_at(uint32_t k, uint32_t c, uint32_t& K, uint32_t& run, uint32_t& ones, uint32_t& pKm1)
 {
-  m.acc = (m.acc << n) | code; m.nb += n;
-  if (m.nb >= 32u) {
-    m.nb -= 32u;
-    if (m.wpos >= MEL_RAW_WORDS) m.err = 1;
-    else raw[m.wpos] = (uint32_t)(m.acc >> m.nb);                      // MSB first: the first bit of the stream is bit 31 of word 0 (every lane stores the same word)
-    m.wpos++;
+  const uint32_t full = c >= 85u ? (c - 53u) >> 5 : 0u;        // whole runs of 32 at k = 12
+  const uint32_t cc = c - 32u * full;
+  if (cc >= 53u) { K = 12u; run = cc - 53u; pKm1 = 37u; }
+  else {
+    const uint64_t m = MEL_PM << (63u - cc);                   // the P[j] <= cc, the largest of them in the top set bit
+    const uint32_t lz = (uint32_t)__builtin_clzll(m);          // (bit 0 of MEL_PM: m != 0)
+    K = (uint32_t)__popcll(m) - 1u; run = lz;
+    const uint64_t m2 = m & ~(0x8000000000000000ull >> lz);
+    pKm1 = m2 ? cc - (uint32_t)__builtin_clzll(m2) : 0u;
   }
-}
-
-__device__ __forceinline__ void melf_zero_run(MelFast& m, uint32_t* raw, uint32_t n, int lane)
-{
-  while (n > 0) {
-    const uint32_t need = (1u << mel_exp(m.k)) - m.run;
-    if (n >= need) { melf_append(m, raw, 1, 1, lane); n -= need; m.run = 0; m.k = m.k < 12 ? m.k + 1 : 12; }
-    else { m.run += n; n = 0; }
-  }
-}
-
-__device__ __forceinline__ void melf_one(MelFast& m, uint32_t* raw, int lane)
-{
-  melf_append(m, raw, m.run, mel_exp(m.k) + 1u, lane);      // a 0 followed by e bits of the run count
-  m.run = 0; m.k = m.k > 0 ? m.k - 1 : 0;
+  ones = K - k + full;
 }
 
 // raw bit string -> MEL bytes (mel_emit_bit / byte emission of :326-347): `raw` holds total_bits bits, MSB first, a
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
 
   for (int i = lane; i < PMS_WORDS; i += 64) L.ms[i] = 0;
   for (int i = lane; i < PVLC_WORDS; i += 64) L.vlc[i] = 0;
+  if (lane < (int)MEL_RAW_WORDS) reinterpret_cast<uint32_t*>(L.mel)[lane] = 0;
   wave_sync();
   if (lane == 0) { L.vlc[0] = 0xF; outb[OUT_CAP - 1] = 0xFF; }            // vlc_init: head byte, 4 bits already used (:365-375)
   wave_sync();
@@ -744,8 +749,34 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   // wave-uniform stream state
   uint32_t ms_pend = 0, ms_base = 0, ms_k = 0, ms_ff = 0;   // pending bits in L.ms and where they start, bytes written, last byte was 0xFF
   uint32_t v_pend = 4, v_base = 0, v_pos = 1, v_prev = 0xFF;   // pending bits in L.vlc and where they start, bytes "written" (incl. the head), last byte
-  MelFast melf = { 0, 0, 0, 0, 0, 0 };
-  uint32_t* const mel_raw = reinterpret_cast<uint32_t*>(L.mel);       // raw MEL words until the block ends, then its bytes
+  uint32_t mel_k = 0, mel_c = 0, mel_bits = 0, mel_err = 0;           // MEL coder: state (see mel_at), raw bits written
+  uint32_t* const mel_raw = reinterpret_cast<uint32_t*>(L.mel);       // raw MEL bit string until the block ends, then its bytes
+  // `len` bits of `code` at bit `pos` of the raw string, MSB first (len <= 24)
+  auto mel_or = [&](uint32_t code, uint32_t len, uint32_t pos) {
+    if (len) {
+      const uint32_t sh = pos & 31u, w = pos >> 5;
+      const uint64_t v = (uint64_t)code << (64u - sh - len);
+      atomicOr(&mel_raw[w], (uint32_t)(v >> 32));
+      if (sh + len > 32u) atomicOr(&mel_raw[w + 1u], (uint32_t)v);
+    }
+  };
+  // '1' bits of completed runs, from the scalar side (lane 0 writes them): n <= 24
+  auto mel_ones = [&](uint32_t n) {
+    if (n == 0u) return;
+    if (mel_bits + n > MEL_RAW_BITS) mel_err = 1;
+    else if (lane == 0) mel_or((1u << n) - 1u, n, mel_bits);
+    mel_bits += n;
+  };
+  // zeros that no "1" event follows in this step: c keeps them; once the coder is through a run at k = 12 the finished runs
+  // leave their bits (c stays below 85 between steps)
+  auto mel_zeros = [&](uint32_t n) {
+    mel_c += n;
+    if (mel_c >= 85u) {
+      const uint32_t full = (mel_c - 53u) >> 5;
+      mel_ones(12u - mel_k + full);
+      mel_k = 12u; mel_c -= 32u * full;
+    }
+  };
   uint32_t err = 0, any_sig = 0;
   bool prev_sig = false;                                 // the previous step had a significant sample
 
@@ -947,13 +978,18 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   }
   const bool ragged = (QH & (RPS - 1u)) != 0 || (H & 1u) != 0;           // the last step has quad rows / sample rows that do not exist
 
-  // one 32-bit value of at most 32 bits OR-ed into a bit buffer at bit position pos (no branch: the second word gets zeros
-  // when the value does not straddle)
+  // one 32-bit value of at most 32 bits OR-ed into a bit buffer at bit position pos (the second word gets zeros when the
+  // value does not straddle).  Lanes with nothing to add stay out: a lane without bits has the position of the next lane
+  // that has some, and on sparse content -- most quads of a step without a significant sample -- sixty lanes sent their
+  // zeros to ONE word, same-address LDS atomics that the bank serves one after the other (8K frame at 0.01 bytes per
+  // sample: 0.46 ms of block coding, 0.18 with these ten atomics per lane and step left out altogether).
   auto or32 = [&](uint32_t* buf, uint32_t pos, uint32_t v) {
-    const uint32_t sh = pos & 31u;
-    uint32_t* wp = buf + (pos >> 5);
-    atomicOr(wp, v << sh);
-    atomicOr(wp + 1, (v >> 1) >> (sh ^ 31u));
+    if (v != 0u) {
+      const uint32_t sh = pos & 31u;
+      uint32_t* wp = buf + (pos >> 5);
+      atomicOr(wp, v << sh);
+      atomicOr(wp + 1, (v >> 1) >> (sh ^ 31u));
+    }
   };
   // bytes of x that are not zero -> 0x80 in that byte (bytes < 0x80); 0x80-flags of four bytes -> bits 0..3
   auto nz_flags = [](uint32_t x) -> uint32_t { return (x + 0x7F7F7F7Fu) & 0x80808080u; };
@@ -1029,7 +1065,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       prev_sig = step_sig;
       if (skip) {
         const uint32_t nq = (uint32_t)__popcll(__ballot(active)) + (uint32_t)__popcll(__ballot(has_q1 && active));
-        melf_zero_run(melf, mel_raw, nq, lane);
+        mel_zeros(nq);
         last_S = 0;
         continue;
       }
@@ -1145,36 +1181,66 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     }
 
     // ---- MEL events of the step (quads with context 0, and in the first row the "both u > 0" event, :664, :763, :883):
-    // lane-major, within a lane quad 0, quad 1, then the u event.  The adaptive run-length coder is serial; it walks the
-    // "1" events only, in scalar code, taking the length of the zero run in front of each from population counts of the
-    // event masks (no compaction through LDS, no prefix sum).
+    // lane-major, within a lane quad 0, quad 1, then the u event (see the note at mel_at)
     if (ABL & 8) { any_sig |= (uint32_t)(__ballot((vb ^ mp[0] ^ mp[1] ^ sv[0] ^ sv[7] ^ chi[1] ^ incl) == 0x12345u) != 0ull); continue; }
     if (!(ABL & 1)) {
-      const uint64_t V0 = __ballot(active && chi[0] == 0u), V1 = __ballot(active && has_q1 && chi[1] == 0u);
-      const uint64_t B0 = V0 & __ballot(rho0 != 0u), B1 = V1 & __ballot(rho1 != 0u);
-      uint64_t V2 = 0, B2 = 0;
-      if (step == 0) { V2 = __ballot(ev2_valid); B2 = V2 & __ballot(ev2_bit != 0u); }
-      if (V0 | V1 | V2) {                                                    // (dense content: most steps have no quad with context 0)
-      uint64_t ones = B0 | B1 | B2;
-      uint32_t done = 0;                                                     // events already coded
-      while (ones) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(ones);
-        ones &= ones - 1ull;
-        const uint64_t below = (1ull << l) - 1ull;
-        const uint32_t idx = (uint32_t)__popcll(V0 & below) + (uint32_t)__popcll(V1 & below) + (uint32_t)__popcll(V2 & below);
-        const uint32_t vl3 = (uint32_t)((V0 >> l) & 1ull) | ((uint32_t)((V1 >> l) & 1ull) << 1) | ((uint32_t)((V2 >> l) & 1ull) << 2);
-        uint32_t bl3 = (uint32_t)((B0 >> l) & 1ull) | ((uint32_t)((B1 >> l) & 1ull) << 1) | ((uint32_t)((B2 >> l) & 1ull) << 2);
-        while (bl3) {                                                        // the lane's "1" events, in order
-          const uint32_t j = (uint32_t)__builtin_ctz(bl3);
-          bl3 &= bl3 - 1u;
-          const uint32_t at = idx + (uint32_t)__popc(vl3 & ((1u << j) - 1u));
-          melf_zero_run(melf, mel_raw, at - done, lane);
-          melf_one(melf, mel_raw, lane);
-          done = at + 1u;
+      // the lane's events: bits 0..2 valid (quad 0, quad 1, u), bits 4..6 their values
+      const uint32_t fl = ((active && chi[0] == 0u) ? (rho0 != 0u ? 0x11u : 0x01u) : 0u) |
+                          ((active && has_q1 && chi[1] == 0u) ? (rho1 != 0u ? 0x22u : 0x02u) : 0u) |
+                          ((step == 0 && ev2_valid) ? (ev2_bit != 0u ? 0x44u : 0x04u) : 0u);
+      if (__ballot((fl & 7u) != 0u) != 0ull) {                                // (dense content: most steps have no quad with context 0)
+        // 64 consecutive events at a time, event e in lane e & 63: the first quad row of the block has three events per
+        // lane (its PPR lanes come first), every other row two
+        const uint32_t nwords = step == 0 ? 3u : 2u;
+        for (uint32_t wd = 0; wd < nwords; ++wd) {
+          const uint32_t e = 64u * wd + (uint32_t)lane;
+          uint32_t from, slot;
+          if (step == 0) {
+            const uint32_t e2 = e - 3u * PPR;
+            const bool fr = e < 3u * PPR;
+            from = fr ? e / 3u : PPR + (e2 >> 1);
+            slot = fr ? e - 3u * (e / 3u) : e2 & 1u;
+          } else { from = e >> 1; slot = e & 1u; }
+          const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) << 2), (int)fl) >> slot;
+          const bool valid = from < 64u && (g & 1u) != 0u, one = valid && (g & 16u) != 0u;
+          const uint64_t Vw = __ballot(valid), Bw = __ballot(one);
+          if (Vw == 0ull) continue;
+          const uint32_t nvalid = (uint32_t)__popcll(Vw);
+          if (Bw == 0ull) { mel_c += nvalid; continue; }
+          // valid events in front of the lane's, in this word
+          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(Vw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Vw, 0u));
+          uint32_t info = 0;                                                  // (k, c) at the lane's "1" event
+          {
+            uint64_t ones = Bw;
+            uint32_t consumed = 0;
+            while (ones) {
+              const uint32_t l = (uint32_t)__builtin_ctzll(ones);
+              ones &= ones - 1ull;
+              const uint32_t bf = rdlane(before, (int)l);
+              mel_c += bf - consumed; consumed = bf + 1u;
+              info = (uint32_t)lane == l ? (mel_k | (mel_c << 4)) : info;
+              uint32_t K, run, nones, pKm1;
+              mel_at(mel_k, mel_c, K, run, nones, pKm1);
+              mel_k = max(K, 1u) - 1u; mel_c = K ? pKm1 : 0u;                 // :352-358: the coder steps down, its run starts anew
+            }
+            mel_c += nvalid - consumed;
+          }
+          // the lanes' bits: '1' for every run completed since the last "1" event, then '0' and the open run's length in e bits
+          uint32_t code = 0, len = 0;
+          if (one) {
+            uint32_t K, run, nones, pKm1;
+            mel_at(info & 15u, info >> 4, K, run, nones, pKm1);
+            const uint32_t eb = mel_exp(K);
+            code = (((1u << nones) - 1u) << (eb + 1u)) | run;
+            len = nones + eb + 1u;
+          }
+          const uint32_t at_incl = wave_incl_scan(len, lane);
+          const uint32_t wbits = rdlane(at_incl, 63);
+          if (mel_bits + wbits > MEL_RAW_BITS) mel_err = 1;
+          else mel_or(code, len, mel_bits + at_incl - len);
+          mel_bits += wbits;
         }
-      }
-      const uint32_t nev = (uint32_t)__popcll(V0) + (uint32_t)__popcll(V1) + (uint32_t)__popcll(V2);
-      melf_zero_run(melf, mel_raw, nev - done, lane);
+        mel_zeros(0u);
       }
     }
 
@@ -1234,7 +1300,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     v_carry = compact(L.vlc, pos, v_base + v_pend, PVLC_WORDS);
   }
 
-  err |= melf.err;
+  err |= mel_err;
   uint32_t total = 0, ms_len = ms_k;
   MelState mel = { 0, 0, 0, 0, 0, 0, 0 };                 // the byte-level state the termination works on (mel_stuff)
   if (!err && any_sig) {
@@ -1249,16 +1315,19 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
       }
     } else if (ms_ff) ms_len--;
     // ---- terminate_mel_vlc (:412-441) ----
-    if (melf.run > 0) melf_append(melf, mel_raw, 1, 1, lane);
-    err |= melf.err;
+    {
+      // the zeros behind the last "1" event: a '1' for every run they completed, and one for the run under way (:412-415)
+      uint32_t K, run, nones, pKm1;
+      mel_at(mel_k, mel_c, K, run, nones, pKm1);
+      mel_ones(nones + (run > 0u ? 1u : 0u));
+    }
+    err |= mel_err;
     {
       // the raw words move to the (now idle) MagSgn bit buffer, the bytes are written where the words were
       uint32_t* rawc = L.ms + 128;
-      const uint32_t total_bits = 32u * melf.wpos + melf.nb;
+      const uint32_t total_bits = mel_bits;
       wave_sync();
-      if ((uint32_t)lane < melf.wpos) rawc[lane] = mel_raw[lane];
-      if ((uint32_t)lane == melf.wpos) rawc[lane] = melf.nb ? (uint32_t)(melf.acc << (32u - melf.nb)) : 0u;
-      if ((uint32_t)lane == melf.wpos + 1u) rawc[lane] = 0;
+      if ((uint32_t)lane < MEL_RAW_WORDS) rawc[lane] = (uint32_t)lane < MEL_RAW_WORDS - 1u ? mel_raw[lane] : 0u;
       wave_sync();
       mel_stuff(rawc, err ? 0u : total_bits, L.mel, mel, lane);
       wave_sync();

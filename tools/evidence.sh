@@ -54,6 +54,7 @@ if [ -z "$QUICK" ]; then
   done
   ( OJPH_BENCH_BACKEND=gloo OJPH_BENCH_ONE_GPU=1 timeout 400 python bench.py --gpus 2 --steps 20 --no-cpu-baseline 2>> $R/bench2.err | tail -1 ) > $R/bench_2ranks_one_gpu.json
   ( timeout 300 python tools/block_sizes.py 2>&1 | grep "^block" ) > $R/block_sizes.txt
+  ( SWEEP_STAGES=1 timeout 300 python tools/qstep_sweep.py 2>&1 | grep "qstep\|stages\|alone" ) > $R/rate_sweep.txt
   ( timeout 100 python tools/fuzz_blocks_gpu.py 45 5 2>&1 | tail -2 ) > $R/fuzz_blocks.txt
   ( timeout 100 python tools/fuzz_part2_gpu.py 45 7 2>&1 | tail -2 ) > $R/fuzz_part2.txt
   bash tools/ab_env.sh OJPHGPU_DWT_TRIP 1 2 c3_8k_444_12b_irv97:16 c2_4k_rgb_8b_rev53:8 c4_16k_gray_16b_rev53_tiled:16 c5_4k_444_10b_irv97_batch:16 > /dev/null 2>&1; cp gpurun_out/ab_env.txt $R/ab_dwt_trip.txt
