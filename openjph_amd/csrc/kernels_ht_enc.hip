@@ -983,13 +983,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
   // that has some, and on sparse content -- most quads of a step without a significant sample -- sixty lanes sent their
   // zeros to ONE word, same-address LDS atomics that the bank serves one after the other (8K frame at 0.01 bytes per
   // sample: 0.46 ms of block coding, 0.18 with these ten atomics per lane and step left out altogether).
+  // (the callers test once per buffer: `tot` / `vl`, the lane's bits of the step)
   auto or32 = [&](uint32_t* buf, uint32_t pos, uint32_t v) {
-    if (v != 0u) {
-      const uint32_t sh = pos & 31u;
-      uint32_t* wp = buf + (pos >> 5);
-      atomicOr(wp, v << sh);
-      atomicOr(wp + 1, (v >> 1) >> (sh ^ 31u));
-    }
+    const uint32_t sh = pos & 31u;
+    uint32_t* wp = buf + (pos >> 5);
+    atomicOr(wp, v << sh);
+    atomicOr(wp + 1, (v >> 1) >> (sh ^ 31u));
   };
   // bytes of x that are not zero -> 0x80 in that byte (bytes < 0x80); 0x80-flags of four bytes -> bits 0..3
   auto nz_flags = [](uint32_t x) -> uint32_t { return (x + 0x7F7F7F7Fu) & 0x80808080u; };
@@ -1261,10 +1260,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
           pr[2 * q] = v0 | (v1 << m0); pr[2 * q + 1] = v2 | (v3 << m2);
           ln[q] = (m + (m >> 8)) & 0xFFu;                                     // bits of the quad's first two samples
         }
-        or32(L.ms, at, pr[0]);
-        or32(L.ms, at + ln[0], pr[1]);
-        or32(L.ms, at + tot0, pr[2]);
-        or32(L.ms, at + tot0 + ln[1], pr[3]);
+        if (tot != 0u) {
+          or32(L.ms, at, pr[0]);
+          or32(L.ms, at + ln[0], pr[1]);
+          or32(L.ms, at + tot0, pr[2]);
+          or32(L.ms, at + tot0 + ln[1], pr[3]);
+        }
       } else {
         uint32_t pos = at;
 #pragma unroll
@@ -1274,7 +1275,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
           pos += m;
         }
       }
-      or32(L.vlc, v_base + v_pend + (incl >> 16) - vl, vb);
+      if (vl != 0u) or32(L.vlc, v_base + v_pend + (incl >> 16) - vl, vb);
     }
     wave_sync();
     // ---- byte stuffing of the windows that are complete ----
