@@ -649,6 +649,19 @@ def test_grid_parameter_validation():
     assert Plan(make_params(64, 64, 3)).frame_shape == (3, 64, 64)
 
 
+def test_oracle_equals_reference_on_sparse_blocks(ref):
+    """the planes of tests/test_gpu_codec.py::test_encoder_mel_regimes (long runs of empty quads, isolated significant
+    samples at fixed and random distances: the MEL coder's regimes, ojph_block_encoder.cpp:317-362) through the oracle
+    pipeline and through the reference: the same codestream"""
+    from tests import cpu_pipeline as cp
+    from tests.test_gpu_codec import _sparse_plane
+    for kind in ("one-late", "every1", "every2", "every3", "every7", "every33", "every100", "every1000", "p4", "p20", "p150", "p2000", "bands"):
+        for bd, h, w, block in ((10, 128, 192, (64, 64)), (8, 70, 130, (32, 32)), (12, 64, 256, (128, 32))):
+            img = _sparse_plane(kind, h, w, bd, seed=len(kind) + bd)
+            kw = dict(bit_depth=bd, num_decomps=0, block=block)
+            assert cp.encode(img, **kw)[0] == ref.encode(img, **kw), (kind, bd)
+
+
 def test_irreversible_tolerance_vs_simd_reference(ref):
     """9/7 against the SIMD build of the reference (which is not bit-stable against its own generic
     build): same rule as the reference's tests (tests/test_executables.cpp:132-133): MSE within 1 %,

@@ -65,6 +65,45 @@ def test_encode_decode_matches_oracle(case):
         assert np.array_equal(dec, img)
 
 
+def _sparse_plane(kind, h, w, bd, seed):
+    """planes whose code-blocks (no decomposition: the samples are the blocks') exercise the MEL coder's regimes: long runs
+    of context-0 quads without a significant sample (the coder climbs to k = 12 and stays), isolated significant samples at
+    fixed and at random distances (k going up and down), both mixed with dense rows"""
+    rng = np.random.default_rng(seed)
+    mid = 1 << (bd - 1)
+    img = np.full((1, h, w), mid, np.int64)
+    if kind == "one-late":                 # one sample at the very end of every block's last row
+        img[0, 63::64, 63::64] += 5
+    elif kind.startswith("every"):         # a significant sample every n-th quad of the raster
+        n = int(kind[5:])
+        q = np.arange((h // 2) * (w // 2))
+        ys, xs = np.divmod(q[::n], w // 2)
+        img[0, 2 * ys, 2 * xs] += rng.integers(1, 40, ys.size) * rng.choice([-1, 1], ys.size)
+    elif kind.startswith("p"):             # significant with probability 1 / n
+        n = int(kind[1:])
+        m = rng.random((h, w)) < 1.0 / n
+        img[0][m] += (rng.integers(1, 1 << (bd - 2), int(m.sum())) * rng.choice([-1, 1], int(m.sum())))
+    elif kind == "bands":                  # dense rows between long empty stretches
+        for y0 in range(0, h, 24):
+            img[0, y0:y0 + 2] += rng.integers(-200, 200, (2, w))
+    return np.clip(img, 1, (1 << bd) - 1)      # (not the most negative value: without a decomposition its magnitude has K_max + 1 bits)
+
+
+@pytest.mark.parametrize("kind", ["one-late", "every1", "every2", "every3", "every7", "every33", "every100", "every1000",
+                                  "p4", "p20", "p150", "p2000", "bands"])
+def test_encoder_mel_regimes(kind):
+    """(kernels_ht_enc.hip: mel_at, the event walk; ojph_block_encoder.cpp:317-362)"""
+    from openjph_amd import codec
+    from tests import cpu_pipeline as cp
+    for bd, h, w, block in ((10, 128, 192, (64, 64)), (8, 70, 130, (32, 32)), (12, 64, 256, (128, 32))):
+        img = _sparse_plane(kind, h, w, bd, seed=len(kind) + bd)
+        kw = dict(bit_depth=bd, num_decomps=0, block=block)
+        got = codec.encode(img, **kw)
+        want = cp.encode(img, **kw)[0]
+        assert got == want, "%s, %d-bit %dx%d: codestream differs (%d vs %d bytes)" % (kind, bd, w, h, len(got), len(want))
+        assert np.array_equal(codec.decode(got), img)
+
+
 @pytest.mark.parametrize("i", range(9), ids=lambda i: "grid%d" % i)
 def test_grid_encode_decode_matches_oracle(i):
     """sub-sampled components, image and tile offsets (tests/golden_cases.py GRID_CASES): the GPU
