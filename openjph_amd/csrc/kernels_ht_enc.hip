@@ -1214,13 +1214,23 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
             uint32_t consumed = 0;
             while (ones) {
               const uint32_t l = (uint32_t)__builtin_ctzll(ones);
-              ones &= ones - 1ull;
+              asm("s_bitset0_b64 %0, %1" : "+s"(ones) : "s"(l));
               const uint32_t bf = rdlane(before, (int)l);
               mel_c += bf - consumed; consumed = bf + 1u;
-              info = (uint32_t)lane == l ? (mel_k | (mel_c << 4)) : info;
-              uint32_t K, run, nones, pKm1;
-              mel_at(mel_k, mel_c, K, run, nones, pKm1);
-              mel_k = max(K, 1u) - 1u; mel_c = K ? pKm1 : 0u;                 // :352-358: the coder steps down, its run starts anew
+              info = (uint32_t)lane == l ? (mel_k | (mel_c << 4)) : info;     // (a v_writelane would need the lane number in M0: no shorter)
+              // :352-358: the coder steps down, its run starts anew -- k = max(K - 1, 0), c = P[k] (mel_at's pKm1: 0 for K = 0)
+              uint32_t K, pKm1;
+              if (mel_c >= 85u) mel_c -= (mel_c - 53u) & ~31u;                // (whole runs at k = 12 behind it: rare)
+              if (mel_c >= 53u) { K = 12u; pKm1 = 37u; }
+              else {
+                const uint64_t m = MEL_PM << (63u - mel_c);
+                K = (uint32_t)__popcll(m) - 1u;
+                const uint64_t m2 = m & ~(0x8000000000000000ull >> (uint32_t)__builtin_clzll(m));
+                pKm1 = m2 ? mel_c - (uint32_t)__builtin_clzll(m2) : 0u;
+              }
+              int km1 = (int)K - 1;
+              asm("s_max_i32 %0, %1, 0" : "=s"(km1) : "s"(km1) : "scc");      // (kept scalar: the compiler's saturating subtract is a vector instruction and a read-back)
+              mel_k = (uint32_t)km1; mel_c = pKm1;
             }
             mel_c += nvalid - consumed;
           }
